@@ -1,0 +1,141 @@
+// Weight / bias gradient of the channels-last Conv1d (see conv1d_cl.hip):
+//   dw[co][ci][j] += sum_{b,t} dy[b,t,co] * x[b, t + j*dil - pad, ci]
+//   dbias[co]     += sum_{b,t} dy[b,t,co]
+// GEMM per tap: M = Cout, N = Cin, K = B*T (the reduction runs over ROWS).  Both
+// operands are channels-last, i.e. K-major, which is exactly the operand layout
+// of v_mfma_f32_16x16x4_f32 (lane l holds A[l&15][l>>4]): 16 lanes read 16
+// consecutive channels of one row, conflict-free, no transposes.  Rows are split
+// across blocks (split-K) and combined with f32 atomics, so the result is f32
+// regardless of the activation dtype.
+//
+// NOTE (round-1 state): bf16 activations are widened to f32 while staging, so
+// this kernel runs at the f32 MFMA rate (157 TF peak).  The bf16-rate variant
+// (ds_read_b64_tr_b16 operand transposes) is the next step -- see DESIGN.md.
+#include "ptpp_common.h"
+
+namespace {
+
+constexpr int KR = 32;    // rows per K chunk
+constexpr int TS = 80;    // LDS row stride in floats (64 + 16: conflict-free b32 reads)
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           float* __restrict__ dw, float* __restrict__ dbias,
+                                                           const int* __restrict__ lengths, int B, int T_, int Cin,
+                                                           int Cout, int ks, int dil, int pad, int ldx, int lddy,
+                                                           int in_mask, int nCO, int nCI, int nsplit, int tchunks) {
+  __shared__ float dYs[KR * TS];
+  __shared__ float Xs[KR * TS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  int bid = blockIdx.x;
+  const int cot = bid % nCO; bid /= nCO;
+  const int cit = bid % nCI; bid /= nCI;
+  const int j = bid % ks;    bid /= ks;
+  const int split = bid;
+  const int co0 = cot * 64, ci0 = cit * 64;
+  const int shift = j * dil - pad;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool do_bias = dbias && cit == 0 && j == 0;
+
+  const int total = B * tchunks;
+  for (int ch = split; ch < total; ch += nsplit) {
+    const int b = ch / tchunks, tb = (ch % tchunks) * KR;
+    const int Tin = (in_mask && lengths) ? min(lengths[b], T_) : T_;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 4, c4 = (idx & 15) * 4;
+      const int t = tb + row;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < T_) {
+        const T* src = dy + ((int64_t)b * T_ + t) * lddy + co0 + c4;
+        if (co0 + c4 + 3 < Cout) v = Elem<T>::ld4(src);
+        else
+          for (int e = 0; e < 4; ++e)
+            if (co0 + c4 + e < Cout) v[e] = Elem<T>::ld(src + e);
+      }
+      *reinterpret_cast<f32x4*>(&dYs[row * TS + c4]) = v;
+      f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int ts = t + shift;
+      if (t < T_ && ts >= 0 && ts < Tin) {
+        const T* src = x + ((int64_t)b * T_ + ts) * ldx + ci0 + c4;
+        if (ci0 + c4 + 3 < Cin) u = Elem<T>::ld4(src);
+        else
+          for (int e = 0; e < 4; ++e)
+            if (ci0 + c4 + e < Cin) u[e] = Elem<T>::ld(src + e);
+      }
+      *reinterpret_cast<f32x4*>(&Xs[row * TS + c4]) = u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KR / 4; ++kk) {
+      const int k = kk * 4 + lg;
+      float af[2], bf[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = dYs[k * TS + wr * 32 + a * 16 + lr];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bf[c] = Xs[k * TS + wc * 32 + c * 16 + lr];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[c], acc[a][c], 0, 0, 0);
+    }
+    if (do_bias && tid < 64) {
+#pragma unroll 8
+      for (int r = 0; r < KR; ++r) bsum += dYs[r * TS + tid];
+    }
+    __syncthreads();
+  }
+
+  // D[i = co (rows 4*lg + r)][j = ci (col lr)]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ci = ci0 + wc * 32 + c * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wr * 32 + a * 16 + lg * 4 + r;
+        if (co < Cout && ci < Cin) atomicAdd(dw + ((int64_t)co * Cin + ci) * ks + j, acc[a][c][r]);
+      }
+    }
+  if (do_bias && tid < 64 && co0 + tid < Cout) atomicAdd(dbias + co0 + tid, bsum);
+}
+
+}  // namespace
+
+extern "C" int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, const int32_t* lengths, int B,
+                                 int T, int Cin, int Cout, int ks, int dil, int pad, int ldx, int lddy, int in_mask,
+                                 int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && dy && dw, "conv1d_wgrad: null pointer");
+  PTPP_CHECK_ARG(B > 0 && T > 0 && Cin > 0 && Cout > 0 && ks > 0 && dil > 0, "conv1d_wgrad: bad shape");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "conv1d_wgrad: bad dtype %d", dtype);
+  PTPP_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0, "conv1d_wgrad: row strides must be multiples of 4");
+  PTPP_CHECK_ARG(!in_mask || lengths, "conv1d_wgrad: in_mask needs lengths");
+  const int nCO = (Cout + 63) / 64, nCI = (Cin + 63) / 64;
+  const int tchunks = (T + KR - 1) / KR;
+  const int total = B * tchunks;
+  const int tiles = nCO * nCI * ks;
+  int nsplit = (2048 + tiles - 1) / tiles;  // aim for ~8 blocks per CU
+  if (nsplit > total) nsplit = total;
+  if (nsplit < 1) nsplit = 1;
+  dim3 grid((unsigned)((int64_t)tiles * nsplit)), blk(256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PTPP_F32)
+    hipLaunchKernelGGL(conv1d_wgrad_kernel<float>, grid, blk, 0, st, (const float*)x, (const float*)dy, dw, dbias,
+                       lengths, B, T, Cin, Cout, ks, dil, pad, ldx, lddy, in_mask, nCO, nCI, nsplit, tchunks);
+  else
+    hipLaunchKernelGGL(conv1d_wgrad_kernel<bf16_raw>, grid, blk, 0, st, (const bf16_raw*)x, (const bf16_raw*)dy, dw,
+                       dbias, lengths, B, T, Cin, Cout, ks, dil, pad, ldx, lddy, in_mask, nCO, nCI, nsplit, tchunks);
+  PTPP_CHECK_LAUNCH("conv1d_wgrad");
+  return PTPP_OK;
+}

@@ -1,0 +1,221 @@
+// LayerNorm over the channel dimension of channels-last rows (HBM-bound).
+// One 64-lane wave per row: each lane owns 4 consecutive channels per 256-wide
+// slab (8/16-byte vector loads), statistics by wavefront shuffles in f32.
+#include "ptpp_common.h"
+
+namespace {
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     T* __restrict__ y, T* __restrict__ sum_out,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     const int* __restrict__ lengths, int64_t rows, int Tlen, int C,
+                                                     float eps, int out_mask) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+      v[i] = Elem<T>::ld4(x + row * C + c);
+      if (res) v[i] += Elem<T>::ld4(res + row * C + c);
+      if (sum_out) Elem<T>::st4(sum_out + row * C + c, v[i]);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  bool keep = true;
+  if (out_mask) {
+    const int b = (int)(row / Tlen), t = (int)(row % Tlen);
+    keep = t < lengths[b];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < C) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = keep ? (v[i][e] - mean) * rstd * g[e] + bb[e] : 0.f;
+      Elem<T>::st4(y + row * C + c, o);
+    }
+  }
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xs,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     const int* __restrict__ lengths, int64_t rows, int Tlen, int C,
+                                                     int out_mask) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  f32x4 g[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    g[i] = c < C ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t row = wid; row < rows; row += nw) {
+    bool keep = true;
+    if (out_mask) {
+      const int b = (int)(row / Tlen), t = (int)(row % Tlen);
+      keep = t < lengths[b];
+    }
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 d[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = i * 256 + lane * 4;
+      d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < C && keep) {
+        d[i] = Elem<T>::ld4(dy + row * C + c);
+        const f32x4 xv = Elem<T>::ld4(xs + row * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - mu) * rs;
+          const float dg = d[i][e] * g[i][e];
+          s1 += dg;
+          s2 += dg * xh[i][e];
+          ag[i][e] += d[i][e] * xh[i][e];
+          ab[i][e] += d[i][e];
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = i * 256 + lane * 4;
+      if (c < C) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (d[i][e] * g[i][e] - m1 - xh[i][e] * m2);
+        Elem<T>::st4(dx + row * C + c, o);
+      }
+    }
+  }
+  // column sums: combine the block's 4 waves through LDS, one atomic per column
+  __shared__ float red[2][4][256 * NV];
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][w][i * 256 + lane * 4 + e] = ag[i][e];
+      red[1][w][i * 256 + lane * 4 + e] = ab[i][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    if (dgamma) atomicAdd(dgamma + c, sg);
+    if (dbeta) atomicAdd(dbeta + c, sb);
+  }
+}
+
+template <typename T>
+int ln_fwd_dispatch(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* sum_out,
+                    float* mean, float* rstd, const int* lengths, int64_t rows, int Tlen, int C, float eps,
+                    int out_mask, hipStream_t st) {
+  const int nv = (C + 255) / 256;
+  const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+#define LN_FWD(NV)                                                                                          \
+  hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, blk, 0, st, (const T*)x, (const T*)res, gamma, beta, (T*)y, \
+                     (T*)sum_out, mean, rstd, lengths, rows, Tlen, C, eps, out_mask)
+  switch (nv) {
+    case 1: LN_FWD(1); break;
+    case 2: LN_FWD(2); break;
+    case 3: LN_FWD(3); break;
+    case 4: LN_FWD(4); break;
+    default: ptpp_set_error("layernorm: C=%d > 1024 unsupported", C); return PTPP_ENOTSUP;
+  }
+#undef LN_FWD
+  PTPP_CHECK_LAUNCH("layernorm_fwd");
+  return PTPP_OK;
+}
+
+template <typename T>
+int ln_bwd_dispatch(const void* dy, const void* xs, const float* gamma, const float* mean, const float* rstd, void* dx,
+                    float* dgamma, float* dbeta, const int* lengths, int64_t rows, int Tlen, int C, int out_mask,
+                    hipStream_t st) {
+  const int nv = (C + 255) / 256;
+  int64_t nb = (rows + 3) / 4;
+  if (nb > 1024) nb = 1024;
+  const dim3 grid((unsigned)nb), blk(256);
+#define LN_BWD(NV)                                                                                             \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, blk, 0, st, (const T*)dy, (const T*)xs, gamma, mean, rstd, (T*)dx, \
+                     dgamma, dbeta, lengths, rows, Tlen, C, out_mask)
+  switch (nv) {
+    case 1: LN_BWD(1); break;
+    case 2: LN_BWD(2); break;
+    case 3: LN_BWD(3); break;
+    case 4: LN_BWD(4); break;
+    default: ptpp_set_error("layernorm: C=%d > 1024 unsupported", C); return PTPP_ENOTSUP;
+  }
+#undef LN_BWD
+  PTPP_CHECK_LAUNCH("layernorm_bwd");
+  return PTPP_OK;
+}
+
+}  // namespace
+
+extern "C" int ptpp_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                                  void* sum_out, float* mean, float* rstd, const int32_t* lengths, int B, int T, int C,
+                                  float eps, int out_mask, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null pointer");
+  PTPP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0, "layernorm_fwd: bad shape B=%d T=%d C=%d", B, T, C);
+  PTPP_CHECK_ARG(!out_mask || lengths, "layernorm_fwd: out_mask needs lengths");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t rows = (int64_t)B * T;
+  if (dtype == PTPP_F32)
+    return ln_fwd_dispatch<float>(x, res, gamma, beta, y, sum_out, mean, rstd, lengths, rows, T, C, eps, out_mask, st);
+  if (dtype == PTPP_BF16)
+    return ln_fwd_dispatch<bf16_raw>(x, res, gamma, beta, y, sum_out, mean, rstd, lengths, rows, T, C, eps, out_mask,
+                                     st);
+  PTPP_CHECK_ARG(false, "layernorm_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int ptpp_layernorm_bwd(const void* dy, const void* xsum, const float* gamma, const float* mean,
+                                  const float* rstd, void* dx, float* dgamma, float* dbeta, const int32_t* lengths,
+                                  int B, int T, int C, int out_mask, int dtype, void* stream) {
+  PTPP_CHECK_ARG(dy && xsum && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+  PTPP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0, "layernorm_bwd: bad shape");
+  PTPP_CHECK_ARG(!out_mask || lengths, "layernorm_bwd: out_mask needs lengths");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t rows = (int64_t)B * T;
+  if (dtype == PTPP_F32)
+    return ln_bwd_dispatch<float>(dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, lengths, rows, T, C, out_mask, st);
+  if (dtype == PTPP_BF16)
+    return ln_bwd_dispatch<bf16_raw>(dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, lengths, rows, T, C, out_mask,
+                                     st);
+  PTPP_CHECK_ARG(false, "layernorm_bwd: bad dtype %d", dtype);
+}

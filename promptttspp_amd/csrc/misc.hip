@@ -1,0 +1,79 @@
+// Small fused elementwise / single-channel kernels (all HBM-bound).
+#include "ptpp_common.h"
+
+namespace {
+
+template <typename T>
+__global__ void add3_scale_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                                  T* __restrict__ y, float scale, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 v = Elem<T>::ld4(a + i * 4);
+    if (b) v += Elem<T>::ld4(b + i * 4);
+    if (c) v += Elem<T>::ld4(c + i * 4);
+    Elem<T>::st4(y + i * 4, v * scale);
+  }
+}
+
+// conv_post (Cout = 1) + tanh: one thread per output sample, the ks*C taps live
+// in LDS; x rows are re-read by neighbouring threads out of L1/L2.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_post_tanh_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             float bias, float* __restrict__ y, int T_, int C, int ks) {
+  extern __shared__ float wsm[];
+  for (int i = threadIdx.x; i < ks * C; i += 256) wsm[i] = w[i];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T_) return;
+  const int pad = ks / 2;
+  const T* xb = x + (int64_t)b * T_ * C;
+  float acc = bias;
+  for (int j = 0; j < ks; ++j) {
+    const int ts = t + j - pad;
+    if (ts < 0 || ts >= T_) continue;
+    const T* xr = xb + (int64_t)ts * C;
+    const float* wr = wsm + j * C;
+    for (int c = 0; c < C; c += 4) {
+      const f32x4 v = Elem<T>::ld4(xr + c);
+      acc += v[0] * wr[c] + v[1] * wr[c + 1] + v[2] * wr[c + 2] + v[3] * wr[c + 3];
+    }
+  }
+  y[(int64_t)b * T_ + t] = tanhf(acc);
+}
+
+}  // namespace
+
+extern "C" int ptpp_add3_scale(const void* a, const void* b, const void* c, void* y, float scale, int64_t n, int dtype,
+                               void* stream) {
+  PTPP_CHECK_ARG(a && y && n > 0 && n % 4 == 0, "add3_scale: bad args");
+  const int64_t n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PTPP_F32)
+    hipLaunchKernelGGL(add3_scale_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b,
+                       (const float*)c, (float*)y, scale, n4);
+  else if (dtype == PTPP_BF16)
+    hipLaunchKernelGGL(add3_scale_kernel<bf16_raw>, dim3(grid), dim3(256), 0, st, (const bf16_raw*)a,
+                       (const bf16_raw*)b, (const bf16_raw*)c, (bf16_raw*)y, scale, n4);
+  else
+    PTPP_CHECK_ARG(false, "add3_scale: bad dtype");
+  PTPP_CHECK_LAUNCH("add3_scale");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_conv_post_tanh(const void* x, const float* w, float bias, float* y, int B, int T, int C, int ks,
+                                   int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && w && y && B > 0 && T > 0 && C > 0 && C % 4 == 0 && ks > 0 && (ks & 1),
+                 "conv_post_tanh: bad args");
+  dim3 grid((T + 255) / 256, B), blk(256);
+  const size_t smem = (size_t)ks * C * sizeof(float);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PTPP_F32)
+    hipLaunchKernelGGL(conv_post_tanh_kernel<float>, grid, blk, smem, st, (const float*)x, w, bias, y, T, C, ks);
+  else if (dtype == PTPP_BF16)
+    hipLaunchKernelGGL(conv_post_tanh_kernel<bf16_raw>, grid, blk, smem, st, (const bf16_raw*)x, w, bias, y, T, C, ks);
+  else
+    PTPP_CHECK_ARG(false, "conv_post_tanh: bad dtype");
+  PTPP_CHECK_LAUNCH("conv_post_tanh");
+  return PTPP_OK;
+}

@@ -1,0 +1,96 @@
+// Weight packing and (B,C,T) <-> (B,T,C) layout bridges.
+#include "ptpp_common.h"
+
+namespace {
+
+// mode 0: wp[co][j][c]  = w[co][c][j]          (c <  Cin, else 0), rows = Cout, inner = CinP
+// mode 1: wp[ci][j][c]  = w[c][ci][ks-1-j]     (c < Cout, else 0), rows = Cin,  inner = CoutP
+template <typename T>
+__global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp, int cout, int cin, int ks,
+                                 int mode, int rows, int inner, int innerp) {
+  const int64_t n = (int64_t)rows * ks * innerp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % innerp);
+    const int j = (int)((i / innerp) % ks);
+    const int r = (int)(i / ((int64_t)innerp * ks));
+    float v = 0.f;
+    if (c < inner) {
+      if (mode == 0)
+        v = w[((int64_t)r * cin + c) * ks + j];
+      else
+        v = w[((int64_t)c * cin + r) * ks + (ks - 1 - j)];
+    }
+    Elem<T>::st(wp + i, v);
+  }
+}
+
+// 32x32 LDS-tiled transpose of the two inner dims with dtype conversion.
+template <typename TI, typename TO>
+__global__ void transpose_kernel(const TI* __restrict__ x, TO* __restrict__ y, int R, int S) {
+  // x: (B, R, S) -> y: (B, S, R)
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
+  const TI* xb = x + (int64_t)b * R * S;
+  TO* yb = y + (int64_t)b * R * S;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, s = s0 + threadIdx.x;
+    if (r < R && s < S) tile[i][threadIdx.x] = Elem<TI>::ld(xb + (int64_t)r * S + s);
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int s = s0 + i, r = r0 + threadIdx.x;
+    if (r < R && s < S) Elem<TO>::st(yb + (int64_t)s * R + r, tile[threadIdx.x][i]);
+  }
+}
+
+}  // namespace
+
+extern "C" int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin, int ks, int mode, int dtype,
+                                     void* stream) {
+  PTPP_CHECK_ARG(w && wp, "pack_conv_weight: null pointer");
+  PTPP_CHECK_ARG(cout > 0 && cin > 0 && ks > 0 && (mode == 0 || mode == 1), "pack_conv_weight: bad args");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "pack_conv_weight: bad dtype");
+  const int rows = mode == 0 ? cout : cin;
+  const int inner = mode == 0 ? cin : cout;
+  const int innerp = ptpp_conv_cin_padded(inner, dtype);
+  const int64_t n = (int64_t)rows * ks * innerp;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PTPP_F32)
+    hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)wp, cout, cin, ks, mode, rows,
+                       inner, innerp);
+  else
+    hipLaunchKernelGGL(pack_conv_kernel<bf16_raw>, dim3(grid), dim3(256), 0, st, w, (bf16_raw*)wp, cout, cin, ks, mode,
+                       rows, inner, innerp);
+  PTPP_CHECK_LAUNCH("pack_conv_weight");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_bct_to_btc(const float* x, void* y, int B, int C, int T, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0, "bct_to_btc: bad args");
+  dim3 grid((T + 31) / 32, (C + 31) / 32, B), blk(32, 8);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PTPP_F32)
+    hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, st, x, (float*)y, C, T);
+  else if (dtype == PTPP_BF16)
+    hipLaunchKernelGGL((transpose_kernel<float, bf16_raw>), grid, blk, 0, st, x, (bf16_raw*)y, C, T);
+  else
+    PTPP_CHECK_ARG(false, "bct_to_btc: bad dtype");
+  PTPP_CHECK_LAUNCH("bct_to_btc");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_btc_to_bct(const void* x, float* y, int B, int T, int C, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0, "btc_to_bct: bad args");
+  dim3 grid((C + 31) / 32, (T + 31) / 32, B), blk(32, 8);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PTPP_F32)
+    hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, st, (const float*)x, y, T, C);
+  else if (dtype == PTPP_BF16)
+    hipLaunchKernelGGL((transpose_kernel<bf16_raw, float>), grid, blk, 0, st, (const bf16_raw*)x, y, T, C);
+  else
+    PTPP_CHECK_ARG(false, "btc_to_bct: bad dtype");
+  PTPP_CHECK_LAUNCH("btc_to_bct");
+  return PTPP_OK;
+}

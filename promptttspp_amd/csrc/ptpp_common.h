@@ -1,0 +1,123 @@
+// Shared device/host helpers for libptpp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ptpp.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef unsigned short bf16_raw;  // storage type of a bf16 element
+
+// ---- error plumbing ---------------------------------------------------------
+void ptpp_set_error(const char* fmt, ...);
+
+#define PTPP_CHECK_ARG(cond, ...)  \
+  do {                             \
+    if (!(cond)) {                 \
+      ptpp_set_error(__VA_ARGS__); \
+      return PTPP_EINVAL;          \
+    }                              \
+  } while (0)
+
+#define PTPP_CHECK_LAUNCH(name)                                       \
+  do {                                                                \
+    hipError_t e__ = hipGetLastError();                               \
+    if (e__ != hipSuccess) {                                          \
+      ptpp_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return PTPP_ELAUNCH;                                            \
+    }                                                                 \
+  } while (0)
+
+// ---- bf16 <-> f32 (round to nearest even, like torch) -------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_raw v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_raw)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_raw)(u >> 16);
+}
+
+// Element traits: how many elements in a 16-byte chunk and vector load/store of
+// 4 consecutive elements as f32.
+template <typename T>
+struct Elem;
+
+template <>
+struct Elem<float> {
+  static constexpr int PER16 = 4;
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ f32x4 ld4(const float* p) {
+    return *reinterpret_cast<const f32x4*>(p);
+  }
+  static __device__ __forceinline__ void st4(float* p, f32x4 v) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  }
+};
+
+template <>
+struct Elem<bf16_raw> {
+  static constexpr int PER16 = 8;
+  static __device__ __forceinline__ float ld(const bf16_raw* p) {
+    return bf16_to_f32(*p);
+  }
+  static __device__ __forceinline__ void st(bf16_raw* p, float v) {
+    *p = f32_to_bf16(v);
+  }
+  static __device__ __forceinline__ f32x4 ld4(const bf16_raw* p) {
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    f32x4 v;
+    v[0] = __uint_as_float(r.x << 16);
+    v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16);
+    v[3] = __uint_as_float(r.y & 0xffff0000u);
+    return v;
+  }
+  static __device__ __forceinline__ void st4(bf16_raw* p, f32x4 v) {
+    uint2 r;
+    r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+  }
+};
+
+// ---- activations ------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case PTPP_ACT_RELU:
+      return v > 0.f ? v : 0.f;
+    case PTPP_ACT_GELU:
+      return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    case PTPP_ACT_SWISH:
+      return v / (1.f + __expf(-v));
+    case PTPP_ACT_TANH:
+      return tanhf(v);
+    case PTPP_ACT_MISH: {
+      // x * tanh(softplus(x)); softplus with torch's threshold of 20
+      float sp = v > 20.f ? v : log1pf(__expf(v));
+      return v * tanhf(sp);
+    }
+    default:
+      return v;
+  }
+}
+
+// ---- wave reductions (wave = 64 lanes) ---------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware block remap: hardware places block b on XCD b % 8; give each XCD a
+// contiguous range of logical tiles so neighbours share L2 (bijective for any n).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}

@@ -1,0 +1,187 @@
+"""GPU: each HIP kernel (through the C ABI) against a plain PyTorch fp32 CPU
+reference of the same op / the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from conftest import load_golden, rel_err
+
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2e-5
+BF16_TOL = 2e-2
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy((scale * np.random.default_rng(seed).standard_normal(shape)).astype(np.float32))
+
+
+CONV_CASES = [
+    # B, T, Cin, Cout, ks, dil
+    (2, 37, 80, 512, 7, 1),     # conv_pre shape (Cin not a multiple of 32/64)
+    (3, 150, 256, 256, 17, 1),  # frame prior
+    (2, 70, 256, 1024, 9, 1),   # conformer FFN w_1
+    (2, 70, 1024, 256, 9, 1),   # conformer FFN w_2
+    (2, 200, 256, 512, 3, 8),   # DiffNet dilated
+    (1, 300, 32, 32, 11, 5),    # BigVGAN last stage
+    (2, 260, 64, 64, 7, 3),
+    (2, 33, 256, 4, 1, 1),      # MDN head (Linear)
+    (2, 45, 256, 2, 1, 1),      # pitch out layer, Cout not /4
+    (1, 129, 128, 640, 3, 1),   # upsample-as-conv geometry
+    (4, 5, 256, 256, 3, 1),     # very short sequences
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv1d_fwd(case, dtype, dev):
+    from promptttspp_amd import ops
+
+    B, T, Cin, Cout, ks, dil = case
+    pad = (ks - 1) * dil // 2
+    x = rnd(1, B, T, Cin)
+    w = rnd(2, Cout, Cin, ks) / np.sqrt(Cin * ks)
+    b = rnd(3, Cout, scale=0.1)
+    res = rnd(4, B, T, Cout)
+    lens = torch.tensor([T, max(1, T // 2), max(1, T - 3), 1][:B], dtype=torch.int32)
+    if dtype == torch.bfloat16:  # compare against the same rounded operands
+        x, w, res = x.bfloat16().float(), w.bfloat16().float(), res.bfloat16().float()
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float()[:, :, None]
+    ref = F.conv1d((x * mask).transpose(1, 2), w, b, padding=pad, dilation=dil).transpose(1, 2)
+    ref = res + 0.5 * F.gelu(ref) * mask
+    wp = ops.pack_conv_weight(w.to(dev), dtype)
+    y = ops.conv1d(x.to(dev, dtype), wp, b.to(dev), Cout, ks=ks, dil=dil, pad=pad, act="gelu", lengths=lens,
+                   in_mask=True, out_mask=True, res=res.to(dev, dtype), out_scale=0.5)
+    assert rel_err(y.float().cpu(), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+    # no masks / no residual / no bias path
+    ref2 = F.conv1d(x.transpose(1, 2), w, None, padding=pad, dilation=dil).transpose(1, 2)
+    y2 = ops.conv1d(x.to(dev, dtype), wp, None, Cout, ks=ks, dil=dil, pad=pad)
+    assert rel_err(y2.float().cpu(), ref2) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+
+def test_conv1d_transpose_detecting(dev):
+    """asymmetric weights + identity-like input catch row/col swaps in the MFMA
+    output mapping (cdna_hip_programming.md G9)."""
+    from promptttspp_amd import ops
+
+    T, C = 64, 64
+    x = torch.eye(T, C).unsqueeze(0)
+    w = (torch.arange(C * C, dtype=torch.float32).reshape(C, C, 1) % 97) / 97.0
+    y = ops.conv1d(x.to(dev), ops.pack_conv_weight(w.to(dev), torch.float32), None, C)
+    assert torch.equal(y.cpu()[0], w[:, :, 0].t())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv1d_dgrad_via_mode1_pack(dtype, dev):
+    """data gradient = the same kernel on flipped/transposed packed weights."""
+    from promptttspp_amd import ops
+
+    B, T, Cin, Cout, ks, dil = 2, 90, 256, 512, 3, 4
+    pad = (ks - 1) * dil // 2
+    x = rnd(1, B, T, Cin).requires_grad_()
+    w = rnd(2, Cout, Cin, ks) / np.sqrt(Cin * ks)
+    dy = rnd(3, B, T, Cout)
+    if dtype == torch.bfloat16:
+        w, dy = w.bfloat16().float(), dy.bfloat16().float()
+    y = F.conv1d(x.transpose(1, 2), w, None, padding=pad, dilation=dil).transpose(1, 2)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    wpt = ops.pack_conv_weight(w.to(dev), dtype, mode=1)
+    dx = ops.conv1d(dy.to(dev, dtype), wpt, None, Cin, ks=ks, dil=dil, pad=(ks - 1) * dil - pad)
+    assert rel_err(dx.float().cpu(), dx_ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 150, 256, 256, 5, 1), (3, 70, 80, 256, 1, 1), (2, 90, 256, 4, 1, 1),
+                                  (2, 64, 256, 512, 3, 8)])
+def test_conv1d_wgrad(case, dtype, dev):
+    from promptttspp_amd import ops
+
+    B, T, Cin, Cout, ks, dil = case
+    pad = (ks - 1) * dil // 2
+    x = rnd(1, B, T, Cin)
+    dy = rnd(3, B, T, Cout)
+    lens = torch.tensor([T, T // 2, T - 1][:B], dtype=torch.int32)
+    if dtype == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float()[:, :, None]
+    w = torch.zeros(Cout, Cin, ks, requires_grad=True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = F.conv1d((x * mask).transpose(1, 2), w, b, padding=pad, dilation=dil).transpose(1, 2)
+    dw_ref, db_ref = torch.autograd.grad(y, (w, b), dy)
+    dw, db = ops.conv1d_wgrad(x.to(dev, dtype), dy.to(dev, dtype), Cin, Cout, ks, dil, pad, lengths=lens, in_mask=True)
+    assert rel_err(dw.cpu(), dw_ref) < 1e-4
+    assert rel_err(db.cpu(), db_ref) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [256, 768, 80])
+def test_layernorm_fwd_bwd(dtype, C, dev):
+    from promptttspp_amd import ops
+
+    B, T = 3, 41
+    x = (rnd(1, B, T, C, scale=2.0) + 0.3)
+    res = rnd(2, B, T, C)
+    g = 1.0 + 0.1 * rnd(3, C)
+    bta = 0.1 * rnd(4, C)
+    dy = rnd(5, B, T, C)
+    lens = torch.tensor([T, 7, 1], dtype=torch.int32)
+    if dtype == torch.bfloat16:
+        x, res, dy = x.bfloat16().float(), res.bfloat16().float(), dy.bfloat16().float()
+    tol = 1e-5 if dtype == torch.float32 else BF16_TOL
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float()[:, :, None]
+    xs = (x + res).requires_grad_()
+    gp, bp = g.clone().requires_grad_(), bta.clone().requires_grad_()
+    ref = R.layer_norm_last(xs, gp, bp, 1e-5) * mask
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(ref, (xs, gp, bp), dy)
+    y, mean, rstd, xsum = ops.layernorm_fwd(x.to(dev, dtype), g.to(dev), bta.to(dev), 1e-5, res=res.to(dev, dtype),
+                                            lengths=lens, out_mask=True, save_stats=True, save_sum=True)
+    assert rel_err(y.float().cpu(), ref.detach()) < tol
+    dx, dg, db = ops.layernorm_bwd(dy.to(dev, dtype), xsum, g.to(dev), mean, rstd, lengths=lens, out_mask=True)
+    assert rel_err(dx.float().cpu(), dx_ref) < tol
+    assert rel_err(dg.cpu(), dg_ref) < (1e-4 if dtype == torch.float32 else BF16_TOL)
+    assert rel_err(db.cpu(), db_ref) < (1e-4 if dtype == torch.float32 else BF16_TOL)
+    # eps 1e-12 (ESPnet variant), no residual, no mask
+    y2, *_ = ops.layernorm_fwd(x.to(dev, dtype), g.to(dev), bta.to(dev), 1e-12)
+    assert rel_err(y2.float().cpu(), R.layer_norm_last(x, g, bta, 1e-12)) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_aa_snake_golden(dtype, dev):
+    from promptttspp_amd import ops
+
+    g = load_golden("aa_snake")
+    up, dn = ops._taps(g["f_up"]), ops._taps(g["f_dn"])
+    for T in [1, 2, 5, 6, 7, 13, 64, 131]:
+        x = g[f"x{T}"]
+        if dtype == torch.bfloat16:
+            x = x.bfloat16().float()
+        ref = R.aa_snake(x, g["alpha"], g["f_up"], g["f_dn"]) if dtype == torch.bfloat16 else g[f"y{T}"]
+        y = ops.aa_snake(x.transpose(1, 2).contiguous().to(dev, dtype), g["alpha"].to(dev), up, dn)
+        assert rel_err(y.float().cpu().transpose(1, 2), ref) < (1e-5 if dtype == torch.float32 else BF16_TOL), T
+
+
+def test_aa_snake_long_and_wide(dev):
+    """lengths spanning several per-thread runs (R = 66) and C = 512."""
+    from promptttspp_amd import ops
+
+    g = load_golden("aa_snake")
+    up, dn = ops._taps(g["f_up"]), ops._taps(g["f_dn"])
+    for (B, C, T) in [(2, 512, 67), (1, 32, 1000), (3, 64, 133)]:
+        x = rnd(T, B, C, T, scale=1.5)
+        la = 0.3 * rnd(C, C)
+        ref = R.aa_snake(x, la, g["f_up"], g["f_dn"])
+        y = ops.aa_snake(x.transpose(1, 2).contiguous().to(dev), la.to(dev), up, dn)
+        assert rel_err(y.cpu().transpose(1, 2), ref) < 1e-5
+
+
+def test_layout_bridges(dev):
+    from promptttspp_amd import ops
+
+    x = rnd(1, 3, 80, 77)
+    y = ops.bct_to_btc(x.to(dev), torch.float32)
+    assert torch.equal(y.cpu(), x.transpose(1, 2))
+    assert torch.equal(ops.btc_to_bct(y).cpu(), x)
+    yb = ops.bct_to_btc(x.to(dev), torch.bfloat16)
+    assert torch.equal(yb.cpu(), x.transpose(1, 2).bfloat16())
