@@ -67,10 +67,10 @@ def synth_tensor(name, shape, seed, gain=1.0):
     return v.astype(np.float32).reshape(shape)
 
 
-def fill_state_dict(module, seed, gain=1.0, overrides=None):
+def fill_state_dict(module, seed, gain=1.0, overrides=None, offsets=None):
     """Overwrite every (non-kept) entry of ``module.state_dict()`` in place.
     ``overrides``: {name_suffix: gain} for individual tensors (e.g. to tame the
-    duration head).  Returns [(name, shape)] of what was filled."""
+    duration head); ``offsets``: {name_suffix: constant added}.  Returns [(name, shape)] of what was filled."""
     filled = []
     sd = module.state_dict()
     with torch.no_grad():
@@ -83,6 +83,10 @@ def fill_state_dict(module, seed, gain=1.0, overrides=None):
                     if name.endswith(suf):
                         g = og
             t.copy_(torch.from_numpy(synth_tensor(name, t.shape, seed, g)))
+            if offsets:
+                for suf, off in offsets.items():
+                    if name.endswith(suf):
+                        t.add_(off)
             filled.append((name, tuple(t.shape)))
     return filled
 
