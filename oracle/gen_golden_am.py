@@ -45,8 +45,16 @@ def injected_rng(randn_list=None, rand_list=None, randn_like_list=None):
             return t
         return f
 
+    inner = old_defaults = None
     if randn_list is not None:
         torch.randn = mk(qs[0], "randn")
+        # p_sample binds `noise_fn=torch.randn` at definition time (diffusion.py:203):
+        # re-point that default at the queue too, or the per-step noise is not injected
+        import promptttspp.modules.diffusion as D
+
+        inner = D.GaussianDiffusion.p_sample.__wrapped__
+        old_defaults = inner.__defaults__
+        inner.__defaults__ = (torch.randn,) + tuple(old_defaults[1:])
     if rand_list is not None:
         torch.rand = mk(qs[1], "rand")
     if randn_like_list is not None:
@@ -55,6 +63,8 @@ def injected_rng(randn_list=None, rand_list=None, randn_like_list=None):
         yield
     finally:
         torch.randn, torch.rand, torch.randn_like = o
+        if inner is not None:
+            inner.__defaults__ = old_defaults
 
 
 @gen
