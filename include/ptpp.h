@@ -11,17 +11,19 @@
  *
  * Conventions
  *   - Every pointer is a DEVICE pointer owned by the caller (torch tensors:
- *     Tensor.data_ptr()).  The library allocates nothing persistent.
+ *     Tensor.data_ptr()) unless a parameter says HOST.  The library allocates
+ *     nothing persistent.
  *   - Activations are channels-last: a (B, T, C) tensor is B*T rows of C
- *     contiguous elements with an explicit row stride `ld*` (in elements).
- *     The Python boundary transposes the reference's (B, C, T) tensors.
+ *     contiguous elements, with an explicit row stride `ld*` (in elements)
+ *     where noted.  The Python boundary transposes the reference's (B, C, T).
  *   - `dtype`: PTPP_F32 (exact f32 MFMA path, parity mode) or PTPP_BF16
  *     (bf16 storage + bf16 MFMA, f32 accumulate).  Bias, LayerNorm/Snake
- *     parameters, masks/lengths and all statistics are always f32 / i32.
+ *     parameters, lengths, statistics and gradients of parameters are f32/i32.
  *   - `lengths` (int32[B], may be NULL): per-utterance valid length; it
- *     replaces the reference's float/int mask tensors (sequence_mask,
- *     utils/model.py:30-34).  Row t of utterance b is "valid" iff
- *     t < lengths[b].
+ *     replaces the reference's mask tensors (sequence_mask,
+ *     utils/model.py:30-34).  Row t of utterance b is valid iff t < lengths[b].
+ *   - Dropout is counter based: element keep-mask = f(seed, element index), so
+ *     the backward pass regenerates it from the same (p, seed); p == 0 disables.
  *   - All launches are asynchronous on `stream` (a hipStream_t passed as
  *     void*); no call synchronises.  Re-entrant across streams.
  *   - Return value: 0 on success, negative PTPP_E* otherwise; never throws.
@@ -52,12 +54,17 @@ extern "C" {
 #define PTPP_ACT_TANH 4
 #define PTPP_ACT_MISH 5
 
+/* attention variants */
+#define PTPP_ATTN_RELPOS_NEW 0    /* esp/transformer/attention.py:207-305 */
+#define PTPP_ATTN_RELPOS_LEGACY 1 /* esp/transformer/attention.py:111-206 */
+#define PTPP_ATTN_PLAIN 2         /* no positional term (BERT self-attention) */
+
 const char* ptpp_last_error(void);
 int ptpp_version(void);
 
 /* ------------------------------------------------------------------ *
- * Weight packing (run once per weight update; folds the cast to the
- * compute dtype that torch.autocast would otherwise do per use).
+ * Weight packing (once per weight version; folds the cast to the compute
+ * dtype that torch.autocast would otherwise do per use).
  * ------------------------------------------------------------------ */
 
 /* Padded per-tap channel count of a packed weight for `dtype`. */
@@ -71,17 +78,19 @@ int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin, int ks,
 
 /* ------------------------------------------------------------------ *
  * Conv1d / Linear as an MFMA implicit GEMM with fused epilogue.
- *   y[b,t,:] = res[b,t,:] + out_scale * mask_out(act(W * x_masked + bias))
+ *   y = res_scale*res + res2
+ *       + out_scale * drop(mask_out(act(W * x_masked + bias)))
  * Replaces nn.Conv1d / nn.Linear + the elementwise ops around them in
- *   esp/transformer/multi_layer_conv.py:52-67   (k=9, ReLU, masks)
+ *   esp/transformer/multi_layer_conv.py:52-67   (k=9, ReLU, masks, dropout)
  *   modules/variance_adaptor.py:31-36           (k=3/5, ReLU)
- *   modules/frame_prior.py:85-89                (k=17, GELU)
+ *   modules/frame_prior.py:85-89                (k=17)
  *   modules/denoiser.py:58-64,69-83             (k=3 dilated, 1x1)
  *   esp/transformer/attention.py:32-35,229      (Linear 256x256)
  *   modules/mdn.py:50-78, modules/prompt_encoder.py:45-51 (Linear heads/MLP)
  *   vocoders/bigvgan.py:24-47,84-118            (dilated Conv1d, and
  *       ConvTranspose1d re-expressed as a 3-tap conv with Cout*stride
  *       outputs -- see promptttspp_amd/vocoders/bigvgan.py)
+ * The data gradient is the same kernel on a mode-1 packed weight.
  * ------------------------------------------------------------------ */
 typedef struct {
   const void* x;      /* (B*T, Cin) rows, stride ldx                */
@@ -101,65 +110,136 @@ typedef struct {
 
 int ptpp_conv1d_fwd(const ptpp_conv1d_args* a, void* stream);
 
-/* Same, with a second residual and a scale on the first:
- *   y = res_scale*res + res2 + out_scale*mask_out(act(...))
- * (lets the last conv of each AMP block accumulate the 3-block mean of
- *  vocoders/bigvgan.py:124-128 without an extra pass). */
+/* Full form: second residual, residual scale (AMP-block mean of
+ * vocoders/bigvgan.py:124-128) and fused dropout on the conv term. */
 int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, int ldr2,
-                       float res_scale, void* stream);
+                       float res_scale, float drop_p, uint64_t drop_seed,
+                       void* stream);
 
-/* Weight gradient of the convolution above (f32 accumulate, f32 output):
- *   dw[Cout][Cin][ks] (+)= sum_{b,t} dy[b,t,co] * x[b, t + j*dil - pad, ci]
- *   dbias[Cout]       (+)= sum_{b,t} dy[b,t,co]
- * `accumulate` != 0 adds to dw/dbias (gradient accumulation), else overwrites
- * via a zero-fill the caller performs (dw must be zeroed by the caller when
- * accumulate == 0; the kernel always uses atomic adds across row splits). */
+/* Weight / bias gradient (f32 accumulate, f32 output, atomics across the
+ * row split -- the caller zero-fills dw/dbias or accumulates into them):
+ *   dw[Cout][Cin][ks] += sum_{b,t} dy[b,t,co] * x[b, t + j*dil - pad, ci]
+ *   dbias[Cout]       += sum_{b,t} dy[b,t,co]                 (dbias nullable) */
 int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias,
                       const int32_t* lengths, int B, int T, int Cin, int Cout,
                       int ks, int dil, int pad, int ldx, int lddy, int in_mask,
                       int dtype, void* stream);
 
+/* Backward of the conv epilogue (contiguous (B,T,C)):
+ *   dz = dy * scale * [t < len] * relu'(y) * dropmask           */
+int ptpp_epilogue_bwd(const void* dy, const void* y, void* dz,
+                      const int32_t* lengths, int B, int T, int C, float scale,
+                      int relu, int out_mask, float drop_p, uint64_t seed,
+                      int dtype, void* stream);
+
 /* ------------------------------------------------------------------ *
  * LayerNorm over the channel (last) dimension, biased variance.
- *   y = (x [+ res] - mean) * rsqrt(var + eps) * gamma + beta   [* mask]
+ *   s = drop_in(act_in(x)) + res ;  y = drop_out(LN(s)*gamma+beta) * mask
  * Replaces the three LayerNorm variants of SURVEY.md F13:
  *   esp/transformer/layer_norm.py:12-33 (eps 1e-12),
  *   layers/norm.py:19-32 (eps 1e-5, (B,C,T) layout),
- *   modules/frame_prior.py:22-34 (eps 1e-5).
- * mean/rstd (f32, one per row) are written when non-NULL (for backward).
+ *   modules/frame_prior.py:22-34 (eps 1e-5),
+ * and the elementwise ops fused around them (frame_prior.py:85-89:
+ * LN(x + dropout(gelu(z))); variance_adaptor.py:31-36: dropout(LN(.))*mask).
+ * act_in: PTPP_ACT_NONE or PTPP_ACT_GELU.  sum_out (s) / mean / rstd are
+ * written when non-NULL (saved for backward).
  * ------------------------------------------------------------------ */
 int ptpp_layernorm_fwd(const void* x, const void* res, const float* gamma,
                        const float* beta, void* y, void* sum_out, float* mean,
                        float* rstd, const int32_t* lengths, int B, int T, int C,
-                       float eps, int out_mask, int dtype, void* stream);
+                       float eps, int out_mask, int act_in, float drop_in_p,
+                       uint64_t drop_in_seed, float drop_out_p,
+                       uint64_t drop_out_seed, int dtype, void* stream);
 
-/* dx (and optionally the same gradient to `res`, which is dx) ; dgamma/dbeta
- * are accumulated with atomics into f32 buffers the caller zeroed. */
-int ptpp_layernorm_bwd(const void* dy, const void* xsum, const float* gamma,
-                       const float* mean, const float* rstd, void* dx,
-                       float* dgamma, float* dbeta, const int32_t* lengths,
-                       int B, int T, int C, int out_mask, int dtype,
+/* dsum = dL/ds (also the gradient of `res`); dz = dsum*dropmask_in*act_in'(z)
+ * when act_in/drop_in were used (z = the forward `x`).  dgamma/dbeta are
+ * atomically accumulated into caller-zeroed f32 buffers (nullable). */
+int ptpp_layernorm_bwd(const void* dy, const void* xsum, const void* z,
+                       const float* gamma, const float* mean, const float* rstd,
+                       void* dsum, void* dz, float* dgamma, float* dbeta,
+                       const int32_t* lengths, int B, int T, int C, int out_mask,
+                       int act_in, float drop_in_p, uint64_t drop_in_seed,
+                       float drop_out_p, uint64_t drop_out_seed, int dtype,
                        void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Relative-position multi-head attention for short sequences
+ * (esp/transformer/attention.py:63-93,142-206,237-305).
+ *   q,k,v: (B,T,*) rows with stride ld, head h at columns [h*dk,(h+1)*dk)
+ *   pos:   linear_pos(pos_emb): (2T-1, H*dk) new / (T, H*dk) legacy, stride ldpos
+ *   bias_u/bias_v: (H, dk) f32;  ctx: (B,T,H*dk) rows with stride ldctx
+ *   probs: (B,H,T,T) f32 softmax output (NULL in inference; saved for bwd)
+ * ------------------------------------------------------------------ */
+int ptpp_attention_fwd(const void* q, const void* k, const void* v,
+                       const void* pos, const float* bias_u, const float* bias_v,
+                       void* ctx, float* probs, const int32_t* lengths, int B,
+                       int T, int H, int dk, int ld, int ldpos, int ldctx,
+                       int variant, int dtype, void* stream);
+
+/* dS: (B,H,T,T) f32 workspace; dq/dk_out/dv_out: (B,T,*) rows, stride lddq;
+ * dpos: (2T-1, H*dk) f32 (overwritten); du/dvb: (H*dk) f32 accumulated with
+ * atomics into caller-zeroed buffers.  Variants: NEW and PLAIN. */
+int ptpp_attention_bwd(const void* q, const void* k, const void* v,
+                       const void* pos, const float* bias_u, const float* bias_v,
+                       const float* probs, const void* dctx, float* dS, void* dq,
+                       void* dk_out, void* dv_out, float* dpos, float* du,
+                       float* dvb, const int32_t* lengths, int B, int T, int H,
+                       int dk, int ld, int ldpos, int lddctx, int lddq,
+                       int variant, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Length regulator as a gather / segment-sum instead of the reference's
+ * dense 0/1 path matmul (utils/model.py:37-47, variance_adaptor.py:129-131).
+ *   cum: (B, Tp) int32 inclusive cumulative durations
+ *   y[b,f,:] = x[b, p(f), :],  p(f) = #{p : cum[b,p] <= f}   (0 past the end)
+ * ------------------------------------------------------------------ */
+int ptpp_length_regulate_fwd(const void* x, const int32_t* cum, void* y, int B,
+                             int Tp, int Tf, int C, int dtype, void* stream);
+int ptpp_length_regulate_bwd(const void* dy, const int32_t* cum, void* dx, int B,
+                             int Tp, int Tf, int C, int dtype, void* stream);
+
+/* y = drop(x*scale + pe[t,:]) -- positional encodings (modules/embedding.py:91,
+ * esp/transformer/embedding.py:255,326); pe (T,C) f32 or NULL. */
+int ptpp_posenc_fwd(const void* x, const float* pe, void* y, int B, int T, int C,
+                    float scale, float drop_p, uint64_t seed, int dtype,
+                    void* stream);
+
+/* ------------------------------------------------------------------ *
+ * DiffNet residual block glue (modules/denoiser.py:69-83,136-140).
+ * ------------------------------------------------------------------ */
+/* g = sigmoid(a[:, :C]) * tanh(a[:, C:]) ; a: (rows, 2C), g: (rows, C) */
+int ptpp_gate_fwd(const void* a, void* g, int64_t rows, int C, int dtype,
+                  void* stream);
+/* da (rows, row stride ldda >= 2C) from dg; lets the caller write each layer's
+ * gradient straight into its slice of the batched conditioner gradient. */
+int ptpp_gate_bwd(const void* a, const void* dg, void* da, int64_t rows, int C,
+                  int ldda, int dtype, void* stream);
+/* xn = o ? (x + o[:, :C])/sqrt2 : x ; skip(f32) = (init?0:skip) + o[:, C:] ;
+ * yin = xn + dnext[b,:]  (o, yin nullable) */
+int ptpp_diffnet_post_fwd(const void* o, const void* x, float* skip,
+                          const float* dnext, void* xn, void* yin, int B, int T,
+                          int C, int init, int dtype, void* stream);
+/* dout (rows, 2C) = [gx/sqrt2 | gskip], masked rows zero */
+int ptpp_diffnet_post_bwd(const void* gx, const void* gskip, void* dout,
+                          const int32_t* lengths, int B, int T, int C, int dtype,
+                          void* stream);
+/* out[b,c] = sum_t x[b,t,c] (f32) */
+int ptpp_colsum_batch(const void* x, float* out, int B, int T, int C, int dtype,
+                      void* stream);
 
 /* ------------------------------------------------------------------ *
  * Anti-aliased Snake activation, one fused pass (layers/activations.py:22-44,
  * 74-138): replicate-pad -> x2 polyphase Kaiser-sinc up-FIR (12 taps, gain 2)
  * -> x + sin^2(x e^alpha)/(e^alpha + 1e-9) -> 12-tap low-pass, stride 2.
- *   x, y: (B, T, C) channels-last; log_alpha: (C) f32 (log domain, as
- *   stored in the state dict); filt_up/filt_down: HOST pointers to the 12 f32
- *   taps of `up.filter` / `down.lowpass.filter` (passed as kernel arguments;
- *   they are identical in the reference).
+ *   x, y: (B, T, C) channels-last; log_alpha: (C) f32 (log domain, as stored
+ *   in the state dict); filt_up/filt_down: HOST pointers to the 12 f32 taps of
+ *   `up.filter` / `down.lowpass.filter` (passed as kernel arguments).
  * ------------------------------------------------------------------ */
 int ptpp_aa_snake_fwd(const void* x, void* y, const float* log_alpha,
                       const float* filt_up, const float* filt_down, int B,
                       int T, int C, int dtype, void* stream);
 
-/* ------------------------------------------------------------------ *
- * Small fused elementwise / reduction kernels on channels-last rows.
- * ------------------------------------------------------------------ */
-
-/* y = (a + b + c) * scale  (b, c nullable) -- AMP block mean
- * (vocoders/bigvgan.py:124-128). */
+/* y = (a + b + c) * scale  (b, c nullable) */
 int ptpp_add3_scale(const void* a, const void* b, const void* c, void* y,
                     float scale, int64_t n, int dtype, void* stream);
 
@@ -175,6 +255,20 @@ int ptpp_bct_to_btc(const float* x, void* y, int B, int C, int T, int dtype,
                     void* stream);
 int ptpp_btc_to_bct(const void* x, float* y, int B, int T, int C, int dtype,
                     void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Fused multi-tensor optimiser step (trainers/tts.py:206-211):
+ * clip_grad_norm_(max_norm) then AdamW, for ALL parameters in two launches
+ * and without a host sync.  `refs`: device array of nt records
+ * {float* p; const float* g; float* m; float* v; int64 n; int64 block0},
+ * block0 = index of the tensor's first 4096-element block in the flat grid.
+ * ------------------------------------------------------------------ */
+int ptpp_grad_sumsq(const void* refs, int nt, long long total_blocks,
+                    float* sumsq, void* stream);
+int ptpp_adamw_step(const void* refs, int nt, long long total_blocks,
+                    const float* sumsq, const float* lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step,
+                    float max_norm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,13 +7,14 @@ silently routes around the HIP kernels.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_longlong, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libptpp_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SWISH, ACT_TANH, ACT_MISH = 0, 1, 2, 3, 4, 5
+ATTN_NEW, ATTN_LEGACY, ATTN_PLAIN = 0, 1, 2
 
 
 class PtppError(RuntimeError):
@@ -48,31 +49,37 @@ class ConvArgs(Structure):
     ]
 
 
+P, I, F, U64, I64 = c_void_p, c_int, c_float, c_uint64, c_int64
+
 # name -> (restype, argtypes); every symbol include/ptpp.h declares.
 SIGNATURES = {
     "ptpp_last_error": (ctypes.c_char_p, []),
-    "ptpp_version": (c_int, []),
-    "ptpp_conv_cin_padded": (c_int, [c_int, c_int]),
-    "ptpp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "ptpp_conv1d_fwd": (c_int, [POINTER(ConvArgs), c_void_p]),
-    "ptpp_conv1d_fwd_ex": (c_int, [POINTER(ConvArgs), c_void_p, c_int, c_float, c_void_p]),
-    "ptpp_conv1d_wgrad": (
-        c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p],
-    ),
-    "ptpp_layernorm_fwd": (
-        c_int,
-        [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
-    ),
-    "ptpp_layernorm_bwd": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p]),
-    "ptpp_aa_snake_fwd": (
-        c_int,
-        [c_void_p, c_void_p, c_void_p, POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_int, c_void_p],
-    ),
-    "ptpp_add3_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p]),
-    "ptpp_conv_post_tanh": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "ptpp_bct_to_btc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "ptpp_btc_to_bct": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ptpp_version": (I, []),
+    "ptpp_conv_cin_padded": (I, [I, I]),
+    "ptpp_pack_conv_weight": (I, [P, P, I, I, I, I, I, P]),
+    "ptpp_conv1d_fwd": (I, [POINTER(ConvArgs), P]),
+    "ptpp_conv1d_fwd_ex": (I, [POINTER(ConvArgs), P, I, F, F, U64, P]),
+    "ptpp_conv1d_wgrad": (I, [P, P, P, P, P] + [I] * 11 + [P]),
+    "ptpp_epilogue_bwd": (I, [P, P, P, P, I, I, I, F, I, I, F, U64, I, P]),
+    "ptpp_layernorm_fwd": (I, [P] * 9 + [I, I, I, F, I, I, F, U64, F, U64, I, P]),
+    "ptpp_layernorm_bwd": (I, [P] * 11 + [I, I, I, I, I, F, U64, F, U64, I, P]),
+    "ptpp_attention_fwd": (I, [P] * 9 + [I] * 9 + [P]),
+    "ptpp_attention_bwd": (I, [P] * 16 + [I] * 10 + [P]),
+    "ptpp_length_regulate_fwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "ptpp_length_regulate_bwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "ptpp_posenc_fwd": (I, [P, P, P, I, I, I, F, F, U64, I, P]),
+    "ptpp_gate_fwd": (I, [P, P, I64, I, I, P]),
+    "ptpp_gate_bwd": (I, [P, P, P, I64, I, I, I, P]),
+    "ptpp_diffnet_post_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "ptpp_diffnet_post_bwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "ptpp_colsum_batch": (I, [P, P, I, I, I, I, P]),
+    "ptpp_aa_snake_fwd": (I, [P, P, P, POINTER(c_float), POINTER(c_float), I, I, I, I, P]),
+    "ptpp_add3_scale": (I, [P, P, P, P, F, I64, I, P]),
+    "ptpp_conv_post_tanh": (I, [P, P, F, P, I, I, I, I, I, P]),
+    "ptpp_bct_to_btc": (I, [P, P, I, I, I, I, P]),
+    "ptpp_btc_to_bct": (I, [P, P, I, I, I, I, P]),
+    "ptpp_grad_sumsq": (I, [P, I, c_longlong, P, P]),
+    "ptpp_adamw_step": (I, [P, I, c_longlong, P, P, F, F, F, F, I, F, P]),
 }
 
 _lib = None

@@ -1,0 +1,338 @@
+// Multi-head attention with Transformer-XL style relative positions
+// (esp/transformer/attention.py:63-93,142-206,237-305) for SHORT sequences
+// (phones per utterance ~70, <= 1024): latency/launch bound, not FLOP bound
+// (8 kFLOP x T per phone), so the design goal is ONE launch per layer for all
+// (b, h, row) with the rel-shift folded into an index computation and the
+// softmax reductions done with wavefront shuffles.
+//
+//   score[i,j] = ((q_i + u) . k_j + bd[i,j]) / sqrt(dk)
+//   new    : bd[i,j] = (q_i + v) . p[T-1-i+j]                 p: (2T-1, C)
+//   legacy : flat = (i+1) T + j, (r,c) = divmod(flat, T+1);    p: (T, C)
+//            bd[i,j] = c == 0 ? 0 : (q_r + v) . p[c-1]         (r in {i, i+1})
+//   plain  : bd = 0 (u = v = 0): standard scaled dot-product attention (BERT)
+//   masked keys (j >= len_b) get probability 0; masked query rows output 0.
+//
+// One wave owns one query row: lanes run over keys j for the scores (q+u, q+v in
+// LDS, broadcast reads; k/p rows streamed with 8/16-byte loads out of L2), a
+// shuffle max/sum softmax, then lanes run over 4-channel vectors for P.V.
+#include "ptpp_common.h"
+
+namespace {
+
+enum { VAR_NEW = 0, VAR_LEGACY = 1, VAR_PLAIN = 2 };
+
+struct AttnP {
+  const void *q, *k, *v, *pos;
+  const float *bias_u, *bias_v;
+  void* ctx;
+  float* probs;
+  const int* lengths;
+  int B, T, H, dk, ld, ldpos, ldctx, variant;
+  float scale;
+};
+
+template <typename T>
+__device__ __forceinline__ float dot_row(const float* __restrict__ a, const T* __restrict__ row, int dk) {
+  float s = 0.f;
+  for (int d = 0; d < dk; d += 4) {
+    const f32x4 r = Elem<T>::ld4(row + d);
+    const f32x4 av = *reinterpret_cast<const f32x4*>(a + d);
+    s += av[0] * r[0] + av[1] * r[1] + av[2] * r[2] + av[3] * r[3];
+  }
+  return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+  const int Tn = p.T, dk = p.dk;
+  const int Tpad = (Tn + 3) & ~3;  // keep every per-wave LDS region 16-byte aligned
+  float* qu = lds + w * (3 * dk + Tpad);
+  float* qv = qu + dk;
+  float* qv2 = qv + dk;
+  float* sc = qv2 + dk;
+  if (i >= Tn) return;
+  const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
+  const int hc = h * dk;
+  const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + hc;
+  const T* kb = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + hc;
+  const T* vb = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + hc;
+  const T* pb = p.pos ? reinterpret_cast<const T*>(p.pos) + hc : nullptr;
+  T* ob = reinterpret_cast<T*>(p.ctx) + ((int64_t)b * Tn + i) * p.ldctx + hc;
+  float* prow = p.probs ? p.probs + (((int64_t)b * p.H + h) * Tn + i) * Tn : nullptr;
+
+  if (i >= len) {  // padded query: probabilities are all zeroed by the mask
+    for (int d = lane * 4; d < dk; d += 256) Elem<T>::st4(ob + d, f32x4{0.f, 0.f, 0.f, 0.f});
+    if (prow) for (int j = lane; j < Tn; j += 64) prow[j] = 0.f;
+    return;
+  }
+  for (int d = lane * 4; d < dk; d += 256) {
+    const f32x4 qi = Elem<T>::ld4(qb + (int64_t)i * p.ld + d);
+    f32x4 bu = f32x4{0.f, 0.f, 0.f, 0.f}, bv = bu;
+    if (p.variant != VAR_PLAIN) {
+      bu = *reinterpret_cast<const f32x4*>(p.bias_u + hc + d);
+      bv = *reinterpret_cast<const f32x4*>(p.bias_v + hc + d);
+    }
+    *reinterpret_cast<f32x4*>(qu + d) = qi + bu;
+    *reinterpret_cast<f32x4*>(qv + d) = qi + bv;
+    if (p.variant == VAR_LEGACY) {
+      f32x4 qn = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i + 1 < Tn) qn = Elem<T>::ld4(qb + (int64_t)(i + 1) * p.ld + d) + bv;
+      *reinterpret_cast<f32x4*>(qv2 + d) = qn;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible
+
+  float mx = -3.0e38f;
+  for (int j = lane; j < len; j += 64) {
+    float s = dot_row<T>(qu, kb + (int64_t)j * p.ld, dk);
+    if (p.variant == VAR_NEW) {
+      s += dot_row<T>(qv, pb + (int64_t)(Tn - 1 - i + j) * p.ldpos, dk);
+    } else if (p.variant == VAR_LEGACY) {
+      const int flat = (i + 1) * Tn + j;
+      const int r = flat / (Tn + 1), c = flat - r * (Tn + 1);
+      if (c != 0) s += dot_row<T>(r == i ? qv : qv2, pb + (int64_t)(c - 1) * p.ldpos, dk);
+    }
+    s *= p.scale;
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int j = lane; j < len; j += 64) {
+    const float e = __expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  for (int j = lane; j < Tn; j += 64) {
+    const float pr = j < len ? sc[j] * inv : 0.f;
+    if (j < len) sc[j] = pr;
+    if (prow) prow[j] = pr;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+
+  // ctx[d] = sum_j P[j] V[j][d]: lanes = (key part) x (4-channel vector)
+  const int nvec = dk >> 2;            // vectors per head (<= 64)
+  const int parts = 64 / nvec;         // power of two for dk in {64, 128, 256}
+  const int dv = (lane % nvec) * 4, part = lane / nvec;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (part < parts)
+    for (int j = part; j < len; j += parts) acc += Elem<T>::ld4(vb + (int64_t)j * p.ld + dv) * sc[j];
+  for (int o = nvec; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (lane < nvec) Elem<T>::st4(ob + dv, acc);
+}
+
+// ---- backward, kernel 1: per query row -> dS row, dq, du, dv ------------------
+struct AttnBwdP {
+  const void *q, *k, *v, *pos, *dctx;
+  const float *bias_u, *bias_v, *probs;
+  float* dS;       // (B,H,T,T)
+  void* dq;        // (B,T,*) with stride lddq
+  float *du, *dvb; // (H*dk) accumulators
+  const int* lengths;
+  int B, T, H, dk, ld, ldpos, lddctx, lddq, variant;
+  float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+  const int Tn = p.T, dk = p.dk;
+  const int Tpad = (Tn + 3) & ~3;
+  float* go = lds + w * (dk + Tpad);  // dctx_i
+  float* ds = go + dk;
+  if (i >= Tn) return;
+  const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
+  const int hc = h * dk;
+  const T* kb = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + hc;
+  const T* vb = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + hc;
+  const T* pb = p.pos ? reinterpret_cast<const T*>(p.pos) + hc : nullptr;
+  const T* gb = reinterpret_cast<const T*>(p.dctx) + ((int64_t)b * Tn + i) * p.lddctx + hc;
+  T* dqr = reinterpret_cast<T*>(p.dq) + ((int64_t)b * Tn + i) * p.lddq + hc;
+  const float* prow = p.probs + (((int64_t)b * p.H + h) * Tn + i) * Tn;
+  float* dsrow = p.dS + (((int64_t)b * p.H + h) * Tn + i) * Tn;
+  if (i >= len) {
+    for (int d = lane * 4; d < dk; d += 256) Elem<T>::st4(dqr + d, f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int j = lane; j < Tn; j += 64) dsrow[j] = 0.f;
+    return;
+  }
+  for (int d = lane * 4; d < dk; d += 256) *reinterpret_cast<f32x4*>(go + d) = Elem<T>::ld4(gb + d);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  float dsum = 0.f;
+  for (int j = lane; j < len; j += 64) {
+    const float dp = dot_row<T>(go, vb + (int64_t)j * p.ld, dk);
+    ds[j] = dp;
+    dsum += prow[j] * dp;
+  }
+  dsum = wave_sum(dsum);
+  for (int j = lane; j < Tn; j += 64) {
+    const float v = j < len ? prow[j] * (ds[j] - dsum) * p.scale : 0.f;
+    if (j < len) ds[j] = v;
+    dsrow[j] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  const int nvec = dk >> 2, parts = 64 / nvec;
+  const int dv = (lane % nvec) * 4, part = lane / nvec;
+  f32x4 au = f32x4{0.f, 0.f, 0.f, 0.f}, av = au;
+  if (part < parts)
+    for (int j = part; j < len; j += parts) {
+      au += Elem<T>::ld4(kb + (int64_t)j * p.ld + dv) * ds[j];
+      if (p.variant == VAR_NEW) av += Elem<T>::ld4(pb + (int64_t)(Tn - 1 - i + j) * p.ldpos + dv) * ds[j];
+    }
+  for (int o = nvec; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      au[e] += __shfl_xor(au[e], o, 64);
+      av[e] += __shfl_xor(av[e], o, 64);
+    }
+  }
+  if (lane < nvec) {
+    Elem<T>::st4(dqr + dv, au + av);
+    if (p.variant == VAR_NEW) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(p.du + hc + dv + e, au[e]);
+        atomicAdd(p.dvb + hc + dv + e, av[e]);
+      }
+    }
+  }
+}
+
+// ---- backward, kernel 2: per key row -> dK, dV --------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_col_kernel(const AttnBwdP p, void* dk_out, void* dv_out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+  const int Tn = p.T, dk = p.dk;
+  if (j >= Tn) return;
+  const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
+  const int hc = h * dk;
+  const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + hc;
+  const T* gb = reinterpret_cast<const T*>(p.dctx) + (int64_t)b * Tn * p.lddctx + hc;
+  const float* pcol = p.probs + ((int64_t)b * p.H + h) * Tn * Tn + j;
+  const float* dcol = p.dS + ((int64_t)b * p.H + h) * Tn * Tn + j;
+  T* dkr = reinterpret_cast<T*>(dk_out) + ((int64_t)b * Tn + j) * p.lddq + hc;
+  T* dvr = reinterpret_cast<T*>(dv_out) + ((int64_t)b * Tn + j) * p.lddq + hc;
+  const int nvec = dk >> 2, parts = 64 / nvec;
+  const int dv = (lane % nvec) * 4, part = lane / nvec;
+  f32x4 ak = f32x4{0.f, 0.f, 0.f, 0.f}, av = ak;
+  if (j < len && part < parts) {
+    f32x4 bu = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.variant != VAR_PLAIN) bu = *reinterpret_cast<const f32x4*>(p.bias_u + hc + dv);
+    for (int i = part; i < len; i += parts) {
+      const float dsv = dcol[(int64_t)i * Tn], pv = pcol[(int64_t)i * Tn];
+      ak += (Elem<T>::ld4(qb + (int64_t)i * p.ld + dv) + bu) * dsv;
+      av += Elem<T>::ld4(gb + (int64_t)i * p.lddctx + dv) * pv;
+    }
+  }
+  for (int o = nvec; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ak[e] += __shfl_xor(ak[e], o, 64);
+      av[e] += __shfl_xor(av[e], o, 64);
+    }
+  }
+  if (lane < nvec) {
+    Elem<T>::st4(dkr + dv, ak);
+    Elem<T>::st4(dvr + dv, av);
+  }
+}
+
+// ---- backward, kernel 3 ("new" variant): gradient of the projected positional
+// table, summed over the batch: dpos[m] = sum_{b,i} dS[b,h,i,j=m-(T-1)+i] (q_i + v)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_pos_kernel(const AttnBwdP p, float* dpos) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + w, h = blockIdx.y;
+  const int Tn = p.T, dk = p.dk, L = 2 * Tn - 1;
+  if (m >= L) return;
+  const int hc = h * dk;
+  const int nvec = dk >> 2, parts = 64 / nvec;
+  const int dv = (lane % nvec) * 4, part = lane / nvec;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias_v + hc + dv);
+  const int ilo = max(0, Tn - 1 - m), ihi = min(Tn - 1, 2 * Tn - 2 - m);  // 0 <= j = m-(T-1)+i < T
+  if (part < parts)
+    for (int b = 0; b < p.B; ++b) {
+      const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
+      const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + hc;
+      const float* dsb = p.dS + ((int64_t)b * p.H + h) * Tn * Tn;
+      for (int i = ilo + part; i <= ihi && i < len; i += parts) {
+        const int j = m - (Tn - 1) + i;
+        acc += (Elem<T>::ld4(qb + (int64_t)i * p.ld + dv) + bv) * dsb[(int64_t)i * Tn + j];
+      }
+    }
+  for (int o = nvec; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (lane < nvec) *reinterpret_cast<f32x4*>(dpos + (int64_t)m * (p.H * dk) + hc + dv) = acc;
+}
+
+bool shape_ok(int B, int T, int H, int dk) {
+  return B > 0 && T > 0 && T <= 2048 && H > 0 && (dk == 64 || dk == 128 || dk == 256);
+}
+
+}  // namespace
+
+extern "C" int ptpp_attention_fwd(const void* q, const void* k, const void* v, const void* pos, const float* bias_u,
+                                  const float* bias_v, void* ctx, float* probs, const int32_t* lengths, int B, int T_,
+                                  int H, int dk, int ld, int ldpos, int ldctx, int variant, int dtype, void* stream) {
+  PTPP_CHECK_ARG(q && k && v && ctx, "attention_fwd: null pointer");
+  PTPP_CHECK_ARG(shape_ok(B, T_, H, dk), "attention_fwd: unsupported shape B=%d T=%d H=%d dk=%d", B, T_, H, dk);
+  PTPP_CHECK_ARG(variant >= 0 && variant <= 2, "attention_fwd: bad variant");
+  PTPP_CHECK_ARG(variant == VAR_PLAIN || (pos && bias_u && bias_v), "attention_fwd: rel-pos variant needs pos/u/v");
+  PTPP_CHECK_ARG(ld % 4 == 0 && ldctx % 4 == 0 && (variant == VAR_PLAIN || ldpos % 4 == 0), "attention_fwd: strides");
+  AttnP p{q, k, v, pos, bias_u, bias_v, ctx, probs, lengths, B, T_, H, dk, ld, ldpos, ldctx, variant,
+          1.0f / sqrtf((float)dk)};
+  const size_t smem = (size_t)4 * (3 * dk + ((T_ + 3) & ~3)) * sizeof(float);
+  dim3 grid((T_ + 3) / 4, H, B);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PTPP_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), smem, st, p);
+  else if (dtype == PTPP_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_raw>, grid, dim3(256), smem, st, p);
+  else PTPP_CHECK_ARG(false, "attention_fwd: bad dtype");
+  PTPP_CHECK_LAUNCH("attention_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, const void* pos, const float* bias_u,
+                                  const float* bias_v, const float* probs, const void* dctx, float* dS, void* dq,
+                                  void* dk_out, void* dv_out, float* dpos, float* du, float* dvb,
+                                  const int32_t* lengths, int B, int T_, int H, int dk, int ld, int ldpos, int lddctx,
+                                  int lddq, int variant, int dtype, void* stream) {
+  PTPP_CHECK_ARG(q && k && v && probs && dctx && dS && dq && dk_out && dv_out, "attention_bwd: null pointer");
+  PTPP_CHECK_ARG(shape_ok(B, T_, H, dk), "attention_bwd: unsupported shape");
+  PTPP_CHECK_ARG(variant == VAR_NEW || variant == VAR_PLAIN,
+                 "attention_bwd: only the 'new' rel-pos and plain variants are trainable (legacy is inference-only)");
+  PTPP_CHECK_ARG(variant == VAR_PLAIN || (pos && bias_u && bias_v && dpos && du && dvb), "attention_bwd: rel-pos args");
+  AttnBwdP p{q, k, v, pos, dctx, bias_u, bias_v, probs, dS, dq, du, dvb, lengths, B, T_, H, dk, ld, ldpos, lddctx,
+             lddq, variant, 1.0f / sqrtf((float)dk)};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((T_ + 3) / 4, H, B);
+  const size_t smem = (size_t)4 * (dk + ((T_ + 3) & ~3)) * sizeof(float);
+#define ATTN_BWD(TT)                                                                                  \
+  hipLaunchKernelGGL(attn_bwd_row_kernel<TT>, grid, dim3(256), smem, st, p);                          \
+  hipLaunchKernelGGL(attn_bwd_col_kernel<TT>, grid, dim3(256), 0, st, p, dk_out, dv_out);             \
+  if (variant == VAR_NEW)                                                                             \
+    hipLaunchKernelGGL(attn_bwd_pos_kernel<TT>, dim3((2 * T_ - 1 + 3) / 4, H), dim3(256), 0, st, p, dpos);
+  if (dtype == PTPP_F32) { ATTN_BWD(float) }
+  else if (dtype == PTPP_BF16) { ATTN_BWD(bf16_raw) }
+  else PTPP_CHECK_ARG(false, "attention_bwd: bad dtype");
+#undef ATTN_BWD
+  PTPP_CHECK_LAUNCH("attention_bwd");
+  return PTPP_OK;
+}

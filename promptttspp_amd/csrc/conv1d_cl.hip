@@ -67,6 +67,9 @@ struct ConvP {
   int act, in_mask, out_mask;
   float out_scale, res_scale;
   int nMT, nNT;
+  unsigned drop_thresh16;  // 0 = no dropout
+  float drop_inv_keep;
+  unsigned long long drop_seed;
 };
 
 template <typename T, int NCH, int WM, int FM, int FN>
@@ -201,6 +204,9 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvP p) {
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = keep ? act_apply(v[e], p.act) * p.out_scale : 0.f;
+        if (p.drop_thresh16)
+          v *= drop_mask4(p.drop_seed, (uint64_t)(((int64_t)b * p.T + t) * p.Cout + co) >> 2, p.drop_thresh16,
+                          p.drop_inv_keep);
         if (rb) v += Elem<T>::ld4(rb + (int64_t)t * p.ldr + co) * p.res_scale;
         if (r2b) v += Elem<T>::ld4(r2b + (int64_t)t * p.ldr2 + co);
         Elem<T>::st4(yb + (int64_t)t * p.ldy + co, v);
@@ -263,7 +269,7 @@ extern "C" int ptpp_conv_cin_padded(int cin, int dtype) {
 
 // Extended argument block (adds the second residual of the AMP-block mean).
 extern "C" int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, int ldr2, float res_scale,
-                                  void* stream) {
+                                  float drop_p, uint64_t drop_seed, void* stream) {
   PTPP_CHECK_ARG(a && a->x && a->wp && a->y, "conv1d: null pointer");
   PTPP_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "conv1d: bad dtype %d", a->dtype);
   const int kc = a->dtype == PTPP_BF16 ? 8 : 4;
@@ -288,6 +294,11 @@ extern "C" int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, i
   p.cinp = ptpp_conv_cin_padded(a->Cin, a->dtype);
   p.act = a->act; p.in_mask = a->in_mask; p.out_mask = a->out_mask;
   p.out_scale = a->out_scale; p.res_scale = res_scale;
+  PTPP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "conv1d: bad dropout p");
+  PTPP_CHECK_ARG(drop_p == 0.f || (a->Cout & 3) == 0, "conv1d: dropout needs Cout %% 4 == 0");
+  p.drop_thresh16 = drop_p > 0.f ? (unsigned)(drop_p * 65536.f + 0.5f) : 0u;
+  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - p.drop_thresh16 / 65536.f) : 1.f;
+  p.drop_seed = drop_seed;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool wide = (p.cinp % (8 * kc)) == 0;
   if (a->dtype == PTPP_F32)
@@ -296,5 +307,5 @@ extern "C" int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, i
 }
 
 extern "C" int ptpp_conv1d_fwd(const ptpp_conv1d_args* a, void* stream) {
-  return ptpp_conv1d_fwd_ex(a, nullptr, 0, 1.0f, stream);
+  return ptpp_conv1d_fwd_ex(a, nullptr, 0, 1.0f, 0.f, 0, stream);
 }

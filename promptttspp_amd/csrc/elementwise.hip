@@ -1,0 +1,321 @@
+// Fused elementwise / gather / segment kernels of the acoustic model (HBM-bound).
+// All tensors are channels-last (B, T, C) contiguous, C % 4 == 0, processed as
+// 4-wide vectors (8 B bf16 / 16 B f32 per lane).
+#include "ptpp_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// ---------------------------------------------------------------------------
+// backward of the conv epilogue: dz = dy * out_scale * [t < len] * relu'(y) * dropmask
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void epilogue_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dz,
+                                    const int* __restrict__ lengths, int Tlen, int C, int64_t nvec, float scale,
+                                    int relu, int out_mask, uint32_t thresh16, float inv_keep, uint64_t seed) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cv;
+    f32x4 g = Elem<T>::ld4(dy + i * 4) * scale;
+    if (out_mask) {
+      const int b = (int)(row / Tlen), t = (int)(row % Tlen);
+      if (t >= lengths[b]) g = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (relu) {
+      const f32x4 yv = Elem<T>::ld4(y + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] * inv_keep : 0.f;  // y > 0 implies "kept"
+    } else if (thresh16) {
+      g *= drop_mask4(seed, (uint64_t)i, thresh16, inv_keep);
+    }
+    Elem<T>::st4(dz + i * 4, g);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// y = drop(x * scale + pe[t, :])   (positional encodings, modules/embedding.py:91,
+// esp/transformer/embedding.py:255,326); pe is (T, C) f32 or NULL
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void posenc_kernel(const T* __restrict__ x, const float* __restrict__ pe, T* __restrict__ y, int Tlen, int C,
+                              int64_t nvec, float scale, uint32_t thresh16, float inv_keep, uint64_t seed) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cv;
+    const int c = (int)(i % cv) * 4, t = (int)(row % Tlen);
+    f32x4 v = Elem<T>::ld4(x + i * 4) * scale;
+    if (pe) v += *reinterpret_cast<const f32x4*>(pe + (int64_t)t * C + c);
+    if (thresh16) v *= drop_mask4(seed, (uint64_t)i, thresh16, inv_keep);
+    Elem<T>::st4(y + i * 4, v);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// WaveNet gate (modules/denoiser.py:76-77): g = sigmoid(a[:, :C]) * tanh(a[:, C:])
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void gate_fwd_kernel(const T* __restrict__ a, T* __restrict__ g, int C, int64_t nvec) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cv;
+    const int c = (int)(i % cv) * 4;
+    const f32x4 s = Elem<T>::ld4(a + row * 2 * C + c), f = Elem<T>::ld4(a + row * 2 * C + C + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = sigmoidf_(s[e]) * tanhf(f[e]);
+    Elem<T>::st4(g + i * 4, o);
+  }
+}
+
+template <typename T>
+__global__ void gate_bwd_kernel(const T* __restrict__ a, const T* __restrict__ dg, T* __restrict__ da, int C,
+                                int ldda, int64_t nvec) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cv;
+    const int c = (int)(i % cv) * 4;
+    const f32x4 s = Elem<T>::ld4(a + row * 2 * C + c), f = Elem<T>::ld4(a + row * 2 * C + C + c);
+    const f32x4 d = Elem<T>::ld4(dg + i * 4);
+    f32x4 ds, df;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float sg = sigmoidf_(s[e]), th = tanhf(f[e]);
+      ds[e] = d[e] * th * sg * (1.f - sg);
+      df[e] = d[e] * sg * (1.f - th * th);
+    }
+    Elem<T>::st4(da + row * ldda + c, ds);
+    Elem<T>::st4(da + row * ldda + C + c, df);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// DiffNet residual/skip update (modules/denoiser.py:79-83, 136-140):
+//   xn   = o ? (x + o[:, :C]) / sqrt(2) : x
+//   skip = (init ? 0 : skip) + o[:, C:]            (f32 accumulator)
+//   yin  = xn + dnext[b, :]                        (input of the next dilated conv)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void diffnet_post_kernel(const T* __restrict__ o, const T* __restrict__ x, float* __restrict__ skip,
+                                    const float* __restrict__ dnext, T* __restrict__ xn, T* __restrict__ yin, int Tlen,
+                                    int C, int64_t nvec, int init) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cv;
+    const int c = (int)(i % cv) * 4;
+    f32x4 v = Elem<T>::ld4(x + i * 4);
+    if (o) {
+      v = (v + Elem<T>::ld4(o + row * 2 * C + c)) * 0.70710678118654752f;
+      f32x4 s = Elem<T>::ld4(o + row * 2 * C + C + c);
+      if (!init) s += *reinterpret_cast<const f32x4*>(skip + i * 4);
+      *reinterpret_cast<f32x4*>(skip + i * 4) = s;
+      Elem<T>::st4(xn + i * 4, v);
+    }
+    if (yin) {
+      const int b = (int)(row / Tlen);
+      Elem<T>::st4(yin + i * 4, v + *reinterpret_cast<const f32x4*>(dnext + (int64_t)b * C + c));
+    }
+  }
+}
+
+// backward: do[:, :C] = gx / sqrt(2), do[:, C:] = gskip   (masked rows -> 0)
+template <typename T>
+__global__ void diffnet_post_bwd_kernel(const T* __restrict__ gx, const T* __restrict__ gskip, T* __restrict__ dout,
+                                        const int* __restrict__ lengths, int Tlen, int C, int64_t nvec) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cv;
+    const int c = (int)(i % cv) * 4;
+    f32x4 a = Elem<T>::ld4(gx + i * 4) * 0.70710678118654752f, s = Elem<T>::ld4(gskip + i * 4);
+    if (lengths) {
+      const int b = (int)(row / Tlen), t = (int)(row % Tlen);
+      if (t >= lengths[b]) a = s = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    Elem<T>::st4(dout + row * 2 * C + c, a);
+    Elem<T>::st4(dout + row * 2 * C + C + c, s);
+  }
+}
+
+// per-utterance column sums: out[b, c] = sum_t x[b, t, c]   (f32)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_batch_kernel(const T* __restrict__ x, float* __restrict__ out, int Tlen,
+                                                           int C) {
+  const int b = blockIdx.y;
+  const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int w = threadIdx.x >> 6;
+  __shared__ f32x4 red[4][64];
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (int t = w; t < Tlen; t += 4) acc += Elem<T>::ld4(x + ((int64_t)b * Tlen + t) * C + c);
+  red[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const f32x4 s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    *reinterpret_cast<f32x4*>(out + (int64_t)b * C + c) = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// length regulator as a gather (utils/model.py:37-47 + variance_adaptor.py:129-131
+// compute x @ path with a dense 0/1 path): frame f of utterance b copies phone
+// p(f) = #{p : cum[b,p] <= f}, cum = inclusive cumsum of the integer durations.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void length_regulate_fwd_kernel(const T* __restrict__ x, const int* __restrict__ cum,
+                                                                  T* __restrict__ y, int Tp, int Tf, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t fr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (fr >= Tf) return;
+  const int* cb = cum + (int64_t)b * Tp;
+  int lo = 0, hi = Tp;  // first p with cum[p] > f
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cb[mid] > (int)fr) hi = mid; else lo = mid + 1;
+  }
+  T* yr = y + ((int64_t)b * Tf + fr) * C;
+  const T* xr = x + ((int64_t)b * Tp + lo) * C;
+  for (int c = lane * 4; c < C; c += 256) {
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (lo < Tp) v = Elem<T>::ld4(xr + c);
+    Elem<T>::st4(yr + c, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void length_regulate_bwd_kernel(const T* __restrict__ dy, const int* __restrict__ cum,
+                                                                  T* __restrict__ dx, int Tp, int Tf, int C) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (p >= Tp) return;
+  const int* cb = cum + (int64_t)b * Tp;
+  const int f0 = p ? cb[p - 1] : 0, f1 = min(cb[p], Tf);
+  for (int c = lane * 4; c < C; c += 256) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = f0; f < f1; ++f) acc += Elem<T>::ld4(dy + ((int64_t)b * Tf + f) * C + c);
+    Elem<T>::st4(dx + ((int64_t)b * Tp + p) * C + c, acc);
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+inline uint32_t thresh_of(float p) { return p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u; }
+inline float inv_keep_of(float p) { return p > 0.f ? 1.f / (1.f - thresh_of(p) / 65536.f) : 1.f; }
+
+}  // namespace
+
+#define DISPATCH_T(dtype, name, ...)                         \
+  if (dtype == PTPP_F32) { using T = float; __VA_ARGS__; }   \
+  else if (dtype == PTPP_BF16) { using T = bf16_raw; __VA_ARGS__; } \
+  else { ptpp_set_error("%s: bad dtype %d", name, dtype); return PTPP_EINVAL; }
+
+extern "C" int ptpp_epilogue_bwd(const void* dy, const void* y, void* dz, const int32_t* lengths, int B, int T_, int C,
+                                 float scale, int relu, int out_mask, float drop_p, uint64_t seed, int dtype,
+                                 void* stream) {
+  PTPP_CHECK_ARG(dy && dz && B > 0 && T_ > 0 && C > 0 && C % 4 == 0, "epilogue_bwd: bad args");
+  PTPP_CHECK_ARG(!relu || y, "epilogue_bwd: relu needs y");
+  PTPP_CHECK_ARG(!out_mask || lengths, "epilogue_bwd: out_mask needs lengths");
+  const int64_t nvec = (int64_t)B * T_ * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "epilogue_bwd",
+             hipLaunchKernelGGL(epilogue_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)dy,
+                                (const T*)y, (T*)dz, lengths, T_, C, nvec, scale, relu, out_mask, thresh_of(drop_p),
+                                inv_keep_of(drop_p), seed));
+  PTPP_CHECK_LAUNCH("epilogue_bwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_posenc_fwd(const void* x, const float* pe, void* y, int B, int T_, int C, float scale, float drop_p,
+                               uint64_t seed, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && y && B > 0 && T_ > 0 && C > 0 && C % 4 == 0, "posenc_fwd: bad args");
+  const int64_t nvec = (int64_t)B * T_ * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "posenc_fwd",
+             hipLaunchKernelGGL(posenc_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)x, pe, (T*)y, T_, C,
+                                nvec, scale, thresh_of(drop_p), inv_keep_of(drop_p), seed));
+  PTPP_CHECK_LAUNCH("posenc_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_gate_fwd(const void* a, void* g, int64_t rows, int C, int dtype, void* stream) {
+  PTPP_CHECK_ARG(a && g && rows > 0 && C > 0 && C % 4 == 0, "gate_fwd: bad args");
+  const int64_t nvec = rows * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "gate_fwd",
+             hipLaunchKernelGGL(gate_fwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)a, (T*)g, C, nvec));
+  PTPP_CHECK_LAUNCH("gate_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_gate_bwd(const void* a, const void* dg, void* da, int64_t rows, int C, int ldda, int dtype,
+                             void* stream) {
+  PTPP_CHECK_ARG(a && dg && da && rows > 0 && C > 0 && C % 4 == 0 && ldda % 4 == 0 && ldda >= 2 * C, "gate_bwd: bad args");
+  const int64_t nvec = rows * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "gate_bwd",
+             hipLaunchKernelGGL(gate_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)a, (const T*)dg,
+                                (T*)da, C, ldda, nvec));
+  PTPP_CHECK_LAUNCH("gate_bwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_diffnet_post_fwd(const void* o, const void* x, float* skip, const float* dnext, void* xn, void* yin,
+                                     int B, int T_, int C, int init, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && B > 0 && T_ > 0 && C > 0 && C % 4 == 0, "diffnet_post_fwd: bad args");
+  PTPP_CHECK_ARG(!o || (skip && xn), "diffnet_post_fwd: o needs skip and xn");
+  PTPP_CHECK_ARG(!yin || dnext, "diffnet_post_fwd: yin needs dnext");
+  const int64_t nvec = (int64_t)B * T_ * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "diffnet_post_fwd",
+             hipLaunchKernelGGL(diffnet_post_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)o, (const T*)x,
+                                skip, dnext, (T*)xn, (T*)yin, T_, C, nvec, init));
+  PTPP_CHECK_LAUNCH("diffnet_post_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_diffnet_post_bwd(const void* gx, const void* gskip, void* dout, const int32_t* lengths, int B, int T_,
+                                     int C, int dtype, void* stream) {
+  PTPP_CHECK_ARG(gx && gskip && dout && B > 0 && T_ > 0 && C > 0 && C % 4 == 0, "diffnet_post_bwd: bad args");
+  const int64_t nvec = (int64_t)B * T_ * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "diffnet_post_bwd",
+             hipLaunchKernelGGL(diffnet_post_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)gx,
+                                (const T*)gskip, (T*)dout, lengths, T_, C, nvec));
+  PTPP_CHECK_LAUNCH("diffnet_post_bwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_colsum_batch(const void* x, float* out, int B, int T_, int C, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && out && B > 0 && T_ > 0 && C > 0 && C % 4 == 0, "colsum_batch: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((C / 4 + 63) / 64, B);
+  DISPATCH_T(dtype, "colsum_batch",
+             hipLaunchKernelGGL(colsum_batch_kernel<T>, grid, dim3(256), 0, st, (const T*)x, out, T_, C));
+  PTPP_CHECK_LAUNCH("colsum_batch");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_length_regulate_fwd(const void* x, const int32_t* cum, void* y, int B, int Tp, int Tf, int C,
+                                        int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && cum && y && B > 0 && Tp > 0 && Tf > 0 && C > 0 && C % 4 == 0, "length_regulate_fwd: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((Tf + 3) / 4, B);
+  DISPATCH_T(dtype, "length_regulate_fwd",
+             hipLaunchKernelGGL(length_regulate_fwd_kernel<T>, grid, dim3(256), 0, st, (const T*)x, cum, (T*)y, Tp, Tf, C));
+  PTPP_CHECK_LAUNCH("length_regulate_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_length_regulate_bwd(const void* dy, const int32_t* cum, void* dx, int B, int Tp, int Tf, int C,
+                                        int dtype, void* stream) {
+  PTPP_CHECK_ARG(dy && cum && dx && B > 0 && Tp > 0 && Tf > 0 && C > 0 && C % 4 == 0, "length_regulate_bwd: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((Tp + 3) / 4, B);
+  DISPATCH_T(dtype, "length_regulate_bwd",
+             hipLaunchKernelGGL(length_regulate_bwd_kernel<T>, grid, dim3(256), 0, st, (const T*)dy, cum, (T*)dx, Tp, Tf, C));
+  PTPP_CHECK_LAUNCH("length_regulate_bwd");
+  return PTPP_OK;
+}

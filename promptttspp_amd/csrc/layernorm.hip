@@ -1,9 +1,27 @@
 // LayerNorm over the channel dimension of channels-last rows (HBM-bound).
 // One 64-lane wave per row: each lane owns 4 consecutive channels per 256-wide
 // slab (8/16-byte vector loads), statistics by wavefront shuffles in f32.
+//
+//   s = drop_in(act_in(x)) + res            (act_in: none | GELU; res optional)
+//   y = drop_out(LN(s) * gamma + beta) * [t < len]
+//
+// covers the plain LayerNorms (esp layer_norm.py, layers/norm.py), the frame
+// prior's  x = LN(x + dropout(gelu(conv(x))))  (frame_prior.py:85-89) and the
+// predictors'  dropout(LN(relu(conv)))*mask  (variance_adaptor.py:31-36).
 #include "ptpp_common.h"
 
 namespace {
+
+struct LnDrop {
+  unsigned in_thresh, out_thresh;
+  float in_inv, out_inv;
+  unsigned long long in_seed, out_seed;
+};
+
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float v) {
+  return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+}
 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
@@ -11,7 +29,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      T* __restrict__ y, T* __restrict__ sum_out,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      const int* __restrict__ lengths, int64_t rows, int Tlen, int C,
-                                                     float eps, int out_mask) {
+                                                     float eps, int out_mask, int act_in, const LnDrop dp) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -23,6 +41,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < C) {
       v[i] = Elem<T>::ld4(x + row * C + c);
+      if (act_in == PTPP_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = gelu_f(v[i][e]);
+      }
+      if (dp.in_thresh) v[i] *= drop_mask4(dp.in_seed, (uint64_t)(row * C + c) >> 2, dp.in_thresh, dp.in_inv);
       if (res) v[i] += Elem<T>::ld4(res + row * C + c);
       if (sum_out) Elem<T>::st4(sum_out + row * C + c, v[i]);
       s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
@@ -60,6 +83,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = keep ? (v[i][e] - mean) * rstd * g[e] + bb[e] : 0.f;
+      if (dp.out_thresh) o *= drop_mask4(dp.out_seed, (uint64_t)(row * C + c) >> 2, dp.out_thresh, dp.out_inv);
       Elem<T>::st4(y + row * C + c, o);
     }
   }
@@ -67,11 +91,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xs,
-                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     const T* __restrict__ z, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     T* __restrict__ dsum, T* __restrict__ dz,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      const int* __restrict__ lengths, int64_t rows, int Tlen, int C,
-                                                     int out_mask) {
+                                                     int out_mask, int act_in, const LnDrop dp) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
@@ -99,6 +124,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (c < C && keep) {
         d[i] = Elem<T>::ld4(dy + row * C + c);
+        if (dp.out_thresh) d[i] *= drop_mask4(dp.out_seed, (uint64_t)(row * C + c) >> 2, dp.out_thresh, dp.out_inv);
         const f32x4 xv = Elem<T>::ld4(xs + row * C + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -119,7 +145,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (d[i][e] * g[i][e] - m1 - xh[i][e] * m2);
-        Elem<T>::st4(dx + row * C + c, o);
+        if (dsum) Elem<T>::st4(dsum + row * C + c, o);
+        if (dz) {
+          if (dp.in_thresh) o *= drop_mask4(dp.in_seed, (uint64_t)(row * C + c) >> 2, dp.in_thresh, dp.in_inv);
+          if (act_in == PTPP_ACT_GELU) {
+            const f32x4 zv = Elem<T>::ld4(z + row * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= gelu_grad(zv[e]);
+          }
+          Elem<T>::st4(dz + row * C + c, o);
+        }
       }
     }
   }
@@ -142,15 +177,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
+LnDrop make_drop(float pin, uint64_t sin_, float pout, uint64_t sout) {
+  LnDrop d;
+  d.in_thresh = pin > 0.f ? (unsigned)(pin * 65536.f + 0.5f) : 0u;
+  d.out_thresh = pout > 0.f ? (unsigned)(pout * 65536.f + 0.5f) : 0u;
+  d.in_inv = pin > 0.f ? 1.f / (1.f - d.in_thresh / 65536.f) : 1.f;
+  d.out_inv = pout > 0.f ? 1.f / (1.f - d.out_thresh / 65536.f) : 1.f;
+  d.in_seed = sin_;
+  d.out_seed = sout;
+  return d;
+}
+
 template <typename T>
 int ln_fwd_dispatch(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* sum_out,
                     float* mean, float* rstd, const int* lengths, int64_t rows, int Tlen, int C, float eps,
-                    int out_mask, hipStream_t st) {
+                    int out_mask, int act_in, const LnDrop& dp, hipStream_t st) {
   const int nv = (C + 255) / 256;
   const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
 #define LN_FWD(NV)                                                                                          \
   hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, blk, 0, st, (const T*)x, (const T*)res, gamma, beta, (T*)y, \
-                     (T*)sum_out, mean, rstd, lengths, rows, Tlen, C, eps, out_mask)
+                     (T*)sum_out, mean, rstd, lengths, rows, Tlen, C, eps, out_mask, act_in, dp)
   switch (nv) {
     case 1: LN_FWD(1); break;
     case 2: LN_FWD(2); break;
@@ -164,16 +210,16 @@ int ln_fwd_dispatch(const void* x, const void* res, const float* gamma, const fl
 }
 
 template <typename T>
-int ln_bwd_dispatch(const void* dy, const void* xs, const float* gamma, const float* mean, const float* rstd, void* dx,
-                    float* dgamma, float* dbeta, const int* lengths, int64_t rows, int Tlen, int C, int out_mask,
-                    hipStream_t st) {
+int ln_bwd_dispatch(const void* dy, const void* xs, const void* z, const float* gamma, const float* mean,
+                    const float* rstd, void* dsum, void* dz, float* dgamma, float* dbeta, const int* lengths,
+                    int64_t rows, int Tlen, int C, int out_mask, int act_in, const LnDrop& dp, hipStream_t st) {
   const int nv = (C + 255) / 256;
   int64_t nb = (rows + 3) / 4;
   if (nb > 1024) nb = 1024;
   const dim3 grid((unsigned)nb), blk(256);
-#define LN_BWD(NV)                                                                                             \
-  hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, blk, 0, st, (const T*)dy, (const T*)xs, gamma, mean, rstd, (T*)dx, \
-                     dgamma, dbeta, lengths, rows, Tlen, C, out_mask)
+#define LN_BWD(NV)                                                                                              \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, blk, 0, st, (const T*)dy, (const T*)xs, (const T*)z, gamma, mean, \
+                     rstd, (T*)dsum, (T*)dz, dgamma, dbeta, lengths, rows, Tlen, C, out_mask, act_in, dp)
   switch (nv) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -190,32 +236,41 @@ int ln_bwd_dispatch(const void* dy, const void* xs, const float* gamma, const fl
 
 extern "C" int ptpp_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y,
                                   void* sum_out, float* mean, float* rstd, const int32_t* lengths, int B, int T, int C,
-                                  float eps, int out_mask, int dtype, void* stream) {
+                                  float eps, int out_mask, int act_in, float drop_in_p, uint64_t drop_in_seed,
+                                  float drop_out_p, uint64_t drop_out_seed, int dtype, void* stream) {
   PTPP_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null pointer");
   PTPP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0, "layernorm_fwd: bad shape B=%d T=%d C=%d", B, T, C);
   PTPP_CHECK_ARG(!out_mask || lengths, "layernorm_fwd: out_mask needs lengths");
+  PTPP_CHECK_ARG(act_in == PTPP_ACT_NONE || act_in == PTPP_ACT_GELU, "layernorm_fwd: act_in must be none or gelu");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t rows = (int64_t)B * T;
+  const LnDrop dp = make_drop(drop_in_p, drop_in_seed, drop_out_p, drop_out_seed);
   if (dtype == PTPP_F32)
-    return ln_fwd_dispatch<float>(x, res, gamma, beta, y, sum_out, mean, rstd, lengths, rows, T, C, eps, out_mask, st);
+    return ln_fwd_dispatch<float>(x, res, gamma, beta, y, sum_out, mean, rstd, lengths, rows, T, C, eps, out_mask,
+                                  act_in, dp, st);
   if (dtype == PTPP_BF16)
     return ln_fwd_dispatch<bf16_raw>(x, res, gamma, beta, y, sum_out, mean, rstd, lengths, rows, T, C, eps, out_mask,
-                                     st);
+                                     act_in, dp, st);
   PTPP_CHECK_ARG(false, "layernorm_fwd: bad dtype %d", dtype);
 }
 
-extern "C" int ptpp_layernorm_bwd(const void* dy, const void* xsum, const float* gamma, const float* mean,
-                                  const float* rstd, void* dx, float* dgamma, float* dbeta, const int32_t* lengths,
-                                  int B, int T, int C, int out_mask, int dtype, void* stream) {
-  PTPP_CHECK_ARG(dy && xsum && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+extern "C" int ptpp_layernorm_bwd(const void* dy, const void* xsum, const void* z, const float* gamma,
+                                  const float* mean, const float* rstd, void* dsum, void* dz, float* dgamma,
+                                  float* dbeta, const int32_t* lengths, int B, int T, int C, int out_mask, int act_in,
+                                  float drop_in_p, uint64_t drop_in_seed, float drop_out_p, uint64_t drop_out_seed,
+                                  int dtype, void* stream) {
+  PTPP_CHECK_ARG(dy && xsum && gamma && mean && rstd && (dsum || dz), "layernorm_bwd: null pointer");
   PTPP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0, "layernorm_bwd: bad shape");
   PTPP_CHECK_ARG(!out_mask || lengths, "layernorm_bwd: out_mask needs lengths");
+  PTPP_CHECK_ARG(act_in == PTPP_ACT_NONE || (act_in == PTPP_ACT_GELU && z && dz), "layernorm_bwd: gelu needs z and dz");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t rows = (int64_t)B * T;
+  const LnDrop dp = make_drop(drop_in_p, drop_in_seed, drop_out_p, drop_out_seed);
   if (dtype == PTPP_F32)
-    return ln_bwd_dispatch<float>(dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, lengths, rows, T, C, out_mask, st);
+    return ln_bwd_dispatch<float>(dy, xsum, z, gamma, mean, rstd, dsum, dz, dgamma, dbeta, lengths, rows, T, C,
+                                  out_mask, act_in, dp, st);
   if (dtype == PTPP_BF16)
-    return ln_bwd_dispatch<bf16_raw>(dy, xsum, gamma, mean, rstd, dx, dgamma, dbeta, lengths, rows, T, C, out_mask,
-                                     st);
+    return ln_bwd_dispatch<bf16_raw>(dy, xsum, z, gamma, mean, rstd, dsum, dz, dgamma, dbeta, lengths, rows, T, C,
+                                     out_mask, act_in, dp, st);
   PTPP_CHECK_ARG(false, "layernorm_bwd: bad dtype %d", dtype);
 }

@@ -121,3 +121,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + slot;
 }
+
+// ---- counter-based dropout ---------------------------------------------------
+// One 64-bit splitmix hash of (seed, vector index) yields four 16-bit lanes, one
+// per element of a 4-wide vector: element e of vector v is KEPT iff
+// bits16(e) >= thresh16, thresh16 = round(p * 65536).  The same (seed, index)
+// regenerates the mask in the backward pass, so no mask tensor is stored.
+__device__ __forceinline__ uint64_t drop_hash(uint64_t seed, uint64_t vec_idx) {
+  uint64_t z = seed + (vec_idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ f32x4 drop_mask4(uint64_t seed, uint64_t vec_idx, uint32_t thresh16, float inv_keep) {
+  const uint64_t h = drop_hash(seed, vec_idx);
+  f32x4 m;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m[e] = ((uint32_t)(h >> (16 * e)) & 0xffffu) >= thresh16 ? inv_keep : 0.f;
+  return m;
+}

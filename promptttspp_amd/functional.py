@@ -1,0 +1,332 @@
+"""Differentiable ops of the hot path: ``torch.autograd.Function`` wrappers whose
+forward AND backward are hand-written HIP kernels (promptttspp_amd/csrc) called
+through the C ABI.  All activations are channels-last (B, T, C) in the compute
+dtype; parameters stay f32 (master weights) and are packed/cast per version.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+# ----------------------------------------------------------------------------
+# dropout seeds: every dropout site of every forward draws a fresh counter value;
+# the (p, seed) pair is all the backward needs to regenerate the mask.
+# ----------------------------------------------------------------------------
+_seed_state = {"base": None, "ctr": 0}
+
+
+def manual_seed(seed):
+    _seed_state["base"] = int(seed) & 0xFFFFFFFF
+    _seed_state["ctr"] = 0
+
+
+def next_seed():
+    if _seed_state["base"] is None:
+        _seed_state["base"] = torch.initial_seed() & 0xFFFFFFFF
+    _seed_state["ctr"] += 1
+    return ((_seed_state["base"] << 32) ^ (_seed_state["ctr"] * 0x9E3779B1)) & 0xFFFFFFFFFFFFFFFF
+
+
+# ----------------------------------------------------------------------------
+# packed-weight cache (per parameter version)
+# ----------------------------------------------------------------------------
+_pack_cache = {}
+
+
+def packed(w, dtype, mode=0):
+    """Packed K-contiguous operand of weight ``w`` (f32, (Cout,Cin[,ks]))."""
+    if not isinstance(w, torch.nn.Parameter):
+        return ops.pack_conv_weight(w, dtype, mode)
+    key = (id(w), mode, dtype)
+    ent = _pack_cache.get(key)
+    if ent is not None and ent[0] == w._version and ent[1] == w.data_ptr():
+        return ent[2]
+    wp = ops.pack_conv_weight(w, dtype, mode)
+    _pack_cache[key] = (w._version, w.data_ptr(), wp)
+    return wp
+
+
+def clear_caches():
+    _pack_cache.clear()
+
+
+def _f32c(t):
+    return None if t is None else t.detach().float().contiguous()
+
+
+def _kc(dtype):
+    """elements per 16-byte MFMA operand chunk"""
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def conv_cfg(ks=1, dil=1, pad=0, act=None, lengths=None, in_mask=False, out_mask=False, out_scale=1.0, drop_p=0.0):
+    assert act in (None, "none", "relu"), "training-capable conv epilogues: none | relu"
+    return SimpleNamespace(ks=ks, dil=dil, pad=pad, act=act, lengths=lengths, in_mask=in_mask, out_mask=out_mask,
+                           out_scale=out_scale, drop_p=drop_p)
+
+
+class Conv1dFn(Function):
+    """y = res + out_scale * drop(mask(act(conv(x_masked) + b)))  (channels-last)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, cfg):
+        w3 = w if w.dim() == 3 else w.unsqueeze(-1)
+        cout, cin, ks = w3.shape
+        assert ks == cfg.ks and cin == x.shape[-1]
+        seed = next_seed() if cfg.drop_p > 0 else 0
+        kc = _kc(x.dtype)
+        xk, wk = x, w
+        if cin % kc:  # tiny channel counts: zero-pad K to the 16-byte operand granule
+            xk = torch.nn.functional.pad(x, (0, kc - cin % kc))
+            wk = torch.nn.functional.pad(w3.detach(), (0, 0, 0, kc - cin % kc))
+        y = ops.conv1d(xk, packed(wk, x.dtype), _f32c(b), cout, ks=ks, dil=cfg.dil, pad=cfg.pad, act=cfg.act,
+                       lengths=cfg.lengths, in_mask=cfg.in_mask, out_mask=cfg.out_mask, res=res,
+                       out_scale=cfg.out_scale, drop_p=cfg.drop_p, drop_seed=seed)
+        ctx.cfg, ctx.seed, ctx.has_res, ctx.has_b = cfg, seed, res is not None, b is not None
+        ctx.save_for_backward(x, w, y if cfg.act == "relu" else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        cfg = ctx.cfg
+        w3 = w if w.dim() == 3 else w.unsqueeze(-1)
+        cout, cin, ks = w3.shape
+        relu = cfg.act == "relu"
+        dy = dy.contiguous()
+        if relu or cfg.out_mask or cfg.out_scale != 1.0 or cfg.drop_p > 0:
+            dz = ops.epilogue_bwd(dy, y, cfg.lengths, cfg.out_scale, relu, cfg.out_mask, cfg.drop_p, ctx.seed)
+        else:
+            dz = dy
+        dx = dw = db = None
+        kc = _kc(dz.dtype)
+        wk, coutp = w, cout
+        if cout % kc:  # e.g. the 2-channel pitch head: pad the gradient rows to the operand granule
+            coutp = cout + kc - cout % kc
+            dz = torch.nn.functional.pad(dz, (0, coutp - cout))
+            wk = torch.nn.functional.pad(w3.detach(), (0, 0, 0, 0, 0, coutp - cout))
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv1d(dz, packed(wk, dz.dtype, mode=1), None, cin, ks=ks, dil=cfg.dil,
+                            pad=(ks - 1) * cfg.dil - cfg.pad, lengths=cfg.lengths, out_mask=cfg.in_mask)
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            xk = x if cin % 4 == 0 else torch.nn.functional.pad(x, (0, 4 - cin % 4))
+            dw, db = ops.conv1d_wgrad(xk, dz, cin, coutp, ks, cfg.dil, cfg.pad, cfg.lengths, cfg.in_mask, ctx.has_b)
+            dw = dw[:cout].reshape(w.shape)
+            db = db[:cout] if db is not None else None
+        return dx, dw, db, (dy if ctx.has_res else None), None
+
+
+def conv1d(x, w, b=None, res=None, **kw):
+    return Conv1dFn.apply(x, w, b, res, conv_cfg(**kw))
+
+
+def linear(x, w, b=None, **kw):
+    """nn.Linear on the last dim of a (B, T, Cin) or (N, Cin) tensor."""
+    if x.dim() == 2:
+        return Conv1dFn.apply(x.unsqueeze(0), w, b, None, conv_cfg(**kw)).squeeze(0)
+    return Conv1dFn.apply(x, w, b, None, conv_cfg(**kw))
+
+
+# ----------------------------------------------------------------------------
+class LayerNormFn(Function):
+    """y = drop_out(LN(drop_in(act_in(x)) + res) * gamma + beta) * mask."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, cfg):
+        x = x.contiguous()
+        fused_in = res is not None or cfg.act_in is not None or cfg.drop_in > 0
+        s_in = (cfg.drop_in, next_seed()) if cfg.drop_in > 0 else (0.0, 0)
+        s_out = (cfg.drop_out, next_seed()) if cfg.drop_out > 0 else (0.0, 0)
+        g, b = _f32c(gamma).reshape(-1), _f32c(beta).reshape(-1)
+        y, mean, rstd, xsum = ops.layernorm_fwd(x, g, b, cfg.eps, res=res, lengths=cfg.lengths, out_mask=cfg.out_mask,
+                                                save_stats=True, save_sum=fused_in, act_in=cfg.act_in, drop_in=s_in,
+                                                drop_out=s_out)
+        ctx.cfg, ctx.s_in, ctx.s_out, ctx.has_res, ctx.fused_in = cfg, s_in, s_out, res is not None, fused_in
+        ctx.gshape = gamma.shape
+        ctx.save_for_backward(x, xsum if fused_in else None, g, mean, rstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, xsum, g, mean, rstd = ctx.saved_tensors
+        cfg = ctx.cfg
+        want_dz = cfg.act_in is not None or cfg.drop_in > 0
+        dsum, dz, dg, db = ops.layernorm_bwd(dy, xsum if ctx.fused_in else x, g, mean, rstd, cfg.lengths, cfg.out_mask,
+                                             z=x if cfg.act_in is not None else None, act_in=cfg.act_in,
+                                             drop_in=ctx.s_in, drop_out=ctx.s_out, want_dz=want_dz)
+        return (dz if want_dz else dsum), (dsum if ctx.has_res else None), dg.view(ctx.gshape), db.view(ctx.gshape), None
+
+
+def layer_norm(x, gamma, beta, eps, res=None, lengths=None, out_mask=False, act_in=None, drop_in=0.0, drop_out=0.0):
+    cfg = SimpleNamespace(eps=eps, lengths=lengths, out_mask=out_mask, act_in=act_in, drop_in=drop_in, drop_out=drop_out)
+    return LayerNormFn.apply(x, res, gamma, beta, cfg)
+
+
+# ----------------------------------------------------------------------------
+class AttentionFn(Function):
+    """Relative-position MHA core on a fused (B, T, 3C) q|k|v projection."""
+
+    @staticmethod
+    def forward(ctx, qkv, pos, bias_u, bias_v, lengths, heads, variant):
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        q, k, v = qkv[:, :, :C], qkv[:, :, C : 2 * C], qkv[:, :, 2 * C :]
+        u, vb = _f32c(bias_u), _f32c(bias_v)
+        need_bwd = any(ctx.needs_input_grad)
+        octx, probs = ops.attention_fwd(q, k, v, pos, u, vb, lengths, heads, variant, save_probs=need_bwd)
+        ctx.heads, ctx.variant, ctx.lengths = heads, variant, lengths
+        ctx.ushape = bias_u.shape if bias_u is not None else None
+        ctx.save_for_backward(qkv, pos, u, vb, probs)
+        return octx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dctx):
+        qkv, pos, u, vb, probs = ctx.saved_tensors
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        dqkv = torch.empty_like(qkv)
+        dpos, du, dvb = ops.attention_bwd(qkv[:, :, :C], qkv[:, :, C : 2 * C], qkv[:, :, 2 * C :], pos, u, vb, probs,
+                                          dctx, ctx.lengths, ctx.heads, ctx.variant, dqkv[:, :, :C],
+                                          dqkv[:, :, C : 2 * C], dqkv[:, :, 2 * C :])
+        if dpos is not None:
+            dpos = dpos.to(pos.dtype)
+            du, dvb = du.view(ctx.ushape), dvb.view(ctx.ushape)
+        return dqkv, dpos, du, dvb, None, None, None
+
+
+def attention(qkv, pos, bias_u, bias_v, lengths, heads, variant):
+    return AttentionFn.apply(qkv, pos, bias_u, bias_v, lengths, heads, variant)
+
+
+# ----------------------------------------------------------------------------
+class LengthRegulateFn(Function):
+    @staticmethod
+    def forward(ctx, x, cum, Tf):
+        ctx.cum, ctx.Tp = cum, x.shape[1]
+        return ops.length_regulate_fwd(x.contiguous(), cum, Tf)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return ops.length_regulate_bwd(dy, ctx.cum, ctx.Tp), None, None
+
+
+def length_regulate(x, durations, Tf):
+    """x: (B, Tp, C); durations: (B, Tp) integer-valued (float or int) frames per
+    phone -> (B, Tf, C), frame f copying its phone (rows past the total are 0)."""
+    cum = torch.cumsum(durations.to(torch.int64), dim=1).clamp_(max=2**31 - 1).to(torch.int32).contiguous()
+    return LengthRegulateFn.apply(x, cum, int(Tf))
+
+
+class PosEncFn(Function):
+    @staticmethod
+    def forward(ctx, x, pe, scale, drop_p):
+        ctx.scale, ctx.p = scale, drop_p
+        ctx.seed = next_seed() if drop_p > 0 else 0
+        return ops.posenc(x.contiguous(), pe, scale, drop_p, ctx.seed)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return ops.epilogue_bwd(dy, None, None, ctx.scale, False, False, ctx.p, ctx.seed), None, None, None
+
+
+def posenc(x, pe, scale, drop_p=0.0):
+    return PosEncFn.apply(x, pe, scale, drop_p)
+
+
+# ----------------------------------------------------------------------------
+# DiffNet residual stack (modules/denoiser.py:69-83,136-140) with a hand-written
+# backward: per layer  conv(k3,dilated, +cond slice) -> gate -> 1x1 conv -> post.
+# ----------------------------------------------------------------------------
+def diffnet_cond_all(cond, cond_ws, cond_bs):
+    """All layers' conditioner projections as ONE GEMM: (B,T,Cc) -> (B,T,L*2C)."""
+    w = torch.cat([cw.reshape(cw.shape[0], -1) for cw in cond_ws], dim=0)
+    b = torch.cat(list(cond_bs), dim=0)
+    return ops.conv1d(cond, ops.pack_conv_weight(w, cond.dtype), _f32c(b), w.shape[0]), w
+
+
+def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
+    """weights: per layer (dil_w, dil_b, out_w, out_b).  Returns (skip_sum f32, saved)."""
+    L = len(weights)
+    B, T, C = h0.shape
+    skip = torch.empty((B, T, C), device=h0.device, dtype=torch.float32)
+    x = h0
+    _, yin = ops.diffnet_post_fwd(None, h0, None, dsteps[:, 0].contiguous(), init=True)
+    saved = []
+    for l, (dw, db, ow, ob) in enumerate(weights):
+        d = 2 ** (l % cycle)
+        a = ops.conv1d(yin, packed(dw, h0.dtype), _f32c(db), 2 * C, ks=3, dil=d, pad=d,
+                       res=cond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
+        g = ops.gate_fwd(a)
+        o = ops.conv1d(g, packed(ow, h0.dtype), _f32c(ob), 2 * C, lengths=lengths, out_mask=lengths is not None)
+        if save:
+            saved.append((yin, a, g))
+        nxt = dsteps[:, l + 1].contiguous() if l + 1 < L else None
+        x, yin = ops.diffnet_post_fwd(o, x, skip, nxt, init=(l == 0))
+    return skip, saved
+
+
+class DiffNetStackFn(Function):
+    @staticmethod
+    def forward(ctx, h0, cond, dsteps, lengths, cycle, *flat):
+        L = len(flat) // 6
+        ws = [flat[6 * l : 6 * l + 6] for l in range(L)]  # dil_w, dil_b, cond_w, cond_b, out_w, out_b
+        cond_all, wc = diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws])
+        skip, saved = diffnet_stack_forward(h0, cond_all, dsteps, [(w[0], w[1], w[4], w[5]) for w in ws], lengths,
+                                            cycle, save=True)
+        ctx.L, ctx.cycle, ctx.lengths, ctx.saved, ctx.ws, ctx.wc = L, cycle, lengths, saved, ws, wc
+        ctx.save_for_backward(cond)
+        return (skip * (1.0 / math.sqrt(L))).to(h0.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (cond,) = ctx.saved_tensors
+        L, ws = ctx.L, ctx.ws
+        B, T, C = gout.shape
+        dt = gout.dtype
+        gS = (gout.float() * (1.0 / math.sqrt(L))).to(dt).contiguous()
+        gx = torch.zeros_like(gS)
+        sx = torch.zeros((B, C), device=gout.device, dtype=torch.float32)
+        dcond_all = torch.empty((B, T, L * 2 * C), device=gout.device, dtype=dt)
+        dd = torch.empty((B, L, C), device=gout.device, dtype=torch.float32)
+        grads = [None] * (6 * L)
+        r2 = 1.0 / math.sqrt(2.0)
+        for l in reversed(range(L)):
+            yin, a, g = ctx.saved[l]
+            dil_w, _, _, _, out_w, _ = ws[l]
+            d = 2 ** (l % ctx.cycle)
+            do = ops.diffnet_post_bwd(gx, gS, ctx.lengths)
+            dwo, dbo = ops.conv1d_wgrad(g, do, C, 2 * C, 1, 1, 0)
+            dg = ops.conv1d(do, packed(out_w, dt, mode=1), None, C)
+            da = ops.gate_bwd(a, dg, dcond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
+            dwd, dbd = ops.conv1d_wgrad(yin, da, C, 2 * C, 3, d, d)
+            gx = ops.conv1d(da, packed(dil_w, dt, mode=1), None, C, ks=3, dil=d, pad=d, res=gx, res_scale=r2)
+            sn = ops.colsum_batch(gx)
+            dd[:, l] = sn - sx * r2
+            sx = sn
+            grads[6 * l + 0], grads[6 * l + 1] = dwd.view_as(dil_w), dbd
+            grads[6 * l + 4], grads[6 * l + 5] = dwo.view_as(out_w), dbo
+            ctx.saved[l] = None
+        dcond = None
+        if ctx.needs_input_grad[1]:
+            dcond = ops.conv1d(dcond_all, ops.pack_conv_weight(ctx.wc, dt, mode=1), None, cond.shape[-1])
+        dwc, dbc = ops.conv1d_wgrad(cond, dcond_all, cond.shape[-1], L * 2 * C, 1, 1, 0)
+        for l in range(L):
+            grads[6 * l + 2] = dwc[l * 2 * C : (l + 1) * 2 * C].view_as(ws[l][2])
+            grads[6 * l + 3] = dbc[l * 2 * C : (l + 1) * 2 * C]
+        return (gx, dcond, dd, None, None, *grads)
+
+
+def diffnet_stack(h0, cond, dsteps, lengths, cycle, layer_params):
+    """layer_params: list of (dil_w, dil_b, cond_w, cond_b, out_w, out_b)."""
+    flat = [t for lp in layer_params for t in lp]
+    return DiffNetStackFn.apply(h0, cond, dsteps, lengths, cycle, *flat)

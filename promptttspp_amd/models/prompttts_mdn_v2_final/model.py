@@ -1,0 +1,167 @@
+"""PromptTTS++ acoustic model on the MI355X HIP path (reference:
+promptttspp/models/prompttts_mdn_v2_final/model.py:28-344).
+
+Same class name, constructor, methods (``forward`` / ``infer`` / ``infer_batch`` /
+``sample_style_emb`` / ``generate_style_emb``), loss-dict keys and state-dict
+layout as the reference, so ``hydra.utils.instantiate(cfg.model)`` and reference
+checkpoints work unchanged.  Internally every per-phone / per-frame tensor is
+channels-last (B, T, C) in the compute dtype and masks are int32 lengths; the
+(B, C, T) layout only exists at the public method boundary.
+
+Deliberate deviations from the reference's side effects (results identical):
+* ``forward`` does not mutate the caller's ``duration`` tensor (the reference's
+  ``to_log_scale`` does);
+* the prompt may be ``List[str]`` or pre-tokenised ``(input_ids, attention_mask)``.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...config import compute_dtype
+from ...modules.diffusion import GaussianDiffusion
+from ...modules.esp import ConformerEncoder
+from ...modules.mdn import mdn_get_most_probable_sigma_and_mu, mdn_loss, mdn_sample_sigma_and_mu
+from ...utils.model import sequence_mask
+
+
+class PromptTTSMDNDurCFG(nn.Module):
+    def __init__(self, phoneme_embedding, encoder, variance_adaptor, reference_encoder, prompt_encoder, decoder,
+                 out_conv=None, style_mdn=None, norm_style_emb=False, mdn_disable_amp=False, loss_dec_scale=8.0):
+        super().__init__()
+        self.phoneme_emb = phoneme_embedding
+        self.encoder = encoder
+        self.variance_adaptor = variance_adaptor
+        self.reference_encoder = reference_encoder
+        self.prompt_encoder = prompt_encoder
+        self.style_mdn = style_mdn
+        self.decoder = decoder
+        self.out_conv = out_conv
+        self.norm_style_emb = norm_style_emb
+        self.mdn_disable_amp = mdn_disable_amp
+        self.loss_dec_scale = loss_dec_scale
+        if not isinstance(encoder, ConformerEncoder) or not isinstance(decoder, GaussianDiffusion):
+            raise NotImplementedError(
+                "promptttspp_amd implements the encoder=ConformerEncoder / decoder=GaussianDiffusion(DiffNet) "
+                "configuration of prompttts_mdn_v2_wo_erg_final.yaml")
+        assert self.variance_adaptor.frame_prior_network is not None
+
+    # ---------------------------------------------------------------------------------
+    def _encode(self, phoneme, phone_lengths):
+        """ids (B,Tp) -> encoder output (B,Tp,C) channels-last + masks."""
+        dt = compute_dtype()
+        Tp = phoneme.shape[-1]
+        plen = phone_lengths.to(device=phoneme.device, dtype=torch.int32)
+        pmask = (torch.arange(Tp, device=phoneme.device)[None, :] < plen[:, None])  # (B,Tp) bool
+        pm1 = pmask.unsqueeze(-1).float()
+        x = self.phoneme_emb.forward_cl(phoneme, pm1, dt)
+        x = self.encoder.forward_cl(x.contiguous(), plen, pm1)
+        return x, plen, pmask
+
+    def _norm_style(self, e):
+        return F.normalize(e, dim=1) if self.norm_style_emb else e
+
+    def forward(self, batch):
+        (phoneme, duration, phone_lengths, mel, log_cf0, vuv, energy, frame_lengths, prompt) = batch
+        dev = phoneme.device
+        dt = compute_dtype()
+        x, plen, pmask = self._encode(phoneme, phone_lengths)
+
+        Tf = mel.shape[-1]
+        flen = frame_lengths.to(device=dev, dtype=torch.int32)
+        fmask = (torch.arange(Tf, device=dev)[None, :] < flen[:, None])  # (B,Tf)
+        fm1 = fmask.unsqueeze(-1).float()
+        n_frames = fm1.sum()
+
+        style_emb = self._norm_style(self.reference_encoder(mel, frame_lengths))  # (B,C,1) f32
+        prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
+        if self.style_mdn is not None:
+            style_mdn_out = self.style_mdn(prompt_emb.transpose(-1, -2))
+        x = x + style_emb.transpose(1, 2).to(dt)  # broadcast over every phone, padded ones too (model.py:111)
+
+        h, dur_out, cf0_pred, vuv_pred, energy_pred = self.variance_adaptor.forward_cl(
+            x, plen, flen, fm1, duration.squeeze(1), log_cf0.squeeze(1),
+            None if self.variance_adaptor.energy_emb is None else energy.squeeze(1))
+
+        mel_cl = mel.transpose(1, 2).float().contiguous()
+        noise, pred = self.decoder.forward_cl(h, mel_cl, flen)
+        loss_dec = ((noise - pred) * fm1).abs().sum() / n_frames / self.loss_dec_scale
+
+        dur = duration.squeeze(1).float()
+        log_dur = torch.where(dur != 0, torch.log(dur.clamp_min(1e-30)), dur)  # to_log_scale, out of place
+        pmb = pmask.unsqueeze(-1)
+        loss_dur = mdn_loss(*dur_out, log_dur.unsqueeze(-1), reduce=False, mask=pmb).masked_select(pmb).mean()
+
+        loss_cf0 = (cf0_pred - log_cf0.squeeze(1)).abs().sum() / n_frames
+        loss_vuv = (vuv_pred - vuv.squeeze(1)).abs().sum() / n_frames
+        if self.style_mdn is not None:
+            loss_style = mdn_loss(*style_mdn_out, style_emb.detach().transpose(-1, -2)).mean()
+        else:
+            loss_style = (style_emb.detach() - prompt_emb).pow(2).mean()
+
+        loss = loss_dec + loss_dur + loss_cf0 + loss_vuv + loss_style
+        out = dict(loss=loss, dec=loss_dec, dur=loss_dur, cf0=loss_cf0, vuv=loss_vuv, style=loss_style)
+        if energy_pred is not None:
+            loss_energy = (energy_pred - energy.squeeze(1)).abs().sum() / n_frames
+            out["loss"] = loss + loss_energy
+            out["energy"] = loss_energy
+        return out
+
+    # ---------------------------------------------------------------------------------
+    def sample_style_emb(self, log_pi, log_sigma, mu, noise_scale, use_max):
+        if use_max:
+            sigma, mu = mdn_get_most_probable_sigma_and_mu(log_pi, log_sigma, mu)
+        else:
+            sigma, mu = mdn_sample_sigma_and_mu(log_pi, log_sigma, mu)
+        style_emb = mu + sigma * torch.randn_like(sigma) * noise_scale
+        if self.norm_style_emb:
+            style_emb = F.normalize(style_emb, dim=-1)
+        return style_emb.transpose(-1, -2)
+
+    def _style(self, style_prompt, reference_mel, ref_lengths, device, use_max, noise_scale):
+        assert (style_prompt is not None) ^ (reference_mel is not None), "One of style inputs must not be None."
+        if style_prompt is not None:
+            emb = self._norm_style(self.prompt_encoder(style_prompt, device))
+            if self.style_mdn is not None:
+                emb = self.sample_style_emb(*self.style_mdn(emb.transpose(-1, -2)), noise_scale=noise_scale,
+                                            use_max=use_max)
+            return emb
+        return self._norm_style(self.reference_encoder(reference_mel, ref_lengths))
+
+    @torch.no_grad()
+    def _synthesize(self, phoneme, phone_lengths, style_emb, zero_padded_durations, noise_fn=None):
+        x, plen, pmask = self._encode(phoneme, phone_lengths)
+        x = x + style_emb.transpose(1, 2).to(x.dtype)
+        h, flen, fm1, cf0, vuv, dur = self.variance_adaptor.infer_cl(x, plen, pmask if zero_padded_durations else None)
+        mel = self.decoder.inference_cl(h, noise_fn) * fm1  # (B,Tf,80) f32
+        self.last_durations = dur
+        return mel.transpose(1, 2).contiguous(), cf0.unsqueeze(1), vuv.unsqueeze(1), flen
+
+    @torch.no_grad()
+    def infer(self, x, style_prompt=None, reference_mel=None, use_max=True, noise_scale=1.0, return_f0=False,
+              noise_fn=None):
+        """x: (1, L) phoneme ids -> mel (1, 80, Tf) [, log_cf0, vuv]."""
+        lengths = torch.full((x.shape[0],), x.shape[-1], device=x.device, dtype=torch.long)
+        ref_len = None if reference_mel is None else torch.LongTensor([reference_mel.shape[-1]])
+        style = self._style(style_prompt, reference_mel, ref_len, x.device, use_max, noise_scale)
+        mel, cf0, vuv, _ = self._synthesize(x, lengths, style, False, noise_fn)
+        return (mel, cf0, vuv) if return_f0 else mel
+
+    @torch.no_grad()
+    def infer_batch(self, phoneme, phone_lengths, style_prompt=None, reference_mel=None, ref_lengths=None,
+                    use_max=True, noise_scale=1.0, return_f0=False, noise_fn=None):
+        if reference_mel is not None:
+            assert ref_lengths is not None
+        style = self._style(style_prompt, reference_mel, ref_lengths, phoneme.device, use_max, noise_scale)
+        mel, cf0, vuv, flen = self._synthesize(phoneme, phone_lengths, style, True, noise_fn)
+        return (mel, cf0, vuv, flen) if return_f0 else (mel, flen)
+
+    @torch.no_grad()
+    def generate_style_emb(self, style_prompt, reference_mel, use_max=True, noise_scale=1.0):
+        prompt_emb = self._norm_style(self.prompt_encoder(style_prompt, reference_mel.device))
+        if self.style_mdn is not None:
+            prompt_emb = self.sample_style_emb(*self.style_mdn(prompt_emb.transpose(-1, -2)), noise_scale=noise_scale,
+                                               use_max=use_max)
+        prompt_emb = self._norm_style(prompt_emb)
+        ref_emb = self._norm_style(self.reference_encoder(reference_mel, torch.LongTensor([reference_mel.shape[-1]])))
+        return prompt_emb, ref_emb

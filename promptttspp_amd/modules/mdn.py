@@ -1,0 +1,86 @@
+"""Mixture-density heads and losses (reference: promptttspp/modules/mdn.py:37-257).
+
+The heads are three Linear layers fused into ONE f32 MFMA GEMM launch
+(``mdn_disable_amp``: the MDN island is always float32).  The loss algebra acts
+on (B, T, G, D) tensors with G*D <= 2560 per row -- a few kB per utterance -- and
+is expressed with torch tensor ops in f32 (no kernel of its own: it is far off
+the roofline-relevant path)."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as PF
+
+
+class MDNLayer(nn.Module):
+    def __init__(self, in_dim, out_dim, num_gaussians=30, dim_wise=False):
+        super().__init__()
+        self.in_dim, self.out_dim, self.num_gaussians, self.dim_wise = in_dim, out_dim, num_gaussians, dim_wise
+        self.log_pi = nn.Linear(in_dim, out_dim * num_gaussians if dim_wise else num_gaussians)
+        self.log_sigma = nn.Linear(in_dim, out_dim * num_gaussians)
+        self.mu = nn.Linear(in_dim, out_dim * num_gaussians)
+
+    def forward(self, minibatch):
+        """(B, T, D_in) -> log_pi (B,T,G[,D]), log_sigma (B,T,G,D), mu (B,T,G,D); f32."""
+        x = minibatch.float().contiguous()
+        B, T, _ = x.shape
+        G, D = self.num_gaussians, self.out_dim
+        w = torch.cat([self.log_pi.weight, self.log_sigma.weight, self.mu.weight], dim=0)
+        b = torch.cat([self.log_pi.bias, self.log_sigma.bias, self.mu.bias], dim=0)
+        y = PF.linear(x, w, b)
+        n_pi = self.log_pi.weight.shape[0]
+        log_pi, log_sigma, mu = y[..., :n_pi], y[..., n_pi : n_pi + G * D], y[..., n_pi + G * D :]
+        if self.dim_wise:
+            log_pi = F.log_softmax(log_pi.reshape(B, T, G, D), dim=2)
+        else:
+            log_pi = F.log_softmax(log_pi, dim=2)
+        return log_pi, log_sigma.reshape(B, T, G, D), mu.reshape(B, T, G, D)
+
+
+def mdn_loss(log_pi, log_sigma, mu, target, log_pi_min=-7.0, log_sigma_min=-7.0, reduce=True, mask=None):
+    """Negative log-likelihood of `target` (B,T,D) under the mixture: clamp log_sigma
+    / log_pi from below, clamp the centred target to +-5 sigma, Gaussian log-density
+    + log weight, -logsumexp over components (mdn.py:81-175)."""
+    dim_wise = log_pi.dim() == 4
+    log_sigma = log_sigma.clamp(min=log_sigma_min)
+    log_pi = log_pi.clamp(min=log_pi_min)
+    sigma = torch.exp(log_sigma)
+    d = target.unsqueeze(2) - mu
+    d = torch.maximum(torch.minimum(d, 5 * sigma), -5 * sigma)
+    log_prob = -0.5 * (d / sigma) ** 2 - log_sigma - 0.5 * math.log(2 * math.pi)
+    if dim_wise:
+        ll = log_prob + log_pi
+    else:
+        ll = log_prob.sum(dim=3) + log_pi
+    if mask is not None:
+        m = ~mask.unsqueeze(-1) if ll.dim() == 4 else ~mask
+        ll = ll.masked_fill(m.expand_as(ll), -float("inf"))
+    loss = -torch.logsumexp(ll, dim=2)
+    return loss.mean(dim=1) if reduce else loss
+
+
+def _select(log_pi, log_sigma, mu, idx):
+    """gather the chosen component per (b,t[,d])"""
+    if log_pi.dim() == 4:
+        idx = idx.unsqueeze(2)  # (B,T,1,D)
+    else:
+        idx = idx[:, :, None, None].expand(-1, -1, 1, mu.shape[3])
+    return torch.exp(log_sigma.gather(2, idx).squeeze(2)), mu.gather(2, idx).squeeze(2)
+
+
+def mdn_get_most_probable_sigma_and_mu(log_pi, log_sigma, mu):
+    """(sigma, mu) of the largest-weight component (mdn.py:178-223); the arg-max
+    index is the integer the parity tests pin bit-exactly."""
+    return _select(log_pi, log_sigma, mu, log_pi.argmax(dim=2))
+
+
+def mdn_sample_sigma_and_mu(log_pi, log_sigma, mu):
+    """(sigma, mu) of a component drawn from the mixture weights (mdn.py:226-257)."""
+    if log_pi.dim() == 4:
+        probs = log_pi.exp().permute(0, 1, 3, 2)  # (B,T,D,G)
+    else:
+        probs = log_pi.exp()
+    idx = torch.distributions.Categorical(probs=probs).sample()
+    return _select(log_pi, log_sigma, mu, idx)

@@ -1,8 +1,9 @@
-"""Thin torch-tensor wrappers over the C ABI (include/ptpp.h).
+"""Thin torch-tensor wrappers over the C ABI (include/ptpp.h) -- no autograd here
+(see functional.py).
 
-Every function here launches hand-written HIP kernels from libptpp_hip.so on
-torch's current stream.  Tensors must live on a ROCm device; nothing here has a
-CPU implementation (the CPU restatement lives in ``oracle/`` and is test-only).
+Every function launches hand-written HIP kernels from libptpp_hip.so on torch's
+current stream.  Tensors must live on a ROCm device; nothing here has a CPU
+implementation (the CPU restatement lives in ``oracle/`` and is test-only).
 
 Layout: activations are channels-last ``(B, T, C)`` contiguous tensors in the
 compute dtype (torch.float32 or torch.bfloat16).
@@ -12,17 +13,10 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, BF16, F32, ConvArgs, check
+from ._lib import BF16, F32, ConvArgs, check
 
-_ACT = {
-    None: 0,
-    "none": 0,
-    "relu": 1,
-    "gelu": 2,
-    "swish": 3,
-    "tanh": 4,
-    "mish": 5,
-}
+_ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "swish": 3, "tanh": 4, "mish": 5}
+_VARIANT = {"new": 0, "legacy": 1, "plain": 2}
 
 
 def dtype_code(dt):
@@ -49,12 +43,16 @@ def _need_gpu(t):
         )
 
 
-def _i32(lengths, device):
+def i32(lengths, device):
     if lengths is None:
         return None
     if lengths.dtype != torch.int32 or lengths.device != device:
         lengths = lengths.to(device=device, dtype=torch.int32)
     return lengths.contiguous()
+
+
+def _rows3(x):
+    assert x.dim() == 3 and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1), "expected (B,T,C) rows"
 
 
 # ----------------------------------------------------------------------------
@@ -75,8 +73,7 @@ def pack_conv_weight(w, dtype, mode=0):
     w = w.detach().contiguous().float()
     cout, cin, ks = w.shape
     rows, inner = (cout, cin) if mode == 0 else (cin, cout)
-    innerp = cin_padded(inner, dtype)
-    wp = torch.empty((rows, ks, innerp), device=w.device, dtype=dtype)
+    wp = torch.empty((rows, ks, cin_padded(inner, dtype)), device=w.device, dtype=dtype)
     check(
         _lib.load().ptpp_pack_conv_weight(_ptr(w), _ptr(wp), cout, cin, ks, mode, dtype_code(dtype), _stream()),
         "ptpp_pack_conv_weight",
@@ -87,40 +84,21 @@ def pack_conv_weight(w, dtype, mode=0):
 # ----------------------------------------------------------------------------
 # conv1d / linear
 # ----------------------------------------------------------------------------
-def conv1d(
-    x,
-    wp,
-    bias,
-    cout,
-    ks=1,
-    dil=1,
-    pad=0,
-    act=None,
-    lengths=None,
-    in_mask=False,
-    out_mask=False,
-    res=None,
-    out_scale=1.0,
-    res2=None,
-    res_scale=1.0,
-    out=None,
-):
+def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mask=False, out_mask=False, res=None,
+           out_scale=1.0, res2=None, res_scale=1.0, drop_p=0.0, drop_seed=0, out=None):
     """Channels-last conv / linear with the fused epilogue (see ptpp.h).
-
-    x: (B, T, Cin) ; wp: packed weight from :func:`pack_conv_weight` ;
-    bias: (cout) f32 or None.  Returns y: (B, T, cout) in x.dtype.
-    """
+    x: (B, T, Cin); wp: packed weight; bias: (cout) f32 or None -> (B, T, cout)."""
     _need_gpu(x)
-    assert x.dim() == 3 and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1), "x must be (B,T,C) rows"
+    _rows3(x)
     B, T, cin = x.shape
     y = out if out is not None else torch.empty((B, T, cout), device=x.device, dtype=x.dtype)
-    lengths = _i32(lengths, x.device)
+    lengths = i32(lengths, x.device)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous()
     a = ConvArgs()
-    a.x, a.wp, a.bias, a.res, a.y = x.data_ptr(), wp.data_ptr(), (bias.data_ptr() if bias is not None else None), (
-        res.data_ptr() if res is not None else None
-    ), y.data_ptr()
+    a.x, a.wp, a.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.res = res.data_ptr() if res is not None else None
     a.lengths = lengths.data_ptr() if lengths is not None else None
     a.B, a.T, a.Cin, a.Cout, a.ks, a.dil, a.pad = B, T, cin, cout, ks, dil, pad
     a.ldx, a.ldy = x.stride(1), y.stride(1)
@@ -129,18 +107,16 @@ def conv1d(
     a.in_mask, a.out_mask = int(bool(in_mask)), int(bool(out_mask))
     a.out_scale = float(out_scale)
     a.dtype = dtype_code(x.dtype)
-    if res is not None:
-        assert res.dtype == x.dtype and res.shape == y.shape
-    if res2 is not None:
-        assert res2.dtype == x.dtype and res2.shape == y.shape
+    for r in (res, res2):
+        if r is not None:
+            assert r.dtype == x.dtype and r.shape == y.shape and r.stride(2) == 1
     lib = _lib.load()
-    if res2 is None and res_scale == 1.0:
+    if res2 is None and res_scale == 1.0 and drop_p == 0.0:
         check(lib.ptpp_conv1d_fwd(ctypes.byref(a), _stream()), "ptpp_conv1d_fwd")
     else:
         check(
-            lib.ptpp_conv1d_fwd_ex(
-                ctypes.byref(a), _ptr(res2), res2.stride(1) if res2 is not None else 0, float(res_scale), _stream()
-            ),
+            lib.ptpp_conv1d_fwd_ex(ctypes.byref(a), _ptr(res2), res2.stride(1) if res2 is not None else 0,
+                                   float(res_scale), float(drop_p), int(drop_seed), _stream()),
             "ptpp_conv1d_fwd_ex",
         )
     return y
@@ -152,21 +128,34 @@ def conv1d_wgrad(x, dy, cin, cout, ks, dil, pad, lengths=None, in_mask=False, wa
     B, T, _ = x.shape
     dw = torch.zeros((cout, cin, ks), device=x.device, dtype=torch.float32)
     db = torch.zeros((cout,), device=x.device, dtype=torch.float32) if want_bias else None
-    lengths = _i32(lengths, x.device)
+    lengths = i32(lengths, x.device)
     check(
-        _lib.load().ptpp_conv1d_wgrad(
-            _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(lengths), B, T, cin, cout, ks, dil, pad,
-            x.stride(1), dy.stride(1), int(bool(in_mask)), dtype_code(x.dtype), _stream(),
-        ),
+        _lib.load().ptpp_conv1d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(lengths), B, T, cin, cout, ks, dil,
+                                      pad, x.stride(1), dy.stride(1), int(bool(in_mask)), dtype_code(x.dtype), _stream()),
         "ptpp_conv1d_wgrad",
     )
     return dw, db
 
 
+def epilogue_bwd(dy, y=None, lengths=None, scale=1.0, relu=False, out_mask=False, drop_p=0.0, seed=0):
+    _need_gpu(dy)
+    dy = dy.contiguous()
+    B, T, C = dy.shape
+    dz = torch.empty_like(dy)
+    lengths = i32(lengths, dy.device)
+    check(
+        _lib.load().ptpp_epilogue_bwd(_ptr(dy), _ptr(y), _ptr(dz), _ptr(lengths), B, T, C, float(scale), int(relu),
+                                      int(bool(out_mask)), float(drop_p), int(seed), dtype_code(dy.dtype), _stream()),
+        "ptpp_epilogue_bwd",
+    )
+    return dz
+
+
 # ----------------------------------------------------------------------------
 # layer norm
 # ----------------------------------------------------------------------------
-def layernorm_fwd(x, gamma, beta, eps, res=None, lengths=None, out_mask=False, save_stats=False, save_sum=False):
+def layernorm_fwd(x, gamma, beta, eps, res=None, lengths=None, out_mask=False, save_stats=False, save_sum=False,
+                  act_in=None, drop_in=(0.0, 0), drop_out=(0.0, 0)):
     _need_gpu(x)
     assert x.is_contiguous() and x.dim() == 3
     B, T, C = x.shape
@@ -175,38 +164,168 @@ def layernorm_fwd(x, gamma, beta, eps, res=None, lengths=None, out_mask=False, s
     if save_stats:
         mean = torch.empty((B * T,), device=x.device, dtype=torch.float32)
         rstd = torch.empty((B * T,), device=x.device, dtype=torch.float32)
-    if save_sum and res is not None:
+    if save_sum:
         xsum = torch.empty_like(x)
-    lengths = _i32(lengths, x.device)
+    lengths = i32(lengths, x.device)
     check(
-        _lib.load().ptpp_layernorm_fwd(
-            _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(xsum), _ptr(mean), _ptr(rstd), _ptr(lengths),
-            B, T, C, float(eps), int(bool(out_mask)), dtype_code(x.dtype), _stream(),
-        ),
+        _lib.load().ptpp_layernorm_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(xsum), _ptr(mean),
+                                       _ptr(rstd), _ptr(lengths), B, T, C, float(eps), int(bool(out_mask)), _ACT[act_in],
+                                       float(drop_in[0]), int(drop_in[1]), float(drop_out[0]), int(drop_out[1]),
+                                       dtype_code(x.dtype), _stream()),
         "ptpp_layernorm_fwd",
     )
     return y, mean, rstd, xsum
 
 
-def layernorm_bwd(dy, xsum, gamma, mean, rstd, lengths=None, out_mask=False):
+def layernorm_bwd(dy, xsum, gamma, mean, rstd, lengths=None, out_mask=False, z=None, act_in=None, drop_in=(0.0, 0),
+                  drop_out=(0.0, 0), want_dz=False):
+    """Returns (dsum, dz or None, dgamma, dbeta)."""
     _need_gpu(dy)
+    dy = dy.contiguous()
     B, T, C = dy.shape
-    dx = torch.empty_like(dy)
+    dsum = torch.empty_like(dy)
+    dz = torch.empty_like(dy) if want_dz else None
     dgamma = torch.zeros((C,), device=dy.device, dtype=torch.float32)
     dbeta = torch.zeros((C,), device=dy.device, dtype=torch.float32)
-    lengths = _i32(lengths, dy.device)
+    lengths = i32(lengths, dy.device)
     check(
-        _lib.load().ptpp_layernorm_bwd(
-            _ptr(dy.contiguous()), _ptr(xsum), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dgamma),
-            _ptr(dbeta), _ptr(lengths), B, T, C, int(bool(out_mask)), dtype_code(dy.dtype), _stream(),
-        ),
+        _lib.load().ptpp_layernorm_bwd(_ptr(dy), _ptr(xsum), _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dsum),
+                                       _ptr(dz), _ptr(dgamma), _ptr(dbeta), _ptr(lengths), B, T, C, int(bool(out_mask)),
+                                       _ACT[act_in], float(drop_in[0]), int(drop_in[1]), float(drop_out[0]),
+                                       int(drop_out[1]), dtype_code(dy.dtype), _stream()),
         "ptpp_layernorm_bwd",
     )
-    return dx, dgamma, dbeta
+    return dsum, dz, dgamma, dbeta
 
 
 # ----------------------------------------------------------------------------
-# anti-aliased snake, misc
+# attention
+# ----------------------------------------------------------------------------
+def attention_fwd(q, k, v, pos, bias_u, bias_v, lengths, heads, variant, save_probs=False):
+    """q,k,v: (B,T,C) views with a common row stride (e.g. slices of a fused
+    (B,T,3C) projection); pos: (L, C) or None; returns (ctx (B,T,C), probs)."""
+    _need_gpu(q)
+    B, T, C = q.shape
+    assert k.stride(1) == q.stride(1) == v.stride(1) and q.stride(2) == 1
+    dk = C // heads
+    ctx = torch.empty((B, T, C), device=q.device, dtype=q.dtype)
+    probs = torch.empty((B, heads, T, T), device=q.device, dtype=torch.float32) if save_probs else None
+    lengths = i32(lengths, q.device)
+    check(
+        _lib.load().ptpp_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(pos), _ptr(bias_u), _ptr(bias_v), _ptr(ctx),
+                                       _ptr(probs), _ptr(lengths), B, T, heads, dk, q.stride(1),
+                                       pos.stride(0) if pos is not None else 0, C, _VARIANT[variant],
+                                       dtype_code(q.dtype), _stream()),
+        "ptpp_attention_fwd",
+    )
+    return ctx, probs
+
+
+def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, variant, dq, dk_, dv):
+    """dq/dk_/dv: preallocated (B,T,C) views sharing a row stride (slices of a
+    (B,T,3C) buffer).  Returns (dpos (L,C) f32 or None, du, dvb)."""
+    _need_gpu(q)
+    B, T, C = q.shape
+    dkh = C // heads
+    dctx = dctx.contiguous()
+    dS = torch.empty((B, heads, T, T), device=q.device, dtype=torch.float32)
+    dpos = du = dvb = None
+    if variant == "new":
+        dpos = torch.empty((2 * T - 1, C), device=q.device, dtype=torch.float32)
+        du = torch.zeros((C,), device=q.device, dtype=torch.float32)
+        dvb = torch.zeros((C,), device=q.device, dtype=torch.float32)
+    lengths = i32(lengths, q.device)
+    check(
+        _lib.load().ptpp_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(pos), _ptr(bias_u), _ptr(bias_v), _ptr(probs),
+                                       _ptr(dctx), _ptr(dS), _ptr(dq), _ptr(dk_), _ptr(dv), _ptr(dpos), _ptr(du),
+                                       _ptr(dvb), _ptr(lengths), B, T, heads, dkh, q.stride(1),
+                                       pos.stride(0) if pos is not None else 0, C, dq.stride(1), _VARIANT[variant],
+                                       dtype_code(q.dtype), _stream()),
+        "ptpp_attention_bwd",
+    )
+    return dpos, du, dvb
+
+
+# ----------------------------------------------------------------------------
+# length regulator, positional encoding, DiffNet glue
+# ----------------------------------------------------------------------------
+def length_regulate_fwd(x, cum, Tf):
+    _need_gpu(x)
+    assert x.is_contiguous() and cum.dtype == torch.int32 and cum.is_contiguous()
+    B, Tp, C = x.shape
+    y = torch.empty((B, Tf, C), device=x.device, dtype=x.dtype)
+    check(_lib.load().ptpp_length_regulate_fwd(_ptr(x), _ptr(cum), _ptr(y), B, Tp, Tf, C, dtype_code(x.dtype), _stream()),
+          "ptpp_length_regulate_fwd")
+    return y
+
+
+def length_regulate_bwd(dy, cum, Tp):
+    _need_gpu(dy)
+    dy = dy.contiguous()
+    B, Tf, C = dy.shape
+    dx = torch.empty((B, Tp, C), device=dy.device, dtype=dy.dtype)
+    check(_lib.load().ptpp_length_regulate_bwd(_ptr(dy), _ptr(cum), _ptr(dx), B, Tp, Tf, C, dtype_code(dy.dtype), _stream()),
+          "ptpp_length_regulate_bwd")
+    return dx
+
+
+def posenc(x, pe, scale, drop_p=0.0, seed=0):
+    _need_gpu(x)
+    assert x.is_contiguous()
+    B, T, C = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().ptpp_posenc_fwd(_ptr(x), _ptr(pe), _ptr(y), B, T, C, float(scale), float(drop_p), int(seed),
+                                      dtype_code(x.dtype), _stream()), "ptpp_posenc_fwd")
+    return y
+
+
+def gate_fwd(a):
+    _need_gpu(a)
+    assert a.is_contiguous()
+    B, T, C2 = a.shape
+    g = torch.empty((B, T, C2 // 2), device=a.device, dtype=a.dtype)
+    check(_lib.load().ptpp_gate_fwd(_ptr(a), _ptr(g), B * T, C2 // 2, dtype_code(a.dtype), _stream()), "ptpp_gate_fwd")
+    return g
+
+
+def gate_bwd(a, dg, da):
+    """da: (B,T,2C) view with row stride >= 2C (written in place)."""
+    B, T, C2 = a.shape
+    assert da.stride(2) == 1
+    check(_lib.load().ptpp_gate_bwd(_ptr(a), _ptr(dg.contiguous()), _ptr(da), B * T, C2 // 2, da.stride(1),
+                                    dtype_code(a.dtype), _stream()), "ptpp_gate_bwd")
+    return da
+
+
+def diffnet_post_fwd(o, x, skip, dnext, init, want_yin=True):
+    """Returns (xn, yin)."""
+    B, T, C = x.shape
+    xn = torch.empty_like(x) if o is not None else x
+    yin = torch.empty_like(x) if (want_yin and dnext is not None) else None
+    check(_lib.load().ptpp_diffnet_post_fwd(_ptr(o), _ptr(x), _ptr(skip), _ptr(dnext), _ptr(xn) if o is not None else None,
+                                            _ptr(yin), B, T, C, int(init), dtype_code(x.dtype), _stream()),
+          "ptpp_diffnet_post_fwd")
+    return xn, yin
+
+
+def diffnet_post_bwd(gx, gskip, lengths):
+    B, T, C = gx.shape
+    dout = torch.empty((B, T, 2 * C), device=gx.device, dtype=gx.dtype)
+    lengths = i32(lengths, gx.device)
+    check(_lib.load().ptpp_diffnet_post_bwd(_ptr(gx), _ptr(gskip), _ptr(dout), _ptr(lengths), B, T, C,
+                                            dtype_code(gx.dtype), _stream()), "ptpp_diffnet_post_bwd")
+    return dout
+
+
+def colsum_batch(x):
+    B, T, C = x.shape
+    out = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    check(_lib.load().ptpp_colsum_batch(_ptr(x), _ptr(out), B, T, C, dtype_code(x.dtype), _stream()), "ptpp_colsum_batch")
+    return out
+
+
+# ----------------------------------------------------------------------------
+# anti-aliased snake, vocoder tail, layout bridges
 # ----------------------------------------------------------------------------
 def _taps(filt):
     arr = (ctypes.c_float * 12)()
@@ -218,42 +337,31 @@ def _taps(filt):
 
 
 def aa_snake(x, log_alpha, taps_up, taps_down, out=None):
-    """x: (B,T,C) ; log_alpha: (C) f32 device tensor ; taps_*: ctypes float[12]
-    (see :func:`_taps`)."""
+    """x: (B,T,C); log_alpha: (C) f32 device tensor; taps_*: ctypes float[12]."""
     _need_gpu(x)
     assert x.is_contiguous()
     B, T, C = x.shape
     y = out if out is not None else torch.empty_like(x)
-    check(
-        _lib.load().ptpp_aa_snake_fwd(
-            _ptr(x), _ptr(y), _ptr(log_alpha), taps_up, taps_down, B, T, C, dtype_code(x.dtype), _stream()
-        ),
-        "ptpp_aa_snake_fwd",
-    )
+    check(_lib.load().ptpp_aa_snake_fwd(_ptr(x), _ptr(y), _ptr(log_alpha), taps_up, taps_down, B, T, C,
+                                        dtype_code(x.dtype), _stream()), "ptpp_aa_snake_fwd")
     return y
 
 
 def add3_scale(a, b, c, scale):
     _need_gpu(a)
     y = torch.empty_like(a)
-    check(
-        _lib.load().ptpp_add3_scale(_ptr(a), _ptr(b), _ptr(c), _ptr(y), float(scale), a.numel(), dtype_code(a.dtype), _stream()),
-        "ptpp_add3_scale",
-    )
+    check(_lib.load().ptpp_add3_scale(_ptr(a), _ptr(b), _ptr(c), _ptr(y), float(scale), a.numel(), dtype_code(a.dtype),
+                                      _stream()), "ptpp_add3_scale")
     return y
 
 
 def conv_post_tanh(x, w, bias):
-    """x: (B,T,C) ; w: (ks, C) f32 ; returns (B, T) f32."""
+    """x: (B,T,C); w: (ks, C) f32; returns (B, T) f32."""
     _need_gpu(x)
     B, T, C = x.shape
     y = torch.empty((B, T), device=x.device, dtype=torch.float32)
-    check(
-        _lib.load().ptpp_conv_post_tanh(
-            _ptr(x), _ptr(w), float(bias), _ptr(y), B, T, C, w.shape[0], dtype_code(x.dtype), _stream()
-        ),
-        "ptpp_conv_post_tanh",
-    )
+    check(_lib.load().ptpp_conv_post_tanh(_ptr(x), _ptr(w), float(bias), _ptr(y), B, T, C, w.shape[0],
+                                          dtype_code(x.dtype), _stream()), "ptpp_conv_post_tanh")
     return y
 
 
@@ -270,7 +378,7 @@ def bct_to_btc(x, dtype):
 def btc_to_bct(x):
     """(B, T, C) compute dtype -> (B, C, T) f32."""
     _need_gpu(x)
-    assert x.is_contiguous()
+    x = x.contiguous()
     B, T, C = x.shape
     y = torch.empty((B, C, T), device=x.device, dtype=torch.float32)
     check(_lib.load().ptpp_btc_to_bct(_ptr(x), _ptr(y), B, T, C, dtype_code(x.dtype), _stream()), "ptpp_btc_to_bct")

@@ -1,0 +1,86 @@
+"""FusedAdamW: the trainer's ``clip_grad_norm_(1.0)`` + ``AdamW.step()``
+(reference: promptttspp/trainers/tts.py:206-211, conf/optimizer/adamw.yaml) as two
+HIP launches over ALL parameters with no host synchronisation
+(``ptpp_grad_sumsq`` + ``ptpp_adamw_step``).  Same constructor as
+``torch.optim.AdamW`` (params, lr, betas, eps, weight_decay) plus ``max_grad_norm``;
+LR schedulers keep working through ``param_groups[i]['lr']``."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _ptr, _stream
+
+_BLOCK = 4096  # elements per block, must match adamw.hip (CHUNK)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0):
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.max_grad_norm = float(max_grad_norm)
+        self._tables = {}
+        self._sumsq = None
+        self._lr_dev = {}
+
+    def _table(self, gi, group):
+        """Device pointer table for the group's parameters that have grads."""
+        ps = [p for p in group["params"] if p.grad is not None]
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        ent = self._tables.get(gi)
+        if ent is not None and ent[0] == key:
+            return ent[1], ent[2], ent[3]
+        rows, blk = [], 0
+        for p in ps:
+            assert p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() and p.is_cuda
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["exp_avg"] = torch.zeros_like(p)
+                st["exp_avg_sq"] = torch.zeros_like(p)
+            n = p.numel()
+            rows.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n, blk])
+            blk += (n + _BLOCK - 1) // _BLOCK
+        tab = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(ps[0].device)
+        self._tables[gi] = (key, tab, len(ps), blk)
+        return tab, len(ps), blk
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        lib = _lib.load()
+        live = [(gi, g) for gi, g in enumerate(self.param_groups) if any(p.grad is not None for p in g["params"])]
+        if not live:
+            return loss
+        dev = next(p for p in live[0][1]["params"] if p.grad is not None).device
+        if self._sumsq is None:
+            self._sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        if self.max_grad_norm > 0:
+            # global norm over every group: accumulate group sums into one scalar
+            total = None
+            for gi, g in live:
+                tab, nt, nblk = self._table(gi, g)
+                part = self._sumsq if total is None else torch.zeros_like(self._sumsq)
+                _lib.check(lib.ptpp_grad_sumsq(_ptr(tab), nt, nblk, _ptr(part), _stream()), "ptpp_grad_sumsq")
+                total = part if total is None else total.add_(part)
+            if total is not self._sumsq:
+                self._sumsq.copy_(total)
+        for gi, g in live:
+            tab, nt, nblk = self._table(gi, g)
+            g["step"] = g.get("step", 0) + 1
+            lr_dev = self._lr_dev.get(gi)
+            if lr_dev is None:
+                lr_dev = self._lr_dev[gi] = torch.zeros(1, device=dev, dtype=torch.float32)
+            lr_dev.fill_(float(g["lr"]))
+            b1, b2 = g["betas"]
+            _lib.check(
+                lib.ptpp_adamw_step(_ptr(tab), nt, nblk, _ptr(self._sumsq), _ptr(lr_dev), float(b1), float(b2),
+                                    float(g["eps"]), float(g["weight_decay"]), int(g["step"]), self.max_grad_norm,
+                                    _stream()),
+                "ptpp_adamw_step",
+            )
+        return loss
+
+    def grad_norm(self):
+        """sqrt of the last computed sum of squares (device tensor; no sync)."""
+        return self._sumsq.sqrt() if self._sumsq is not None else None

@@ -138,7 +138,7 @@ def test_layernorm_fwd_bwd(dtype, C, dev):
     y, mean, rstd, xsum = ops.layernorm_fwd(x.to(dev, dtype), g.to(dev), bta.to(dev), 1e-5, res=res.to(dev, dtype),
                                             lengths=lens, out_mask=True, save_stats=True, save_sum=True)
     assert rel_err(y.float().cpu(), ref.detach()) < tol
-    dx, dg, db = ops.layernorm_bwd(dy.to(dev, dtype), xsum, g.to(dev), mean, rstd, lengths=lens, out_mask=True)
+    dx, _, dg, db = ops.layernorm_bwd(dy.to(dev, dtype), xsum, g.to(dev), mean, rstd, lengths=lens, out_mask=True)
     assert rel_err(dx.float().cpu(), dx_ref) < tol
     assert rel_err(dg.cpu(), dg_ref) < (1e-4 if dtype == torch.float32 else BF16_TOL)
     assert rel_err(db.cpu(), db_ref) < (1e-4 if dtype == torch.float32 else BF16_TOL)
@@ -185,3 +185,73 @@ def test_layout_bridges(dev):
     assert torch.equal(ops.btc_to_bct(y).cpu(), x)
     yb = ops.bct_to_btc(x.to(dev), torch.bfloat16)
     assert torch.equal(yb.cpu(), x.transpose(1, 2).bfloat16())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_gelu_residual_mode(dtype, dev):
+    """y = LN(res + gelu(z)) (frame prior) forward/backward vs torch autograd."""
+    from promptttspp_amd import functional as PF
+
+    B, T, C = 2, 33, 256
+    z, res, dy = rnd(1, B, T, C), rnd(2, B, T, C), rnd(3, B, T, C)
+    g, bta = 1.0 + 0.1 * rnd(4, C), 0.1 * rnd(5, C)
+    if dtype == torch.bfloat16:
+        z, res, dy = z.bfloat16().float(), res.bfloat16().float(), dy.bfloat16().float()
+    zr, rr, gr, br = z.clone().requires_grad_(), res.clone().requires_grad_(), g.clone().requires_grad_(), bta.clone().requires_grad_()
+    ref = R.layer_norm_last(rr + F.gelu(zr), gr, br, 1e-5)
+    gz, gres, gg, gb = torch.autograd.grad(ref, (zr, rr, gr, br), dy)
+    zd, rd = z.to(dev, dtype).requires_grad_(), res.to(dev, dtype).requires_grad_()
+    gd, bd = g.to(dev).requires_grad_(), bta.to(dev).requires_grad_()
+    y = PF.layer_norm(zd, gd, bd, 1e-5, res=rd, act_in="gelu")
+    tol = 2e-5 if dtype == torch.float32 else BF16_TOL
+    assert rel_err(y.float().cpu(), ref.detach()) < tol
+    y.backward(dy.to(dev, dtype))
+    assert rel_err(zd.grad.float().cpu(), gz) < tol and rel_err(rd.grad.float().cpu(), gres) < tol
+    assert rel_err(gd.grad.cpu(), gg) < (1e-4 if dtype == torch.float32 else BF16_TOL)
+    assert rel_err(bd.grad.cpu(), gb) < (1e-4 if dtype == torch.float32 else BF16_TOL)
+
+
+def test_fused_dropout_is_consistent_between_forward_and_backward(dev):
+    from promptttspp_amd import functional as PF
+
+    PF.manual_seed(7)
+    B, T, C = 4, 200, 256
+    x = torch.ones(B, T, C, device=dev, requires_grad=True)
+    w = torch.eye(C, device=dev).unsqueeze(-1).requires_grad_()
+    y = PF.conv1d(x, w, None, drop_p=0.5)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.5) < 0.01                       # keep rate
+    assert torch.allclose(y[y != 0], torch.full_like(y[y != 0], 2.0))  # 1/(1-p) scaling
+    y.backward(torch.ones_like(y))
+    assert torch.equal((x.grad != 0), (y != 0))         # same mask regenerated in backward
+    y2 = PF.conv1d(x, w, None, drop_p=0.5)
+    assert not torch.equal(y2 != 0, y != 0)             # fresh mask per call
+    # LayerNorm output dropout + posenc dropout
+    g, b = torch.ones(C, device=dev, requires_grad=True), torch.zeros(C, device=dev, requires_grad=True)
+    xin = torch.randn(B, T, C, device=dev, requires_grad=True)
+    z = PF.layer_norm(xin, g, b, 1e-5, drop_out=0.25)
+    assert abs((z == 0).float().mean().item() - 0.25) < 0.01
+    pe = PF.posenc(xin, None, 2.0, 0.1)
+    assert abs((pe == 0).float().mean().item() - 0.1) < 0.01
+    pe.sum().backward()
+    assert torch.equal(xin.grad == 0, pe == 0)
+
+
+def test_fused_adamw_matches_torch(dev):
+    from promptttspp_amd.optim import FusedAdamW
+
+    torch.manual_seed(0)
+    shapes = [(256, 256, 9), (1024,), (3, 5), (80, 256, 1), (4099,)]
+    ps_ref = [torch.randn(s, requires_grad=True) for s in shapes]
+    ps = [p.detach().clone().to(dev).requires_grad_() for p in ps_ref]
+    o_ref = torch.optim.AdamW(ps_ref, lr=1e-3, betas=(0.9, 0.98), weight_decay=0.01)
+    o = FusedAdamW(ps, lr=1e-3, betas=(0.9, 0.98), weight_decay=0.01, max_grad_norm=1.0)
+    for step in range(3):
+        for a, b in zip(ps_ref, ps):
+            gr = torch.randn(a.shape) * (3.0 if step == 0 else 0.01)
+            a.grad, b.grad = gr.clone(), gr.to(dev)
+        torch.nn.utils.clip_grad_norm_(ps_ref, 1.0)
+        o_ref.step()
+        o.step()
+        for a, b in zip(ps_ref, ps):
+            assert rel_err(b.detach().cpu(), a.detach()) < 1e-5, step
