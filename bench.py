@@ -1,0 +1,290 @@
+#!/usr/bin/env python
+"""Headline benchmark: PromptTTS++ training step (prompttts_mdn_v2_wo_erg_final, bf16,
+dataset.max_tokens=30000 per GPU) on synthetic LibriTTS-R-shaped batches, plus the BigVGAN
+24 kHz vocoder real-time factor, on N MI355X GPUs (one process per GPU, RCCL over xGMI).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line:  metric = mel-frames/sec (valid frames of all ranks per
+second of optimiser steps: forward + backward + gradient exchange + clip + AdamW +
+Noam step, train mode with dropout), `roofline` for the dominant kernel family (the
+MFMA implicit-GEMM conv), `cpu_baseline` (the oracle = CPU restatement of the reference,
+timed on the host cores on a bounded sample), and the BigVGAN RTF as extra keys.
+"""
+import argparse
+import json
+import math
+import os
+import random
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+warnings.simplefilter("ignore")
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--max-tokens", type=int, default=30000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-vocoder", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--voc-batch", type=int, default=64)
+    ap.add_argument("--voc-frames", type=int, default=1000)
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------
+def build_model(dev):
+    from promptttspp_amd import hydra_lite as H
+
+    cfg = H.load_node(os.path.join(ROOT, "egs", "proposed", "bin", "conf", "model", "prompttts_mdn_v2_wo_erg_final.yaml"))
+    torch.manual_seed(1234)  # identical random-init weights on every rank
+    return H.instantiate(cfg).to(dev)
+
+
+def make_batches(rank, world, n, max_tokens, dev):
+    """Reference DP sharding (trainers/tts.py:122-143): pack the length-sorted corpus into
+    global batches of max_tokens*W with size multiple W, shuffle with seed 42, rank r takes
+    x[r::W] of each global batch -> ~max_tokens padded frames per GPU."""
+    from promptttspp_amd.datasets.prompttts import PromptTTSCollator
+    from promptttspp_amd.datasets.synthetic import SyntheticLibriTTSR
+    from promptttspp_amd.datasets.utils import batch_by_size
+
+    ds = SyntheticLibriTTSR(num_utts=20000, seed=1234)
+    gb = batch_by_size(ds.ordered_indices(), ds.num_tokens, max_tokens=max_tokens * world, required_batch_size_multiple=world)
+    gb = [b for b in gb if len(b) % world == 0 and len(b) >= world]
+    random.Random(42).shuffle(gb)
+    coll = PromptTTSCollator()
+    out = []
+    for b in gb[:n]:
+        items = coll([ds[i] for i in b[rank::world]])[2:]
+        items = [tuple(t.to(dev) for t in x) if isinstance(x, tuple) else x.to(dev) for x in items]
+        out.append(items)
+    return out
+
+
+def train_setup(model, world):
+    from promptttspp_amd.optim import FusedAdamW
+    from promptttspp_amd.parallel import FlatGradReducer
+    from promptttspp_amd.utils.lr_scheduler import NoamLR
+
+    params = [p for p in model.parameters() if p.requires_grad]
+    red = FlatGradReducer(params)
+    red.broadcast_parameters(model)
+    opt = FusedAdamW(params, lr=1e-3, betas=(0.9, 0.98), weight_decay=0.0, max_grad_norm=1.0)  # conf/optimizer/adamw.yaml + clip 1.0
+    sched = NoamLR(opt, warmup_steps=4000)
+    return red, opt, sched
+
+
+def train_step(model, batch, red, opt, sched):
+    red.zero_grad()
+    out = model(batch)
+    out["loss"].backward()
+    red.finish()
+    opt.step()
+    sched.step()
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+def conv_roofline(model, batch, red, opt, sched, dtype_name):
+    """Instrumented extra step: HIP events around every launch of the implicit-GEMM conv
+    family (forward, data-gradient) on torch's current stream; algorithmic FLOPs =
+    2 * valid_rows * Cin * Cout * ks per launch."""
+    from promptttspp_amd import ops
+
+    recs = []
+    orig = ops.conv1d
+
+    def timed(x, wp, bias, cout, ks=1, dil=1, pad=0, lengths=None, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig(x, wp, bias, cout, ks=ks, dil=dil, pad=pad, lengths=lengths, **kw)
+        e1.record()
+        rows = float(lengths.sum()) if lengths is not None and (kw.get("out_mask") or kw.get("in_mask")) else x.shape[0] * x.shape[1]
+        recs.append((e0, e1, 2.0 * rows * x.shape[2] * cout * ks))
+        return y
+
+    ops.conv1d = timed
+    try:
+        train_step(model, batch, red, opt, sched)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv1d = orig
+    tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+    tot_flop = sum(f for _, _, f in recs)
+    ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else 157.3
+    return {"bound": "mfma", "kernel": "conv1d_cl_kernel<%s> (fwd + dgrad launches of one step)" % dtype_name,
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
+            "flop_per_step": tot_flop}
+
+
+def cpu_baseline(model, batch):
+    """The oracle (CPU restatement of the reference, fp32 PyTorch) on the host cores:
+    forward + backward + clip + AdamW on a bounded sample (the first utterances of one
+    bench batch, ~2.5 k frames)."""
+    from oracle import ref_torch as R
+
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    n = 4
+    phon, dur, plen, mel, cf0, vuv, energy, flen, (ids, am) = [x if isinstance(x, tuple) else x[:n].cpu() for x in batch]
+    ids, am = ids[:n].cpu(), am[:n].cpu()
+    Tp, Tf = int(plen.max()), int(flen.max())
+    cb = (phon[:, :Tp], dur[:, :, :Tp], plen, mel[:, :, :Tf], cf0[:, :, :Tf], vuv[:, :, :Tf], flen, ids, am)
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    train_names = [k for k, p in model.named_parameters() if p.requires_grad]
+    for k in train_names:
+        sd[k].requires_grad_()
+    opt = torch.optim.AdamW([sd[k] for k in train_names], lr=1e-3, betas=(0.9, 0.98), weight_decay=0.0)
+    g = torch.Generator().manual_seed(0)
+    t = torch.randint(0, 100, (n,), generator=g)
+    noise = torch.randn(n, 80, Tf, generator=g)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = R.model_forward(sd, cb, t, noise, train_bn=True)["loss"]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([sd[k] for k in train_names], 1.0)
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    frames = int(flen.sum())
+    return {"value": round(frames / best, 1), "unit": "mel-frames/sec", "cores": ncores, "kind": "port",
+            "sample": f"{n} utterances / {frames} valid frames of one bench batch, fp32, dropout off, best of 2 after 1 warm-up "
+                      f"({best:.2f} s/step)"}
+
+
+def vocoder_leg(dev, batch, frames, dtype):
+    from promptttspp_amd.vocoders import BigVGAN
+
+    torch.manual_seed(7)
+    voc = BigVGAN(80, 512, [6, 5, 4, 2], [12, 10, 8, 4], [3, 7, 11], [[1, 3, 5]] * 3).to(dev).eval().set_compute_dtype(dtype)
+    with torch.no_grad():
+        for name, p in voc.named_parameters():
+            if name.endswith("weight_g"):
+                p.mul_(0.4)  # keep the random-init generator off the tanh rails
+    x = torch.clamp(-5.5 + 2.1 * torch.randn(batch, 80, frames, device=dev), -11.5, 2.0)
+    for _ in range(2):
+        voc(x)
+    torch.cuda.synchronize()
+    iters = 3
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        voc(x)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+# ------------------------------------------------------------------------------------------
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+
+    from promptttspp_amd import _lib, config
+    from promptttspp_amd import functional as PF
+
+    _lib.load()  # fail loudly if the HIP extension is missing
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    config.set_compute_dtype(dtype)
+    PF.manual_seed(1000 + rank)  # different dropout streams per rank
+
+    model = build_model(dev).train()
+    batches = make_batches(rank, world, a.steps + a.warmup + 1, a.max_tokens, dev)
+    assert len(batches) >= a.steps + a.warmup + 1
+    red, opt, sched = train_setup(model, world)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        train_step(model, batches[i], red, opt, sched)
+    barrier()
+    t0 = time.perf_counter()
+    frames = 0
+    for i in range(a.steps):
+        b = batches[a.warmup + i]
+        out = train_step(model, b, red, opt, sched)
+        frames += int(b[7].sum())  # frame_lengths (already a host-known quantity of the batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    loss = float(out["loss"])
+
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([dt, float(frames)], device=dev, dtype=torch.float64)
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        dt, frames = float(tmax[0]), float(tt[1])
+
+    voc = None
+    if not a.no_vocoder:
+        vdt = vocoder_leg(dev, a.voc_batch, a.voc_frames, dtype)
+        if world > 1:
+            import torch.distributed as dist
+
+            v = torch.tensor([vdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            vdt = float(v[0])
+        audio_s = a.voc_batch * a.voc_frames * 0.01 * world
+        voc = {"rtf": vdt / audio_s, "ms_per_batch": 1e3 * vdt, "batch": a.voc_batch, "frames": a.voc_frames,
+               "algorithmic_tflops": world * a.voc_batch * a.voc_frames * 444.5e6 / vdt / 1e12,
+               "algorithmic_hbm_gbs": world * a.voc_batch * a.voc_frames * 789312 * (2 if a.dtype == "bf16" else 4) / vdt / 1e9,
+               "hbm_frac_of_peak": world * a.voc_batch * a.voc_frames * 789312 * (2 if a.dtype == "bf16" else 4) / vdt / 1e9 / (HBM_PEAK_GBS * world)}
+
+    if rank == 0:
+        roof = conv_roofline(model, batches[a.warmup + a.steps], red, opt, sched, a.dtype)
+        cpu = None if a.no_cpu_baseline else cpu_baseline(model, batches[a.warmup])
+        B = batches[a.warmup][0].shape[0]
+        line = {
+            "metric": "mel-frames/sec (train)", "value": round(frames / dt, 1), "unit": "mel-frames/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "train.py model=prompttts_mdn_v2_wo_erg_final, dataset.max_tokens=%d per GPU, synthetic "
+                                   "LibriTTS-R-shaped utterances, fwd+bwd+clip+AdamW+Noam, train mode (dropout on)" % a.max_tokens,
+                       "utts_per_gpu_batch": int(B), "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
+            "roofline": roof, "cpu_baseline": cpu,
+            "per_gpu_value": round(frames / dt / world, 1),
+            "bigvgan": voc,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -373,7 +373,7 @@ def frame_prior(sd, p, x, mask, n=6, ks=17):
     """FramePriorNetwork (frame_prior.py:79-92); x (B,C,T), mask (B,1,T)."""
     B, C, T = x.shape
     x = x * mask
-    x = x * math.sqrt(C) + sinusoid(torch.arange(T), C).t()[None]
+    x = x * math.sqrt(C) + sinusoid(torch.arange(T), C).t()[None].to(x.device)
     x = layer_norm_c(x, sd[p + ".norm_emb.gamma"], sd[p + ".norm_emb.beta"])
     for i in range(n):
         r = F.gelu(_conv(sd, f"{p}.convs.{i}", x * mask, padding=ks // 2))

@@ -99,7 +99,16 @@ class Conv1dFn(Function):
         cout, cin, ks = w3.shape
         relu = cfg.act == "relu"
         dy = dy.contiguous()
-        if relu or cfg.out_mask or cfg.out_scale != 1.0 or cfg.drop_p > 0:
+        if cout % 4 and (relu or cfg.out_mask or cfg.out_scale != 1.0):
+            # 1-3 output channels (pitch/V-UV head): a (B,T,2) tensor, not worth a vector kernel
+            assert cfg.drop_p == 0
+            dz = dy * cfg.out_scale
+            if cfg.out_mask:
+                t = torch.arange(dy.shape[1], device=dy.device)
+                dz = dz * (t[None, :] < cfg.lengths[:, None]).unsqueeze(-1).to(dz.dtype)
+            if relu:
+                dz = dz * (y > 0).to(dz.dtype)
+        elif relu or cfg.out_mask or cfg.out_scale != 1.0 or cfg.drop_p > 0:
             dz = ops.epilogue_bwd(dy, y, cfg.lengths, cfg.out_scale, relu, cfg.out_mask, cfg.drop_p, ctx.seed)
         else:
             dz = dy
@@ -139,6 +148,7 @@ class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, res, gamma, beta, cfg):
         x = x.contiguous()
+        res = res.contiguous() if res is not None else None
         fused_in = res is not None or cfg.act_in is not None or cfg.drop_in > 0
         s_in = (cfg.drop_in, next_seed()) if cfg.drop_in > 0 else (0.0, 0)
         s_out = (cfg.drop_out, next_seed()) if cfg.drop_out > 0 else (0.0, 0)

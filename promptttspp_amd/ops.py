@@ -51,8 +51,22 @@ def i32(lengths, device):
     return lengths.contiguous()
 
 
+def _ld(t):
+    """Row stride (elements) of a (B, T, C) tensor whose rows are C contiguous elements
+    and whose batches are T consecutive rows; size-1 dims may carry arbitrary strides."""
+    assert t.dim() == 3, "expected a (B, T, C) tensor"
+    B, T, C = t.shape
+    assert C == 1 or t.stride(2) == 1, "channels must be contiguous"
+    if T > 1:
+        ld = t.stride(1)
+        assert B == 1 or t.stride(0) == T * ld, "batches must be T consecutive rows"
+    else:
+        ld = t.stride(0) if B > 1 else C
+    return ld
+
+
 def _rows3(x):
-    assert x.dim() == 3 and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1), "expected (B,T,C) rows"
+    _ld(x)
 
 
 # ----------------------------------------------------------------------------
@@ -101,21 +115,21 @@ def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mas
     a.res = res.data_ptr() if res is not None else None
     a.lengths = lengths.data_ptr() if lengths is not None else None
     a.B, a.T, a.Cin, a.Cout, a.ks, a.dil, a.pad = B, T, cin, cout, ks, dil, pad
-    a.ldx, a.ldy = x.stride(1), y.stride(1)
-    a.ldr = res.stride(1) if res is not None else 0
+    a.ldx, a.ldy = _ld(x), _ld(y)
+    a.ldr = _ld(res) if res is not None else 0
     a.act = _ACT[act]
     a.in_mask, a.out_mask = int(bool(in_mask)), int(bool(out_mask))
     a.out_scale = float(out_scale)
     a.dtype = dtype_code(x.dtype)
     for r in (res, res2):
         if r is not None:
-            assert r.dtype == x.dtype and r.shape == y.shape and r.stride(2) == 1
+            assert r.dtype == x.dtype and r.shape == y.shape
     lib = _lib.load()
     if res2 is None and res_scale == 1.0 and drop_p == 0.0:
         check(lib.ptpp_conv1d_fwd(ctypes.byref(a), _stream()), "ptpp_conv1d_fwd")
     else:
         check(
-            lib.ptpp_conv1d_fwd_ex(ctypes.byref(a), _ptr(res2), res2.stride(1) if res2 is not None else 0,
+            lib.ptpp_conv1d_fwd_ex(ctypes.byref(a), _ptr(res2), _ld(res2) if res2 is not None else 0,
                                    float(res_scale), float(drop_p), int(drop_seed), _stream()),
             "ptpp_conv1d_fwd_ex",
         )
@@ -131,7 +145,7 @@ def conv1d_wgrad(x, dy, cin, cout, ks, dil, pad, lengths=None, in_mask=False, wa
     lengths = i32(lengths, x.device)
     check(
         _lib.load().ptpp_conv1d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(lengths), B, T, cin, cout, ks, dil,
-                                      pad, x.stride(1), dy.stride(1), int(bool(in_mask)), dtype_code(x.dtype), _stream()),
+                                      pad, _ld(x), _ld(dy), int(bool(in_mask)), dtype_code(x.dtype), _stream()),
         "ptpp_conv1d_wgrad",
     )
     return dw, db
@@ -206,14 +220,14 @@ def attention_fwd(q, k, v, pos, bias_u, bias_v, lengths, heads, variant, save_pr
     (B,T,3C) projection); pos: (L, C) or None; returns (ctx (B,T,C), probs)."""
     _need_gpu(q)
     B, T, C = q.shape
-    assert k.stride(1) == q.stride(1) == v.stride(1) and q.stride(2) == 1
+    assert _ld(k) == _ld(q) == _ld(v)
     dk = C // heads
     ctx = torch.empty((B, T, C), device=q.device, dtype=q.dtype)
     probs = torch.empty((B, heads, T, T), device=q.device, dtype=torch.float32) if save_probs else None
     lengths = i32(lengths, q.device)
     check(
         _lib.load().ptpp_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(pos), _ptr(bias_u), _ptr(bias_v), _ptr(ctx),
-                                       _ptr(probs), _ptr(lengths), B, T, heads, dk, q.stride(1),
+                                       _ptr(probs), _ptr(lengths), B, T, heads, dk, _ld(q),
                                        pos.stride(0) if pos is not None else 0, C, _VARIANT[variant],
                                        dtype_code(q.dtype), _stream()),
         "ptpp_attention_fwd",
@@ -238,8 +252,8 @@ def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, var
     check(
         _lib.load().ptpp_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(pos), _ptr(bias_u), _ptr(bias_v), _ptr(probs),
                                        _ptr(dctx), _ptr(dS), _ptr(dq), _ptr(dk_), _ptr(dv), _ptr(dpos), _ptr(du),
-                                       _ptr(dvb), _ptr(lengths), B, T, heads, dkh, q.stride(1),
-                                       pos.stride(0) if pos is not None else 0, C, dq.stride(1), _VARIANT[variant],
+                                       _ptr(dvb), _ptr(lengths), B, T, heads, dkh, _ld(q),
+                                       pos.stride(0) if pos is not None else 0, C, _ld(dq), _VARIANT[variant],
                                        dtype_code(q.dtype), _stream()),
         "ptpp_attention_bwd",
     )
@@ -291,8 +305,7 @@ def gate_fwd(a):
 def gate_bwd(a, dg, da):
     """da: (B,T,2C) view with row stride >= 2C (written in place)."""
     B, T, C2 = a.shape
-    assert da.stride(2) == 1
-    check(_lib.load().ptpp_gate_bwd(_ptr(a), _ptr(dg.contiguous()), _ptr(da), B * T, C2 // 2, da.stride(1),
+    check(_lib.load().ptpp_gate_bwd(_ptr(a), _ptr(dg.contiguous()), _ptr(da), B * T, C2 // 2, _ld(da),
                                     dtype_code(a.dtype), _stream()), "ptpp_gate_bwd")
     return da
 

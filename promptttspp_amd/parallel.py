@@ -1,0 +1,82 @@
+"""Data-parallel gradient exchange for one-process-per-GPU training over RCCL/xGMI.
+
+The reference wraps the model in DistributedDataParallel (trainers/tts.py:116-117):
+a broadcast of parameters at construction and a bucketed mean all-reduce of ~74.6 M
+f32 gradients (298 MB) per step.  Here the gradients of all trainable parameters
+live in ONE flat f32 buffer (``p.grad`` are views), cut into a few LARGE buckets --
+xGMI is point-to-point (7 links/GPU), so few big collectives beat many 25 MB ones --
+and each bucket's all-reduce is issued from a post-accumulate hook as soon as the
+last gradient of the bucket has been written, overlapping the rest of backward.
+The flat buffer also gives the fused optimiser a single zero-fill and stable
+pointers (no per-step pointer-table rebuilds).
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradReducer:
+    def __init__(self, params, bucket_elems=32 * 1024 * 1024, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        # Backward produces gradients roughly in reverse registration order: lay the
+        # buffer out in that order so buckets complete front to back.
+        self.buckets = []  # [start, end, n_params]
+        off, start, count = 0, 0, 0
+        self._bucket_of = {}
+        for p in reversed(self.params):
+            n = p.numel()
+            p.grad = self.flat[off : off + n].view_as(p)
+            self._bucket_of[id(p)] = len(self.buckets)
+            off += n
+            count += 1
+            if off - start >= bucket_elems:
+                self.buckets.append([start, off, count])
+                start, count = off, 0
+        if count:
+            self.buckets.append([start, off, count])
+        self._pending = [b[2] for b in self.buckets]
+        self._works = []
+        self._launched = [False] * len(self.buckets)
+        if self.world > 1:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    # -- parameter broadcast (DDP constructor semantics) ------------------------------
+    def broadcast_parameters(self, module, src=0):
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t, src, group=self.group)
+
+    def _launch(self, bi):
+        a, b, _ = self.buckets[bi]
+        self._launched[bi] = True
+        self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _hook(self, p):
+        bi = self._bucket_of[id(p)]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def zero_grad(self):
+        self.flat.zero_()
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def finish(self):
+        """Wait for the bucket all-reduces and turn sums into means."""
+        if self.world == 1:
+            return
+        for bi, done in enumerate(self._launched):
+            if not done:  # parameters that received no gradient this step
+                self._launch(bi)
+        for w in self._works:
+            w.wait()
+        self.flat.mul_(1.0 / self.world)
