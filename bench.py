@@ -192,6 +192,11 @@ def vocoder_leg(dev, batch, frames, dtype):
 
 
 # ------------------------------------------------------------------------------------------
+def log(msg):
+    if os.environ.get("PTPP_BENCH_VERBOSE"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -214,8 +219,11 @@ def main():
     config.set_compute_dtype(dtype)
     PF.manual_seed(1000 + rank)  # different dropout streams per rank
 
+    log("building model")
     model = build_model(dev).train()
+    log("building batches")
     batches = make_batches(rank, world, a.steps + a.warmup + 1, a.max_tokens, dev)
+    log(f"{len(batches)} batches, first: B={batches[0][0].shape[0]} Tp={batches[0][0].shape[1]} Tf={batches[0][3].shape[2]}")
     assert len(batches) >= a.steps + a.warmup + 1
     red, opt, sched = train_setup(model, world)
 
@@ -228,6 +236,8 @@ def main():
 
     for i in range(a.warmup):
         train_step(model, batches[i], red, opt, sched)
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
     barrier()
     t0 = time.perf_counter()
     frames = 0
@@ -238,6 +248,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     loss = float(out["loss"])
+    log(f"timed region done: {dt:.3f}s for {a.steps} steps, loss {loss:.4f}")
 
     if world > 1:
         import torch.distributed as dist
@@ -263,9 +274,12 @@ def main():
                "algorithmic_hbm_gbs": world * a.voc_batch * a.voc_frames * 789312 * (2 if a.dtype == "bf16" else 4) / vdt / 1e9,
                "hbm_frac_of_peak": world * a.voc_batch * a.voc_frames * 789312 * (2 if a.dtype == "bf16" else 4) / vdt / 1e9 / (HBM_PEAK_GBS * world)}
 
+    log("vocoder leg done")
     if rank == 0:
         roof = conv_roofline(model, batches[a.warmup + a.steps], red, opt, sched, a.dtype)
+        log(f"roofline pass done: {roof['achieved']} TFLOP/s")
         cpu = None if a.no_cpu_baseline else cpu_baseline(model, batches[a.warmup])
+        log("cpu baseline done")
         B = batches[a.warmup][0].shape[0]
         line = {
             "metric": "mel-frames/sec (train)", "value": round(frames / dt, 1), "unit": "mel-frames/sec",

@@ -228,6 +228,46 @@ int ptpp_colsum_batch(const void* x, float* out, int B, int T, int C, int dtype,
                       void* stream);
 
 /* ------------------------------------------------------------------ *
+ * BatchNorm with batch statistics + activation on channels-last rows, GLU,
+ * depthwise Conv1d, 3x3/stride-2 im2col.  Conformer convolution module
+ * (esp/conformer/convolution.py:58-85: GLU -> depthwise k7 -> BatchNorm1d ->
+ * Swish) and the GST reference encoder (modules/reference_encoder.py:65-81:
+ * Conv2d 3x3 s2 -> BatchNorm2d -> ReLU; the Conv2d itself is im2col + the
+ * MFMA GEMM above).  `rows` = all rows, padded positions included, exactly
+ * like the reference's train-mode BatchNorm.
+ * ------------------------------------------------------------------ */
+/* out[c] += sum_r x[r,c]  (mean == NULL)  or  sum_r (x[r,c]-mean[c])^2 ; out zeroed by caller */
+int ptpp_col_reduce(const void* x, const float* mean, float* out, int64_t rows,
+                    int C, int dtype, void* stream);
+/* y = act(gamma*(x-mean)*rstd + beta), act in {NONE, RELU, SWISH} */
+int ptpp_bn_act_fwd(const void* x, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, void* y, int64_t rows,
+                    int C, int act, int dtype, void* stream);
+/* sums (2C f32, overwritten): [sum g | sum g*xhat], g = dy*act'(.) -> dbeta, dgamma;
+ * dx = gamma*rstd*(g - (sum_g + xhat*sum_gx)/rows) (train) or gamma*rstd*g (eval) */
+int ptpp_bn_act_bwd(const void* x, const void* dy, const float* mean,
+                    const float* rstd, const float* gamma, const float* beta,
+                    float* sums, void* dx, int64_t rows, int C, int act, int train,
+                    int dtype, void* stream);
+/* u = h[:, :C] * sigmoid(h[:, C:]) and its backward */
+int ptpp_glu_fwd(const void* h, void* u, int64_t rows, int C, int dtype, void* stream);
+int ptpp_glu_bwd(const void* h, const void* du, void* dh, int64_t rows, int C,
+                 int dtype, void* stream);
+/* depthwise conv over time, w: (C, ks) f32, "same" padding, output rows t >= len
+ * zeroed; flip=1: data gradient (input = dy, masked rows ignored). ks in {7,15,31} */
+int ptpp_dwconv1d(const void* u, const float* w, const float* bias, void* y,
+                  const int32_t* lengths, int B, int T, int C, int ks, int flip,
+                  int dtype, void* stream);
+int ptpp_dwconv1d_wgrad(const void* u, const void* dy, float* dw, float* dbias,
+                        const int32_t* lengths, int B, int T, int C, int ks,
+                        int dtype, void* stream);
+/* x: (B,H,W,C) channels-last -> col: (B*Ho*Wo, 9*C), Ho=(H-1)/2+1; and its adjoint */
+int ptpp_im2col3x3s2(const void* x, void* col, int B, int H, int W, int C,
+                     int dtype, void* stream);
+int ptpp_col2im3x3s2(const void* dcol, void* dx, int B, int H, int W, int C,
+                     int dtype, void* stream);
+
+/* ------------------------------------------------------------------ *
  * Anti-aliased Snake activation, one fused pass (layers/activations.py:22-44,
  * 74-138): replicate-pad -> x2 polyphase Kaiser-sinc up-FIR (12 taps, gain 2)
  * -> x + sin^2(x e^alpha)/(e^alpha + 1e-9) -> 12-tap low-pass, stride 2.

@@ -7,4 +7,13 @@ names, constructor kwargs, method signatures and state-dict keys) so Hydra
 at the repo root; the arithmetic runs in hand-written HIP kernels behind the
 C ABI of ``include/ptpp.h`` (``promptttspp_amd/csrc``).
 """
+import os
+
+# The few modules still on PyTorch-ROCm library ops (reference-encoder Conv2d stack,
+# Conformer depthwise conv; see DESIGN.md) see a new (batch, length) shape every step
+# (token-bucket batching).  MIOpen's default find mode benchmarks every solver --
+# including its naive reference kernels -- per new shape (measured: 7 s/step); FAST
+# mode picks a solver from its heuristics instead.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 __version__ = "0.1.0"

@@ -73,6 +73,15 @@ SIGNATURES = {
     "ptpp_diffnet_post_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "ptpp_diffnet_post_bwd": (I, [P, P, P, P, I, I, I, I, P]),
     "ptpp_colsum_batch": (I, [P, P, I, I, I, I, P]),
+    "ptpp_col_reduce": (I, [P, P, P, I64, I, I, P]),
+    "ptpp_bn_act_fwd": (I, [P, P, P, P, P, P, I64, I, I, I, P]),
+    "ptpp_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, I64, I, I, I, I, P]),
+    "ptpp_glu_fwd": (I, [P, P, I64, I, I, P]),
+    "ptpp_glu_bwd": (I, [P, P, P, I64, I, I, P]),
+    "ptpp_dwconv1d": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
+    "ptpp_dwconv1d_wgrad": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "ptpp_im2col3x3s2": (I, [P, P, I, I, I, I, I, P]),
+    "ptpp_col2im3x3s2": (I, [P, P, I, I, I, I, I, P]),
     "ptpp_aa_snake_fwd": (I, [P, P, P, POINTER(c_float), POINTER(c_float), I, I, I, I, P]),
     "ptpp_add3_scale": (I, [P, P, P, P, F, I64, I, P]),
     "ptpp_conv_post_tanh": (I, [P, P, F, P, I, I, I, I, I, P]),

@@ -1,0 +1,418 @@
+// BatchNorm (training-mode batch statistics) + activation on channels-last rows, GLU,
+// depthwise Conv1d and the 3x3/stride-2 im2col of the GST reference encoder.
+// These serve the Conformer convolution module (esp/conformer/convolution.py:58-85)
+// and the reference encoder's Conv2d+BatchNorm2d+ReLU stack
+// (modules/reference_encoder.py:65-81) -- all HBM-bound row-streaming kernels:
+// a thread owns 4 consecutive channels (8/16-byte vectors), per-channel reductions
+// go through LDS and one f32 atomic per column per block.
+#include "ptpp_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// act codes: 0 none, 1 relu, 3 swish
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == PTPP_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == PTPP_ACT_SWISH) return z * sigm(z);
+  return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == PTPP_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == PTPP_ACT_SWISH) { const float s = sigm(z); return s * (1.f + z * (1.f - s)); }
+  return 1.f;
+}
+
+// block geometry for column reductions: 256 threads = RG row-groups x CV vector-columns
+struct ColGeom { int cv, rg; };
+__device__ __forceinline__ ColGeom col_geom(int C) {
+  ColGeom g; g.cv = C >> 2; g.rg = 256 / g.cv; return g;
+}
+
+// out[k][c] += sum_r f_k(x[r,c]) ; mode 0: {x}, mode 1: {(x-mean)^2}
+template <typename T>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                         float* __restrict__ out, int64_t rows, int C, int rows_per_block) {
+  const ColGeom g = col_geom(C);
+  const int cvi = threadIdx.x % g.cv, rgi = threadIdx.x / g.cv;
+  const int c = cvi * 4;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (mean && rgi < g.rg) mu = *reinterpret_cast<const f32x4*>(mean + c);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  if (rgi < g.rg)
+    for (int64_t r = r0 + rgi; r < r1; r += g.rg) {
+      f32x4 v = Elem<T>::ld4(x + r * C + c);
+      if (mean) { v -= mu; v *= v; }
+      acc += v;
+    }
+  __shared__ f32x4 red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (rgi == 0) {
+    for (int k = 1; k < g.rg; ++k) acc += red[k * g.cv + cvi];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, acc[e]);
+  }
+}
+
+// y = act(gamma * (x - mean) * rstd + beta)
+template <typename T>
+__global__ void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+                                  int C, int64_t nvec, int act) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * 4;
+    const f32x4 v = Elem<T>::ld4(x + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_fwd(gamma[c + e] * (v[e] - mean[c + e]) * rstd[c + e] + beta[c + e], act);
+    Elem<T>::st4(y + i * 4, o);
+  }
+}
+
+// pass 1 of the backward: sums[0][c] = sum g, sums[1][c] = sum g * xhat, g = dy * act'(z)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ sums, int64_t rows, int C, int act,
+                                                            int rows_per_block) {
+  const ColGeom g = col_geom(C);
+  const int cvi = threadIdx.x % g.cv, rgi = threadIdx.x / g.cv;
+  const int c = cvi * 4;
+  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  if (rgi < g.rg) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    for (int64_t r = r0 + rgi; r < r1; r += g.rg) {
+      const f32x4 v = Elem<T>::ld4(x + r * C + c), d = Elem<T>::ld4(dy + r * C + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (v[e] - mu[e]) * rs[e];
+        const float gg = d[e] * act_grad(ga[e] * xh + be[e], act);
+        a0[e] += gg;
+        a1[e] += gg * xh;
+      }
+    }
+  }
+  __shared__ f32x4 red[2][256];
+  red[0][threadIdx.x] = a0;
+  red[1][threadIdx.x] = a1;
+  __syncthreads();
+  if (rgi == 0) {
+    for (int k = 1; k < g.rg; ++k) { a0 += red[0][k * g.cv + cvi]; a1 += red[1][k * g.cv + cvi]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { atomicAdd(sums + c + e, a0[e]); atomicAdd(sums + C + c + e, a1[e]); }
+  }
+}
+
+// pass 2: dx = gamma * rstd * (g - sum_g / N - xhat * sum_gx / N)   (train) ; = gamma * rstd * g (eval)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ sums, T* __restrict__ dx,
+                                    int C, int64_t nvec, int act, float inv_n, int train) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * 4;
+    const f32x4 v = Elem<T>::ld4(x + i * 4), d = Elem<T>::ld4(dy + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (v[e] - mean[c + e]) * rstd[c + e];
+      const float gg = d[e] * act_grad(gamma[c + e] * xh + beta[c + e], act);
+      const float corr = train ? (sums[c + e] + xh * sums[C + c + e]) * inv_n : 0.f;
+      o[e] = gamma[c + e] * rstd[c + e] * (gg - corr);
+    }
+    Elem<T>::st4(dx + i * 4, o);
+  }
+}
+
+// u = a * sigmoid(g), h = [a | g] (rows, 2C)
+template <typename T>
+__global__ void glu_fwd_kernel(const T* __restrict__ h, T* __restrict__ u, int C, int64_t nvec) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cv;
+    const int c = (int)(i % cv) * 4;
+    const f32x4 a = Elem<T>::ld4(h + row * 2 * C + c), g = Elem<T>::ld4(h + row * 2 * C + C + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = a[e] * sigm(g[e]);
+    Elem<T>::st4(u + i * 4, o);
+  }
+}
+template <typename T>
+__global__ void glu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ du, T* __restrict__ dh, int C, int64_t nvec) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cv;
+    const int c = (int)(i % cv) * 4;
+    const f32x4 a = Elem<T>::ld4(h + row * 2 * C + c), g = Elem<T>::ld4(h + row * 2 * C + C + c), d = Elem<T>::ld4(du + i * 4);
+    f32x4 da, dg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float s = sigm(g[e]);
+      da[e] = d[e] * s;
+      dg[e] = d[e] * a[e] * s * (1.f - s);
+    }
+    Elem<T>::st4(dh + row * 2 * C + c, da);
+    Elem<T>::st4(dh + row * 2 * C + C + c, dg);
+  }
+}
+
+// depthwise conv over time: y[b,t,c] = [t < len] * (bias[c] + sum_j w[c][j] * u[b, t + j - pad, c])
+// flip = 1 computes the data gradient: du[b,t,c] = sum_j w[c][j] * dym[b, t - j + pad, c], dym = dy masked
+template <typename T, int KS>
+__global__ void dwconv_kernel(const T* __restrict__ u, const float* __restrict__ w, const float* __restrict__ bias,
+                              T* __restrict__ y, const int* __restrict__ lengths, int Tlen, int C, int64_t nvec, int flip) {
+  const int cv = C >> 2;
+  constexpr int PAD = KS / 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cv;
+    const int c = (int)(i % cv) * 4;
+    const int b = (int)(row / Tlen), t = (int)(row % Tlen);
+    const int len = lengths ? min(lengths[b], Tlen) : Tlen;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!flip && bias) acc = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int ts = flip ? t - j + PAD : t + j - PAD;
+      const int lim = flip ? len : Tlen;  // the gradient only comes from unmasked output rows
+      if (ts < 0 || ts >= lim) continue;
+      const f32x4 v = Elem<T>::ld4(u + ((int64_t)b * Tlen + ts) * C + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += w[(c + e) * KS + j] * v[e];
+    }
+    if (!flip && t >= len) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    Elem<T>::st4(y + i * 4, acc);
+  }
+}
+
+// dw[c][j] += sum_{b,t<len} dy[b,t,c] * u[b, t + j - pad, c] ; dbias[c] += sum dy
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ u, const T* __restrict__ dy,
+                                                           float* __restrict__ dw, float* __restrict__ dbias,
+                                                           const int* __restrict__ lengths, int Tlen, int C, int64_t rows,
+                                                           int rows_per_block) {
+  const ColGeom g = col_geom(C);
+  const int cvi = threadIdx.x % g.cv, rgi = threadIdx.x / g.cv;
+  const int c = cvi * 4;
+  constexpr int PAD = KS / 2;
+  f32x4 aw[KS], ab = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < KS; ++j) aw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  if (rgi < g.rg)
+    for (int64_t r = r0 + rgi; r < r1; r += g.rg) {
+      const int b = (int)(r / Tlen), t = (int)(r % Tlen);
+      const int len = lengths ? min(lengths[b], Tlen) : Tlen;
+      if (t >= len) continue;
+      const f32x4 d = Elem<T>::ld4(dy + r * C + c);
+      ab += d;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const int ts = t + j - PAD;
+        if (ts < 0 || ts >= Tlen) continue;
+        aw[j] += d * Elem<T>::ld4(u + ((int64_t)b * Tlen + ts) * C + c);
+      }
+    }
+  __shared__ f32x4 red[256];
+#pragma unroll
+  for (int j = 0; j <= KS; ++j) {
+    const f32x4 v = j < KS ? aw[j < KS ? j : 0] : ab;
+    __syncthreads();
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (rgi == 0) {
+      f32x4 s = v;
+      for (int k = 1; k < g.rg; ++k) s += red[k * g.cv + cvi];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (j < KS) atomicAdd(dw + (c + e) * KS + j, s[e]);
+        else if (dbias) atomicAdd(dbias + c + e, s[e]);
+      }
+    }
+  }
+}
+
+// im2col for Conv2d(k=3, stride=2, pad=1) on channels-last (B, H, W, C):
+// col[(b, ho, wo)][(kh*3 + kw)*C + c] = x[b, 2ho + kh - 1, 2wo + kw - 1, c]  (0 outside)
+template <typename T>
+__global__ void im2col3x3s2_kernel(const T* __restrict__ x, T* __restrict__ col, int H, int W, int C, int Ho, int Wo,
+                                   int64_t nvec) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * 4;
+    int64_t q = i / cv;
+    const int k = (int)(q % 9); q /= 9;
+    const int wo = (int)(q % Wo); q /= Wo;
+    const int ho = (int)(q % Ho);
+    const int b = (int)(q / Ho);
+    const int hi = 2 * ho + k / 3 - 1, wi = 2 * wo + k % 3 - 1;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = Elem<T>::ld4(x + (((int64_t)b * H + hi) * W + wi) * C + c);
+    Elem<T>::st4(col + i * 4, v);
+  }
+}
+
+// col2im (gather form): dx[b,hi,wi,c] = sum over (ho,kh),(wo,kw) with 2ho+kh-1 == hi, 2wo+kw-1 == wi of dcol[...]
+template <typename T>
+__global__ void col2im3x3s2_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int H, int W, int C, int Ho, int Wo,
+                                   int64_t nvec) {
+  const int cv = C >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * 4;
+    int64_t q = i / cv;
+    const int wi = (int)(q % W); q /= W;
+    const int hi = (int)(q % H);
+    const int b = (int)(q / H);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h2 = hi + 1 - kh;
+      if (h2 < 0 || (h2 & 1)) continue;
+      const int ho = h2 >> 1;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w2 = wi + 1 - kw;
+        if (w2 < 0 || (w2 & 1)) continue;
+        const int wo = w2 >> 1;
+        if (wo >= Wo) continue;
+        acc += Elem<T>::ld4(dcol + ((((int64_t)b * Ho + ho) * Wo + wo) * 9 + kh * 3 + kw) * C + c);
+      }
+    }
+    Elem<T>::st4(dx + i * 4, acc);
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+inline bool cgeom_ok(int C) { return C > 0 && C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0; }
+
+}  // namespace
+
+#define DISPATCH_T(dtype, name, ...)                         \
+  if (dtype == PTPP_F32) { using T = float; __VA_ARGS__; }   \
+  else if (dtype == PTPP_BF16) { using T = bf16_raw; __VA_ARGS__; } \
+  else { ptpp_set_error("%s: bad dtype %d", name, dtype); return PTPP_EINVAL; }
+
+extern "C" int ptpp_col_reduce(const void* x, const float* mean, float* out, int64_t rows, int C, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && out && rows > 0 && cgeom_ok(C), "col_reduce: bad args (C=%d)", C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rpb = 256;
+  const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
+  DISPATCH_T(dtype, "col_reduce",
+             hipLaunchKernelGGL(col_reduce_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)x, mean, out, rows, C, rpb));
+  PTPP_CHECK_LAUNCH("col_reduce");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_bn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               void* y, int64_t rows, int C, int act, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && mean && rstd && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0, "bn_act_fwd: bad args");
+  const int64_t nvec = rows * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "bn_act_fwd",
+             hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma,
+                                beta, (T*)y, C, nvec, act));
+  PTPP_CHECK_LAUNCH("bn_act_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_bn_act_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, float* sums, void* dx, int64_t rows, int C, int act, int train, int dtype,
+                               void* stream) {
+  PTPP_CHECK_ARG(x && dy && mean && rstd && gamma && beta && sums && dx && rows > 0 && cgeom_ok(C), "bn_act_bwd: bad args");
+  const int64_t nvec = rows * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rpb = 256;
+  const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
+  if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, st) != hipSuccess) { ptpp_set_error("bn_act_bwd: memset"); return PTPP_ELAUNCH; }
+  DISPATCH_T(dtype, "bn_act_bwd",
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)x, (const T*)dy, mean, rstd,
+                                gamma, beta, sums, rows, C, act, rpb);
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)x, (const T*)dy,
+                                mean, rstd, gamma, beta, sums, (T*)dx, C, nvec, act, 1.0f / (float)rows, train));
+  PTPP_CHECK_LAUNCH("bn_act_bwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_glu_fwd(const void* h, void* u, int64_t rows, int C, int dtype, void* stream) {
+  PTPP_CHECK_ARG(h && u && rows > 0 && C > 0 && C % 4 == 0, "glu_fwd: bad args");
+  const int64_t nvec = rows * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "glu_fwd", hipLaunchKernelGGL(glu_fwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)h, (T*)u, C, nvec));
+  PTPP_CHECK_LAUNCH("glu_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_glu_bwd(const void* h, const void* du, void* dh, int64_t rows, int C, int dtype, void* stream) {
+  PTPP_CHECK_ARG(h && du && dh && rows > 0 && C > 0 && C % 4 == 0, "glu_bwd: bad args");
+  const int64_t nvec = rows * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "glu_bwd",
+             hipLaunchKernelGGL(glu_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)h, (const T*)du, (T*)dh, C, nvec));
+  PTPP_CHECK_LAUNCH("glu_bwd");
+  return PTPP_OK;
+}
+
+#define DW_LAUNCH(KS_)                                                                                                   \
+  hipLaunchKernelGGL((dwconv_kernel<T, KS_>), dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)u, w, bias, (T*)y, lengths, \
+                     T_, C, nvec, flip)
+
+extern "C" int ptpp_dwconv1d(const void* u, const float* w, const float* bias, void* y, const int32_t* lengths, int B, int T_,
+                             int C, int ks, int flip, int dtype, void* stream) {
+  PTPP_CHECK_ARG(u && w && y && B > 0 && T_ > 0 && C > 0 && C % 4 == 0, "dwconv1d: bad args");
+  PTPP_CHECK_ARG(ks == 7 || ks == 15 || ks == 31, "dwconv1d: kernel size %d not built (7, 15, 31)", ks);
+  const int64_t nvec = (int64_t)B * T_ * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "dwconv1d", if (ks == 7) { DW_LAUNCH(7); } else if (ks == 15) { DW_LAUNCH(15); } else { DW_LAUNCH(31); });
+  PTPP_CHECK_LAUNCH("dwconv1d");
+  return PTPP_OK;
+}
+
+#define DWW_LAUNCH(KS_)                                                                                              \
+  hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS_>), dim3(nb), dim3(256), 0, st, (const T*)u, (const T*)dy, dw, dbias, \
+                     lengths, T_, C, rows, rpb)
+
+extern "C" int ptpp_dwconv1d_wgrad(const void* u, const void* dy, float* dw, float* dbias, const int32_t* lengths, int B,
+                                   int T_, int C, int ks, int dtype, void* stream) {
+  PTPP_CHECK_ARG(u && dy && dw && B > 0 && T_ > 0 && cgeom_ok(C), "dwconv1d_wgrad: bad args");
+  PTPP_CHECK_ARG(ks == 7 || ks == 15 || ks == 31, "dwconv1d_wgrad: kernel size %d not built", ks);
+  const int64_t rows = (int64_t)B * T_;
+  const int rpb = 128;
+  const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "dwconv1d_wgrad", if (ks == 7) { DWW_LAUNCH(7); } else if (ks == 15) { DWW_LAUNCH(15); } else { DWW_LAUNCH(31); });
+  PTPP_CHECK_LAUNCH("dwconv1d_wgrad");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_im2col3x3s2(const void* x, void* col, int B, int H, int W, int C, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && col && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "im2col3x3s2: bad args");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t nvec = (int64_t)B * Ho * Wo * 9 * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "im2col3x3s2",
+             hipLaunchKernelGGL(im2col3x3s2_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)x, (T*)col, H, W, C, Ho, Wo, nvec));
+  PTPP_CHECK_LAUNCH("im2col3x3s2");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_col2im3x3s2(const void* dcol, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
+  PTPP_CHECK_ARG(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "col2im3x3s2: bad args");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t nvec = (int64_t)B * H * W * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "col2im3x3s2",
+             hipLaunchKernelGGL(col2im3x3s2_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)dcol, (T*)dx, H, W, C, Ho, Wo, nvec));
+  PTPP_CHECK_LAUNCH("col2im3x3s2");
+  return PTPP_OK;
+}

@@ -17,9 +17,7 @@ keys (Appendix A of SURVEY.md), re-designed for MI355X:
 
 Supported configuration = the one the reference's YAMLs use
 (``normalize_before``, macaron FFN pair, conv1d position-wise layers, CNN
-module, relative positions "new" (training) and "legacy" (demo)).  The GLU /
-depthwise / BatchNorm / Swish middle of the CNN module (0.4 MFLOP per phone,
-<0.5 % of the encoder) still runs on torch ops this round -- see DESIGN.md.
+module, relative positions "new" (training) and "legacy" (demo)).
 """
 import math
 
@@ -28,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import functional as PF
+from ... import nn_ops as NO
 from ...config import compute_dtype
 
 LN_EPS = 1e-12  # ESPnet LayerNorm (transformer/layer_norm.py:21)
@@ -110,13 +109,10 @@ class ConvolutionModule(nn.Module):
 
     def cl(self, x, lengths, mask_bt1, res, out_drop):
         h = PF.conv1d(x, self.pointwise_conv1.weight, self.pointwise_conv1.bias, lengths=lengths, out_mask=True)
-        # --- GLU -> depthwise k=7 -> mask -> BatchNorm (batch stats incl. padding in
-        #     train mode, like the reference) -> Swish: torch ops this round ---
-        a, g = h.float().chunk(2, dim=-1)
-        h = (a * torch.sigmoid(g)).transpose(1, 2)
-        h = self.depthwise_conv(h) * mask_bt1.transpose(1, 2)
-        h = self.norm(h)
-        h = (h * torch.sigmoid(h)).transpose(1, 2).to(x.dtype).contiguous()
+        # GLU -> depthwise k=7 (masked) -> BatchNorm1d (train mode: batch statistics over
+        # ALL rows, padded ones included, like the reference) -> Swish: HIP kernels (bn_dw.hip)
+        h = NO.dwconv1d(NO.glu(h), self.depthwise_conv.weight, self.depthwise_conv.bias, lengths)
+        h = NO.batch_norm_act(h, self.norm, act="swish")
         # x = residual + dropout(mask * pw2(h)) * mask
         return PF.conv1d(h, self.pointwise_conv2.weight, self.pointwise_conv2.bias, res=res, lengths=lengths,
                          out_mask=True, drop_p=out_drop)

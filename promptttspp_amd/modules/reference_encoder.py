@@ -2,17 +2,22 @@
 6 x (Conv2d 3x3 stride 2, no bias -> BatchNorm2d -> ReLU) on (B,1,T,80), then a GRU
 whose last valid hidden state is the reference embedding.
 
-Round-1 state: this 3 MFLOP/frame side branch still runs on PyTorch-ROCm library
-ops (MIOpen conv/BN, rocBLAS GRU) -- it is the next module to move onto the HIP
-conv kernel (a 3x3 stride-2 Conv2d over (T, F) is a conv1d over T with
-K = 3*F_in*C_in).  Two deliberate differences from the reference's op sequence,
-neither changing results: the GRU runs on the padded batch and the state at
-step len-1 is gathered (the GRU is causal), which removes the reference's
-lengths->CPU copy + pack_padded_sequence host sync (reference_encoder.py:118-121).
+MI355X design: the spectrogram stays channels-last (B, T, F, C); each Conv2d is an
+im2col gather + ONE MFMA GEMM launch (K = 9*Cin, the same implicit-GEMM kernel as
+every other dense layer), BatchNorm2d(+ReLU) is the fused batch-statistics kernel
+pair of bn_dw.hip, and the GRU input projection for all (<= ~12) steps is one GEMM.
+Nothing here goes through MIOpen, whose per-shape solver search cannot cope with
+token-bucket batches that change shape every step.
+
+Differences from the reference's op sequence that do not change results: the GRU
+runs on the padded batch and freezes each sequence's state after its last valid
+step (the packed-sequence semantics), which removes the reference's lengths->CPU
+copy + pack_padded_sequence host sync (reference_encoder.py:118-121).
 """
 import torch
 import torch.nn as nn
 
+from .. import nn_ops as NO
 from ..config import compute_dtype
 
 
@@ -22,6 +27,8 @@ class ReferenceEncoder(nn.Module):
         super().__init__()
         assert conv_kernel_size % 2 == 1, "kernel size must be odd."
         assert len(conv_chans_list) == conv_layers
+        if conv_kernel_size != 3 or conv_stride != 2 or gru_layers != 1:
+            raise NotImplementedError("promptttspp_amd implements the reference config: 3x3 stride-2 convs, 1 GRU layer")
         self.conv_stride, self.conv_layers = conv_stride, conv_layers
         padding = (conv_kernel_size - 1) // 2
         convs = []
@@ -29,7 +36,7 @@ class ReferenceEncoder(nn.Module):
             cin = 1 if i == 0 else conv_chans_list[i - 1]
             convs += [nn.Conv2d(cin, conv_chans_list[i], conv_kernel_size, stride=conv_stride, padding=padding, bias=False),
                       nn.BatchNorm2d(conv_chans_list[i]), nn.ReLU(inplace=True)]
-        self.convs = nn.Sequential(*convs)
+        self.convs = nn.Sequential(*convs)  # parameter holders (reference key names convs.{0,1,3,4,...})
         f = idim
         for _ in range(conv_layers):
             f = (f - conv_kernel_size + 2 * padding) // conv_stride + 1
@@ -37,16 +44,17 @@ class ReferenceEncoder(nn.Module):
 
     def forward(self, speech, in_lens=None):
         """speech (B, idim, T) float -> (B, gru_units, 1) float32."""
-        B = speech.size(0)
-        amp = compute_dtype() == torch.bfloat16 and speech.is_cuda
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            hs = self.convs(speech.transpose(1, 2).unsqueeze(1)).transpose(1, 2)  # (B, T', C', F')
-            hs = hs.contiguous().view(B, hs.size(1), -1)
-            self.gru.flatten_parameters()
-            out, h_last = self.gru(hs)
+        B, _, T = speech.shape
+        x = speech.transpose(1, 2).unsqueeze(-1).to(compute_dtype()).contiguous()  # (B, T, F, 1)
+        for i in range(self.conv_layers):
+            x = NO.conv2d_3x3s2(x, self.convs[3 * i].weight)
+            x = NO.batch_norm_act(x, self.convs[3 * i + 1], act="relu")
+        # reference flattens (B, C, T', F') -> (B, T', C*F'): channel-major features
+        hs = x.permute(0, 1, 3, 2).reshape(B, x.shape[1], -1)
         if in_lens is None:
-            ref = h_last[-1]
+            lens = torch.full((B,), hs.shape[1], device=speech.device, dtype=torch.long)
         else:
             lens = torch.ceil(in_lens.to(speech.device).float() / (self.conv_stride**self.conv_layers)).long().clamp(min=1)
-            ref = out.gather(1, (lens - 1).view(B, 1, 1).expand(-1, 1, out.size(-1))).squeeze(1)
-        return ref.float().unsqueeze(-1)
+        g = self.gru
+        ref = NO.gru_last_state(hs.contiguous(), g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, lens)
+        return ref.unsqueeze(-1)

@@ -1,0 +1,204 @@
+"""Differentiable BatchNorm(+activation), GLU, depthwise Conv1d, Conv2d(3x3, stride 2)
+and GRU on the HIP kernels of csrc/bn_dw.hip -- the pieces of the Conformer
+convolution module and of the GST reference encoder.  No MIOpen: with token-bucket
+batching every step has a new (batch, length) shape, and MIOpen's per-shape solver
+search / kernel JIT made these few small ops cost ~1.3 s of host time per step
+(profiles/r01_train_step_v0.md)."""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from . import functional as PF
+from . import ops
+from .ops import _ptr, _stream, dtype_code
+
+_ACT = {None: 0, "relu": 1, "swish": 3}
+
+
+def _chk(status, what):
+    _lib.check(status, what)
+
+
+def col_reduce(x2d, mean=None):
+    """x2d: (rows, C) -> (C,) f32: sum_r x or sum_r (x-mean)^2."""
+    rows, C = x2d.shape
+    out = torch.zeros(C, device=x2d.device, dtype=torch.float32)
+    _chk(_lib.load().ptpp_col_reduce(_ptr(x2d), _ptr(mean), _ptr(out), rows, C, dtype_code(x2d.dtype), _stream()),
+         "ptpp_col_reduce")
+    return out
+
+
+class BatchNormActFn(Function):
+    """y = act(BN(x)) over channels-last rows (rows, C); training: batch statistics
+    (biased variance for normalisation, unbiased for the running estimate, like
+    torch.nn.BatchNorm), updates running stats in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act):
+        shape = x.shape
+        x2 = x.contiguous().view(-1, shape[-1])
+        rows, C = x2.shape
+        if training:
+            mean = col_reduce(x2) / rows
+            var = col_reduce(x2, mean) / rows
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var * (rows / max(rows - 1, 1)), alpha=momentum)
+        else:
+            mean, var = running_mean.float(), running_var.float()
+        rstd = torch.rsqrt(var + eps)
+        g, b = PF._f32c(gamma), PF._f32c(beta)
+        y = torch.empty_like(x2)
+        _chk(_lib.load().ptpp_bn_act_fwd(_ptr(x2), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(y), rows, C, _ACT[act],
+                                         dtype_code(x2.dtype), _stream()), "ptpp_bn_act_fwd")
+        ctx.act, ctx.training, ctx.shape = act, training, shape
+        ctx.save_for_backward(x2, mean.contiguous(), rstd.contiguous(), g, b)
+        return y.view(shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, mean, rstd, g, b = ctx.saved_tensors
+        rows, C = x2.shape
+        dy2 = dy.contiguous().view(rows, C)
+        sums = torch.empty(2 * C, device=x2.device, dtype=torch.float32)
+        dx = torch.empty_like(x2)
+        _chk(_lib.load().ptpp_bn_act_bwd(_ptr(x2), _ptr(dy2), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(sums), _ptr(dx),
+                                         rows, C, _ACT[ctx.act], int(ctx.training), dtype_code(x2.dtype), _stream()),
+             "ptpp_bn_act_bwd")
+        return dx.view(ctx.shape), sums[C:].clone(), sums[:C].clone(), None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, act=None):
+    """``bn``: an nn.BatchNorm1d/2d parameter holder; x channels-last (..., C)."""
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, act)
+
+
+class GluFn(Function):
+    @staticmethod
+    def forward(ctx, h):
+        h = h.contiguous()
+        rows, C = h.numel() // h.shape[-1], h.shape[-1] // 2
+        u = torch.empty(h.shape[:-1] + (C,), device=h.device, dtype=h.dtype)
+        _chk(_lib.load().ptpp_glu_fwd(_ptr(h), _ptr(u), rows, C, dtype_code(h.dtype), _stream()), "ptpp_glu_fwd")
+        ctx.save_for_backward(h)
+        return u
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, du):
+        (h,) = ctx.saved_tensors
+        rows, C = h.numel() // h.shape[-1], h.shape[-1] // 2
+        dh = torch.empty_like(h)
+        _chk(_lib.load().ptpp_glu_bwd(_ptr(h), _ptr(du.contiguous()), _ptr(dh), rows, C, dtype_code(h.dtype), _stream()),
+             "ptpp_glu_bwd")
+        return dh
+
+
+def glu(h):
+    return GluFn.apply(h)
+
+
+class DwConvFn(Function):
+    """Depthwise Conv1d over time on (B, T, C), 'same' padding, output masked by lengths."""
+
+    @staticmethod
+    def forward(ctx, u, w, b, lengths):
+        u = u.contiguous()
+        B, T, C = u.shape
+        ks = w.shape[-1]
+        wf, bf = PF._f32c(w).reshape(C, ks), PF._f32c(b)
+        y = torch.empty_like(u)
+        lengths = ops.i32(lengths, u.device)
+        _chk(_lib.load().ptpp_dwconv1d(_ptr(u), _ptr(wf), _ptr(bf), _ptr(y), _ptr(lengths), B, T, C, ks, 0,
+                                       dtype_code(u.dtype), _stream()), "ptpp_dwconv1d")
+        ctx.lengths, ctx.wshape, ctx.has_b = lengths, w.shape, b is not None
+        ctx.save_for_backward(u, wf)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        u, wf = ctx.saved_tensors
+        B, T, C = u.shape
+        ks = wf.shape[-1]
+        dy = dy.contiguous()
+        du = torch.empty_like(u)
+        lib = _lib.load()
+        _chk(lib.ptpp_dwconv1d(_ptr(dy), _ptr(wf), None, _ptr(du), _ptr(ctx.lengths), B, T, C, ks, 1, dtype_code(u.dtype),
+                               _stream()), "ptpp_dwconv1d(bwd)")
+        dw = torch.zeros((C, ks), device=u.device, dtype=torch.float32)
+        db = torch.zeros((C,), device=u.device, dtype=torch.float32) if ctx.has_b else None
+        _chk(lib.ptpp_dwconv1d_wgrad(_ptr(u), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ctx.lengths), B, T, C, ks,
+                                     dtype_code(u.dtype), _stream()), "ptpp_dwconv1d_wgrad")
+        return du, dw.view(ctx.wshape), db, None
+
+
+def dwconv1d(u, w, b, lengths):
+    return DwConvFn.apply(u, w, b, lengths)
+
+
+class Im2Col3x3s2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        col = torch.empty((B * Ho * Wo, 9 * C), device=x.device, dtype=x.dtype)
+        _chk(_lib.load().ptpp_im2col3x3s2(_ptr(x), _ptr(col), B, H, W, C, dtype_code(x.dtype), _stream()), "ptpp_im2col3x3s2")
+        ctx.shape = (B, H, W, C)
+        return col
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dcol):
+        B, H, W, C = ctx.shape
+        dx = torch.empty(ctx.shape, device=dcol.device, dtype=dcol.dtype)
+        _chk(_lib.load().ptpp_col2im3x3s2(_ptr(dcol.contiguous()), _ptr(dx), B, H, W, C, dtype_code(dcol.dtype), _stream()),
+             "ptpp_col2im3x3s2")
+        return dx
+
+
+def conv2d_3x3s2(x, weight):
+    """x: (B, H, W, Cin) channels-last; weight: nn.Conv2d weight (Cout, Cin, 3, 3), no bias.
+    -> (B, Ho, Wo, Cout): im2col gather + ONE MFMA GEMM (K = 9*Cin)."""
+    B, H, W, C = x.shape
+    cout = weight.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    kc = 8
+    if C % kc:  # first layer (Cin = 1): zero-pad channels to the MFMA operand granule
+        padc = kc - C % kc
+        x = torch.nn.functional.pad(x, (0, padc))
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, padc))
+        C += padc
+    col = Im2Col3x3s2Fn.apply(x)
+    wg = weight.permute(0, 2, 3, 1).reshape(cout, 9 * C)  # K index = (kh*3 + kw)*Cin + ci
+    y = PF.linear(col, wg)
+    return y.view(B, Ho, Wo, cout)
+
+
+def gru_last_state(x, weight_ih, weight_hh, bias_ih, bias_hh, lens):
+    """Single-layer GRU over (B, L, I), returning each sequence's hidden state at its
+    last valid step (B, H) (reference: packed GRU, modules/reference_encoder.py:108-123).
+    L = ceil(frames/64) <= ~12 steps: the input projection for all steps is ONE HIP GEMM;
+    the recurrent (B,H)x(H,3H) products go to the library GEMM (torch.addmm -> rocBLAS)
+    and the gate algebra is a few (B, H) elementwise ops per step, in float32."""
+    B, L, _ = x.shape
+    Hn = weight_hh.shape[1]
+    gi_all = PF.linear(x, weight_ih, bias_ih).float()  # (B, L, 3H)
+    h = x.new_zeros((B, Hn), dtype=torch.float32)
+    whh_t = weight_hh.t()
+    for s in range(L):
+        gi = gi_all[:, s]
+        gh = torch.addmm(bias_hh, h, whh_t)
+        r = torch.sigmoid(gi[:, :Hn] + gh[:, :Hn])
+        z = torch.sigmoid(gi[:, Hn : 2 * Hn] + gh[:, Hn : 2 * Hn])
+        n = torch.tanh(gi[:, 2 * Hn :] + r * gh[:, 2 * Hn :])
+        hn = (1 - z) * n + z * h
+        h = torch.where((s < lens).unsqueeze(-1), hn, h)
+    return h
