@@ -4,6 +4,7 @@ through the C ABI.  All activations are channels-last (B, T, C) in the compute
 dtype; parameters stay f32 (master weights) and are packed/cast per version.
 """
 import math
+import weakref
 from types import SimpleNamespace
 
 import torch
@@ -43,10 +44,12 @@ def packed(w, dtype, mode=0):
         return ops.pack_conv_weight(w, dtype, mode)
     key = (id(w), mode, dtype)
     ent = _pack_cache.get(key)
-    if ent is not None and ent[0] == w._version and ent[1] == w.data_ptr():
+    # an entry is valid only for the SAME live Parameter object (ids and device addresses
+    # are recycled when models are freed), same in-place version and same storage
+    if ent is not None and ent[3]() is w and ent[0] == w._version and ent[1] == w.data_ptr():
         return ent[2]
     wp = ops.pack_conv_weight(w, dtype, mode)
-    _pack_cache[key] = (w._version, w.data_ptr(), wp)
+    _pack_cache[key] = (w._version, w.data_ptr(), wp, weakref.ref(w, lambda _r, k=key: _pack_cache.pop(k, None)))
     return wp
 
 
