@@ -8,9 +8,9 @@
 // across blocks (split-K) and combined with f32 atomics, so the result is f32
 // regardless of the activation dtype.
 //
-// NOTE (round-1 state): bf16 activations are widened to f32 while staging, so
-// this kernel runs at the f32 MFMA rate (157 TF peak).  The bf16-rate variant
-// (ds_read_b64_tr_b16 operand transposes) is the next step -- see DESIGN.md.
+// This file holds the exact-f32 kernel (f32 activations, and the rare bf16 shapes with
+// unaligned rows, which are widened while staging).  bf16 tensors normally take the
+// bf16-rate kernel in conv1d_wgrad_bf16.hip (ds_read_b64_tr_b16 operand transposes).
 #include "ptpp_common.h"
 
 namespace {
@@ -113,6 +113,9 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const T* __restrict__
 
 }  // namespace
 
+int ptpp_wgrad_bf16_launch(const void* x, const void* dy, float* dw, float* dbias, const int32_t* lengths, int B, int T,
+                           int Cin, int Cout, int ks, int dil, int pad, int ldx, int lddy, int in_mask, hipStream_t st);
+
 extern "C" int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, const int32_t* lengths, int B,
                                  int T, int Cin, int Cout, int ks, int dil, int pad, int ldx, int lddy, int in_mask,
                                  int dtype, void* stream) {
@@ -121,6 +124,13 @@ extern "C" int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float
   PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "conv1d_wgrad: bad dtype %d", dtype);
   PTPP_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0, "conv1d_wgrad: row strides must be multiples of 4");
   PTPP_CHECK_ARG(!in_mask || lengths, "conv1d_wgrad: in_mask needs lengths");
+  if (dtype == PTPP_BF16 && ldx % 8 == 0 && lddy % 8 == 0 && Cin % 8 == 0 && Cout % 8 == 0 &&
+      ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
+    // bf16-rate path (LDS transpose reads); shapes it cannot take fall through to the f32-MFMA kernel
+    const int rc = ptpp_wgrad_bf16_launch(x, dy, dw, dbias, lengths, B, T, Cin, Cout, ks, dil, pad, ldx, lddy, in_mask,
+                                          reinterpret_cast<hipStream_t>(stream));
+    if (rc != PTPP_ENOTSUP) return rc;
+  }
   const int nCO = (Cout + 63) / 64, nCI = (Cin + 63) / 64;
   const int tchunks = (T + KR - 1) / KR;
   const int total = B * tchunks;

@@ -1,0 +1,90 @@
+"""CPU, world_size 2, gloo: the data-parallel pieces that do not need a GPU --
+the flat-bucket gradient reducer (mean all-reduce == single-process gradient of the
+concatenated batch for a mean-normalised loss), parameter broadcast, and the reference's
+rank sharding x[rank::W] of token-bucket batches (trainers/tts.py:122-143)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from promptttspp_amd.parallel import FlatGradReducer
+
+        torch.manual_seed(100 + rank)  # different init per rank: broadcast must fix it
+        model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 4))
+        red = FlatGradReducer(model.parameters(), bucket_elems=100)  # several buckets
+        assert len(red.buckets) >= 2
+        red.broadcast_parameters(model)
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(8, 16, generator=g)
+        y = torch.randn(8, 4, generator=g)
+        xs, ys = x[rank::world], y[rank::world]
+        for step in range(2):
+            red.zero_grad()
+            loss = ((model(xs) - ys) ** 2).mean()
+            loss.backward()
+            red.finish()
+        if rank == 0:
+            # plain numpy: torch tensors would travel as shared-memory handles that die with this process
+            out.put({"flat": red.flat.numpy().copy(), "params": [p.detach().numpy().copy() for p in model.parameters()],
+                     "x": x.numpy().copy(), "y": y.numpy().copy()})
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_flat_grad_reducer_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    res = {k: ([torch.from_numpy(a) for a in v] if isinstance(v, list) else torch.from_numpy(v)) for k, v in res.items()}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference with rank 0's (broadcast) parameters on the full batch
+    model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 4))
+    with torch.no_grad():
+        for p, v in zip(model.parameters(), res["params"]):
+            p.copy_(v)
+    loss = ((model(res["x"]) - res["y"]) ** 2).mean()
+    loss.backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in reversed(list(model.parameters()))])  # reducer layout: reverse order
+    assert torch.allclose(res["flat"], ref, atol=1e-6)
+
+
+def test_rank_sharding_of_token_bucket_batches():
+    from promptttspp_amd.datasets.synthetic import SyntheticLibriTTSR
+    from promptttspp_amd.datasets.utils import batch_by_size
+
+    ds = SyntheticLibriTTSR(num_utts=1500, seed=1234)
+    for W in (1, 2, 8):
+        gb = batch_by_size(ds.ordered_indices(), ds.num_tokens, max_tokens=30000 * W, required_batch_size_multiple=W)
+        gb = [b for b in gb if len(b) % W == 0]
+        for b in gb[:: max(1, len(gb) // 10)]:
+            shards = [b[r::W] for r in range(W)]
+            assert sorted(i for s in shards for i in s) == sorted(b)          # a partition
+            assert len({len(s) for s in shards}) == 1                            # equal utterance counts
+            tok = [len(s) * max(ds.num_tokens(i) for i in s) for s in shards]
+            assert max(tok) <= 30000 * 1.02                                      # ~max_tokens padded frames per GPU
+            fr = [sum(ds.num_tokens(i) for i in s) for s in shards]
+            assert (max(fr) - min(fr)) / max(fr) < 0.1                           # interleaving balances the work

@@ -80,3 +80,28 @@ def test_weight_cache_follows_state_dict(dev):
     y2 = m(g["x"].to(dev)).cpu()
     assert rel_err(y2, R.bigvgan(sd2, g["x"])) < 1e-4
     assert rel_err(y1, y2) > 1e-2
+
+
+def test_f0_aware_bigvgan_matches_reference_golden(dev):
+    """F0AwareBigVGAN with the reference's RNG draws injected (rand -> initial phases,
+    randn_like -> additive noise, randn_like -> the unused noise branch)."""
+    from promptttspp_amd.vocoders import F0AwareBigVGAN
+
+    g = load_golden("bigvgan_f0")
+    m = F0AwareBigVGAN(sampling_rate=24000, harmonic_num=8, **BIGVGAN_KW)
+    keys = key_shapes(g["keys"])
+    assert sorted((k, tuple(v.shape)) for k, v in m.state_dict().items()) == sorted(keys)
+    sd = vocoder_sd(keys, 120)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval().set_compute_dtype(torch.float32)
+    B, L = g["nz"].shape[0], g["nz"].shape[1]
+    q_rand, q_like = [g["rand_ini"].clone().to(dev)], [g["nz"].to(dev), torch.zeros(B, L, 1, device=dev)]
+    o_rand, o_like = torch.rand, torch.randn_like
+    torch.rand = lambda *a, **k: q_rand.pop(0)
+    torch.randn_like = lambda *a, **k: q_like.pop(0)
+    try:
+        y = m(g["x"].to(dev), g["f0"].to(dev)).cpu()
+    finally:
+        torch.rand, torch.randn_like = o_rand, o_like
+    assert y.shape == g["y"].shape
+    assert rel_err(y, g["y"]) < 1e-3

@@ -93,7 +93,7 @@ def test_conv1d_dgrad_via_mode1_pack(dtype, dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 150, 256, 256, 5, 1), (3, 70, 80, 256, 1, 1), (2, 90, 256, 4, 1, 1),
+@pytest.mark.parametrize("case", [(2, 150, 256, 256, 5, 1), (3, 70, 80, 256, 1, 1), (2, 90, 256, 4, 1, 1), (2, 131, 256, 256, 17, 1), (3, 45, 256, 1024, 9, 1),
                                   (2, 64, 256, 512, 3, 8)])
 def test_conv1d_wgrad(case, dtype, dev):
     from promptttspp_amd import ops
