@@ -135,14 +135,16 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
 
 def cpu_baseline(model, batch):
     """The oracle (CPU restatement of the reference, fp32 PyTorch) on the host cores:
-    forward + backward + clip + AdamW on a BOUNDED sample (the 2 shortest-index utterances
-    of one bench batch, ~1.2 k frames; one warm-up step + one timed step)."""
+    forward + backward + clip + AdamW on a BOUNDED sample (the first 16 utterances of one
+    bench batch, ~8 k frames; one warm-up step + one timed step)."""
     from oracle import ref_torch as R
 
     ncores = os.cpu_count() or 1
-    nthr = int(os.environ.get("PTPP_CPU_THREADS", min(ncores, 64)))
+    # (more threads than ~32 make this many-small-ops workload SLOWER on the 256-thread GPU host:
+    #  measured 0.35 / 0.59 / 1.30 s per step at 16 / 32 / 64 threads for 2 utterances)
+    nthr = int(os.environ.get("PTPP_CPU_THREADS", min(ncores, 32)))
     torch.set_num_threads(nthr)
-    n = 2
+    n = min(16, batch[0].shape[0])
     phon, dur, plen, mel, cf0, vuv, energy, flen, (ids, am) = [x if isinstance(x, tuple) else x[:n].cpu() for x in batch]
     ids, am = ids[:n].cpu(), am[:n].cpu()
     Tp, Tf = int(plen.max()), int(flen.max())
