@@ -32,6 +32,7 @@
 #ifndef PTPP_H_
 #define PTPP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -116,14 +117,19 @@ int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, int ldr2,
                        float res_scale, float drop_p, uint64_t drop_seed,
                        void* stream);
 
-/* Weight / bias gradient (f32 accumulate, f32 output, atomics across the
- * row split -- the caller zero-fills dw/dbias or accumulates into them):
+/* Weight / bias gradient (f32 accumulate, f32 output; ACCUMULATES: the
+ * caller zero-fills dw/dbias or hands in a gradient buffer to add to):
  *   dw[Cout][Cin][ks] += sum_{b,t} dy[b,t,co] * x[b, t + j*dil - pad, ci]
- *   dbias[Cout]       += sum_{b,t} dy[b,t,co]                 (dbias nullable) */
+ *   dbias[Cout]       += sum_{b,t} dy[b,t,co]                 (dbias nullable)
+ * The rows are split across blocks.  workspace: optional 16-byte aligned
+ * device scratch (>= 4*Cout*Cin*ks bytes to be used; 64 MiB is plenty): the
+ * split partials are stored there and summed in a fixed order by a second
+ * kernel (deterministic dw).  NULL -> partials combined with f32 atomics. */
 int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias,
                       const int32_t* lengths, int B, int T, int Cin, int Cout,
                       int ks, int dil, int pad, int ldx, int lddy, int in_mask,
-                      int dtype, void* stream);
+                      int dtype, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* Backward of the conv epilogue (contiguous (B,T,C)):
  *   dz = dy * scale * [t < len] * relu'(y) * dropmask           */

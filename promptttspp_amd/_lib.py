@@ -49,7 +49,7 @@ class ConvArgs(Structure):
     ]
 
 
-P, I, F, U64, I64 = c_void_p, c_int, c_float, c_uint64, c_int64
+P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/ptpp.h declares.
 SIGNATURES = {
@@ -59,7 +59,7 @@ SIGNATURES = {
     "ptpp_pack_conv_weight": (I, [P, P, I, I, I, I, I, P]),
     "ptpp_conv1d_fwd": (I, [POINTER(ConvArgs), P]),
     "ptpp_conv1d_fwd_ex": (I, [POINTER(ConvArgs), P, I, F, F, U64, P]),
-    "ptpp_conv1d_wgrad": (I, [P, P, P, P, P] + [I] * 11 + [P]),
+    "ptpp_conv1d_wgrad": (I, [P, P, P, P, P] + [I] * 11 + [P, SZ, P]),
     "ptpp_epilogue_bwd": (I, [P, P, P, P, I, I, I, F, I, I, F, U64, I, P]),
     "ptpp_layernorm_fwd": (I, [P] * 9 + [I, I, I, F, I, I, F, U64, F, U64, I, P]),
     "ptpp_layernorm_bwd": (I, [P] * 11 + [I, I, I, I, I, F, U64, F, U64, I, P]),

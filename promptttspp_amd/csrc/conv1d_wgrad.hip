@@ -114,11 +114,12 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const T* __restrict__
 }  // namespace
 
 int ptpp_wgrad_bf16_launch(const void* x, const void* dy, float* dw, float* dbias, const int32_t* lengths, int B, int T,
-                           int Cin, int Cout, int ks, int dil, int pad, int ldx, int lddy, int in_mask, hipStream_t st);
+                           int Cin, int Cout, int ks, int dil, int pad, int ldx, int lddy, int in_mask, void* ws,
+                           size_t ws_bytes, hipStream_t st);
 
 extern "C" int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, const int32_t* lengths, int B,
                                  int T, int Cin, int Cout, int ks, int dil, int pad, int ldx, int lddy, int in_mask,
-                                 int dtype, void* stream) {
+                                 int dtype, void* workspace, size_t workspace_bytes, void* stream) {
   PTPP_CHECK_ARG(x && dy && dw, "conv1d_wgrad: null pointer");
   PTPP_CHECK_ARG(B > 0 && T > 0 && Cin > 0 && Cout > 0 && ks > 0 && dil > 0, "conv1d_wgrad: bad shape");
   PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "conv1d_wgrad: bad dtype %d", dtype);
@@ -126,10 +127,9 @@ extern "C" int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float
   PTPP_CHECK_ARG(!in_mask || lengths, "conv1d_wgrad: in_mask needs lengths");
   if (dtype == PTPP_BF16 && ldx % 8 == 0 && lddy % 8 == 0 && Cin % 8 == 0 && Cout % 8 == 0 &&
       ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
-    // bf16-rate path (LDS transpose reads); shapes it cannot take fall through to the f32-MFMA kernel
-    const int rc = ptpp_wgrad_bf16_launch(x, dy, dw, dbias, lengths, B, T, Cin, Cout, ks, dil, pad, ldx, lddy, in_mask,
-                                          reinterpret_cast<hipStream_t>(stream));
-    if (rc != PTPP_ENOTSUP) return rc;
+    // bf16-rate path (LDS transpose reads)
+    return ptpp_wgrad_bf16_launch(x, dy, dw, dbias, lengths, B, T, Cin, Cout, ks, dil, pad, ldx, lddy, in_mask, workspace,
+                                  workspace_bytes, reinterpret_cast<hipStream_t>(stream));
   }
   const int nCO = (Cout + 63) / 64, nCI = (Cin + 63) / 64;
   const int tchunks = (T + KR - 1) / KR;

@@ -6,151 +6,313 @@
 // free: tiles are staged row-major [row][channel] with plain 16-byte copies, and each
 // operand fragment is two tr reads (4 rows x 16 channels each).
 //
-// A block owns a 64(co) x 64(ci) tile for a GROUP of up to 5 taps: the dy chunk (32 rows)
-// is staged once and reused by every tap, the x window (32 + (taps-1)*dil rows) serves
-// all taps at shifted row offsets.  Rows are split across blocks (split-K) and combined
-// with f32 atomics.
+// A block owns one (TM co x TN ci) tile of ONE tap and a strided subset of the 32-row
+// K-chunks (split-K).  Wave tile = TM/2 x TN/2 (up to 64x64 = 16 accumulator tiles).
+// Measured: with one chunk in flight a loop iteration costs a full ~1.2 us memory round
+// trip, 5x its MFMA time, and a register pipeline two chunks deep spills.  So the chunks
+// go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a
+// 4-stage ring, three chunks in flight across raw s_barriers with counted vmcnt waits.
+// LDS-DMA writes lane-linear 1 KiB pieces, so the bank swizzle of the transpose reads is
+// applied to the per-lane SOURCE address; rows outside the utterance read a zero page.
+// The bias gradient is one extra MFMA per dy fragment against an all-ones operand.
+//
+// Split-K partials: device-scope f32 atomics run at only ~80 G/s on the 8-XCD part
+// (measured), so with a caller-provided workspace every block STORES its partial tile
+// ([split][tap][co][ci], coalesced) and a second kernel sums the splits in a fixed order
+// and adds into dw: deterministic, and ~10x cheaper than the atomics.  Without a
+// workspace the partials are combined with atomics (fewer splits).
 #include "ptpp_common.h"
+#include <cstdlib>
 
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short v4s;
 typedef __attribute__((ext_vector_type(8))) short v8s;
 
-constexpr int KR = 32;   // rows per K chunk (= one MFMA K)
-constexpr int LS = 72;   // LDS row stride in bf16 elements (64 + 8: 16-byte aligned rows, de-phased banks)
-constexpr int NT = 5;    // taps per block (accumulators: NT x 16 VGPRs)
+constexpr int KR = 32;  // rows per K chunk (one MFMA K-step)
+constexpr int NS = 4;   // LDS ring stages (NS - 1 chunks in flight)
 
+__device__ uint4 g_zero_page[64];  // source of out-of-range rows
+
+// The transpose reads are issued as inline asm: for a compiler-visible LDS read hipcc drains
+// ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)) first, which would serialise the ring.  The
+// kernel counts vmcnt / lgkmcnt itself (wait_vm, lds_fence).
 __device__ __forceinline__ v4s tr_read(const bf16_raw* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)p);
+  v4s r;
+  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) bf16_raw*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a));
+  return r;
 }
-
-// 8 consecutive rows (k = 8g .. 8g+7) of column (c0 + i) for lane l = 16 g + i
-__device__ __forceinline__ bf16x8_t frag(const bf16_raw* tile, int row0, int c0, int lane) {
-  const int g = lane >> 4, i = lane & 15;
-  const bf16_raw* p = tile + (row0 + 8 * g + (i >> 2)) * LS + c0 + 4 * (i & 3);
-  const v4s lo = tr_read(p), hi = tr_read(p + 4 * LS);
+struct Frag {
+  v4s lo, hi;
+};
+// wait for this wave's LDS reads; the operands tie the fragments to the wait so that no
+// consumer can be scheduled above it
+template <int N>
+__device__ __forceinline__ void lds_fence(Frag (&f)[N]) {
+  if constexpr (N == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo),
+                   "+v"(f[3].hi));
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi));
+}
+__device__ __forceinline__ bf16x8_t join(const Frag& f) {
   v8s v;
-  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  v[0] = f.lo[0]; v[1] = f.lo[1]; v[2] = f.lo[2]; v[3] = f.lo[3];
+  v[4] = f.hi[0]; v[5] = f.hi[1]; v[6] = f.hi[2]; v[7] = f.hi[3];
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-__global__ __launch_bounds__(256) void conv1d_wgrad_bf16_kernel(const bf16_raw* __restrict__ x,
-                                                                const bf16_raw* __restrict__ dy, float* __restrict__ dw,
-                                                                float* __restrict__ dbias, const int* __restrict__ lengths,
-                                                                int B, int T_, int Cin, int Cout, int ks, int dil, int pad,
-                                                                int ldx, int lddy, int in_mask, int nCO, int nCI, int nTG,
-                                                                int nsplit, int tchunks) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_raw* dYs = reinterpret_cast<bf16_raw*>(smem);  // [KR][LS]
-  bf16_raw* Xs = dYs + KR * LS;                       // [XR][LS]
+// 16-byte-chunk swizzle of an LDS row of CPR chunks.  A 32-lane group of a tr read touches
+// rows {r0..r0+3, r0+8..r0+11} x two adjacent chunks: give those 8 rows distinct chunk
+// pairs (CPR = 16: one 256-byte row spans all 64 banks) or distinct pairs per row parity
+// (CPR = 8: two rows span the banks).
+template <int CPR>
+__device__ __forceinline__ int sw(int row);
+template <>
+__device__ __forceinline__ int sw<16>(int row) { return ((row & 3) | ((row >> 1) & 4)) << 1; }
+template <>
+__device__ __forceinline__ int sw<8>(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
+
+// 8 consecutive rows (k = 8g .. 8g+7) of column (c0 + i) for lane l = 16 g + i
+template <int TW>
+__device__ __forceinline__ Frag frag(const bf16_raw* tile, int row0, int c0, int lane) {
+  constexpr int CPR = TW / 8;
+  const int g = lane >> 4, i = lane & 15;
+  const int row = row0 + 8 * g + (i >> 2);
+  const int col = c0 + 4 * (i & 3);
+  const bf16_raw* p = tile + row * TW + (((col >> 3) ^ sw<CPR>(row)) << 3) + (col & 7);
+  Frag f;
+  f.lo = tr_read(p);
+  f.hi = tr_read(p + 4 * TW);  // sw(row + 4) == sw(row)
+  return f;
+}
+
+struct WgP {
+  const bf16_raw* x;
+  const bf16_raw* dy;
+  float* dw;
+  float* dbias;
+  const int* lengths;
+  int B, T, Cin, Cout, ks, dil, pad, ldx, lddy, in_mask;
+  int nCO, nCI, nsplit, tchunks;
+  float* ws;  // [nsplit][ks][Cout][Cin] partials, or nullptr -> atomics into dw
+};
+
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int FM, int FN>
+__global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16_kernel(const WgP p, const int* __restrict__ lengths) {
+  constexpr int TM = 2 * FM * 16, TN = 2 * FN * 16;
+  constexpr int CY = TM / 8, CX = TN / 8;          // 16-byte chunks per row
+  constexpr int RY = 64 / CY, RX = 64 / CX;        // rows per 1 KiB piece
+  constexpr int LY = KR / RY / 4, LX = KR / RX / 4;  // pieces per wave and chunk
+  constexpr int LPW = LY + LX;                     // LDS-DMA instructions per wave and chunk
+  constexpr int STAGE = KR * (TM + TN);            // elements per ring stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object (see header)
+  bf16_raw* S = reinterpret_cast<bf16_raw*>(smem);  // [NS][dy: KR x TM | x: KR x TN]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
 
-  int bid = blockIdx.x;
-  const int cot = bid % nCO; bid /= nCO;
-  const int cit = bid % nCI; bid /= nCI;
-  const int tg = bid % nTG;  bid /= nTG;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = bid % p.nCO; bid /= p.nCO;
+  const int cit = bid % p.nCI; bid /= p.nCI;
+  const int j = bid % p.ks;    bid /= p.ks;
   const int split = bid;
-  const int co0 = cot * 64, ci0 = cit * 64;
-  const int j0 = tg * NT, nt = min(NT, ks - j0);
-  const int XR = KR + (nt - 1) * dil;
+  const int co0 = cot * TM, ci0 = cit * TN;
+  const int shift = j * p.dil - p.pad;
 
-  f32x4 acc[NT][2][2];
+  f32x4 acc[FM][FN], accb[FM];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int a = 0; a < FM; ++a) {
+    accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) acc[j][a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-  const bool do_bias = dbias && cit == 0 && tg == 0;
+    for (int c = 0; c < FN; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = p.dbias && cit == 0 && j == 0 && wc == 0;  // wave-uniform
+  const int total = p.B * p.tchunks;
+  const int n = split < total ? (total - split + p.nsplit - 1) / p.nsplit : 0;  // chunks of this block
+  const char* zero = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
 
-  const int total = B * tchunks;
-  for (int ch = split; ch < total; ch += nsplit) {
-    const int b = ch / tchunks, tb = (ch % tchunks) * KR;
-    const int Tin = (in_mask && lengths) ? min(lengths[b], T_) : T_;
-    // stage dy chunk: KR rows x 8 chunks of 8 channels
-    {
-      const int row = tid >> 3, c8 = (tid & 7) * 8;
-      const int t = tb + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (t < T_ && co0 + c8 < Cout) v = *reinterpret_cast<const uint4*>(dy + ((int64_t)b * T_ + t) * lddy + co0 + c8);
-      *reinterpret_cast<uint4*>(dYs + row * LS + c8) = v;
+  // per-lane source coordinates inside a chunk (fixed for the whole loop)
+  int yrow[LY], ycol[LY], xrow[LX], xcol[LX];
+#pragma unroll
+  for (int q = 0; q < LY; ++q) {
+    const int pi = wave * LY + q;
+    yrow[q] = pi * RY + lane / CY;
+    ycol[q] = ((lane % CY) ^ sw<CY>(yrow[q])) * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < LX; ++q) {
+    const int pi = wave * LX + q;
+    xrow[q] = pi * RX + lane / CX;
+    xcol[q] = ((lane % CX) ^ sw<CX>(xrow[q])) * 8;
+  }
+
+  auto issue = [&](int i) {  // chunk number i of this block -> ring stage i % NS
+    const int ch = split + i * p.nsplit;
+    const int b = ch / p.tchunks, tb = (ch - b * p.tchunks) * KR;
+    const int Tin = lengths ? min(lengths[b], p.T) : p.T;
+    bf16_raw* st = S + (i % NS) * STAGE;
+    const bf16_raw* dyb = p.dy + (int64_t)b * p.T * p.lddy + co0;
+    const bf16_raw* xb = p.x + (int64_t)b * p.T * p.ldx + ci0;
+#pragma unroll
+    for (int q = 0; q < LY; ++q) {
+      const int t = tb + yrow[q];
+      const bool ok = t < p.T && co0 + ycol[q] < p.Cout;
+      const char* src = ok ? reinterpret_cast<const char*>(dyb + (int64_t)t * p.lddy + ycol[q]) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + (wave * LY + q) * 512), 16, 0, 0);
     }
-    // stage x window
-    const int xbase = tb + j0 * dil - pad;
-    for (int idx = tid; idx < XR * 8; idx += 256) {
-      const int row = idx >> 3, c8 = (idx & 7) * 8;
-      const int ts = xbase + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ts >= 0 && ts < Tin && ci0 + c8 < Cin) v = *reinterpret_cast<const uint4*>(x + ((int64_t)b * T_ + ts) * ldx + ci0 + c8);
-      *reinterpret_cast<uint4*>(Xs + row * LS + c8) = v;
+#pragma unroll
+    for (int q = 0; q < LX; ++q) {
+      const int t = tb + xrow[q], ts = t + shift;
+      const bool ok = t < p.T && ts >= 0 && ts < Tin && ci0 + xcol[q] < p.Cin;
+      const char* src = ok ? reinterpret_cast<const char*>(xb + (int64_t)ts * p.ldx + xcol[q]) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + KR * TM + (wave * LX + q) * 512), 16, 0, 0);
     }
-    __syncthreads();
-    bf16x8_t af[2];
+  };
+
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, v8s{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
+
 #pragma unroll
-    for (int a = 0; a < 2; ++a) af[a] = frag(dYs, 0, wr * 32 + a * 16, lane);
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < n) issue(i);
+  for (int i = 0; i < n; ++i) {
+    // chunk i has landed once at most the loads of the (up to NS - 2) younger chunks are outstanding
+    const int younger = min(n - 1 - i, NS - 2);
+    if (younger == 2) wait_vm<2 * LPW>();
+    else if (younger == 1) wait_vm<LPW>();
+    else wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's pieces of chunk i visible; everyone done reading chunk i - 1
+    if (i + NS - 1 < n) issue(i + NS - 1);  // into the stage chunk i - 1 just vacated
+    const bf16_raw* Yb = S + (i % NS) * STAGE;
+    const bf16_raw* Xb = Yb + KR * TM;
+    Frag fa[FM], fb[FN];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (j < nt) {
-        bf16x8_t bf[2];
+    for (int a = 0; a < FM; ++a) fa[a] = frag<TM>(Yb, 0, (wr * FM + a) * 16, lane);
 #pragma unroll
-        for (int c = 0; c < 2; ++c) bf[c] = frag(Xs, j * dil, wc * 32 + c * 16, lane);
+    for (int c = 0; c < FN; ++c) fb[c] = frag<TN>(Xb, 0, (wc * FN + c) * 16, lane);
+    lds_fence(fa);
+    lds_fence(fb);
+    bf16x8_t af[FM], bfr[FN];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < FM; ++a) af[a] = join(fa[a]);
 #pragma unroll
-          for (int c = 0; c < 2; ++c)
-            acc[j][a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[c], acc[j][a][c], 0, 0, 0);
-      }
+    for (int c = 0; c < FN; ++c) bfr[c] = join(fb[c]);
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int c = 0; c < FN; ++c)
+        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[c], acc[a][c], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int a = 0; a < FM; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
     }
-    if (do_bias && tid < 64) {
-#pragma unroll 8
-      for (int r = 0; r < KR; ++r) bsum += bf16_to_f32(dYs[r * LS + tid]);
-    }
-    __syncthreads();
   }
 
   // D[i = co (rows 4*(lane>>4) + r)][j = ci (col lane&15)]
   const int lr = lane & 15, lg = lane >> 4;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    if (j < nt) {
+  for (int a = 0; a < FM; ++a)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+    for (int c = 0; c < FN; ++c) {
+      const int ci = ci0 + (wc * FN + c) * 16 + lr;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int ci = ci0 + wc * 32 + c * 16 + lr;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = co0 + wr * 32 + a * 16 + lg * 4 + r;
-            if (co < Cout && ci < Cin) atomicAdd(dw + ((int64_t)co * Cin + ci) * ks + j0 + j, acc[j][a][c][r]);
-          }
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + (wr * FM + a) * 16 + lg * 4 + r;
+        if (co < p.Cout && ci < p.Cin) {
+          if (p.ws) p.ws[(((int64_t)split * p.ks + j) * p.Cout + co) * p.Cin + ci] = acc[a][c][r];
+          else atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * p.ks + j, acc[a][c][r]);
         }
+      }
     }
+  if (do_bias && lr == 0) {  // every column of accb holds the row sums
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + (wr * FM + a) * 16 + lg * 4 + r;
+        if (co < p.Cout) atomicAdd(p.dbias + co, accb[a][r]);
+      }
   }
-  if (do_bias && tid < 64 && co0 + tid < Cout) atomicAdd(dbias + co0 + tid, bsum);
+}
+
+// dw[co][ci][j] += sum_s ws[s][j][co][ci]  (fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
+                                                           int Cout, int Cin, int ks) {
+  const int64_t E = (int64_t)ks * Cout * Cin;
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= E) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(ws + e);
+  for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)k * E + e);
+  const int j = (int)(e / ((int64_t)Cout * Cin));
+  const int64_t rem = e - (int64_t)j * Cout * Cin;  // co * Cin + ci  (Cin % 4 == 0: the 4 share co)
+  float* d = dw + rem * ks + j;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[(int64_t)k * ks] += s[k];
+}
+
+template <int FM, int FN>
+int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
+  constexpr int TM = 2 * FM * 16, TN = 2 * FN * 16;
+  p.nCO = (p.Cout + TM - 1) / TM;
+  p.nCI = (p.Cin + TN - 1) / TN;
+  p.tchunks = (p.T + KR - 1) / KR;
+  const int total = p.B * p.tchunks;
+  const int tiles = p.nCO * p.nCI * p.ks;
+  const size_t ebytes = (size_t)p.ks * p.Cout * p.Cin * sizeof(float);
+  int nsplit;
+  if (p.ws && ws_bytes >= ebytes) {
+    nsplit = (384 + tiles - 1) / tiles;  // 1-2 resident blocks per CU (measured optimum 256..512 blocks)
+    if (nsplit > 48) nsplit = 48;        // few output tiles: more splits only add partial traffic
+    if ((size_t)nsplit * ebytes > ws_bytes) nsplit = (int)(ws_bytes / ebytes);
+    if (nsplit > (total + 7) / 8) nsplit = (total + 7) / 8;
+  } else {
+    p.ws = nullptr;
+    // atomics: ~80 G/s device-wide, so few splits -- about 2 M atomics per launch
+    nsplit = (int)((size_t)(8u << 20) / ebytes);
+    if (nsplit > (512 + tiles - 1) / tiles) nsplit = (512 + tiles - 1) / tiles;
+    if (nsplit > (total + 3) / 4) nsplit = (total + 3) / 4;
+  }
+  if (nsplit < 1) nsplit = 1;
+  if (const char* e = getenv("PTPP_TUNE_NSPLIT")) nsplit = atoi(e) < total ? atoi(e) : total;
+  p.nsplit = nsplit;
+  const size_t smem = (size_t)NS * KR * (TM + TN) * sizeof(bf16_raw);
+  hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<FM, FN>), dim3((unsigned)((int64_t)tiles * nsplit)), dim3(256), smem, st, p,
+                     p.in_mask ? p.lengths : nullptr);
+  PTPP_CHECK_LAUNCH("conv1d_wgrad(bf16)");
+  if (p.ws) {
+    const int64_t n4 = (int64_t)p.ks * p.Cout * p.Cin / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.ws, p.dw, nsplit, p.Cout,
+                       p.Cin, p.ks);
+    PTPP_CHECK_LAUNCH("conv1d_wgrad(reduce)");
+  }
+  return PTPP_OK;
 }
 
 }  // namespace
 
 // called by ptpp_conv1d_wgrad for bf16 tensors with 16-byte aligned rows
 int ptpp_wgrad_bf16_launch(const void* x, const void* dy, float* dw, float* dbias, const int32_t* lengths, int B, int T,
-                           int Cin, int Cout, int ks, int dil, int pad, int ldx, int lddy, int in_mask, hipStream_t st) {
-  const int nCO = (Cout + 63) / 64, nCI = (Cin + 63) / 64, nTG = (ks + NT - 1) / NT;
-  const int tchunks = (T + KR - 1) / KR;
-  const int total = B * tchunks;
-  const int tiles = nCO * nCI * nTG;
-  int nsplit = (1024 + tiles - 1) / tiles;  // ~4 blocks per CU
-  if (nsplit > total) nsplit = total;
-  if (nsplit < 1) nsplit = 1;
-  const int ntmax = ks < NT ? ks : NT;
-  const size_t smem = (size_t)(KR + KR + (ntmax - 1) * dil) * LS * sizeof(bf16_raw);
-  if (smem > 64 * 1024) return PTPP_ENOTSUP;
-  hipLaunchKernelGGL(conv1d_wgrad_bf16_kernel, dim3((unsigned)((int64_t)tiles * nsplit)), dim3(256), smem, st,
-                     (const bf16_raw*)x, (const bf16_raw*)dy, dw, dbias, lengths, B, T, Cin, Cout, ks, dil, pad, ldx, lddy,
-                     in_mask, nCO, nCI, nTG, nsplit, tchunks);
-  PTPP_CHECK_LAUNCH("conv1d_wgrad(bf16)");
-  return PTPP_OK;
+                           int Cin, int Cout, int ks, int dil, int pad, int ldx, int lddy, int in_mask, void* ws,
+                           size_t ws_bytes, hipStream_t st) {
+  WgP p;
+  p.ws = ((uintptr_t)ws % 16) == 0 ? (float*)ws : nullptr;
+  p.x = (const bf16_raw*)x; p.dy = (const bf16_raw*)dy; p.dw = dw; p.dbias = dbias; p.lengths = lengths;
+  p.B = B; p.T = T; p.Cin = Cin; p.Cout = Cout; p.ks = ks; p.dil = dil; p.pad = pad; p.ldx = ldx; p.lddy = lddy;
+  p.in_mask = in_mask;
+  bool bigM = Cout > 64, bigN = Cin > 64;
+  if (const char* e = getenv("PTPP_TUNE_TILE")) { bigM = bigM && (atoi(e) & 2); bigN = bigN && (atoi(e) & 1); }
+  if (bigM && bigN) return launch<4, 4>(p, ws_bytes, st);
+  if (bigM) return launch<4, 2>(p, ws_bytes, st);
+  if (bigN) return launch<2, 4>(p, ws_bytes, st);
+  return launch<2, 2>(p, ws_bytes, st);
 }

@@ -53,12 +53,92 @@ def packed(w, dtype, mode=0):
     return wp
 
 
+_cat_cache = {}
+
+
+def _cat_cached(ts, kind, make):
+    """Cache of a tensor derived from a LIST of live parameters (fused projections)."""
+    key = (tuple(id(t) for t in ts), kind)
+    vers = tuple((t._version, t.data_ptr()) for t in ts)
+    ent = _cat_cache.get(key)
+    if ent is not None and ent[0] == vers and all(r() is t for r, t in zip(ent[2], ts)):
+        return ent[1]
+    val = make()
+    _cat_cache[key] = (vers, val, [weakref.ref(t, lambda _r, k=key: _cat_cache.pop(k, None)) for t in ts])
+    return val
+
+
+def packed_cat(ws, dtype, mode=0):
+    """Packed operand of the row-wise concatenation of several (Cout_i, Cin[,1]) weights."""
+    return _cat_cached(ws, ("w", mode, dtype), lambda: ops.pack_conv_weight(
+        torch.cat([w.detach().reshape(w.shape[0], -1) for w in ws], dim=0), dtype, mode))
+
+
+def bias_cat(bs):
+    return _cat_cached(bs, "b", lambda: torch.cat([b.detach().float() for b in bs], dim=0))
+
+
 def clear_caches():
     _pack_cache.clear()
+    _cat_cache.clear()
 
 
 def _f32c(t):
     return None if t is None else t.detach().float().contiguous()
+
+
+# ----------------------------------------------------------------------------
+# direct gradient accumulation: the weight-gradient kernels ADD (atomics) into whatever
+# f32 buffer they are given.  When the trainer has laid all ``p.grad`` out as views of one
+# pre-zeroed flat buffer (parallel.FlatGradReducer), the backward functions hand the kernels
+# ``p.grad`` itself and return None to autograd: no zero-fill, no ``grad +=`` launch, no
+# temporary per parameter.  Autograd's post-accumulate hooks do not fire for such
+# parameters, so uses are counted in forward and the reducer is notified when the last
+# pending use of a parameter has been accumulated.
+# ----------------------------------------------------------------------------
+_direct = {"on": False, "notify": None, "uses": {}}
+
+
+def enable_direct_grads(on=True, notify=None):
+    _direct["on"], _direct["notify"] = bool(on), notify
+    _direct["uses"].clear()
+
+
+def reset_direct_uses():
+    _direct["uses"].clear()
+
+
+def direct_grads_enabled():
+    return _direct["on"]
+
+
+def _sink(p):
+    """``p.grad`` if gradients of parameter ``p`` can be accumulated in place, else None."""
+    if not _direct["on"] or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous():
+        return None
+    return g
+
+
+def _use(p):
+    """forward side: one more pending in-place accumulation into p.grad"""
+    if _direct["notify"] is not None:
+        u = _direct["uses"]
+        u[id(p)] = u.get(id(p), 0) + 1
+
+
+def _done(p):
+    """backward side: an in-place accumulation into p.grad has been enqueued"""
+    if _direct["notify"] is not None:
+        u = _direct["uses"]
+        n = u.get(id(p), 1) - 1
+        if n <= 0:
+            u.pop(id(p), None)
+            _direct["notify"](p)
+        else:
+            u[id(p)] = n
 
 
 def _kc(dtype):
@@ -90,6 +170,13 @@ class Conv1dFn(Function):
                        lengths=cfg.lengths, in_mask=cfg.in_mask, out_mask=cfg.out_mask, res=res,
                        out_scale=cfg.out_scale, drop_p=cfg.drop_p, drop_seed=seed)
         ctx.cfg, ctx.seed, ctx.has_res, ctx.has_b = cfg, seed, res is not None, b is not None
+        # in-place gradient targets (None -> autograd accumulates the returned tensors)
+        ctx.direct = None
+        if cin % kc == 0 and cout % kc == 0 and _sink(w) is not None and (b is None or _sink(b) is not None):
+            ctx.direct = (w, b)
+            _use(w)
+            if b is not None:
+                _use(b)
         ctx.save_for_backward(x, w, y if cfg.act == "relu" else None)
         return y
 
@@ -125,7 +212,14 @@ class Conv1dFn(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv1d(dz, packed(wk, dz.dtype, mode=1), None, cin, ks=ks, dil=cfg.dil,
                             pad=(ks - 1) * cfg.dil - cfg.pad, lengths=cfg.lengths, out_mask=cfg.in_mask)
-        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+        if ctx.direct is not None:
+            pw, pb = ctx.direct
+            ops.conv1d_wgrad(x, dz, cin, cout, ks, cfg.dil, cfg.pad, cfg.lengths, cfg.in_mask, pb is not None,
+                             dw_out=pw.grad, db_out=pb.grad if pb is not None else None)
+            _done(pw)
+            if pb is not None:
+                _done(pb)
+        elif ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             xk = x if cin % 4 == 0 else torch.nn.functional.pad(x, (0, 4 - cin % 4))
             dw, db = ops.conv1d_wgrad(xk, dz, cin, coutp, ks, cfg.dil, cfg.pad, cfg.lengths, cfg.in_mask, ctx.has_b)
             dw = dw[:cout].reshape(w.shape)
@@ -135,6 +229,57 @@ class Conv1dFn(Function):
 
 def conv1d(x, w, b=None, res=None, **kw):
     return Conv1dFn.apply(x, w, b, res, conv_cfg(**kw))
+
+
+class FusedLinearFn(Function):
+    """y = x @ cat(w_0..w_n)^T + cat(b_0..b_n): several nn.Linear layers that read the same
+    input (q|k|v) as ONE GEMM, each layer keeping its own parameters and gradients."""
+
+    @staticmethod
+    def forward(ctx, x, n, *params):
+        ws, bs = params[:n], params[n:]
+        ctx.n, ctx.couts = n, [w.shape[0] for w in ws]
+        y = ops.conv1d(x, packed_cat(ws, x.dtype), bias_cat(bs), sum(ctx.couts))
+        ctx.direct = all(_sink(p) is not None for p in params)
+        if ctx.direct:
+            for p in params:
+                _use(p)
+        ctx.params = params  # long-lived leaves: kept by reference (their .grad is the target)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        params, n = ctx.params, ctx.n
+        ws, bs = params[:n], params[n:]
+        dy = dy.contiguous()
+        cin = x.shape[-1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv1d(dy, packed_cat(ws, dy.dtype, mode=1), None, cin)
+        gw, gb, c0 = [], [], 0
+        for w, b, co in zip(ws, bs, ctx.couts):
+            dw, db = ops.conv1d_wgrad(x, dy[:, :, c0 : c0 + co], cin, co, 1, 1, 0,
+                                      dw_out=w.grad if ctx.direct else None, db_out=b.grad if ctx.direct else None)
+            c0 += co
+            if ctx.direct:
+                _done(w)
+                _done(b)
+                gw.append(None)
+                gb.append(None)
+            else:
+                gw.append(dw.view_as(w))
+                gb.append(db)
+        return (dx, None, *gw, *gb)
+
+
+def linear_fused(x, layers):
+    """layers: nn.Linear modules sharing the input x (B, T, Cin) -> (B, T, sum Cout_i)."""
+    ws = [l.weight for l in layers]
+    bs = [l.bias for l in layers]
+    return FusedLinearFn.apply(x, len(ws), *ws, *bs)
 
 
 def linear(x, w, b=None, **kw):
@@ -161,6 +306,11 @@ class LayerNormFn(Function):
                                                 drop_out=s_out)
         ctx.cfg, ctx.s_in, ctx.s_out, ctx.has_res, ctx.fused_in = cfg, s_in, s_out, res is not None, fused_in
         ctx.gshape = gamma.shape
+        ctx.direct = None
+        if _sink(gamma) is not None and _sink(beta) is not None:
+            ctx.direct = (gamma, beta)
+            _use(gamma)
+            _use(beta)
         ctx.save_for_backward(x, xsum if fused_in else None, g, mean, rstd)
         return y
 
@@ -170,10 +320,19 @@ class LayerNormFn(Function):
         x, xsum, g, mean, rstd = ctx.saved_tensors
         cfg = ctx.cfg
         want_dz = cfg.act_in is not None or cfg.drop_in > 0
+        pg, pb = ctx.direct if ctx.direct is not None else (None, None)
         dsum, dz, dg, db = ops.layernorm_bwd(dy, xsum if ctx.fused_in else x, g, mean, rstd, cfg.lengths, cfg.out_mask,
                                              z=x if cfg.act_in is not None else None, act_in=cfg.act_in,
-                                             drop_in=ctx.s_in, drop_out=ctx.s_out, want_dz=want_dz)
-        return (dz if want_dz else dsum), (dsum if ctx.has_res else None), dg.view(ctx.gshape), db.view(ctx.gshape), None
+                                             drop_in=ctx.s_in, drop_out=ctx.s_out, want_dz=want_dz,
+                                             dgamma_out=pg.grad if pg is not None else None,
+                                             dbeta_out=pb.grad if pb is not None else None)
+        if pg is not None:
+            _done(pg)
+            _done(pb)
+            dg = db = None
+        else:
+            dg, db = dg.view(ctx.gshape), db.view(ctx.gshape)
+        return (dz if want_dz else dsum), (dsum if ctx.has_res else None), dg, db, None
 
 
 def layer_norm(x, gamma, beta, eps, res=None, lengths=None, out_mask=False, act_in=None, drop_in=0.0, drop_out=0.0):
@@ -195,6 +354,11 @@ class AttentionFn(Function):
         octx, probs = ops.attention_fwd(q, k, v, pos, u, vb, lengths, heads, variant, save_probs=need_bwd)
         ctx.heads, ctx.variant, ctx.lengths = heads, variant, lengths
         ctx.ushape = bias_u.shape if bias_u is not None else None
+        ctx.direct = None
+        if need_bwd and variant == "new" and _sink(bias_u) is not None and _sink(bias_v) is not None:
+            ctx.direct = (bias_u, bias_v)
+            _use(bias_u)
+            _use(bias_v)
         ctx.save_for_backward(qkv, pos, u, vb, probs)
         return octx
 
@@ -205,12 +369,19 @@ class AttentionFn(Function):
         B, T, C3 = qkv.shape
         C = C3 // 3
         dqkv = torch.empty_like(qkv)
+        pu, pv = ctx.direct if ctx.direct is not None else (None, None)
         dpos, du, dvb = ops.attention_bwd(qkv[:, :, :C], qkv[:, :, C : 2 * C], qkv[:, :, 2 * C :], pos, u, vb, probs,
                                           dctx, ctx.lengths, ctx.heads, ctx.variant, dqkv[:, :, :C],
-                                          dqkv[:, :, C : 2 * C], dqkv[:, :, 2 * C :])
+                                          dqkv[:, :, C : 2 * C], dqkv[:, :, 2 * C :],
+                                          du_out=pu.grad if pu is not None else None,
+                                          dvb_out=pv.grad if pv is not None else None)
         if dpos is not None:
             dpos = dpos.to(pos.dtype)
             du, dvb = du.view(ctx.ushape), dvb.view(ctx.ushape)
+        if pu is not None:
+            _done(pu)
+            _done(pv)
+            du = dvb = None
         return dqkv, dpos, du, dvb, None, None, None
 
 
@@ -261,9 +432,9 @@ def posenc(x, pe, scale, drop_p=0.0):
 # ----------------------------------------------------------------------------
 def diffnet_cond_all(cond, cond_ws, cond_bs):
     """All layers' conditioner projections as ONE GEMM: (B,T,Cc) -> (B,T,L*2C)."""
-    w = torch.cat([cw.reshape(cw.shape[0], -1) for cw in cond_ws], dim=0)
-    b = torch.cat(list(cond_bs), dim=0)
-    return ops.conv1d(cond, ops.pack_conv_weight(w, cond.dtype), _f32c(b), w.shape[0]), w
+    cond_ws = list(cond_ws)
+    rows = sum(cw.shape[0] for cw in cond_ws)
+    return ops.conv1d(cond, packed_cat(cond_ws, cond.dtype), bias_cat(list(cond_bs)), rows), cond_ws
 
 
 def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
@@ -296,6 +467,10 @@ class DiffNetStackFn(Function):
         skip, saved = diffnet_stack_forward(h0, cond_all, dsteps, [(w[0], w[1], w[4], w[5]) for w in ws], lengths,
                                             cycle, save=True)
         ctx.L, ctx.cycle, ctx.lengths, ctx.saved, ctx.ws, ctx.wc = L, cycle, lengths, saved, ws, wc
+        ctx.direct = all(_sink(t) is not None for t in flat)
+        if ctx.direct:
+            for t in flat:
+                _use(t)
         ctx.save_for_backward(cond)
         return (skip * (1.0 / math.sqrt(L))).to(h0.dtype)
 
@@ -318,24 +493,38 @@ class DiffNetStackFn(Function):
             dil_w, _, _, _, out_w, _ = ws[l]
             d = 2 ** (l % ctx.cycle)
             do = ops.diffnet_post_bwd(gx, gS, ctx.lengths)
-            dwo, dbo = ops.conv1d_wgrad(g, do, C, 2 * C, 1, 1, 0)
+            tg = [t.grad if ctx.direct else None for t in ws[l]]
+            dwo, dbo = ops.conv1d_wgrad(g, do, C, 2 * C, 1, 1, 0, dw_out=tg[4], db_out=tg[5])
             dg = ops.conv1d(do, packed(out_w, dt, mode=1), None, C)
             da = ops.gate_bwd(a, dg, dcond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
-            dwd, dbd = ops.conv1d_wgrad(yin, da, C, 2 * C, 3, d, d)
+            dwd, dbd = ops.conv1d_wgrad(yin, da, C, 2 * C, 3, d, d, dw_out=tg[0], db_out=tg[1])
             gx = ops.conv1d(da, packed(dil_w, dt, mode=1), None, C, ks=3, dil=d, pad=d, res=gx, res_scale=r2)
             sn = ops.colsum_batch(gx)
             dd[:, l] = sn - sx * r2
             sx = sn
-            grads[6 * l + 0], grads[6 * l + 1] = dwd.view_as(dil_w), dbd
-            grads[6 * l + 4], grads[6 * l + 5] = dwo.view_as(out_w), dbo
+            if ctx.direct:
+                for i in (0, 1, 4, 5):
+                    _done(ws[l][i])
+            else:
+                grads[6 * l + 0], grads[6 * l + 1] = dwd.view_as(dil_w), dbd
+                grads[6 * l + 4], grads[6 * l + 5] = dwo.view_as(out_w), dbo
             ctx.saved[l] = None
         dcond = None
         if ctx.needs_input_grad[1]:
-            dcond = ops.conv1d(dcond_all, ops.pack_conv_weight(ctx.wc, dt, mode=1), None, cond.shape[-1])
-        dwc, dbc = ops.conv1d_wgrad(cond, dcond_all, cond.shape[-1], L * 2 * C, 1, 1, 0)
-        for l in range(L):
-            grads[6 * l + 2] = dwc[l * 2 * C : (l + 1) * 2 * C].view_as(ws[l][2])
-            grads[6 * l + 3] = dbc[l * 2 * C : (l + 1) * 2 * C]
+            dcond = ops.conv1d(dcond_all, packed_cat(ctx.wc, dt, mode=1), None, cond.shape[-1])
+        if ctx.direct:
+            # the fused conditioner GEMM's weight gradient, one column block per layer, straight into
+            # that layer's own gradient buffer
+            for l in range(L):
+                ops.conv1d_wgrad(cond, dcond_all[:, :, l * 2 * C : (l + 1) * 2 * C], cond.shape[-1], 2 * C, 1, 1, 0,
+                                 dw_out=ws[l][2].grad, db_out=ws[l][3].grad)
+                _done(ws[l][2])
+                _done(ws[l][3])
+        else:
+            dwc, dbc = ops.conv1d_wgrad(cond, dcond_all, cond.shape[-1], L * 2 * C, 1, 1, 0)
+            for l in range(L):
+                grads[6 * l + 2] = dwc[l * 2 * C : (l + 1) * 2 * C].view_as(ws[l][2])
+                grads[6 * l + 3] = dbc[l * 2 * C : (l + 1) * 2 * C]
         return (gx, dcond, dd, None, None, *grads)
 
 

@@ -90,7 +90,10 @@ class PromptTTSMDNDurCFG(nn.Module):
         dur = duration.squeeze(1).float()
         log_dur = torch.where(dur != 0, torch.log(dur.clamp_min(1e-30)), dur)  # to_log_scale, out of place
         pmb = pmask.unsqueeze(-1)
-        loss_dur = mdn_loss(*dur_out, log_dur.unsqueeze(-1), reduce=False, mask=pmb).masked_select(pmb).mean()
+        # reference: .masked_select(mask).mean() -- a dynamic-size gather whose size the host must
+        # wait for; the masked mean below is the same number without the device sync
+        nll = mdn_loss(*dur_out, log_dur.unsqueeze(-1), reduce=False, mask=pmb)
+        loss_dur = torch.where(pmb, nll, torch.zeros_like(nll)).sum() / pmb.sum()
 
         loss_cf0 = (cf0_pred - log_cf0.squeeze(1)).abs().sum() / n_frames
         loss_vuv = (vuv_pred - vuv.squeeze(1)).abs().sum() / n_frames

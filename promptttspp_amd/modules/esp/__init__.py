@@ -87,9 +87,7 @@ class RelPositionMultiHeadedAttention(nn.Module):
         assert dropout_rate == 0.0, "attention dropout is 0 in every reference config"
 
     def cl(self, x, pos_emb, lengths, res, out_drop):
-        wqkv = torch.cat([self.linear_q.weight, self.linear_k.weight, self.linear_v.weight], dim=0)
-        bqkv = torch.cat([self.linear_q.bias, self.linear_k.bias, self.linear_v.bias], dim=0)
-        qkv = PF.linear(x, wqkv, bqkv)
+        qkv = PF.linear_fused(x, (self.linear_q, self.linear_k, self.linear_v))
         pp = PF.linear(pos_emb.unsqueeze(0), self.linear_pos.weight)[0]
         ctx = PF.attention(qkv, pp, self.pos_bias_u, self.pos_bias_v, lengths, self.h, self.variant)
         # x = residual + dropout(att * mask)

@@ -58,8 +58,15 @@ class BertWrapper(nn.Module):
         ids, am = self.tokenize(prompts, device)
         amp = compute_dtype() == torch.bfloat16 and ids.is_cuda
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            out = self.model(input_ids=ids, attention_mask=am).last_hidden_state
-        return out[:, 0, :].float()
+            # BertModel.forward, layer by layer (bit-identical, checked on CPU): the library's
+            # mask helper inspects the mask on the HOST (mask.all()), a device sync that stalls
+            # the launch queue once per step.  Same modules, same state-dict keys.
+            h = self.model.embeddings(input_ids=ids)
+            ext = (1.0 - am[:, None, None, :].to(h.dtype)) * torch.finfo(h.dtype).min
+            for layer in self.model.encoder.layer:
+                out = layer(h, attention_mask=ext)
+                h = out[0] if isinstance(out, tuple) else out
+        return h[:, 0, :].float()
 
 
 class PromptEncoder(nn.Module):

@@ -136,16 +136,44 @@ def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mas
     return y
 
 
-def conv1d_wgrad(x, dy, cin, cout, ks, dil, pad, lengths=None, in_mask=False, want_bias=True):
-    """Returns (dw (Cout,Cin,ks) f32, dbias (Cout) f32 or None)."""
+_WS_BYTES = 64 << 20
+_ws = {}
+
+
+def workspace(device):
+    """Per-device scratch for the deterministic split-K reduction of the weight gradients.
+    One buffer is enough: its users are ordered on the stream."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    w = _ws.get(key)
+    if w is None:
+        w = _ws[key] = torch.empty(_WS_BYTES, device=device, dtype=torch.uint8)
+    return w
+
+
+def _acc_target(t, n):
+    """An f32 contiguous accumulation target handed in by the caller (e.g. ``p.grad``)."""
+    assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+    return t
+
+
+def conv1d_wgrad(x, dy, cin, cout, ks, dil, pad, lengths=None, in_mask=False, want_bias=True, dw_out=None,
+                 db_out=None):
+    """Returns (dw (Cout,Cin,ks) f32, dbias (Cout) f32 or None).  ``dw_out`` / ``db_out``: f32 buffers the
+    kernel ACCUMULATES into (it adds with atomics) instead of fresh zero-filled ones."""
     _need_gpu(x)
     B, T, _ = x.shape
-    dw = torch.zeros((cout, cin, ks), device=x.device, dtype=torch.float32)
-    db = torch.zeros((cout,), device=x.device, dtype=torch.float32) if want_bias else None
+    dw = _acc_target(dw_out, cout * cin * ks) if dw_out is not None else \
+        torch.zeros((cout, cin, ks), device=x.device, dtype=torch.float32)
+    db = None
+    if want_bias:
+        db = _acc_target(db_out, cout) if db_out is not None else \
+            torch.zeros((cout,), device=x.device, dtype=torch.float32)
     lengths = i32(lengths, x.device)
+    ws = workspace(x.device)
     check(
         _lib.load().ptpp_conv1d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(lengths), B, T, cin, cout, ks, dil,
-                                      pad, _ld(x), _ld(dy), int(bool(in_mask)), dtype_code(x.dtype), _stream()),
+                                      pad, _ld(x), _ld(dy), int(bool(in_mask)), dtype_code(x.dtype), _ptr(ws), ws.numel(),
+                                      _stream()),
         "ptpp_conv1d_wgrad",
     )
     return dw, db
@@ -192,15 +220,17 @@ def layernorm_fwd(x, gamma, beta, eps, res=None, lengths=None, out_mask=False, s
 
 
 def layernorm_bwd(dy, xsum, gamma, mean, rstd, lengths=None, out_mask=False, z=None, act_in=None, drop_in=(0.0, 0),
-                  drop_out=(0.0, 0), want_dz=False):
-    """Returns (dsum, dz or None, dgamma, dbeta)."""
+                  drop_out=(0.0, 0), want_dz=False, dgamma_out=None, dbeta_out=None):
+    """Returns (dsum, dz or None, dgamma, dbeta); ``*_out``: f32 buffers to accumulate into."""
     _need_gpu(dy)
     dy = dy.contiguous()
     B, T, C = dy.shape
     dsum = torch.empty_like(dy)
     dz = torch.empty_like(dy) if want_dz else None
-    dgamma = torch.zeros((C,), device=dy.device, dtype=torch.float32)
-    dbeta = torch.zeros((C,), device=dy.device, dtype=torch.float32)
+    dgamma = _acc_target(dgamma_out, C) if dgamma_out is not None else \
+        torch.zeros((C,), device=dy.device, dtype=torch.float32)
+    dbeta = _acc_target(dbeta_out, C) if dbeta_out is not None else \
+        torch.zeros((C,), device=dy.device, dtype=torch.float32)
     lengths = i32(lengths, dy.device)
     check(
         _lib.load().ptpp_layernorm_bwd(_ptr(dy), _ptr(xsum), _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dsum),
@@ -235,7 +265,8 @@ def attention_fwd(q, k, v, pos, bias_u, bias_v, lengths, heads, variant, save_pr
     return ctx, probs
 
 
-def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, variant, dq, dk_, dv):
+def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, variant, dq, dk_, dv, du_out=None,
+                  dvb_out=None):
     """dq/dk_/dv: preallocated (B,T,C) views sharing a row stride (slices of a
     (B,T,3C) buffer).  Returns (dpos (L,C) f32 or None, du, dvb)."""
     _need_gpu(q)
@@ -246,8 +277,9 @@ def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, var
     dpos = du = dvb = None
     if variant == "new":
         dpos = torch.empty((2 * T - 1, C), device=q.device, dtype=torch.float32)
-        du = torch.zeros((C,), device=q.device, dtype=torch.float32)
-        dvb = torch.zeros((C,), device=q.device, dtype=torch.float32)
+        du = _acc_target(du_out, C) if du_out is not None else torch.zeros((C,), device=q.device, dtype=torch.float32)
+        dvb = _acc_target(dvb_out, C) if dvb_out is not None else \
+            torch.zeros((C,), device=q.device, dtype=torch.float32)
     lengths = i32(lengths, q.device)
     check(
         _lib.load().ptpp_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(pos), _ptr(bias_u), _ptr(bias_v), _ptr(probs),

@@ -9,13 +9,18 @@ and each bucket's all-reduce is issued from a post-accumulate hook as soon as th
 last gradient of the bucket has been written, overlapping the rest of backward.
 The flat buffer also gives the fused optimiser a single zero-fill and stable
 pointers (no per-step pointer-table rebuilds).
+
+With ``direct=True`` (default) the weight-gradient kernels accumulate straight into the
+views of the flat buffer (functional.enable_direct_grads): no per-parameter zero-fill,
+temporary or ``grad +=`` launch.  Autograd's post-accumulate hooks do not fire for
+gradients written that way, so functional notifies ``_hook`` itself.
 """
 import torch
 import torch.distributed as dist
 
 
 class FlatGradReducer:
-    def __init__(self, params, bucket_elems=32 * 1024 * 1024, process_group=None):
+    def __init__(self, params, bucket_elems=32 * 1024 * 1024, process_group=None, direct=True):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -44,6 +49,10 @@ class FlatGradReducer:
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
+        if direct and dev.type == "cuda":
+            from . import functional as PF
+
+            PF.enable_direct_grads(True, notify=self._hook if self.world > 1 else None)
 
     # -- parameter broadcast (DDP constructor semantics) ------------------------------
     def broadcast_parameters(self, module, src=0):
@@ -59,13 +68,19 @@ class FlatGradReducer:
         self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _hook(self, p):
-        bi = self._bucket_of[id(p)]
+        bi = self._bucket_of.get(id(p))
+        if bi is None or self._launched[bi]:
+            return
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
 
     def zero_grad(self):
         self.flat.zero_()
+        if self.flat.is_cuda:
+            from . import functional as PF
+
+            PF.reset_direct_uses()
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
