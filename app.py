@@ -1,0 +1,96 @@
+"""Synthesis entry point (reference: app.py): load the acoustic model + F0-aware BigVGAN from
+``conf/demo.yaml`` and synthesise from a phoneme sequence and a style prompt or a reference mel.
+
+The reference wraps this in a Gradio UI fed by g2p_en / nltk; that text front-end is outside this
+build, so ``synthesize`` starts from phoneme ids.  With gradio and the
+reference's text package importable, ``build_ui`` offers the same two-tab demo."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from promptttspp.utils.model import lowpass_filter  # noqa: E402
+
+try:
+    from hydra.utils import instantiate
+except ImportError:
+    from promptttspp_amd.hydra_lite import instantiate
+
+CONF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "egs", "proposed", "bin", "conf")
+
+
+def load_model(model_cfg, model_ckpt_path, vocoder_cfg, vocoder_ckpt_path, device=None):
+    """reference app.py:28-40; checkpoints are optional here (random init when absent)."""
+    device = device or torch.device("cuda")
+    model = instantiate(model_cfg)
+    if model_ckpt_path and os.path.exists(model_ckpt_path):
+        model.load_state_dict(torch.load(model_ckpt_path, map_location="cpu")["model"])
+    vocoder = instantiate(vocoder_cfg)
+    if vocoder_ckpt_path and os.path.exists(vocoder_ckpt_path):
+        vocoder.load_state_dict(torch.load(vocoder_ckpt_path, map_location="cpu")["generator"])
+    return model.to(device).eval(), vocoder.to(device).eval()
+
+
+@torch.no_grad()
+def synthesize(model, vocoder, phoneme_ids, style_prompt=None, reference_mel=None, mel_stats=None, noise_scale=0.5):
+    """reference app.py:50-82 (``onclick_synthesis``) from phoneme ids (1, Tp):
+    infer -> 20 Hz low-pass on log-F0 -> F0 -> de-normalise mel -> vocoder.  Returns (wav, mel)."""
+    assert style_prompt is not None or reference_mel is not None
+    device = next(model.parameters()).device
+    mean = mel_stats["mean"] if mel_stats is not None else 0.0
+    std = mel_stats["std"] if mel_stats is not None else 1.0
+    kw = dict(use_max=True, noise_scale=noise_scale, return_f0=True)
+    if style_prompt is not None:
+        dec, log_cf0, vuv = model.infer(phoneme_ids.to(device), style_prompt=style_prompt, **kw)
+    else:
+        dec, log_cf0, vuv = model.infer(phoneme_ids.to(device), reference_mel=((reference_mel - mean) / std).to(device), **kw)
+    modfs = int(1.0 / (10 * 0.001))
+    f0 = lowpass_filter(log_cf0, modfs, cutoff=20).exp()
+    f0[vuv < 0.5] = 0
+    dec = dec * std + mean
+    return vocoder(dec, f0).squeeze(1).cpu(), dec.cpu()
+
+
+def build_ui(model, vocoder, to_mel, mel_stats):  # pragma: no cover - needs gradio + the text front-end
+    import gradio as gr
+    from g2p_en import G2p
+    from promptttspp.text.eng import symbols, text_to_sequence
+
+    g2p = G2p()
+
+    def ids_of(text):
+        ph = [p if p not in [",", "."] else "sil" for p in g2p(text)]
+        return torch.LongTensor(text_to_sequence(" ".join(p for p in ph if p in symbols)))[None, :]
+
+    def with_prompt(content, style):
+        wav, _ = synthesize(model, vocoder, ids_of(content), style_prompt=[style], mel_stats=mel_stats)
+        return to_mel.sample_rate, wav.squeeze().numpy()
+
+    with gr.Blocks() as demo:
+        gr.Markdown("# PromptTTS++ (MI355X build)")
+        content = gr.Textbox("This is text to speech demo.", lines=3, label="Content prompt")
+        style = gr.Textbox("A man speaks slowly in a low tone.", lines=3, label="Style prompt")
+        button = gr.Button("Synthesize")
+        wav = gr.Audio(label="Output wav")
+        button.click(with_prompt, inputs=[content, style], outputs=[wav])
+    demo.launch()
+
+
+def main(argv=None):
+    from promptttspp_amd.hydra_lite import compose
+
+    cfg = compose(CONF, "demo", list(argv if argv is not None else sys.argv[1:]))
+    model, vocoder = load_model(cfg.model, cfg.model_ckpt_path, cfg.vocoder, cfg.vocoder_ckpt_path)
+    to_mel = instantiate(cfg.transforms)
+    stats = None
+    if os.path.exists(str(cfg.mel_stats_file)):
+        import yaml
+
+        stats = yaml.safe_load(open(cfg.mel_stats_file))
+    build_ui(model, vocoder, to_mel, stats)
+
+
+if __name__ == "__main__":
+    main()

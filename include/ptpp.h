@@ -175,12 +175,16 @@ int ptpp_layernorm_bwd(const void* dy, const void* xsum, const void* z,
  *   pos:   linear_pos(pos_emb): (2T-1, H*dk) new / (T, H*dk) legacy, stride ldpos
  *   bias_u/bias_v: (H, dk) f32;  ctx: (B,T,H*dk) rows with stride ldctx
  *   probs: (B,H,T,T) f32 softmax output (NULL in inference; saved for bwd)
+ *   drop_p/drop_seed: dropout on the attention probabilities (BERT's
+ *   attention_probs_dropout_prob) for FORWARD-ONLY use (frozen layers): needs
+ *   probs == NULL; 0 = off.
  * ------------------------------------------------------------------ */
 int ptpp_attention_fwd(const void* q, const void* k, const void* v,
                        const void* pos, const float* bias_u, const float* bias_v,
                        void* ctx, float* probs, const int32_t* lengths, int B,
                        int T, int H, int dk, int ld, int ldpos, int ldctx,
-                       int variant, int dtype, void* stream);
+                       int variant, float drop_p, uint64_t drop_seed, int dtype,
+                       void* stream);
 
 /* dS: (B,H,T,T) f32 workspace; dq/dk_out/dv_out: (B,T,*) rows, stride lddq;
  * dpos: (2T-1, H*dk) f32 (overwritten); du/dvb: (H*dk) f32 accumulated with

@@ -29,6 +29,9 @@ struct AttnP {
   const int* lengths;
   int B, T, H, dk, ld, ldpos, ldctx, variant;
   float scale;
+  unsigned drop_thresh16;  // attention-probability dropout (forward-only use), 0 = off
+  float drop_inv_keep;
+  unsigned long long drop_seed;
 };
 
 template <typename T>
@@ -110,8 +113,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
   }
   sum = wave_sum(sum);
   const float inv = 1.f / sum;
+  const uint64_t drow = (((uint64_t)b * p.H + h) * Tn + i) * (uint64_t)Tn;  // element index of P[b,h,i,0]
   for (int j = lane; j < Tn; j += 64) {
-    const float pr = j < len ? sc[j] * inv : 0.f;
+    float pr = j < len ? sc[j] * inv : 0.f;
+    if (p.drop_thresh16 && j < len) {
+      const uint64_t e = drow + j;
+      const uint32_t bits = (uint32_t)(drop_hash(p.drop_seed, e >> 2) >> (16 * (e & 3))) & 0xffffu;
+      pr = bits >= p.drop_thresh16 ? pr * p.drop_inv_keep : 0.f;
+    }
     if (j < len) sc[j] = pr;
     if (prow) prow[j] = pr;
   }
@@ -291,14 +300,20 @@ bool shape_ok(int B, int T, int H, int dk) {
 
 extern "C" int ptpp_attention_fwd(const void* q, const void* k, const void* v, const void* pos, const float* bias_u,
                                   const float* bias_v, void* ctx, float* probs, const int32_t* lengths, int B, int T_,
-                                  int H, int dk, int ld, int ldpos, int ldctx, int variant, int dtype, void* stream) {
+                                  int H, int dk, int ld, int ldpos, int ldctx, int variant, float drop_p,
+                                  uint64_t drop_seed, int dtype, void* stream) {
   PTPP_CHECK_ARG(q && k && v && ctx, "attention_fwd: null pointer");
+  PTPP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || !probs),
+                 "attention_fwd: probability dropout is forward-only (probs must be NULL)");
   PTPP_CHECK_ARG(shape_ok(B, T_, H, dk), "attention_fwd: unsupported shape B=%d T=%d H=%d dk=%d", B, T_, H, dk);
   PTPP_CHECK_ARG(variant >= 0 && variant <= 2, "attention_fwd: bad variant");
   PTPP_CHECK_ARG(variant == VAR_PLAIN || (pos && bias_u && bias_v), "attention_fwd: rel-pos variant needs pos/u/v");
   PTPP_CHECK_ARG(ld % 4 == 0 && ldctx % 4 == 0 && (variant == VAR_PLAIN || ldpos % 4 == 0), "attention_fwd: strides");
   AttnP p{q, k, v, pos, bias_u, bias_v, ctx, probs, lengths, B, T_, H, dk, ld, ldpos, ldctx, variant,
           1.0f / sqrtf((float)dk)};
+  p.drop_thresh16 = drop_p > 0.f ? (unsigned)(drop_p * 65536.f + 0.5f) : 0u;
+  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - p.drop_thresh16 / 65536.f) : 1.f;
+  p.drop_seed = drop_seed;
   const size_t smem = (size_t)4 * (3 * dk + ((T_ + 3) & ~3)) * sizeof(float);
   dim3 grid((T_ + 3) / 4, H, B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

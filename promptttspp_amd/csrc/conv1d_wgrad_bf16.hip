@@ -22,7 +22,6 @@
 // and adds into dw: deterministic, and ~10x cheaper than the atomics.  Without a
 // workspace the partials are combined with atomics (fewer splits).
 #include "ptpp_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -283,7 +282,6 @@ int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
     if (nsplit > (total + 3) / 4) nsplit = (total + 3) / 4;
   }
   if (nsplit < 1) nsplit = 1;
-  if (const char* e = getenv("PTPP_TUNE_NSPLIT")) nsplit = atoi(e) < total ? atoi(e) : total;
   p.nsplit = nsplit;
   const size_t smem = (size_t)NS * KR * (TM + TN) * sizeof(bf16_raw);
   hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<FM, FN>), dim3((unsigned)((int64_t)tiles * nsplit)), dim3(256), smem, st, p,
@@ -309,8 +307,7 @@ int ptpp_wgrad_bf16_launch(const void* x, const void* dy, float* dw, float* dbia
   p.x = (const bf16_raw*)x; p.dy = (const bf16_raw*)dy; p.dw = dw; p.dbias = dbias; p.lengths = lengths;
   p.B = B; p.T = T; p.Cin = Cin; p.Cout = Cout; p.ks = ks; p.dil = dil; p.pad = pad; p.ldx = ldx; p.lddy = lddy;
   p.in_mask = in_mask;
-  bool bigM = Cout > 64, bigN = Cin > 64;
-  if (const char* e = getenv("PTPP_TUNE_TILE")) { bigM = bigM && (atoi(e) & 2); bigN = bigN && (atoi(e) & 1); }
+  const bool bigM = Cout > 64, bigN = Cin > 64;
   if (bigM && bigN) return launch<4, 4>(p, ws_bytes, st);
   if (bigM) return launch<4, 2>(p, ws_bytes, st);
   if (bigN) return launch<2, 4>(p, ws_bytes, st);

@@ -15,6 +15,17 @@
 
 namespace {
 
+// sin of the snake argument.  f32 tensors (parity mode): libm-accurate sinf.  bf16 tensors:
+// the hardware v_sin_f32 (|abs err| ~1e-6 for the |x*alpha| < 256 this activation sees,
+// far inside the bf16 output rounding); the accurate routine's range reduction made this
+// memory-bound kernel ALU-bound (profiles/r01_bigvgan_*).
+template <typename T>
+__device__ __forceinline__ float snake_sin(float v) {
+  if constexpr (sizeof(T) == 2) return __sinf(v);
+  else return sinf(v);
+}
+
+
 struct SnakeFilt {
   float up[12];
   float dn[12];
@@ -68,8 +79,8 @@ __global__ __launch_bounds__(256) void aa_snake_kernel(const T* __restrict__ x, 
     ue *= 2.0f;                                                                           \
     f32x4 so, se;                                                                         \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                       \
-      const float s1 = sinf(uo[e] * ea[e]);                                               \
-      const float s2 = sinf(ue[e] * ea[e]);                                               \
+      const float s1 = snake_sin<T>(uo[e] * ea[e]);                                       \
+      const float s2 = snake_sin<T>(ue[e] * ea[e]);                                       \
       so[e] = uo[e] + inv[e] * (s1 * s1);                                                 \
       se[e] = ue[e] + inv[e] * (s2 * s2);                                                 \
     }                                                                                     \

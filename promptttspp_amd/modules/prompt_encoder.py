@@ -45,6 +45,7 @@ class BertWrapper(nn.Module):
             p.requires_grad = False
         for p in self.model.encoder.layer[-1].attention.parameters():
             p.requires_grad = True
+        self.hip_frozen_layers = True  # False: every layer through the library modules
 
     def tokenize(self, prompts, device):
         if isinstance(prompts, (tuple, list)) and len(prompts) == 2 and isinstance(prompts[0], torch.Tensor):
@@ -57,16 +58,62 @@ class BertWrapper(nn.Module):
     def forward(self, prompts: List[str], device: torch.device) -> torch.Tensor:
         ids, am = self.tokenize(prompts, device)
         amp = compute_dtype() == torch.bfloat16 and ids.is_cuda
+        layers = list(self.model.encoder.layer)
+        # BertModel.forward, layer by layer (checked bit-identical on CPU): the library's mask helper
+        # inspects the mask on the HOST (mask.all()), a device sync that stalls the launch queue once per
+        # step.  Same modules, same state-dict keys.
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            # BertModel.forward, layer by layer (bit-identical, checked on CPU): the library's
-            # mask helper inspects the mask on the HOST (mask.all()), a device sync that stalls
-            # the launch queue once per step.  Same modules, same state-dict keys.
             h = self.model.embeddings(input_ids=ids)
+        n_hip = 0
+        if ids.is_cuda and self.hip_frozen_layers:
+            # frozen layers (no gradient flows into or through them: the embeddings are frozen too) run
+            # forward-only on the HIP kernels: 7 launches per layer, weights packed once
+            while n_hip < len(layers) and not any(p.requires_grad for p in layers[n_hip].parameters()):
+                n_hip += 1
+            if n_hip and not (torch.is_grad_enabled() and h.requires_grad):
+                lengths = am.sum(dim=1).to(torch.int32)
+                hc = h.detach().to(compute_dtype()).contiguous()
+                for layer in layers[:n_hip]:
+                    hc = self._frozen_layer(layer, hc, lengths)
+                h = hc.float()
+            else:
+                n_hip = 0
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             ext = (1.0 - am[:, None, None, :].to(h.dtype)) * torch.finfo(h.dtype).min
-            for layer in self.model.encoder.layer:
+            for layer in layers[n_hip:]:
                 out = layer(h, attention_mask=ext)
                 h = out[0] if isinstance(out, tuple) else out
         return h[:, 0, :].float()
+
+    @torch.no_grad()
+    def _frozen_layer(self, layer, h, lengths):
+        """One post-LN BERT layer, forward only, on (B, T, 768) in the compute dtype (reference:
+        transformers BertLayer = BertAttention(BertSelfAttention + BertSelfOutput) + BertIntermediate
+        (exact GELU) + BertOutput; dropout sites as in train mode).  Keys at positions >= length are
+        masked (right-padded attention masks, as the tokenizer produces)."""
+        from .. import ops
+
+        att, dt = layer.attention, h.dtype
+        C = h.shape[-1]
+        sa = att.self
+        H = sa.num_attention_heads
+        tr = self.training
+        p_att = float(sa.dropout.p) if tr else 0.0
+        p_hid = float(att.output.dropout.p) if tr else 0.0
+        qkv_w = [sa.query.weight, sa.key.weight, sa.value.weight]
+        qkv = ops.conv1d(h, PF.packed_cat(qkv_w, dt), PF.bias_cat([sa.query.bias, sa.key.bias, sa.value.bias]), 3 * C)
+        ctx, _ = ops.attention_fwd(qkv[:, :, :C], qkv[:, :, C : 2 * C], qkv[:, :, 2 * C :], None, None, None, lengths, H,
+                                   "plain", drop_p=p_att, drop_seed=PF.next_seed() if p_att > 0 else 0)
+        a = ops.conv1d(ctx, PF.packed(att.output.dense.weight, dt), att.output.dense.bias, C, res=h, drop_p=p_hid,
+                       drop_seed=PF.next_seed() if p_hid > 0 else 0)
+        ln = att.output.LayerNorm
+        h1 = ops.layernorm_fwd(a, ln.weight, ln.bias, ln.eps)[0]
+        inter = ops.conv1d(h1, PF.packed(layer.intermediate.dense.weight, dt), layer.intermediate.dense.bias,
+                           layer.intermediate.dense.out_features, act="gelu")
+        o = ops.conv1d(inter, PF.packed(layer.output.dense.weight, dt), layer.output.dense.bias, C, res=h1, drop_p=p_hid,
+                       drop_seed=PF.next_seed() if p_hid > 0 else 0)
+        ln2 = layer.output.LayerNorm
+        return ops.layernorm_fwd(o, ln2.weight, ln2.bias, ln2.eps)[0]
 
 
 class PromptEncoder(nn.Module):

@@ -27,7 +27,15 @@ def dtype_code(dt):
     raise TypeError(f"promptttspp_amd: unsupported compute dtype {dt}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """torch's current HIP stream as a raw handle (the C calls: ~0.3 us instead of ~7 us for the
+    torch.cuda.current_stream() object -- this runs once per kernel launch)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -245,7 +253,7 @@ def layernorm_bwd(dy, xsum, gamma, mean, rstd, lengths=None, out_mask=False, z=N
 # ----------------------------------------------------------------------------
 # attention
 # ----------------------------------------------------------------------------
-def attention_fwd(q, k, v, pos, bias_u, bias_v, lengths, heads, variant, save_probs=False):
+def attention_fwd(q, k, v, pos, bias_u, bias_v, lengths, heads, variant, save_probs=False, drop_p=0.0, drop_seed=0):
     """q,k,v: (B,T,C) views with a common row stride (e.g. slices of a fused
     (B,T,3C) projection); pos: (L, C) or None; returns (ctx (B,T,C), probs)."""
     _need_gpu(q)
@@ -259,7 +267,7 @@ def attention_fwd(q, k, v, pos, bias_u, bias_v, lengths, heads, variant, save_pr
         _lib.load().ptpp_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(pos), _ptr(bias_u), _ptr(bias_v), _ptr(ctx),
                                        _ptr(probs), _ptr(lengths), B, T, heads, dk, _ld(q),
                                        pos.stride(0) if pos is not None else 0, C, _VARIANT[variant],
-                                       dtype_code(q.dtype), _stream()),
+                                       float(drop_p), int(drop_seed), dtype_code(q.dtype), _stream()),
         "ptpp_attention_fwd",
     )
     return ctx, probs

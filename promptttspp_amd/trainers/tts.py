@@ -1,0 +1,252 @@
+"""TTSTrainer: the training loop behind ``egs/proposed/bin/train.py`` with the reference's
+config contract and checkpoint format (reference: promptttspp/trainers/tts.py:36-258),
+laid out for one-process-per-GPU training on MI355X:
+
+* launch: under ``torchrun`` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) each
+  process drives one GPU; without it ``run()`` spawns one process per visible GPU like the
+  reference's ``mp.spawn`` (rendezvous on 127.0.0.1);
+* data parallelism: ``parallel.FlatGradReducer`` (flat f32 gradient buffer, a few large
+  RCCL all-reduce buckets overlapped with backward) instead of DistributedDataParallel;
+  batches follow the reference exactly -- ``batch_by_size(max_tokens,
+  required_batch_size_multiple=W)`` and rank r takes ``x[r::W]`` of every global batch;
+* step: forward in the configured compute dtype (``train.compute_dtype``: bf16 | f32; the
+  reference's ``train.fp16`` switch selects bf16 here -- no GradScaler is needed), backward,
+  clip-by-global-norm(1.0) + optimiser step.  With ``FusedAdamW`` the clip is fused into
+  the optimiser's two launches and nothing syncs the host;
+* logging: loss values are kept on the device and read back every ``train.log_interval``
+  steps (the reference's per-step ``.item()`` is a device sync per loss per step);
+* checkpoints: ``{"epoch", "model", "optimizer", "lr_scheduler"}`` in ``ckpt/last.ckpt``
+  and ``ckpt/epoch-N.ckpt``, interchangeable with the reference's.
+"""
+import logging
+import os
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, DistributedSampler
+
+from .. import config as ptpp_config
+from ..datasets.utils import ShuffleBatchSampler, batch_by_size
+from ..utils.seed import seed_everything
+from ..utils.tracker import Tracker
+
+try:  # hydra / omegaconf when installed, the in-tree loader otherwise
+    from hydra.utils import instantiate
+    from omegaconf import OmegaConf
+
+    def _save_cfg(cfg, path):
+        OmegaConf.save(cfg, path)
+except ImportError:  # pragma: no cover - this image has no hydra
+    from ..hydra_lite import instantiate, to_yaml
+
+    def _save_cfg(cfg, path):
+        Path(path).write_text(to_yaml(cfg))
+
+
+def _get(node, key, default=None):
+    try:
+        return node[key] if key in node else default
+    except TypeError:
+        return getattr(node, key, default)
+
+
+def shard_batches(batches, rank, world):
+    """The reference's DP sharding of token-bucket batches (trainers/tts.py:138-142)."""
+    if world == 1:
+        return list(batches)
+    return [x[rank::world] for x in batches if len(x) % world == 0]
+
+
+class TTSTrainer:
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    # ------------------------------------------------------------------ launch
+    def run(self):
+        if "RANK" in os.environ:  # torchrun: this process is one rank
+            return self._train(int(os.environ.get("LOCAL_RANK", 0)), int(os.environ["RANK"]),
+                               int(os.environ.get("WORLD_SIZE", 1)))
+        n = torch.cuda.device_count()
+        if n > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "65535")
+            torch.multiprocessing.spawn(self._spawned, nprocs=n, args=(n,))
+        else:
+            self._train(0, 0, 1)
+
+    def _spawned(self, rank, world):
+        self._train(rank, rank, world)
+
+    # ------------------------------------------------------------------ pieces
+    def _device(self, local_rank):
+        if not torch.cuda.is_available():
+            raise RuntimeError("TTSTrainer needs a ROCm device: the model has no CPU path")
+        torch.cuda.set_device(local_rank)
+        return torch.device(f"cuda:{local_rank}")
+
+    def _loaders(self, cfg, rank, world):
+        to_mel = instantiate(cfg.transforms) if _get(cfg, "transforms") is not None else None
+        collator = instantiate(cfg.dataset.collator)
+        train_ds = instantiate(cfg.dataset.train, to_mel=to_mel)
+        sampler = None
+        if _get(cfg.dataset, "dynamic_batch", False):
+            batches = batch_by_size(train_ds.ordered_indices(), train_ds.num_tokens,
+                                    max_tokens=_get(cfg.dataset, "max_tokens", 30000),
+                                    required_batch_size_multiple=world)
+            batches = shard_batches(batches, rank, world)
+            train_dl = DataLoader(train_ds, batch_sampler=ShuffleBatchSampler(batches, drop_last=True, shuffle=True),
+                                  pin_memory=True, collate_fn=collator, num_workers=cfg.train.num_workers)
+        else:
+            sampler = DistributedSampler(train_ds, shuffle=True, drop_last=True) if world > 1 else None
+            train_dl = DataLoader(train_ds, batch_size=cfg.train.batch_size, sampler=sampler, shuffle=sampler is None,
+                                  pin_memory=True, drop_last=True, collate_fn=collator,
+                                  num_workers=cfg.train.num_workers)
+        valid_dl = None
+        if rank == 0 and _get(cfg.dataset, "valid") is not None:
+            valid_ds = instantiate(cfg.dataset.valid, to_mel=to_mel)
+            valid_dl = DataLoader(valid_ds, batch_size=cfg.train.batch_size, shuffle=False, pin_memory=True,
+                                  collate_fn=collator, num_workers=cfg.train.num_workers)
+        return train_dl, valid_dl, sampler
+
+    @staticmethod
+    def _to_device(batch, device):
+        def mv(a):
+            if isinstance(a, torch.Tensor):
+                return a.to(device, non_blocking=True)
+            if isinstance(a, tuple) and a and isinstance(a[0], torch.Tensor):
+                return tuple(t.to(device, non_blocking=True) for t in a)
+            return a
+        return [mv(a) for a in batch][2:]  # drop (ids, wav paths) like the reference
+
+    # ------------------------------------------------------------------ main loop
+    def _train(self, local_rank, rank, world):
+        from ..optim import FusedAdamW
+        from ..parallel import FlatGradReducer
+
+        cfg = self.cfg
+        if world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "65535")
+            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)  # nccl == RCCL
+        seed_everything(cfg.train.seed)
+        device = self._device(local_rank)
+        dt = _get(cfg.train, "compute_dtype", "bf16" if _get(cfg.train, "fp16", False) else "f32")
+        ptpp_config.set_compute_dtype(torch.bfloat16 if str(dt) in ("bf16", "bfloat16") else torch.float32)
+
+        logger = writer = tracker = None
+        if rank == 0:
+            out = Path(cfg.output_dir)
+            ckpt_dir, log_dir = out / "ckpt", out / "logs"
+            for d in (ckpt_dir, log_dir):
+                d.mkdir(parents=True, exist_ok=True)
+            _save_cfg(cfg, out / "config.yaml")
+            logger = logging.getLogger(str(log_dir))
+            logger.setLevel(logging.DEBUG)
+            h = logging.FileHandler(log_dir / "train.log")
+            h.setFormatter(logging.Formatter("%(asctime)s %(name)s:%(lineno)s %(funcName)s [%(levelname)s]: %(message)s"))
+            logger.addHandler(h)
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+
+                writer = SummaryWriter(log_dir=log_dir / "tensorboard")
+            except Exception:  # tensorboard is optional
+                writer = None
+
+        model = instantiate(cfg.model).to(device)
+        if rank == 0:
+            logger.info(f"model parameter : {sum(p.numel() for p in model.parameters())}")
+        params = [p for p in model.parameters() if p.requires_grad]
+        optimizer = instantiate(cfg.optimizer, params=params)
+        fused = isinstance(optimizer, FusedAdamW)
+        if fused and optimizer.max_grad_norm <= 0:
+            optimizer.max_grad_norm = 1.0  # the trainer's clip_grad_norm_(1.0), fused
+        lr_scheduler = instantiate(cfg.train.lr_scheduler, optimizer=optimizer) if "lr_scheduler" in cfg.train else None
+        per_epoch_scheduler = _get(cfg.train, "per_epoch_scheduler", True)
+
+        start_epoch = 1
+        if _get(cfg, "pretrained") is not None:
+            try:
+                missing = model.load_state_dict(torch.load(cfg.pretrained, map_location=device)["model"], strict=False)
+                print("Using pretrained", missing)
+            except Exception as e:  # reference behaviour: carry on from scratch
+                print(f"Failed loading pretrained: {e}")
+        if _get(cfg, "ckpt_path") is not None:
+            try:
+                ckpt = torch.load(cfg.ckpt_path, map_location=device)
+                model.load_state_dict(ckpt["model"])
+                optimizer.load_state_dict(ckpt["optimizer"])
+                if lr_scheduler is not None and "lr_scheduler" in ckpt:
+                    lr_scheduler.load_state_dict(ckpt["lr_scheduler"])
+                start_epoch = ckpt["epoch"] + 1
+            except Exception as e:
+                print(f"Failed loading checkpoint: {e}")
+
+        reducer = FlatGradReducer(params)      # p.grad become views of one flat buffer
+        reducer.broadcast_parameters(model)    # DDP constructor semantics
+
+        train_dl, valid_dl, sampler = self._loaders(cfg, rank, world)
+        global_step = (start_epoch - 1) * len(train_dl) + 1
+        log_interval = int(_get(cfg.train, "log_interval", 50))
+        if rank == 0:
+            tracker = Tracker(log_dir / "loss.csv", mode="a" if _get(cfg, "ckpt_path") is not None else "w")
+
+        for epoch in range(start_epoch, cfg.train.num_epochs + 1):
+            if sampler is not None:
+                sampler.set_epoch(epoch)
+            model.train()
+            pending = []  # device-resident loss dicts since the last read-back
+            for batch in train_dl:
+                batch = self._to_device(batch, device)
+                reducer.zero_grad()
+                loss_dict = model(batch)
+                loss_dict["loss"].backward()
+                reducer.finish()
+                if not fused:
+                    torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+                optimizer.step()
+                if not per_epoch_scheduler and lr_scheduler is not None:
+                    lr_scheduler.step()
+                global_step += 1
+                if rank == 0:
+                    pending.append({k: v.detach() for k, v in loss_dict.items()})
+                    if len(pending) >= log_interval:
+                        self._flush(tracker, pending, "train")
+            if rank == 0:
+                self._flush(tracker, pending, "train")
+                s = ", ".join(f'{k.split("/")[1]}: {v.mean():.5f}' for k, v in tracker.items() if k.startswith("train"))
+                logger.info(f"Train: {epoch}, {s}")
+                if writer is not None:
+                    for k, v in tracker.items():
+                        writer.add_scalar(k, v.mean(), global_step)
+                if valid_dl is not None:
+                    model.eval()
+                    vals = []
+                    with torch.no_grad():
+                        for batch in valid_dl:
+                            vals.append({k: v.detach() for k, v in model(self._to_device(batch, device)).items()})
+                    self._flush(tracker, vals, "valid")
+                    s = ", ".join(f'{k.split("/")[1]}: {v.mean():.5f}' for k, v in tracker.items() if k.startswith("valid"))
+                    logger.info(f"Valid: {epoch}, {s}")
+                save_obj = {"epoch": epoch, "model": model.state_dict(), "optimizer": optimizer.state_dict()}
+                if lr_scheduler is not None:
+                    save_obj["lr_scheduler"] = lr_scheduler.state_dict()
+                torch.save(save_obj, ckpt_dir / "last.ckpt")
+                if epoch % cfg.train.save_interval == 0:
+                    torch.save(save_obj, ckpt_dir / f"epoch-{epoch}.ckpt")
+                tracker.write(epoch, clear=True)
+            if per_epoch_scheduler and lr_scheduler is not None:
+                lr_scheduler.step()
+        if world > 1:
+            dist.barrier()
+
+    @staticmethod
+    def _flush(tracker, pending, prefix):
+        """One host read-back for a whole window of steps."""
+        if not pending:
+            return
+        keys = list(pending[0].keys())
+        vals = torch.stack([torch.stack([d[k].float() for k in keys]) for d in pending]).cpu()
+        for row in vals:
+            tracker.update(**{f"{prefix}/{k}": float(x) for k, x in zip(keys, row)})
+        pending.clear()

@@ -82,3 +82,25 @@ def test_host_logic_matches_reference():
             assert np.array_equal(np.array([len(b) for b in bs]), d[f"sizes_{mt}_{W}"].numpy())
     for s, lr in zip(d["noam_steps"].tolist(), d["noam_lr"].tolist()):
         assert abs(1e-3 * noam_scale(int(s), 4000) - lr) < 1e-12
+
+
+def test_trainer_and_entry_points_import_and_shard_like_the_reference():
+    """trainers.tts.TTSTrainer exists under the reference's dotted path; its DP batch sharding is the
+    reference's ``x[rank::W] for x in batches if len(x) % W == 0`` (trainers/tts.py:138-142)."""
+    import importlib
+
+    from promptttspp.trainers.tts import TTSTrainer, shard_batches
+
+    assert importlib.import_module("promptttspp_amd.trainers.tts").TTSTrainer is TTSTrainer
+    batches = [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9, 10, 11, 12, 13, 14]]
+    assert shard_batches(batches, 0, 1) == batches
+    assert shard_batches(batches, 1, 2) == [[1, 3], [8], [10, 12, 14]]
+    assert shard_batches(batches, 0, 2) == [[0, 2], [7], [9, 11, 13]]
+    from promptttspp_amd.hydra_lite import compose
+    import os
+
+    conf = os.path.join(os.path.dirname(__file__), "..", "egs", "proposed", "bin", "conf")
+    cfg = compose(conf, "train", ["dataset=synthetic", "optimizer=fused_adamw", "train.num_epochs=1"])
+    assert cfg.model["_target_"].startswith("promptttspp.models.prompttts_mdn_v2_final")
+    assert cfg.dataset.dynamic_batch and cfg.train.num_epochs == 1
+    assert cfg.optimizer["_target_"].endswith("FusedAdamW")
