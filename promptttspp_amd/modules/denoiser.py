@@ -83,10 +83,12 @@ class DiffNet(nn.Module):
     # -- pieces ----------------------------------------------------------------
     def step_embeddings(self, t):
         """t (B,) int64 -> per-layer diffusion-step projections (B, L, C) f32."""
-        e = self.mlp(self.diffusion_embedding(t).float())
-        w = torch.stack([l.diffusion_projection.weight for l in self.residual_layers])  # (L, C, C)
-        b = torch.stack([l.diffusion_projection.bias for l in self.residual_layers])
-        return torch.einsum("bc,lkc->blk", e, w) + b[None]
+        e = self.diffusion_embedding(t).float()
+        e = PF.linear(self.mlp[1](PF.linear(e, self.mlp[0].weight, self.mlp[0].bias)), self.mlp[2].weight, self.mlp[2].bias)
+        # all L per-layer projections as ONE exact-f32 GEMM on the HIP kernel (each layer keeps its own
+        # parameters / gradients): (B, C) -> (B, L*C)
+        y = PF.linear_fused(e.unsqueeze(0), [l.diffusion_projection for l in self.residual_layers])
+        return y.view(e.shape[0], len(self.residual_layers), -1)
 
     def cond_all(self, cond):
         """All layers' conditioner projections (B,T,L*2C) -- step independent."""

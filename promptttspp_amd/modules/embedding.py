@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as PF
-from .esp import sinusoid_table
+from .esp import position_rows
 
 
 class PositionalEncoding(nn.Module):
@@ -17,15 +17,9 @@ class PositionalEncoding(nn.Module):
         self._cache = {}
 
     def table(self, T, device):
-        key = (T, str(device))
-        t = self._cache.get(key)
-        if t is None:
-            pos = torch.arange(T - 1, -1, -1) if self.reverse else torch.arange(T)
-            t = sinusoid_table(pos, self.d_model).to(device).contiguous()
-            if len(self._cache) > 64:
-                self._cache.clear()
-            self._cache[key] = t
-        return t
+        if self.reverse:
+            return position_rows(T - 1, T, True, self.d_model, device)
+        return position_rows(0, T, False, self.d_model, device)
 
     def forward_cl(self, x):
         """x: (B, T, C) channels-last."""

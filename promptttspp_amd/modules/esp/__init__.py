@@ -42,6 +42,29 @@ def sinusoid_table(positions, d):
     return pe
 
 
+# Master tables: the encodings of positions N-1 ... -(N-1) (descending) and 0 ... N-1 are computed ONCE
+# per (d, device, dtype) -- on the CPU, exactly like the per-length tables before -- and every length
+# takes a contiguous row slice.  (Measured: building a table per new sequence length cost 20-50 ms of
+# host time per table; with token-bucket batching almost every step has new lengths.)
+_MASTER_N = 8192
+_master_cache = {}
+
+
+def position_rows(first, count, descending, d, device, dtype=torch.float32):
+    """Rows encoding positions first, first-1, ... (descending) or first, first+1, ... (ascending)."""
+    last = first - (count - 1) if descending else first + (count - 1)
+    if max(abs(first), abs(last)) >= _MASTER_N or (not descending and min(first, last) < 0):
+        step = -1 if descending else 1
+        return sinusoid_table(torch.arange(first, first + step * count, step), d).to(device=device, dtype=dtype)
+    key = (d, str(device), dtype, descending)
+    m = _master_cache.get(key)
+    if m is None:
+        pos = torch.arange(_MASTER_N - 1, -_MASTER_N, -1) if descending else torch.arange(_MASTER_N)
+        m = _master_cache[key] = sinusoid_table(pos, d).to(device=device, dtype=dtype).contiguous()
+    i0 = (_MASTER_N - 1) - first if descending else first
+    return m[i0 : i0 + count]
+
+
 class _LN(nn.LayerNorm):
     """Parameter holder with ESPnet's key names (weight/bias) and eps."""
 
@@ -165,19 +188,9 @@ class Encoder(nn.Module):
         """rows handed to linear_pos.  new (embedding.py:263-331): relative positions
         T-1 ... -(T-1).  legacy (embedding.py:220-257): the table is built once for
         5000 positions in reverse order and sliced, so row k encodes position 4999-k."""
-        key = (T, str(device), dtype)
-        t = self._pos_cache.get(key)
-        if t is None:
-            if self.variant == "new":
-                pos = torch.arange(T - 1, -T, -1)
-            else:
-                n = max(T, 5000)
-                pos = torch.arange(n - 1, n - 1 - T, -1)
-            t = sinusoid_table(pos, self.attention_dim).to(device=device, dtype=dtype)
-            if len(self._pos_cache) > 64:
-                self._pos_cache.clear()
-            self._pos_cache[key] = t
-        return t
+        if self.variant == "new":
+            return position_rows(T - 1, 2 * T - 1, True, self.attention_dim, device, dtype)
+        return position_rows(max(T, 5000) - 1, T, True, self.attention_dim, device, dtype)
 
     def cl(self, x, lengths, mask_bt1):
         p = self.positional_dropout_rate if self.training else 0.0

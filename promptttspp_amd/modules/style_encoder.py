@@ -3,6 +3,8 @@ import math
 
 import torch
 import torch.nn as nn
+
+from .. import functional as PF
 import torch.nn.functional as F
 
 from .reference_encoder import ReferenceEncoder
@@ -26,12 +28,14 @@ class MultiHeadedAttention(nn.Module):
         """ref_emb (B,1,q_dim), gst_emb (N,k_dim) -> (B,1,n_feat).  10 tokens x 1
         query per utterance: ~0.2 MFLOP, torch ops."""
         B = ref_emb.shape[0]
-        q = self.linear_q(ref_emb).view(B, self.h, 1, self.d_k)
-        k = self.linear_k(gst_emb).view(-1, self.h, self.d_k).transpose(0, 1)
-        v = self.linear_v(gst_emb).view(-1, self.h, self.d_k).transpose(0, 1)
-        score = F.softmax((q @ k.transpose(-1, -2).unsqueeze(0)) / math.sqrt(self.d_k * self.h), dim=-1)
-        o = (self.dropout(score) @ v.unsqueeze(0)).reshape(B, 1, -1)
-        return self.linear_out(o)
+        lin = lambda m, x: PF.linear(x, m.weight, m.bias)  # noqa: E731  (HIP GEMM, exact f32 for f32 inputs)
+        q = lin(self.linear_q, ref_emb.float()).view(B, self.h, 1, self.d_k)
+        k = lin(self.linear_k, gst_emb.float().unsqueeze(0))[0].view(-1, self.h, self.d_k).transpose(0, 1)  # (h, N, dk)
+        v = lin(self.linear_v, gst_emb.float().unsqueeze(0))[0].view(-1, self.h, self.d_k).transpose(0, 1)
+        # 1 query x N tokens per head: broadcast products instead of batched library GEMMs
+        score = F.softmax((q * k.unsqueeze(0)).sum(-1) / math.sqrt(self.d_k * self.h), dim=-1)  # (B, h, N)
+        o = (self.dropout(score).unsqueeze(-1) * v.unsqueeze(0)).sum(2).reshape(B, 1, -1)
+        return lin(self.linear_out, o)
 
 
 class StyleTokenLayer(nn.Module):

@@ -186,16 +186,16 @@ def gru_last_state(x, weight_ih, weight_hh, bias_ih, bias_hh, lens):
     """Single-layer GRU over (B, L, I), returning each sequence's hidden state at its
     last valid step (B, H) (reference: packed GRU, modules/reference_encoder.py:108-123).
     L = ceil(frames/64) <= ~12 steps: the input projection for all steps is ONE HIP GEMM;
-    the recurrent (B,H)x(H,3H) products go to the library GEMM (torch.addmm -> rocBLAS)
-    and the gate algebra is a few (B, H) elementwise ops per step, in float32."""
+    the recurrent (B,H)x(H,3H) products use the same kernel in exact f32 (no library GEMM:
+    rocBLAS/hipBLASLt pick a solution per new (B, ...) shape on the HOST, milliseconds each with
+    token-bucket batching) and the gate algebra is a few (B, H) elementwise ops per step."""
     B, L, _ = x.shape
     Hn = weight_hh.shape[1]
     gi_all = PF.linear(x, weight_ih, bias_ih).float()  # (B, L, 3H)
     h = x.new_zeros((B, Hn), dtype=torch.float32)
-    whh_t = weight_hh.t()
     for s in range(L):
         gi = gi_all[:, s]
-        gh = torch.addmm(bias_hh, h, whh_t)
+        gh = PF.linear(h, weight_hh, bias_hh)
         r = torch.sigmoid(gi[:, :Hn] + gh[:, :Hn])
         z = torch.sigmoid(gi[:, Hn : 2 * Hn] + gh[:, Hn : 2 * Hn])
         n = torch.tanh(gi[:, 2 * Hn :] + r * gh[:, 2 * Hn :])
