@@ -153,70 +153,84 @@ struct AttnBwdP {
   float scale;
 };
 
+constexpr int ROWS_PER_WAVE = 4;  // query rows per wave in attn_bwd_row_kernel
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.y, b = blockIdx.z;
   const int Tn = p.T, dk = p.dk;
   const int Tpad = (Tn + 3) & ~3;
   float* go = lds + w * (dk + Tpad);  // dctx_i
   float* ds = go + dk;
-  if (i >= Tn) return;
+  float* red = lds + 4 * (dk + Tpad);  // [4 waves][2][dk] partial du / dvb of the block
   const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
   const int hc = h * dk;
   const T* kb = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + hc;
   const T* vb = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + hc;
   const T* pb = p.pos ? reinterpret_cast<const T*>(p.pos) + hc : nullptr;
-  const T* gb = reinterpret_cast<const T*>(p.dctx) + ((int64_t)b * Tn + i) * p.lddctx + hc;
-  T* dqr = reinterpret_cast<T*>(p.dq) + ((int64_t)b * Tn + i) * p.lddq + hc;
-  const float* prow = p.probs + (((int64_t)b * p.H + h) * Tn + i) * Tn;
-  float* dsrow = p.dS + (((int64_t)b * p.H + h) * Tn + i) * Tn;
-  if (i >= len) {
-    for (int d = lane * 4; d < dk; d += 256) Elem<T>::st4(dqr + d, f32x4{0.f, 0.f, 0.f, 0.f});
-    for (int j = lane; j < Tn; j += 64) dsrow[j] = 0.f;
-    return;
-  }
-  for (int d = lane * 4; d < dk; d += 256) *reinterpret_cast<f32x4*>(go + d) = Elem<T>::ld4(gb + d);
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  float dsum = 0.f;
-  for (int j = lane; j < len; j += 64) {
-    const float dp = dot_row<T>(go, vb + (int64_t)j * p.ld, dk);
-    ds[j] = dp;
-    dsum += prow[j] * dp;
-  }
-  dsum = wave_sum(dsum);
-  for (int j = lane; j < Tn; j += 64) {
-    const float v = j < len ? prow[j] * (ds[j] - dsum) * p.scale : 0.f;
-    if (j < len) ds[j] = v;
-    dsrow[j] = v;
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);
   const int nvec = dk >> 2, parts = 64 / nvec;
   const int dv = (lane % nvec) * 4, part = lane / nvec;
-  f32x4 au = f32x4{0.f, 0.f, 0.f, 0.f}, av = au;
-  if (part < parts)
-    for (int j = part; j < len; j += parts) {
-      au += Elem<T>::ld4(kb + (int64_t)j * p.ld + dv) * ds[j];
-      if (p.variant == VAR_NEW) av += Elem<T>::ld4(pb + (int64_t)(Tn - 1 - i + j) * p.ldpos + dv) * ds[j];
+  // du / dvb: summed over the wave's rows in registers, over the block's waves in LDS, then ONE
+  // atomic per channel and block (per-row atomics onto the same H*dk addresses serialised the kernel)
+  f32x4 su = f32x4{0.f, 0.f, 0.f, 0.f}, sv = su;
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int i = (blockIdx.x * 4 + w) * ROWS_PER_WAVE + rr;
+    if (i >= Tn) break;
+    const T* gb = reinterpret_cast<const T*>(p.dctx) + ((int64_t)b * Tn + i) * p.lddctx + hc;
+    T* dqr = reinterpret_cast<T*>(p.dq) + ((int64_t)b * Tn + i) * p.lddq + hc;
+    const float* prow = p.probs + (((int64_t)b * p.H + h) * Tn + i) * Tn;
+    float* dsrow = p.dS + (((int64_t)b * p.H + h) * Tn + i) * Tn;
+    if (i >= len) {
+      for (int d = lane * 4; d < dk; d += 256) Elem<T>::st4(dqr + d, f32x4{0.f, 0.f, 0.f, 0.f});
+      for (int j = lane; j < Tn; j += 64) dsrow[j] = 0.f;
+      continue;
     }
-  for (int o = nvec; o < 64; o <<= 1) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      au[e] += __shfl_xor(au[e], o, 64);
-      av[e] += __shfl_xor(av[e], o, 64);
+    __builtin_amdgcn_wave_barrier();  // the previous row's LDS reads are done
+    for (int d = lane * 4; d < dk; d += 256) *reinterpret_cast<f32x4*>(go + d) = Elem<T>::ld4(gb + d);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float dsum = 0.f;
+    for (int j = lane; j < len; j += 64) {
+      const float dp = dot_row<T>(go, vb + (int64_t)j * p.ld, dk);
+      ds[j] = dp;
+      dsum += prow[j] * dp;
     }
-  }
-  if (lane < nvec) {
-    Elem<T>::st4(dqr + dv, au + av);
-    if (p.variant == VAR_NEW) {
+    dsum = wave_sum(dsum);
+    for (int j = lane; j < Tn; j += 64) {
+      const float v = j < len ? prow[j] * (ds[j] - dsum) * p.scale : 0.f;
+      if (j < len) ds[j] = v;
+      dsrow[j] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    f32x4 au = f32x4{0.f, 0.f, 0.f, 0.f}, av = au;
+    if (part < parts)
+      for (int j = part; j < len; j += parts) {
+        au += Elem<T>::ld4(kb + (int64_t)j * p.ld + dv) * ds[j];
+        if (p.variant == VAR_NEW) av += Elem<T>::ld4(pb + (int64_t)(Tn - 1 - i + j) * p.ldpos + dv) * ds[j];
+      }
+    for (int o = nvec; o < 64; o <<= 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        atomicAdd(p.du + hc + dv + e, au[e]);
-        atomicAdd(p.dvb + hc + dv + e, av[e]);
+        au[e] += __shfl_xor(au[e], o, 64);
+        av[e] += __shfl_xor(av[e], o, 64);
       }
+    }
+    if (lane < nvec) Elem<T>::st4(dqr + dv, au + av);
+    su += au;
+    sv += av;
+  }
+  if (p.variant == VAR_NEW) {
+    if (lane < nvec) {
+      *reinterpret_cast<f32x4*>(red + (w * 2 + 0) * dk + dv) = su;
+      *reinterpret_cast<f32x4*>(red + (w * 2 + 1) * dk + dv) = sv;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * dk; c += 256) {
+      const float v = red[c] + red[2 * dk + c] + red[4 * dk + c] + red[6 * dk + c];
+      atomicAdd((c < dk ? p.du : p.dvb) + hc + (c < dk ? c : c - dk), v);
     }
   }
 }
@@ -267,6 +281,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_pos_kernel(const AttnBwdP p, float* dpos) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int m = blockIdx.x * 4 + w, h = blockIdx.y;
+  const int nbg = gridDim.z, bper = (p.B + nbg - 1) / nbg;  // batch groups: more blocks than (L/4) x H
+  const int b0 = blockIdx.z * bper, b1 = min(p.B, b0 + bper);
   const int Tn = p.T, dk = p.dk, L = 2 * Tn - 1;
   if (m >= L) return;
   const int hc = h * dk;
@@ -276,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_bwd_pos_kernel(const AttnBwdP p, flo
   const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias_v + hc + dv);
   const int ilo = max(0, Tn - 1 - m), ihi = min(Tn - 1, 2 * Tn - 2 - m);  // 0 <= j = m-(T-1)+i < T
   if (part < parts)
-    for (int b = 0; b < p.B; ++b) {
+    for (int b = b0; b < b1; ++b) {
       const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
       const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + hc;
       const float* dsb = p.dS + ((int64_t)b * p.H + h) * Tn * Tn;
@@ -289,7 +305,13 @@ __global__ __launch_bounds__(256) void attn_bwd_pos_kernel(const AttnBwdP p, flo
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
   }
-  if (lane < nvec) *reinterpret_cast<f32x4*>(dpos + (int64_t)m * (p.H * dk) + hc + dv) = acc;
+  if (lane < nvec) {
+    float* d = dpos + (int64_t)m * (p.H * dk) + hc + dv;
+    if (nbg == 1) *reinterpret_cast<f32x4*>(d) = acc;
+    else
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(d + e, acc[e]);
+  }
 }
 
 bool shape_ok(int B, int T, int H, int dk) {
@@ -338,12 +360,19 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
              lddq, variant, 1.0f / sqrtf((float)dk)};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((T_ + 3) / 4, H, B);
-  const size_t smem = (size_t)4 * (dk + ((T_ + 3) & ~3)) * sizeof(float);
+  dim3 grid_row((T_ + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), H, B);
+  const size_t smem = (size_t)(4 * (dk + ((T_ + 3) & ~3)) + 8 * dk) * sizeof(float);
+  // dpos: batch groups so that (L/4) x H x groups >= ~1024 blocks; groups > 1 accumulate with atomics
+  // into the buffer zeroed here
+  const int lblk = (2 * T_ - 1 + 3) / 4 * H;
+  int nbg = (1024 + lblk - 1) / lblk;
+  if (nbg > B) nbg = B;
+  if (variant == VAR_NEW && nbg > 1) (void)hipMemsetAsync(dpos, 0, (size_t)(2 * T_ - 1) * H * dk * sizeof(float), st);
 #define ATTN_BWD(TT)                                                                                  \
-  hipLaunchKernelGGL(attn_bwd_row_kernel<TT>, grid, dim3(256), smem, st, p);                          \
+  hipLaunchKernelGGL(attn_bwd_row_kernel<TT>, grid_row, dim3(256), smem, st, p);                      \
   hipLaunchKernelGGL(attn_bwd_col_kernel<TT>, grid, dim3(256), 0, st, p, dk_out, dv_out);             \
   if (variant == VAR_NEW)                                                                             \
-    hipLaunchKernelGGL(attn_bwd_pos_kernel<TT>, dim3((2 * T_ - 1 + 3) / 4, H), dim3(256), 0, st, p, dpos);
+    hipLaunchKernelGGL(attn_bwd_pos_kernel<TT>, dim3((2 * T_ - 1 + 3) / 4, H, nbg), dim3(256), 0, st, p, dpos);
   if (dtype == PTPP_F32) { ATTN_BWD(float) }
   else if (dtype == PTPP_BF16) { ATTN_BWD(bf16_raw) }
   else PTPP_CHECK_ARG(false, "attention_bwd: bad dtype");

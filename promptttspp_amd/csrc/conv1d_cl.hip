@@ -90,15 +90,16 @@ struct ConvP {
   unsigned long long drop_seed;
 };
 
-template <typename T, int NCH, int WM, int FM, int FN>
-__global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvP p) {
-  constexpr int WN = 4 / WM;
+template <typename T, int NCH, int WM, int FM, int FN, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv1d_cl_kernel(const ConvP p) {
+  constexpr int WN = NW / WM;
+  constexpr int NT = NW * 64;  // threads per block
   constexpr int BM = WM * FM * 16;
   constexpr int BN = WN * FN * 16;
   constexpr int KC = 16 / (int)sizeof(T);
   constexpr int BKE = NCH * KC;
   constexpr int WCH = BN * NCH;                 // 16-B chunks in a W tile
-  constexpr int WREG = (WCH + 255) / 256;       // chunks per thread
+  constexpr int WREG = (WCH + NT - 1) / NT;     // chunks per thread
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int BMW = BM + (p.ks - 1) * p.dil;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvP p) {
     const int ci = s / p.ks, j = s - ci * p.ks;
 #pragma unroll
     for (int i = 0; i < WREG; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int n = idx / NCH, c = idx % NCH;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (idx < WCH && n0 + n < p.Cout)
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvP p) {
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < WREG; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int n = idx / NCH, c = idx % NCH;
       const int q = wperm<T, FN>(n);
       if (idx < WCH) Ws[buf * WCH + q * NCH + (c ^ swz<NCH>(q))] = wreg[i];
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvP p) {
   };
   auto stage_x = [&](int ci, int buf) {
     uint4* dst = Xs + buf * BMW * NCH;
-    for (int idx = tid; idx < BMW * NCH; idx += 256) {
+    for (int idx = tid; idx < BMW * NCH; idx += NT) {
       const int r = idx / NCH, c = idx % NCH;
       const int ts = t0 - p.pad + r;
       const int ch = ci * BKE + c * KC;
@@ -311,9 +312,9 @@ __global__ __launch_bounds__(256) void conv1d_cl_kernel(const ConvP p) {
   }
 }
 
-template <typename T, int NCH, int WM, int FM, int FN>
+template <typename T, int NCH, int WM, int FM, int FN, int NW = 4>
 int launch_cfg(ConvP& p, hipStream_t st) {
-  constexpr int WN = 4 / WM;
+  constexpr int WN = NW / WM;
   constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
   p.nMT = (p.T + BM - 1) / BM;
   p.nNT = (p.Cout + BN - 1) / BN;
@@ -323,11 +324,11 @@ int launch_cfg(ConvP& p, hipStream_t st) {
     ptpp_set_error("conv1d: LDS window too large (%zu B)", smem);
     return PTPP_EINVAL;
   }
-  auto kern = conv1d_cl_kernel<T, NCH, WM, FM, FN>;
+  auto kern = conv1d_cl_kernel<T, NCH, WM, FM, FN, NW>;
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int64_t nblk = (int64_t)p.B * p.nMT * p.nNT;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NW * 64), smem, st, p);
   PTPP_CHECK_LAUNCH("conv1d_fwd");
   return PTPP_OK;
 }
@@ -336,12 +337,15 @@ template <typename T, int NCH>
 int launch_tiles(ConvP& p, hipStream_t st) {
   // Tile choice: BN follows Cout; BM follows the per-utterance length so short
   // (phone-level) sequences do not waste MFMA work on padding rows.
-  if (p.Cout <= 32) return launch_cfg<T, NCH, 4, 4, 2>(p, st);   // 256 x 32
-  if (p.Cout <= 64) return launch_cfg<T, NCH, 2, 4, 2>(p, st);   // 128 x 64
-  if (p.T <= 48) return launch_cfg<T, NCH, 1, 2, 2>(p, st);      //  32 x 128
+  // Many small waves per block: measured (tools/bench_wgrad.py) 1.3-2.6x faster than 4 waves of
+  // 64 x 64 on every shape of the training step -- with K = ks*Cin of a few hundred the K loop is
+  // dominated by global->LDS latency and barriers, which 4-8 waves per SIMD hide and 2 do not.
+  if (p.Cout <= 32) return launch_cfg<T, NCH, 8, 2, 2, 8>(p, st);      // 256 x 32, 8 waves of 32 x 32
+  if (p.Cout <= 64) return launch_cfg<T, NCH, 4, 2, 2, 8>(p, st);      // 128 x 64, 8 waves of 32 x 32
+  if (p.T <= 48) return launch_cfg<T, NCH, 2, 1, 2, 8>(p, st);         //  32 x 128, 8 waves of 16 x 32
   if (p.T <= 96 || (p.T % 128 != 0 && p.T % 128 <= 64 && p.T < 512))
-    return launch_cfg<T, NCH, 2, 2, 4>(p, st);                   //  64 x 128
-  return launch_cfg<T, NCH, 2, 4, 4>(p, st);                     // 128 x 128
+    return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);                      //  64 x 128, 8 waves of 32 x 32
+  return launch_cfg<T, NCH, 4, 2, 2, 16>(p, st);                       // 128 x 128, 16 waves of 32 x 32
 }
 
 }  // namespace

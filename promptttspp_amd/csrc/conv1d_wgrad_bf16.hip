@@ -107,18 +107,20 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int FM, int FN>
-__global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16_kernel(const WgP p, const int* __restrict__ lengths) {
-  constexpr int TM = 2 * FM * 16, TN = 2 * FN * 16;
+template <int FM, int FN, int WR = 2, int WC = 2>
+__global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const WgP p, const int* __restrict__ lengths) {
+  constexpr int NW = WR * WC;  // waves per block, WR x WC over (co, ci)
+  constexpr int TM = WR * FM * 16, TN = WC * FN * 16;
   constexpr int CY = TM / 8, CX = TN / 8;          // 16-byte chunks per row
   constexpr int RY = 64 / CY, RX = 64 / CX;        // rows per 1 KiB piece
-  constexpr int LY = KR / RY / 4, LX = KR / RX / 4;  // pieces per wave and chunk
+  constexpr int LY = KR / RY / NW, LX = KR / RX / NW;  // pieces per wave and chunk
+  static_assert(LY >= 1 && LX >= 1 && LY * RY * NW == KR && LX * RX * NW == KR, "pieces must divide over the waves");
   constexpr int LPW = LY + LX;                     // LDS-DMA instructions per wave and chunk
   constexpr int STAGE = KR * (TM + TN);            // elements per ring stage
   extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object (see header)
   bf16_raw* S = reinterpret_cast<bf16_raw*>(smem);  // [NS][dy: KR x TM | x: KR x TN]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
 
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int cot = bid % p.nCO; bid /= p.nCO;
@@ -259,9 +261,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int k = 0; k < 4; ++k) d[(int64_t)k * ks] += s[k];
 }
 
-template <int FM, int FN>
+template <int FM, int FN, int WR = 2, int WC = 2>
 int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
-  constexpr int TM = 2 * FM * 16, TN = 2 * FN * 16;
+  constexpr int TM = WR * FM * 16, TN = WC * FN * 16;
   p.nCO = (p.Cout + TM - 1) / TM;
   p.nCI = (p.Cin + TN - 1) / TN;
   p.tchunks = (p.T + KR - 1) / KR;
@@ -284,7 +286,8 @@ int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
   if (nsplit < 1) nsplit = 1;
   p.nsplit = nsplit;
   const size_t smem = (size_t)NS * KR * (TM + TN) * sizeof(bf16_raw);
-  hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<FM, FN>), dim3((unsigned)((int64_t)tiles * nsplit)), dim3(256), smem, st, p,
+  hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<FM, FN, WR, WC>), dim3((unsigned)((int64_t)tiles * nsplit)), dim3(WR * WC * 64), smem,
+                     st, p,
                      p.in_mask ? p.lengths : nullptr);
   PTPP_CHECK_LAUNCH("conv1d_wgrad(bf16)");
   if (p.ws) {
@@ -308,6 +311,7 @@ int ptpp_wgrad_bf16_launch(const void* x, const void* dy, float* dw, float* dbia
   p.B = B; p.T = T; p.Cin = Cin; p.Cout = Cout; p.ks = ks; p.dil = dil; p.pad = pad; p.ldx = ldx; p.lddy = lddy;
   p.in_mask = in_mask;
   const bool bigM = Cout > 64, bigN = Cin > 64;
+  // (8 waves of 32 x 64 / 64 x 32 measured equal to 4 waves of 64 x 64 here: this kernel is not latency-bound)
   if (bigM && bigN) return launch<4, 4>(p, ws_bytes, st);
   if (bigM) return launch<4, 2>(p, ws_bytes, st);
   if (bigN) return launch<2, 4>(p, ws_bytes, st);
