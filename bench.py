@@ -29,6 +29,11 @@ warnings.simplefilter("ignore")
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+# HBM bytes per launch of the dominant kernel (conv1d_cl_kernel<bf16>, 128 x 128 tiles), from the PMC
+# passes of this same command committed as profiles/r01_pmc_train_v7.txt: FETCH_SIZE 23 688 KiB
+# (doubled: gfx950 tallies 128-byte requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE 22 149 KiB.
+# bench.py cannot run rocprofv3 on itself, so the roofline line carries this measured constant.
+CONV_TRAFFIC_BYTES_PER_LAUNCH = (2 * 23688.4 + 22148.7) * 1024
 
 
 def parse():
@@ -128,7 +133,8 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
     ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else 157.3
     return {"bound": "mfma", "kernel": "conv1d_cl_kernel<%s> (fwd + dgrad launches of one step)" % dtype_name,
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": round(CONV_TRAFFIC_BYTES_PER_LAUNCH) if dtype_name == "bf16" else None,
             "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
             "flop_per_step": tot_flop}
 
