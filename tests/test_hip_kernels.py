@@ -255,3 +255,55 @@ def test_fused_adamw_matches_torch(dev):
         o.step()
         for a, b in zip(ps_ref, ps):
             assert rel_err(b.detach().cpu(), a.detach()) < 1e-5, step
+
+
+def test_conv_family_at_bench_size_properties(dev):
+    """BASELINE-sized shapes (one 30 000-token batch: 19 utterances x 1580 frames, DiffNet's dilated
+    256 -> 512, k = 3 conv) through size-independent properties, bf16:
+      * forward: linearity  conv(a x1 + x2) = a conv(x1) + conv(x2)  (bias-free) within bf16 rounding, and
+        the first two utterances against a float32 torch convolution of the same bf16 operands;
+      * weight gradient (LDS-DMA kernel + workspace reduction): bit-identical across two runs
+        (deterministic split-K), accumulate semantics (second call adds), one tap against an einsum;
+      * ragged lengths: rows past each length contribute nothing (in_mask) and produce zeros (out_mask)."""
+    from promptttspp_amd import ops
+
+    torch.manual_seed(0)
+    B, T, Cin, Cout, ks, dil = 19, 1580, 256, 512, 3, 4
+    pad = dil * (ks - 1) // 2
+    x1 = torch.randn(B, T, Cin, device=dev).bfloat16()
+    x2 = torch.randn(B, T, Cin, device=dev).bfloat16()
+    w = torch.randn(Cout, Cin, ks, device=dev) * 0.05
+    wp = ops.pack_conv_weight(w, torch.bfloat16)
+    conv = lambda x, **kw: ops.conv1d(x, wp, None, Cout, ks=ks, dil=dil, pad=pad, **kw).float()  # noqa: E731
+    y1, y2 = conv(x1), conv(x2)
+    xs = (0.5 * x1.float() + x2.float()).bfloat16()          # exactly representable scaling, rounded sum
+    ys = conv(xs)
+    ref = 0.5 * y1 + y2
+    assert float((ys - ref).abs().max()) < 3e-2 * float(ref.abs().max())   # bf16 input/output rounding
+    t_ref = F.conv1d(x1[:2].float().transpose(1, 2), w.bfloat16().float(), None, padding=pad, dilation=dil).transpose(1, 2)
+    assert rel_err(y1[:2].cpu(), t_ref.cpu()) < 4e-3
+
+    lens = torch.randint(T // 3, T + 1, (B,), dtype=torch.int32, device=dev)
+    ym = conv(x1, lengths=lens, in_mask=True, out_mask=True)
+    tpos = torch.arange(T, device=dev)[None, :]
+    valid = (tpos < lens[:, None]).unsqueeze(-1)
+    assert float(ym.masked_select(~valid.expand_as(ym)).abs().max()) == 0.0
+    xz = torch.where(valid, x1, torch.zeros_like(x1))
+    assert torch.equal(ym, torch.where(valid, conv(xz), torch.zeros_like(ym)))  # masked input == zeroed input
+
+    dy = torch.randn(B, T, Cout, device=dev).bfloat16()
+    dw_a, db_a = ops.conv1d_wgrad(x1, dy, Cin, Cout, ks, dil, pad)
+    dw_b, db_b = ops.conv1d_wgrad(x1, dy, Cin, Cout, ks, dil, pad)
+    assert torch.equal(dw_a, dw_b)                                          # deterministic split-K reduction
+    ops.conv1d_wgrad(x1, dy, Cin, Cout, ks, dil, pad, dw_out=dw_b, db_out=db_b)
+    assert rel_err(dw_b.cpu(), (2 * dw_a).cpu()) < 1e-6 and rel_err(db_b.cpu(), (2 * db_a).cpu()) < 1e-5
+    j = 2
+    sh = j * dil - pad
+    xsft = torch.zeros_like(x1)
+    xsft[:, : T - sh] = x1[:, sh:]
+    tap = torch.einsum("btc,btd->cd", dy.float(), xsft.float())
+    assert rel_err(dw_a[:, :, j].cpu(), tap.cpu()) < 1e-4
+    assert rel_err(db_a.cpu(), dy.float().sum((0, 1)).cpu()) < 1e-5
+    dw_m, _ = ops.conv1d_wgrad(x1, dy, Cin, Cout, ks, dil, pad, lengths=lens, in_mask=True)
+    dw_z, _ = ops.conv1d_wgrad(xz, dy, Cin, Cout, ks, dil, pad)
+    assert torch.equal(dw_m, dw_z)
