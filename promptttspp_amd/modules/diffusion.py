@@ -73,6 +73,7 @@ class GaussianDiffusion(nn.Module):
             self.register_buffer(name, f32(val))
         # test / reproducibility hook: {"t": LongTensor(B), "noise": (B,M,T)} consumed by the next forward
         self.injected = None
+        self.use_graph = True  # HIP-graph replay of the sampler steps on the GPU
 
     def _norm(self, x):
         if self.norm_scale is not None:
@@ -121,28 +122,68 @@ class GaussianDiffusion(nn.Module):
 
     # -- sampling ----------------------------------------------------------------------
     @torch.no_grad()
-    def p_sample_cl(self, x, i, cond, cond_all, noise):
-        B = x.shape[0]
-        t = torch.full((B,), i, device=x.device, dtype=torch.long)
+    def _p_sample_core(self, x, t, cond, cond_all, noise):
+        """One reverse step for a device tensor of step indices ``t`` (B,): x_{t-1} = mean + sigma_t * noise
+        (reference: diffusion.py:283-302; at t == 0 the caller passes zero noise)."""
         eps = self.denoise_fn.forward_cl(x.to(cond.dtype), t, cond, None, cond_all=cond_all).float()
         x0 = self.predict_start_from_noise(x, t, eps).clamp_(-1.0, 1.0)
         mean, _, logvar = self.q_posterior(x0, x, t)
-        if i == 0:
-            return mean
         return mean + (0.5 * logvar).exp() * noise
 
     @torch.no_grad()
-    def inference_cl(self, cond, noise_fn=None):
+    def p_sample_cl(self, x, i, cond, cond_all, noise):
+        B = x.shape[0]
+        t = torch.full((B,), i, device=x.device, dtype=torch.long)
+        if noise is None:  # i == 0: the posterior mean
+            noise = torch.zeros_like(x)
+        return self._p_sample_core(x, t, cond, cond_all, noise)
+
+    @torch.no_grad()
+    def inference_cl(self, cond, noise_fn=None, use_graph=None):
         """cond (B,T,Cc) channels-last -> mel (B,T,M) f32.  ``noise_fn(step|-1, shape)``
-        optionally supplies the initial (-1) and per-step noise (tests)."""
+        optionally supplies the initial (-1) and per-step noise (tests).
+
+        The reverse loop is ~90 kernel launches per step and launch-bound for the batch sizes of
+        synthesis, so on the GPU one step is captured into a HIP graph after the first (eager, cache
+        warming) step and replayed for the remaining K-2: the graph reads x / t / noise from static
+        buffers, writes x back and decrements t itself; the host only refills the noise buffer."""
         B, T, _ = cond.shape
         shape = (B, T, self.out_dim)
         draw = noise_fn if noise_fn is not None else (lambda i, s: torch.randn(s, device=cond.device))
         x = draw(-1, shape)
         cond_all = self.denoise_fn.cond_all(cond)
-        for i in reversed(range(self.K_step)):
-            x = self.p_sample_cl(x, i, cond, cond_all, draw(i, shape) if i > 0 else None)
-        return self._denorm(x)
+        K = self.K_step
+        if use_graph is None:
+            use_graph = self.use_graph
+        if not (use_graph and cond.is_cuda and K > 3):
+            for i in reversed(range(K)):
+                x = self.p_sample_cl(x, i, cond, cond_all, draw(i, shape) if i > 0 else None)
+            return self._denorm(x)
+        x = self.p_sample_cl(x, K - 1, cond, cond_all, draw(K - 1, shape))  # eager: packs weights, sizes the pools
+        xs = x.clone()
+        ts = torch.full((B,), K - 2, device=x.device, dtype=torch.long)
+        ns = torch.zeros_like(xs)
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                xs.copy_(self._p_sample_core(xs, ts, cond, cond_all, ns))
+                ts.sub_(1)
+        except Exception as e:  # capture refused (driver / allocator state): same kernels, launched eagerly
+            import warnings
+
+            warnings.warn(f"HIP graph capture of the sampler step failed ({type(e).__name__}: {e}); running eagerly")
+            for i in reversed(range(K - 1)):
+                x = self.p_sample_cl(x, i, cond, cond_all, draw(i, shape) if i > 0 else None)
+            return self._denorm(x)
+        # (capture does not execute: xs / ts still hold the state after step K-1)
+        for i in reversed(range(K - 1)):
+            if i > 0:
+                ns.copy_(draw(i, shape))
+            else:
+                ns.zero_()
+            g.replay()
+        return self._denorm(xs)
 
     def inference(self, cond, lengths=None, g=None):
         """Reference signature: cond (B,T,Cc) -> (B,T,M)."""
