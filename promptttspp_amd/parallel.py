@@ -46,6 +46,7 @@ class FlatGradReducer:
         self._pending = [b[2] for b in self.buckets]
         self._works = []
         self._launched = [False] * len(self.buckets)
+        self._seen = set()
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
@@ -68,9 +69,14 @@ class FlatGradReducer:
         self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _hook(self, p):
-        bi = self._bucket_of.get(id(p))
-        if bi is None or self._launched[bi]:
+        # A parameter can be reported twice in one step: by functional's direct-accumulation path when
+        # its last weight-gradient kernel has been enqueued, and by autograd's post-accumulate hook
+        # (which this PyTorch also fires for the None gradient those functions return).  Count once.
+        pid = id(p)
+        bi = self._bucket_of.get(pid)
+        if bi is None or self._launched[bi] or pid in self._seen:
             return
+        self._seen.add(pid)
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
@@ -84,6 +90,7 @@ class FlatGradReducer:
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._seen = set()
 
     def finish(self):
         """Wait for the bucket all-reduces and turn sums into means."""
