@@ -217,13 +217,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    # PTPP_BENCH_SELFTEST=1: all ranks on device 0 over gloo -- exercises the N > 1 code path on a 1-GPU
+    # box (RCCL refuses two ranks per device); never set for measurements
+    selftest = bool(os.environ.get("PTPP_BENCH_SELFTEST"))
+    if selftest:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        if selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     from promptttspp_amd import _lib, config
     from promptttspp_amd import functional as PF
@@ -290,10 +298,11 @@ def main():
                "hbm_frac_of_peak": world * a.voc_batch * a.voc_frames * 789312 * (2 if a.dtype == "bf16" else 4) / vdt / 1e9 / (HBM_PEAK_GBS * world)}
 
     log("vocoder leg done")
+    # the instrumented step contains the gradient all-reduce: EVERY rank runs it, rank 0 reports
+    roof = conv_roofline(model, batches[a.warmup + a.steps], red, opt, sched, a.dtype)
     if rank == 0:
-        roof = conv_roofline(model, batches[a.warmup + a.steps], red, opt, sched, a.dtype)
         log(f"roofline pass done: {roof['achieved']} TFLOP/s")
-        cpu = None if a.no_cpu_baseline else cpu_baseline(model, batches[a.warmup])
+        cpu = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(model, batches[a.warmup])  # N = 1 only
         log("cpu baseline done")
         B = batches[a.warmup][0].shape[0]
         line = {

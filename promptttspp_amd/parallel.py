@@ -47,6 +47,7 @@ class FlatGradReducer:
         self._works = []
         self._launched = [False] * len(self.buckets)
         self._seen = set()
+        self._next = 0
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
@@ -78,8 +79,11 @@ class FlatGradReducer:
             return
         self._seen.add(pid)
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        # collectives must be issued in the SAME order on every rank: buckets go out strictly in index
+        # order (the buffer is laid out in backward order, so this costs little overlap)
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def zero_grad(self):
         self.flat.zero_()
@@ -91,14 +95,16 @@ class FlatGradReducer:
         self._launched = [False] * len(self.buckets)
         self._works = []
         self._seen = set()
+        self._next = 0
 
     def finish(self):
         """Wait for the bucket all-reduces and turn sums into means."""
         if self.world == 1:
             return
-        for bi, done in enumerate(self._launched):
-            if not done:  # parameters that received no gradient this step
+        for bi in range(self._next, len(self.buckets)):  # buckets with parameters that received no gradient
+            if not self._launched[bi]:
                 self._launch(bi)
+        self._next = len(self.buckets)
         for w in self._works:
             w.wait()
         self.flat.mul_(1.0 / self.world)
