@@ -199,6 +199,7 @@ int launch_tiles(ConvP& p, hipStream_t st) {
   if (p.T <= 48) return launch_cfg<T, NCH, 2, 1, 2, 8>(p, st);         //  32 x 128, 8 waves of 16 x 32
   if (p.T <= 96 || (p.T % 128 != 0 && p.T % 128 <= 64 && p.T < 512))
     return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);                      //  64 x 128, 8 waves of 32 x 32
+  // (64 x 128 and 256 x 64 tiles measured 10-45 % slower on the frame-level shapes)
   return launch_cfg<T, NCH, 4, 2, 2, 16>(p, st);                       // 128 x 128, 16 waves of 32 x 32
 }
 
