@@ -278,6 +278,24 @@ int ptpp_col2im3x3s2(const void* dcol, void* dx, int B, int H, int W, int C,
                      int dtype, void* stream);
 
 /* ------------------------------------------------------------------ *
+ * GRU cell gate algebra of the GST reference encoder
+ * (modules/reference_encoder.py:108-123, torch.nn.GRU semantics), f32:
+ *   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n),
+ *   h' = (1 - z) n + z h;  rows with step >= lens[b] keep h (packed sequence).
+ *   gi: (B, 3H) rows with stride ldgi (a time slice of W_ih x + b_ih);
+ *   gh: (B, 3H) = W_hh h + b_hh; h, hout: (B, H).  lens nullable.
+ * Backward recomputes the gates: dgi (rows with stride lddgi), dgh, dh
+ * (the direct dh'/dh term; the W_hh path is the caller's GEMM).
+ * ------------------------------------------------------------------ */
+int ptpp_gru_gate_fwd(const float* gi, int64_t ldgi, const float* gh,
+                      const float* h, const int32_t* lens, int step,
+                      float* hout, int B, int H, void* stream);
+int ptpp_gru_gate_bwd(const float* gi, int64_t ldgi, const float* gh,
+                      const float* h, const int32_t* lens, int step,
+                      const float* dhout, float* dgi, int64_t lddgi,
+                      float* dgh, float* dh, int B, int H, void* stream);
+
+/* ------------------------------------------------------------------ *
  * Anti-aliased Snake activation, one fused pass (layers/activations.py:22-44,
  * 74-138): replicate-pad -> x2 polyphase Kaiser-sinc up-FIR (12 taps, gain 2)
  * -> x + sin^2(x e^alpha)/(e^alpha + 1e-9) -> 12-tap low-pass, stride 2.

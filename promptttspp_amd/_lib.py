@@ -82,6 +82,8 @@ SIGNATURES = {
     "ptpp_dwconv1d_wgrad": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "ptpp_im2col3x3s2": (I, [P, P, I, I, I, I, I, P]),
     "ptpp_col2im3x3s2": (I, [P, P, I, I, I, I, I, P]),
+    "ptpp_gru_gate_fwd": (I, [P, I64, P, P, P, I, P, I, I, P]),
+    "ptpp_gru_gate_bwd": (I, [P, I64, P, P, P, I, P, P, I64, P, P, I, I, P]),
     "ptpp_aa_snake_fwd": (I, [P, P, P, POINTER(c_float), POINTER(c_float), I, I, I, I, P]),
     "ptpp_add3_scale": (I, [P, P, P, P, F, I64, I, P]),
     "ptpp_conv_post_tanh": (I, [P, P, F, P, I, I, I, I, I, P]),

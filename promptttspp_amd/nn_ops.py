@@ -182,6 +182,72 @@ def conv2d_3x3s2(x, weight):
     return y.view(B, Ho, Wo, cout)
 
 
+class GruFn(Function):
+    """The GRU recurrence with a hand-written backward: per step ONE GEMM (W_hh h + b_hh, exact f32, on
+    the conv kernel) and ONE gate kernel (csrc/gru.hip), forward and backward.  Inputs: gi_all (B, L, 3H)
+    f32 = W_ih x + b_ih for all steps, weight_hh (3H, H), bias_hh (3H), lens (B) int32."""
+
+    @staticmethod
+    def forward(ctx, gi_all, weight_hh, bias_hh, lens):
+        gi_all = gi_all.contiguous()
+        B, L, H3 = gi_all.shape
+        Hn = H3 // 3
+        lib = _lib.load()
+        wp = PF.packed(weight_hh, torch.float32)
+        bh = PF._f32c(bias_hh)
+        h = torch.zeros((B, Hn), device=gi_all.device, dtype=torch.float32)
+        hs, ghs = [h], []
+        for s in range(L):
+            gh = ops.conv1d(h.unsqueeze(0), wp, bh, H3)[0]
+            hn = torch.empty_like(h)
+            _chk(lib.ptpp_gru_gate_fwd(ctypes.c_void_p(gi_all.data_ptr() + 4 * s * H3), L * H3, _ptr(gh), _ptr(h), _ptr(lens),
+                                       s, _ptr(hn), B, Hn, _stream()), "ptpp_gru_gate_fwd")
+            ghs.append(gh)
+            hs.append(hn)
+            h = hn
+        ctx.hs, ctx.ghs, ctx.lens, ctx.w = hs, ghs, lens, weight_hh
+        ctx.sink = PF._sink(weight_hh) is not None and PF._sink(bias_hh) is not None
+        if ctx.sink:
+            PF._use(weight_hh)
+            PF._use(bias_hh)
+        ctx.b = bias_hh
+        ctx.save_for_backward(gi_all)
+        return h
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dh):
+        (gi_all,) = ctx.saved_tensors
+        B, L, H3 = gi_all.shape
+        Hn = H3 // 3
+        lib = _lib.load()
+        w = ctx.w
+        wpt = PF.packed(w, torch.float32, mode=1)
+        dgi_all = torch.empty_like(gi_all)
+        if ctx.sink:
+            dw, db = w.grad, ctx.b.grad
+        else:
+            dw = torch.zeros((H3, Hn, 1), device=dh.device, dtype=torch.float32)
+            db = torch.zeros((H3,), device=dh.device, dtype=torch.float32)
+        dh = dh.contiguous().float()
+        for s in reversed(range(L)):
+            h_prev, gh = ctx.hs[s], ctx.ghs[s]
+            dgh = torch.empty_like(gh)
+            dhp = torch.empty_like(dh)
+            _chk(lib.ptpp_gru_gate_bwd(ctypes.c_void_p(gi_all.data_ptr() + 4 * s * H3), L * H3, _ptr(gh), _ptr(h_prev),
+                                       _ptr(ctx.lens), s, _ptr(dh), ctypes.c_void_p(dgi_all.data_ptr() + 4 * s * H3), L * H3,
+                                       _ptr(dgh), _ptr(dhp), B, Hn, _stream()), "ptpp_gru_gate_bwd")
+            # dh_{s-1} = direct term + dgh W_hh ;  dW_hh += dgh^T h_{s-1} ;  db_hh += sum_b dgh
+            dh = ops.conv1d(dgh.unsqueeze(0), wpt, None, Hn, res=dhp.unsqueeze(0))[0]
+            ops.conv1d_wgrad(h_prev.unsqueeze(0), dgh.unsqueeze(0), Hn, H3, 1, 1, 0, dw_out=dw, db_out=db)
+        ctx.hs = ctx.ghs = None
+        if ctx.sink:
+            PF._done(w)
+            PF._done(ctx.b)
+            return dgi_all, None, None, None
+        return dgi_all, dw.view_as(w), db, None
+
+
 def gru_last_state(x, weight_ih, weight_hh, bias_ih, bias_hh, lens):
     """Single-layer GRU over (B, L, I), returning each sequence's hidden state at its
     last valid step (B, H) (reference: packed GRU, modules/reference_encoder.py:108-123).
@@ -189,16 +255,5 @@ def gru_last_state(x, weight_ih, weight_hh, bias_ih, bias_hh, lens):
     the recurrent (B,H)x(H,3H) products use the same kernel in exact f32 (no library GEMM:
     rocBLAS/hipBLASLt pick a solution per new (B, ...) shape on the HOST, milliseconds each with
     token-bucket batching) and the gate algebra is a few (B, H) elementwise ops per step."""
-    B, L, _ = x.shape
-    Hn = weight_hh.shape[1]
     gi_all = PF.linear(x, weight_ih, bias_ih).float()  # (B, L, 3H)
-    h = x.new_zeros((B, Hn), dtype=torch.float32)
-    for s in range(L):
-        gi = gi_all[:, s]
-        gh = PF.linear(h, weight_hh, bias_hh)
-        r = torch.sigmoid(gi[:, :Hn] + gh[:, :Hn])
-        z = torch.sigmoid(gi[:, Hn : 2 * Hn] + gh[:, Hn : 2 * Hn])
-        n = torch.tanh(gi[:, 2 * Hn :] + r * gh[:, 2 * Hn :])
-        hn = (1 - z) * n + z * h
-        h = torch.where((s < lens).unsqueeze(-1), hn, h)
-    return h
+    return GruFn.apply(gi_all, weight_hh, bias_hh, ops.i32(lens, x.device))
