@@ -54,6 +54,7 @@ extern "C" {
 #define PTPP_ACT_SWISH 3
 #define PTPP_ACT_TANH 4
 #define PTPP_ACT_MISH 5
+#define PTPP_ACT_GATE 6 /* conv epilogue only, bf16: DiffNet gate sigmoid(a)*tanh(b) fused (see ptpp_conv1d_fwd) */
 
 /* attention variants */
 #define PTPP_ATTN_RELPOS_NEW 0    /* esp/transformer/attention.py:207-305 */
@@ -109,6 +110,10 @@ typedef struct {
   int32_t dtype;
 } ptpp_conv1d_args;
 
+/* act == PTPP_ACT_GATE (bf16, Cout % 8 == 0, 16-byte aligned rows): the weight rows / bias / residual are
+ * laid out as interleaved groups [4 gate channels | their 4 filter channels]; the epilogue writes
+ * y[.., Cout/2] = sigmoid(gate) * tanh(filter) of (conv + bias + res) -- modules/denoiser.py:69-83 without
+ * materialising the 2C-channel pre-activation (inference). */
 int ptpp_conv1d_fwd(const ptpp_conv1d_args* a, void* stream);
 
 /* Full form: second residual, residual scale (AMP-block mean of

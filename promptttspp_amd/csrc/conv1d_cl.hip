@@ -231,6 +231,10 @@ extern "C" int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, i
     if (a->bias) PTPP_CHECK_ARG(((uintptr_t)a->bias % 16) == 0, "conv1d: bias misaligned");
   }
   PTPP_CHECK_ARG(!(a->in_mask || a->out_mask) || a->lengths, "conv1d: masks need lengths");
+  if (a->act == PTPP_ACT_GATE)
+    PTPP_CHECK_ARG(a->dtype == PTPP_BF16 && (a->Cout & 7) == 0 && (a->ldy & 7) == 0 && ((uintptr_t)a->y & 15) == 0 &&
+                       (!a->res || ((a->ldr & 7) == 0 && ((uintptr_t)a->res & 15) == 0)) && !res2 && drop_p == 0.f,
+                   "conv1d: the fused gate epilogue needs bf16, Cout %% 8 == 0 and 16-byte aligned rows");
   ConvP p;
   p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.res = a->res; p.res2 = res2; p.y = a->y;
   p.lengths = a->lengths;

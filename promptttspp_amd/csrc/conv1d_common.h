@@ -126,6 +126,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
               v1[0] += __uint_as_float(r.z << 16); v1[1] += __uint_as_float(r.z & 0xffff0000u);
               v1[2] += __uint_as_float(r.w << 16); v1[3] += __uint_as_float(r.w & 0xffff0000u);
             }
+            if (e_act == PTPP_ACT_GATE) {
+              // fused DiffNet gate: the 8 channels are [4 "gate" | their 4 "filter" partners] (weights
+              // packed in that interleaved order); y has Cout / 2 channels
+              uint2 o;
+              float gte[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) gte[e] = keep ? tanhf(v1[e]) / (1.f + __expf(-v0[e])) : 0.f;
+              o.x = (uint32_t)f32_to_bf16(gte[0]) | ((uint32_t)f32_to_bf16(gte[1]) << 16);
+              o.y = (uint32_t)f32_to_bf16(gte[2]) | ((uint32_t)f32_to_bf16(gte[3]) << 16);
+              *reinterpret_cast<uint2*>(yb + (int64_t)t * e_ldy + (co >> 1)) = o;
+              continue;
+            }
             uint4 o;
             o.x = (uint32_t)f32_to_bf16(v0[0]) | ((uint32_t)f32_to_bf16(v0[1]) << 16);
             o.y = (uint32_t)f32_to_bf16(v0[2]) | ((uint32_t)f32_to_bf16(v0[3]) << 16);

@@ -430,11 +430,37 @@ def posenc(x, pe, scale, drop_p=0.0):
 # DiffNet residual stack (modules/denoiser.py:69-83,136-140) with a hand-written
 # backward: per layer  conv(k3,dilated, +cond slice) -> gate -> 1x1 conv -> post.
 # ----------------------------------------------------------------------------
-def diffnet_cond_all(cond, cond_ws, cond_bs):
-    """All layers' conditioner projections as ONE GEMM: (B,T,Cc) -> (B,T,L*2C)."""
-    cond_ws = list(cond_ws)
+def diffnet_fused_gate(dtype):
+    """Inference in bf16 fuses the DiffNet gate into the dilated conv's epilogue (ptpp.h, PTPP_ACT_GATE)."""
+    return dtype == torch.bfloat16
+
+
+_gate_perm_cache = {}
+
+
+def _gate_perm(c2, device):
+    """Row order [4 gate | 4 filter] per group of 8 for a 2C-channel (gate | filter) tensor."""
+    key = (c2, str(device))
+    p = _gate_perm_cache.get(key)
+    if p is None:
+        C = c2 // 2
+        k = torch.arange(C // 4, device=device)[:, None] * 4 + torch.arange(4, device=device)[None, :]  # (C/4, 4)
+        p = _gate_perm_cache[key] = torch.cat([k, k + C], dim=1).reshape(-1)
+    return p
+
+
+def diffnet_cond_all(cond, cond_ws, cond_bs, gate_perm=False):
+    """All layers' conditioner projections as ONE GEMM: (B,T,Cc) -> (B,T,L*2C).  ``gate_perm``: each
+    layer's 2C channels in the interleaved order of the fused gate epilogue (inference)."""
+    cond_ws, cond_bs = list(cond_ws), list(cond_bs)
     rows = sum(cw.shape[0] for cw in cond_ws)
-    return ops.conv1d(cond, packed_cat(cond_ws, cond.dtype), bias_cat(list(cond_bs)), rows), cond_ws
+    if not gate_perm:
+        return ops.conv1d(cond, packed_cat(cond_ws, cond.dtype), bias_cat(cond_bs), rows), cond_ws
+    perm = _gate_perm(cond_ws[0].shape[0], cond.device)
+    wp = _cat_cached(cond_ws, ("wg", cond.dtype), lambda: ops.pack_conv_weight(
+        torch.cat([w.detach().reshape(w.shape[0], -1)[perm] for w in cond_ws], dim=0), cond.dtype))
+    bp = _cat_cached(cond_bs, "bg", lambda: torch.cat([b.detach().float()[perm] for b in cond_bs], dim=0))
+    return ops.conv1d(cond, wp, bp, rows), cond_ws
 
 
 def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
@@ -445,11 +471,21 @@ def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
     x = h0
     _, yin = ops.diffnet_post_fwd(None, h0, None, dsteps[:, 0].contiguous(), init=True)
     saved = []
+    fused = (not save) and lengths is None and diffnet_fused_gate(h0.dtype)  # cond_all is in gate order then
+    perm = _gate_perm(2 * C, h0.device) if fused else None
     for l, (dw, db, ow, ob) in enumerate(weights):
         d = 2 ** (l % cycle)
-        a = ops.conv1d(yin, packed(dw, h0.dtype), _f32c(db), 2 * C, ks=3, dil=d, pad=d,
-                       res=cond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
-        g = ops.gate_fwd(a)
+        if fused:
+            wp = _cat_cached([dw], ("wg1", h0.dtype), lambda dw=dw: ops.pack_conv_weight(dw.detach()[perm], h0.dtype))
+            bp = _cat_cached([db], "bg1", lambda db=db: db.detach().float()[perm].contiguous())
+            g = torch.empty((B, T, C), device=h0.device, dtype=h0.dtype)
+            ops.conv1d(yin, wp, bp, 2 * C, ks=3, dil=d, pad=d, act="gate", res=cond_all[:, :, l * 2 * C : (l + 1) * 2 * C],
+                       out=g)
+            a = None
+        else:
+            a = ops.conv1d(yin, packed(dw, h0.dtype), _f32c(db), 2 * C, ks=3, dil=d, pad=d,
+                           res=cond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
+            g = ops.gate_fwd(a)
         o = ops.conv1d(g, packed(ow, h0.dtype), _f32c(ob), 2 * C, lengths=lengths, out_mask=lengths is not None)
         if save:
             saved.append((yin, a, g))

@@ -91,10 +91,12 @@ class DiffNet(nn.Module):
         return y.view(e.shape[0], len(self.residual_layers), -1)
 
     def cond_all(self, cond):
-        """All layers' conditioner projections (B,T,L*2C) -- step independent."""
+        """All layers' conditioner projections (B,T,L*2C) -- step independent (inference: in the channel
+        order the fused gate epilogue expects when the compute dtype is bf16)."""
         ls = self.residual_layers
         return PF.diffnet_cond_all(cond, [l.conditioner_projection.weight for l in ls],
-                                   [l.conditioner_projection.bias for l in ls])[0]
+                                   [l.conditioner_projection.bias for l in ls],
+                                   gate_perm=PF.diffnet_fused_gate(cond.dtype))[0]
 
     def forward_cl(self, x, t, cond, lengths=None, cond_all=None):
         """x (B,T,in_dim), cond (B,T,Cc) channels-last; t (B,) -> (B,T,in_dim).
@@ -109,6 +111,7 @@ class DiffNet(nn.Module):
                 [(l.dilated_conv.weight, l.dilated_conv.bias, l.conditioner_projection.weight,
                   l.conditioner_projection.bias, l.output_projection.weight, l.output_projection.bias) for l in ls])
         else:
+            assert lengths is None, "a precomputed cond_all (sampler) is laid out for the unmasked inference path"
             s, _ = PF.diffnet_stack_forward(
                 h0, cond_all, dsteps,
                 [(l.dilated_conv.weight, l.dilated_conv.bias, l.output_projection.weight, l.output_projection.bias)

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import BF16, F32, ConvArgs, check
 
-_ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "swish": 3, "tanh": 4, "mish": 5}
+_ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "swish": 3, "tanh": 4, "mish": 5, "gate": 6}
 _VARIANT = {"new": 0, "legacy": 1, "plain": 2}
 
 
@@ -131,7 +131,7 @@ def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mas
     a.dtype = dtype_code(x.dtype)
     for r in (res, res2):
         if r is not None:
-            assert r.dtype == x.dtype and r.shape == y.shape
+            assert r.dtype == x.dtype and r.shape[:2] == y.shape[:2] and r.shape[2] == cout
     lib = _lib.load()
     if res2 is None and res_scale == 1.0 and drop_p == 0.0:
         check(lib.ptpp_conv1d_fwd(ctypes.byref(a), _stream()), "ptpp_conv1d_fwd")

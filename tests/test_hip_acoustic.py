@@ -528,3 +528,29 @@ def test_bert_frozen_layers_on_hip_match_library_layers(dev):
     out_t.sum().backward()
     g = bw.model.encoder.layer[-1].attention.self.query.weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+
+
+def test_sampler_fused_gate_and_graph_consistency(dev):
+    """bf16 sampler: the fused gate epilogue (PTPP_ACT_GATE, interleaved weight rows) and the HIP-graph replay
+    against the unfused / eager path on the same injected noise: same mel within bf16 rounding."""
+    from promptttspp_amd import config
+    from promptttspp_amd import functional as PF
+
+    g = load_golden("diffusion")
+    m, _ = load(node("decoder"), key_shapes(g["keys"]), 90, dev)
+    m.eval()
+    B, T = 3, 90
+    cond = rnd(5, B, T, 256).to(dev)
+    noise_fn = lambda i, s: rnd(2000 + i, *s).to(dev)  # noqa: E731
+    outs = {}
+    with config.use_dtype(torch.bfloat16), torch.no_grad():
+        for name, fused, graph in (("ref", False, False), ("fused", True, False), ("fused+graph", True, True)):
+            orig = PF.diffnet_fused_gate
+            PF.diffnet_fused_gate = (lambda dt: dt == torch.bfloat16) if fused else (lambda dt: False)
+            try:
+                outs[name] = m.inference_cl(cond.bfloat16(), noise_fn, use_graph=graph).float().cpu()
+            finally:
+                PF.diffnet_fused_gate = orig
+    assert torch.isfinite(outs["ref"]).all()
+    assert rel_err(outs["fused"], outs["ref"]) < 3e-2
+    assert rel_err(outs["fused+graph"], outs["fused"]) < 1e-6   # the graph replays the same kernels
