@@ -96,12 +96,50 @@ def _f32c(t):
 # parameters, so uses are counted in forward and the reducer is notified when the last
 # pending use of a parameter has been accumulated.
 # ----------------------------------------------------------------------------
-_direct = {"on": False, "notify": None, "uses": {}}
+_direct = {"on": False, "notify": None, "uses": {}, "async": False, "side": None}
 
 
-def enable_direct_grads(on=True, notify=None):
+def enable_direct_grads(on=True, notify=None, async_wgrad=True):
+    """``async_wgrad``: in direct mode the weight-gradient kernels (which nothing downstream in backward
+    consumes) run on a side stream, concurrently with the data-gradient chain on the main stream -- each
+    kernel alone leaves the machine under-used (latency / write-phase bound), together they overlap.
+    ``sync_wgrad_stream()`` joins the streams (FlatGradReducer.finish / before a bucket all-reduce)."""
     _direct["on"], _direct["notify"] = bool(on), notify
+    _direct["async"] = bool(on) and bool(async_wgrad)
     _direct["uses"].clear()
+
+
+class wgrad_stream:
+    """``with wgrad_stream(t1, t2, ...):`` -- run the enclosed launches on the weight-gradient side stream
+    (after everything already enqueued on the current stream); the tensors are kept alive for it."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.ctx = None
+
+    def __enter__(self):
+        if not (_direct["async"] and self.tensors and self.tensors[0].is_cuda and not torch.cuda.is_current_stream_capturing()):
+            return self
+        side = _direct["side"]
+        if side is None:
+            side = _direct["side"] = torch.cuda.Stream(device=self.tensors[0].device)
+        side.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            for t in self.tensors:
+                t.record_stream(_direct["side"])
+        return False
+
+
+def sync_wgrad_stream():
+    """The current stream waits for the weight-gradient kernels enqueued so far."""
+    if _direct["side"] is not None:
+        torch.cuda.current_stream().wait_stream(_direct["side"])
 
 
 def reset_direct_uses():
@@ -214,8 +252,9 @@ class Conv1dFn(Function):
                             pad=(ks - 1) * cfg.dil - cfg.pad, lengths=cfg.lengths, out_mask=cfg.in_mask)
         if ctx.direct is not None:
             pw, pb = ctx.direct
-            ops.conv1d_wgrad(x, dz, cin, cout, ks, cfg.dil, cfg.pad, cfg.lengths, cfg.in_mask, pb is not None,
-                             dw_out=pw.grad, db_out=pb.grad if pb is not None else None)
+            with wgrad_stream(x, dz):
+                ops.conv1d_wgrad(x, dz, cin, cout, ks, cfg.dil, cfg.pad, cfg.lengths, cfg.in_mask, pb is not None,
+                                 dw_out=pw.grad, db_out=pb.grad if pb is not None else None)
             _done(pw)
             if pb is not None:
                 _done(pb)
@@ -261,8 +300,9 @@ class FusedLinearFn(Function):
             dx = ops.conv1d(dy, packed_cat(ws, dy.dtype, mode=1), None, cin)
         gw, gb, c0 = [], [], 0
         for w, b, co in zip(ws, bs, ctx.couts):
-            dw, db = ops.conv1d_wgrad(x, dy[:, :, c0 : c0 + co], cin, co, 1, 1, 0,
-                                      dw_out=w.grad if ctx.direct else None, db_out=b.grad if ctx.direct else None)
+            with wgrad_stream(*((x, dy) if ctx.direct else ())):
+                dw, db = ops.conv1d_wgrad(x, dy[:, :, c0 : c0 + co], cin, co, 1, 1, 0,
+                                          dw_out=w.grad if ctx.direct else None, db_out=b.grad if ctx.direct else None)
             c0 += co
             if ctx.direct:
                 _done(w)
@@ -530,10 +570,12 @@ class DiffNetStackFn(Function):
             d = 2 ** (l % ctx.cycle)
             do = ops.diffnet_post_bwd(gx, gS, ctx.lengths)
             tg = [t.grad if ctx.direct else None for t in ws[l]]
-            dwo, dbo = ops.conv1d_wgrad(g, do, C, 2 * C, 1, 1, 0, dw_out=tg[4], db_out=tg[5])
+            with wgrad_stream(*((g, do) if ctx.direct else ())):
+                dwo, dbo = ops.conv1d_wgrad(g, do, C, 2 * C, 1, 1, 0, dw_out=tg[4], db_out=tg[5])
             dg = ops.conv1d(do, packed(out_w, dt, mode=1), None, C)
             da = ops.gate_bwd(a, dg, dcond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
-            dwd, dbd = ops.conv1d_wgrad(yin, da, C, 2 * C, 3, d, d, dw_out=tg[0], db_out=tg[1])
+            with wgrad_stream(*((yin, da) if ctx.direct else ())):
+                dwd, dbd = ops.conv1d_wgrad(yin, da, C, 2 * C, 3, d, d, dw_out=tg[0], db_out=tg[1])
             gx = ops.conv1d(da, packed(dil_w, dt, mode=1), None, C, ks=3, dil=d, pad=d, res=gx, res_scale=r2)
             sn = ops.colsum_batch(gx)
             dd[:, l] = sn - sx * r2
@@ -552,11 +594,12 @@ class DiffNetStackFn(Function):
             # the fused conditioner GEMM's weight gradient in ONE launch (Cout = L*2C: 2.7x the throughput
             # of L per-layer launches), then one multi-tensor add of each layer's row block into its own
             # gradient buffer
-            dwc, dbc = ops.conv1d_wgrad(cond, dcond_all, cond.shape[-1], L * 2 * C, 1, 1, 0)
-            dwl = dwc.view(L, 2 * C, -1)
-            dbl = dbc.view(L, 2 * C)
-            torch._foreach_add_([ws[l][2].grad.view(2 * C, -1) for l in range(L)] + [ws[l][3].grad for l in range(L)],
-                                [dwl[l] for l in range(L)] + [dbl[l] for l in range(L)])
+            with wgrad_stream(cond, dcond_all):
+                dwc, dbc = ops.conv1d_wgrad(cond, dcond_all, cond.shape[-1], L * 2 * C, 1, 1, 0)
+                dwl = dwc.view(L, 2 * C, -1)
+                dbl = dbc.view(L, 2 * C)
+                torch._foreach_add_([ws[l][2].grad.view(2 * C, -1) for l in range(L)] + [ws[l][3].grad for l in range(L)],
+                                    [dwl[l] for l in range(L)] + [dbl[l] for l in range(L)])
             for l in range(L):
                 _done(ws[l][2])
                 _done(ws[l][3])

@@ -67,6 +67,10 @@ class FlatGradReducer:
     def _launch(self, bi):
         a, b, _ = self.buckets[bi]
         self._launched[bi] = True
+        if self.flat.is_cuda:
+            from . import functional as PF
+
+            PF.sync_wgrad_stream()  # the collective orders itself after the CURRENT stream only
         self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _hook(self, p):
@@ -98,7 +102,11 @@ class FlatGradReducer:
         self._next = 0
 
     def finish(self):
-        """Wait for the bucket all-reduces and turn sums into means."""
+        """Join the weight-gradient side stream, wait for the bucket all-reduces, turn sums into means."""
+        if self.flat.is_cuda:
+            from . import functional as PF
+
+            PF.sync_wgrad_stream()
         if self.world == 1:
             return
         for bi in range(self._next, len(self.buckets)):  # buckets with parameters that received no gradient
