@@ -129,6 +129,8 @@ class BigVGAN(nn.Module):
         self.compute_dtype = torch.bfloat16
         self._packed = None
         self._packed_key = None
+        self.parallel_blocks = True  # the 3 AMP blocks of a stage on 3 streams
+        self._streams = None
 
     # -- drop-in helpers ------------------------------------------------------
     def remove_weight_norm(self):
@@ -200,6 +202,9 @@ class BigVGAN(nn.Module):
             h = self._conv(h, up).view(B, T * u, up.cout // u)
             if source_hook is not None:
                 h = source_hook(s, h)
+            if self.parallel_blocks and h.is_cuda and len(blocks) == 3 and not torch.cuda.is_current_stream_capturing():
+                h = self._mrf_parallel(h, blocks, inv)
+                continue
             acc = None
             for layers in blocks:
                 xb = h
@@ -213,6 +218,37 @@ class BigVGAN(nn.Module):
                         acc = self._conv(a, c2, res=xb, res_scale=inv, out_scale=inv, res2=acc)
             h = acc
         return h, pk
+
+    def _mrf_parallel(self, h, blocks, inv):
+        """The three AMP blocks of a stage read the same input and are independent until their mean
+        (vocoders/bigvgan.py:124-128): each runs on its own stream -- every kernel alone is latency /
+        write-phase bound, together they fill the machine -- and the partial results
+        (x_k + conv2(...)) / 3 are summed by one kernel."""
+        main = torch.cuda.current_stream()
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=h.device) for _ in range(2)]
+        outs = []
+        for k, layers in enumerate(blocks):
+            st = main if k == 0 else self._streams[k - 1]
+            if st is not main:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                xb = h
+                for li, (act1, c1, act2, c2) in enumerate(layers):
+                    a = act1.forward_cl(xb)
+                    a = self._conv(a, c1)
+                    a = act2.forward_cl(a)
+                    if li + 1 < len(layers):
+                        xb = self._conv(a, c2, res=xb)
+                    else:
+                        xb = self._conv(a, c2, res=xb, res_scale=inv, out_scale=inv)
+                outs.append(xb)
+            if st is not main:
+                h.record_stream(st)
+        for k in (1, 2):
+            main.wait_stream(self._streams[k - 1])
+            outs[k].record_stream(main)
+        return ops.add3_scale(outs[0], outs[1], outs[2], 1.0)
 
     @torch.no_grad()
     def forward(self, x):

@@ -49,6 +49,8 @@ class F0AwareBigVGAN(BigVGAN):
         self.compute_dtype = compute_dtype()
         self._packed = None
         self._packed_key = None
+        self.parallel_blocks = True
+        self._streams = None
 
     def _source_term(self, s, h, src):
         """noise_convs[s](har_source) as channels-last (B, T_s, C): strided windows x matrix."""
