@@ -114,24 +114,32 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
     orig = ops.conv1d
 
     def timed(x, wp, bias, cout, ks=1, dil=1, pad=0, lengths=None, **kw):
+        T = x.shape[1]
+        # the launches that take the 128 x 128-tile instantiation (tile choice of conv1d_cl.hip::launch_tiles)
+        big = (x.dtype == torch.bfloat16 and cout > 64 and x.shape[2] % 64 == 0
+               and not (T <= 96 or (T % 128 != 0 and T % 128 <= 64 and T < 512)))
+        if not big:
+            return orig(x, wp, bias, cout, ks=ks, dil=dil, pad=pad, lengths=lengths, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         y = orig(x, wp, bias, cout, ks=ks, dil=dil, pad=pad, lengths=lengths, **kw)
         e1.record()
-        rows = float(lengths.sum()) if lengths is not None and (kw.get("out_mask") or kw.get("in_mask")) else x.shape[0] * x.shape[1]
+        rows = float(lengths.sum()) if lengths is not None and (kw.get("out_mask") or kw.get("in_mask")) else x.shape[0] * T
         recs.append((e0, e1, 2.0 * rows * x.shape[2] * cout * ks))
         return y
 
     ops.conv1d = timed
     try:
+        # keep the device busy while the host enqueues the step, so that the events bracket kernel
+        # execution and not launch gaps (the instrumented step is host-bound)
+        torch.cuda._sleep(int(0.08 * 2.4e9))
         train_step(model, batch, red, opt, sched)
         torch.cuda.synchronize()
     finally:
         ops.conv1d = orig
-    # the dominant kernel = the 128 x 128-tile instantiation that takes the frame-level layers
-    # (rocprof: conv1d_cl_kernel<unsigned short, 8, 4, 2, 2, 16>); phone-level / GRU / BERT launches of the
-    # same family use smaller tiles and are listed in profiles/, not averaged in here
-    recs = [r for r in recs if r[2] >= 2e9] or recs
+    # the dominant kernel = the 128 x 128-tile instantiation (rocprof: conv1d_cl_kernel<unsigned short, 8, 4,
+    # 2, 2, 16>; profiles/r01_train_step_final.md is the rocprofv3 summary of the training leg of this
+    # command); launches of the same family with smaller tiles are listed there, not averaged in here
     tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
     tot_flop = sum(f for _, _, f in recs)
     ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
@@ -299,7 +307,10 @@ def main():
 
     log("vocoder leg done")
     # the instrumented step contains the gradient all-reduce: EVERY rank runs it, rank 0 reports
-    roof = conv_roofline(model, batches[a.warmup + a.steps], red, opt, sched, a.dtype)
+    # instrumented on the timed batch with the longest utterances (the 128 x 128-tile instantiation takes
+    # every frame-level layer there; short-utterance batches route some launches to the 64 x 128 tiles)
+    rb = max(range(a.warmup, a.warmup + a.steps), key=lambda i: batches[i][3].shape[2])
+    roof = conv_roofline(model, batches[rb], red, opt, sched, a.dtype)
     if rank == 0:
         log(f"roofline pass done: {roof['achieved']} TFLOP/s")
         cpu = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(model, batches[a.warmup])  # N = 1 only
