@@ -4,6 +4,7 @@ through the C ABI.  All activations are channels-last (B, T, C) in the compute
 dtype; parameters stay f32 (master weights) and are packed/cast per version.
 """
 import math
+import os
 import weakref
 from types import SimpleNamespace
 
@@ -105,7 +106,7 @@ def enable_direct_grads(on=True, notify=None, async_wgrad=True):
     kernel alone leaves the machine under-used (latency / write-phase bound), together they overlap.
     ``sync_wgrad_stream()`` joins the streams (FlatGradReducer.finish / before a bucket all-reduce)."""
     _direct["on"], _direct["notify"] = bool(on), notify
-    _direct["async"] = bool(on) and bool(async_wgrad)
+    _direct["async"] = bool(on) and bool(async_wgrad) and not os.environ.get("PTPP_NO_ASYNC_WGRAD")
     _direct["uses"].clear()
 
 

@@ -54,7 +54,10 @@ class FlatGradReducer:
         if direct and dev.type == "cuda":
             from . import functional as PF
 
-            PF.enable_direct_grads(True, notify=self._hook if self.world > 1 else None)
+            # the weight-gradient side stream is used at world size 1 only: with a collective in the step it
+            # measured far slower in the 2-rank gloo self-test (tools/diag_dp_async.py: finish() 577 vs 101
+            # ms) and could not be tried over RCCL here, so multi-rank runs keep everything on one stream
+            PF.enable_direct_grads(True, notify=self._hook if self.world > 1 else None, async_wgrad=self.world == 1)
 
     # -- parameter broadcast (DDP constructor semantics) ------------------------------
     def broadcast_parameters(self, module, src=0):
