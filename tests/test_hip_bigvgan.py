@@ -105,3 +105,21 @@ def test_f0_aware_bigvgan_matches_reference_golden(dev):
         torch.rand, torch.randn_like = o_rand, o_like
     assert y.shape == g["y"].shape
     assert rel_err(y, g["y"]) < 1e-3
+
+
+def test_bigvgan_bench_size_batch_independence(dev):
+    """BASELINE config 4 size (64 x 1000 frames, bf16): tiles never span utterances, so every utterance of
+    the batch must come out BIT-IDENTICAL to the same utterance synthesised alone (streams / tile order /
+    batch index must not change the arithmetic), finite and inside (-1, 1)."""
+    from oracle.fill import fill_state_dict
+    from promptttspp_amd.vocoders import BigVGAN
+
+    torch.manual_seed(3)
+    m = BigVGAN(80, 512, [6, 5, 4, 2], [12, 10, 8, 4], [3, 7, 11], [[1, 3, 5]] * 3)
+    fill_state_dict(m, seed=5, overrides={"weight_g": 0.4})
+    m = m.to(dev).eval().set_compute_dtype(torch.bfloat16)
+    x = torch.clamp(-5.5 + 2.1 * torch.randn(64, 80, 1000, device=dev), -11.5, 2.0)
+    y = m(x)
+    assert y.shape == (64, 1, 240000) and torch.isfinite(y).all() and float(y.abs().max()) <= 1.0
+    for b in (0, 37, 63):
+        assert torch.equal(m(x[b : b + 1])[0], y[b]), b
