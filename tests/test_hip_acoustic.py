@@ -554,3 +554,40 @@ def test_sampler_fused_gate_and_graph_consistency(dev):
     assert torch.isfinite(outs["ref"]).all()
     assert rel_err(outs["fused"], outs["ref"]) < 3e-2
     assert rel_err(outs["fused+graph"], outs["fused"]) < 1e-6   # the graph replays the same kernels
+
+
+def test_model_forward_bench_size_properties(dev):
+    """One BASELINE-sized training batch (max_tokens = 30 000 synthetic LibriTTS-R utterances), eval mode, f32:
+    the forward is bit-reproducible, and the five losses do not change when the batch is padded with extra
+    phone / frame columns (every mask, the length regulator and the tile edge handling at full size)."""
+    import sys
+
+    import torch.nn.functional as F
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    torch.manual_seed(0)
+    model = bench.build_model(dev).eval()
+    batch = bench.make_batches(0, 1, 1, 30000, dev)[0]
+    phon, dur, plen, mel, cf0, vuv, energy, flen, prompt = batch
+    B, Tf = mel.shape[0], mel.shape[2]
+    g = torch.Generator().manual_seed(5)
+    inj = {"t": torch.randint(0, 100, (B,), generator=g), "noise": torch.randn(B, 80, Tf, generator=g)}
+
+    def losses(b, noise):
+        model.decoder.injected = {"t": inj["t"], "noise": noise}
+        with torch.no_grad():
+            out = model(b)
+        return {k: float(v) for k, v in out.items()}
+
+    a = losses(batch, inj["noise"])
+    assert all(np.isfinite(v) for v in a.values())
+    assert losses(batch, inj["noise"]) == a                                  # bit-reproducible
+    pp, pf = 9, 70                                                              # extra padded phones / frames
+    padp = lambda x: F.pad(x, (0, pp))                                          # noqa: E731
+    padf = lambda x: F.pad(x, (0, pf))                                          # noqa: E731
+    padded = [padp(phon), padp(dur), plen, padf(mel), padf(cf0), padf(vuv), padf(energy), flen, prompt]
+    b2 = losses(padded, padf(inj["noise"]))
+    for k in a:
+        assert abs(a[k] - b2[k]) <= 2e-5 * max(1.0, abs(a[k])), (k, a[k], b2[k])
