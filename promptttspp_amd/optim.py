@@ -79,6 +79,9 @@ class FusedAdamW(torch.optim.Optimizer):
                                     _stream()),
                 "ptpp_adamw_step",
             )
+            # the kernel writes the parameters through raw pointers: tell autograd (and every cache
+            # keyed on Tensor._version -- the packed-weight caches of functional.py) that they changed
+            torch.autograd.graph.increment_version([p for p in g["params"] if p.grad is not None])
         return loss
 
     def grad_norm(self):

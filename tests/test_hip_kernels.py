@@ -307,3 +307,24 @@ def test_conv_family_at_bench_size_properties(dev):
     dw_m, _ = ops.conv1d_wgrad(x1, dy, Cin, Cout, ks, dil, pad, lengths=lens, in_mask=True)
     dw_z, _ = ops.conv1d_wgrad(xz, dy, Cin, Cout, ks, dil, pad)
     assert torch.equal(dw_m, dw_z)
+
+
+def test_fused_adamw_invalidates_packed_weight_caches(dev):
+    """FusedAdamW updates parameters through raw pointers; the packed-operand caches are keyed on
+    Tensor._version, so the optimiser must bump it: the NEXT forward has to see the updated weights."""
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd.optim import FusedAdamW
+
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 32).to(dev)
+    x = torch.randn(2, 10, 64, device=dev)
+    opt = FusedAdamW(lin.parameters(), lr=0.1)
+    y0 = PF.linear(x, lin.weight, lin.bias)
+    v0 = lin.weight._version
+    y0.square().mean().backward()
+    opt.step()
+    assert lin.weight._version > v0
+    y1 = PF.linear(x, lin.weight, lin.bias)
+    ref = F.linear(x, lin.weight.detach(), lin.bias.detach())
+    assert rel_err(y1.detach().cpu(), ref.cpu()) < 1e-5          # the new weights, not the cached pack
+    assert float((y1 - y0).abs().max()) > 1e-3
