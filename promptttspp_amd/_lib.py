@@ -57,6 +57,7 @@ SIGNATURES = {
     "ptpp_version": (I, []),
     "ptpp_conv_cin_padded": (I, [I, I]),
     "ptpp_pack_conv_weight": (I, [P, P, I, I, I, I, I, P]),
+    "ptpp_pack_conv_weights_batched": (I, [P, I, I, P]),
     "ptpp_conv1d_fwd": (I, [POINTER(ConvArgs), P]),
     "ptpp_conv1d_fwd_ex": (I, [POINTER(ConvArgs), P, I, F, F, U64, P]),
     "ptpp_conv1d_wgrad": (I, [P, P, P, P, P] + [I] * 11 + [P, SZ, P]),

@@ -24,6 +24,40 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp
   }
 }
 
+// Batched re-pack after an optimiser step: ONE launch for every cached operand (a training step uses
+// ~350 packed operands; one launch each was ~4 ms of the step).  Table row (int64 x 10):
+//   src f32 (cout, cin, ks) | dst base | cout | cin | ks | mode | dtype | innerp of dst | row/col offset | first block
+// Each source element goes to
+//   mode 0: dst[((off + co) * ks + j) * innerp + ci]          (rows of several sources stack: fused QKV ...)
+//   mode 1: dst[(ci * ks + ks-1-j) * innerp + off + co]       (their columns concatenate)
+// The padding columns of dst were zeroed when the buffer was created.
+constexpr int PACK_CHUNK = 2048;  // source elements per block
+
+__global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {  // last row whose first block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid * 10 + 9] <= (int64_t)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const int64_t* e = tab + lo * 10;
+  const float* src = reinterpret_cast<const float*>(e[0]);
+  const int cout = (int)e[2], cin = (int)e[3], ks = (int)e[4], mode = (int)e[5], dtype = (int)e[6];
+  const int64_t innerp = e[7], off = e[8];
+  const int64_t total = (int64_t)cout * cin * ks;
+  const int64_t base = ((int64_t)blockIdx.x - e[9]) * PACK_CHUNK;
+  for (int k = threadIdx.x; k < PACK_CHUNK; k += 256) {
+    const int64_t i = base + k;
+    if (i >= total) break;
+    const int j = (int)(i % ks);
+    const int ci = (int)((i / ks) % cin);
+    const int co = (int)(i / ((int64_t)ks * cin));
+    const int64_t d = mode == 0 ? ((off + co) * ks + j) * innerp + ci : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
+    if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = src[i];
+    else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(src[i]);
+  }
+}
+
 // 32x32 LDS-tiled transpose of the two inner dims with dtype conversion.
 template <typename TI, typename TO>
 __global__ void transpose_kernel(const TI* __restrict__ x, TO* __restrict__ y, int R, int S) {
@@ -64,6 +98,14 @@ extern "C" int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin
     hipLaunchKernelGGL(pack_conv_kernel<bf16_raw>, dim3(grid), dim3(256), 0, st, w, (bf16_raw*)wp, cout, cin, ks, mode,
                        rows, inner, innerp);
   PTPP_CHECK_LAUNCH("pack_conv_weight");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_pack_conv_weights_batched(const int64_t* table, int n_entries, int total_blocks, void* stream) {
+  PTPP_CHECK_ARG(table && n_entries > 0 && total_blocks > 0, "pack_conv_weights_batched: bad args");
+  hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table,
+                     n_entries);
+  PTPP_CHECK_LAUNCH("pack_conv_weights_batched");
   return PTPP_OK;
 }
 

@@ -34,31 +34,111 @@ def next_seed():
 
 
 # ----------------------------------------------------------------------------
-# packed-weight cache (per parameter version)
+# packed-weight cache.  Every conv / linear weight is consumed as a packed K-contiguous operand in the
+# compute dtype (mode 0: forward, mode 1: flipped / transposed for the data gradient); fused projections
+# (q|k|v, the DiffNet conditioner stack) pack SEVERAL parameters into one operand.  An entry is valid
+# for the same live Parameter objects at the same Tensor._version and storage.  After an optimiser step
+# every trainable entry is stale: ``repack_all()`` refreshes all of them in ONE launch
+# (ptpp_pack_conv_weights_batched, a device pointer table rebuilt only when the set of entries changes);
+# anything still stale when it is next used is re-packed on its own.
 # ----------------------------------------------------------------------------
+class _PackEntry:
+    __slots__ = ("refs", "vers", "wp", "mode", "dtype", "__weakref__")
+
+    def srcs(self):
+        out = [r() for r in self.refs]
+        return None if any(t is None for t in out) else out
+
+    @staticmethod
+    def stamp(ws):
+        return tuple((w._version, w.data_ptr()) for w in ws)
+
+
 _pack_cache = {}
+_repack = {"key": None, "table": None, "n": 0, "blocks": 0}
+_PACK_CHUNK = 2048  # PTPP_PACK_CHUNK
+
+
+def _pack_now(ws, dtype, mode):
+    w = ws[0] if len(ws) == 1 else torch.cat([t.detach().reshape(t.shape[0], -1) for t in ws], dim=0)
+    return ops.pack_conv_weight(w, dtype, mode)
+
+
+def _packed_entry(ws, dtype, mode):
+    key = (tuple(id(w) for w in ws), mode, dtype)
+    ent = _pack_cache.get(key)
+    if ent is not None:
+        live = ent.srcs()
+        if live is not None and all(a is b for a, b in zip(live, ws)):
+            if ent.vers != _PackEntry.stamp(ws):
+                ent.wp, ent.vers = _pack_now(ws, dtype, mode), _PackEntry.stamp(ws)
+            return ent
+    ent = _PackEntry()
+    ent.refs = [weakref.ref(w, lambda _r, k=key: _pack_cache.pop(k, None)) for w in ws]
+    ent.mode, ent.dtype = mode, dtype
+    ent.wp, ent.vers = _pack_now(ws, dtype, mode), _PackEntry.stamp(ws)
+    _pack_cache[key] = ent
+    return ent
 
 
 def packed(w, dtype, mode=0):
     """Packed K-contiguous operand of weight ``w`` (f32, (Cout,Cin[,ks]))."""
     if not isinstance(w, torch.nn.Parameter):
         return ops.pack_conv_weight(w, dtype, mode)
-    key = (id(w), mode, dtype)
-    ent = _pack_cache.get(key)
-    # an entry is valid only for the SAME live Parameter object (ids and device addresses
-    # are recycled when models are freed), same in-place version and same storage
-    if ent is not None and ent[3]() is w and ent[0] == w._version and ent[1] == w.data_ptr():
-        return ent[2]
-    wp = ops.pack_conv_weight(w, dtype, mode)
-    _pack_cache[key] = (w._version, w.data_ptr(), wp, weakref.ref(w, lambda _r, k=key: _pack_cache.pop(k, None)))
-    return wp
+    return _packed_entry((w,), dtype, mode).wp
+
+
+def packed_cat(ws, dtype, mode=0):
+    """Packed operand of the row-wise concatenation of several (Cout_i, Cin[,1]) weights."""
+    ws = tuple(ws)
+    if not all(isinstance(w, torch.nn.Parameter) for w in ws):
+        return _pack_now(ws, dtype, mode)
+    return _packed_entry(ws, dtype, mode).wp
+
+
+def repack_all():
+    """Refresh every stale cached operand in one launch (call right after an in-place parameter update)."""
+    todo = []
+    for ent in list(_pack_cache.values()):
+        ws = ent.srcs()
+        if ws is None or not ws[0].is_cuda:
+            continue
+        st = _PackEntry.stamp(ws)
+        if st != ent.vers:
+            todo.append((ent, ws, st))
+    if not todo:
+        return
+    key = tuple((id(e), e.wp.data_ptr(), st) for e, _, st in todo)
+    key = tuple((k[0], k[1], tuple(p for _, p in k[2])) for k in key)  # entry, dst, source pointers
+    if key != _repack["key"]:
+        rows, blk = [], 0
+        for ent, ws, _ in todo:
+            w0 = ws[0]
+            cin = w0.shape[1]
+            ks = w0.shape[2] if w0.dim() == 3 else 1
+            dcode = ops.dtype_code(ent.dtype)
+            total_cout = sum(w.shape[0] for w in ws)
+            innerp = ops.cin_padded(cin if ent.mode == 0 else total_cout, ent.dtype)
+            off = 0
+            for w in ws:
+                assert w.dtype == torch.float32 and w.is_contiguous()
+                rows.append([w.data_ptr(), ent.wp.data_ptr(), w.shape[0], cin, ks, ent.mode, dcode, innerp, off, blk])
+                blk += (w.numel() + _PACK_CHUNK - 1) // _PACK_CHUNK
+                off += w.shape[0]
+        import numpy as np
+
+        _repack["table"] = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(todo[0][1][0].device)
+        _repack["key"], _repack["n"], _repack["blocks"] = key, len(rows), blk
+    ops.pack_conv_weights_batched(_repack["table"], _repack["n"], _repack["blocks"])
+    for ent, _, st in todo:
+        ent.vers = st
 
 
 _cat_cache = {}
 
 
 def _cat_cached(ts, kind, make):
-    """Cache of a tensor derived from a LIST of live parameters (fused projections)."""
+    """Cache of a tensor derived from a LIST of live parameters (fused biases, permuted operands)."""
     key = (tuple(id(t) for t in ts), kind)
     vers = tuple((t._version, t.data_ptr()) for t in ts)
     ent = _cat_cache.get(key)
@@ -69,12 +149,6 @@ def _cat_cached(ts, kind, make):
     return val
 
 
-def packed_cat(ws, dtype, mode=0):
-    """Packed operand of the row-wise concatenation of several (Cout_i, Cin[,1]) weights."""
-    return _cat_cached(ws, ("w", mode, dtype), lambda: ops.pack_conv_weight(
-        torch.cat([w.detach().reshape(w.shape[0], -1) for w in ws], dim=0), dtype, mode))
-
-
 def bias_cat(bs):
     return _cat_cached(bs, "b", lambda: torch.cat([b.detach().float() for b in bs], dim=0))
 
@@ -82,6 +156,7 @@ def bias_cat(bs):
 def clear_caches():
     _pack_cache.clear()
     _cat_cache.clear()
+    _repack["key"] = None
 
 
 def _f32c(t):

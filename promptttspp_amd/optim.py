@@ -82,6 +82,9 @@ class FusedAdamW(torch.optim.Optimizer):
             # the kernel writes the parameters through raw pointers: tell autograd (and every cache
             # keyed on Tensor._version -- the packed-weight caches of functional.py) that they changed
             torch.autograd.graph.increment_version([p for p in g["params"] if p.grad is not None])
+        from . import functional as PF
+
+        PF.repack_all()  # one launch refreshes every cached packed operand of the updated weights
         return loss
 
     def grad_norm(self):

@@ -328,3 +328,34 @@ def test_fused_adamw_invalidates_packed_weight_caches(dev):
     ref = F.linear(x, lin.weight.detach(), lin.bias.detach())
     assert rel_err(y1.detach().cpu(), ref.cpu()) < 1e-5          # the new weights, not the cached pack
     assert float((y1 - y0).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_repack_matches_per_tensor_pack(dtype, dev):
+    """repack_all() (one launch over a pointer table, after FusedAdamW) must leave every cached operand --
+    forward and data-gradient forms, single weights, k > 1 convs, odd channel counts with padding, fused
+    q|k|v stacks -- identical to a fresh per-tensor pack of the updated weights."""
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd import ops
+    from promptttspp_amd.optim import FusedAdamW
+
+    torch.manual_seed(1)
+    PF.clear_caches()
+    conv = torch.nn.Conv1d(80, 256, 5).to(dev)
+    lin = torch.nn.Linear(256, 104).to(dev)
+    qkv = [torch.nn.Linear(64, 64).to(dev) for _ in range(3)]
+    params = [conv.weight, lin.weight] + [m.weight for m in qkv]
+    opt = FusedAdamW(params, lr=0.05)
+    for step in range(3):
+        got = [PF.packed(conv.weight, dtype), PF.packed(conv.weight, dtype, 1), PF.packed(lin.weight, dtype),
+               PF.packed(lin.weight, dtype, 1), PF.packed_cat([m.weight for m in qkv], dtype),
+               PF.packed_cat([m.weight for m in qkv], dtype, 1)]
+        cat = torch.cat([m.weight.detach() for m in qkv], dim=0)
+        want = [ops.pack_conv_weight(conv.weight, dtype), ops.pack_conv_weight(conv.weight, dtype, 1),
+                ops.pack_conv_weight(lin.weight, dtype), ops.pack_conv_weight(lin.weight, dtype, 1),
+                ops.pack_conv_weight(cat, dtype), ops.pack_conv_weight(cat, dtype, 1)]
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.shape == b.shape and torch.equal(a, b), (step, i)
+        for p in params:
+            p.grad = torch.randn_like(p)
+        opt.step()  # bumps versions and calls repack_all()
