@@ -81,9 +81,9 @@ int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin, int ks,
 /* Re-pack MANY operands in one launch (after an optimiser step).  table: device array of n_entries rows
  * of 10 int64: {src f32 (cout,cin,ks), dst base, cout, cin, ks, mode, dtype, innerp of dst,
  * row (mode 0) / column (mode 1) offset inside dst, first block}; block b serves the last row whose
- * "first block" <= b, 2048 source elements per block; total_blocks = sum of ceil(cout*cin*ks / 2048).
+ * "first block" <= b, one 64 x 64 (cout x cin) tile with all taps per block; total_blocks = sum of
+ * ceil(cout/64) * ceil(cin/64).
  * Several sources may share one dst (fused projections).  dst padding is NOT written (zero it once). */
-#define PTPP_PACK_CHUNK 2048
 int ptpp_pack_conv_weights_batched(const int64_t* table, int n_entries,
                                    int total_blocks, void* stream);
 

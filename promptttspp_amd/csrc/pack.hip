@@ -27,13 +27,15 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp
 // Batched re-pack after an optimiser step: ONE launch for every cached operand (a training step uses
 // ~350 packed operands; one launch each was ~4 ms of the step).  Table row (int64 x 10):
 //   src f32 (cout, cin, ks) | dst base | cout | cin | ks | mode | dtype | innerp of dst | row/col offset | first block
-// Each source element goes to
+// A block serves one 64 x 64 (co x ci) tile of one source, all taps.  Each source element goes to
 //   mode 0: dst[((off + co) * ks + j) * innerp + ci]          (rows of several sources stack: fused QKV ...)
 //   mode 1: dst[(ci * ks + ks-1-j) * innerp + off + co]       (their columns concatenate)
 // The padding columns of dst were zeroed when the buffer was created.
-constexpr int PACK_CHUNK = 2048;  // source elements per block
-
+// A block owns one 64 (co) x 64 (ci) tile of a source, all taps: reads run along ci, mode-0 writes along
+// ci, mode-1 writes along co after a transpose through LDS (element-wise scattered 2-byte writes made
+// the first version of this kernel 1 ms per step).
 __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __restrict__ tab, int n) {
+  __shared__ float tile[64][65];
   int lo = 0, hi = n - 1;
   while (lo < hi) {  // last row whose first block <= blockIdx.x
     const int mid = (lo + hi + 1) >> 1;
@@ -44,17 +46,37 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
   const float* src = reinterpret_cast<const float*>(e[0]);
   const int cout = (int)e[2], cin = (int)e[3], ks = (int)e[4], mode = (int)e[5], dtype = (int)e[6];
   const int64_t innerp = e[7], off = e[8];
-  const int64_t total = (int64_t)cout * cin * ks;
-  const int64_t base = ((int64_t)blockIdx.x - e[9]) * PACK_CHUNK;
-  for (int k = threadIdx.x; k < PACK_CHUNK; k += 256) {
-    const int64_t i = base + k;
-    if (i >= total) break;
-    const int j = (int)(i % ks);
-    const int ci = (int)((i / ks) % cin);
-    const int co = (int)(i / ((int64_t)ks * cin));
-    const int64_t d = mode == 0 ? ((off + co) * ks + j) * innerp + ci : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
-    if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = src[i];
-    else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(src[i]);
+  const int lb = (int)((int64_t)blockIdx.x - e[9]);
+  const int nci = (cin + 63) / 64;
+  const int co0 = (lb / nci) * 64, ci0 = (lb % nci) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int j = 0; j < ks; ++j) {
+    // tile[co_l][ci_l], reads with ci fastest
+    for (int r = ty; r < 64; r += 4) {
+      const int co = co0 + r, ci = ci0 + tx;
+      tile[r][tx] = (co < cout && ci < cin) ? src[((int64_t)co * cin + ci) * ks + j] : 0.f;
+    }
+    __syncthreads();
+    if (mode == 0) {
+      for (int r = ty; r < 64; r += 4) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < cout && ci < cin) {
+          const int64_t d = ((off + co) * ks + j) * innerp + ci;
+          if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = tile[r][tx];
+          else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(tile[r][tx]);
+        }
+      }
+    } else {
+      for (int r = ty; r < 64; r += 4) {  // r indexes ci here, writes run along co
+        const int ci = ci0 + r, co = co0 + tx;
+        if (co < cout && ci < cin) {
+          const int64_t d = ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
+          if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = tile[tx][r];
+          else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(tile[tx][r]);
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -56,7 +56,6 @@ class _PackEntry:
 
 _pack_cache = {}
 _repack = {"key": None, "table": None, "n": 0, "blocks": 0}
-_PACK_CHUNK = 2048  # PTPP_PACK_CHUNK
 
 
 def _pack_now(ws, dtype, mode):
@@ -123,7 +122,7 @@ def repack_all():
             for w in ws:
                 assert w.dtype == torch.float32 and w.is_contiguous()
                 rows.append([w.data_ptr(), ent.wp.data_ptr(), w.shape[0], cin, ks, ent.mode, dcode, innerp, off, blk])
-                blk += (w.numel() + _PACK_CHUNK - 1) // _PACK_CHUNK
+                blk += ((w.shape[0] + 63) // 64) * ((cin + 63) // 64)
                 off += w.shape[0]
         import numpy as np
 

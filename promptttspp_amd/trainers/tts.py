@@ -121,6 +121,7 @@ class TTSTrainer:
 
     # ------------------------------------------------------------------ main loop
     def _train(self, local_rank, rank, world):
+        from .. import functional as PF
         from ..optim import FusedAdamW
         from ..parallel import FlatGradReducer
 
@@ -205,6 +206,8 @@ class TTSTrainer:
                 if not fused:
                     torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
                 optimizer.step()
+                if not fused:
+                    PF.repack_all()  # (FusedAdamW does this itself) refresh the packed operands in one launch
                 if not per_epoch_scheduler and lr_scheduler is not None:
                     lr_scheduler.step()
                 global_step += 1
