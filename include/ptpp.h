@@ -171,16 +171,28 @@ int ptpp_layernorm_fwd(const void* x, const void* res, const float* gamma,
                        uint64_t drop_in_seed, float drop_out_p,
                        uint64_t drop_out_seed, int dtype, void* stream);
 
+/* Reduction scratch (ptpp_layernorm_bwd, ptpp_col_reduce, ptpp_bn_act_bwd): f32 atomics from
+ * many blocks on one cache line serialise on MI355X (~50 ns per block visit), so per-column sums
+ * go through a caller-owned scratch: block b adds its totals into replica b % 32, and a small
+ * finishing launch sums the replicas, delivers the result and zeroes the scratch again.
+ *   - PTPP_RED_SCRATCH_BYTES(C) bytes of device memory, 16-byte aligned;
+ *   - all ZERO before the first call (the kernels leave it zero);
+ *   - one per stream: calls that may overlap must not share it, and it must not double as the
+ *     conv1d_wgrad workspace. */
+#define PTPP_RED_REPLICAS 32
+#define PTPP_RED_SCRATCH_BYTES(C) (PTPP_RED_REPLICAS * 8 * (size_t)(C))
+
 /* dsum = dL/ds (also the gradient of `res`); dz = dsum*dropmask_in*act_in'(z)
- * when act_in/drop_in were used (z = the forward `x`).  dgamma/dbeta are
- * atomically accumulated into caller-zeroed f32 buffers (nullable). */
+ * when act_in/drop_in were used (z = the forward `x`).  dgamma/dbeta (nullable)
+ * are f32 buffers the totals are ADDED to (`+=`, ordered on the stream); scratch
+ * is needed when either is non-NULL. */
 int ptpp_layernorm_bwd(const void* dy, const void* xsum, const void* z,
                        const float* gamma, const float* mean, const float* rstd,
                        void* dsum, void* dz, float* dgamma, float* dbeta,
                        const int32_t* lengths, int B, int T, int C, int out_mask,
                        int act_in, float drop_in_p, uint64_t drop_in_seed,
                        float drop_out_p, uint64_t drop_out_seed, int dtype,
-                       void* stream);
+                       void* scratch, size_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Relative-position multi-head attention for short sequences
@@ -260,9 +272,11 @@ int ptpp_colsum_batch(const void* x, float* out, int B, int T, int C, int dtype,
  * MFMA GEMM above).  `rows` = all rows, padded positions included, exactly
  * like the reference's train-mode BatchNorm.
  * ------------------------------------------------------------------ */
-/* out[c] += sum_r x[r,c]  (mean == NULL)  or  sum_r (x[r,c]-mean[c])^2 ; out zeroed by caller */
+/* out[c] = sum_r x[r,c]  (mean == NULL)  or  sum_r (x[r,c]-mean[c])^2 ; out (C f32) is overwritten.
+ * scratch: the reduction scratch described at ptpp_layernorm_bwd. */
 int ptpp_col_reduce(const void* x, const float* mean, float* out, int64_t rows,
-                    int C, int dtype, void* stream);
+                    int C, int dtype, void* scratch, size_t scratch_bytes,
+                    void* stream);
 /* y = act(gamma*(x-mean)*rstd + beta), act in {NONE, RELU, SWISH} */
 int ptpp_bn_act_fwd(const void* x, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, void* y, int64_t rows,
@@ -272,7 +286,7 @@ int ptpp_bn_act_fwd(const void* x, const float* mean, const float* rstd,
 int ptpp_bn_act_bwd(const void* x, const void* dy, const float* mean,
                     const float* rstd, const float* gamma, const float* beta,
                     float* sums, void* dx, int64_t rows, int C, int act, int train,
-                    int dtype, void* stream);
+                    int dtype, void* scratch, size_t scratch_bytes, void* stream);
 /* u = h[:, :C] * sigmoid(h[:, C:]) and its backward */
 int ptpp_glu_fwd(const void* h, void* u, int64_t rows, int C, int dtype, void* stream);
 int ptpp_glu_bwd(const void* h, const void* du, void* dh, int64_t rows, int C,

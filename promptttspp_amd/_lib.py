@@ -63,7 +63,7 @@ SIGNATURES = {
     "ptpp_conv1d_wgrad": (I, [P, P, P, P, P] + [I] * 11 + [P, SZ, P]),
     "ptpp_epilogue_bwd": (I, [P, P, P, P, I, I, I, F, I, I, F, U64, I, P]),
     "ptpp_layernorm_fwd": (I, [P] * 9 + [I, I, I, F, I, I, F, U64, F, U64, I, P]),
-    "ptpp_layernorm_bwd": (I, [P] * 11 + [I, I, I, I, I, F, U64, F, U64, I, P]),
+    "ptpp_layernorm_bwd": (I, [P] * 11 + [I, I, I, I, I, F, U64, F, U64, I, P, SZ, P]),
     "ptpp_attention_fwd": (I, [P] * 9 + [I] * 8 + [F, U64, I, P]),
     "ptpp_attention_bwd": (I, [P] * 16 + [I] * 10 + [P]),
     "ptpp_length_regulate_fwd": (I, [P, P, P, I, I, I, I, I, P]),
@@ -74,9 +74,9 @@ SIGNATURES = {
     "ptpp_diffnet_post_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "ptpp_diffnet_post_bwd": (I, [P, P, P, P, I, I, I, I, P]),
     "ptpp_colsum_batch": (I, [P, P, I, I, I, I, P]),
-    "ptpp_col_reduce": (I, [P, P, P, I64, I, I, P]),
+    "ptpp_col_reduce": (I, [P, P, P, I64, I, I, P, SZ, P]),
     "ptpp_bn_act_fwd": (I, [P, P, P, P, P, P, I64, I, I, I, P]),
-    "ptpp_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, I64, I, I, I, I, P]),
+    "ptpp_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, I64, I, I, I, I, P, SZ, P]),
     "ptpp_glu_fwd": (I, [P, P, I64, I, I, P]),
     "ptpp_glu_bwd": (I, [P, P, P, I64, I, I, P]),
     "ptpp_dwconv1d": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),

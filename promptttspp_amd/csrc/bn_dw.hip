@@ -4,7 +4,7 @@
 // and the reference encoder's Conv2d+BatchNorm2d+ReLU stack
 // (modules/reference_encoder.py:65-81) -- all HBM-bound row-streaming kernels:
 // a thread owns 4 consecutive channels (8/16-byte vectors), per-channel reductions
-// go through LDS and one f32 atomic per column per block.
+// go through LDS and the replicated cross-block sums of ptpp_common.h.
 #include "ptpp_common.h"
 
 namespace {
@@ -29,38 +29,65 @@ __device__ __forceinline__ ColGeom col_geom(int C) {
   ColGeom g; g.cv = C >> 2; g.rg = 256 / g.cv; return g;
 }
 
-// out[k][c] += sum_r f_k(x[r,c]) ; mode 0: {x}, mode 1: {(x-mean)^2}
+// out[c] = sum_r f(x[r,c]) ; f = x (mean == NULL) or (x-mean)^2.  Block totals -> replicated sums (red_block_add) -> red_sum_kernel.
 template <typename T>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x, const float* __restrict__ mean,
-                                                         float* __restrict__ out, int64_t rows, int C, int rows_per_block) {
+                                                         void* scratch, int64_t rows, int C, int rows_per_block) {
   const ColGeom g = col_geom(C);
   const int cvi = threadIdx.x % g.cv, rgi = threadIdx.x / g.cv;
   const int c = cvi * 4;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (mean && rgi < g.rg) mu = *reinterpret_cast<const f32x4*>(mean + c);
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  if (rgi < g.rg)
+  if (rgi < g.rg) {
+    const f32x4 mu = mean ? *reinterpret_cast<const f32x4*>(mean + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int64_t r = r0 + rgi; r < r1; r += g.rg) {
       f32x4 v = Elem<T>::ld4(x + r * C + c);
       if (mean) { v -= mu; v *= v; }
       acc += v;
     }
+  }
   __shared__ f32x4 red[256];
+  __shared__ float tot[1024];
   red[threadIdx.x] = acc;
   __syncthreads();
   if (rgi == 0) {
     for (int k = 1; k < g.rg; ++k) acc += red[k * g.cv + cvi];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, acc[e]);
+    for (int e = 0; e < 4; ++e) tot[c + e] = acc[e];
+  }
+  __syncthreads();
+  red_block_add(scratch, tot, C);
+}
+
+// y = act(gamma * (x - mean) * rstd + beta): a thread keeps its 4 channels' constants in registers
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y, int64_t rows,
+                                                         int C, int act, int rows_per_block) {
+  const ColGeom g = col_geom(C);
+  const int cvi = threadIdx.x % g.cv, rgi = threadIdx.x / g.cv;
+  if (rgi >= g.rg) return;
+  const int c = cvi * 4;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+#pragma unroll 4
+  for (int64_t r = r0 + rgi; r < r1; r += g.rg) {
+    const f32x4 v = Elem<T>::ld4(x + r * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_fwd(ga[e] * (v[e] - mu[e]) * rs[e] + be[e], act);
+    Elem<T>::st4(y + r * C + c, o);
   }
 }
 
-// y = act(gamma * (x - mean) * rstd + beta)
+// the same for channel counts the row geometry does not cover (C/4 does not divide 256)
 template <typename T>
-__global__ void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                  const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
-                                  int C, int64_t nvec, int act) {
+__global__ void bn_act_fwd_generic_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, T* __restrict__ y, int C, int64_t nvec, int act) {
   const int cv = C >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv) * 4;
@@ -77,7 +104,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ sums, int64_t rows, int C, int act,
+                                                            void* scratch, int64_t rows, int C, int act,
                                                             int rows_per_block) {
   const ColGeom g = col_geom(C);
   const int cvi = threadIdx.x % g.cv, rgi = threadIdx.x / g.cv;
@@ -87,6 +114,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   if (rgi < g.rg) {
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll 4
     for (int64_t r = r0 + rgi; r < r1; r += g.rg) {
       const f32x4 v = Elem<T>::ld4(x + r * C + c), d = Elem<T>::ld4(dy + r * C + c);
 #pragma unroll
@@ -99,35 +127,49 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
   }
   __shared__ f32x4 red[2][256];
+  __shared__ float tot[2048];
   red[0][threadIdx.x] = a0;
   red[1][threadIdx.x] = a1;
   __syncthreads();
   if (rgi == 0) {
     for (int k = 1; k < g.rg; ++k) { a0 += red[0][k * g.cv + cvi]; a1 += red[1][k * g.cv + cvi]; }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { atomicAdd(sums + c + e, a0[e]); atomicAdd(sums + C + c + e, a1[e]); }
+    for (int e = 0; e < 4; ++e) { tot[c + e] = a0[e]; tot[C + c + e] = a1[e]; }
   }
+  __syncthreads();
+  red_block_add(scratch, tot, 2 * C);
 }
 
 // pass 2: dx = gamma * rstd * (g - sum_g / N - xhat * sum_gx / N)   (train) ; = gamma * rstd * g (eval)
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
-                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, const float* __restrict__ sums, T* __restrict__ dx,
-                                    int C, int64_t nvec, int act, float inv_n, int train) {
-  const int cv = C >> 2;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cv) * 4;
-    const f32x4 v = Elem<T>::ld4(x + i * 4), d = Elem<T>::ld4(dy + i * 4);
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ sums, T* __restrict__ dx, int64_t rows,
+                                                           int C, int act, float inv_n, int train, int rows_per_block) {
+  const ColGeom g = col_geom(C);
+  const int cvi = threadIdx.x % g.cv, rgi = threadIdx.x / g.cv;
+  if (rgi >= g.rg) return;
+  const int c = cvi * 4;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+  f32x4 sg = f32x4{0.f, 0.f, 0.f, 0.f}, sgx = sg;
+  if (train) {
+    sg = *reinterpret_cast<const f32x4*>(sums + c) * inv_n;
+    sgx = *reinterpret_cast<const f32x4*>(sums + C + c) * inv_n;
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+#pragma unroll 4
+  for (int64_t r = r0 + rgi; r < r1; r += g.rg) {
+    const f32x4 v = Elem<T>::ld4(x + r * C + c), d = Elem<T>::ld4(dy + r * C + c);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float xh = (v[e] - mean[c + e]) * rstd[c + e];
-      const float gg = d[e] * act_grad(gamma[c + e] * xh + beta[c + e], act);
-      const float corr = train ? (sums[c + e] + xh * sums[C + c + e]) * inv_n : 0.f;
-      o[e] = gamma[c + e] * rstd[c + e] * (gg - corr);
+      const float xh = (v[e] - mu[e]) * rs[e];
+      const float gg = d[e] * act_grad(ga[e] * xh + be[e], act);
+      o[e] = ga[e] * rs[e] * (gg - (sg[e] + xh * sgx[e]));
     }
-    Elem<T>::st4(dx + i * 4, o);
+    Elem<T>::st4(dx + r * C + c, o);
   }
 }
 
@@ -303,13 +345,19 @@ inline bool cgeom_ok(int C) { return C > 0 && C % 4 == 0 && (C / 4) <= 256 && 25
   else if (dtype == PTPP_BF16) { using T = bf16_raw; __VA_ARGS__; } \
   else { ptpp_set_error("%s: bad dtype %d", name, dtype); return PTPP_EINVAL; }
 
-extern "C" int ptpp_col_reduce(const void* x, const float* mean, float* out, int64_t rows, int C, int dtype, void* stream) {
+// rows per block: a thread handles `per_thread` rows
+inline int stream_rpb(int C, int per_thread) { return (256 / (C / 4)) * per_thread; }
+
+extern "C" int ptpp_col_reduce(const void* x, const float* mean, float* out, int64_t rows, int C, int dtype,
+                               void* scratch, size_t scratch_bytes, void* stream) {
   PTPP_CHECK_ARG(x && out && rows > 0 && cgeom_ok(C), "col_reduce: bad args (C=%d)", C);
+  PTPP_CHECK_ARG(red_scratch_ok(scratch, scratch_bytes, C), "col_reduce: reduction scratch missing or too small");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int rpb = 256;
+  const int rpb = stream_rpb(C, 8);
   const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
   DISPATCH_T(dtype, "col_reduce",
-             hipLaunchKernelGGL(col_reduce_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)x, mean, out, rows, C, rpb));
+             hipLaunchKernelGGL(col_reduce_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)x, mean, scratch, rows, C, rpb));
+  red_sum_launch(scratch, C, out, C, nullptr, 0, st);
   PTPP_CHECK_LAUNCH("col_reduce");
   return PTPP_OK;
 }
@@ -317,29 +365,39 @@ extern "C" int ptpp_col_reduce(const void* x, const float* mean, float* out, int
 extern "C" int ptpp_bn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                void* y, int64_t rows, int C, int act, int dtype, void* stream) {
   PTPP_CHECK_ARG(x && mean && rstd && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0, "bn_act_fwd: bad args");
-  const int64_t nvec = rows * C / 4;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  DISPATCH_T(dtype, "bn_act_fwd",
-             hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)x, mean, rstd, gamma,
-                                beta, (T*)y, C, nvec, act));
+  if (cgeom_ok(C)) {
+    const int rpb = stream_rpb(C, 8);
+    const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
+    DISPATCH_T(dtype, "bn_act_fwd",
+               hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta,
+                                  (T*)y, rows, C, act, rpb));
+  } else {
+    const int64_t nvec = rows * C / 4;
+    DISPATCH_T(dtype, "bn_act_fwd",
+               hipLaunchKernelGGL(bn_act_fwd_generic_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)x, mean,
+                                  rstd, gamma, beta, (T*)y, C, nvec, act));
+  }
   PTPP_CHECK_LAUNCH("bn_act_fwd");
   return PTPP_OK;
 }
 
 extern "C" int ptpp_bn_act_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, float* sums, void* dx, int64_t rows, int C, int act, int train, int dtype,
-                               void* stream) {
+                               void* scratch, size_t scratch_bytes, void* stream) {
   PTPP_CHECK_ARG(x && dy && mean && rstd && gamma && beta && sums && dx && rows > 0 && cgeom_ok(C), "bn_act_bwd: bad args");
-  const int64_t nvec = rows * C / 4;
+  PTPP_CHECK_ARG(red_scratch_ok(scratch, scratch_bytes, 2 * C), "bn_act_bwd: reduction scratch missing or too small");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int rpb = 256;
+  const int rpb = stream_rpb(C, 8);
   const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
-  if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, st) != hipSuccess) { ptpp_set_error("bn_act_bwd: memset"); return PTPP_ELAUNCH; }
+  const int rpb2 = stream_rpb(C, 8);
+  const unsigned nb2 = (unsigned)((rows + rpb2 - 1) / rpb2);
   DISPATCH_T(dtype, "bn_act_bwd",
              hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)x, (const T*)dy, mean, rstd,
-                                gamma, beta, sums, rows, C, act, rpb);
-             hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)x, (const T*)dy,
-                                mean, rstd, gamma, beta, sums, (T*)dx, C, nvec, act, 1.0f / (float)rows, train));
+                                gamma, beta, scratch, rows, C, act, rpb);
+             red_sum_launch(scratch, 2 * C, sums, 2 * C, nullptr, 0, st);
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(nb2), dim3(256), 0, st, (const T*)x, (const T*)dy, mean, rstd,
+                                gamma, beta, sums, (T*)dx, rows, C, act, 1.0f / (float)rows, train, rpb2));
   PTPP_CHECK_LAUNCH("bn_act_bwd");
   return PTPP_OK;
 }

@@ -89,14 +89,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
+// Backward: a wave per row (grid-stride); dgamma / dbeta go wave -> block (LDS) -> replicated
+// cross-block sums (ptpp_common.h), and red_sum_kernel adds the totals to the caller's buffers.
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xs,
                                                      const T* __restrict__ z, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dsum, T* __restrict__ dz,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     const int* __restrict__ lengths, int64_t rows, int Tlen, int C,
-                                                     int out_mask, int act_in, const LnDrop dp) {
+                                                     void* scratch, const int* __restrict__ lengths, int64_t rows,
+                                                     int Tlen, int C, int out_mask, int act_in, const LnDrop dp) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
@@ -158,8 +159,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  // column sums: combine the block's 4 waves through LDS, one atomic per column
+  if (!scratch) return;
+  // column sums: combine the block's 4 waves through LDS, then one low-contention atomic per column
   __shared__ float red[2][4][256 * NV];
+  __shared__ float tot[2 * 256 * NV];  // [0, C) dgamma, [C, 2C) dbeta
   const int w = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -169,12 +172,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       red[1][w][i * 256 + lane * 4 + e] = ab[i][e];
     }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-    const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-    if (dgamma) atomicAdd(dgamma + c, sg);
-    if (dbeta) atomicAdd(dbeta + c, sb);
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    const int k = c >= C, cc = c - k * C;
+    tot[c] = red[k][0][cc] + red[k][1][cc] + red[k][2][cc] + red[k][3][cc];
   }
+  __syncthreads();
+  red_block_add(scratch, tot, 2 * C);
 }
 
 LnDrop make_drop(float pin, uint64_t sin_, float pout, uint64_t sout) {
@@ -211,15 +214,22 @@ int ln_fwd_dispatch(const void* x, const void* res, const float* gamma, const fl
 
 template <typename T>
 int ln_bwd_dispatch(const void* dy, const void* xs, const void* z, const float* gamma, const float* mean,
-                    const float* rstd, void* dsum, void* dz, float* dgamma, float* dbeta, const int* lengths,
-                    int64_t rows, int Tlen, int C, int out_mask, int act_in, const LnDrop& dp, hipStream_t st) {
+                    const float* rstd, void* dsum, void* dz, float* dgamma, float* dbeta, void* scratch,
+                    size_t scratch_bytes, const int* lengths, int64_t rows, int Tlen, int C, int out_mask, int act_in,
+                    const LnDrop& dp, hipStream_t st) {
   const int nv = (C + 255) / 256;
   int64_t nb = (rows + 3) / 4;
-  if (nb > 1024) nb = 1024;
+  if (nb > 2048) nb = 2048;
+  const bool sums = dgamma || dbeta;
+  if (sums && !red_scratch_ok(scratch, scratch_bytes, 2 * C)) {
+    ptpp_set_error("layernorm_bwd: reduction scratch missing or too small");
+    return PTPP_EINVAL;
+  }
+  if (!sums) scratch = nullptr;
   const dim3 grid((unsigned)nb), blk(256);
 #define LN_BWD(NV)                                                                                              \
   hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, blk, 0, st, (const T*)dy, (const T*)xs, (const T*)z, gamma, mean, \
-                     rstd, (T*)dsum, (T*)dz, dgamma, dbeta, lengths, rows, Tlen, C, out_mask, act_in, dp)
+                     rstd, (T*)dsum, (T*)dz, scratch, lengths, rows, Tlen, C, out_mask, act_in, dp)
   switch (nv) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -228,6 +238,7 @@ int ln_bwd_dispatch(const void* dy, const void* xs, const void* z, const float* 
     default: ptpp_set_error("layernorm: C=%d > 1024 unsupported", C); return PTPP_ENOTSUP;
   }
 #undef LN_BWD
+  if (sums) red_sum_launch(scratch, 2 * C, dgamma, C, dbeta, 1, st);
   PTPP_CHECK_LAUNCH("layernorm_bwd");
   return PTPP_OK;
 }
@@ -258,7 +269,7 @@ extern "C" int ptpp_layernorm_bwd(const void* dy, const void* xsum, const void* 
                                   const float* mean, const float* rstd, void* dsum, void* dz, float* dgamma,
                                   float* dbeta, const int32_t* lengths, int B, int T, int C, int out_mask, int act_in,
                                   float drop_in_p, uint64_t drop_in_seed, float drop_out_p, uint64_t drop_out_seed,
-                                  int dtype, void* stream) {
+                                  int dtype, void* scratch, size_t scratch_bytes, void* stream) {
   PTPP_CHECK_ARG(dy && xsum && gamma && mean && rstd && (dsum || dz), "layernorm_bwd: null pointer");
   PTPP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0, "layernorm_bwd: bad shape");
   PTPP_CHECK_ARG(!out_mask || lengths, "layernorm_bwd: out_mask needs lengths");
@@ -267,10 +278,10 @@ extern "C" int ptpp_layernorm_bwd(const void* dy, const void* xsum, const void* 
   const int64_t rows = (int64_t)B * T;
   const LnDrop dp = make_drop(drop_in_p, drop_in_seed, drop_out_p, drop_out_seed);
   if (dtype == PTPP_F32)
-    return ln_bwd_dispatch<float>(dy, xsum, z, gamma, mean, rstd, dsum, dz, dgamma, dbeta, lengths, rows, T, C,
+    return ln_bwd_dispatch<float>(dy, xsum, z, gamma, mean, rstd, dsum, dz, dgamma, dbeta, scratch, scratch_bytes, lengths, rows, T, C,
                                   out_mask, act_in, dp, st);
   if (dtype == PTPP_BF16)
-    return ln_bwd_dispatch<bf16_raw>(dy, xsum, z, gamma, mean, rstd, dsum, dz, dgamma, dbeta, lengths, rows, T, C,
+    return ln_bwd_dispatch<bf16_raw>(dy, xsum, z, gamma, mean, rstd, dsum, dz, dgamma, dbeta, scratch, scratch_bytes, lengths, rows, T, C,
                                      out_mask, act_in, dp, st);
   PTPP_CHECK_ARG(false, "layernorm_bwd: bad dtype %d", dtype);
 }

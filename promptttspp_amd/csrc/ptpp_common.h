@@ -113,6 +113,47 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- cross-block column sums --------------------------------------------------------
+// f32 atomics from many blocks on the same cache line serialise on MI355X: measured ~50 ns per
+// block visit (2125 blocks adding 32 columns into one 128-byte line = 114 us around a 35 MB read).
+// A ticket counter + "last block sums the partials" is no better here: the ticket is the same
+// contended atomic and its release fence writes the XCD's dirty L2 lines back (173 us measured
+// for the LayerNorm backward).  So: block b adds its KC block totals into replica b % 32 of a
+// caller-provided scratch (32 x fewer visits per line, the replicas sit on different lines /
+// channels), and a one-wave-per-64-columns finishing launch sums the replicas, delivers the
+// totals and zeroes the scratch again (include/ptpp.h "Reduction scratch").
+constexpr int PTPP_RED_NREP = PTPP_RED_REPLICAS;
+// every thread of the block calls this; tot = the block's KC totals in LDS (visible to the block)
+__device__ __forceinline__ void red_block_add(void* scratch, const float* tot, int KC) {
+  float* mine = reinterpret_cast<float*>(scratch) + (size_t)(blockIdx.x % PTPP_RED_NREP) * KC;
+  for (int c = threadIdx.x; c < KC; c += blockDim.x) atomicAdd(mine + c, tot[c]);
+}
+// column c < n0 goes to dst0[c], the rest to dst1[c - n0] (either may be NULL: dropped);
+// accumulate: dst += total, else dst = total
+static __global__ void red_sum_kernel(float* __restrict__ scratch, int KC, float* __restrict__ dst0, int n0,
+                                      float* __restrict__ dst1, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= KC) return;
+  float v[PTPP_RED_NREP];
+#pragma unroll
+  for (int r = 0; r < PTPP_RED_NREP; ++r) v[r] = scratch[(size_t)r * KC + c];
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < PTPP_RED_NREP; ++r) {
+    s += v[r];
+    scratch[(size_t)r * KC + c] = 0.f;
+  }
+  float* d = c < n0 ? (dst0 ? dst0 + c : nullptr) : (dst1 ? dst1 + (c - n0) : nullptr);
+  if (d) *d = accumulate ? *d + s : s;
+}
+inline void red_sum_launch(void* scratch, int KC, float* dst0, int n0, float* dst1, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(red_sum_kernel, dim3((KC + 63) / 64), dim3(64), 0, st, reinterpret_cast<float*>(scratch), KC, dst0,
+                     n0, dst1, accumulate);
+}
+inline bool red_scratch_ok(const void* scratch, size_t bytes, int KC) {
+  return scratch && bytes >= (size_t)PTPP_RED_NREP * KC * sizeof(float);
+}
+
 // XCD-aware block remap: hardware places block b on XCD b % 8; give each XCD a
 // contiguous range of logical tiles so neighbours share L2 (bijective for any n).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -25,8 +25,9 @@ def _chk(status, what):
 def col_reduce(x2d, mean=None):
     """x2d: (rows, C) -> (C,) f32: sum_r x or sum_r (x-mean)^2."""
     rows, C = x2d.shape
-    out = torch.zeros(C, device=x2d.device, dtype=torch.float32)
-    _chk(_lib.load().ptpp_col_reduce(_ptr(x2d), _ptr(mean), _ptr(out), rows, C, dtype_code(x2d.dtype), _stream()),
+    out = torch.empty(C, device=x2d.device, dtype=torch.float32)
+    _chk(_lib.load().ptpp_col_reduce(_ptr(x2d), _ptr(mean), _ptr(out), rows, C, dtype_code(x2d.dtype),
+                                     *ops.reduction_scratch(x2d.device), _stream()),
          "ptpp_col_reduce")
     return out
 
@@ -67,7 +68,8 @@ class BatchNormActFn(Function):
         sums = torch.empty(2 * C, device=x2.device, dtype=torch.float32)
         dx = torch.empty_like(x2)
         _chk(_lib.load().ptpp_bn_act_bwd(_ptr(x2), _ptr(dy2), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(sums), _ptr(dx),
-                                         rows, C, _ACT[ctx.act], int(ctx.training), dtype_code(x2.dtype), _stream()),
+                                         rows, C, _ACT[ctx.act], int(ctx.training), dtype_code(x2.dtype),
+                                         *ops.reduction_scratch(x2.device), _stream()),
              "ptpp_bn_act_bwd")
         return dx.view(ctx.shape), sums[C:].clone(), sums[:C].clone(), None, None, None, None, None, None
 

@@ -164,6 +164,20 @@ def workspace(device):
     return w
 
 
+_RED_BYTES = 32 * 8 * 1024  # PTPP_RED_SCRATCH_BYTES(1024), the widest supported row
+_red = {}
+
+
+def reduction_scratch(device):
+    """The zero-filled scratch of the cross-block column sums (include/ptpp.h "Reduction scratch"),
+    one per (device, stream).  Returns (pointer, bytes)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
+    w = _red.get(key)
+    if w is None:
+        w = _red[key] = torch.zeros(_RED_BYTES, device=device, dtype=torch.uint8)
+    return _ptr(w), _RED_BYTES
+
+
 def _acc_target(t, n):
     """An f32 contiguous accumulation target handed in by the caller (e.g. ``p.grad``)."""
     assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
@@ -250,7 +264,7 @@ def layernorm_bwd(dy, xsum, gamma, mean, rstd, lengths=None, out_mask=False, z=N
         _lib.load().ptpp_layernorm_bwd(_ptr(dy), _ptr(xsum), _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dsum),
                                        _ptr(dz), _ptr(dgamma), _ptr(dbeta), _ptr(lengths), B, T, C, int(bool(out_mask)),
                                        _ACT[act_in], float(drop_in[0]), int(drop_in[1]), float(drop_out[0]),
-                                       int(drop_out[1]), dtype_code(dy.dtype), _stream()),
+                                       int(drop_out[1]), dtype_code(dy.dtype), *reduction_scratch(dy.device), _stream()),
         "ptpp_layernorm_bwd",
     )
     return dsum, dz, dgamma, dbeta
