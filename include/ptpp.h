@@ -80,12 +80,13 @@ int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin, int ks,
 
 /* Re-pack MANY operands in one launch (after an optimiser step).  table: device array of n_entries rows
  * of 10 int64: {src f32 (cout,cin,ks), dst base, cout, cin, ks, mode, dtype, innerp of dst,
- * row (mode 0) / column (mode 1) offset inside dst, first block}; block b serves the last row whose
- * "first block" <= b, one 64 x 64 (cout x cin) tile with all taps per block; total_blocks = sum of
- * ceil(cout/64) * ceil(cin/64).
+ * row (mode 0) / column (mode 1) offset inside dst, first block}; block b serves row block_map[b]
+ * (block_map NULL: the last row whose "first block" <= b, by binary search), one 32 x 32
+ * (cout x cin) tile with all taps per block; total_blocks = sum of ceil(cout/32) * ceil(cin/32).
  * Several sources may share one dst (fused projections).  dst padding is NOT written (zero it once). */
 int ptpp_pack_conv_weights_batched(const int64_t* table, int n_entries,
-                                   int total_blocks, void* stream);
+                                   const int32_t* block_map, int total_blocks,
+                                   void* stream);
 
 /* ------------------------------------------------------------------ *
  * Conv1d / Linear as an MFMA implicit GEMM with fused epilogue.
@@ -357,14 +358,19 @@ int ptpp_btc_to_bct(const void* x, float* y, int B, int T, int C, int dtype,
  * clip_grad_norm_(max_norm) then AdamW, for ALL parameters in two launches
  * and without a host sync.  `refs`: device array of nt records
  * {float* p; const float* g; float* m; float* v; int64 n; int64 block0},
- * block0 = index of the tensor's first 4096-element block in the flat grid.
+ * block0 = index of the tensor's first 4096-element block in the flat grid;
+ * block_map (nullable: binary search over block0 instead) = the record index
+ * of every block.  sumsq: PTPP_SUMSQ_SLOTS floats -- the sum of squares is
+ * spread over the slots (atomics on one address serialise), ptpp_grad_sumsq
+ * overwrites them and ptpp_adamw_step clips by sqrt(sum of the slots).
  * ------------------------------------------------------------------ */
-int ptpp_grad_sumsq(const void* refs, int nt, long long total_blocks,
-                    float* sumsq, void* stream);
-int ptpp_adamw_step(const void* refs, int nt, long long total_blocks,
-                    const float* sumsq, const float* lr, float beta1,
-                    float beta2, float eps, float weight_decay, int step,
-                    float max_norm, void* stream);
+#define PTPP_SUMSQ_SLOTS 64
+int ptpp_grad_sumsq(const void* refs, int nt, const int32_t* block_map,
+                    long long total_blocks, float* sumsq, void* stream);
+int ptpp_adamw_step(const void* refs, int nt, const int32_t* block_map,
+                    long long total_blocks, const float* sumsq, const float* lr,
+                    float beta1, float beta2, float eps, float weight_decay,
+                    int step, float max_norm, void* stream);
 
 #ifdef __cplusplus
 }

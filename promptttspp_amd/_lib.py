@@ -57,7 +57,7 @@ SIGNATURES = {
     "ptpp_version": (I, []),
     "ptpp_conv_cin_padded": (I, [I, I]),
     "ptpp_pack_conv_weight": (I, [P, P, I, I, I, I, I, P]),
-    "ptpp_pack_conv_weights_batched": (I, [P, I, I, P]),
+    "ptpp_pack_conv_weights_batched": (I, [P, I, P, I, P]),
     "ptpp_conv1d_fwd": (I, [POINTER(ConvArgs), P]),
     "ptpp_conv1d_fwd_ex": (I, [POINTER(ConvArgs), P, I, F, F, U64, P]),
     "ptpp_conv1d_wgrad": (I, [P, P, P, P, P] + [I] * 11 + [P, SZ, P]),
@@ -90,8 +90,8 @@ SIGNATURES = {
     "ptpp_conv_post_tanh": (I, [P, P, F, P, I, I, I, I, I, P]),
     "ptpp_bct_to_btc": (I, [P, P, I, I, I, I, P]),
     "ptpp_btc_to_bct": (I, [P, P, I, I, I, I, P]),
-    "ptpp_grad_sumsq": (I, [P, I, c_longlong, P, P]),
-    "ptpp_adamw_step": (I, [P, I, c_longlong, P, P, F, F, F, F, I, F, P]),
+    "ptpp_grad_sumsq": (I, [P, I, P, c_longlong, P, P]),
+    "ptpp_adamw_step": (I, [P, I, P, c_longlong, P, P, F, F, F, F, I, F, P]),
 }
 
 _lib = None

@@ -445,7 +445,9 @@ extern "C" int ptpp_dwconv1d_wgrad(const void* u, const void* dy, float* dw, flo
   PTPP_CHECK_ARG(u && dy && dw && B > 0 && T_ > 0 && cgeom_ok(C), "dwconv1d_wgrad: bad args");
   PTPP_CHECK_ARG(ks == 7 || ks == 15 || ks == 31, "dwconv1d_wgrad: kernel size %d not built", ks);
   const int64_t rows = (int64_t)B * T_;
-  const int rpb = 128;
+  // phoneme-level inputs are a few thousand rows: 32 rows per block keeps >100 blocks in flight and
+  // ~100 block visits per accumulator line (atomics on one line serialise at ~50 ns per visit)
+  const int rpb = rows > 65536 ? 128 : 32;
   const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   DISPATCH_T(dtype, "dwconv1d_wgrad", if (ks == 7) { DWW_LAUNCH(7); } else if (ks == 15) { DWW_LAUNCH(15); } else { DWW_LAUNCH(31); });

@@ -199,6 +199,13 @@ int launch_tiles(ConvP& p, hipStream_t st) {
   if (p.T <= 48) return launch_cfg<T, NCH, 2, 1, 2, 8>(p, st);         //  32 x 128, 8 waves of 16 x 32
   if (p.T <= 96 || (p.T % 128 != 0 && p.T % 128 <= 64 && p.T < 512))
     return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);                      //  64 x 128, 8 waves of 32 x 32
+  // a grid that cannot fill the 256 CUs with 128-row tiles (the frozen BERT's (B*tokens) x 768 GEMMs:
+  // 60-72 blocks, 59 us each) gets smaller tiles: its K loop is latency-bound, more blocks = more overlap
+  const long long nt = (p.Cout + 127) / 128;
+  if ((long long)p.B * ((p.T + 127) / 128) * nt < 192) {
+    if ((long long)p.B * ((p.T + 63) / 64) * nt < 192) return launch_cfg<T, NCH, 2, 1, 2, 8>(p, st);
+    return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);
+  }
   // (64 x 128 and 256 x 64 tiles measured 10-45 % slower on the frame-level shapes)
   return launch_cfg<T, NCH, 4, 2, 2, 16>(p, st);                       // 128 x 128, 16 waves of 32 x 32
 }

@@ -27,16 +27,18 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp
 // Batched re-pack after an optimiser step: ONE launch for every cached operand (a training step uses
 // ~350 packed operands; one launch each was ~4 ms of the step).  Table row (int64 x 10):
 //   src f32 (cout, cin, ks) | dst base | cout | cin | ks | mode | dtype | innerp of dst | row/col offset | first block
-// A block serves one 64 x 64 (co x ci) tile of one source, all taps.  Each source element goes to
+// A block serves one 32 x 32 (co x ci) tile of one source, all taps.  Each source element goes to
 //   mode 0: dst[((off + co) * ks + j) * innerp + ci]          (rows of several sources stack: fused QKV ...)
 //   mode 1: dst[(ci * ks + ks-1-j) * innerp + off + co]       (their columns concatenate)
 // The padding columns of dst were zeroed when the buffer was created.
-// A block owns one 64 (co) x 64 (ci) tile of a source, all taps: reads run along ci, mode-0 writes along
+// A block owns one 32 (co) x 32 (ci) tile of a source, all taps: reads run along ci, mode-0 writes along
 // ci, mode-1 writes along co after a transpose through LDS (element-wise scattered 2-byte writes made
 // the first version of this kernel 1 ms per step).
-__global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __restrict__ tab, int n) {
-  __shared__ float tile[64][65];
+__global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __restrict__ tab, int n,
+                                                           const int* __restrict__ block_map) {
+  __shared__ float tile[32][33];
   int lo = 0, hi = n - 1;
+  if (block_map) lo = hi = block_map[blockIdx.x];
   while (lo < hi) {  // last row whose first block <= blockIdx.x
     const int mid = (lo + hi + 1) >> 1;
     if (tab[mid * 10 + 9] <= (int64_t)blockIdx.x) lo = mid;
@@ -47,18 +49,18 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
   const int cout = (int)e[2], cin = (int)e[3], ks = (int)e[4], mode = (int)e[5], dtype = (int)e[6];
   const int64_t innerp = e[7], off = e[8];
   const int lb = (int)((int64_t)blockIdx.x - e[9]);
-  const int nci = (cin + 63) / 64;
-  const int co0 = (lb / nci) * 64, ci0 = (lb % nci) * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const int nci = (cin + 31) / 32;
+  const int co0 = (lb / nci) * 32, ci0 = (lb % nci) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int j = 0; j < ks; ++j) {
     // tile[co_l][ci_l], reads with ci fastest
-    for (int r = ty; r < 64; r += 4) {
+    for (int r = ty; r < 32; r += 8) {
       const int co = co0 + r, ci = ci0 + tx;
       tile[r][tx] = (co < cout && ci < cin) ? src[((int64_t)co * cin + ci) * ks + j] : 0.f;
     }
     __syncthreads();
     if (mode == 0) {
-      for (int r = ty; r < 64; r += 4) {
+      for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
         if (co < cout && ci < cin) {
           const int64_t d = ((off + co) * ks + j) * innerp + ci;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
         }
       }
     } else {
-      for (int r = ty; r < 64; r += 4) {  // r indexes ci here, writes run along co
+      for (int r = ty; r < 32; r += 8) {  // r indexes ci here, writes run along co
         const int ci = ci0 + r, co = co0 + tx;
         if (co < cout && ci < cin) {
           const int64_t d = ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
@@ -123,10 +125,11 @@ extern "C" int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin
   return PTPP_OK;
 }
 
-extern "C" int ptpp_pack_conv_weights_batched(const int64_t* table, int n_entries, int total_blocks, void* stream) {
+extern "C" int ptpp_pack_conv_weights_batched(const int64_t* table, int n_entries, const int32_t* block_map,
+                                              int total_blocks, void* stream) {
   PTPP_CHECK_ARG(table && n_entries > 0 && total_blocks > 0, "pack_conv_weights_batched: bad args");
   hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table,
-                     n_entries);
+                     n_entries, block_map);
   PTPP_CHECK_LAUNCH("pack_conv_weights_batched");
   return PTPP_OK;
 }

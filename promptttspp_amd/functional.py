@@ -55,7 +55,7 @@ class _PackEntry:
 
 
 _pack_cache = {}
-_repack = {"key": None, "table": None, "n": 0, "blocks": 0}
+_repack = {"key": None, "table": None, "map": None, "n": 0, "blocks": 0}
 
 
 def _pack_now(ws, dtype, mode):
@@ -110,7 +110,9 @@ def repack_all():
     key = tuple((id(e), e.wp.data_ptr(), st) for e, _, st in todo)
     key = tuple((k[0], k[1], tuple(p for _, p in k[2])) for k in key)  # entry, dst, source pointers
     if key != _repack["key"]:
-        rows, blk = [], 0
+        import numpy as np
+
+        rows, blk, owners = [], 0, []
         for ent, ws, _ in todo:
             w0 = ws[0]
             cin = w0.shape[1]
@@ -122,13 +124,15 @@ def repack_all():
             for w in ws:
                 assert w.dtype == torch.float32 and w.is_contiguous()
                 rows.append([w.data_ptr(), ent.wp.data_ptr(), w.shape[0], cin, ks, ent.mode, dcode, innerp, off, blk])
-                blk += ((w.shape[0] + 63) // 64) * ((cin + 63) // 64)
+                nb = ((w.shape[0] + 31) // 32) * ((cin + 31) // 32)
+                owners.append(np.full(nb, len(rows) - 1, dtype=np.int32))
+                blk += nb
                 off += w.shape[0]
-        import numpy as np
-
-        _repack["table"] = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(todo[0][1][0].device)
+        dev = todo[0][1][0].device
+        _repack["table"] = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
+        _repack["map"] = torch.from_numpy(np.concatenate(owners)).to(dev)  # block -> table row
         _repack["key"], _repack["n"], _repack["blocks"] = key, len(rows), blk
-    ops.pack_conv_weights_batched(_repack["table"], _repack["n"], _repack["blocks"])
+    ops.pack_conv_weights_batched(_repack["table"], _repack["n"], _repack["map"], _repack["blocks"])
     for ent, _, st in todo:
         ent.vers = st
 

@@ -103,8 +103,9 @@ def pack_conv_weight(w, dtype, mode=0):
     return wp
 
 
-def pack_conv_weights_batched(table, n_entries, total_blocks):
-    check(_lib.load().ptpp_pack_conv_weights_batched(_ptr(table), int(n_entries), int(total_blocks), _stream()),
+def pack_conv_weights_batched(table, n_entries, block_map, total_blocks):
+    check(_lib.load().ptpp_pack_conv_weights_batched(_ptr(table), int(n_entries), _ptr(block_map), int(total_blocks),
+                                                     _stream()),
           "ptpp_pack_conv_weights_batched")
 
 

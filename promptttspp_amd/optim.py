@@ -13,6 +13,7 @@ from . import _lib
 from .ops import _ptr, _stream
 
 _BLOCK = 4096  # elements per block, must match adamw.hip (CHUNK)
+_SLOTS = 64  # PTPP_SUMSQ_SLOTS
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -30,8 +31,8 @@ class FusedAdamW(torch.optim.Optimizer):
         key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
         ent = self._tables.get(gi)
         if ent is not None and ent[0] == key:
-            return ent[1], ent[2], ent[3]
-        rows, blk = [], 0
+            return ent[1:]
+        rows, blk, owners = [], 0, []
         for p in ps:
             assert p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() and p.is_cuda
             st = self.state[p]
@@ -40,10 +41,13 @@ class FusedAdamW(torch.optim.Optimizer):
                 st["exp_avg_sq"] = torch.zeros_like(p)
             n = p.numel()
             rows.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n, blk])
-            blk += (n + _BLOCK - 1) // _BLOCK
+            nb = (n + _BLOCK - 1) // _BLOCK
+            owners.append(np.full(nb, len(rows) - 1, dtype=np.int32))
+            blk += nb
         tab = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(ps[0].device)
-        self._tables[gi] = (key, tab, len(ps), blk)
-        return tab, len(ps), blk
+        bmap = torch.from_numpy(np.concatenate(owners)).to(ps[0].device)  # block -> record
+        self._tables[gi] = (key, tab, len(ps), blk, bmap)
+        return tab, len(ps), blk, bmap
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -54,19 +58,19 @@ class FusedAdamW(torch.optim.Optimizer):
             return loss
         dev = next(p for p in live[0][1]["params"] if p.grad is not None).device
         if self._sumsq is None:
-            self._sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+            self._sumsq = torch.zeros(_SLOTS, device=dev, dtype=torch.float32)
         if self.max_grad_norm > 0:
             # global norm over every group: accumulate group sums into one scalar
             total = None
             for gi, g in live:
-                tab, nt, nblk = self._table(gi, g)
+                tab, nt, nblk, bmap = self._table(gi, g)
                 part = self._sumsq if total is None else torch.zeros_like(self._sumsq)
-                _lib.check(lib.ptpp_grad_sumsq(_ptr(tab), nt, nblk, _ptr(part), _stream()), "ptpp_grad_sumsq")
+                _lib.check(lib.ptpp_grad_sumsq(_ptr(tab), nt, _ptr(bmap), nblk, _ptr(part), _stream()), "ptpp_grad_sumsq")
                 total = part if total is None else total.add_(part)
             if total is not self._sumsq:
                 self._sumsq.copy_(total)
         for gi, g in live:
-            tab, nt, nblk = self._table(gi, g)
+            tab, nt, nblk, bmap = self._table(gi, g)
             g["step"] = g.get("step", 0) + 1
             lr_dev = self._lr_dev.get(gi)
             if lr_dev is None:
@@ -74,7 +78,7 @@ class FusedAdamW(torch.optim.Optimizer):
             lr_dev.fill_(float(g["lr"]))
             b1, b2 = g["betas"]
             _lib.check(
-                lib.ptpp_adamw_step(_ptr(tab), nt, nblk, _ptr(self._sumsq), _ptr(lr_dev), float(b1), float(b2),
+                lib.ptpp_adamw_step(_ptr(tab), nt, _ptr(bmap), nblk, _ptr(self._sumsq), _ptr(lr_dev), float(b1), float(b2),
                                     float(g["eps"]), float(g["weight_decay"]), int(g["step"]), self.max_grad_norm,
                                     _stream()),
                 "ptpp_adamw_step",
@@ -89,4 +93,4 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def grad_norm(self):
         """sqrt of the last computed sum of squares (device tensor; no sync)."""
-        return self._sumsq.sqrt() if self._sumsq is not None else None
+        return self._sumsq.sum().sqrt() if self._sumsq is not None else None
