@@ -63,6 +63,9 @@ extern "C" {
 
 const char* ptpp_last_error(void);
 int ptpp_version(void);
+/* Stream fork/join: everything enqueued on `waiter` after this call runs after everything enqueued on
+ * `signaler` before it (hipEventRecord + hipStreamWaitEvent on a pooled event; both raw hipStream_t). */
+int ptpp_stream_wait(void* waiter, void* signaler);
 
 /* ------------------------------------------------------------------ *
  * Weight packing (once per weight version; folds the cast to the compute

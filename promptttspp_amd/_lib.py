@@ -55,6 +55,7 @@ P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, ctypes.c_si
 SIGNATURES = {
     "ptpp_last_error": (ctypes.c_char_p, []),
     "ptpp_version": (I, []),
+    "ptpp_stream_wait": (I, [P, P]),
     "ptpp_conv_cin_padded": (I, [I, I]),
     "ptpp_pack_conv_weight": (I, [P, P, I, I, I, I, I, P]),
     "ptpp_pack_conv_weights_batched": (I, [P, I, P, I, P]),

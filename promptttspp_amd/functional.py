@@ -3,6 +3,7 @@ forward AND backward are hand-written HIP kernels (promptttspp_amd/csrc) called
 through the C ABI.  All activations are channels-last (B, T, C) in the compute
 dtype; parameters stay f32 (master weights) and are packed/cast per version.
 """
+import ctypes
 import math
 import os
 import weakref
@@ -12,7 +13,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import ops
+from . import _lib, ops
 
 # ----------------------------------------------------------------------------
 # dropout seeds: every dropout site of every forward draws a fresh counter value;
@@ -175,7 +176,7 @@ def _f32c(t):
 # parameters, so uses are counted in forward and the reducer is notified when the last
 # pending use of a parameter has been accumulated.
 # ----------------------------------------------------------------------------
-_direct = {"on": False, "notify": None, "uses": {}, "async": False, "side": None}
+_direct = {"on": False, "notify": None, "uses": {}, "async": False, "side": None, "side_h": None}
 
 
 def enable_direct_grads(on=True, notify=None, async_wgrad=True):
@@ -190,11 +191,16 @@ def enable_direct_grads(on=True, notify=None, async_wgrad=True):
 
 class wgrad_stream:
     """``with wgrad_stream(t1, t2, ...):`` -- run the enclosed launches on the weight-gradient side stream
-    (after everything already enqueued on the current stream); the tensors are kept alive for it."""
+    (after everything already enqueued on the current stream); the tensors are kept alive for it.
+    Default: only this package's own launches move (``ops._stream_override`` + one ``ptpp_stream_wait``
+    call: ~3 us of host time); ``torch_ops=True`` also switches torch's current stream, for blocks that
+    allocate or run torch ops (~25 us)."""
 
-    def __init__(self, *tensors):
+    def __init__(self, *tensors, torch_ops=False):
         self.tensors = [t for t in tensors if t is not None]
+        self.torch_ops = torch_ops
         self.ctx = None
+        self.on = False
 
     def __enter__(self):
         if not (_direct["async"] and self.tensors and self.tensors[0].is_cuda and not torch.cuda.is_current_stream_capturing()):
@@ -202,14 +208,22 @@ class wgrad_stream:
         side = _direct["side"]
         if side is None:
             side = _direct["side"] = torch.cuda.Stream(device=self.tensors[0].device)
-        side.wait_stream(torch.cuda.current_stream())
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
+            _direct["side_h"] = ctypes.c_void_p(side.cuda_stream)
+        _lib.check(_lib.load().ptpp_stream_wait(_direct["side_h"], ops._stream()), "ptpp_stream_wait")
+        self.on = True
+        if self.torch_ops:
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        else:
+            ops._stream_override = _direct["side_h"]
         return self
 
     def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
+        if self.on:
+            if self.ctx is not None:
+                self.ctx.__exit__(*exc)
+            else:
+                ops._stream_override = None
             for t in self.tensors:
                 t.record_stream(_direct["side"])
         return False
@@ -673,7 +687,7 @@ class DiffNetStackFn(Function):
             # the fused conditioner GEMM's weight gradient in ONE launch (Cout = L*2C: 2.7x the throughput
             # of L per-layer launches), then one multi-tensor add of each layer's row block into its own
             # gradient buffer
-            with wgrad_stream(cond, dcond_all):
+            with wgrad_stream(cond, dcond_all, torch_ops=True):
                 dwc, dbc = ops.conv1d_wgrad(cond, dcond_all, cond.shape[-1], L * 2 * C, 1, 1, 0)
                 dwl = dwc.view(L, 2 * C, -1)
                 dbl = dbc.view(L, 2 * C)

@@ -31,9 +31,14 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+_stream_override = None  # set by functional.wgrad_stream: launch on this raw stream instead of torch's current one
+
+
 def _stream():
     """torch's current HIP stream as a raw handle (the C calls: ~0.3 us instead of ~7 us for the
     torch.cuda.current_stream() object -- this runs once per kernel launch)."""
+    if _stream_override is not None:
+        return _stream_override
     if _raw_stream is not None and _cur_device is not None:
         return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
