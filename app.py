@@ -53,6 +53,56 @@ def synthesize(model, vocoder, phoneme_ids, style_prompt=None, reference_mel=Non
     return vocoder(dec, f0).squeeze(1).cpu(), dec.cpu()
 
 
+@torch.no_grad()
+def synthesize_batch(model, vocoder, phoneme_ids, style_prompts=None, reference_mels=None, mel_stats=None,
+                     noise_scale=0.5, batch_vocoder=False):
+    """Many utterances at once (the batch the reference's synthesize.py walks one row at a time):
+    ``phoneme_ids``: list of 1-D id tensors; ``style_prompts``: list of str, or ``reference_mels``: list of
+    (80, T_i) un-normalised mels.  One ``infer_batch`` for the acoustic model; the vocoder runs per utterance
+    on its exact-length mel (identical to the one-row pipeline) or, ``batch_vocoder=True``, once on the padded
+    batch (the last few ms of each utterance then see the neighbour padding instead of zeros).
+    Returns (list of 1-D wavs, list of (80, Tf_i) de-normalised mels), on the CPU."""
+    assert (style_prompts is None) != (reference_mels is None)
+    device = next(model.parameters()).device
+    mean = mel_stats["mean"] if mel_stats is not None else 0.0
+    std = mel_stats["std"] if mel_stats is not None else 1.0
+    n = len(phoneme_ids)
+    plen = torch.tensor([len(p) for p in phoneme_ids], dtype=torch.long)
+    ph = torch.zeros(n, int(plen.max()), dtype=torch.long)
+    for i, p in enumerate(phoneme_ids):
+        ph[i, : len(p)] = torch.as_tensor(p, dtype=torch.long)
+    kw = dict(use_max=True, noise_scale=noise_scale, return_f0=True)
+    if style_prompts is not None:
+        mel, cf0, vuv, flen = model.infer_batch(ph.to(device), plen.to(device), style_prompt=list(style_prompts), **kw)
+    else:
+        rlen = torch.tensor([m.shape[-1] for m in reference_mels], dtype=torch.long)
+        ref = torch.zeros(n, reference_mels[0].shape[0], int(rlen.max()))
+        for i, m in enumerate(reference_mels):
+            ref[i, :, : m.shape[-1]] = (m - mean) / std
+        mel, cf0, vuv, flen = model.infer_batch(ph.to(device), plen.to(device), reference_mel=ref.to(device),
+                                                ref_lengths=rlen, **kw)
+    flen = [int(x) for x in flen.cpu()]
+    modfs = int(1.0 / (10 * 0.001))
+    mel = mel * std + mean
+    wavs, mels = [], []
+    if batch_vocoder:
+        f0 = lowpass_filter(cf0, modfs, cutoff=20).exp()  # NB: filters the padded tracks; see the docstring
+        f0[vuv < 0.5] = 0
+        wav = vocoder(mel, f0).squeeze(1)
+        hop = wav.shape[-1] // mel.shape[-1]
+        for i in range(n):
+            wavs.append(wav[i, : flen[i] * hop].float().cpu())
+            mels.append(mel[i, :, : flen[i]].float().cpu())
+        return wavs, mels
+    for i in range(n):
+        T = flen[i]
+        f0 = lowpass_filter(cf0[i : i + 1, :, :T], modfs, cutoff=20).exp()
+        f0[vuv[i : i + 1, :, :T] < 0.5] = 0
+        wavs.append(vocoder(mel[i : i + 1, :, :T].contiguous(), f0.contiguous()).reshape(-1).float().cpu())
+        mels.append(mel[i, :, :T].float().cpu())
+    return wavs, mels
+
+
 def build_ui(model, vocoder, to_mel, mel_stats):  # pragma: no cover - needs gradio + the text front-end
     import gradio as gr
     from g2p_en import G2p

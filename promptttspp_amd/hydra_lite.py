@@ -81,17 +81,40 @@ def _lookup(root, path_keys):
 
 
 def _resolve(root):
-    """Resolve ${...} interpolations in place (string-valued leaves only)."""
+    """Resolve ${...} interpolations in place (string-valued leaves only).  A referenced value that
+    itself holds interpolations is resolved relative to ITS OWN location first."""
 
-    def interp(expr, here):
-        # here: key path of the node CONTAINING the leaf
+    def target(expr, here):
+        # here: key path of the node CONTAINING the leaf; returns the absolute key path of the target
         ndots = len(expr) - len(expr.lstrip("."))
         rest = expr.lstrip(".")
         if ndots == 0:
             base = []
         else:
             base = here[: len(here) - (ndots - 1)] if ndots - 1 <= len(here) else []
-        return _lookup(root, base + (rest.split(".") if rest else []))
+        return base + (rest.split(".") if rest else [])
+
+    def fetch(expr, here, depth):
+        if depth > 32:
+            raise ValueError(f"interpolation cycle at ${{{expr}}}")
+        tp = target(expr, here)
+        val = _lookup(root, tp)
+        if isinstance(val, str) and "${" in val:
+            val = resolve_str(val, tp[:-1], depth + 1)
+        elif isinstance(val, (dict, list)):
+            walk(val, tp)
+        return val
+
+    def resolve_str(v, here, depth=0):
+        s = v.strip()
+        if s.startswith("${") and s.endswith("}") and s.count("${") == 1:
+            return copy.deepcopy(fetch(s[2:-1], here, depth))
+        out = v
+        while "${" in out:
+            a = out.index("${")
+            b = out.index("}", a)
+            out = out[:a] + str(fetch(out[a + 2 : b], here, depth)) + out[b + 1 :]
+        return out
 
     def walk(node, path):
         items = node.items() if isinstance(node, dict) else enumerate(node)
@@ -99,20 +122,7 @@ def _resolve(root):
             if isinstance(v, (dict, list)):
                 walk(v, path + [k])
             elif isinstance(v, str) and "${" in v:
-                s = v.strip()
-                if s.startswith("${") and s.endswith("}") and s.count("${") == 1:
-                    val = interp(s[2:-1], path)
-                    for _ in range(8):  # chained references
-                        if isinstance(val, str) and val.strip().startswith("${"):
-                            val = interp(val.strip()[2:-1], path)
-                    node[k] = copy.deepcopy(val)
-                else:
-                    out = v
-                    while "${" in out:
-                        a = out.index("${")
-                        b = out.index("}", a)
-                        out = out[:a] + str(interp(out[a + 2 : b], path)) + out[b + 1 :]
-                    node[k] = out
+                node[k] = resolve_str(v, path)
 
     walk(root, [])
     return root
