@@ -281,6 +281,13 @@ int ptpp_colsum_batch(const void* x, float* out, int B, int T, int C, int dtype,
 int ptpp_col_reduce(const void* x, const float* mean, float* out, int64_t rows,
                     int C, int dtype, void* scratch, size_t scratch_bytes,
                     void* stream);
+/* Training-mode statistics in one call (4 launches): mean[c], rstd[c] = rsqrt(biased var + eps) over
+ * all rows (two passes: sums, then centred squares), and -- when the pointers are non-NULL -- the
+ * running estimates updated in place like torch.nn.BatchNorm: running = (1-momentum)*running +
+ * momentum*{mean, unbiased var}.  scratch: the reduction scratch described at ptpp_layernorm_bwd. */
+int ptpp_bn_stats(const void* x, int64_t rows, int C, float momentum, float eps,
+                  float* running_mean, float* running_var, float* mean, float* rstd,
+                  int dtype, void* scratch, size_t scratch_bytes, void* stream);
 /* y = act(gamma*(x-mean)*rstd + beta), act in {NONE, RELU, SWISH} */
 int ptpp_bn_act_fwd(const void* x, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, void* y, int64_t rows,

@@ -76,6 +76,7 @@ SIGNATURES = {
     "ptpp_diffnet_post_bwd": (I, [P, P, P, P, I, I, I, I, P]),
     "ptpp_colsum_batch": (I, [P, P, I, I, I, I, P]),
     "ptpp_col_reduce": (I, [P, P, P, I64, I, I, P, SZ, P]),
+    "ptpp_bn_stats": (I, [P, I64, I, F, F, P, P, P, P, I, P, SZ, P]),
     "ptpp_bn_act_fwd": (I, [P, P, P, P, P, P, I64, I, I, I, P]),
     "ptpp_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, I64, I, I, I, I, P, SZ, P]),
     "ptpp_glu_fwd": (I, [P, P, I64, I, I, P]),

@@ -60,6 +60,32 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
   red_block_add(scratch, tot, C);
 }
 
+// finishing launches of the training-mode statistics: replicas -> mean (+ running mean), then
+// replicas -> biased variance -> rstd (+ running variance, unbiased); the scratch is zeroed again
+__global__ void bn_stats_finish_kernel(float* __restrict__ scratch, int C, int stage, float inv_rows, float unbias,
+                                       float momentum, float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float v[PTPP_RED_NREP];
+#pragma unroll
+  for (int r = 0; r < PTPP_RED_NREP; ++r) v[r] = scratch[(size_t)r * C + c];
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < PTPP_RED_NREP; ++r) {
+    s += v[r];
+    scratch[(size_t)r * C + c] = 0.f;
+  }
+  s *= inv_rows;
+  if (stage == 0) {
+    mean[c] = s;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * s;
+  } else {
+    rstd[c] = rsqrtf(s + eps);
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (s * unbias);
+  }
+}
+
 // y = act(gamma * (x - mean) * rstd + beta): a thread keeps its 4 channels' constants in registers
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
@@ -359,6 +385,30 @@ extern "C" int ptpp_col_reduce(const void* x, const float* mean, float* out, int
              hipLaunchKernelGGL(col_reduce_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)x, mean, scratch, rows, C, rpb));
   red_sum_launch(scratch, C, out, C, nullptr, 0, st);
   PTPP_CHECK_LAUNCH("col_reduce");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_bn_stats(const void* x, int64_t rows, int C, float momentum, float eps, float* running_mean,
+                             float* running_var, float* mean, float* rstd, int dtype, void* scratch, size_t scratch_bytes,
+                             void* stream) {
+  PTPP_CHECK_ARG(x && mean && rstd && rows > 0 && cgeom_ok(C), "bn_stats: bad args (C=%d)", C);
+  PTPP_CHECK_ARG(red_scratch_ok(scratch, scratch_bytes, C), "bn_stats: reduction scratch missing or too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rpb = stream_rpb(C, 8);
+  const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
+  const float inv = 1.0f / (float)rows, unbias = (float)rows / (float)(rows > 1 ? rows - 1 : 1);
+  float* sc = reinterpret_cast<float*>(scratch);
+  const dim3 fg((C + 63) / 64), fb(64);
+  DISPATCH_T(dtype, "bn_stats",
+             hipLaunchKernelGGL(col_reduce_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)x, (const float*)nullptr, scratch,
+                                rows, C, rpb);
+             hipLaunchKernelGGL(bn_stats_finish_kernel, fg, fb, 0, st, sc, C, 0, inv, unbias, momentum, eps, mean, rstd,
+                                running_mean, running_var);
+             hipLaunchKernelGGL(col_reduce_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)x, (const float*)mean, scratch,
+                                rows, C, rpb);
+             hipLaunchKernelGGL(bn_stats_finish_kernel, fg, fb, 0, st, sc, C, 1, inv, unbias, momentum, eps, mean, rstd,
+                                running_mean, running_var));
+  PTPP_CHECK_LAUNCH("bn_stats");
   return PTPP_OK;
 }
 

@@ -602,7 +602,8 @@ def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
     B, T, C = h0.shape
     skip = torch.empty((B, T, C), device=h0.device, dtype=torch.float32)
     x = h0
-    _, yin = ops.diffnet_post_fwd(None, h0, None, dsteps[:, 0].contiguous(), init=True)
+    ds = dsteps.transpose(0, 1).contiguous()  # (L, B, C): one copy, then ds[l] are contiguous views
+    _, yin = ops.diffnet_post_fwd(None, h0, None, ds[0], init=True)
     saved = []
     fused = (not save) and lengths is None and diffnet_fused_gate(h0.dtype)  # cond_all is in gate order then
     perm = _gate_perm(2 * C, h0.device) if fused else None
@@ -622,7 +623,7 @@ def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
         o = ops.conv1d(g, packed(ow, h0.dtype), _f32c(ob), 2 * C, lengths=lengths, out_mask=lengths is not None)
         if save:
             saved.append((yin, a, g))
-        nxt = dsteps[:, l + 1].contiguous() if l + 1 < L else None
+        nxt = ds[l + 1] if l + 1 < L else None
         x, yin = ops.diffnet_post_fwd(o, x, skip, nxt, init=(l == 0))
     return skip, saved
 
@@ -652,9 +653,10 @@ class DiffNetStackFn(Function):
         dt = gout.dtype
         gS = (gout.float() * (1.0 / math.sqrt(L))).to(dt).contiguous()
         gx = torch.zeros_like(gS)
-        sx = torch.zeros((B, C), device=gout.device, dtype=torch.float32)
+        # per-layer column sums of gx land in rows of one buffer; the step-embedding gradients
+        # dd[:, l] = S[l] - S[l+1] / sqrt(2) are formed after the loop in two launches (not 3 per layer)
+        S = torch.zeros((L + 1, B, C), device=gout.device, dtype=torch.float32)
         dcond_all = torch.empty((B, T, L * 2 * C), device=gout.device, dtype=dt)
-        dd = torch.empty((B, L, C), device=gout.device, dtype=torch.float32)
         grads = [None] * (6 * L)
         r2 = 1.0 / math.sqrt(2.0)
         for l in reversed(range(L)):
@@ -670,9 +672,7 @@ class DiffNetStackFn(Function):
             with wgrad_stream(*((yin, da) if ctx.direct else ())):
                 dwd, dbd = ops.conv1d_wgrad(yin, da, C, 2 * C, 3, d, d, dw_out=tg[0], db_out=tg[1])
             gx = ops.conv1d(da, packed(dil_w, dt, mode=1), None, C, ks=3, dil=d, pad=d, res=gx, res_scale=r2)
-            sn = ops.colsum_batch(gx)
-            dd[:, l] = sn - sx * r2
-            sx = sn
+            ops.colsum_batch(gx, out=S[l])
             if ctx.direct:
                 for i in (0, 1, 4, 5):
                     _done(ws[l][i])
@@ -680,6 +680,7 @@ class DiffNetStackFn(Function):
                 grads[6 * l + 0], grads[6 * l + 1] = dwd.view_as(dil_w), dbd
                 grads[6 * l + 4], grads[6 * l + 5] = dwo.view_as(out_w), dbo
             ctx.saved[l] = None
+        dd = torch.sub(S[:L], S[1:], alpha=r2).transpose(0, 1)  # (B, L, C)
         dcond = None
         if ctx.needs_input_grad[1]:
             dcond = ops.conv1d(dcond_all, packed_cat(ctx.wc, dt, mode=1), None, cond.shape[-1])

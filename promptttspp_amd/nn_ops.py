@@ -43,14 +43,19 @@ class BatchNormActFn(Function):
         x2 = x.contiguous().view(-1, shape[-1])
         rows, C = x2.shape
         if training:
-            mean = col_reduce(x2) / rows
-            var = col_reduce(x2, mean) / rows
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var * (rows / max(rows - 1, 1)), alpha=momentum)
+            # sums -> mean -> centred squares -> rstd and the running estimates, 4 launches in one call
+            mean = torch.empty(C, device=x2.device, dtype=torch.float32)
+            rstd = torch.empty(C, device=x2.device, dtype=torch.float32)
+            track = running_mean is not None and running_var is not None
+            if track:
+                assert running_mean.dtype == torch.float32 and running_var.dtype == torch.float32
+            _chk(_lib.load().ptpp_bn_stats(_ptr(x2), rows, C, float(momentum if momentum is not None else 0.1), float(eps),
+                                           _ptr(running_mean) if track else None, _ptr(running_var) if track else None,
+                                           _ptr(mean), _ptr(rstd), dtype_code(x2.dtype), *ops.reduction_scratch(x2.device),
+                                           _stream()), "ptpp_bn_stats")
         else:
-            mean, var = running_mean.float(), running_var.float()
-        rstd = torch.rsqrt(var + eps)
+            mean = running_mean.float()
+            rstd = torch.rsqrt(running_var.float() + eps)
         g, b = PF._f32c(gamma), PF._f32c(beta)
         y = torch.empty_like(x2)
         _chk(_lib.load().ptpp_bn_act_fwd(_ptr(x2), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(y), rows, C, _ACT[act],
@@ -71,7 +76,7 @@ class BatchNormActFn(Function):
                                          rows, C, _ACT[ctx.act], int(ctx.training), dtype_code(x2.dtype),
                                          *ops.reduction_scratch(x2.device), _stream()),
              "ptpp_bn_act_bwd")
-        return dx.view(ctx.shape), sums[C:].clone(), sums[:C].clone(), None, None, None, None, None, None
+        return dx.view(ctx.shape), sums[C:], sums[:C], None, None, None, None, None, None
 
 
 def batch_norm_act(x, bn, act=None):

@@ -396,9 +396,11 @@ def diffnet_post_bwd(gx, gskip, lengths):
     return dout
 
 
-def colsum_batch(x):
+def colsum_batch(x, out=None):
     B, T, C = x.shape
-    out = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    assert out.shape == (B, C) and out.dtype == torch.float32 and out.is_contiguous()
     check(_lib.load().ptpp_colsum_batch(_ptr(x), _ptr(out), B, T, C, dtype_code(x.dtype), _stream()), "ptpp_colsum_batch")
     return out
 
