@@ -359,3 +359,64 @@ def test_batched_repack_matches_per_tensor_pack(dtype, dev):
         for p in params:
             p.grad = torch.randn_like(p)
         opt.step()  # bumps versions and calls repack_all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(4097, 32), (700, 256), (50000, 64)])
+def test_batchnorm_act_matches_torch_and_leaves_scratch_zero(dtype, rows, C, dev):
+    """Training-mode BatchNorm + activation (ptpp_bn_stats / bn_act_fwd / bn_act_bwd: replicated
+    cross-block sums) against torch.nn.BatchNorm1d on the CPU: output, running estimates, dx, dgamma,
+    dbeta; the reduction scratch must be all zero again after every call."""
+    from promptttspp_amd import nn_ops, ops
+
+    x = rnd(1, rows, C, scale=1.5) + 0.5 * rnd(2, 1, C)
+    dy = rnd(3, rows, C)
+    if dtype == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+    tol = 2e-5 if dtype == torch.float32 else BF16_TOL
+    bn_ref = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn_ref.weight.copy_(1.0 + 0.2 * rnd(4, C))
+        bn_ref.bias.copy_(0.1 * rnd(5, C))
+        bn_ref.running_mean.copy_(0.3 * rnd(6, C))
+        bn_ref.running_var.copy_(1.0 + 0.1 * rnd(7, C).abs())
+    bn = torch.nn.BatchNorm1d(C)
+    bn.load_state_dict(bn_ref.state_dict())
+    bn = bn.to(dev)
+    xr = x.clone().requires_grad_()
+    zr = bn_ref(xr)
+    yr = zr * torch.sigmoid(zr)  # swish, the Conformer convolution module's activation
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(yr, (xr, bn_ref.weight, bn_ref.bias), dy)
+    xd = x.to(dev, dtype).requires_grad_()
+    y = nn_ops.batch_norm_act(xd, bn, act="swish")
+    dx, dg, db = torch.autograd.grad(y, (xd, bn.weight, bn.bias), dy.to(dev, dtype))
+    assert rel_err(y.float().cpu(), yr.detach()) < tol
+    assert rel_err(bn.running_mean.cpu(), bn_ref.running_mean) < 1e-5
+    assert rel_err(bn.running_var.cpu(), bn_ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    assert rel_err(dx.float().cpu(), dx_ref) < (1e-4 if dtype == torch.float32 else BF16_TOL)
+    assert rel_err(dg.cpu(), dg_ref) < (1e-4 if dtype == torch.float32 else BF16_TOL)
+    assert rel_err(db.cpu(), db_ref) < (1e-4 if dtype == torch.float32 else BF16_TOL)
+    torch.cuda.synchronize()
+    key = [k for k in ops._red if k[2] == ops._stream().value]
+    assert key and int(ops._red[key[0]].count_nonzero()) == 0
+
+
+def test_layernorm_bwd_accumulates_into_given_buffers(dev):
+    """dgamma / dbeta are ADDED to the caller's buffers (the trainer hands in views of the flat gradient
+    buffer), twice in a row, and the result does not depend on the buffers' previous content."""
+    from promptttspp_amd import ops
+
+    B, T, C = 5, 333, 512
+    x, dy = rnd(1, B, T, C), rnd(2, B, T, C)
+    g, b = 1.0 + 0.1 * rnd(3, C), 0.1 * rnd(4, C)
+    xs = x.clone().requires_grad_()
+    gp, bp = g.clone().requires_grad_(), b.clone().requires_grad_()
+    _, dg_ref, db_ref = torch.autograd.grad(R.layer_norm_last(xs, gp, bp, 1e-5), (xs, gp, bp), dy)
+    y, mean, rstd, xsum = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev), 1e-5, save_stats=True, save_sum=True)
+    acc_g = torch.full((C,), 3.0, device=dev)
+    acc_b = torch.full((C,), -2.0, device=dev)
+    for _ in range(2):
+        ops.layernorm_bwd(dy.to(dev), xsum, g.to(dev), mean, rstd, dgamma_out=acc_g, dbeta_out=acc_b)
+    assert rel_err((acc_g.cpu() - 3.0) / 2, dg_ref) < 1e-4
+    assert rel_err((acc_b.cpu() + 2.0) / 2, db_ref) < 1e-4
