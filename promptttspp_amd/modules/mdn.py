@@ -27,9 +27,9 @@ class MDNLayer(nn.Module):
         x = minibatch.float().contiguous()
         B, T, _ = x.shape
         G, D = self.num_gaussians, self.out_dim
-        w = torch.cat([self.log_pi.weight, self.log_sigma.weight, self.mu.weight], dim=0)
-        b = torch.cat([self.log_pi.bias, self.log_sigma.bias, self.mu.bias], dim=0)
-        y = PF.linear(x, w, b)
+        # the three heads read the same input: ONE GEMM over their concatenated rows (the packed operand is
+        # cached on the three Parameters, their gradients go straight into each layer's own buffer)
+        y = PF.linear_fused(x, [self.log_pi, self.log_sigma, self.mu])
         n_pi = self.log_pi.weight.shape[0]
         log_pi, log_sigma, mu = y[..., :n_pi], y[..., n_pi : n_pi + G * D], y[..., n_pi + G * D :]
         if self.dim_wise:
