@@ -30,10 +30,11 @@ warnings.simplefilter("ignore")
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel (conv1d_cl_kernel<bf16>, 128 x 128 tiles), from the PMC
-# passes of this same command committed as profiles/r01_pmc_train_v7.txt: FETCH_SIZE 23 688 KiB
-# (doubled: gfx950 tallies 128-byte requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE 22 149 KiB.
+# passes of this same command committed as profiles/r01_pmc_final_hbm.txt: FETCH_SIZE 27 434 KiB
+# (doubled: gfx950 tallies 128-byte requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE 27 743 KiB,
+# means over the 476 launches of that instantiation in the profiled steps.
 # bench.py cannot run rocprofv3 on itself, so the roofline line carries this measured constant.
-CONV_TRAFFIC_BYTES_PER_LAUNCH = (2 * 23688.4 + 22148.7) * 1024
+CONV_TRAFFIC_BYTES_PER_LAUNCH = (2 * 27433.6 + 27743.3) * 1024
 
 
 def parse():
