@@ -55,9 +55,13 @@ __global__ __launch_bounds__(256) void aa_snake_kernel(const T* __restrict__ x, 
   const int last = T_ - 1;
   auto ldx = [&](int t) { return Elem<T>::ld4(xb + (int64_t)min(max(t, 0), last) * C); };
 
-  f32x4 xw[6], sw[12];
+  // nx: the six x rows the coming group of steps will consume, requested one group (~600 VALU
+  // instructions) ahead so their latency never stalls the walk
+  f32x4 xw[6], sw[12], nx[6];
 #pragma unroll
   for (int a = 0; a < 6; ++a) xw[a] = ldx(t0 - 6 + a);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) nx[a] = ldx(t0 + a);
 #pragma unroll
   for (int i = 0; i < 12; ++i) sw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int mlast = 2 * T_ - 1;
@@ -68,7 +72,8 @@ __global__ __launch_bounds__(256) void aa_snake_kernel(const T* __restrict__ x, 
 #define SNAKE_STEP(K)                                                                     \
   {                                                                                       \
     const int tp = tg + (K);                                                              \
-    xw[(K) % 6] = ldx(tp + 6);                                                            \
+    xw[(K) % 6] = nx[(K)];                                                                \
+    nx[(K)] = ldx(tp + 12);                                                               \
     f32x4 uo = f32x4{0.f, 0.f, 0.f, 0.f}, ue = f32x4{0.f, 0.f, 0.f, 0.f};                 \
     _Pragma("unroll") for (int a = 0; a < 6; ++a) {                                       \
       const f32x4 xv = xw[((K) + 1 + a) % 6];                                             \
