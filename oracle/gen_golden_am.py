@@ -211,9 +211,11 @@ def bert():
     _save("bert", ids=ids, am=am, cls=cls, keys=_keys(b))
 
 
-def build_model(variant="new"):
+def build_model(variant="new", conformer_decoder=False):
     """Reference PromptTTSMDNDurCFG from explicit kwargs (conf/model/prompttts_mdn_v2_wo_erg_final.yaml)
-    with BertWrapper replaced by a random-init HF BertModel taking (ids, mask)."""
+    with BertWrapper replaced by a random-init HF BertModel taking (ids, mask).  ``conformer_decoder``: the
+    non-diffusion decoder branch of the same class (model.py:123-126: Conformer on the frame sequence +
+    out_conv), 2 blocks."""
     _ref()
     from promptttspp.layers.embedding import PhonemeEmbedding
     from promptttspp.models.prompttts_mdn_v2_final.model import PromptTTSMDNDurCFG
@@ -250,9 +252,11 @@ def build_model(variant="new"):
                                        conv_chans_list=[128, 128, 256, 256, 512, 512], conv_kernel_size=3,
                                        conv_stride=2, gru_layers=1, gru_units=256),
         prompt_encoder=pe,
-        decoder=GaussianDiffusion(in_dim=256, out_dim=80, norm_scale=6.0,
-                                  denoise_fn=DiffNet(in_dim=80, encoder_hidden_dim=256, residual_layers=20,
-                                                     residual_channels=256, kernel_size=3, dilation_cycle_length=4)),
+        decoder=(ConformerEncoder(rel_pos_type=variant, **dict(ENC_KW, num_blocks=2)) if conformer_decoder else
+                 GaussianDiffusion(in_dim=256, out_dim=80, norm_scale=6.0,
+                                   denoise_fn=DiffNet(in_dim=80, encoder_hidden_dim=256, residual_layers=20,
+                                                      residual_channels=256, kernel_size=3, dilation_cycle_length=4))),
+        out_conv=nn.Conv1d(256, 80, 1) if conformer_decoder else None,
         style_mdn=MDNLayer(256, 256, 10, True),
         norm_style_emb=True, mdn_disable_amp=True,
     )
@@ -406,6 +410,37 @@ def model_infer():
                 out["style_noise"] = sn
         out["phon"], out["plen"], out["mel"], out["flen_in"], out["ids"], out["am"] = phon, plen, mel, flen, ids, am
     _save("model_infer", **out)
+
+
+@gen
+def model_conformer_decoder():
+    """The class's other decoder branch: losses (eval, train with dropout zeroed), gradients, and the
+    deterministic infer_batch mel of the reference-mel path."""
+    m = build_model(conformer_decoder=True)
+    fill_state_dict(m, seed=300, overrides=TAME, offsets=TAME_OFF)
+    phon, dur, plen, mel, cf0, vuv, energy, flen, ids, am = synth_batch(301)
+
+    def run():
+        return m([phon, dur.clone(), plen, mel, cf0, vuv, energy, flen, (ids, am)])
+
+    m.eval()
+    with torch.no_grad():
+        ev = run()
+        y, c0, vv, fl = m.infer_batch(phon, plen, reference_mel=mel, ref_lengths=flen, return_f0=True)
+    zero_dropout(m)
+    m.train()
+    out = run()
+    out["loss"].backward()
+    grads = {}
+    for name in ("decoder.encoder.encoders.1.feed_forward.w_2.weight", "decoder.encoder.encoders.0.self_attn.pos_bias_v",
+                 "out_conv.weight", "out_conv.bias", "variance_adaptor.frame_prior_network.convs.2.weight",
+                 "encoder.encoder.encoders.0.feed_forward.w_1.weight"):
+        g = dict(m.named_parameters())[name].grad
+        grads["g:" + name] = g if g.numel() <= 70000 else g.flatten()[:: max(1, g.numel() // 4096)][:4096]
+    total_sq = sum(float(p.grad.pow(2).sum()) for p in m.parameters() if p.grad is not None)
+    _save("model_conformer_decoder", phon=phon, dur=dur, plen=plen, mel=mel, cf0=cf0, vuv=vuv, flen=flen, ids=ids, am=am,
+          **{"ev_" + k: v for k, v in ev.items()}, **{"tr_" + k: v.detach() for k, v in out.items()},
+          grad_norm=np.sqrt(total_sq), keys=_keys(m), infer_mel=y, infer_flen=fl, infer_cf0=c0, infer_vuv=vv, **grads)
 
 
 @gen

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import functional as PF
 from ... import ops
 from ...config import compute_dtype
 from ...modules.diffusion import GaussianDiffusion
@@ -40,10 +41,13 @@ class PromptTTSMDNDurCFG(nn.Module):
         self.norm_style_emb = norm_style_emb
         self.mdn_disable_amp = mdn_disable_amp
         self.loss_dec_scale = loss_dec_scale
-        if not isinstance(encoder, ConformerEncoder) or not isinstance(decoder, GaussianDiffusion):
+        if not isinstance(encoder, ConformerEncoder) or not isinstance(decoder, (GaussianDiffusion, ConformerEncoder)):
             raise NotImplementedError(
-                "promptttspp_amd implements the encoder=ConformerEncoder / decoder=GaussianDiffusion(DiffNet) "
-                "configuration of prompttts_mdn_v2_wo_erg_final.yaml")
+                "promptttspp_amd implements encoder=ConformerEncoder with decoder=GaussianDiffusion(DiffNet) "
+                "(prompttts_mdn_v2_wo_erg_final.yaml) or decoder=ConformerEncoder + out_conv (model.py:123-126)")
+        self.conformer_decoder = isinstance(decoder, ConformerEncoder)
+        if self.conformer_decoder:
+            assert out_conv is not None  # reference model.py:66-67
         assert self.variance_adaptor.frame_prior_network is not None
 
     # ---------------------------------------------------------------------------------
@@ -57,6 +61,13 @@ class PromptTTSMDNDurCFG(nn.Module):
         x = self.phoneme_emb.forward_cl(phoneme, pm1, dt)
         x = self.encoder.forward_cl(x.contiguous(), plen, pm1)
         return x, plen, pmask
+
+    def _decode_conformer(self, h, flen, fm1):
+        """(B,Tf,C) -> out_conv(decoder(h)) * frame_mask, (B,Tf,80) channels-last (model.py:124-125)."""
+        oc = self.out_conv
+        y = self.decoder.forward_cl(h.contiguous(), flen, fm1)
+        return PF.conv1d(y, oc.weight, oc.bias, ks=oc.kernel_size[0], dil=oc.dilation[0], pad=oc.padding[0],
+                         lengths=flen, out_mask=True)
 
     def _norm_style(self, e):
         return F.normalize(e, dim=1) if self.norm_style_emb else e
@@ -84,8 +95,13 @@ class PromptTTSMDNDurCFG(nn.Module):
             None if self.variance_adaptor.energy_emb is None else energy.squeeze(1))
 
         mel_cl = mel.transpose(1, 2).float().contiguous()
-        noise, pred = self.decoder.forward_cl(h, mel_cl, flen)
-        loss_dec = ((noise - pred) * fm1).abs().sum() / n_frames / self.loss_dec_scale
+        if self.conformer_decoder:
+            # non-diffusion branch (model.py:123-126): Conformer over the frame sequence, out_conv, L1 to the mel
+            pred = self._decode_conformer(h, flen, fm1)
+            loss_dec = (pred.float() - mel_cl).abs().sum() / n_frames / self.loss_dec_scale
+        else:
+            noise, pred = self.decoder.forward_cl(h, mel_cl, flen)
+            loss_dec = ((noise - pred) * fm1).abs().sum() / n_frames / self.loss_dec_scale
 
         dur = duration.squeeze(1).float()
         log_dur = torch.where(dur != 0, torch.log(dur.clamp_min(1e-30)), dur)  # to_log_scale, out of place
@@ -136,7 +152,10 @@ class PromptTTSMDNDurCFG(nn.Module):
         x, plen, pmask = self._encode(phoneme, phone_lengths)
         x = x + style_emb.transpose(1, 2).to(x.dtype)
         h, flen, fm1, cf0, vuv, dur = self.variance_adaptor.infer_cl(x, plen, pmask if zero_padded_durations else None)
-        mel = self.decoder.inference_cl(h, noise_fn) * fm1  # (B,Tf,80) f32
+        if self.conformer_decoder:
+            mel = self._decode_conformer(h, flen, fm1).float()
+        else:
+            mel = self.decoder.inference_cl(h, noise_fn) * fm1  # (B,Tf,80) f32
         self.last_durations = dur
         return mel.transpose(1, 2).contiguous(), cf0.unsqueeze(1), vuv.unsqueeze(1), flen
 

@@ -591,3 +591,60 @@ def test_model_forward_bench_size_properties(dev):
     b2 = losses(padded, padf(inj["noise"]))
     for k in a:
         assert abs(a[k] - b2[k]) <= 2e-5 * max(1.0, abs(a[k])), (k, a[k], b2[k])
+
+
+def _confdec_model(dev):
+    """PromptTTSMDNDurCFG with the non-diffusion decoder branch (reference model.py:123-126): the final
+    config with ``decoder`` = a 2-block ConformerEncoder and ``out_conv`` = Conv1d(256, 80, 1), weights
+    from the same (seed, name) recipe as the fixture (oracle/gen_golden_am.py::model_conformer_decoder)."""
+    from promptttspp_amd import hydra_lite as H
+
+    cfg = H.load_node(os.path.join(CONF, "prompttts_mdn_v2_wo_erg_final.yaml"))
+    dec = dict(cfg["encoder"])
+    dec["num_blocks"] = 2
+    cfg["decoder"] = dec
+    cfg["out_conv"] = {"_target_": "torch.nn.Conv1d", "in_channels": 256, "out_channels": 80, "kernel_size": 1}
+    g = load_golden("model_conformer_decoder")
+    m, _ = load(H.instantiate(cfg), key_shapes(g["keys"]), 300, dev, TAME, TAME_OFF)
+    return m, g
+
+
+def test_conformer_decoder_branch_losses_grads_and_infer(dev):
+    """the class's Conformer-decoder + out_conv branch against the reference's own outputs --
+    eval losses, train-mode losses, gradients, and the (deterministic) infer_batch mel within 1e-3."""
+    m, g = _confdec_model(dev)
+    m.eval()
+    batch = _batch(g, dev)
+    with torch.no_grad():
+        out = m(batch)
+        mel, cf0, vuv, flen = m.infer_batch(g["phon"].to(dev), g["plen"].to(dev), reference_mel=g["mel"].to(dev),
+                                            ref_lengths=g["flen"], return_f0=True)
+    for k in ("loss", "dec", "dur", "cf0", "vuv", "style"):
+        ref = float(g["ev_" + k])
+        assert abs(float(out[k]) - ref) < 1e-4 * max(1.0, abs(ref)), k
+    assert torch.equal(flen.cpu().long(), g["infer_flen"].long())  # integer frame lengths: bit-exact
+    assert mel.shape == g["infer_mel"].shape
+    assert rel_err(mel.float().cpu(), g["infer_mel"]) < 1e-3
+    assert rel_err(cf0.float().cpu(), g["infer_cf0"]) < 1e-3
+
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        for a in ("dropout_rate", "positional_dropout_rate", "p_dropout", "p"):
+            if isinstance(getattr(mod, a, None), float):
+                setattr(mod, a, 0.0)
+    m.train()
+    out = m(_batch(g, dev))
+    for k in ("loss", "dec", "dur", "cf0", "vuv", "style"):
+        ref = float(g["tr_" + k])
+        assert abs(float(out[k]) - ref) < 1e-4 * max(1.0, abs(ref)), k
+    out["loss"].backward()
+    params = dict(m.named_parameters())
+    for key in g:
+        if key.startswith("g:"):
+            gr = params[key[2:]].grad
+            ref = g[key]
+            got = gr.cpu() if gr.numel() <= 70000 else gr.flatten()[:: max(1, gr.numel() // 4096)][:4096].cpu()
+            assert rel_err(got, ref) < 2e-3, key
+    total = sum(float(p.grad.pow(2).sum()) for p in m.parameters() if p.grad is not None) ** 0.5
+    assert abs(total - float(g["grad_norm"])) < 2e-3 * float(g["grad_norm"])
