@@ -187,8 +187,73 @@ int launch_cfg(ConvP& p, hipStream_t st) {
   return PTPP_OK;
 }
 
+// ---- skinny GEMM: a handful of rows (one per utterance: step-embedding MLP, prompt adaptor, GRU,
+// style heads) against a long K.  The tile kernel gives such a launch 2-8 blocks that walk K serially
+// (33-70 us for a 32 x 1024 x 256 product, all of it load -> LDS -> barrier latency).  Here a block owns
+// one 16 x 16 output tile and its 4 waves split K: fragments come straight from global memory
+// (16 bytes per lane, no LDS, no barrier in the loop), partial tiles meet in LDS, wave 0 runs the
+// shared epilogue.  Rows are addressed linearly (row r = b*T + t; batches are T consecutive rows).
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const ConvP p) {
+  constexpr int KC = 16 / (int)sizeof(T);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int nt = blockIdx.x % p.nNT, mt = blockIdx.x / p.nNT;
+  const int n0 = nt * 16, t0 = mt * 16;
+  const int rows = p.T;  // the launcher flattened (B, T) to (1, B*T)
+  const T* xrow = reinterpret_cast<const T*>(p.x) + (int64_t)min(t0 + lr, rows - 1) * p.ldx;
+  const T* wrow = reinterpret_cast<const T*>(p.wp) + (int64_t)min(n0 + lr, p.Cout - 1) * p.cinp;
+  const int xch = p.Cin / KC;  // the zero-padded tail chunks of the packed weight rows contribute nothing
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  // loop bounds are WAVE-UNIFORM (an MFMA needs every lane): a lane whose chunk lies past the row
+  // contributes zeros instead of skipping
+  const uint4 zero = uint4{0u, 0u, 0u, 0u};
+  int cb = wave * 4;
+  for (; cb + 48 + 3 < xch; cb += 64) {  // four independent 16-byte fragment pairs in flight per lane
+    uint4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const uint4*>(wrow + (int64_t)(cb + lg + 16 * u) * KC);
+      b[u] = *reinterpret_cast<const uint4*>(xrow + (int64_t)(cb + lg + 16 * u) * KC);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Mma<T>::run(acc, a[u], b[u]);
+  }
+  for (; cb < xch; cb += 16) {
+    const int c = cb + lg;
+    const bool in = c < xch;
+    const uint4 a = in ? *reinterpret_cast<const uint4*>(wrow + (int64_t)c * KC) : zero;
+    const uint4 b = in ? *reinterpret_cast<const uint4*>(xrow + (int64_t)c * KC) : zero;
+    Mma<T>::run(acc, a, b);
+  }
+  __shared__ f32x4 part[3][64];
+  if (wave) part[wave - 1][lane] = acc;
+  __syncthreads();
+  if (wave) return;
+  f32x4 tot[1][1];
+  tot[0][0] = acc + part[0][lane] + part[1][lane] + part[2][lane];
+  conv_epilogue<T, 1, 1>(p, tot, 0, t0, n0, 0, 0, lane, rows);
+}
+
+inline bool skinny_ok(const ConvP& p) {
+  return p.ks == 1 && (int64_t)p.B * p.T <= 128 && p.cinp >= 256 && !p.in_mask && !p.out_mask && !p.res2 &&
+         p.drop_thresh16 == 0 && p.act != PTPP_ACT_GATE;
+}
+
+template <typename T>
+int launch_skinny(ConvP& p, hipStream_t st) {
+  p.T = p.B * p.T;
+  p.B = 1;
+  p.nMT = (p.T + 15) / 16;
+  p.nNT = (p.Cout + 15) / 16;
+  hipLaunchKernelGGL(gemm_skinny_kernel<T>, dim3((unsigned)(p.nMT * p.nNT)), dim3(256), 0, st, p);
+  PTPP_CHECK_LAUNCH("conv1d_fwd (skinny)");
+  return PTPP_OK;
+}
+
 template <typename T, int NCH>
 int launch_tiles(ConvP& p, hipStream_t st) {
+  if (skinny_ok(p)) return launch_skinny<T>(p, st);
   // Tile choice: BN follows Cout; BM follows the per-utterance length so short
   // (phone-level) sequences do not waste MFMA work on padding rows.
   // Many small waves per block: measured (tools/bench_wgrad.py) 1.3-2.6x faster than 4 waves of

@@ -420,3 +420,35 @@ def test_layernorm_bwd_accumulates_into_given_buffers(dev):
         ops.layernorm_bwd(dy.to(dev), xsum, g.to(dev), mean, rstd, dgamma_out=acc_g, dbeta_out=acc_b)
     assert rel_err((acc_g.cpu() - 3.0) / 2, dg_ref) < 1e-4
     assert rel_err((acc_b.cpu() + 2.0) / 2, db_ref) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cin,cout,act", [(32, 1024, 256, None), (19, 256, 1024, "mish"), (96, 768, 512, "relu"),
+                                               (1, 512, 12, None), (128, 264, 80, "swish"), (33, 256, 5120, None)])
+def test_skinny_gemm_path(rows, cin, cout, act, dtype, dev):
+    """Linear layers over a handful of rows (ks = 1, <= 128 rows, K >= 256) take the split-K skinny kernel:
+    same contract as the tile kernel -- bias, activation, residual, out_scale, (B, 1, C) and (1, T, C) views."""
+    from promptttspp_amd import ops
+
+    x = rnd(1, rows, cin)
+    w = rnd(2, cout, cin, scale=1.0 / np.sqrt(cin))
+    b = 0.1 * rnd(3, cout)
+    res = rnd(4, rows, cout)
+    if dtype == torch.bfloat16:
+        x, w, res = x.bfloat16().float(), w.bfloat16().float(), res.bfloat16().float()
+    z = x @ w.t() + b
+    if act == "mish":
+        z = F.mish(z)
+    elif act == "relu":
+        z = F.relu(z)
+    elif act == "swish":
+        z = F.silu(z)
+    ref = res + 0.5 * z
+    tol = F32_TOL * 5 if dtype == torch.float32 else BF16_TOL
+    wp = ops.pack_conv_weight(w.to(dev), dtype)
+    for shape in ((1, rows, cin), (rows, 1, cin)):
+        xd = x.to(dev, dtype).view(shape)
+        rd = res.to(dev, dtype).view(shape[0], shape[1], cout)
+        y = ops.conv1d(xd, wp, b.to(dev), cout, act=act, res=rd, out_scale=0.5)
+        assert y.shape == (shape[0], shape[1], cout)
+        assert rel_err(y.float().cpu().view(rows, cout), ref) < tol
