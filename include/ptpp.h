@@ -134,6 +134,14 @@ int ptpp_conv1d_fwd(const ptpp_conv1d_args* a, void* stream);
 int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, int ldr2,
                        float res_scale, float drop_p, uint64_t drop_seed,
                        void* stream);
+/* The same with an optional scratch (16-byte aligned device memory, NULL = none): layers with few
+ * output tiles and a long K (Conformer FFN k = 9, BERT FFN) are then split over K -- f32 partial sums
+ * of B*T*Cout elements per split go through the scratch and a second launch adds them and applies the
+ * epilogue.  Results are deterministic; 64 MiB covers every shape of the path (the conv1d_wgrad
+ * workspace of the same stream can be shared: the calls are ordered on the stream). */
+int ptpp_conv1d_fwd_ws(const ptpp_conv1d_args* a, const void* res2, int ldr2,
+                       float res_scale, float drop_p, uint64_t drop_seed,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight / bias gradient (f32 accumulate, f32 output; ACCUMULATES: the
  * caller zero-fills dw/dbias or hands in a gradient buffer to add to):

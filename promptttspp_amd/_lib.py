@@ -61,6 +61,7 @@ SIGNATURES = {
     "ptpp_pack_conv_weights_batched": (I, [P, I, P, I, P]),
     "ptpp_conv1d_fwd": (I, [POINTER(ConvArgs), P]),
     "ptpp_conv1d_fwd_ex": (I, [POINTER(ConvArgs), P, I, F, F, U64, P]),
+    "ptpp_conv1d_fwd_ws": (I, [POINTER(ConvArgs), P, I, F, F, U64, P, SZ, P]),
     "ptpp_conv1d_wgrad": (I, [P, P, P, P, P] + [I] * 11 + [P, SZ, P]),
     "ptpp_epilogue_bwd": (I, [P, P, P, P, I, I, I, F, I, I, F, U64, I, P]),
     "ptpp_layernorm_fwd": (I, [P] * 9 + [I, I, I, F, I, I, F, U64, F, U64, I, P]),

@@ -48,7 +48,11 @@ struct Mma<bf16_raw> {
   }
 };
 
-template <typename T, int NCH, int WM, int FM, int FN, int NW = 4>
+// SK: split-K variant -- block (b, mt, nt, split) walks only its share of the Cin chunks and stores raw
+// f32 partial sums; conv_splitk_finish_kernel adds the splits and applies the epilogue.  For layers with
+// few output tiles and a long K (Conformer FFN k = 9: 144 K steps, BERT FFN: 48) every K step costs a
+// global -> LDS round trip that one or two resident blocks per CU cannot hide; more blocks can.
+template <typename T, int NCH, int WM, int FM, int FN, int NW = 4, bool SK = false>
 __global__ __launch_bounds__(NW * 64) void conv1d_cl_kernel(const ConvP p) {
   constexpr int WN = NW / WM;
   constexpr int NT = NW * 64;  // threads per block
@@ -72,7 +76,9 @@ __global__ __launch_bounds__(NW * 64) void conv1d_cl_kernel(const ConvP p) {
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int nt = lid % p.nNT;
   const int mt = (lid / p.nNT) % p.nMT;
-  const int b = lid / (p.nNT * p.nMT);
+  const int ball = lid / (p.nNT * p.nMT);
+  const int b = SK ? ball % p.B : ball;
+  const int split = SK ? ball / p.B : 0;
   const int t0 = mt * BM, n0 = nt * BN;
 
   const int len = p.lengths ? min(p.lengths[b], p.T) : p.T;
@@ -89,7 +95,11 @@ __global__ __launch_bounds__(NW * 64) void conv1d_cl_kernel(const ConvP p) {
 
   const int nC = p.cinp / BKE;
   // a tile whose rows are all masked out contributes nothing: skip the K loop
-  const int steps = (p.out_mask && t0 >= len) ? 0 : nC * p.ks;
+  int sbeg = 0, steps = (p.out_mask && t0 >= len) ? 0 : nC * p.ks;
+  if constexpr (SK) {  // whole chunks per split, so a split starts at tap 0 of a chunk
+    sbeg = (int)((int64_t)split * nC / p.nsplit) * p.ks;
+    steps = (int)((int64_t)(split + 1) * nC / p.nsplit) * p.ks;
+  }
 
   uint4 wreg[WREG];
   auto load_w = [&](int s) {
@@ -126,9 +136,9 @@ __global__ __launch_bounds__(NW * 64) void conv1d_cl_kernel(const ConvP p) {
     }
   };
 
-  if (steps > 0) load_w(0);
+  if (steps > sbeg) load_w(sbeg);
   int wbuf = 0, xbuf = 1;
-  for (int s = 0; s < steps; ++s) {
+  for (int s = sbeg; s < steps; ++s) {
     const int ci = s / p.ks, j = s - ci * p.ks;
     if (j == 0) {
       xbuf ^= 1;
@@ -163,7 +173,83 @@ __global__ __launch_bounds__(NW * 64) void conv1d_cl_kernel(const ConvP p) {
     wbuf ^= 1;
   }
 
-  conv_epilogue<T, FM, FN>(p, acc, b, t0, n0, wm, wn, lane, len);
+  if constexpr (SK) {
+    float* wsb = p.ws + ((int64_t)split * p.B + b) * p.T * p.Cout;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+      const int t = t0 + (wm * FM + fm) * 16 + lr;
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        int co;  // the channel a lane's fragment holds: same maps as conv_epilogue
+        if constexpr (sizeof(T) == 2 && FN % 2 == 0) co = n0 + wn * FN * 16 + (fn >> 1) * 32 + lg * 8 + (fn & 1) * 4;
+        else co = n0 + (wn * FN + fn) * 16 + lg * 4;
+        if (t < p.T && co < p.Cout) *reinterpret_cast<f32x4*>(wsb + (int64_t)t * p.Cout + co) = acc[fm][fn];
+      }
+    }
+  } else {
+    conv_epilogue<T, FM, FN>(p, acc, b, t0, n0, wm, wn, lane, len);
+  }
+}
+
+// sum of the split-K partials + the epilogue of conv_epilogue (bias, activation, mask, scale, dropout,
+// residuals), 4 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p) {
+  const int cv = p.Cout >> 2;
+  const int64_t nvec = (int64_t)p.B * p.T * cv;
+  const int64_t slab = (int64_t)p.B * p.T * p.Cout;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cv;
+    const int co = (int)(i - row * cv) * 4;
+    const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + row * p.Cout + co);
+    for (int s = 1; s < p.nsplit; ++s) v += *reinterpret_cast<const f32x4*>(p.ws + s * slab + row * p.Cout + co);
+    const bool keep = !(p.out_mask && t >= min(p.lengths[b], p.T));
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = keep ? act_apply(v[e], p.act) * p.out_scale : 0.f;
+    if (p.drop_thresh16) v *= drop_mask4(p.drop_seed, (uint64_t)(row * p.Cout + co) >> 2, p.drop_thresh16, p.drop_inv_keep);
+    if (p.res) v += Elem<T>::ld4(reinterpret_cast<const T*>(p.res) + row * p.ldr + co) * p.res_scale;
+    if (p.res2) v += Elem<T>::ld4(reinterpret_cast<const T*>(p.res2) + row * p.ldr2 + co);
+    Elem<T>::st4(reinterpret_cast<T*>(p.y) + row * p.ldy + co, v);
+  }
+}
+
+// split-K launch of a small-tile configuration (see conv1d_cl_kernel): nsplit chosen so that about four
+// 8-wave blocks per CU are in flight; needs the caller's workspace
+template <typename T, int NCH, int WM, int FM, int FN, int NW>
+bool launch_splitk(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes, int* status) {
+  constexpr int WN = NW / WM;
+  constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
+  constexpr int KC = 16 / (int)sizeof(T);
+  const int nC = p.cinp / (NCH * KC);
+  const int nMT = (p.T + BM - 1) / BM, nNT = (p.Cout + BN - 1) / BN;
+  const int64_t blocks = (int64_t)p.B * nMT * nNT;
+  if (!ws || (p.Cout & 3) || p.act == PTPP_ACT_GATE || (int64_t)nC * p.ks < 32 || blocks >= 512) return false;
+  int64_t ns = (1024 + blocks - 1) / blocks;
+  if (ns > 8) ns = 8;
+  if (ns > nC) ns = nC;
+  const int64_t slab = (int64_t)p.B * p.T * p.Cout * (int64_t)sizeof(float);
+  if (ns * slab > (int64_t)ws_bytes) ns = (int64_t)ws_bytes / slab;
+  if (ns < 2) return false;
+  p.ws = reinterpret_cast<float*>(ws);
+  p.nsplit = (int)ns;
+  p.nMT = nMT;
+  p.nNT = nNT;
+  const int BMW = BM + (p.ks - 1) * p.dil;
+  const size_t smem = (size_t)(2 * BN * NCH + 2 * BMW * NCH) * 16;
+  if (smem > 160 * 1024) return false;
+  auto kern = conv1d_cl_kernel<T, NCH, WM, FM, FN, NW, true>;
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * ns)), dim3(NW * 64), smem, st, p);
+  const int64_t nvec = (int64_t)p.B * p.T * (p.Cout >> 2);
+  int64_t fb = (nvec + 255) / 256;
+  if (fb > 4096) fb = 4096;
+  hipLaunchKernelGGL(conv_splitk_finish_kernel<T>, dim3((unsigned)fb), dim3(256), 0, st, p);
+  *status = hipGetLastError() == hipSuccess ? PTPP_OK : PTPP_ELAUNCH;
+  if (*status != PTPP_OK) ptpp_set_error("conv1d_fwd (split-K): launch failed");
+  return true;
 }
 
 template <typename T, int NCH, int WM, int FM, int FN, int NW = 4>
@@ -252,8 +338,9 @@ int launch_skinny(ConvP& p, hipStream_t st) {
 }
 
 template <typename T, int NCH>
-int launch_tiles(ConvP& p, hipStream_t st) {
+int launch_tiles(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes) {
   if (skinny_ok(p)) return launch_skinny<T>(p, st);
+  int sk_status = PTPP_OK;
   // Tile choice: BN follows Cout; BM follows the per-utterance length so short
   // (phone-level) sequences do not waste MFMA work on padding rows.
   // Many small waves per block: measured (tools/bench_wgrad.py) 1.3-2.6x faster than 4 waves of
@@ -261,14 +348,28 @@ int launch_tiles(ConvP& p, hipStream_t st) {
   // dominated by global->LDS latency and barriers, which 4-8 waves per SIMD hide and 2 do not.
   if (p.Cout <= 32) return launch_cfg<T, NCH, 8, 2, 2, 8>(p, st);      // 256 x 32, 8 waves of 32 x 32
   if (p.Cout <= 64) return launch_cfg<T, NCH, 4, 2, 2, 8>(p, st);      // 128 x 64, 8 waves of 32 x 32
-  if (p.T <= 48) return launch_cfg<T, NCH, 2, 1, 2, 8>(p, st);         //  32 x 128, 8 waves of 16 x 32
-  if (p.T <= 96 || (p.T % 128 != 0 && p.T % 128 <= 64 && p.T < 512))
+  // The small-tile configurations first try split-K (long K, few tiles: launch_splitk decides).
+  if (p.T <= 48) {
+    if (p.T > 32 && launch_splitk<T, NCH, 2, 2, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
+    if (launch_splitk<T, NCH, 2, 1, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
+    return launch_cfg<T, NCH, 2, 1, 2, 8>(p, st);                      //  32 x 128, 8 waves of 16 x 32
+  }
+  if (p.T <= 96 || (p.T % 128 != 0 && p.T % 128 <= 64 && p.T < 512)) {
+    if (launch_splitk<T, NCH, 2, 2, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
     return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);                      //  64 x 128, 8 waves of 32 x 32
+  }
   // a grid that cannot fill the 256 CUs with 128-row tiles (the frozen BERT's (B*tokens) x 768 GEMMs:
   // 60-72 blocks, 59 us each) gets smaller tiles: its K loop is latency-bound, more blocks = more overlap
   const long long nt = (p.Cout + 127) / 128;
   if ((long long)p.B * ((p.T + 127) / 128) * nt < 192) {
-    if ((long long)p.B * ((p.T + 63) / 64) * nt < 192) return launch_cfg<T, NCH, 2, 1, 2, 8>(p, st);
+    // long K: keep the 128-row tiles (every weight tile fetched from L2 serves 128 rows, not 32) and get the
+    // parallelism from split-K instead
+    if (launch_splitk<T, NCH, 4, 2, 2, 16>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
+    if ((long long)p.B * ((p.T + 63) / 64) * nt < 192) {
+      if (launch_splitk<T, NCH, 2, 1, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
+      return launch_cfg<T, NCH, 2, 1, 2, 8>(p, st);
+    }
+    if (launch_splitk<T, NCH, 2, 2, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
     return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);
   }
   // (64 x 128 and 256 x 64 tiles measured 10-45 % slower on the frame-level shapes)
@@ -284,9 +385,10 @@ extern "C" int ptpp_conv_cin_padded(int cin, int dtype) {
   return (cin + q - 1) / q * q;
 }
 
-// Extended argument block (adds the second residual of the AMP-block mean).
-extern "C" int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, int ldr2, float res_scale,
-                                  float drop_p, uint64_t drop_seed, void* stream) {
+// Full form: second residual of the AMP-block mean, fused dropout, optional split-K workspace.
+extern "C" int ptpp_conv1d_fwd_ws(const ptpp_conv1d_args* a, const void* res2, int ldr2, float res_scale,
+                                  float drop_p, uint64_t drop_seed, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
   PTPP_CHECK_ARG(a && a->x && a->wp && a->y, "conv1d: null pointer");
   PTPP_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "conv1d: bad dtype %d", a->dtype);
   const int kc = a->dtype == PTPP_BF16 ? 8 : 4;
@@ -320,11 +422,21 @@ extern "C" int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, i
   p.drop_thresh16 = drop_p > 0.f ? (unsigned)(drop_p * 65536.f + 0.5f) : 0u;
   p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - p.drop_thresh16 / 65536.f) : 1.f;
   p.drop_seed = drop_seed;
+  p.ws = nullptr;
+  p.nsplit = 1;
+  if (workspace && ((uintptr_t)workspace & 15)) workspace = nullptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool wide = (p.cinp % (8 * kc)) == 0;
   if (a->dtype == PTPP_F32)
-    return wide ? launch_tiles<float, 8>(p, st) : launch_tiles<float, 4>(p, st);
-  return wide ? launch_tiles<bf16_raw, 8>(p, st) : launch_tiles<bf16_raw, 4>(p, st);
+    return wide ? launch_tiles<float, 8>(p, st, workspace, workspace_bytes)
+                : launch_tiles<float, 4>(p, st, workspace, workspace_bytes);
+  return wide ? launch_tiles<bf16_raw, 8>(p, st, workspace, workspace_bytes)
+              : launch_tiles<bf16_raw, 4>(p, st, workspace, workspace_bytes);
+}
+
+extern "C" int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, int ldr2, float res_scale,
+                                  float drop_p, uint64_t drop_seed, void* stream) {
+  return ptpp_conv1d_fwd_ws(a, res2, ldr2, res_scale, drop_p, drop_seed, nullptr, 0, stream);
 }
 
 extern "C" int ptpp_conv1d_fwd(const ptpp_conv1d_args* a, void* stream) {

@@ -45,6 +45,8 @@ struct ConvP {
   unsigned drop_thresh16;  // 0 = no dropout
   float drop_inv_keep;
   unsigned long long drop_seed;
+  float* ws;   // split-K: f32 partial sums [nsplit][B][T][Cout] (no epilogue), summed by conv_splitk_finish_kernel
+  int nsplit;  // 1 = no split
 };
 
 // Fused epilogue of one (BM x BN) tile: acc[fm][fn] is the MFMA accumulator of the wave's

@@ -144,7 +144,15 @@ def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mas
         if r is not None:
             assert r.dtype == x.dtype and r.shape[:2] == y.shape[:2] and r.shape[2] == cout
     lib = _lib.load()
-    if res2 is None and res_scale == 1.0 and drop_p == 0.0:
+    if T <= 512 and ks * cin >= 2048 and not torch.cuda.is_current_stream_capturing():
+        # few rows per utterance and a long K: hand the kernel the per-stream scratch so it may split K
+        ws = workspace(x.device)
+        check(
+            lib.ptpp_conv1d_fwd_ws(ctypes.byref(a), _ptr(res2), _ld(res2) if res2 is not None else 0, float(res_scale),
+                                   float(drop_p), int(drop_seed), _ptr(ws), ws.numel(), _stream()),
+            "ptpp_conv1d_fwd_ws",
+        )
+    elif res2 is None and res_scale == 1.0 and drop_p == 0.0:
         check(lib.ptpp_conv1d_fwd(ctypes.byref(a), _stream()), "ptpp_conv1d_fwd")
     else:
         check(

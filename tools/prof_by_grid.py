@@ -14,8 +14,10 @@ if not cols:
 print("columns:", cols)
 gx = "grid_x" if "grid_x" in cols else "grid_size_x"
 wx = "workgroup_x" if "workgroup_x" in cols else "workgroup_size_x"
-q = f"select name, {gx}, {wx}, count(*), sum(end-start)/1e3, avg(end-start)/1e3 from kernels where name like ? " \
-    f"group by name, {gx}, {wx} order by 5 desc limit 40"
+gy, gz = gx.replace("_x", "_y"), gx.replace("_x", "_z")
+limit = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+q = f"select name, {gx}*{gy}*{gz}, {wx}, count(*), sum(end-start)/1e3, avg(end-start)/1e3 from kernels where name like ? " \
+    f"group by name, {gx}*{gy}*{gz}, {wx} order by 5 desc limit {limit}"
 for r in cur.execute(q, (f"%{pat}%",)).fetchall():
     print(f"{r[0][:90]:90s} grid={r[1]:>8} wg={r[2]:>5} n={r[3]:>6} total={r[4]:>10.0f}us avg={r[5]:>8.1f}us")
 scol = "stream_id" if "stream_id" in cols else ("stream" if "stream" in cols else None)
