@@ -225,15 +225,17 @@ int ptpp_attention_fwd(const void* q, const void* k, const void* v,
                        void* stream);
 
 /* dS: (B,H,T,T) f32 workspace; dq/dk_out/dv_out: (B,T,*) rows, stride lddq;
- * dpos: (2T-1, H*dk) f32 (overwritten); du/dvb: (H*dk) f32 accumulated with
- * atomics into caller-zeroed buffers.  Variants: NEW and PLAIN. */
+ * dpos: (2T-1, H*dk) f32 (overwritten); du/dvb: (H*dk) f32 buffers the totals are
+ * ADDED to (through the reduction scratch described at ptpp_layernorm_bwd, here
+ * PTPP_RED_SCRATCH_BYTES(H*dk) bytes; needed for the NEW variant).  Variants: NEW and PLAIN. */
 int ptpp_attention_bwd(const void* q, const void* k, const void* v,
                        const void* pos, const float* bias_u, const float* bias_v,
                        const float* probs, const void* dctx, float* dS, void* dq,
                        void* dk_out, void* dv_out, float* dpos, float* du,
                        float* dvb, const int32_t* lengths, int B, int T, int H,
                        int dk, int ld, int ldpos, int lddctx, int lddq,
-                       int variant, int dtype, void* stream);
+                       int variant, int dtype, void* scratch, size_t scratch_bytes,
+                       void* stream);
 
 /* ------------------------------------------------------------------ *
  * Length regulator as a gather / segment-sum instead of the reference's

@@ -147,13 +147,18 @@ struct AttnBwdP {
   const float *bias_u, *bias_v, *probs;
   float* dS;       // (B,H,T,T)
   void* dq;        // (B,T,*) with stride lddq
-  float *du, *dvb; // (H*dk) accumulators
+  float *du, *dvb; // (H*dk) accumulators (filled by red_sum_kernel from the scratch)
+  float* scratch;  // reduction scratch: 32 replicas of [du | dvb]
   const int* lengths;
   int B, T, H, dk, ld, ldpos, lddctx, lddq, variant;
   float scale;
 };
 
-constexpr int ROWS_PER_WAVE = 4;  // query rows per wave in attn_bwd_row_kernel
+// Query rows per wave in attn_bwd_row_kernel.  One: the row loops are chains of dependent L2 reads, so
+// the kernel wants many resident waves (4 rows per wave left 1.75 waves per SIMD on the phone-level
+// shapes); the du / dvb sums, which once forced several rows per wave to cut same-address atomics, now go
+// through the replicated reduction scratch (ptpp_common.h).
+constexpr int ROWS_PER_WAVE = 1;
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
@@ -228,9 +233,10 @@ __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
       *reinterpret_cast<f32x4*>(red + (w * 2 + 1) * dk + dv) = sv;
     }
     __syncthreads();
+    float* rep = p.scratch + (size_t)((blockIdx.x + gridDim.x * blockIdx.z) % PTPP_RED_NREP) * (2 * p.H * dk);
     for (int c = threadIdx.x; c < 2 * dk; c += 256) {
       const float v = red[c] + red[2 * dk + c] + red[4 * dk + c] + red[6 * dk + c];
-      atomicAdd((c < dk ? p.du : p.dvb) + hc + (c < dk ? c : c - dk), v);
+      atomicAdd(rep + (c < dk ? hc + c : p.H * dk + hc + (c - dk)), v);  // [du (H*dk) | dvb (H*dk)]
     }
   }
 }
@@ -350,14 +356,17 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
                                   const float* bias_v, const float* probs, const void* dctx, float* dS, void* dq,
                                   void* dk_out, void* dv_out, float* dpos, float* du, float* dvb,
                                   const int32_t* lengths, int B, int T_, int H, int dk, int ld, int ldpos, int lddctx,
-                                  int lddq, int variant, int dtype, void* stream) {
+                                  int lddq, int variant, int dtype, void* scratch, size_t scratch_bytes,
+                                  void* stream) {
   PTPP_CHECK_ARG(q && k && v && probs && dctx && dS && dq && dk_out && dv_out, "attention_bwd: null pointer");
   PTPP_CHECK_ARG(shape_ok(B, T_, H, dk), "attention_bwd: unsupported shape");
   PTPP_CHECK_ARG(variant == VAR_NEW || variant == VAR_PLAIN,
                  "attention_bwd: only the 'new' rel-pos and plain variants are trainable (legacy is inference-only)");
   PTPP_CHECK_ARG(variant == VAR_PLAIN || (pos && bias_u && bias_v && dpos && du && dvb), "attention_bwd: rel-pos args");
-  AttnBwdP p{q, k, v, pos, dctx, bias_u, bias_v, probs, dS, dq, du, dvb, lengths, B, T_, H, dk, ld, ldpos, lddctx,
-             lddq, variant, 1.0f / sqrtf((float)dk)};
+  PTPP_CHECK_ARG(variant == VAR_PLAIN || red_scratch_ok(scratch, scratch_bytes, 2 * H * dk),
+                 "attention_bwd: reduction scratch missing or too small");
+  AttnBwdP p{q, k, v, pos, dctx, bias_u, bias_v, probs, dS, dq, du, dvb, reinterpret_cast<float*>(scratch), lengths,
+             B, T_, H, dk, ld, ldpos, lddctx, lddq, variant, 1.0f / sqrtf((float)dk)};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((T_ + 3) / 4, H, B);
   dim3 grid_row((T_ + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), H, B);
@@ -377,6 +386,7 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
   else if (dtype == PTPP_BF16) { ATTN_BWD(bf16_raw) }
   else PTPP_CHECK_ARG(false, "attention_bwd: bad dtype");
 #undef ATTN_BWD
+  if (variant == VAR_NEW) red_sum_launch(scratch, 2 * H * dk, du, H * dk, dvb, 1, st);
   PTPP_CHECK_LAUNCH("attention_bwd");
   return PTPP_OK;
 }

@@ -328,7 +328,7 @@ def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, var
                                        _ptr(dctx), _ptr(dS), _ptr(dq), _ptr(dk_), _ptr(dv), _ptr(dpos), _ptr(du),
                                        _ptr(dvb), _ptr(lengths), B, T, heads, dkh, _ld(q),
                                        pos.stride(0) if pos is not None else 0, C, _ld(dq), _VARIANT[variant],
-                                       dtype_code(q.dtype), _stream()),
+                                       dtype_code(q.dtype), *reduction_scratch(q.device), _stream()),
         "ptpp_attention_bwd",
     )
     return dpos, du, dvb
