@@ -117,47 +117,63 @@ def pack_conv_weights_batched(table, n_entries, block_map, total_blocks):
 # ----------------------------------------------------------------------------
 # conv1d / linear
 # ----------------------------------------------------------------------------
+_conv_args = ConvArgs()  # one reusable argument block: the C side copies it before returning
+_conv_args_ref = ctypes.byref(_conv_args)
+
+
+def _ld_fast(t):
+    return t.shape[2] if t.is_contiguous() else _ld(t)
+
+
 def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mask=False, out_mask=False, res=None,
            out_scale=1.0, res2=None, res_scale=1.0, drop_p=0.0, drop_seed=0, out=None):
     """Channels-last conv / linear with the fused epilogue (see ptpp.h).
-    x: (B, T, Cin); wp: packed weight; bias: (cout) f32 or None -> (B, T, cout)."""
-    _need_gpu(x)
-    _rows3(x)
+    x: (B, T, Cin); wp: packed weight; bias: (cout) f32 or None -> (B, T, cout).
+    (Called ~170 times per training step: written for low host overhead.)"""
+    if not x.is_cuda:
+        _need_gpu(x)
     B, T, cin = x.shape
     y = out if out is not None else torch.empty((B, T, cout), device=x.device, dtype=x.dtype)
-    lengths = i32(lengths, x.device)
+    if lengths is not None:
+        lengths = i32(lengths, x.device)
+    a = _conv_args
+    a.x, a.wp, a.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous()
-    a = ConvArgs()
-    a.x, a.wp, a.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
-    a.bias = bias.data_ptr() if bias is not None else None
-    a.res = res.data_ptr() if res is not None else None
+        a.bias = bias.data_ptr()
+    else:
+        a.bias = None
     a.lengths = lengths.data_ptr() if lengths is not None else None
     a.B, a.T, a.Cin, a.Cout, a.ks, a.dil, a.pad = B, T, cin, cout, ks, dil, pad
-    a.ldx, a.ldy = _ld(x), _ld(y)
-    a.ldr = _ld(res) if res is not None else 0
+    a.ldx, a.ldy = _ld_fast(x), _ld_fast(y)
+    if res is not None:
+        assert res.dtype == x.dtype and res.shape[0] == B and res.shape[1] == T and res.shape[2] == cout
+        a.res, a.ldr = res.data_ptr(), _ld_fast(res)
+    else:
+        a.res, a.ldr = None, 0
+    ldr2 = 0
+    if res2 is not None:
+        assert res2.dtype == x.dtype and res2.shape[0] == B and res2.shape[1] == T and res2.shape[2] == cout
+        ldr2 = _ld_fast(res2)
     a.act = _ACT[act]
     a.in_mask, a.out_mask = int(bool(in_mask)), int(bool(out_mask))
     a.out_scale = float(out_scale)
-    a.dtype = dtype_code(x.dtype)
-    for r in (res, res2):
-        if r is not None:
-            assert r.dtype == x.dtype and r.shape[:2] == y.shape[:2] and r.shape[2] == cout
+    a.dtype = BF16 if x.dtype == torch.bfloat16 else dtype_code(x.dtype)
     lib = _lib.load()
     if T <= 512 and ks * cin >= 2048 and not torch.cuda.is_current_stream_capturing():
         # few rows per utterance and a long K: hand the kernel the per-stream scratch so it may split K
         ws = workspace(x.device)
         check(
-            lib.ptpp_conv1d_fwd_ws(ctypes.byref(a), _ptr(res2), _ld(res2) if res2 is not None else 0, float(res_scale),
-                                   float(drop_p), int(drop_seed), _ptr(ws), ws.numel(), _stream()),
+            lib.ptpp_conv1d_fwd_ws(_conv_args_ref, _ptr(res2), ldr2, float(res_scale), float(drop_p), int(drop_seed),
+                                   _ptr(ws), ws.numel(), _stream()),
             "ptpp_conv1d_fwd_ws",
         )
     elif res2 is None and res_scale == 1.0 and drop_p == 0.0:
-        check(lib.ptpp_conv1d_fwd(ctypes.byref(a), _stream()), "ptpp_conv1d_fwd")
+        check(lib.ptpp_conv1d_fwd(_conv_args_ref, _stream()), "ptpp_conv1d_fwd")
     else:
         check(
-            lib.ptpp_conv1d_fwd_ex(ctypes.byref(a), _ptr(res2), _ld(res2) if res2 is not None else 0,
-                                   float(res_scale), float(drop_p), int(drop_seed), _stream()),
+            lib.ptpp_conv1d_fwd_ex(_conv_args_ref, _ptr(res2), ldr2, float(res_scale), float(drop_p), int(drop_seed),
+                                   _stream()),
             "ptpp_conv1d_fwd_ex",
         )
     return y
