@@ -97,7 +97,10 @@ def train_setup(model, world):
 def train_step(model, batch, red, opt, sched):
     red.zero_grad()
     out = model(batch)
-    out["loss"].backward()
+    # backward on the calling thread: most nodes are Python autograd Functions, and the engine's worker
+    # thread would take the GIL from this (idle) one for each of them (tools/diag_backward_thread.py)
+    with torch.autograd.set_multithreading_enabled(False):
+        out["loss"].backward()
     red.finish()
     opt.step()
     sched.step()
@@ -118,7 +121,8 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         T = x.shape[1]
         # the launches that take the 128 x 128-tile instantiation (tile choice of conv1d_cl.hip::launch_tiles)
         big = (x.dtype == torch.bfloat16 and cout > 64 and x.shape[2] % 64 == 0
-               and not (T <= 96 or (T % 128 != 0 and T % 128 <= 64 and T < 512)))
+               and not (T <= 96 or (T % 128 != 0 and T % 128 <= 64 and T < 512))
+               and x.shape[0] * ((T + 127) // 128) * ((cout + 127) // 128) >= 192)  # smaller grids: other tiles / split-K
         if not big:
             return orig(x, wp, bias, cout, ks=ks, dil=dil, pad=pad, lengths=lengths, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -201,7 +201,8 @@ class TTSTrainer:
                 batch = self._to_device(batch, device)
                 reducer.zero_grad()
                 loss_dict = model(batch)
-                loss_dict["loss"].backward()
+                with torch.autograd.set_multithreading_enabled(False):  # Python-heavy backward: stay on this thread
+                    loss_dict["loss"].backward()
                 reducer.finish()
                 if not fused:
                     torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
