@@ -90,6 +90,7 @@ def train_setup(model, world):
     red = FlatGradReducer(params)
     red.broadcast_parameters(model)
     opt = FusedAdamW(params, lr=1e-3, betas=(0.9, 0.98), weight_decay=0.0, max_grad_norm=1.0)  # conf/optimizer/adamw.yaml + clip 1.0
+    opt.stable_grads = True  # p.grad are views of the reducer's flat buffer for the whole run
     sched = NoamLR(opt, warmup_steps=4000)
     return red, opt, sched
 

@@ -47,6 +47,25 @@ class BertWrapper(nn.Module):
             p.requires_grad = True
         self.hip_frozen_layers = True  # False: every layer through the library modules
 
+    def _n_frozen(self, layers):
+        """Number of leading encoder layers without a trainable parameter.  Walking ~200 parameters per
+        forward cost ~0.5 ms of host time per step, so the count is cached; ``train()`` / ``eval()``
+        (and ``refresh_frozen_layers()`` after changing ``requires_grad`` by hand) recompute it."""
+        n = getattr(self, "_n_frozen_cache", None)
+        if n is None:
+            n = 0
+            while n < len(layers) and not any(p.requires_grad for p in layers[n].parameters()):
+                n += 1
+            self._n_frozen_cache = n
+        return n
+
+    def refresh_frozen_layers(self):
+        self._n_frozen_cache = None
+
+    def train(self, mode=True):
+        self._n_frozen_cache = None
+        return super().train(mode)
+
     def tokenize(self, prompts, device):
         if isinstance(prompts, (tuple, list)) and len(prompts) == 2 and isinstance(prompts[0], torch.Tensor):
             return prompts[0].to(device), prompts[1].to(device)
@@ -68,8 +87,7 @@ class BertWrapper(nn.Module):
         if ids.is_cuda and self.hip_frozen_layers:
             # frozen layers (no gradient flows into or through them: the embeddings are frozen too) run
             # forward-only on the HIP kernels: 7 launches per layer, weights packed once
-            while n_hip < len(layers) and not any(p.requires_grad for p in layers[n_hip].parameters()):
-                n_hip += 1
+            n_hip = self._n_frozen(layers)
             if n_hip and not (torch.is_grad_enabled() and h.requires_grad):
                 lengths = am.sum(dim=1).to(torch.int32)
                 hc = h.detach().to(compute_dtype()).contiguous()

@@ -21,17 +21,35 @@ class FusedAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.max_grad_norm = float(max_grad_norm)
+        self.stable_grads = False  # set True by callers whose p.grad tensors live for the whole run (see _table)
         self._tables = {}
         self._sumsq = None
         self._lr_dev = {}
 
+    def _bump_list(self, gi, group):
+        """The parameters of the group that are updated (have a grad): one list object per group, rebuilt only
+        when the table is (its identity tells functional.repack_all that the same set was bumped again)."""
+        ent = self._tables.get(gi)
+        if ent is not None and len(ent) > 7:
+            return ent[7]
+        return [p for p in group["params"] if p.grad is not None]
+
     def _table(self, gi, group):
         """Device pointer table for the group's parameters that have grads."""
+        ent = self._tables.get(gi)
+        if ent is not None and self.stable_grads:
+            # fast validity check (this runs every step over ~700 parameters): same gradient tensor OBJECTS as
+            # when the table was built.  Only sound when the gradients are long-lived tensors (the views of
+            # FlatGradReducer's flat buffer) -- with per-step gradient tensors an id() can be recycled -- so
+            # the owner of such gradients opts in through ``stable_grads``.
+            ps0, gids = ent[5], ent[6]
+            if len(ps0) == len(group["params"]) and all(id(p.grad) == g for p, g in zip(ps0, gids)) and \
+                    ps0[0].data_ptr() == ent[0][0][0] and ps0[-1].data_ptr() == ent[0][-1][0]:
+                return ent[1:5]
         ps = [p for p in group["params"] if p.grad is not None]
         key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
-        ent = self._tables.get(gi)
         if ent is not None and ent[0] == key:
-            return ent[1:]
+            return ent[1:5]
         rows, blk, owners = [], 0, []
         for p in ps:
             assert p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() and p.is_cuda
@@ -46,7 +64,8 @@ class FusedAdamW(torch.optim.Optimizer):
             blk += nb
         tab = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(ps[0].device)
         bmap = torch.from_numpy(np.concatenate(owners)).to(ps[0].device)  # block -> record
-        self._tables[gi] = (key, tab, len(ps), blk, bmap)
+        fast = ps if len(ps) == len(group["params"]) else []  # the id() shortcut needs every parameter to have a grad
+        self._tables[gi] = (key, tab, len(ps), blk, bmap, fast, [id(p.grad) for p in fast], list(ps))
         return tab, len(ps), blk, bmap
 
     @torch.no_grad()
@@ -85,10 +104,11 @@ class FusedAdamW(torch.optim.Optimizer):
             )
             # the kernel writes the parameters through raw pointers: tell autograd (and every cache
             # keyed on Tensor._version -- the packed-weight caches of functional.py) that they changed
-            torch.autograd.graph.increment_version([p for p in g["params"] if p.grad is not None])
+            torch.autograd.graph.increment_version(self._bump_list(gi, g))
         from . import functional as PF
 
-        PF.repack_all()  # one launch refreshes every cached packed operand of the updated weights
+        # one launch refreshes every cached packed operand of the updated weights
+        PF.repack_all(bumped=self._bump_list(live[0][0], live[0][1]) if len(live) == 1 and self.stable_grads else None)
         return loss
 
     def grad_norm(self):

@@ -184,6 +184,8 @@ class TTSTrainer:
                 print(f"Failed loading checkpoint: {e}")
 
         reducer = FlatGradReducer(params)      # p.grad become views of one flat buffer
+        if fused:
+            optimizer.stable_grads = True      # ... for the whole run: FusedAdamW may skip its per-step pointer scan
         reducer.broadcast_parameters(model)    # DDP constructor semantics
 
         train_dl, valid_dl, sampler = self._loaders(cfg, rank, world)

@@ -452,3 +452,65 @@ def test_skinny_gemm_path(rows, cin, cout, act, dtype, dev):
         y = ops.conv1d(xd, wp, b.to(dev), cout, act=act, res=rd, out_scale=0.5)
         assert y.shape == (shape[0], shape[1], cout)
         assert rel_err(y.float().cpu().view(rows, cout), ref) < tol
+
+
+def test_fast_repack_path_keeps_packed_operands_current(dev):
+    """The trainer's configuration (FlatGradReducer gradients + FusedAdamW.stable_grads): from the second
+    step on the optimiser skips its pointer scan and functional.repack_all reuses the cached launch table and
+    only advances the stamps.  After several steps every cached operand must equal a fresh pack of the
+    current weight, no entry may have needed a lazy re-pack, and adding a layer must fall back to the scan."""
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd import ops
+    from promptttspp_amd.optim import FusedAdamW
+    from promptttspp_amd.parallel import FlatGradReducer
+
+    PF.clear_caches()
+    torch.manual_seed(0)
+    net = torch.nn.ModuleList([torch.nn.Linear(64, 96), torch.nn.Linear(96, 32), torch.nn.Conv1d(32, 64, 3, padding=1)]).to(dev)
+    params = list(net.parameters())
+    red = FlatGradReducer(params)
+    opt = FusedAdamW(params, lr=0.05)
+    opt.stable_grads = True
+    x = torch.randn(3, 20, 64, device=dev)
+
+    def fwd(extra=None):
+        h = PF.linear(x, net[0].weight, net[0].bias, act="relu")
+        h = PF.linear(h, net[1].weight, net[1].bias)
+        h = PF.conv1d(h, net[2].weight, net[2].bias, ks=3, pad=1)
+        return h if extra is None else PF.linear(h, extra.weight, extra.bias)
+
+    try:
+        calls = []
+        orig = ops.pack_conv_weight
+        ops.pack_conv_weight = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            for it in range(5):
+                red.zero_grad()
+                y = fwd()
+                y.square().mean().backward()
+                red.finish()
+                opt.step()
+                if it == 0:
+                    n_first = len(calls)  # the first forward/backward packs every operand once
+            assert PF._repack["gen"] is not None            # the fast path is armed ...
+            assert len(calls) == n_first                    # ... and nothing was re-packed one by one since
+            for m in net:
+                w = m.weight if m.weight.dim() == 3 else m.weight.unsqueeze(-1)
+                for mode in (0, 1):
+                    cached = PF.packed(m.weight, torch.float32, mode)
+                    assert torch.equal(cached, orig(w.detach(), torch.float32, mode))
+            ref = F.conv1d(F.linear(F.relu(F.linear(x, net[0].weight, net[0].bias)), net[1].weight, net[1].bias).transpose(1, 2),
+                           net[2].weight, net[2].bias, padding=1).transpose(1, 2)
+            assert rel_err(fwd().detach().cpu(), ref.detach().cpu()) < 1e-4
+            # a new layer enters the cache: the next repack must notice (generation changed) and still be right
+            extra = torch.nn.Linear(64, 16).to(dev)
+            fwd(extra).square().mean().backward()
+            red.finish()
+            opt.step()
+            w = net[0].weight
+            assert torch.equal(PF.packed(w, torch.float32, 0), orig(w.detach().unsqueeze(-1), torch.float32, 0))
+        finally:
+            ops.pack_conv_weight = orig
+    finally:
+        PF.enable_direct_grads(False)
+        PF.clear_caches()
