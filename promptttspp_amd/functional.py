@@ -198,7 +198,7 @@ def _f32c(t):
 # parameters, so uses are counted in forward and the reducer is notified when the last
 # pending use of a parameter has been accumulated.
 # ----------------------------------------------------------------------------
-_direct = {"on": False, "notify": None, "uses": {}, "async": False, "side": None, "side_h": None}
+_direct = {"on": False, "notify": None, "uses": {}, "async": False, "side": None, "side_h": None, "keep": []}
 
 
 def enable_direct_grads(on=True, notify=None, async_wgrad=True):
@@ -209,6 +209,7 @@ def enable_direct_grads(on=True, notify=None, async_wgrad=True):
     _direct["on"], _direct["notify"] = bool(on), notify
     _direct["async"] = bool(on) and bool(async_wgrad) and not os.environ.get("PTPP_NO_ASYNC_WGRAD")
     _direct["uses"].clear()
+    sync_wgrad_stream()  # also releases the tensors held for the side stream
 
 
 class wgrad_stream:
@@ -216,28 +217,35 @@ class wgrad_stream:
     (after everything already enqueued on the current stream); the tensors are kept alive for it.
     Default: only this package's own launches move (``ops._stream_override`` + one ``ptpp_stream_wait``
     call: ~3 us of host time); ``torch_ops=True`` also switches torch's current stream, for blocks that
-    allocate or run torch ops (~25 us)."""
+    allocate or run torch ops (~25 us).  The tensors the side stream reads are held in a list until the
+    streams are joined again (``sync_wgrad_stream``) instead of ``Tensor.record_stream`` (cheaper, and the
+    allocator cannot hand their memory to the main stream before the join)."""
+
+    __slots__ = ("tensors", "torch_ops", "ctx", "on")
 
     def __init__(self, *tensors, torch_ops=False):
-        self.tensors = [t for t in tensors if t is not None]
+        self.tensors = tensors
         self.torch_ops = torch_ops
         self.ctx = None
         self.on = False
 
     def __enter__(self):
-        if not (_direct["async"] and self.tensors and self.tensors[0].is_cuda and not torch.cuda.is_current_stream_capturing()):
+        d = _direct
+        if not d["async"] or not self.tensors or self.tensors[0] is None or not self.tensors[0].is_cuda:
             return self
-        side = _direct["side"]
-        if side is None:
-            side = _direct["side"] = torch.cuda.Stream(device=self.tensors[0].device)
-            _direct["side_h"] = ctypes.c_void_p(side.cuda_stream)
-        _lib.check(_lib.load().ptpp_stream_wait(_direct["side_h"], ops._stream()), "ptpp_stream_wait")
+        side_h = d["side_h"]
+        if side_h is None:
+            if torch.cuda.is_current_stream_capturing():
+                return self
+            d["side"] = torch.cuda.Stream(device=self.tensors[0].device)
+            side_h = d["side_h"] = ctypes.c_void_p(d["side"].cuda_stream)
+        _lib.check(_lib.load().ptpp_stream_wait(side_h, ops._stream()), "ptpp_stream_wait")
         self.on = True
         if self.torch_ops:
-            self.ctx = torch.cuda.stream(side)
+            self.ctx = torch.cuda.stream(d["side"])
             self.ctx.__enter__()
         else:
-            ops._stream_override = _direct["side_h"]
+            ops._stream_override = side_h
         return self
 
     def __exit__(self, *exc):
@@ -246,15 +254,19 @@ class wgrad_stream:
                 self.ctx.__exit__(*exc)
             else:
                 ops._stream_override = None
-            for t in self.tensors:
-                t.record_stream(_direct["side"])
+            keep = _direct["keep"]
+            keep.extend(self.tensors)
+            if len(keep) > 4096:  # nobody joined the streams for a long time: join here
+                sync_wgrad_stream()
         return False
 
 
 def sync_wgrad_stream():
-    """The current stream waits for the weight-gradient kernels enqueued so far."""
+    """The current stream waits for the weight-gradient kernels enqueued so far; the tensors held for the
+    side stream are released (whatever reuses their memory is enqueued after this wait)."""
     if _direct["side"] is not None:
         torch.cuda.current_stream().wait_stream(_direct["side"])
+        _direct["keep"].clear()
 
 
 def reset_direct_uses():

@@ -187,7 +187,8 @@ def workspace(device):
     """Per-device scratch for the deterministic split-K reduction of the weight gradients.
     One buffer is enough: its users are ordered on the stream."""
     # one buffer per (device, stream): its users are ordered on that stream
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
+    idx = device.index
+    key = (idx if idx is not None else torch.cuda.current_device(), _stream().value)
     w = _ws.get(key)
     if w is None:
         w = _ws[key] = torch.empty(_WS_BYTES, device=device, dtype=torch.uint8)
