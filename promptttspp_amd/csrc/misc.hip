@@ -81,10 +81,10 @@ extern "C" int ptpp_conv_post_tanh(const void* x, const float* w, float bias, fl
 
 // ---- stream fork: `waiter` waits for everything enqueued on `signaler` so far ----------------
 // One call instead of torch's event-record + wait_event + stream-guard round trip (~25 us of host time
-// per weight-gradient launch, ~110 per training step).  Events come from a per-device ring; re-recording
-// an event whose earlier wait is still pending is fine (a wait binds to the record it saw when enqueued).
+// per weight-gradient launch, ~110 per training step).  Events come from a per-device ring long enough that an
+// event is not re-recorded while a wait on it can still be pending.
 namespace {
-constexpr int EV_RING = 64, EV_DEVS = 16;
+constexpr int EV_RING = 1024, EV_DEVS = 16;  // (re-recording an event that still has a pending wait is slow on HIP: keep the ring long)
 hipEvent_t g_ev[EV_DEVS][EV_RING];
 bool g_ev_ready[EV_DEVS];
 unsigned g_ev_next[EV_DEVS];

@@ -15,6 +15,8 @@ views of the flat buffer (functional.enable_direct_grads): no per-parameter zero
 temporary or ``grad +=`` launch.  Autograd's post-accumulate hooks do not fire for
 gradients written that way, so functional notifies ``_hook`` itself.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -54,10 +56,13 @@ class FlatGradReducer:
         if direct and dev.type == "cuda":
             from . import functional as PF
 
-            # the weight-gradient side stream is used at world size 1 only: with a collective in the step it
-            # measured far slower in the 2-rank gloo self-test (tools/diag_dp_async.py: finish() 577 vs 101
-            # ms) and could not be tried over RCCL here, so multi-rank runs keep everything on one stream
-            PF.enable_direct_grads(True, notify=self._hook if self.world > 1 else None, async_wgrad=self.world == 1)
+            # The weight-gradient side stream (functional.wgrad_stream) is used at world size 1 only.  With a
+            # collective in the step the 2-rank gloo self-test computes the same gradients
+            # (tests/test_dp_gpu.py) but runs 4.7x slower (PTPP_BENCH_SELFTEST: 714 vs 153 ms/step), and the
+            # RCCL combination cannot be measured on a 1-GPU box -- so multi-rank runs keep everything on one
+            # stream until it can (PTPP_FORCE_ASYNC_WGRAD=1 switches it on for that experiment).
+            PF.enable_direct_grads(True, notify=self._hook if self.world > 1 else None,
+                                   async_wgrad=self.world == 1 or bool(os.environ.get("PTPP_FORCE_ASYNC_WGRAD")))
 
     # -- parameter broadcast (DDP constructor semantics) ------------------------------
     def broadcast_parameters(self, module, src=0):

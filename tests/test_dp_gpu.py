@@ -122,7 +122,7 @@ def _worker(rank, world, port):
         dist.destroy_process_group()
 
 
-def test_dp_training_step_two_ranks_one_device():
+def _run_two_ranks():
     ctx = torch.multiprocessing.get_context("spawn")
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port)) for r in range(2)]
@@ -131,3 +131,17 @@ def test_dp_training_step_two_ranks_one_device():
     for p in procs:
         p.join(timeout=600)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def test_dp_training_step_two_ranks_one_device():
+    _run_two_ranks()
+
+
+def test_dp_training_step_two_ranks_with_the_weight_gradient_side_stream():
+    """The configuration multi-rank RCCL runs use: weight gradients on the side stream, every bucket
+    all-reduce joining it first.  Forced here over gloo (slow with gloo, but the gradients must be the same)."""
+    os.environ["PTPP_FORCE_ASYNC_WGRAD"] = "1"
+    try:
+        _run_two_ranks()
+    finally:
+        del os.environ["PTPP_FORCE_ASYNC_WGRAD"]
