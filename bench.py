@@ -227,6 +227,12 @@ def log(msg):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line (the JSON): native libraries write banners there (RCCL prints its
+    # version block on the first collective), so fd 1 points at stderr for the whole run and the result
+    # goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -246,6 +252,13 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+
+    elif os.environ.get("PTPP_DP_FORCE_COLLECTIVES"):  # diagnostics: one rank over RCCL (see parallel.py)
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from promptttspp_amd import _lib, config
     from promptttspp_amd import functional as PF
@@ -333,7 +346,8 @@ def main():
             "per_gpu_value": round(frames / dt / world, 1),
             "bigvgan": voc,
         }
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1:
         import torch.distributed as dist
 

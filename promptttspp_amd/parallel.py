@@ -26,6 +26,10 @@ class FlatGradReducer:
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # PTPP_DP_FORCE_COLLECTIVES=1 (diagnostics): run the multi-rank machinery -- hooks, bucket all-reduces,
+        # finish() -- at world size 1 too, e.g. one rank over RCCL to look at stream interplay on a 1-GPU box
+        self.collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
+                                             and bool(os.environ.get("PTPP_DP_FORCE_COLLECTIVES")))
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -50,7 +54,7 @@ class FlatGradReducer:
         self._launched = [False] * len(self.buckets)
         self._seen = set()
         self._next = 0
-        if self.world > 1:
+        if self.collective:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
         if direct and dev.type == "cuda":
@@ -61,8 +65,8 @@ class FlatGradReducer:
             # (tests/test_dp_gpu.py) but runs 4.7x slower (PTPP_BENCH_SELFTEST: 714 vs 153 ms/step), and the
             # RCCL combination cannot be measured on a 1-GPU box -- so multi-rank runs keep everything on one
             # stream until it can (PTPP_FORCE_ASYNC_WGRAD=1 switches it on for that experiment).
-            PF.enable_direct_grads(True, notify=self._hook if self.world > 1 else None,
-                                   async_wgrad=self.world == 1 or bool(os.environ.get("PTPP_FORCE_ASYNC_WGRAD")))
+            PF.enable_direct_grads(True, notify=self._hook if self.collective else None,
+                                   async_wgrad=not self.collective or bool(os.environ.get("PTPP_FORCE_ASYNC_WGRAD")))
 
     # -- parameter broadcast (DDP constructor semantics) ------------------------------
     def broadcast_parameters(self, module, src=0):
@@ -115,7 +119,7 @@ class FlatGradReducer:
             from . import functional as PF
 
             PF.sync_wgrad_stream()
-        if self.world == 1:
+        if not self.collective:
             return
         for bi in range(self._next, len(self.buckets)):  # buckets with parameters that received no gradient
             if not self._launched[bi]:
