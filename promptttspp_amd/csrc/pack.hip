@@ -36,7 +36,9 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp
 // the first version of this kernel 1 ms per step).
 __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __restrict__ tab, int n,
                                                            const int* __restrict__ block_map) {
-  __shared__ float tile[32][33];
+  constexpr int KS_FAST = 9;                        // taps held at once by the fast path
+  __shared__ float buf[32 * (32 * KS_FAST + 1)];    // 37 KB; the per-tap path uses its first 32 x 33 floats
+  float (*tile)[33] = reinterpret_cast<float (*)[33]>(buf);
   int lo = 0, hi = n - 1;
   if (block_map) lo = hi = block_map[blockIdx.x];
   while (lo < hi) {  // last row whose first block <= blockIdx.x
@@ -52,6 +54,41 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
   const int nci = (cin + 31) / 32;
   const int co0 = (lb / nci) * 32, ci0 = (lb % nci) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  if (ks <= KS_FAST) {
+    // fast path: a source row segment [ci0, ci0+32) x all taps is CONTIGUOUS (32*ks floats): copy the 32 rows
+    // once, fully coalesced, then serve every tap from LDS (the per-tap path below re-reads the same cache
+    // lines ks times with a stride of ks floats)
+    const int seg = 32 * ks, pitch = seg + 1;
+    const int kmax = (min(cin, ci0 + 32) - ci0) * ks;  // valid floats of a segment
+    for (int idx = threadIdx.x; idx < 32 * seg; idx += 256) {
+      const int r = idx / seg, k = idx - r * seg;
+      const int co = co0 + r;
+      buf[r * pitch + k] = (co < cout && k < kmax) ? src[((int64_t)co * cin + ci0) * ks + k] : 0.f;
+    }
+    __syncthreads();
+    for (int j = 0; j < ks; ++j) {
+      for (int r = ty; r < 32; r += 8) {
+        if (mode == 0) {
+          const int co = co0 + r, ci = ci0 + tx;
+          if (co < cout && ci < cin) {
+            const float v = buf[r * pitch + tx * ks + j];
+            const int64_t d = ((off + co) * ks + j) * innerp + ci;
+            if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = v;
+            else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(v);
+          }
+        } else {  // r indexes ci here, writes run along co
+          const int ci = ci0 + r, co = co0 + tx;
+          if (co < cout && ci < cin) {
+            const float v = buf[tx * pitch + r * ks + j];
+            const int64_t d = ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
+            if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = v;
+            else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(v);
+          }
+        }
+      }
+    }
+    return;
+  }
   for (int j = 0; j < ks; ++j) {
     // tile[co_l][ci_l], reads with ci fastest
     for (int r = ty; r < 32; r += 8) {
