@@ -9,6 +9,7 @@ Layout: activations are channels-last ``(B, T, C)`` contiguous tensors in the
 compute dtype (torch.float32 or torch.bfloat16).
 """
 import ctypes
+import struct
 
 import torch
 
@@ -45,7 +46,8 @@ def _stream():
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    """Device address for a ``void*`` argument (ctypes converts a Python int / None itself)."""
+    return t.data_ptr() if t is not None else None
 
 
 def _need_gpu(t):
@@ -117,7 +119,12 @@ def pack_conv_weights_batched(table, n_entries, block_map, total_blocks):
 # ----------------------------------------------------------------------------
 # conv1d / linear
 # ----------------------------------------------------------------------------
-_conv_args = ConvArgs()  # one reusable argument block: the C side copies it before returning
+# One reusable argument block (the C side copies it before returning), filled by ONE struct.pack_into
+# instead of 21 ctypes attribute stores; the format mirrors ptpp_conv1d_args / _lib.ConvArgs field by field.
+_CONV_FMT = struct.Struct("6Q13ifi")
+assert _CONV_FMT.size <= ctypes.sizeof(ConvArgs) and ctypes.sizeof(ConvArgs) == 112
+_conv_buf = bytearray(ctypes.sizeof(ConvArgs))
+_conv_args = ConvArgs.from_buffer(_conv_buf)
 _conv_args_ref = ctypes.byref(_conv_args)
 
 
@@ -136,29 +143,20 @@ def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mas
     y = out if out is not None else torch.empty((B, T, cout), device=x.device, dtype=x.dtype)
     if lengths is not None:
         lengths = i32(lengths, x.device)
-    a = _conv_args
-    a.x, a.wp, a.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous()
-        a.bias = bias.data_ptr()
-    else:
-        a.bias = None
-    a.lengths = lengths.data_ptr() if lengths is not None else None
-    a.B, a.T, a.Cin, a.Cout, a.ks, a.dil, a.pad = B, T, cin, cout, ks, dil, pad
-    a.ldx, a.ldy = _ld_fast(x), _ld_fast(y)
+    ldr = ldr2 = 0
     if res is not None:
         assert res.dtype == x.dtype and res.shape[0] == B and res.shape[1] == T and res.shape[2] == cout
-        a.res, a.ldr = res.data_ptr(), _ld_fast(res)
-    else:
-        a.res, a.ldr = None, 0
-    ldr2 = 0
+        ldr = _ld_fast(res)
     if res2 is not None:
         assert res2.dtype == x.dtype and res2.shape[0] == B and res2.shape[1] == T and res2.shape[2] == cout
         ldr2 = _ld_fast(res2)
-    a.act = _ACT[act]
-    a.in_mask, a.out_mask = int(bool(in_mask)), int(bool(out_mask))
-    a.out_scale = float(out_scale)
-    a.dtype = BF16 if x.dtype == torch.bfloat16 else dtype_code(x.dtype)
+    _CONV_FMT.pack_into(_conv_buf, 0, x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                        res.data_ptr() if res is not None else 0, y.data_ptr(),
+                        lengths.data_ptr() if lengths is not None else 0, B, T, cin, cout, ks, dil, pad, _ld_fast(x),
+                        _ld_fast(y), ldr, _ACT[act], 1 if in_mask else 0, 1 if out_mask else 0, out_scale,
+                        BF16 if x.dtype == torch.bfloat16 else dtype_code(x.dtype))
     lib = _lib.load()
     if T <= 512 and ks * cin >= 2048 and not torch.cuda.is_current_stream_capturing():
         # few rows per utterance and a long K: hand the kernel the per-stream scratch so it may split K
