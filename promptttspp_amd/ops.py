@@ -179,6 +179,7 @@ def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mas
 
 _WS_BYTES = 64 << 20
 _ws = {}
+_ws_hot = {}  # raw stream handle -> workspace (fast path of conv1d_wgrad)
 
 
 def workspace(device):
@@ -217,20 +218,26 @@ def conv1d_wgrad(x, dy, cin, cout, ks, dil, pad, lengths=None, in_mask=False, wa
                  db_out=None):
     """Returns (dw (Cout,Cin,ks) f32, dbias (Cout) f32 or None).  ``dw_out`` / ``db_out``: f32 buffers the
     kernel ACCUMULATES into (it adds with atomics) instead of fresh zero-filled ones."""
-    _need_gpu(x)
+    if not x.is_cuda:
+        _need_gpu(x)
     B, T, _ = x.shape
+    dev = x.device
     dw = _acc_target(dw_out, cout * cin * ks) if dw_out is not None else \
-        torch.zeros((cout, cin, ks), device=x.device, dtype=torch.float32)
+        torch.zeros((cout, cin, ks), device=dev, dtype=torch.float32)
     db = None
     if want_bias:
-        db = _acc_target(db_out, cout) if db_out is not None else \
-            torch.zeros((cout,), device=x.device, dtype=torch.float32)
-    lengths = i32(lengths, x.device)
-    ws = workspace(x.device)
+        db = _acc_target(db_out, cout) if db_out is not None else torch.zeros((cout,), device=dev, dtype=torch.float32)
+    if lengths is not None:
+        lengths = i32(lengths, dev)
+    st = _stream()
+    ws = _ws_hot.get(st.value)  # (called ~110 times per backward: skip the (device, stream) key of workspace())
+    if ws is None or ws.device != dev:
+        ws = _ws_hot[st.value] = workspace(dev)
     check(
-        _lib.load().ptpp_conv1d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(lengths), B, T, cin, cout, ks, dil,
-                                      pad, _ld(x), _ld(dy), int(bool(in_mask)), dtype_code(x.dtype), _ptr(ws), ws.numel(),
-                                      _stream()),
+        _lib.load().ptpp_conv1d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                      lengths.data_ptr() if lengths is not None else None, B, T, cin, cout, ks, dil, pad,
+                                      _ld_fast(x), _ld_fast(dy), 1 if in_mask else 0,
+                                      BF16 if x.dtype == torch.bfloat16 else dtype_code(x.dtype), ws.data_ptr(), _WS_BYTES, st),
         "ptpp_conv1d_wgrad",
     )
     return dw, db
