@@ -261,6 +261,17 @@ class wgrad_stream:
         return False
 
 
+def side_stream_for_collective():
+    """The weight-gradient side stream, made to wait for everything enqueued on the current stream so far --
+    or None when it is not in use.  A collective issued under ``torch.cuda.stream(<it>)`` is then ordered
+    after every gradient kernel of both streams without stalling the current one."""
+    d = _direct
+    if not d["async"] or d["side"] is None:
+        return None
+    _lib.check(_lib.load().ptpp_stream_wait(d["side_h"], ops._stream()), "ptpp_stream_wait")
+    return d["side"]
+
+
 def sync_wgrad_stream():
     """The current stream waits for the weight-gradient kernels enqueued so far; the tensors held for the
     side stream are released (whatever reuses their memory is enqueued after this wait)."""

@@ -79,11 +79,20 @@ class FlatGradReducer:
     def _launch(self, bi):
         a, b, _ = self.buckets[bi]
         self._launched[bi] = True
+        side = None
         if self.flat.is_cuda:
             from . import functional as PF
 
-            PF.sync_wgrad_stream()  # the collective orders itself after the CURRENT stream only
-        self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            side = PF.side_stream_for_collective()
+            if side is None:
+                PF.sync_wgrad_stream()  # the collective orders itself after the CURRENT stream only
+        if side is not None:
+            # weight gradients run on the side stream: issue the collective FROM that stream (after it has
+            # caught up with this one), so that the main stream -- the critical path -- never waits for it
+            with torch.cuda.stream(side):
+                self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _hook(self, p):
         # A parameter can be reported twice in one step: by functional's direct-accumulation path when
