@@ -244,6 +244,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from promptttspp_amd import functional as PF0
+
+    PF0.create_side_stream(dev)  # before RCCL creates its streams (see the docstring)
     if world > 1:
         import torch.distributed as dist
 

@@ -60,13 +60,19 @@ class FlatGradReducer:
         if direct and dev.type == "cuda":
             from . import functional as PF
 
-            # The weight-gradient side stream (functional.wgrad_stream) is used at world size 1 only.  With a
-            # collective in the step the 2-rank gloo self-test computes the same gradients
-            # (tests/test_dp_gpu.py) but runs 4.7x slower (PTPP_BENCH_SELFTEST: 714 vs 153 ms/step), and the
-            # RCCL combination cannot be measured on a 1-GPU box -- so multi-rank runs keep everything on one
-            # stream until it can (PTPP_FORCE_ASYNC_WGRAD=1 switches it on for that experiment).
+            # The weight-gradient side stream (functional.wgrad_stream): at world size 1, and with several ranks
+            # over RCCL, whose collectives are stream-ordered device work -- every bucket all-reduce is issued
+            # FROM the side stream once it has caught up with the main one (_launch), so the main stream never
+            # waits.  Measured with one rank over RCCL on the 1-GPU box (PTPP_DP_FORCE_COLLECTIVES=1): 25.7-27.2
+            # ms/step against 28.2-28.5 on one stream -- provided the side stream exists BEFORE RCCL creates its
+            # streams (functional.create_side_stream; created after them it shared the main stream's hardware
+            # queue and nothing overlapped).  gloo stages device tensors through the host and blocks the
+            # launching thread: same gradients (tests/test_dp_gpu.py) but 4.7x slower with the side stream, so
+            # gloo runs stay on one stream (PTPP_FORCE_ASYNC_WGRAD=1 overrides).
+            backend = dist.get_backend(process_group) if self.collective else None
             PF.enable_direct_grads(True, notify=self._hook if self.collective else None,
-                                   async_wgrad=not self.collective or bool(os.environ.get("PTPP_FORCE_ASYNC_WGRAD")))
+                                   async_wgrad=(not self.collective or backend == "nccl"
+                                                or bool(os.environ.get("PTPP_FORCE_ASYNC_WGRAD"))))
 
     # -- parameter broadcast (DDP constructor semantics) ------------------------------
     def broadcast_parameters(self, module, src=0):

@@ -126,6 +126,9 @@ class TTSTrainer:
         from ..parallel import FlatGradReducer
 
         cfg = self.cfg
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            PF.create_side_stream(torch.device("cuda", local_rank))  # before RCCL creates its streams
         if world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "65535")

@@ -7,6 +7,12 @@ import bench
 from promptttspp_amd import config
 
 dev = torch.device("cuda:0")
+import os
+if os.environ.get("PTPP_DP_FORCE_COLLECTIVES"):  # one rank over RCCL: the multi-rank machinery on a 1-GPU box
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29556")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 config.set_compute_dtype(torch.bfloat16)
 model = bench.build_model(dev).train()
 batches = bench.make_batches(0, 1, 26, 30000, dev)
