@@ -228,10 +228,12 @@ class BigVGAN(nn.Module):
         if self._streams is None:
             self._streams = [torch.cuda.Stream(device=h.device) for _ in range(2)]
         outs = []
+        # fork FIRST: a wait recorded after block 0 had been enqueued on the main stream made the two side
+        # streams start only when block 0 was done (timeline: 0 ms of the main stream's work overlapped theirs)
+        for st in self._streams:
+            st.wait_stream(main)
         for k, layers in enumerate(blocks):
             st = main if k == 0 else self._streams[k - 1]
-            if st is not main:
-                st.wait_stream(main)
             with torch.cuda.stream(st):
                 xb = h
                 for li, (act1, c1, act2, c2) in enumerate(layers):

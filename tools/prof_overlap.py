@@ -39,3 +39,24 @@ for (a0, b0, n0), (a1, b1, n1) in zip(m[:-1], m[1:]):
 print("main-stream idle gaps > 100 us:", len(gaps), "total %.1f ms" % (sum(g[0] for g in gaps) / 1e6))
 for g in sorted(gaps, reverse=True)[:12]:
     print(f"  {g[0] / 1e3:8.1f} us after {g[1]}  before {g[2]}")
+
+# pairwise overlap between the busiest streams (e.g. BigVGAN's three AMP-block streams)
+top = sorted(by, key=lambda k: -sum(b - a for a, b, _ in by[k]))[:5]
+
+
+def overlap(xs, ys):
+    i = 0
+    ov = 0
+    for a, b, _ in xs:
+        while i < len(ys) and ys[i][1] <= a:
+            i += 1
+        j = i
+        while j < len(ys) and ys[j][0] < b:
+            ov += max(0, min(b, ys[j][1]) - max(a, ys[j][0]))
+            j += 1
+    return ov
+
+
+print("pairwise overlap (ms) between the busiest streams:", top)
+for i, p in enumerate(top):
+    print(f"  stream {p}: busy {sum(b - a for a, b, _ in by[p]) / 1e6:8.1f} |", " ".join(f"{overlap(by[p], by[q]) / 1e6:8.1f}" for q in top))
