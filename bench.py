@@ -119,18 +119,20 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
     orig = ops.conv1d
 
     def timed(x, wp, bias, cout, ks=1, dil=1, pad=0, lengths=None, **kw):
-        T = x.shape[1]
+        Bn, T = x.shape[0], x.shape[1]
+        if ks == 1 and not kw.get("in_mask") and not kw.get("out_mask"):
+            Bn, T = 1, Bn * T  # mask-free linear layers run over the flattened rows (ptpp_conv1d_fwd_ws)
         # the launches that take the 128 x 128-tile instantiation (tile choice of conv1d_cl.hip::launch_tiles)
-        big = (x.dtype == torch.bfloat16 and cout > 64 and x.shape[2] % 64 == 0
+        big = (x.dtype == torch.bfloat16 and cout > 64 and x.shape[2] % 64 == 0 and Bn * T > 128
                and not (T <= 96 or (T % 128 != 0 and T % 128 <= 64 and T < 512))
-               and x.shape[0] * ((T + 127) // 128) * ((cout + 127) // 128) >= 192)  # smaller grids: other tiles / split-K
+               and Bn * ((T + 127) // 128) * ((cout + 127) // 128) >= 192)  # smaller grids: other tiles / split-K
         if not big:
             return orig(x, wp, bias, cout, ks=ks, dil=dil, pad=pad, lengths=lengths, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         y = orig(x, wp, bias, cout, ks=ks, dil=dil, pad=pad, lengths=lengths, **kw)
         e1.record()
-        rows = float(lengths.sum()) if lengths is not None and (kw.get("out_mask") or kw.get("in_mask")) else x.shape[0] * T
+        rows = float(lengths.sum()) if lengths is not None and (kw.get("out_mask") or kw.get("in_mask")) else x.shape[0] * x.shape[1]
         recs.append((e0, e1, 2.0 * rows * x.shape[2] * cout * ks))
         return y
 

@@ -425,6 +425,13 @@ extern "C" int ptpp_conv1d_fwd_ws(const ptpp_conv1d_args* a, const void* res2, i
   p.ws = nullptr;
   p.nsplit = 1;
   if (workspace && ((uintptr_t)workspace & 15)) workspace = nullptr;
+  // A linear layer without sequence masks does not care where one utterance ends: treat the (B, T) rows
+  // as ONE sequence (rows are linear in memory: batches are T consecutive rows) so that short utterances
+  // (BERT: ~25 tokens, phone level: ~100) fill whole 128-row tiles instead of padding each to a tile
+  if (p.ks == 1 && !p.in_mask && !p.out_mask && p.B > 1) {
+    p.T = p.B * p.T;
+    p.B = 1;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool wide = (p.cinp % (8 * kc)) == 0;
   if (a->dtype == PTPP_F32)
