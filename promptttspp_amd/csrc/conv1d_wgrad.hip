@@ -125,6 +125,12 @@ extern "C" int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float
   PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "conv1d_wgrad: bad dtype %d", dtype);
   PTPP_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0, "conv1d_wgrad: row strides must be multiples of 4");
   PTPP_CHECK_ARG(!in_mask || lengths, "conv1d_wgrad: in_mask needs lengths");
+  // ks = 1 without an input mask: the reduction runs over rows, utterance boundaries do not matter -- one
+  // flat sequence (rows are linear in memory) instead of a padded 32-row chunk per short utterance
+  if (ks == 1 && !in_mask && B > 1) {
+    T = B * T;
+    B = 1;
+  }
   if (dtype == PTPP_BF16 && ldx % 8 == 0 && lddy % 8 == 0 && Cin % 8 == 0 && Cout % 8 == 0 &&
       ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
     // bf16-rate path (LDS transpose reads)
