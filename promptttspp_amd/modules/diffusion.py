@@ -154,7 +154,9 @@ class GaussianDiffusion(nn.Module):
         cond_all = self.denoise_fn.cond_all(cond)
         K = self.K_step
         if use_graph is None:
-            use_graph = self.use_graph
+            # replay pays while a step is launch-bound: 1.8x at 1 x 500 frames, 1.2x at 8 x 800, nothing at
+            # 32 x 1000 (profiles/r01_app_path_and_sampler_final.txt) -- large batches run eagerly
+            use_graph = self.use_graph and B * T <= 16384
         if not (use_graph and cond.is_cuda and K > 3):
             for i in reversed(range(K)):
                 x = self.p_sample_cl(x, i, cond, cond_all, draw(i, shape) if i > 0 else None)
