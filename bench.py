@@ -273,6 +273,14 @@ def main():
     config.set_compute_dtype(dtype)
     PF.manual_seed(1000 + rank)  # different dropout streams per rank
 
+    # MI355X has 288 GB: take a slab for the caching allocator up front so that the token-bucket batches
+    # (a new (batch, length) shape almost every step) carve their tensors out of it instead of growing the
+    # pool with hipMalloc calls inside the timed steps (PTPP_RESERVE_GIB=0 disables)
+    gib = float(os.environ.get("PTPP_RESERVE_GIB", "24"))
+    if gib > 0:
+        slab = torch.empty(int(gib * (1 << 30)), device=dev, dtype=torch.uint8)
+        del slab
+
     log("building model")
     model = build_model(dev).train()
     log("building batches")

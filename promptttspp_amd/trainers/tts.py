@@ -157,6 +157,15 @@ class TTSTrainer:
             except Exception:  # tensorboard is optional
                 writer = None
 
+        # a slab for the caching allocator up front (MI355X: 288 GB): token-bucket batches bring a new shape almost
+        # every step, and growing the pool with hipMalloc inside the steps showed as sporadic slow steps
+        gib = float(_get(cfg.train, "reserve_hbm_gib", 16))
+        if gib > 0:
+            try:
+                slab = torch.empty(int(gib * (1 << 30)), device=device, dtype=torch.uint8)
+                del slab
+            except RuntimeError:  # smaller device / shared GPU: carry on without the reservation
+                pass
         model = instantiate(cfg.model).to(device)
         if rank == 0:
             logger.info(f"model parameter : {sum(p.numel() for p in model.parameters())}")
