@@ -22,13 +22,18 @@ CONF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "egs", "proposed
 
 
 def load_model(model_cfg, model_ckpt_path, vocoder_cfg, vocoder_ckpt_path, device=None):
-    """reference app.py:28-40; checkpoints are optional here (random init when absent)."""
+    """reference app.py:28-40.  A checkpoint path of None / "" means random initialisation (tests, benchmarks);
+    a path that is given but does not exist raises, as ``torch.load`` does in the reference."""
     device = device or torch.device("cuda")
     model = instantiate(model_cfg)
-    if model_ckpt_path and os.path.exists(model_ckpt_path):
+    if model_ckpt_path:
+        if not os.path.exists(str(model_ckpt_path)):
+            raise FileNotFoundError(f"model_ckpt_path={model_ckpt_path!r} does not exist")
         model.load_state_dict(torch.load(model_ckpt_path, map_location="cpu")["model"])
     vocoder = instantiate(vocoder_cfg)
-    if vocoder_ckpt_path and os.path.exists(vocoder_ckpt_path):
+    if vocoder_ckpt_path:
+        if not os.path.exists(str(vocoder_ckpt_path)):
+            raise FileNotFoundError(f"vocoder_ckpt_path={vocoder_ckpt_path!r} does not exist")
         vocoder.load_state_dict(torch.load(vocoder_ckpt_path, map_location="cpu")["generator"])
     return model.to(device).eval(), vocoder.to(device).eval()
 
@@ -73,7 +78,11 @@ def synthesize_batch(model, vocoder, phoneme_ids, style_prompts=None, reference_
         ph[i, : len(p)] = torch.as_tensor(p, dtype=torch.long)
     kw = dict(use_max=True, noise_scale=noise_scale, return_f0=True)
     if style_prompts is not None:
-        mel, cf0, vuv, flen = model.infer_batch(ph.to(device), plen.to(device), style_prompt=list(style_prompts), **kw)
+        # a (input_ids, attention_mask) pair of tensors is passed through pre-tokenised (offline boxes
+        # have no BERT vocabulary); anything else is a sequence of strings
+        pre = isinstance(style_prompts, tuple) and len(style_prompts) == 2 and torch.is_tensor(style_prompts[0])
+        mel, cf0, vuv, flen = model.infer_batch(ph.to(device), plen.to(device),
+                                                style_prompt=style_prompts if pre else list(style_prompts), **kw)
     else:
         rlen = torch.tensor([m.shape[-1] for m in reference_mels], dtype=torch.long)
         ref = torch.zeros(n, reference_mels[0].shape[0], int(rlen.max()))

@@ -392,6 +392,25 @@ int ptpp_adamw_step(const void* refs, int nt, const int32_t* block_map,
                     float beta1, float beta2, float eps, float weight_decay,
                     int step, float max_norm, void* stream);
 
+/* ------------------------------------------------------------------ *
+ * Data-parallel gradient exchange over RCCL / xGMI (reference: DistributedDataParallel set up in
+ * trainers/tts.py:52-55 (init_process_group("nccl")) and :117 (DDP(model, device_ids=[rank])), whose
+ * bucketed all-reduce averages the gradients over the ranks during backward).
+ * One process per GPU.  librccl is bound at run time (the instance the process already holds, else ROCm's);
+ * without it these return PTPP_ENOTSUP.  Rank 0 obtains the 128-byte id and hands it to the other ranks
+ * through any side channel (the trainer uses the torch.distributed store); every rank then calls
+ * ptpp_comm_init with the same id.  `comm` is an opaque ncclComm_t.  The collectives are asynchronous on
+ * `stream`, in place, and must be issued in the same order on every rank.
+ * ------------------------------------------------------------------ */
+#define PTPP_COMM_ID_BYTES 128
+int ptpp_comm_unique_id(void* id_out /* HOST, PTPP_COMM_ID_BYTES */);
+int ptpp_comm_init(int rank, int world, const void* unique_id /* HOST */, void** comm_out /* HOST */);
+int ptpp_comm_destroy(void* comm);
+/* buf[i] <- mean over ranks of buf[i]   (n elements of dtype, in place) */
+int ptpp_allreduce_mean(void* buf, int64_t n, int dtype, void* comm, void* stream);
+/* buf <- root's buf  (initial parameter broadcast, DDP's constructor) */
+int ptpp_broadcast(void* buf, int64_t n, int dtype, int root, void* comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

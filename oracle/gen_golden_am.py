@@ -162,6 +162,44 @@ def variance_adaptor():
 
 
 @gen
+def variance_adaptor_energy():
+    """The energy branch of the same class (variance_adaptor.py:139-146, :166-172, :196-202): not used by the
+    wo_erg YAML but part of VarianceAdaptor's contract -- energy_predictor reads the frame-prior output
+    BEFORE the pitch embedding is added."""
+    _ref()
+    from promptttspp.modules.frame_prior import FramePriorNetwork
+    from promptttspp.modules.variance_adaptor import MDNPredictor, Predictor, VarianceAdaptor
+    from promptttspp.utils.model import sequence_mask
+
+    torch.manual_seed(0)
+    va = VarianceAdaptor(
+        duration_predictor=MDNPredictor(256, 1, 3, 0.5, 2, num_gaussians=4, detach=True, disable_amp=True),
+        pitch_predictor=Predictor(256, 2, 5, 0.5, 5, detach=False),
+        pitch_emb=nn.Conv1d(1, 256, 1),
+        energy_predictor=Predictor(256, 1, 3, 0.5, 2, detach=False), energy_emb=nn.Conv1d(1, 256, 1),
+        frame_prior_network=FramePriorNetwork(256, 256, 6, 17, 0.1),
+    )
+    fill_state_dict(va, seed=65, overrides=TAME, offsets=TAME_OFF)
+    va.eval()
+    plen = torch.tensor([9, 6, 2])
+    Tp = 9
+    pm = sequence_mask(plen, Tp).unsqueeze(1).long()
+    x = rnd(66, 3, 256, Tp, scale=0.5) * pm
+    dur = torch.from_numpy(np.random.default_rng(67).integers(1, 7, size=(3, 1, Tp))).float() * pm
+    flen = dur.squeeze(1).sum(-1).long()
+    Tf = int(flen.max())
+    fm = sequence_mask(flen, Tf).unsqueeze(1).float()
+    cf0 = (5.2 + 0.25 * rnd(68, 3, 1, Tf)) * fm
+    energy = (0.3 * rnd(69, 3, 1, Tf)) * fm
+    with torch.no_grad():
+        h, _, cf0p, vuvp, enp = va(x, pm, fm, dur.clone(), cf0, None, energy)
+        hi, fmi, cf0i, vuvi = va.infer_batch(x, pm, return_f0=True)
+        h1, fm1, cf01, vuv1 = va.infer(x[:1], pm[:1], return_f0=True)
+    _save("variance_adaptor_energy", x=x, plen=plen, dur=dur, flen=flen, cf0=cf0, energy=energy, h=h, cf0p=cf0p, vuvp=vuvp,
+          enp=enp, hi=hi, fmi=fmi, cf0i=cf0i, vuvi=vuvi, h1=h1, cf01=cf01, keys=_keys(va))
+
+
+@gen
 def style_encoder():
     _ref()
     from promptttspp.modules.style_encoder import StyleEncoder
@@ -410,6 +448,47 @@ def model_infer():
                 out["style_noise"] = sn
         out["phon"], out["plen"], out["mel"], out["flen_in"], out["ids"], out["am"] = phon, plen, mel, flen, ids, am
     _save("model_infer", **out)
+
+
+@gen
+def model_infer_single():
+    """The single-utterance entry points (model.py:198-262, :327-344): infer() on both style branches,
+    use_max True and False (the Categorical draw is injected), and generate_style_emb()."""
+    m = build_model("new")
+    fill_state_dict(m, seed=100, overrides=TAME, offsets=TAME_OFF)
+    m.eval()
+    phon, dur, plen, mel, cf0, vuv, energy, flen, ids, am = synth_batch(211)
+    x1, ids1, am1, mel1 = phon[:1], ids[:1], am[:1], mel[:1, :, : int(flen[0])]
+    sn = rnd(213, 1, 1, 256)
+    comp = torch.from_numpy(np.random.default_rng(214).integers(0, 10, size=(1, 256)))  # (B, C) component ids
+    out = dict(phon=x1, ids=ids1, am=am1, mel=mel1, style_noise=sn, comp=comp)
+    Cat = torch.distributions.Categorical
+    orig_sample = Cat.sample
+
+    def run(tag, noise_seed, **kw):
+        # pass 1 with throw-away noise to learn Tf (durations do not depend on the diffusion noise)
+        with injected_rng(randn_like_list=[sn] if "style_prompt" in kw else None):
+            y0 = m.infer(x1, **kw)
+        Tf = y0.shape[-1]
+        x_init = rnd(noise_seed, 1, 80, Tf)
+        steps = [rnd(noise_seed * 100 + i, 1, 80, Tf) for i in range(100)]
+        with injected_rng(randn_list=[x_init] + [steps[i] for i in reversed(range(100))],
+                          randn_like_list=[sn] if "style_prompt" in kw else None):
+            y, c0, vv = m.infer(x1, return_f0=True, **kw)
+        out[tag + "_mel"], out[tag + "_cf0"], out[tag + "_vuv"] = y, c0, vv
+
+    with torch.no_grad():
+        run("prompt_max", 215, style_prompt=(ids1, am1), use_max=True, noise_scale=0.5)
+        run("ref", 216, reference_mel=mel1)
+        Cat.sample = lambda self, *a, **k: comp.clone()
+        try:
+            run("prompt_sample", 217, style_prompt=(ids1, am1), use_max=False, noise_scale=0.7)
+        finally:
+            Cat.sample = orig_sample
+        with injected_rng(randn_like_list=[sn]):
+            pe, re_ = m.generate_style_emb((ids1, am1), mel1, use_max=True, noise_scale=0.5)
+        out["gen_prompt_emb"], out["gen_ref_emb"] = pe, re_
+    _save("model_infer_single", **out)
 
 
 @gen

@@ -387,14 +387,26 @@ def length_regulate(x, duration, phone_mask, frame_mask):
     return x @ path.to(x.dtype)
 
 
-def variance_adaptor_forward(sd, p, x, phone_mask, frame_mask, duration, log_cf0):
+def energy_predictor(sd, p, x, mask, n=2, ks=3):
+    """Optional energy head: the same Predictor class as the pitch head with one output channel
+    (variance_adaptor.py:39-67); layer count / kernel size are constructor arguments."""
+    h = predictor_layers(sd, p, x, mask, n, ks)
+    return _conv(sd, p + ".out_layer", h) * mask
+
+
+def variance_adaptor_forward(sd, p, x, phone_mask, frame_mask, duration, log_cf0, energy=None):
     """Training forward (variance_adaptor.py:126-148).  Returns
-    (x_frames, (log_pi, log_sigma, mu), log_cf0_pred, vuv_pred)."""
+    (x_frames, (log_pi, log_sigma, mu), log_cf0_pred, vuv_pred[, energy_pred])."""
     # the duration predictor sees a DETACHED input (MDNPredictor detach=True, variance_adaptor.py:82-83)
     dur_out = duration_predictor(sd, p + ".duration_predictor", x.detach(), phone_mask.to(x.dtype))
     h = length_regulate(x, duration.squeeze(1), phone_mask.to(x.dtype), frame_mask)
     h = frame_prior(sd, p + ".frame_prior_network", h, frame_mask)
     pv = pitch_predictor(sd, p + ".pitch_predictor", h, frame_mask)
+    if p + ".energy_emb.weight" in sd:
+        # energy_predictor reads x BEFORE the pitch embedding is added (variance_adaptor.py:139-146)
+        en = energy_predictor(sd, p + ".energy_predictor", h, frame_mask)
+        h = h + _conv(sd, p + ".pitch_emb", log_cf0) * frame_mask + _conv(sd, p + ".energy_emb", energy) * frame_mask
+        return h, dur_out, pv[:, 0:1], pv[:, 1:2], en
     h = h + _conv(sd, p + ".pitch_emb", log_cf0) * frame_mask
     return h, dur_out, pv[:, 0:1], pv[:, 1:2]
 
@@ -408,7 +420,10 @@ def variance_adaptor_infer_batch(sd, p, x, phone_mask_int):
     h = length_regulate(x, dur.squeeze(1), pm, fm)
     h = frame_prior(sd, p + ".frame_prior_network", h, fm)
     pv = pitch_predictor(sd, p + ".pitch_predictor", h, fm)
-    h = h + _conv(sd, p + ".pitch_emb", pv[:, 0:1]) * fm
+    emb = _conv(sd, p + ".pitch_emb", pv[:, 0:1]) * fm
+    if p + ".energy_emb.weight" in sd:
+        emb = emb + _conv(sd, p + ".energy_emb", energy_predictor(sd, p + ".energy_predictor", h, fm)) * fm
+    h = h + emb
     return h, fm, pv[:, 0:1], pv[:, 1:2], dur, flen
 
 
@@ -615,19 +630,34 @@ def model_forward(sd, batch, t, noise, variant="new", train_bn=False, loss_dec_s
     return dict(loss=loss, dec=loss_dec, dur=loss_dur, cf0=loss_cf0, vuv=loss_vuv, style=loss_style)
 
 
+def mdn_selected(log_sigma, mu, comp):
+    """(sigma, mu) of the component ``comp`` (B, D) chosen per output dimension -- what
+    mdn_sample_sigma_and_mu (mdn.py:226-257) returns once its Categorical draw is known."""
+    idx = comp[:, None, None, :]  # (B,1,1,D) over the G axis
+    return torch.exp(log_sigma.gather(2, idx).squeeze(2)), mu.gather(2, idx).squeeze(2)
+
+
+def style_from_prompt(sd, ids, am, style_noise=None, noise_scale=1.0, comp=None):
+    """prompt -> sampled style embedding (B,256,1) (model.py:185-196,218-227): normalised prompt embedding ->
+    style MDN -> most probable (use_max) or drawn (``comp``) component -> mu + sigma*noise*scale -> normalise."""
+    pe = F.normalize(prompt_encoder(sd, "prompt_encoder", ids, am), dim=1)
+    log_pi, log_sigma, mu = mdn_layer(sd, "style_mdn", pe.transpose(1, 2), 10, 256)
+    sigma, mu = mdn_most_probable(log_pi, log_sigma, mu) if comp is None else mdn_selected(log_sigma, mu, comp)
+    st = mu + sigma * (style_noise if style_noise is not None else 0.0) * noise_scale
+    return F.normalize(st, dim=-1).transpose(1, 2)
+
+
 def model_infer_batch(sd, phoneme, plen, x_init_fn, step_noise_fn, ids=None, am=None, ref_mel=None, ref_len=None,
-                      style_noise=None, noise_scale=1.0, variant="new"):
-    """infer_batch(use_max=True) (model.py:261-325).  x_init_fn(B,Tf) / step_noise_fn(B,Tf)
-    provide the injected sampler noise once Tf is known.  Returns
+                      style_noise=None, noise_scale=1.0, variant="new", comp=None):
+    """infer_batch(use_max=True) (model.py:261-325); with B = 1 and plen = [L] this is infer() (model.py:198-259:
+    all-ones masks).  ``comp``: the injected Categorical draw of use_max=False.  x_init_fn(B,Tf) /
+    step_noise_fn(B,Tf) provide the injected sampler noise once Tf is known.  Returns
     (mel (B,80,Tf), log_cf0, vuv, frame_lengths, durations)."""
     pmi = sequence_mask(plen, phoneme.shape[-1]).unsqueeze(1).to(phoneme.dtype)
     x = sd["phoneme_emb.emb.weight"][phoneme].transpose(1, 2) * pmi
     x = conformer_encoder(sd, "encoder", x.transpose(1, 2), plen, variant=variant).transpose(1, 2)
     if ids is not None:
-        pe = F.normalize(prompt_encoder(sd, "prompt_encoder", ids, am), dim=1)
-        sigma, mu = mdn_most_probable(*mdn_layer(sd, "style_mdn", pe.transpose(1, 2), 10, 256))
-        st = mu + sigma * (style_noise if style_noise is not None else 0.0) * noise_scale
-        style = F.normalize(st, dim=-1).transpose(1, 2)
+        style = style_from_prompt(sd, ids, am, style_noise, noise_scale, comp)
     else:
         style = F.normalize(style_encoder(sd, "reference_encoder", ref_mel, ref_len), dim=1)
     h, fm, cf0, vuv, dur, flen = variance_adaptor_infer_batch(sd, "variance_adaptor", x + style, pmi)

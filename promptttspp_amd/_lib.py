@@ -95,6 +95,11 @@ SIGNATURES = {
     "ptpp_btc_to_bct": (I, [P, P, I, I, I, I, P]),
     "ptpp_grad_sumsq": (I, [P, I, P, c_longlong, P, P]),
     "ptpp_adamw_step": (I, [P, I, P, c_longlong, P, P, F, F, F, F, I, F, P]),
+    "ptpp_comm_unique_id": (I, [P]),
+    "ptpp_comm_init": (I, [I, I, P, POINTER(c_void_p)]),
+    "ptpp_comm_destroy": (I, [P]),
+    "ptpp_allreduce_mean": (I, [P, I64, I, P, P]),
+    "ptpp_broadcast": (I, [P, I64, I, I, P, P]),
 }
 
 _lib = None

@@ -112,10 +112,13 @@ class VarianceAdaptor(nn.Module):
             h = self.frame_prior_network.forward_cl(h, flen)
         pv = self.pitch_predictor.cl(h, flen)  # (B,Tf,2) f32
         log_cf0, vuv = pv[..., 0], pv[..., 1]
-        h = h + self._embed_scalar(self.pitch_emb, log_cf0 if log_cf0_in is None else log_cf0_in, fmask_bt1, h.dtype)
+        # both predictors read the frame-prior output; the embeddings are added together afterwards
+        # (variance_adaptor.py:139-146: energy_predictor(x) runs BEFORE x = x + pitch_emb + energy_emb)
         energy = None
         if self.energy_predictor is not None:
             energy = self.energy_predictor.cl(h, flen)[..., 0]
+        h = h + self._embed_scalar(self.pitch_emb, log_cf0 if log_cf0_in is None else log_cf0_in, fmask_bt1, h.dtype)
+        if self.energy_predictor is not None:
             h = h + self._embed_scalar(self.energy_emb, energy if energy_in is None else energy_in, fmask_bt1, h.dtype)
         return h, log_cf0, vuv, energy
 

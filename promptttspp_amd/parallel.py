@@ -15,40 +15,100 @@ views of the flat buffer (functional.enable_direct_grads): no per-parameter zero
 temporary or ``grad +=`` launch.  Autograd's post-accumulate hooks do not fire for
 gradients written that way, so functional notifies ``_hook`` itself.
 """
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
 
+_ALIGN = 64  # bucket lengths are multiples of this many floats, so a bucket splits evenly over <= 64 ranks
+
+
+class NativeComm:
+    """The C ABI's own RCCL communicator (include/ptpp.h: ptpp_comm_init / ptpp_allreduce_mean /
+    ptpp_broadcast -- SURVEY section 8b): rank 0 draws the unique id, the other ranks receive it through the
+    torch.distributed store of the already initialised default group, every rank joins.  Selected with
+    ``PTPP_DP_BACKEND=native`` (default: torch.distributed's collectives, the same RCCL underneath)."""
+
+    def __init__(self, rank, world, group=None):
+        from . import _lib
+
+        self.lib, self.rank, self.world = _lib.load(), rank, world
+        idbuf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(self.lib.ptpp_comm_unique_id(idbuf), "ptpp_comm_unique_id")
+        if world > 1:
+            box = [idbuf.raw if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            idbuf = ctypes.create_string_buffer(box[0], 128)
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.ptpp_comm_init(rank, world, idbuf, ctypes.byref(self.handle)), "ptpp_comm_init")
+
+    def allreduce_mean(self, t, stream):
+        from . import _lib, ops
+
+        _lib.check(self.lib.ptpp_allreduce_mean(t.data_ptr(), t.numel(), ops.dtype_code(t.dtype), self.handle, stream),
+                   "ptpp_allreduce_mean")
+
+    def broadcast(self, t, src, stream):
+        from . import _lib, ops
+
+        _lib.check(self.lib.ptpp_broadcast(t.data_ptr(), t.numel(), ops.dtype_code(t.dtype), src, self.handle, stream),
+                   "ptpp_broadcast")
+
+    def close(self):
+        if self.handle:
+            self.lib.ptpp_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
 
 class FlatGradReducer:
-    def __init__(self, params, bucket_elems=32 * 1024 * 1024, process_group=None, direct=True):
+    """Knobs for the first multi-GPU sweeps (environment, so the driver's bench command line stays fixed):
+    ``PTPP_DP_BUCKET_MB`` (bucket size, default 128), ``PTPP_DP_ALGO`` = ``allreduce`` (default) | ``rs_ag``
+    (reduce-scatter + all-gather of each bucket, in place), ``PTPP_DP_BACKEND`` = ``torch`` (default) | ``native``
+    (the C ABI's RCCL communicator), ``PTPP_DP_BROADCAST_BUFFERS=1`` (DDP's per-forward broadcast of the
+    BatchNorm running statistics, trainers/tts.py:117 ``broadcast_buffers=True`` default; off by default: each
+    rank keeps its own statistics and rank 0's are checkpointed -- DESIGN.md section 6)."""
+
+    def __init__(self, params, bucket_elems=None, process_group=None, direct=True, algo=None, backend=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        if bucket_elems is None:
+            bucket_elems = int(float(os.environ.get("PTPP_DP_BUCKET_MB", "128")) * (1 << 20)) // 4
+        self.algo = algo or os.environ.get("PTPP_DP_ALGO", "allreduce")
+        assert self.algo in ("allreduce", "rs_ag"), self.algo
+        self.backend = backend or os.environ.get("PTPP_DP_BACKEND", "torch")
+        assert self.backend in ("torch", "native"), self.backend
+        self.native = None
         # PTPP_DP_FORCE_COLLECTIVES=1 (diagnostics): run the multi-rank machinery -- hooks, bucket all-reduces,
         # finish() -- at world size 1 too, e.g. one rank over RCCL to look at stream interplay on a 1-GPU box
         self.collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
                                              and bool(os.environ.get("PTPP_DP_FORCE_COLLECTIVES")))
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         # Backward produces gradients roughly in reverse registration order: lay the
-        # buffer out in that order so buckets complete front to back.
+        # buffer out in that order so buckets complete front to back.  Every bucket ends on a multiple of
+        # _ALIGN floats (a few zero floats of padding) so that it splits evenly over the ranks (rs_ag).
         self.buckets = []  # [start, end, n_params]
         off, start, count = 0, 0, 0
         self._bucket_of = {}
+        slots = []
         for p in reversed(self.params):
             n = p.numel()
-            p.grad = self.flat[off : off + n].view_as(p)
+            slots.append((p, off, n))
             self._bucket_of[id(p)] = len(self.buckets)
             off += n
             count += 1
             if off - start >= bucket_elems:
+                off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
                 self.buckets.append([start, off, count])
                 start, count = off, 0
         if count:
+            off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
             self.buckets.append([start, off, count])
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        for p, o, n in slots:
+            p.grad = self.flat[o : o + n].view_as(p)
         self._pending = [b[2] for b in self.buckets]
         self._works = []
         self._launched = [False] * len(self.buckets)
@@ -57,6 +117,9 @@ class FlatGradReducer:
         if self.collective:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
+            if self.backend == "native":
+                assert dev.type == "cuda", "the native RCCL communicator needs device tensors"
+                self.native = NativeComm(dist.get_rank(process_group), self.world, process_group)
         if direct and dev.type == "cuda":
             from . import functional as PF
 
@@ -71,7 +134,7 @@ class FlatGradReducer:
             # gloo runs stay on one stream (PTPP_FORCE_ASYNC_WGRAD=1 overrides).
             backend = dist.get_backend(process_group) if self.collective else None
             PF.enable_direct_grads(True, notify=self._hook if self.collective else None,
-                                   async_wgrad=(not self.collective or backend == "nccl"
+                                   async_wgrad=(not self.collective or backend == "nccl" or self.native is not None
                                                 or bool(os.environ.get("PTPP_FORCE_ASYNC_WGRAD"))))
 
     # -- parameter broadcast (DDP constructor semantics) ------------------------------
@@ -80,7 +143,49 @@ class FlatGradReducer:
             return
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t, src, group=self.group)
+                self._bcast(t, src)
+
+    def _bcast(self, t, src):
+        if self.native is not None and t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous():
+            from . import ops
+
+            self.native.broadcast(t, src, ops._stream())
+        else:
+            dist.broadcast(t, src, group=self.group)
+
+    def broadcast_buffers(self, module, src=0):
+        """DDP's ``broadcast_buffers=True`` (the reference's default, trainers/tts.py:117): before a forward every
+        rank takes rank 0's BatchNorm running statistics.  Opt-in (``PTPP_DP_BROADCAST_BUFFERS=1``): it only changes
+        what eval-mode BatchNorm would see on ranks other than 0, which never evaluate or checkpoint.  All
+        statistics travel as ONE concatenated tensor (one collective per step instead of ~40)."""
+        if self.world == 1:
+            return
+        bufs = [b for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
+                for b in (m.running_mean, m.running_var) if b is not None]
+        if not bufs:
+            return
+        with torch.no_grad():
+            cat = torch.cat([b.reshape(-1).float() for b in bufs])
+            self._bcast(cat, src)
+            off = 0
+            for b in bufs:
+                b.copy_(cat[off : off + b.numel()].view_as(b))
+                off += b.numel()
+
+    def _reduce(self, t):
+        """Sum (torch backend; finish() divides) or mean (native backend) of ``t`` over the ranks, in place, issued
+        on the current stream; returns a Work handle or None."""
+        if self.native is not None:
+            self.native.allreduce_mean(t, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            return None
+        if self.algo == "rs_ag" and self.world > 1 and t.numel() % self.world == 0 and t.is_cuda and \
+                dist.get_backend(self.group) == "nccl":  # (gloo has no reduce-scatter)
+            r = dist.get_rank(self.group)
+            c = t.numel() // self.world
+            mine = t[r * c : (r + 1) * c]
+            dist.reduce_scatter_tensor(mine, t, op=dist.ReduceOp.SUM, group=self.group)
+            return dist.all_gather_into_tensor(t, mine, group=self.group, async_op=True)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _launch(self, bi):
         a, b, _ = self.buckets[bi]
@@ -96,9 +201,11 @@ class FlatGradReducer:
             # weight gradients run on the side stream: issue the collective FROM that stream (after it has
             # caught up with this one), so that the main stream -- the critical path -- never waits for it
             with torch.cuda.stream(side):
-                self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                w = self._reduce(self.flat[a:b])
         else:
-            self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            w = self._reduce(self.flat[a:b])
+        if w is not None:
+            self._works.append(w)
 
     def _hook(self, p):
         # A parameter can be reported twice in one step: by functional's direct-accumulation path when
@@ -142,4 +249,9 @@ class FlatGradReducer:
         self._next = len(self.buckets)
         for w in self._works:
             w.wait()
-        self.flat.mul_(1.0 / self.world)
+        if self.native is None:
+            self.flat.mul_(1.0 / self.world)
+        elif self.flat.is_cuda:
+            from . import functional as PF
+
+            PF.sync_wgrad_stream()  # the native collectives are plain stream work on the side stream

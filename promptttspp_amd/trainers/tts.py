@@ -199,6 +199,7 @@ class TTSTrainer:
         if fused:
             optimizer.stable_grads = True      # ... for the whole run: FusedAdamW may skip its per-step pointer scan
         reducer.broadcast_parameters(model)    # DDP constructor semantics
+        bcast_buffers = world > 1 and bool(os.environ.get("PTPP_DP_BROADCAST_BUFFERS"))
 
         train_dl, valid_dl, sampler = self._loaders(cfg, rank, world)
         global_step = (start_epoch - 1) * len(train_dl) + 1
@@ -214,6 +215,8 @@ class TTSTrainer:
             for batch in train_dl:
                 batch = self._to_device(batch, device)
                 reducer.zero_grad()
+                if bcast_buffers:
+                    reducer.broadcast_buffers(model)  # DDP(broadcast_buffers=True), trainers/tts.py:117
                 loss_dict = model(batch)
                 with torch.autograd.set_multithreading_enabled(False):  # Python-heavy backward: stay on this thread
                     loss_dict["loss"].backward()

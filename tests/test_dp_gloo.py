@@ -42,7 +42,11 @@ def _worker(rank, world, port, out):
             red.finish()
         if rank == 0:
             # plain numpy: torch tensors would travel as shared-memory handles that die with this process
-            out.put({"flat": red.flat.numpy().copy(), "params": [p.detach().numpy().copy() for p in model.parameters()],
+            # (the flat buffer pads every bucket to a multiple of 64 floats: collect the gradient views, in its order)
+            flat = torch.cat([p.grad.reshape(-1) for p in reversed(list(model.parameters()))])
+            assert all(p.grad.data_ptr() >= red.flat.data_ptr() for p in model.parameters())
+            assert all((b - a) % 64 == 0 for a, b, _ in red.buckets)
+            out.put({"flat": flat.numpy().copy(), "params": [p.detach().numpy().copy() for p in model.parameters()],
                      "x": x.numpy().copy(), "y": y.numpy().copy()})
     finally:
         dist.barrier()

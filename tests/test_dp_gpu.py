@@ -117,6 +117,25 @@ def _worker(rank, world, port):
             if float((a - b_).abs().max()) > 1e-3 * scale + 1e-6:
                 bad.append((i, tuple(a.shape), scale, float((a - b_).abs().max())))
         assert not bad, bad[:5]
+
+        # one optimiser step on the exchanged gradients: every rank must hold bit-identical parameters afterwards
+        # (DDP's invariant, trainers/tts.py:117,206-211), and the BatchNorm statistics after the opt-in buffer
+        # broadcast must be rank 0's
+        from promptttspp_amd.optim import FusedAdamW
+
+        for p, gdp in zip(params, dp):
+            p.grad = gdp
+        FusedAdamW(params, lr=1e-3, max_grad_norm=1.0).step()
+        red.broadcast_buffers(model)
+        torch.cuda.synchronize()
+        sig = torch.stack([p.detach().double().sum() for p in params] +
+                          [b.detach().double().sum() for b in model.buffers() if b.is_floating_point()]).cpu()
+        probe = torch.cat([p.detach().flatten()[:64].float() for p in params]).cpu()
+        sigs, probes = [torch.zeros_like(sig) for _ in range(world)], [torch.zeros_like(probe) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        dist.all_gather(probes, probe)
+        for r in range(1, world):
+            assert torch.equal(sigs[0], sigs[r]) and torch.equal(probes[0], probes[r]), f"rank {r} diverged from rank 0"
     finally:
         dist.barrier()
         dist.destroy_process_group()

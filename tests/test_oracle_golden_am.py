@@ -3,6 +3,7 @@ reference (oracle/gen_golden_am.py)."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 from conftest import key_shapes, load_golden, rel_err
 
 from oracle import ref_torch as R
@@ -81,6 +82,23 @@ def test_variance_adaptor():
     assert torch.equal(dur, g["duri"])  # integer durations: bit exact
     assert torch.equal(fmi, g["fmi"])
     assert rel_err(hi, g["hi"]) < 2e-5 and rel_err(cf0i, g["cf0i"]) < 2e-5 and rel_err(vuvi, g["vuvi"]) < 2e-5
+
+
+def test_variance_adaptor_energy_branch():
+    """energy_predictor reads the frame-prior output before pitch_emb is added (variance_adaptor.py:139-146)."""
+    g = load_golden("variance_adaptor_energy")
+    sd = synth_sd(key_shapes(g["keys"]), 65, TAME, TAME_OFF, prefix="va.")
+    Tp = g["x"].shape[-1]
+    pm = R.sequence_mask(g["plen"], Tp).unsqueeze(1)
+    fm = R.sequence_mask(g["flen"], g["cf0"].shape[-1]).unsqueeze(1).float()
+    h, _, cf0p, vuvp, enp = R.variance_adaptor_forward(sd, "va", g["x"], pm, fm, g["dur"], g["cf0"], g["energy"])
+    assert rel_err(h, g["h"]) < 2e-5 and rel_err(enp, g["enp"]) < 2e-5
+    assert rel_err(cf0p, g["cf0p"]) < 2e-5 and rel_err(vuvp, g["vuvp"]) < 2e-5
+    hi, fmi, cf0i, vuvi, _, _ = R.variance_adaptor_infer_batch(sd, "va", g["x"], pm.long())
+    assert torch.equal(fmi, g["fmi"])
+    assert rel_err(hi, g["hi"]) < 2e-5 and rel_err(cf0i, g["cf0i"]) < 2e-5
+    h1, _, cf01, _, _, _ = R.variance_adaptor_infer_batch(sd, "va", g["x"][:1], pm[:1].long())
+    assert rel_err(h1, g["h1"]) < 2e-5 and rel_err(cf01, g["cf01"]) < 2e-5
 
 
 def test_style_encoder():
@@ -173,6 +191,37 @@ def test_model_infer_batch_integer_and_mel():
                                                    am=g["am"], style_noise=g["style_noise"], noise_scale=0.5)
     assert torch.equal(dur, g["prompt_dur"]) and torch.equal(flen, g["prompt_flen"])
     assert rel_err(mel, g["prompt_mel"]) < 2e-4
+
+
+def single_noise(seed, Tf):
+    x0 = torch.from_numpy(np.random.default_rng(seed).standard_normal((1, 80, Tf)).astype(np.float32))
+    steps = [torch.from_numpy(np.random.default_rng(seed * 100 + i).standard_normal((1, 80, Tf)).astype(np.float32))
+             for i in range(100)]
+    return x0, steps
+
+
+def test_model_infer_single_utterance():
+    """infer() (model.py:198-259) on both style branches, use_max True / False (injected draw), and
+    generate_style_emb (model.py:327-344)."""
+    g = load_golden("model_infer_single")
+    sd = _model_sd(key_shapes(load_golden("model_forward")["keys"]))
+    plen = torch.tensor([g["phon"].shape[1]])
+    cases = [("prompt_max", 215, dict(ids=g["ids"], am=g["am"], style_noise=g["style_noise"], noise_scale=0.5)),
+             ("ref", 216, dict(ref_mel=g["mel"], ref_len=torch.tensor([g["mel"].shape[-1]]))),
+             ("prompt_sample", 217, dict(ids=g["ids"], am=g["am"], style_noise=g["style_noise"], noise_scale=0.7,
+                                         comp=g["comp"]))]
+    for tag, seed, kw in cases:
+        Tf = g[tag + "_mel"].shape[-1]
+        x0, steps = single_noise(seed, Tf)
+        mel, cf0, vuv, flen, dur = R.model_infer_batch(sd, g["phon"], plen, lambda b, t: x0, lambda b, t: steps, **kw)
+        assert int(flen[0]) == Tf, tag                       # integer frame count: exact
+        assert rel_err(mel, g[tag + "_mel"]) < 2e-4, tag
+        assert rel_err(cf0, g[tag + "_cf0"]) < 2e-5 and rel_err(vuv, g[tag + "_vuv"]) < 2e-5, tag
+    pe = R.style_from_prompt(sd, g["ids"], g["am"], g["style_noise"], 0.5)
+    # generate_style_emb normalises the sampled embedding once more over dim 1 (model.py:337-338): idempotent
+    assert rel_err(F.normalize(pe, dim=1), g["gen_prompt_emb"]) < 2e-5
+    re_ = F.normalize(R.style_encoder(sd, "reference_encoder", g["mel"], torch.tensor([g["mel"].shape[-1]])), dim=1)
+    assert rel_err(re_, g["gen_ref_emb"]) < 2e-5
 
 
 def test_nsf_source_and_f0_vocoder():
