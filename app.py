@@ -24,8 +24,11 @@ CONF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "egs", "proposed
 def load_model(model_cfg, model_ckpt_path, vocoder_cfg, vocoder_ckpt_path, device=None):
     """reference app.py:28-40.  A checkpoint path of None / "" means random initialisation (tests, benchmarks);
     a path that is given but does not exist raises, as ``torch.load`` does in the reference."""
+    from promptttspp_amd.modules.prompt_encoder import allow_random_bert
+
     device = device or torch.device("cuda")
-    model = instantiate(model_cfg)
+    with allow_random_bert():  # the checkpoint holds prompt_encoder.bert.model.* (or the caller asked for random weights)
+        model = instantiate(model_cfg)
     if model_ckpt_path:
         if not os.path.exists(str(model_ckpt_path)):
             raise FileNotFoundError(f"model_ckpt_path={model_ckpt_path!r} does not exist")

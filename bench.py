@@ -56,8 +56,11 @@ def build_model(dev):
     from promptttspp_amd import hydra_lite as H
 
     cfg = H.load_node(os.path.join(ROOT, "egs", "proposed", "bin", "conf", "model", "prompttts_mdn_v2_wo_erg_final.yaml"))
+    from promptttspp_amd.modules.prompt_encoder import allow_random_bert
+
     torch.manual_seed(1234)  # identical random-init weights on every rank
-    return H.instantiate(cfg).to(dev)
+    with allow_random_bert():  # random-init weights of the named architecture (no network for checkpoints)
+        return H.instantiate(cfg).to(dev)
 
 
 def make_batches(rank, world, n, max_tokens, dev):

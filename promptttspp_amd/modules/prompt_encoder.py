@@ -8,12 +8,15 @@ the adaptor MLP goes through the HIP GEMM.  (A BERT encoder on the package's own
 GEMM / LayerNorm / plain-attention kernels is the planned replacement:
 ``ptpp_attention_fwd`` already has the PLAIN variant for it.)
 
-Offline behaviour: ``from_pretrained`` needs network/cache; when it is not
-available the wrapper builds the architecture from ``BertConfig()`` (weights then
-come from the model checkpoint, whose state dict contains
-``prompt_encoder.bert.model.*``) and accepts pre-tokenised prompts
+Pretrained weights: like the reference, ``BertModel.from_pretrained(name)`` (local cache first, then the
+hub).  When neither is reachable the constructor RAISES -- training the prompt encoder on 11 frozen layers of
+random weights would be silently useless -- unless random initialisation is explicitly allowed
+(``PTPP_ALLOW_RANDOM_BERT=1`` or ``allow_random_init=True``): tests, benchmarks, and runs whose model
+checkpoint supplies ``prompt_encoder.bert.model.*`` anyway (the trainer / app / synthesize drivers set it when a
+checkpoint path is configured).  Without a vocabulary the wrapper accepts pre-tokenised prompts
 ``(input_ids, attention_mask)`` in place of ``List[str]``.
 """
+import os
 import warnings
 from typing import List
 
@@ -24,19 +27,49 @@ from .. import functional as PF
 from ..config import compute_dtype
 
 
+class allow_random_bert:
+    """``with allow_random_bert():`` -- constructors inside may fall back to a randomly initialised BERT (the caller
+    loads a checkpoint that holds ``prompt_encoder.bert.model.*``, or asked for a random model explicitly)."""
+
+    def __enter__(self):
+        self.old = os.environ.get("PTPP_ALLOW_RANDOM_BERT")
+        os.environ["PTPP_ALLOW_RANDOM_BERT"] = "1"
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop("PTPP_ALLOW_RANDOM_BERT", None)
+        else:
+            os.environ["PTPP_ALLOW_RANDOM_BERT"] = self.old
+        return False
+
+
 class BertWrapper(nn.Module):
-    def __init__(self, class_name="bert-base-uncased"):
+    def __init__(self, class_name="bert-base-uncased", allow_random_init=None):
         super().__init__()
         from transformers import BertConfig, BertModel, BertTokenizer
 
+        def pretrained(cls):
+            try:
+                return cls.from_pretrained(class_name, local_files_only=True)  # the local cache, no network round trip
+            except Exception:
+                return cls.from_pretrained(class_name)  # the hub, like the reference (prompt_encoder.py:25-26)
+
         try:
-            self.model = BertModel.from_pretrained(class_name, local_files_only=True)
-        except Exception as e:  # offline box: architecture only
+            self.model = pretrained(BertModel)
+        except Exception as e:
+            if allow_random_init is None:
+                allow_random_init = os.environ.get("PTPP_ALLOW_RANDOM_BERT", "") not in ("", "0")
+            if not allow_random_init:
+                raise RuntimeError(
+                    f"BertModel.from_pretrained({class_name!r}) failed ({type(e).__name__}: {e}) and random "
+                    "initialisation of the frozen BERT encoder was not allowed.  Provide the pretrained weights (HF "
+                    "cache / network), or -- when a model checkpoint will supply prompt_encoder.bert.model.* -- set "
+                    "PTPP_ALLOW_RANDOM_BERT=1.") from e
             warnings.warn(f"BertModel.from_pretrained({class_name!r}) unavailable ({type(e).__name__}); "
-                          "building bert-base from BertConfig() -- load weights via the model checkpoint")
+                          "building bert-base from BertConfig() -- weights must come from the model checkpoint")
             self.model = BertModel(BertConfig())
         try:
-            self.tokenizer = BertTokenizer.from_pretrained(class_name, local_files_only=True)
+            self.tokenizer = pretrained(BertTokenizer)
             if len(self.tokenizer) < 1000:  # transformers may return a stub vocabulary offline (SURVEY F12)
                 self.tokenizer = None
         except Exception:

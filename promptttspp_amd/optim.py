@@ -111,6 +111,25 @@ class FusedAdamW(torch.optim.Optimizer):
         PF.repack_all(bumped=self._bump_list(live[0][0], live[0][1]) if len(live) == 1 and self.stable_grads else None)
         return loss
 
+    # -- checkpoints interchangeable with torch.optim.AdamW (the reference's optimiser) in both directions: torch keeps
+    # a per-parameter ``state[p]["step"]`` tensor, this class one counter per group -----------------------------------
+    def state_dict(self):
+        sd = super().state_dict()
+        for g in sd["param_groups"]:
+            step = float(g.get("step", 0))
+            for pid in g["params"]:
+                if pid in sd["state"]:
+                    sd["state"][pid] = dict(sd["state"][pid], step=torch.tensor(step))
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for g in self.param_groups:
+            steps = [float(self.state[p].pop("step")) for p in g["params"] if "step" in self.state.get(p, {})]
+            if steps and not g.get("step"):
+                g["step"] = int(max(steps))  # a torch.optim.AdamW checkpoint: continue its bias correction
+        self._tables.clear()  # the moment tensors were replaced: rebuild the pointer tables
+
     def grad_norm(self):
         """sqrt of the last computed sum of squares (device tensor; no sync)."""
         return self._sumsq.sum().sqrt() if self._sumsq is not None else None

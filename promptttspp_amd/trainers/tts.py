@@ -166,7 +166,14 @@ class TTSTrainer:
                 del slab
             except RuntimeError:  # smaller device / shared GPU: carry on without the reservation
                 pass
-        model = instantiate(cfg.model).to(device)
+        # a run that restores a checkpoint gets the BERT weights from it; generated data is a benchmark / smoke run
+        from ..modules.prompt_encoder import allow_random_bert
+        import contextlib
+
+        restores = _get(cfg, "ckpt_path") is not None or _get(cfg, "pretrained") is not None
+        synthetic = "synthetic" in str(_get(cfg.dataset.train, "_target_", ""))
+        with (allow_random_bert() if restores or synthetic else contextlib.nullcontext()):
+            model = instantiate(cfg.model).to(device)
         if rank == 0:
             logger.info(f"model parameter : {sum(p.numel() for p in model.parameters())}")
         params = [p for p in model.parameters() if p.requires_grad]

@@ -46,3 +46,46 @@ def test_bad_arguments_fail_loudly_without_gpu():
     a = _lib.ConvArgs()
     assert _lib.load().ptpp_conv1d_fwd(ctypes.byref(a), None) == -1
     assert b"null" in _lib.load().ptpp_last_error()
+
+
+def test_bert_wrapper_refuses_silent_random_init(monkeypatch):
+    """Offline and without the opt-in, the prompt encoder must not come up with 11 frozen random BERT layers."""
+    import pytest
+
+    from promptttspp_amd.modules.prompt_encoder import BertWrapper, allow_random_bert
+
+    monkeypatch.delenv("PTPP_ALLOW_RANDOM_BERT", raising=False)
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    with pytest.raises(RuntimeError, match="PTPP_ALLOW_RANDOM_BERT"):
+        BertWrapper("bert-base-uncased")
+    with allow_random_bert():
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert BertWrapper("bert-base-uncased").model.config.hidden_size == 768
+    import os
+
+    assert "PTPP_ALLOW_RANDOM_BERT" not in os.environ
+
+
+def test_fused_adamw_state_dict_round_trips_with_torch_adamw():
+    """Checkpoint interchange with the reference's torch.optim.AdamW (host logic only: no step is taken)."""
+    import torch
+
+    from promptttspp_amd.optim import FusedAdamW
+
+    ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))]
+    ref = torch.optim.AdamW(ps, lr=1e-3)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    for _ in range(3):
+        ref.step()
+    fused = FusedAdamW(ps, lr=1e-3)
+    fused.load_state_dict(ref.state_dict())
+    assert fused.param_groups[0]["step"] == 3                      # bias correction continues at step 3
+    assert torch.equal(fused.state[ps[0]]["exp_avg"], ref.state[ps[0]]["exp_avg"])
+    back = torch.optim.AdamW(ps, lr=1e-3)
+    back.load_state_dict(fused.state_dict())                       # and the other direction
+    assert float(back.state[ps[1]]["step"]) == 3.0
+    back.step()                                                    # would raise KeyError('step') without the per-param entry
