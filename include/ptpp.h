@@ -356,6 +356,33 @@ int ptpp_aa_snake_fwd(const void* x, void* y, const float* log_alpha,
                       const float* filt_up, const float* filt_down, int B,
                       int T, int C, int dtype, void* stream);
 
+/* One whole AMP layer of BigVGAN (vocoders/bigvgan.py:42-47 with layers/activations.py:22-44) in ONE kernel:
+ *   y = res_scale * x + out_scale * (conv2(snake2(conv1(snake1(x)))) + b2) [+ res2]
+ * x, y, res2: (B, T, C) channels-last `dtype`, contiguous, all utterances of length T; conv1: ks taps, dilation
+ * dil, padding dil*(ks-1)/2; conv2: ks taps, padding (ks-1)/2; w1p / w2p: ptpp_pack_conv_weight(mode 0)
+ * operands of the (weight-norm folded) (C, C, ks) weights; b1 / b2: (C) f32; log_alpha*: (C) f32 (the Snake
+ * parameter in the log domain); up* / dn*: the 12-tap anti-alias filters of act1 / act2 (HOST values, by value).
+ * res2 (nullable): the running mean of the AMP blocks (bigvgan.py:124-128).  The x tile and its halo stay in
+ * LDS: x is read once and y written once (9 tensor passes when the four stages are separate launches).
+ * Built for C in {32, 64}: ptpp_amp_layer_supported(C, dtype) != 0; otherwise PTPP_ENOTSUP. */
+typedef struct {
+  const void* x;
+  void* y;
+  const void* res2;
+  const void* w1p;
+  const void* w2p;
+  const float* b1;
+  const float* b2;
+  const float* log_alpha1;
+  const float* log_alpha2;
+  float up1[12], dn1[12], up2[12], dn2[12];
+  int32_t B, T, C, ks, dil;
+  float out_scale, res_scale;
+  int32_t dtype;
+} ptpp_amp_layer_args;
+int ptpp_amp_layer_supported(int C, int dtype);
+int ptpp_amp_layer_fwd(const ptpp_amp_layer_args* a, void* stream);
+
 /* y = (a + b + c) * scale  (b, c nullable) */
 int ptpp_add3_scale(const void* a, const void* b, const void* c, void* y,
                     float scale, int64_t n, int dtype, void* stream);

@@ -49,6 +49,15 @@ class ConvArgs(Structure):
     ]
 
 
+class AmpLayerArgs(Structure):
+    """Mirror of ``ptpp_amp_layer_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("x", "y", "res2", "w1p", "w2p", "b1", "b2", "log_alpha1", "log_alpha2")] + \
+               [(n, c_float * 12) for n in ("up1", "dn1", "up2", "dn2")] + \
+               [(n, c_int32) for n in ("B", "T", "C", "ks", "dil")] + \
+               [("out_scale", c_float), ("res_scale", c_float), ("dtype", c_int32)]
+
+
 P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/ptpp.h declares.
@@ -89,6 +98,8 @@ SIGNATURES = {
     "ptpp_gru_gate_fwd": (I, [P, I64, P, P, P, I, P, I, I, P]),
     "ptpp_gru_gate_bwd": (I, [P, I64, P, P, P, I, P, P, I64, P, P, I, I, P]),
     "ptpp_aa_snake_fwd": (I, [P, P, P, POINTER(c_float), POINTER(c_float), I, I, I, I, P]),
+    "ptpp_amp_layer_supported": (I, [I, I]),
+    "ptpp_amp_layer_fwd": (I, [POINTER(AmpLayerArgs), P]),
     "ptpp_add3_scale": (I, [P, P, P, P, F, I64, I, P]),
     "ptpp_conv_post_tanh": (I, [P, P, F, P, I, I, I, I, I, P]),
     "ptpp_bct_to_btc": (I, [P, P, I, I, I, I, P]),

@@ -458,6 +458,32 @@ def aa_snake(x, log_alpha, taps_up, taps_down, out=None):
     return y
 
 
+def amp_layer_supported(C, dtype):
+    return bool(_lib.load().ptpp_amp_layer_supported(int(C), dtype_code(dtype)))
+
+
+def amp_layer(x, w1p, b1, w2p, b2, log_alpha1, log_alpha2, taps1, taps2, ks, dil, res2=None, out_scale=1.0,
+              res_scale=1.0, out=None):
+    """One fused AMP layer (ptpp_amp_layer_fwd): x (B,T,C) -> res_scale*x + out_scale*(conv2(act2(conv1(act1(x))))
+    + b2) [+ res2].  taps1 / taps2: (up, down) ctypes float[12] pairs of act1 / act2 (``_taps``)."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dim() == 3
+    B, T, C = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    a = _lib.AmpLayerArgs()
+    a.x, a.y, a.res2 = x.data_ptr(), y.data_ptr(), _ptr(res2)
+    a.w1p, a.w2p, a.b1, a.b2 = w1p.data_ptr(), w2p.data_ptr(), b1.data_ptr(), b2.data_ptr()
+    a.log_alpha1, a.log_alpha2 = log_alpha1.data_ptr(), log_alpha2.data_ptr()
+    a.up1, a.dn1 = taps1
+    a.up2, a.dn2 = taps2
+    a.B, a.T, a.C, a.ks, a.dil = B, T, C, int(ks), int(dil)
+    a.out_scale, a.res_scale, a.dtype = float(out_scale), float(res_scale), dtype_code(x.dtype)
+    if res2 is not None:
+        assert res2.is_contiguous() and res2.shape == x.shape and res2.dtype == x.dtype
+    check(_lib.load().ptpp_amp_layer_fwd(ctypes.byref(a), _stream()), "ptpp_amp_layer_fwd")
+    return y
+
+
 def add3_scale(a, b, c, scale):
     _need_gpu(a)
     y = torch.empty_like(a)

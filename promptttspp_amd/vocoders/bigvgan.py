@@ -15,7 +15,10 @@ unchanged.  The forward pass is re-designed for MI355X:
   producing u*Cout channels per input frame -- in channels-last memory
   (B, T, u*Cout) IS (B, u*T, Cout), so the same GEMM kernel does the upsampling
   with no scatter / col2im;
-* each anti-aliased Snake is one fused streaming kernel; conv_post + tanh is one.
+* each anti-aliased Snake is one fused streaming kernel; conv_post + tanh is one;
+* in the two narrow stages (C = 64, 32: 74 % of the activation traffic, HBM-bound) a WHOLE AMP layer --
+  Snake, dilated conv, Snake, conv, residual, running block mean -- is ONE kernel on an LDS-resident tile
+  (``ptpp_amp_layer_fwd``): x read once, y written once, instead of 9 tensor passes.
 """
 import torch
 import torch.nn as nn
@@ -129,7 +132,8 @@ class BigVGAN(nn.Module):
         self.compute_dtype = torch.bfloat16
         self._packed = None
         self._packed_key = None
-        self.parallel_blocks = True  # the 3 AMP blocks of a stage on 3 streams
+        self.parallel_blocks = True  # the 3 AMP blocks of a stage on 3 streams (stages without the fused layer kernel)
+        self.fuse_amp_layers = True  # one kernel per AMP layer where ptpp_amp_layer_fwd is built (C = 32, 64)
         self._streams = None
 
     # -- drop-in helpers ------------------------------------------------------
@@ -151,7 +155,7 @@ class BigVGAN(nn.Module):
 
     # -- weight cache -----------------------------------------------------------
     def _weights_key(self):
-        return (self.compute_dtype,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.compute_dtype, self.fuse_amp_layers) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     @torch.no_grad()
     def _prepare(self):
@@ -175,7 +179,13 @@ class BigVGAN(nn.Module):
                 for l in blk.layers:
                     c1 = _PackedConv(folded_weight(l.conv1), l.conv1.bias, l.conv1.dilation[0], l.conv1.padding[0], dt)
                     c2 = _PackedConv(folded_weight(l.conv2), l.conv2.bias, 1, l.conv2.padding[0], dt)
-                    layers.append((l.act1, c1, l.act2, c2))
+                    fused = None
+                    if self.fuse_amp_layers and c1.bias is not None and c2.bias is not None and c1.ks == c2.ks and \
+                            c1.pad == c1.dil * (c1.ks - 1) // 2 and c2.pad == (c2.ks - 1) // 2 and \
+                            ops.amp_layer_supported(c1.cout, dt):
+                        fused = (l.act1.act.alpha.detach().reshape(-1).float().contiguous(),
+                                 l.act2.act.alpha.detach().reshape(-1).float().contiguous(), l.act1.taps(), l.act2.taps())
+                    layers.append((l.act1, c1, l.act2, c2, fused))
                 blocks.append(layers)
             pk["mrfs"].append(blocks)
         w = folded_weight(self.conv_post).detach().float()  # (1, C, ks)
@@ -202,13 +212,16 @@ class BigVGAN(nn.Module):
             h = self._conv(h, up).view(B, T * u, up.cout // u)
             if source_hook is not None:
                 h = source_hook(s, h)
+            if all(l[4] is not None for blk in blocks for l in blk):
+                h = self._mrf_fused(h.contiguous(), blocks, inv)
+                continue
             if self.parallel_blocks and h.is_cuda and len(blocks) == 3 and not torch.cuda.is_current_stream_capturing():
                 h = self._mrf_parallel(h, blocks, inv)
                 continue
             acc = None
             for layers in blocks:
                 xb = h
-                for li, (act1, c1, act2, c2) in enumerate(layers):
+                for li, (act1, c1, act2, c2, _) in enumerate(layers):
                     a = act1.forward_cl(xb)
                     a = self._conv(a, c1)
                     a = act2.forward_cl(a)
@@ -218,6 +231,21 @@ class BigVGAN(nn.Module):
                         acc = self._conv(a, c2, res=xb, res_scale=inv, out_scale=inv, res2=acc)
             h = acc
         return h, pk
+
+    @staticmethod
+    def _mrf_fused(h, blocks, inv):
+        """One kernel per AMP layer (ptpp_amp_layer_fwd); the last layer of each block also folds that block's share
+        of the mean over the blocks (bigvgan.py:124-128) into its epilogue: acc_k = acc_{k-1} + (x_k + conv2(..)) / n."""
+        acc = None
+        for layers in blocks:
+            xb = h
+            for li, (_, c1, _, c2, (la1, la2, t1, t2)) in enumerate(layers):
+                if li + 1 < len(layers):
+                    xb = ops.amp_layer(xb, c1.wp, c1.bias, c2.wp, c2.bias, la1, la2, t1, t2, c1.ks, c1.dil)
+                else:
+                    acc = ops.amp_layer(xb, c1.wp, c1.bias, c2.wp, c2.bias, la1, la2, t1, t2, c1.ks, c1.dil, res2=acc,
+                                        out_scale=inv, res_scale=inv)
+        return acc
 
     def _mrf_parallel(self, h, blocks, inv):
         """The three AMP blocks of a stage read the same input and are independent until their mean
@@ -236,7 +264,7 @@ class BigVGAN(nn.Module):
             st = main if k == 0 else self._streams[k - 1]
             with torch.cuda.stream(st):
                 xb = h
-                for li, (act1, c1, act2, c2) in enumerate(layers):
+                for li, (act1, c1, act2, c2, _) in enumerate(layers):
                     a = act1.forward_cl(xb)
                     a = self._conv(a, c1)
                     a = act2.forward_cl(a)

@@ -50,6 +50,7 @@ class F0AwareBigVGAN(BigVGAN):
         self._packed = None
         self._packed_key = None
         self.parallel_blocks = True
+        self.fuse_amp_layers = True
         self._streams = None
 
     def _source_term(self, s, h, src):

@@ -68,6 +68,9 @@ def test_config5_32_prompts_full_size(dev):
             assert total > 32 * 40
         # the integer side of the batch does not depend on the batch: every utterance run on its own (f32 compute so
         # that the comparison is about batching, not about rounding) gives the same integer durations as in the batch
+        # -- except at its last two phones: the reference adds the style embedding to PADDED phones too
+        # (model.py:111), so in a padded batch the 2-layer k=3 duration predictor sees a non-zero right neighbour
+        # where the single-utterance call sees the conv's zero padding (reference behaviour, kept)
         with config.use_dtype(torch.float32):
             ph = torch.zeros(32, max(len(p) for p in phon), dtype=torch.long)
             for i, p in enumerate(phon):
@@ -82,8 +85,10 @@ def test_config5_32_prompts_full_size(dev):
                 mel1 = model.infer(phon[i][None].to(dev), style_prompt=(prompts[0][i : i + 1, : int(am[i].sum())],
                                                                           prompts[1][i : i + 1, : int(am[i].sum())]),
                                    use_max=True, noise_scale=0.0, noise_fn=lambda i, shape: torch.zeros(shape, device=dev))
-                assert torch.equal(model.last_durations.cpu()[0], dur_b[i, :n]), i   # integer: bit exact
-                assert mel1.shape[-1] == int(flen_b[i])
+                assert torch.equal(model.last_durations.cpu()[0, : n - 2], dur_b[i, : n - 2]), i   # integer: bit exact
+                assert mel1.shape[-1] == int(model.last_durations.sum())
+                if n == ph[:8].shape[1]:  # the longest utterance of the batch has no padding: identical throughout
+                    assert torch.equal(model.last_durations.cpu()[0], dur_b[i, :n]) and mel1.shape[-1] == int(flen_b[i])
     finally:
         config.set_compute_dtype(torch.float32)
 
@@ -114,6 +119,7 @@ def test_bf16_infer_batch_against_reference_golden(dev):
             # (1) free-running bf16 durations vs the reference's
             m.infer_batch(gi["phon"].to(dev), gi["plen"].to(dev), noise_fn=lambda i, s: torch.zeros(s, device=dev), **kw)
             d = (m.last_durations.cpu() - dur_ref).abs()
+            print("bf16 durations vs reference: max |diff|", int(d.max()), "fraction moved", float((d > 0).float().mean()))
             assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 0.15, (int(d.max()), float((d > 0).float().mean()))
             # (2) reference durations imposed -> same frame grid -> mel comparable element by element
             dp = m.variance_adaptor.duration_predictor
@@ -126,6 +132,7 @@ def test_bf16_infer_batch_against_reference_golden(dev):
             assert torch.equal(m.last_durations.cpu(), dur_ref)
             assert torch.equal(flen.cpu().float(), gi["new_flen_ref"].float())
             mse = float(((mel.cpu() - gi["new_mel_ref"]) ** 2).mean())
+            print("bf16 mel MSE vs reference", mse, "cf0 rel err", rel_err(cf0.cpu(), gi["new_cf0_ref"]))
             assert mse < 1e-3, mse
             assert rel_err(cf0.cpu(), gi["new_cf0_ref"]) < 3e-2
     finally:

@@ -293,10 +293,14 @@ def l2_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def _cmp_grads(module, prefix, sdo, names, grads_ref, tol=2e-5, err=rel_err):
+def _cmp_grads(module, prefix, sdo, names, grads_ref, tol=2e-5, err=rel_err, log=None):
     P = dict(module.named_parameters())
     for n, gg in zip(names, grads_ref):
-        assert err(P[n[len(prefix):]].grad.cpu(), gg) < tol, (n, err(P[n[len(prefix):]].grad.cpu(), gg))
+        e = err(P[n[len(prefix):]].grad.cpu(), gg)
+        if log is not None:
+            log.append((n, e))
+        else:
+            assert e < tol, (n, e)
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
@@ -316,9 +320,10 @@ def _module_gradients(dev, ops, mode):
     cdt = torch.float32 if mode == "f32" else torch.bfloat16
     err, tol = (rel_err, 2e-5) if mode == "f32" else (l2_err, 3e-2)
 
-    def chk(a, b):
-        e = err(a.float(), b)
-        assert e < tol, e
+    log = []  # (what, error): asserted together at the end so that a failure shows every number
+
+    def chk(a, b, what="out"):
+        log.append((what, err(a.float(), b)))
 
     # --- frame prior + pitch predictor -------------------------------------------------
     g = load_golden("variance_adaptor")
@@ -345,10 +350,10 @@ def _module_gradients(dev, ops, mode):
         gro = torch.autograd.grad(yo, [xo] + [sdo[n] for n in names], dy)
         xc = ops.bct_to_btc(x.to(dev), cdt).requires_grad_()
         yc = fn_p(xc)
-        chk(yc.detach().cpu().transpose(1, 2), yo.detach())
+        chk(yc.detach().cpu().transpose(1, 2), yo.detach(), names[0].split(".")[1] + ":y")
         yc.backward(dy.transpose(1, 2).contiguous().to(dev).to(yc.dtype))
-        chk(xc.grad.cpu().transpose(1, 2), gro[0])
-        _cmp_grads(m, "va.", sdo, names, gro[1:], tol, err)
+        chk(xc.grad.cpu().transpose(1, 2), gro[0], names[0].split(".")[1] + ":dx")
+        _cmp_grads(m, "va.", sdo, names, gro[1:], tol, err, log)
 
     # --- diffusion decoder (DiffNet stack with the hand-written backward) ---------------
     g = load_golden("diffusion")
@@ -366,8 +371,8 @@ def _module_gradients(dev, ops, mode):
     md.injected = {"t": g["t"], "noise": g["noise"]}
     _, pred2 = md.forward_cl(cc, g["mel"].to(dev), g["mask"].sum(dim=(1, 2)).int().to(dev))
     pred2.backward(dyp.transpose(1, 2).contiguous().to(dev).to(pred2.dtype))
-    chk(cc.grad.cpu(), gro[0].transpose(1, 2))
-    _cmp_grads(md, "dec.", sdo, names, gro[1:], tol, err)
+    chk(cc.grad.cpu(), gro[0].transpose(1, 2), "diffusion:dcond")
+    _cmp_grads(md, "dec.", sdo, names, gro[1:], tol, err, log)
 
     # --- Conformer (attention backward, BatchNorm batch statistics) ---------------------
     g = load_golden("conformer")
@@ -387,10 +392,13 @@ def _module_gradients(dev, ops, mode):
     lens = g["lens"].to(dev).int()
     mask = (torch.arange(xc.shape[1], device=dev)[None] < lens[:, None]).unsqueeze(-1).float()
     yc = mc.forward_cl(xc * 1.0, lens, mask)
-    chk(yc.detach().cpu(), yo.detach())
+    chk(yc.detach().cpu(), yo.detach(), "conformer:y")
     yc.backward(dy.to(dev).to(yc.dtype))
-    chk(xc.grad.cpu(), gro[0])
-    _cmp_grads(mc, "enc.", sdo, names, gro[1:], tol, err)
+    chk(xc.grad.cpu(), gro[0], "conformer:dx")
+    _cmp_grads(mc, "enc.", sdo, names, gro[1:], tol, err, log)
+    print(mode, "module errors vs oracle:", [(n, float(f"{e:.3g}")) for n, e in log])
+    bad = [(n, e) for n, e in log if not e < tol]
+    assert not bad, (bad, log)
 
 
 @pytest.mark.parametrize("variant", ["new", "legacy"])

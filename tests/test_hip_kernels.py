@@ -514,3 +514,75 @@ def test_fast_repack_path_keeps_packed_operands_current(dev):
     finally:
         PF.enable_direct_grads(False)
         PF.clear_caches()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [32, 64])
+def test_fused_amp_layer_matches_oracle(C, dtype, dev):
+    """ptpp_amp_layer_fwd (one kernel: Snake, dilated conv, Snake, conv, residual, block mean) against the oracle's
+    AMP layer (vocoders/bigvgan.py:42-47) -- every (kernel size, dilation) of the generator, lengths shorter than the
+    halo, lengths that are not a multiple of the tile, several tiles per utterance (the tile seams), with and
+    without the running block mean."""
+    from promptttspp_amd import ops
+
+    g = load_golden("aa_snake")
+    taps = (ops._taps(g["f_up"]), ops._taps(g["f_dn"]))
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    cases = [(ks, d, T) for ks in (3, 7, 11) for d in (1, 3, 5) for T in ((1, 7, 300) if ks == 11 else (45,))]
+    cases += [(11, 5, 777), (3, 1, 1030), (7, 3, 513)]
+    for n, (ks, d, T) in enumerate(cases):
+        B = 2
+        r = np.random.default_rng(1000 + n)
+        sd = {}
+        for name, dil in (("conv1", d), ("conv2", 1)):
+            sd[f"l.{name}.weight"] = torch.from_numpy((r.standard_normal((C, C, ks)) / np.sqrt(C * ks)).astype(np.float32))
+            sd[f"l.{name}.bias"] = torch.from_numpy((0.1 * r.standard_normal(C)).astype(np.float32))
+        for a in ("act1", "act2"):
+            sd[f"l.{a}.act.alpha"] = torch.from_numpy((0.3 * r.standard_normal((1, C, 1))).astype(np.float32))
+            sd[f"l.{a}.up.filter"], sd[f"l.{a}.down.lowpass.filter"] = g["f_up"], g["f_dn"]
+        x = torch.from_numpy(r.standard_normal((B, C, T)).astype(np.float32))
+        acc = torch.from_numpy(r.standard_normal((B, C, T)).astype(np.float32))
+        if dtype == torch.bfloat16:
+            x, acc = x.bfloat16().float(), acc.bfloat16().float()
+            for k in list(sd):
+                if k.endswith("weight"):
+                    sd[k] = sd[k].bfloat16().float()
+        ref = R.amp_layer(sd, "l", x, ks, d)
+        xc = x.transpose(1, 2).contiguous().to(dev, dtype)
+        w1 = ops.pack_conv_weight(sd["l.conv1.weight"].to(dev), dtype)
+        w2 = ops.pack_conv_weight(sd["l.conv2.weight"].to(dev), dtype)
+        b1, b2 = sd["l.conv1.bias"].to(dev), sd["l.conv2.bias"].to(dev)
+        la1, la2 = sd["l.act1.act.alpha"].reshape(-1).to(dev), sd["l.act2.act.alpha"].reshape(-1).to(dev)
+        y = ops.amp_layer(xc, w1, b1, w2, b2, la1, la2, taps, taps, ks, d)
+        assert rel_err(y.float().cpu().transpose(1, 2), ref) < tol, (ks, d, T, rel_err(y.float().cpu().transpose(1, 2), ref))
+        # last layer of a block: (x + conv2(..)) / 3 added to the running mean of the blocks
+        y2 = ops.amp_layer(xc, w1, b1, w2, b2, la1, la2, taps, taps, ks, d, res2=acc.transpose(1, 2).contiguous().to(dev, dtype),
+                           out_scale=1 / 3, res_scale=1 / 3)
+        ref2 = acc + ref / 3
+        assert rel_err(y2.float().cpu().transpose(1, 2), ref2) < tol, (ks, d, T, "res2")
+
+
+def test_fused_amp_layer_equals_the_four_launch_pipeline_bf16(dev):
+    """bf16: the fused layer rounds where the separate launches round (a1, c1, a2 and y are bf16 tensors there too), so
+    on a bench-shaped tile it agrees with snake -> conv -> snake -> conv(+res) to bf16 resolution, batch entries are
+    independent, and a run repeats bit for bit."""
+    from promptttspp_amd import ops
+
+    g = load_golden("aa_snake")
+    taps = (ops._taps(g["f_up"]), ops._taps(g["f_dn"]))
+    for C, ks, d, T in ((32, 11, 5, 4000), (64, 7, 3, 2100)):
+        B = 3
+        x = torch.randn(B, T, C, device=dev, generator=torch.Generator(dev).manual_seed(C)).bfloat16()
+        w = [(torch.randn(C, C, ks, device=dev) / (C * ks) ** 0.5) for _ in range(2)]
+        b = [0.1 * torch.randn(C, device=dev) for _ in range(2)]
+        la = [0.3 * torch.randn(C, device=dev) for _ in range(2)]
+        wp = [ops.pack_conv_weight(t, torch.bfloat16) for t in w]
+        y = ops.amp_layer(x, wp[0], b[0], wp[1], b[1], la[0], la[1], taps, taps, ks, d)
+        a = ops.aa_snake(x, la[0], *taps)
+        a = ops.conv1d(a, wp[0], b[0], C, ks=ks, dil=d, pad=d * (ks - 1) // 2)
+        a = ops.aa_snake(a, la[1], *taps)
+        ref = ops.conv1d(a, wp[1], b[1], C, ks=ks, dil=1, pad=(ks - 1) // 2, res=x)
+        assert rel_err(y.float(), ref.float()) < 2e-2
+        assert float((y.float() - ref.float()).abs().mean() / ref.float().abs().mean()) < 5e-3
+        assert torch.equal(y, ops.amp_layer(x, wp[0], b[0], wp[1], b[1], la[0], la[1], taps, taps, ks, d))
+        assert torch.equal(y[1:2], ops.amp_layer(x[1:2].contiguous(), wp[0], b[0], wp[1], b[1], la[0], la[1], taps, taps, ks, d))
