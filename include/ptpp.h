@@ -212,10 +212,11 @@ int ptpp_layernorm_bwd(const void* dy, const void* xsum, const void* z,
  *   q,k,v: (B,T,*) rows with stride ld, head h at columns [h*dk,(h+1)*dk)
  *   pos:   linear_pos(pos_emb): (2T-1, H*dk) new / (T, H*dk) legacy, stride ldpos
  *   bias_u/bias_v: (H, dk) f32;  ctx: (B,T,H*dk) rows with stride ldctx
- *   probs: (B,H,T,T) f32 softmax output (NULL in inference; saved for bwd)
+ *   probs: (B,H,T,T) f32 softmax output BEFORE dropout (NULL in inference; saved for bwd)
  *   drop_p/drop_seed: dropout on the attention probabilities (BERT's
- *   attention_probs_dropout_prob) for FORWARD-ONLY use (frozen layers): needs
- *   probs == NULL; 0 = off.
+ *   attention_probs_dropout_prob, transformers BertSelfAttention; the reference trains
+ *   encoder.layer[-1].attention, modules/prompt_encoder.py:29-31); 0 = off.  The keep-mask is a
+ *   function of (seed, element index): ptpp_attention_bwd regenerates it from the same pair.
  * ------------------------------------------------------------------ */
 int ptpp_attention_fwd(const void* q, const void* k, const void* v,
                        const void* pos, const float* bias_u, const float* bias_v,
@@ -234,8 +235,8 @@ int ptpp_attention_bwd(const void* q, const void* k, const void* v,
                        void* dk_out, void* dv_out, float* dpos, float* du,
                        float* dvb, const int32_t* lengths, int B, int T, int H,
                        int dk, int ld, int ldpos, int lddctx, int lddq,
-                       int variant, int dtype, void* scratch, size_t scratch_bytes,
-                       void* stream);
+                       int variant, float drop_p, uint64_t drop_seed, int dtype,
+                       void* scratch, size_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Length regulator as a gather / segment-sum instead of the reference's

@@ -492,6 +492,69 @@ def model_infer_single():
 
 
 @gen
+def transformer():
+    """The FFT-block Transformer encoder plug-in (modules/transformer.py:226-263), with and without the windowed
+    relative attention: eval output, and train-mode output + gradients with dropout zeroed."""
+    _ref()
+    from promptttspp.modules.transformer import Transformer
+    from promptttspp.utils.model import sequence_mask
+
+    out = {}
+    lens = torch.tensor([19, 11, 4])
+    T = 19
+    mask = sequence_mask(lens, T).unsqueeze(1).float()
+    x = rnd(501, 3, 256, T, scale=0.7) * mask
+    gcond = rnd(502, 3, 256, 1, scale=0.3)
+    dy = rnd(503, 3, 256, T)
+    for tag, rel in (("rel", True), ("abs", False)):
+        torch.manual_seed(0)
+        m = Transformer(channels=256, num_head=2, num_layers=2, kernel_size=3, dropout=0.1, scale=4, window_size=4, use_rel=rel)
+        fill_state_dict(m, seed=510 + int(rel), overrides={"emb_rel_k": 0.5, "emb_rel_v": 0.5})
+        m.eval()
+        with torch.no_grad():
+            out[f"{tag}_y"] = m(x, mask)
+            out[f"{tag}_yg"] = m(x, mask, g=gcond)
+        zero_dropout(m)
+        m.train()
+        xx = x.clone().requires_grad_()
+        y = m(xx, mask)
+        y.backward(dy)
+        out[f"{tag}_dx"] = xx.grad
+        names = ["layers.0.ffn.ffn.conv1.weight", "layers.1.ffn.norm.gamma", "layers.1.attention.norm.beta",
+                 "layers.0.ffn.ffn.conv2.bias"]
+        names += (["layers.0.attention.attention_layer.emb_rel_k", "layers.1.attention.attention_layer.emb_rel_v",
+                   "layers.0.attention.attention_layer.conv_q.weight", "layers.1.attention.attention_layer.conv_o.bias"]
+                  if rel else ["layers.0.attention.attention_layer.qkv.weight", "layers.1.attention.attention_layer.out.weight"])
+        P = dict(m.named_parameters())
+        for n in names:
+            gr = P[n].grad
+            out[f"{tag}_g:{n}"] = gr if gr.numel() <= 70000 else gr.flatten()[:: max(1, gr.numel() // 4096)][:4096]
+        out[f"{tag}_keys"] = _keys(m)
+    _save("transformer", x=x, lens=lens, g=gcond, dy=dy, **out)
+
+
+@gen
+def diffusion_plms():
+    """The PLMS sampler (diffusion.py:223-277, reached through inference() when pndm_speedup is set -- the
+    constructor refuses the argument at :104-105, so the attribute is set on the built module)."""
+    _ref()
+    from collections import deque  # noqa: F401
+
+    m = build_model().decoder
+    fill_state_dict(m, seed=90)
+    m.eval()
+    B, T = 2, 23
+    cond = rnd(91, B, T, 256, scale=0.5)
+    x_init = rnd(95, B, 80, T)
+    out = {}
+    for interval in (10, 25):
+        m.pndm_speedup = interval
+        with torch.no_grad(), injected_rng(randn_list=[x_init]):
+            out[f"mel_{interval}"] = m.inference(cond)
+    _save("diffusion_plms", cond=cond, x_init=x_init, keys=_keys(m), **out)
+
+
+@gen
 def model_conformer_decoder():
     """The class's other decoder branch: losses (eval, train with dropout zeroed), gradients, and the
     deterministic infer_batch mel of the reference-mel path."""

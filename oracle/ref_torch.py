@@ -602,6 +602,90 @@ def diffusion_sample(sd, p, cond, x_init, step_noise, norm_scale=6.0, K=100):
 # --------------------------------------------------------------------------
 
 
+def diffusion_sample_plms(sd, p, cond, x_init, interval, norm_scale=6.0, K=100):
+    """PLMS sampler (diffusion.py:223-277,334-347): pseudo linear multi-step over every ``interval``-th step of the
+    schedule; the first step is a Heun-like two-evaluation start, later ones extrapolate the last <= 4 noise
+    predictions.  No noise is drawn after x_init.  cond (B,C,T), x_init (B,M,T) -> mel (B,M,T)."""
+    sch = diffusion_schedule(K)
+    ac = sch["alphas_cumprod"]
+    B = cond.shape[0]
+
+    def x_pred(x, noise_t, t):
+        a_t = ac[t].view(B, 1, 1)
+        a_prev = ac[torch.clamp(t - interval, min=0)].view(B, 1, 1)
+        a_t_sq, a_prev_sq = a_t.sqrt(), a_prev.sqrt()
+        delta = (a_prev - a_t) * ((1 / (a_t_sq * (a_t_sq + a_prev_sq))) * x
+                                  - 1 / (a_t_sq * (((1 - a_prev) * a_t).sqrt() + ((1 - a_t) * a_prev).sqrt())) * noise_t)
+        return x + delta
+
+    x = x_init
+    hist = []
+    for i in reversed(range(0, K, interval)):
+        t = torch.full((B,), i, dtype=torch.long)
+        e = diffnet(sd, p + ".denoise_fn", x, t, cond)
+        if len(hist) == 0:
+            e_prev = diffnet(sd, p + ".denoise_fn", x_pred(x, e, t), torch.clamp(t - interval, min=0), cond)
+            ep = (e + e_prev) / 2
+        elif len(hist) == 1:
+            ep = (3 * e - hist[-1]) / 2
+        elif len(hist) == 2:
+            ep = (23 * e - 16 * hist[-1] + 5 * hist[-2]) / 12
+        else:
+            ep = (55 * e - 59 * hist[-1] + 37 * hist[-2] - 9 * hist[-3]) / 24
+        x = x_pred(x, ep, t)
+        hist.append(e)
+        hist = hist[-4:]
+    return x * norm_scale
+
+
+# --------------------------------------------------------------------------
+# FFT-block Transformer encoder plug-in  (promptttspp/modules/transformer.py)
+# --------------------------------------------------------------------------
+
+
+def transformer(sd, p, x, mask, heads=2, layers=2, ks=3, window=4, use_rel=True, g=None):
+    """Transformer.forward (transformer.py:226-263): x (B,C,T), mask (B,1,T) float, g (B,C,1) or None.
+    Per layer: x = LN(x + attn(x)); x = LN(x + ffn(x)) * mask, masked scores filled with -1e4."""
+    B, C, T = x.shape
+    D = C // heads
+    am = (mask.unsqueeze(2) * mask.unsqueeze(-1))  # (B,1,T,T)
+    for l in range(layers):
+        if g is not None:
+            x = x + g
+        q_ = f"{p}.layers.{l}.attention"
+        a = q_ + ".attention_layer"
+        if use_rel:
+            sp = lambda t: t.view(B, heads, D, T).transpose(2, 3)  # noqa: E731
+            q, k, v = (sp(_conv(sd, f"{a}.conv_{n}", x)) for n in "qkv")
+            qs = q / math.sqrt(D)
+            sc = qs @ k.transpose(-2, -1)
+            i = torch.arange(T)
+            r = i[None, :] - i[:, None] + window
+            band = ((r >= 0) & (r <= 2 * window)).to(x.dtype)
+            rel = qs @ sd[a + ".emb_rel_k"][0].t()
+            sc = sc + rel.gather(-1, r.clamp(0, 2 * window).expand(B, heads, T, T)) * band
+            sc = sc.masked_fill(am == 0, -1e4)
+            pa = torch.softmax(sc, dim=-1)
+            o = pa @ v
+            jj = i[:, None] + torch.arange(2 * window + 1)[None, :] - window
+            inside = ((jj >= 0) & (jj < T)).to(x.dtype)
+            o = o + (pa.gather(-1, jj.clamp(0, T - 1).expand(B, heads, T, 2 * window + 1)) * inside) @ sd[a + ".emb_rel_v"][0]
+            y = _conv(sd, a + ".conv_o", o.transpose(2, 3).reshape(B, C, T))
+        else:
+            qkv = _conv(sd, a + ".qkv", x).view(B, 3, heads, D, T).transpose(-1, -2)
+            q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+            sc = (q @ k.transpose(-1, -2)) / math.sqrt(D)
+            sc = sc.masked_fill(am == 0, -1e4)
+            o = torch.softmax(sc, dim=-1) @ v
+            y = _conv(sd, a + ".out", o.transpose(-1, -2).reshape(B, C, T))
+        x = layer_norm_c(x + y, sd[q_ + ".norm.gamma"], sd[q_ + ".norm.beta"])
+        f = f"{p}.layers.{l}.ffn"
+        h = torch.relu(_conv(sd, f + ".ffn.conv1", x * mask, padding=ks // 2))
+        h = _conv(sd, f + ".ffn.conv2", h * mask) * mask
+        x = layer_norm_c(x + h, sd[f + ".norm.gamma"], sd[f + ".norm.beta"]) * mask
+    return x
+
+
 def model_forward(sd, batch, t, noise, variant="new", train_bn=False, loss_dec_scale=8.0):
     """PromptTTSMDNDurCFG.forward (model.py:72-183), eval-mode arithmetic with
     injected diffusion (t, noise).  batch = (phoneme, duration (B,1,Tp) f32,

@@ -29,7 +29,7 @@ struct AttnP {
   const int* lengths;
   int B, T, H, dk, ld, ldpos, ldctx, variant;
   float scale;
-  unsigned drop_thresh16;  // attention-probability dropout (forward-only use), 0 = off
+  unsigned drop_thresh16;  // attention-probability dropout, 0 = off
   float drop_inv_keep;
   unsigned long long drop_seed;
 };
@@ -116,13 +116,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
   const uint64_t drow = (((uint64_t)b * p.H + h) * Tn + i) * (uint64_t)Tn;  // element index of P[b,h,i,0]
   for (int j = lane; j < Tn; j += 64) {
     float pr = j < len ? sc[j] * inv : 0.f;
+    if (prow) prow[j] = pr;  // the softmax itself: the backward regenerates the dropout mask from (seed, index)
     if (p.drop_thresh16 && j < len) {
       const uint64_t e = drow + j;
       const uint32_t bits = (uint32_t)(drop_hash(p.drop_seed, e >> 2) >> (16 * (e & 3))) & 0xffffu;
       pr = bits >= p.drop_thresh16 ? pr * p.drop_inv_keep : 0.f;
     }
     if (j < len) sc[j] = pr;
-    if (prow) prow[j] = pr;
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -152,7 +152,16 @@ struct AttnBwdP {
   const int* lengths;
   int B, T, H, dk, ld, ldpos, lddctx, lddq, variant;
   float scale;
+  unsigned drop_thresh16;  // the forward's probability dropout (0 = off): the mask is regenerated here
+  float drop_inv_keep;
+  unsigned long long drop_seed;
 };
+
+// keep-scale of element (b, h, i, j) of the attention probabilities: 1/(1-p) if kept, 0 if dropped (as the forward)
+__device__ __forceinline__ float attn_keep(const AttnBwdP& p, uint64_t e) {
+  const uint32_t bits = (uint32_t)(drop_hash(p.drop_seed, e >> 2) >> (16 * (e & 3))) & 0xffffu;
+  return bits >= p.drop_thresh16 ? p.drop_inv_keep : 0.f;
+}
 
 // Query rows per wave in attn_bwd_row_kernel.  One: the row loops are chains of dependent L2 reads, so
 // the kernel wants many resident waves (4 rows per wave left 1.75 waves per SIMD on the phone-level
@@ -197,8 +206,10 @@ __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     float dsum = 0.f;
+    const uint64_t drow = (((uint64_t)b * p.H + h) * Tn + i) * (uint64_t)Tn;
     for (int j = lane; j < len; j += 64) {
-      const float dp = dot_row<T>(go, vb + (int64_t)j * p.ld, dk);
+      float dp = dot_row<T>(go, vb + (int64_t)j * p.ld, dk);  // d(dropped P)
+      if (p.drop_thresh16) dp *= attn_keep(p, drow + j);        // dP = mask/(1-p) * d(dropped P)
       ds[j] = dp;
       dsum += prow[j] * dp;
     }
@@ -263,7 +274,9 @@ __global__ __launch_bounds__(256) void attn_bwd_col_kernel(const AttnBwdP p, voi
     f32x4 bu = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.variant != VAR_PLAIN) bu = *reinterpret_cast<const f32x4*>(p.bias_u + hc + dv);
     for (int i = part; i < len; i += parts) {
-      const float dsv = dcol[(int64_t)i * Tn], pv = pcol[(int64_t)i * Tn];
+      const float dsv = dcol[(int64_t)i * Tn];
+      float pv = pcol[(int64_t)i * Tn];
+      if (p.drop_thresh16) pv *= attn_keep(p, (((uint64_t)b * p.H + h) * Tn + i) * (uint64_t)Tn + j);  // dV uses the dropped P
       ak += (Elem<T>::ld4(qb + (int64_t)i * p.ld + dv) + bu) * dsv;
       av += Elem<T>::ld4(gb + (int64_t)i * p.lddctx + dv) * pv;
     }
@@ -331,8 +344,7 @@ extern "C" int ptpp_attention_fwd(const void* q, const void* k, const void* v, c
                                   int H, int dk, int ld, int ldpos, int ldctx, int variant, float drop_p,
                                   uint64_t drop_seed, int dtype, void* stream) {
   PTPP_CHECK_ARG(q && k && v && ctx, "attention_fwd: null pointer");
-  PTPP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || !probs),
-                 "attention_fwd: probability dropout is forward-only (probs must be NULL)");
+  PTPP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "attention_fwd: bad dropout p");
   PTPP_CHECK_ARG(shape_ok(B, T_, H, dk), "attention_fwd: unsupported shape B=%d T=%d H=%d dk=%d", B, T_, H, dk);
   PTPP_CHECK_ARG(variant >= 0 && variant <= 2, "attention_fwd: bad variant");
   PTPP_CHECK_ARG(variant == VAR_PLAIN || (pos && bias_u && bias_v), "attention_fwd: rel-pos variant needs pos/u/v");
@@ -356,8 +368,8 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
                                   const float* bias_v, const float* probs, const void* dctx, float* dS, void* dq,
                                   void* dk_out, void* dv_out, float* dpos, float* du, float* dvb,
                                   const int32_t* lengths, int B, int T_, int H, int dk, int ld, int ldpos, int lddctx,
-                                  int lddq, int variant, int dtype, void* scratch, size_t scratch_bytes,
-                                  void* stream) {
+                                  int lddq, int variant, float drop_p, uint64_t drop_seed, int dtype, void* scratch,
+                                  size_t scratch_bytes, void* stream) {
   PTPP_CHECK_ARG(q && k && v && probs && dctx && dS && dq && dk_out && dv_out, "attention_bwd: null pointer");
   PTPP_CHECK_ARG(shape_ok(B, T_, H, dk), "attention_bwd: unsupported shape");
   PTPP_CHECK_ARG(variant == VAR_NEW || variant == VAR_PLAIN,
@@ -367,6 +379,10 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
                  "attention_bwd: reduction scratch missing or too small");
   AttnBwdP p{q, k, v, pos, dctx, bias_u, bias_v, probs, dS, dq, du, dvb, reinterpret_cast<float*>(scratch), lengths,
              B, T_, H, dk, ld, ldpos, lddctx, lddq, variant, 1.0f / sqrtf((float)dk)};
+  PTPP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "attention_bwd: bad dropout p");
+  p.drop_thresh16 = drop_p > 0.f ? (unsigned)(drop_p * 65536.f + 0.5f) : 0u;
+  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - p.drop_thresh16 / 65536.f) : 1.f;
+  p.drop_seed = drop_seed;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((T_ + 3) / 4, H, B);
   dim3 grid_row((T_ + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), H, B);

@@ -24,6 +24,8 @@
 // fragments (2h, 2h+1) hold 8 consecutive channels: every store / residual load is a
 // full 16-byte vector and the four lane groups of a row cover 64 contiguous bytes
 // (the unpermuted layout wrote 8-byte pieces, 32 contiguous bytes per row).
+#include <stdlib.h>
+
 #include "conv1d_common.h"
 
 namespace {
@@ -373,6 +375,17 @@ int launch_tiles(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes) {
     return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);
   }
   // (64 x 128 and 256 x 64 tiles measured 10-45 % slower on the frame-level shapes)
+  static const char* alt = getenv("PTPP_CONV_TILE");  // experiments: wave-tile shapes of the 128-row configurations
+  if (alt) {
+    switch (alt[0]) {
+      case 'b': return launch_cfg<T, NCH, 2, 4, 2, 8>(p, st);   // 128 x 128,  8 waves of 64 x 32
+      case 'c': return launch_cfg<T, NCH, 4, 2, 4, 8>(p, st);   // 128 x 128,  8 waves of 32 x 64
+      case 'd': return launch_cfg<T, NCH, 2, 4, 4, 4>(p, st);   // 128 x 128,  4 waves of 64 x 64
+      case 'e': return launch_cfg<T, NCH, 4, 4, 2, 16>(p, st);  // 256 x 128, 16 waves of 64 x 32
+      case 'f': return launch_cfg<T, NCH, 2, 4, 4, 8>(p, st);   // 128 x 256,  8 waves of 64 x 64
+      default: break;
+    }
+  }
   return launch_cfg<T, NCH, 4, 2, 2, 16>(p, st);                       // 128 x 128, 16 waves of 32 x 32
 }
 

@@ -537,14 +537,16 @@ class AttentionFn(Function):
     """Relative-position MHA core on a fused (B, T, 3C) q|k|v projection."""
 
     @staticmethod
-    def forward(ctx, qkv, pos, bias_u, bias_v, lengths, heads, variant):
+    def forward(ctx, qkv, pos, bias_u, bias_v, lengths, heads, variant, drop_p=0.0):
         B, T, C3 = qkv.shape
         C = C3 // 3
         q, k, v = qkv[:, :, :C], qkv[:, :, C : 2 * C], qkv[:, :, 2 * C :]
         u, vb = _f32c(bias_u), _f32c(bias_v)
         need_bwd = any(ctx.needs_input_grad)
-        octx, probs = ops.attention_fwd(q, k, v, pos, u, vb, lengths, heads, variant, save_probs=need_bwd)
-        ctx.heads, ctx.variant, ctx.lengths = heads, variant, lengths
+        seed = next_seed() if drop_p > 0 else 0
+        octx, probs = ops.attention_fwd(q, k, v, pos, u, vb, lengths, heads, variant, save_probs=need_bwd, drop_p=drop_p,
+                                        drop_seed=seed)
+        ctx.heads, ctx.variant, ctx.lengths, ctx.drop = heads, variant, lengths, (drop_p, seed)
         ctx.ushape = bias_u.shape if bias_u is not None else None
         ctx.direct = None
         if need_bwd and variant == "new" and _sink(bias_u) is not None and _sink(bias_v) is not None:
@@ -566,7 +568,8 @@ class AttentionFn(Function):
                                           dctx, ctx.lengths, ctx.heads, ctx.variant, dqkv[:, :, :C],
                                           dqkv[:, :, C : 2 * C], dqkv[:, :, 2 * C :],
                                           du_out=pu.grad if pu is not None else None,
-                                          dvb_out=pv.grad if pv is not None else None)
+                                          dvb_out=pv.grad if pv is not None else None, drop_p=ctx.drop[0],
+                                          drop_seed=ctx.drop[1])
         if dpos is not None:
             dpos = dpos.to(pos.dtype)
             du, dvb = du.view(ctx.ushape), dvb.view(ctx.ushape)
@@ -574,11 +577,12 @@ class AttentionFn(Function):
             _done(pu)
             _done(pv)
             du = dvb = None
-        return dqkv, dpos, du, dvb, None, None, None
+        return dqkv, dpos, du, dvb, None, None, None, None
 
 
-def attention(qkv, pos, bias_u, bias_v, lengths, heads, variant):
-    return AttentionFn.apply(qkv, pos, bias_u, bias_v, lengths, heads, variant)
+def attention(qkv, pos, bias_u, bias_v, lengths, heads, variant, drop_p=0.0):
+    """``drop_p``: dropout on the attention probabilities (the plain / BERT variant in train mode)."""
+    return AttentionFn.apply(qkv, pos, bias_u, bias_v, lengths, heads, variant, drop_p)
 
 
 # ----------------------------------------------------------------------------

@@ -22,6 +22,7 @@ from ... import ops
 from ...config import compute_dtype
 from ...modules.diffusion import GaussianDiffusion
 from ...modules.esp import ConformerEncoder
+from ...modules.transformer import Transformer
 from ...modules.mdn import mdn_get_most_probable_sigma_and_mu, mdn_loss, mdn_sample_sigma_and_mu
 from ...utils.model import sequence_mask
 
@@ -41,10 +42,12 @@ class PromptTTSMDNDurCFG(nn.Module):
         self.norm_style_emb = norm_style_emb
         self.mdn_disable_amp = mdn_disable_amp
         self.loss_dec_scale = loss_dec_scale
-        if not isinstance(encoder, ConformerEncoder) or not isinstance(decoder, (GaussianDiffusion, ConformerEncoder)):
+        if not isinstance(encoder, (ConformerEncoder, Transformer)) or \
+                not isinstance(decoder, (GaussianDiffusion, ConformerEncoder)):
             raise NotImplementedError(
-                "promptttspp_amd implements encoder=ConformerEncoder with decoder=GaussianDiffusion(DiffNet) "
-                "(prompttts_mdn_v2_wo_erg_final.yaml) or decoder=ConformerEncoder + out_conv (model.py:123-126)")
+                "promptttspp_amd implements encoder=ConformerEncoder (prompttts_mdn_v2_wo_erg_final.yaml) or "
+                "modules.transformer.Transformer (model.py:95) with decoder=GaussianDiffusion(DiffNet) or "
+                "decoder=ConformerEncoder + out_conv (model.py:123-126)")
         self.conformer_decoder = isinstance(decoder, ConformerEncoder)
         if self.conformer_decoder:
             assert out_conv is not None  # reference model.py:66-67
@@ -59,7 +62,10 @@ class PromptTTSMDNDurCFG(nn.Module):
         pmask = (torch.arange(Tp, device=phoneme.device)[None, :] < plen[:, None])  # (B,Tp) bool
         pm1 = pmask.unsqueeze(-1).float()
         x = self.phoneme_emb.forward_cl(phoneme, pm1, dt)
-        x = self.encoder.forward_cl(x.contiguous(), plen, pm1)
+        if isinstance(self.encoder, ConformerEncoder):
+            x = self.encoder.forward_cl(x.contiguous(), plen, pm1)
+        else:  # the FFT-block Transformer plug-in: encoder(x, phone_mask) (model.py:95)
+            x = self.encoder.forward_cl(x.contiguous(), plen)
         return x, plen, pmask
 
     def _decode_conformer(self, h, flen, fm1):

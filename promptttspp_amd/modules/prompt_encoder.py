@@ -1,12 +1,12 @@
 """Prompt encoder: BERT CLS state -> 3-layer MLP (reference:
 promptttspp/modules/prompt_encoder.py:22-56).
 
-The BERT encoder itself is the third-party HuggingFace ``BertModel`` in the
-reference too (un-vendored dependency).  Round-1 state: it runs here as the same
-HF module on PyTorch-ROCm library ops; frozen layers run under ``no_grad``.  Only
-the adaptor MLP goes through the HIP GEMM.  (A BERT encoder on the package's own
-GEMM / LayerNorm / plain-attention kernels is the planned replacement:
-``ptpp_attention_fwd`` already has the PLAIN variant for it.)
+The BERT encoder is the third-party HuggingFace ``BertModel`` in the reference
+(un-vendored dependency): the module tree and state-dict keys are kept, the
+arithmetic runs on this package's kernels -- embeddings, the 11 frozen layers
+(forward only) and the trainable ``encoder.layer[-1].attention`` with autograd
+through the attention-probability dropout (``ptpp_attention_fwd/bwd``, PLAIN
+variant).  The transformers modules themselves are only called for CPU tensors.
 
 Pretrained weights: like the reference, ``BertModel.from_pretrained(name)`` (local cache first, then the
 hub).  When neither is reachable the constructor RAISES -- training the prompt encoder on 11 frozen layers of
@@ -108,33 +108,86 @@ class BertWrapper(nn.Module):
         return enc["input_ids"], enc["attention_mask"]
 
     def forward(self, prompts: List[str], device: torch.device) -> torch.Tensor:
+        """CLS state of the last layer, (B, 768) f32.  On a ROCm device everything runs on the package's kernels:
+        embeddings (gathers + fused LayerNorm/dropout), the frozen layers forward-only, the trainable layer
+        (``encoder.layer[-1].attention``, modules/prompt_encoder.py:29-31) through autograd Functions with hand-written
+        backward -- including the dropout on the attention probabilities, whose mask the backward regenerates."""
         ids, am = self.tokenize(prompts, device)
-        amp = compute_dtype() == torch.bfloat16 and ids.is_cuda
+        if not (ids.is_cuda and self.hip_frozen_layers):
+            return self._forward_library(ids, am)
+        from .. import ops
+
         layers = list(self.model.encoder.layer)
-        # BertModel.forward, layer by layer (checked bit-identical on CPU): the library's mask helper
-        # inspects the mask on the HOST (mask.all()), a device sync that stalls the launch queue once per
-        # step.  Same modules, same state-dict keys.
+        lengths = am.sum(dim=1).to(torch.int32)
+        with torch.no_grad():  # the embeddings are frozen, and nothing upstream of them needs a gradient
+            h = self._embeddings(ids)
+            n_frozen = self._n_frozen(layers)
+            for layer in layers[:n_frozen]:
+                h = self._frozen_layer(layer, h, lengths)
+        for layer in layers[n_frozen:]:
+            if layer is layers[-1]:
+                return self._last_layer_cls(layer, h, lengths).float()
+            h = self._full_layer(layer, h, lengths)
+        return h[:, 0, :].float()
+
+    def _forward_library(self, ids, am):
+        """The same computation through the transformers modules (CPU tensors, or ``hip_frozen_layers = False``: the
+        cross-check of the tests).  BertModel.forward, layer by layer: the library's mask helper inspects the mask on
+        the HOST (mask.all()), a device sync per step; same modules, same state-dict keys."""
+        amp = compute_dtype() == torch.bfloat16 and ids.is_cuda
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             h = self.model.embeddings(input_ids=ids)
-        n_hip = 0
-        if ids.is_cuda and self.hip_frozen_layers:
-            # frozen layers (no gradient flows into or through them: the embeddings are frozen too) run
-            # forward-only on the HIP kernels: 7 launches per layer, weights packed once
-            n_hip = self._n_frozen(layers)
-            if n_hip and not (torch.is_grad_enabled() and h.requires_grad):
-                lengths = am.sum(dim=1).to(torch.int32)
-                hc = h.detach().to(compute_dtype()).contiguous()
-                for layer in layers[:n_hip]:
-                    hc = self._frozen_layer(layer, hc, lengths)
-                h = hc.float()
-            else:
-                n_hip = 0
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             ext = (1.0 - am[:, None, None, :].to(h.dtype)) * torch.finfo(h.dtype).min
-            for layer in layers[n_hip:]:
+            for layer in self.model.encoder.layer:
                 out = layer(h, attention_mask=ext)
                 h = out[0] if isinstance(out, tuple) else out
         return h[:, 0, :].float()
+
+    def _embeddings(self, ids):
+        """BertEmbeddings (transformers): word + absolute position + token-type(0) embeddings -> LayerNorm -> dropout,
+        (B, T, 768) in the compute dtype.  The three gathers are index lookups; LayerNorm + dropout is one kernel."""
+        from .. import ops
+
+        e = self.model.embeddings
+        T = ids.shape[1]
+        x = e.word_embeddings.weight[ids] + e.position_embeddings.weight[:T].unsqueeze(0) + e.token_type_embeddings.weight[0]
+        p = float(e.dropout.p) if self.training else 0.0
+        ln = e.LayerNorm
+        return ops.layernorm_fwd(x.to(compute_dtype()).contiguous(), ln.weight, ln.bias, ln.eps,
+                                 drop_out=(p, PF.next_seed() if p > 0 else 0))[0]
+
+    def _attention_block(self, layer, h, lengths):
+        """BertAttention with autograd: fused q|k|v projection, plain attention with probability dropout, output
+        projection with hidden dropout + residual, LayerNorm."""
+        att = layer.attention
+        sa = att.self
+        tr = self.training
+        qkv = PF.linear_fused(h, [sa.query, sa.key, sa.value])
+        ctx = PF.attention(qkv, None, None, None, lengths, sa.num_attention_heads, "plain",
+                           drop_p=float(sa.dropout.p) if tr else 0.0)
+        a = PF.conv1d(ctx, att.output.dense.weight, att.output.dense.bias, res=h,
+                      drop_p=float(att.output.dropout.p) if tr else 0.0)
+        ln = att.output.LayerNorm
+        return PF.layer_norm(a, ln.weight, ln.bias, ln.eps)
+
+    def _ffn_block(self, layer, h1):
+        """BertIntermediate (exact GELU) + BertOutput on (B, T, 768) rows, differentiable w.r.t. its input."""
+        z = PF.linear(h1, layer.intermediate.dense.weight, layer.intermediate.dense.bias)
+        g = torch.nn.functional.gelu(z.float()).to(z.dtype)
+        o = PF.conv1d(g, layer.output.dense.weight, layer.output.dense.bias, res=h1,
+                      drop_p=float(layer.output.dropout.p) if self.training else 0.0)
+        ln2 = layer.output.LayerNorm
+        return PF.layer_norm(o, ln2.weight, ln2.bias, ln2.eps)
+
+    def _full_layer(self, layer, h, lengths):
+        return self._ffn_block(layer, self._attention_block(layer, h, lengths))
+
+    def _last_layer_cls(self, layer, h, lengths):
+        """The last layer.  Only its CLS row leaves the encoder (prompt_encoder.py:37), and the feed-forward half of a
+        BERT layer acts on each token separately: it runs on the B CLS rows only (the same numbers and the same
+        gradients as the full layer restricted to what is used, a 1/T of the work)."""
+        h1 = self._attention_block(layer, h, lengths)
+        return self._ffn_block(layer, h1[:, 0:1, :].contiguous())[:, 0, :]
 
     @torch.no_grad()
     def _frozen_layer(self, layer, h, lengths):

@@ -1,0 +1,213 @@
+"""FFT-block Transformer encoder plug-in (reference: promptttspp/modules/transformer.py:23-263) -- the alternative
+occupant of the model's ``encoder:`` slot (model.py:95: ``self.encoder(x, phone_mask)``), SURVEY section 8f n3.
+
+Same classes, constructor arguments and state-dict keys as the reference.  Everything GEMM-shaped runs on the
+package's kernels, channels-last: the fused q|k|v projection and the output projection (``ptpp_conv1d_fwd``), the
+plain multi-head attention core incl. probability dropout (``ptpp_attention_fwd/bwd``, PLAIN variant), the
+k-tap / 1x1 feed-forward convolutions with ReLU, masks and dropout fused, and the residual + dropout + LayerNorm of
+every sub-layer (``ptpp_layernorm_fwd/bwd``).  The windowed relative-position attention core (``use_rel=True``,
+Shaw et al. window of +-4) is torch tensor algebra on the device around those projections: its band gathers have no
+kernel of their own yet.
+
+Masking note: the reference fills masked scores with -1e4 (not -inf), which gives PADDED query rows a uniform
+attention over all positions; every layer ends in ``x * mask`` and every convolution reads ``x * mask``, so padded
+rows never reach a valid row or the output.  The PLAIN kernel writes zeros there instead: outputs are identical.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as PF
+from .. import ops
+from ..config import compute_dtype
+from ..layers.norm import LayerNorm
+
+
+def _lengths_of(mask):
+    """(B,1,T) prefix mask -> (B,) int32 lengths"""
+    return mask.sum(dim=(1, 2)).to(torch.int32)
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, channels, n_heads, dropout):
+        super().__init__()
+        assert channels % n_heads == 0
+        self.inter_channels = channels // n_heads
+        self.n_heads = n_heads
+        self.scale = 1 / math.sqrt(self.inter_channels)
+        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.out = nn.Conv1d(channels, channels, 1)
+        self.drop = nn.Dropout(dropout)
+
+    def forward_cl(self, x, lengths):
+        """x (B,T,C).  The reference views the 3C projection as [3][H][D]: q | k | v with contiguous heads -- the
+        layout the attention kernel reads."""
+        qkv = PF.conv1d(x, self.qkv.weight, self.qkv.bias)
+        ctx = PF.attention(qkv, None, None, None, lengths, self.n_heads, "plain",
+                           drop_p=float(self.drop.p) if self.training else 0.0)
+        return PF.conv1d(ctx, self.out.weight, self.out.bias)
+
+    def forward(self, x, mask):
+        """Reference signature: x (B,C,T), mask (B,1,T,T) or None -> (B,C,T)."""
+        B, C, T = x.shape
+        lengths = None if mask is None else mask[:, 0].amax(dim=1).sum(dim=-1).to(torch.int32)
+        return ops.btc_to_bct(self.forward_cl(ops.bct_to_btc(x, compute_dtype()), lengths))
+
+
+class RelativeMultiHeadAttention(nn.Module):
+    """Windowed relative positional attention: scores += q . emb_rel_k[j - i] and output += p . emb_rel_v[j - i]
+    for |j - i| <= window_size (the reference's pad / view re-indexing, written as band gathers)."""
+
+    def __init__(self, channels, n_heads, dropout, window_size=4):
+        super().__init__()
+        assert channels % n_heads == 0
+        self.inter_channels = channels // n_heads
+        self.n_heads = n_heads
+        self.window_size = window_size
+        self.scale = math.sqrt(self.inter_channels)
+        self.conv_q = nn.Conv1d(channels, channels, 1)
+        self.conv_k = nn.Conv1d(channels, channels, 1)
+        self.conv_v = nn.Conv1d(channels, channels, 1)
+        self.conv_o = nn.Conv1d(channels, channels, 1)
+        self.drop = nn.Dropout(dropout)
+        rel_stddev = self.inter_channels ** -0.5
+        self.emb_rel_k = nn.Parameter(torch.randn(1, window_size * 2 + 1, self.inter_channels) * rel_stddev)
+        self.emb_rel_v = nn.Parameter(torch.randn(1, window_size * 2 + 1, self.inter_channels) * rel_stddev)
+        nn.init.xavier_uniform_(self.conv_q.weight)
+        nn.init.xavier_uniform_(self.conv_k.weight)
+        nn.init.xavier_uniform_(self.conv_v.weight)
+
+    def forward_cl(self, x, lengths):
+        B, T, C = x.shape
+        H, D, w = self.n_heads, self.inter_channels, self.window_size
+        qkv = PF.linear_fused(x, [self.conv_q, self.conv_k, self.conv_v]).float()
+        q, k, v = (t.reshape(B, T, H, D).transpose(1, 2) for t in qkv.split(C, dim=-1))  # (B,H,T,D)
+        q = q / self.scale
+        scores = q @ k.transpose(-2, -1)
+        # relative part: r = j - i + w in [0, 2w]; entries outside the band are the reference's zero padding
+        i = torch.arange(T, device=x.device)
+        r = i[None, :] - i[:, None] + w                                 # (T, T)
+        band = (r >= 0) & (r <= 2 * w)
+        rc = r.clamp(0, 2 * w)
+        rel = q @ self.emb_rel_k[0].float().t()                         # (B,H,T,2w+1)
+        scores = scores + rel.gather(-1, rc.expand(B, H, T, T)) * band
+        if lengths is not None:
+            valid = i[None, :] < lengths[:, None]                        # (B,T)
+            scores = scores.masked_fill(~(valid[:, None, :, None] & valid[:, None, None, :]), -1e4)
+        p = self.drop(F.softmax(scores, dim=-1))
+        out = p @ v
+        # relative_weights[i, r] = p[i, i + r - w] (0 outside the sequence)
+        jj = i[:, None] + torch.arange(2 * w + 1, device=x.device)[None, :] - w   # (T, 2w+1)
+        inside = (jj >= 0) & (jj < T)
+        relw = p.gather(-1, jj.clamp(0, T - 1).expand(B, H, T, 2 * w + 1)) * inside
+        out = out + relw @ self.emb_rel_v[0].float()
+        out = out.transpose(1, 2).reshape(B, T, C).to(x.dtype).contiguous()
+        return PF.conv1d(out, self.conv_o.weight, self.conv_o.bias)
+
+    def forward(self, x, mask):
+        lengths = None if mask is None else mask[:, 0].amax(dim=1).sum(dim=-1).to(torch.int32)
+        return ops.btc_to_bct(self.forward_cl(ops.bct_to_btc(x, compute_dtype()), lengths))
+
+
+class FFN(nn.Module):
+    def __init__(self, channels, kernel_size, dropout, scale):
+        super().__init__()
+        self.conv1 = nn.Conv1d(channels, channels * scale, kernel_size, padding=kernel_size // 2)
+        self.conv2 = nn.Conv1d(channels * scale, channels, 1)
+        self.drop = nn.Dropout(dropout)
+
+    def forward_cl(self, x, lengths):
+        """conv2(drop(relu(conv1(x * m))) * m) * m"""
+        k = self.conv1.kernel_size[0]
+        h = PF.conv1d(x, self.conv1.weight, self.conv1.bias, ks=k, pad=k // 2, act="relu", lengths=lengths, in_mask=True,
+                      drop_p=float(self.drop.p) if self.training else 0.0)
+        return PF.conv1d(h, self.conv2.weight, self.conv2.bias, lengths=lengths, in_mask=True, out_mask=True)
+
+    def forward(self, x, x_mask):
+        return ops.btc_to_bct(self.forward_cl(ops.bct_to_btc(x, compute_dtype()), _lengths_of(x_mask)))
+
+
+class _AttnSubLayer(nn.Module):
+    """x = norm(x + dropout(attention(x)))"""
+
+    def forward_cl(self, x, lengths):
+        y = self.attention_layer.forward_cl(x, lengths)
+        return self.norm.forward_cl(y, res=x, drop_in=float(self.dropout.p) if self.training else 0.0)
+
+    def forward(self, x, attn_mask):
+        lengths = None if attn_mask is None else attn_mask[:, 0].amax(dim=1).sum(dim=-1).to(torch.int32)
+        return ops.btc_to_bct(self.forward_cl(ops.bct_to_btc(x, compute_dtype()), lengths))
+
+
+class AttentionLayer(_AttnSubLayer):
+    def __init__(self, channels, num_head, dropout):
+        super().__init__()
+        self.attention_layer = MultiHeadAttention(channels, num_head, dropout)
+        self.norm = LayerNorm(channels)
+        self.dropout = nn.Dropout(dropout)
+
+
+class RelativeAttentionLayer(_AttnSubLayer):
+    def __init__(self, channels, num_head, dropout, window_size):
+        super().__init__()
+        self.attention_layer = RelativeMultiHeadAttention(channels, num_head, dropout, window_size)
+        self.norm = LayerNorm(channels)
+        self.dropout = nn.Dropout(dropout)
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, channels, kernel_size, dropout, scale):
+        super().__init__()
+        self.ffn = FFN(channels, kernel_size, dropout, scale)
+        self.norm = LayerNorm(channels)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward_cl(self, x, lengths):
+        """norm(x + dropout(ffn(x))) * mask"""
+        y = self.ffn.forward_cl(x, lengths)
+        return self.norm.forward_cl(y, res=x, drop_in=float(self.dropout.p) if self.training else 0.0, lengths=lengths,
+                                    out_mask=True)
+
+    def forward(self, x, mask):
+        return ops.btc_to_bct(self.forward_cl(ops.bct_to_btc(x, compute_dtype()), _lengths_of(mask)))
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, channels, num_head, kernel_size, dropout, scale, window_size=None, use_rel=False):
+        super().__init__()
+        if use_rel:
+            self.attention = RelativeAttentionLayer(channels, num_head, dropout, window_size)
+        else:
+            self.attention = AttentionLayer(channels, num_head, dropout)
+        self.ffn = FFNLayer(channels, kernel_size, dropout, scale)
+
+    def forward_cl(self, x, lengths):
+        return self.ffn.forward_cl(self.attention.forward_cl(x, lengths), lengths)
+
+    def forward(self, x, mask, attn_mask):
+        return ops.btc_to_bct(self.forward_cl(ops.bct_to_btc(x, compute_dtype()), _lengths_of(mask)))
+
+
+class Transformer(nn.Module):
+    def __init__(self, channels, num_head, num_layers, kernel_size, dropout, scale=4, window_size=None, use_rel=False):
+        super().__init__()
+        self.channels = channels
+        self.layers = nn.ModuleList([TransformerLayer(channels, num_head, kernel_size, dropout, scale, window_size, use_rel)
+                                     for _ in range(num_layers)])
+
+    def forward_cl(self, x, lengths, g=None):
+        """x (B,T,C) channels-last in the compute dtype; g: optional (B,1,C) / (B,T,C) conditioning added before
+        every layer (transformer.py:258-260)."""
+        for layer in self.layers:
+            if g is not None:
+                x = x + g
+            x = layer.forward_cl(x, lengths)
+        return x
+
+    def forward(self, x, mask, g=None):
+        """Reference signature: x (B,C,T), mask (B,1,T), g (B,C,1) -> (B,C,T)."""
+        gc = None if g is None else g.transpose(1, 2).to(compute_dtype())
+        y = self.forward_cl(ops.bct_to_btc(x, compute_dtype()), _lengths_of(mask), gc)
+        return ops.btc_to_bct(y)

@@ -330,7 +330,7 @@ def attention_fwd(q, k, v, pos, bias_u, bias_v, lengths, heads, variant, save_pr
 
 
 def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, variant, dq, dk_, dv, du_out=None,
-                  dvb_out=None):
+                  dvb_out=None, drop_p=0.0, drop_seed=0):
     """dq/dk_/dv: preallocated (B,T,C) views sharing a row stride (slices of a
     (B,T,3C) buffer).  Returns (dpos (L,C) f32 or None, du, dvb)."""
     _need_gpu(q)
@@ -350,7 +350,8 @@ def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, var
                                        _ptr(dctx), _ptr(dS), _ptr(dq), _ptr(dk_), _ptr(dv), _ptr(dpos), _ptr(du),
                                        _ptr(dvb), _ptr(lengths), B, T, heads, dkh, _ld(q),
                                        pos.stride(0) if pos is not None else 0, C, _ld(dq), _VARIANT[variant],
-                                       dtype_code(q.dtype), *reduction_scratch(q.device), _stream()),
+                                       float(drop_p), int(drop_seed), dtype_code(q.dtype),
+                                       *reduction_scratch(q.device), _stream()),
         "ptpp_attention_bwd",
     )
     return dpos, du, dvb

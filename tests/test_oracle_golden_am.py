@@ -224,6 +224,35 @@ def test_model_infer_single_utterance():
     assert rel_err(re_, g["gen_ref_emb"]) < 2e-5
 
 
+def test_transformer_plugin():
+    """modules/transformer.py: both attention flavours, with and without the per-layer conditioning g, and gradients."""
+    g = load_golden("transformer")
+    mask = R.sequence_mask(g["lens"], g["x"].shape[-1]).unsqueeze(1).float()
+    for tag, rel in (("rel", True), ("abs", False)):
+        sd = synth_sd(key_shapes(g[f"{tag}_keys"]), 510 + int(rel), {"emb_rel_k": 0.5, "emb_rel_v": 0.5}, prefix="t.")
+        assert rel_err(R.transformer(sd, "t", g["x"], mask, use_rel=rel), g[f"{tag}_y"]) < 2e-5
+        assert rel_err(R.transformer(sd, "t", g["x"], mask, use_rel=rel, g=g["g"]), g[f"{tag}_yg"]) < 2e-5
+        names = [k[len(tag) + 3:] for k in g if k.startswith(f"{tag}_g:")]
+        for n in names:
+            sd["t." + n] = sd["t." + n].clone().requires_grad_()
+        xx = g["x"].clone().requires_grad_()
+        grads = torch.autograd.grad(R.transformer(sd, "t", xx, mask, use_rel=rel), [xx] + [sd["t." + n] for n in names], g["dy"])
+        assert rel_err(grads[0], g[f"{tag}_dx"]) < 2e-5
+        for n, gr in zip(names, grads[1:]):
+            ref = g[f"{tag}_g:{n}"]
+            if gr.numel() > 70000:
+                gr = gr.flatten()[:: max(1, gr.numel() // 4096)][:4096]
+            assert rel_err(gr, ref.reshape(gr.shape)) < 5e-5, n
+
+
+def test_plms_sampler():
+    g = load_golden("diffusion_plms")
+    sd = synth_sd(key_shapes(g["keys"]), 90, prefix="dec.")
+    for interval in (10, 25):
+        mel = R.diffusion_sample_plms(sd, "dec", g["cond"].transpose(1, 2), g["x_init"], interval)
+        assert rel_err(mel.transpose(1, 2), g[f"mel_{interval}"]) < 1e-4, interval
+
+
 def test_nsf_source_and_f0_vocoder():
     from test_oracle_golden import vocoder_sd
 
