@@ -29,12 +29,27 @@ warnings.simplefilter("ignore")
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-# HBM bytes per launch of the dominant kernel (conv1d_cl_kernel<bf16>, 128 x 128 tiles), from the PMC
-# passes of this same command committed as profiles/r01_pmc_final_hbm.txt: FETCH_SIZE 27 434 KiB
-# (doubled: gfx950 tallies 128-byte requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE 27 743 KiB,
-# means over the 476 launches of that instantiation in the profiled steps.
-# bench.py cannot run rocprofv3 on itself, so the roofline line carries this measured constant.
-CONV_TRAFFIC_BYTES_PER_LAUNCH = (2 * 27433.6 + 27743.3) * 1024
+# HBM traffic comes from PMC passes (bench.py cannot run rocprofv3 on itself): the committed summaries of
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command / of tools/bench_vocoder.py, written by
+# tools/pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md; the JSON line names the file it read.
+TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r02_hbm_traffic_train.json")
+TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r02_hbm_traffic_bigvgan.json")
+
+
+def measured_traffic(path, kernel_substr=None):
+    """(bytes, provenance) from a committed PMC summary: mean bytes per launch of the kernel whose name contains
+    ``kernel_substr``, or the total per pass of the profiled workload when it is None; (None, reason) if absent."""
+    try:
+        d = json.load(open(path))
+    except OSError as e:
+        return None, f"{os.path.basename(path)} missing ({e.__class__.__name__})"
+    src = f"profiles/{os.path.basename(path)} ({d.get('collected', 'PMC passes')}; command: {d.get('command', '?')})"
+    if kernel_substr is None:
+        return d.get("total_traffic_bytes_per_pass"), src
+    for name, v in d["kernels"].items():
+        if kernel_substr in name:
+            return v["traffic_bytes"], src + f"; mean over {v['launches']} launches of {name[:70]}"
+    return None, src + f"; no kernel matching {kernel_substr!r}"
 
 
 def parse():
@@ -48,6 +63,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--voc-batch", type=int, default=64)
     ap.add_argument("--voc-frames", type=int, default=1000)
+    ap.add_argument("--no-app", action="store_true", help="skip the prompt -> waveform leg (BASELINE config 5)")
     return ap.parse_args()
 
 
@@ -155,9 +171,11 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
     tot_flop = sum(f for _, _, f in recs)
     ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else 157.3
+    traffic, traffic_src = measured_traffic(TRAFFIC_TRAIN, "conv1d_cl_kernel<unsigned short, 8, 4, 2, 2, 16") \
+        if dtype_name == "bf16" else (None, "no PMC pass for the f32 mode")
     return {"bound": "mfma", "kernel": "conv1d_cl_kernel<%s>, 128x128 tiles (frame-level fwd + dgrad launches of one step)" % dtype_name,
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": round(CONV_TRAFFIC_BYTES_PER_LAUNCH) if dtype_name == "bf16" else None,
+            "traffic": traffic, "traffic_source": traffic_src,
             "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
             "flop_per_step": tot_flop}
 
@@ -168,11 +186,9 @@ def cpu_baseline(model, batch):
     bench batch, ~8 k frames; one warm-up step + one timed step)."""
     from oracle import ref_torch as R
 
-    ncores = os.cpu_count() or 1
     # (more threads than ~32 make this many-small-ops workload SLOWER on the 256-thread GPU host:
     #  measured 0.35 / 0.59 / 1.30 s per step at 16 / 32 / 64 threads for 2 utterances)
-    nthr = int(os.environ.get("PTPP_CPU_THREADS", min(ncores, 32)))
-    torch.set_num_threads(nthr)
+    nthr, ncores = _cpu_threads()
     n = min(16, batch[0].shape[0])
     phon, dur, plen, mel, cf0, vuv, energy, flen, (ids, am) = [x if isinstance(x, tuple) else x[:n].cpu() for x in batch]
     ids, am = ids[:n].cpu(), am[:n].cpu()
@@ -203,15 +219,20 @@ def cpu_baseline(model, batch):
                       f"({best:.2f} s/step; host has {ncores} logical cores)"}
 
 
-def vocoder_leg(dev, batch, frames, dtype):
-    from promptttspp_amd.vocoders import BigVGAN
-
-    torch.manual_seed(7)
-    voc = BigVGAN(80, 512, [6, 5, 4, 2], [12, 10, 8, 4], [3, 7, 11], [[1, 3, 5]] * 3).to(dev).eval().set_compute_dtype(dtype)
+def _tame_gain(voc):
     with torch.no_grad():
         for name, p in voc.named_parameters():
             if name.endswith("weight_g"):
                 p.mul_(0.4)  # keep the random-init generator off the tanh rails
+    return voc
+
+
+def vocoder_leg(dev, batch, frames, dtype):
+    """BASELINE config 4: BigVGAN 24 kHz, batch x frames mel frames.  Returns (seconds per batch, generator)."""
+    from promptttspp_amd.vocoders import BigVGAN
+
+    torch.manual_seed(7)
+    voc = _tame_gain(BigVGAN(80, 512, [6, 5, 4, 2], [12, 10, 8, 4], [3, 7, 11], [[1, 3, 5]] * 3)).to(dev).eval().set_compute_dtype(dtype)
     x = torch.clamp(-5.5 + 2.1 * torch.randn(batch, 80, frames, device=dev), -11.5, 2.0)
     for _ in range(2):
         voc(x)
@@ -221,7 +242,148 @@ def vocoder_leg(dev, batch, frames, dtype):
     for _ in range(iters):
         voc(x)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters
+    return (time.perf_counter() - t0) / iters, voc
+
+
+def _cpu_threads():
+    ncores = os.cpu_count() or 1
+    nthr = int(os.environ.get("PTPP_CPU_THREADS", min(ncores, 32)))
+    torch.set_num_threads(nthr)
+    return nthr, ncores
+
+
+def vocoder_cpu_baseline(voc, frames):
+    """The oracle's BigVGAN (CPU restatement of vocoders/bigvgan.py, fp32) on the host cores on a BOUNDED sample:
+    2 utterances of `frames` frames (SURVEY section 8d asks for 8 x 10 s; 2 x 10 s keeps the default bench run short --
+    the vocoder is batch-parallel, so the real-time factor carries over)."""
+    from oracle import ref_torch as R
+
+    nthr, ncores = _cpu_threads()
+    sd = {k: v.detach().float().cpu() for k, v in voc.state_dict().items()}
+    x = torch.clamp(-5.5 + 2.1 * torch.randn(2, 80, frames), -11.5, 2.0)
+    with torch.no_grad():
+        R.bigvgan(sd, x[:1, :, :100])  # warm-up
+        t0 = time.perf_counter()
+        R.bigvgan(sd, x)
+        dt = time.perf_counter() - t0
+    audio = 2 * frames * 0.01
+    return {"value": round(dt / audio, 5), "unit": "RTF (s compute per s of 24 kHz audio; lower is better)", "cores": nthr,
+            "kind": "port", "sample": f"2 x {frames} frames ({audio:.0f} s of audio) in {dt:.1f} s, fp32; host has {ncores} logical cores"}
+
+
+def _tame_durations(model):
+    """A random-init duration head predicts exp(mu + sigma^2/2) of anything: give it the statistics of a
+    trained one (about 5 frames per phone) so that the synthetic prompts produce LibriTTS-R-shaped mels."""
+    with torch.no_grad():
+        ol = model.variance_adaptor.duration_predictor.out_layer
+        ol.mu.weight.mul_(0.05)
+        ol.mu.bias.fill_(1.6)
+        ol.log_sigma.weight.mul_(0.05)
+        ol.log_sigma.bias.fill_(-1.5)
+    return model
+
+
+def app_inputs(n, seed=0):
+    import numpy as np
+
+    r = np.random.default_rng(seed)
+    tp = r.integers(40, 121, size=n)
+    ph = torch.zeros(n, int(tp.max()), dtype=torch.long)
+    for i, L in enumerate(tp):
+        ph[i, :L] = torch.from_numpy(np.concatenate([[1], r.integers(3, 90, size=int(L) - 2), [2]]))
+    Lp = r.integers(12, 49, size=n)
+    ids = torch.zeros(n, int(Lp.max()), dtype=torch.long)
+    am = torch.zeros_like(ids)
+    for i, L in enumerate(Lp):
+        ids[i, 0], ids[i, L - 1] = 101, 102
+        ids[i, 1 : L - 1] = torch.from_numpy(r.integers(1000, 30000, size=int(L) - 2))
+        am[i, :L] = 1
+    return ph, torch.from_numpy(tp), ids, am
+
+
+def app_leg(dev, dtype, n_prompts=32):
+    """BASELINE config 5: prompt -> waveform for 32 prompts, phone sequences Tp ~ U{40..120}: infer_batch (use_max,
+    noise_scale 0.5, 100-step sampler) -> zero-phase low-pass of log-F0 -> F0-aware BigVGAN.  bf16 decoder / vocoder,
+    f32 duration / MDN heads.  Returns a dict incl. the sampler's share, and the models for the CPU baseline."""
+    from promptttspp.utils.model import lowpass_filter
+    from promptttspp_amd import hydra_lite as H
+    from promptttspp_amd.modules.prompt_encoder import allow_random_bert
+
+    conf = os.path.join(ROOT, "egs", "proposed", "bin", "conf")
+    torch.manual_seed(11)
+    with allow_random_bert():
+        model = _tame_durations(H.instantiate(H.load_node(os.path.join(conf, "model", "prompttts_mdn_v2_wo_erg_final.yaml")))).to(dev).eval()
+    voc = _tame_gain(H.instantiate(H.load_node(os.path.join(conf, "vocoder", "bigvgan_f0.yaml")))).to(dev).eval()
+    voc.set_compute_dtype(dtype)
+    ph, pl, ids, am = app_inputs(n_prompts)
+    ph, pl, prm = ph.to(dev), pl.to(dev), (ids.to(dev), am.to(dev))
+    tsamp = [0.0]
+    dec = model.decoder
+    orig = dec.inference_cl
+
+    def timed_sampler(*a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = orig(*a, **k)
+        torch.cuda.synchronize()
+        tsamp[0] += time.perf_counter() - t0
+        return out
+
+    def run():
+        with torch.no_grad():
+            mel, cf0, vuv, flen = model.infer_batch(ph, pl, style_prompt=prm, use_max=True, noise_scale=0.5, return_f0=True)
+            f0 = lowpass_filter(cf0, 100, cutoff=20).exp()
+            f0[vuv < 0.5] = 0
+            wav = voc(mel, f0)
+        return mel, flen, wav
+
+    for _ in range(2):
+        run()
+    dec.inference_cl = timed_sampler
+    torch.cuda.synchronize()
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        mel, flen, wav = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    dec.inference_cl = orig
+    frames = int(flen.sum())
+    res = {"prompts": n_prompts, "ms_per_batch": round(1e3 * dt, 2), "valid_frames": frames, "audio_s": round(frames * 0.01, 1),
+           "rtf": dt / (frames * 0.01), "sampler_ms": round(1e3 * tsamp[0] / n, 2), "padded_mel": list(mel.shape),
+           "finite": bool(torch.isfinite(wav).all())}
+    return res, model, voc
+
+
+def app_cpu_baseline(model, voc, n_prompts=2):
+    """The oracle's prompt -> waveform path on the host cores for a BOUNDED sample (2 prompts; SURVEY section 8d asks for
+    4): encoder + prompt branch + variance adaptor + the 100-step sampler + low-pass + NSF source + F0-aware BigVGAN."""
+    import numpy as np
+    from scipy import signal
+
+    from oracle import ref_torch as R
+
+    nthr, ncores = _cpu_threads()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    sdv = {k: v.detach().float().cpu() for k, v in voc.state_dict().items()}
+    ph, pl, ids, am = app_inputs(n_prompts, seed=1)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        mel, cf0, vuv, flen, _ = R.model_infer_batch(
+            sd, ph, pl, lambda b, t: torch.randn(b, 80, t, generator=g), lambda b, t: [torch.randn(b, 80, t, generator=g) for _ in range(100)],
+            ids=ids, am=am, style_noise=torch.randn(n_prompts, 1, 256, generator=g), noise_scale=0.5)
+        b, a = signal.butter(5, [20 / 50], "lowpass")
+        f0 = torch.from_numpy(np.ascontiguousarray(R.filtfilt_zero_state(cf0.numpy(), b, a))).float().exp()
+        f0[vuv < 0.5] = 0
+        L = f0.shape[-1] * 240
+        src = R.nsf_source(sdv, f0, torch.rand(n_prompts, 9, generator=g), torch.randn(n_prompts, L, 9, generator=g))
+        R.bigvgan(sdv, mel, source=src)
+        dt = time.perf_counter() - t0
+    frames = int(flen.sum())
+    return {"value": round(dt / (frames * 0.01), 4), "unit": "RTF (s compute per s of audio; lower is better)", "cores": nthr,
+            "kind": "port", "sample": f"{n_prompts} prompts, {frames} frames ({frames * 0.01:.1f} s of audio) in {dt:.1f} s, fp32; "
+                                      f"host has {ncores} logical cores"}
 
 
 # ------------------------------------------------------------------------------------------
@@ -326,8 +488,9 @@ def main():
         dt, frames = float(tmax[0]), float(tt[1])
 
     voc = None
+    voc_model = None
     if not a.no_vocoder:
-        vdt = vocoder_leg(dev, a.voc_batch, a.voc_frames, dtype)
+        vdt, voc_model = vocoder_leg(dev, a.voc_batch, a.voc_frames, dtype)
         if world > 1:
             import torch.distributed as dist
 
@@ -335,10 +498,17 @@ def main():
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
             vdt = float(v[0])
         audio_s = a.voc_batch * a.voc_frames * 0.01 * world
+        # algorithmic bytes of SURVEY section 8d: 789 312 activation elements per mel frame (every conv reads its input and
+        # writes its output once, Snake / residual / block mean fused away)
+        alg_bytes = a.voc_batch * a.voc_frames * 789312 * (2 if a.dtype == "bf16" else 4)
+        ach = alg_bytes / vdt / 1e9
+        traffic, tsrc = measured_traffic(TRAFFIC_VOC) if (a.dtype == "bf16" and a.voc_batch == 64 and a.voc_frames == 1000) \
+            else (None, "PMC summary is for 64 x 1000 frames bf16 only")
         voc = {"rtf": vdt / audio_s, "ms_per_batch": 1e3 * vdt, "batch": a.voc_batch, "frames": a.voc_frames,
                "algorithmic_tflops": world * a.voc_batch * a.voc_frames * 444.5e6 / vdt / 1e12,
-               "algorithmic_hbm_gbs": world * a.voc_batch * a.voc_frames * 789312 * (2 if a.dtype == "bf16" else 4) / vdt / 1e9,
-               "hbm_frac_of_peak": world * a.voc_batch * a.voc_frames * 789312 * (2 if a.dtype == "bf16" else 4) / vdt / 1e9 / (HBM_PEAK_GBS * world)}
+               "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg_bytes, "traffic": traffic,
+                            "traffic_source": tsrc, "per": "one forward of the whole generator on one GPU"}}
 
     log("vocoder leg done")
     # the instrumented step contains the gradient all-reduce: EVERY rank runs it, rank 0 reports
@@ -348,8 +518,20 @@ def main():
     roof = conv_roofline(model, batches[rb], red, opt, sched, a.dtype)
     if rank == 0:
         log(f"roofline pass done: {roof['achieved']} TFLOP/s")
-        cpu = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(model, batches[a.warmup])  # N = 1 only
+        one = not (a.no_cpu_baseline or world > 1)  # the CPU baselines run on rank 0 at N = 1 only
+        cpu = cpu_baseline(model, batches[a.warmup]) if one else None
         log("cpu baseline done")
+        if voc is not None and one:
+            voc["cpu_baseline"] = vocoder_cpu_baseline(voc_model, a.voc_frames)
+            log("vocoder cpu baseline done")
+        app = None
+        if not a.no_app and world == 1:
+            del voc_model
+            app, app_model, app_voc = app_leg(dev, dtype)
+            log(f"app leg done: {app['ms_per_batch']} ms")
+            if one:
+                app["cpu_baseline"] = app_cpu_baseline(app_model, app_voc)
+                log("app cpu baseline done")
         B = batches[a.warmup][0].shape[0]
         line = {
             "metric": "mel-frames/sec (train)", "value": round(frames / dt, 1), "unit": "mel-frames/sec",
@@ -361,6 +543,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "per_gpu_value": round(frames / dt / world, 1),
             "bigvgan": voc,
+            "app_path": app,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

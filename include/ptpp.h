@@ -394,6 +394,15 @@ int ptpp_add3_scale(const void* a, const void* b, const void* c, void* y,
 int ptpp_conv_post_tanh(const void* x, const float* w, float bias, float* y,
                         int B, int T, int C, int ks, int dtype, void* stream);
 
+/* Zero-phase IIR low-pass of the predicted log-F0 tracks (utils/model.py:164-196, called at app.py:77 /
+ * synthesize.py:131): y = flip(lfilter(flip(lfilter(x)))) with zero initial state -- the arithmetic of
+ * torchaudio.functional.filtfilt(x, a, b, clamp=False), which the reference uses for tensors.
+ *   x, y: rows x T f32 (row stride ldx); lengths (nullable): per-row valid length (the rest is copied);
+ *   b, a: HOST coefficient arrays of order + 1 doubles; tmp: rows * T doubles of device scratch. */
+int ptpp_filtfilt(const float* x, float* y, double* tmp, const int32_t* lengths,
+                  const double* b, const double* a, int order, int rows, int T,
+                  int ldx, void* stream);
+
 /* Layout bridges between the reference's (B, C, T) f32 tensors and the
  * library's channels-last (B, T, C) `dtype` tensors. */
 int ptpp_bct_to_btc(const float* x, void* y, int B, int C, int T, int dtype,

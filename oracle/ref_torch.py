@@ -748,3 +748,61 @@ def model_infer_batch(sd, phoneme, plen, x_init_fn, step_noise_fn, ids=None, am=
     B, Tf = h.shape[0], h.shape[-1]
     mel = diffusion_sample(sd, "decoder", h, x_init_fn(B, Tf), step_noise_fn(B, Tf)) * fm
     return mel, cf0, vuv, flen, dur
+
+
+# --------------------------------------------------------------------------
+# Data-side neighbours of the path.  Third-party arithmetic: both live in torchaudio
+# (un-vendored, README pins 0.11.0, absent here) -- restated from its published algorithm, PARITY UNPINNED against
+# torchaudio itself; pinned against torch.stft / scipy.signal.lfilter in tests/test_oracle_golden.py.
+# --------------------------------------------------------------------------
+
+
+def mel_spectrogram_np(wav, sample_rate=24000, n_fft=512, win_length=480, hop_length=240, f_min=63.0, f_max=12000.0,
+                       n_mels=80):
+    """log-mel of transforms/mel.py:18-34 with conf/transforms/mel.yaml: numpy restatement (reflect-padded, centred
+    periodic-Hann frames -> rfft -> |.|^2 -> slaney filterbank, slaney norm -> log(clamp 1e-5)).  wav (L,) -> (80, F)."""
+    import numpy as np
+
+    x = np.pad(np.asarray(wav, dtype=np.float64), n_fft // 2, mode="reflect")
+    nfr = 1 + (len(x) - n_fft) // hop_length
+    win = np.zeros(n_fft)
+    off = (n_fft - win_length) // 2
+    win[off : off + win_length] = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(win_length) / win_length)  # periodic Hann
+    fr = np.stack([x[i * hop_length : i * hop_length + n_fft] * win for i in range(nfr)])
+    spec = np.abs(np.fft.rfft(fr, axis=1)) ** 2                       # (F, bins)
+    # slaney mel scale: linear below 1 kHz (200/3 Hz per mel), logarithmic above (27 steps per factor 6.4)
+    def hz2mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-9) / 1000.0) / (np.log(6.4) / 27.0), f * 3.0 / 200.0)
+
+    def mel2hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), m * 200.0 / 3.0)
+
+    freqs = np.linspace(0, sample_rate // 2, n_fft // 2 + 1)
+    fpts = mel2hz(np.linspace(hz2mel(f_min), hz2mel(f_max), n_mels + 2))
+    fdiff = np.diff(fpts)
+    slopes = fpts[None, :] - freqs[:, None]
+    fb = np.maximum(0.0, np.minimum(-slopes[:, :-2] / fdiff[:-1], slopes[:, 2:] / fdiff[1:]))
+    fb = fb * (2.0 / (fpts[2:] - fpts[:-2]))[None, :]
+    return np.log(np.maximum(spec @ fb, 1e-5)).T
+
+
+def filtfilt_zero_state(x, b, a):
+    """torchaudio.functional.filtfilt(x, a, b, clamp=False): lfilter forward, on the time-reversed result, reversed
+    again; direct form, zero initial state (NOT scipy.signal.filtfilt, which pads the edges).  numpy, last axis."""
+    import numpy as np
+
+    def lfilter(v):
+        v = np.asarray(v, dtype=np.float64)
+        y = np.zeros_like(v)
+        n = len(b) - 1
+        for t in range(v.shape[-1]):
+            acc = b[0] * v[..., t]
+            for k in range(1, n + 1):
+                if t - k >= 0:
+                    acc = acc + b[k] * v[..., t - k] - a[k] * y[..., t - k]
+            y[..., t] = acc / a[0]
+        return y
+
+    return lfilter(lfilter(x)[..., ::-1])[..., ::-1]

@@ -102,6 +102,7 @@ SIGNATURES = {
     "ptpp_amp_layer_fwd": (I, [POINTER(AmpLayerArgs), P]),
     "ptpp_add3_scale": (I, [P, P, P, P, F, I64, I, P]),
     "ptpp_conv_post_tanh": (I, [P, P, F, P, I, I, I, I, I, P]),
+    "ptpp_filtfilt": (I, [P, P, P, P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), I, I, I, I, P]),
     "ptpp_bct_to_btc": (I, [P, P, I, I, I, I, P]),
     "ptpp_btc_to_bct": (I, [P, P, I, I, I, I, P]),
     "ptpp_grad_sumsq": (I, [P, I, P, c_longlong, P, P]),

@@ -83,6 +83,44 @@ extern "C" int ptpp_conv_post_tanh(const void* x, const float* w, float bias, fl
 // One call instead of torch's event-record + wait_event + stream-guard round trip (~25 us of host time
 // per weight-gradient launch, ~110 per training step).  Events come from a per-device ring long enough that an
 // event is not re-recorded while a wait on it can still be pending.
+// ---- zero-phase IIR (forward, time-reverse, forward, time-reverse; zero initial state) --------------------
+// torchaudio.functional.filtfilt(x, a, b, clamp=False), which the reference applies to the predicted log-F0 track
+// (utils/model.py:187-192: 5th-order Butterworth, fs = 100 Hz, fc = 20 Hz).  The recurrence is sequential in time
+// and the tracks are short ((B, 1, T) at 100 frames/s): one thread per row walks it twice in double precision, the
+// intermediate in a caller-provided f64 row.  Rows past their length stay untouched (copied).
+constexpr int IIR_MAXORD = 8;
+struct IirP {
+  double b[IIR_MAXORD + 1], a[IIR_MAXORD + 1];
+  int order;
+};
+__global__ void filtfilt_kernel(const float* __restrict__ x, float* __restrict__ y, double* __restrict__ tmp,
+                                const int* __restrict__ lengths, IirP f, int rows, int T, int ldx) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int n = lengths ? min(lengths[r], T) : T;
+  const float* xr = x + (int64_t)r * ldx;
+  float* yr = y + (int64_t)r * ldx;
+  double* tr = tmp + (int64_t)r * T;
+  double z[IIR_MAXORD];
+  // direct form II transposed: y = b0 x + z0; z_i = b_{i+1} x + z_{i+1} - a_{i+1} y
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < IIR_MAXORD; ++i) z[i] = 0.0;
+    for (int t = 0; t < n; ++t) {
+      const int src = pass == 0 ? t : n - 1 - t;  // second pass runs over the time-reversed first result
+      const double xv = pass == 0 ? (double)xr[src] : tr[src];
+      const double yv = f.b[0] * xv + z[0];
+#pragma unroll
+      for (int i = 0; i < IIR_MAXORD; ++i) {
+        if (i < f.order) z[i] = f.b[i + 1] * xv + (i + 1 < f.order ? z[i + 1] : 0.0) - f.a[i + 1] * yv;
+      }
+      if (pass == 0) tr[src] = yv;
+      else yr[src] = (float)yv;
+    }
+  }
+  for (int t = n; t < T; ++t) yr[t] = xr[t];
+}
+
 namespace {
 constexpr int EV_RING = 1024, EV_DEVS = 16;  // (re-recording an event that still has a pending wait is slow on HIP: keep the ring long)
 hipEvent_t g_ev[EV_DEVS][EV_RING];
@@ -112,5 +150,23 @@ extern "C" int ptpp_stream_wait(void* waiter, void* signaler) {
     ptpp_set_error("stream_wait: %s", hipGetErrorString(hipGetLastError()));
     return PTPP_ELAUNCH;
   }
+  return PTPP_OK;
+}
+
+// b, a: HOST arrays of order + 1 coefficients (a[0] is divided out); tmp: rows * T doubles of device scratch
+extern "C" int ptpp_filtfilt(const float* x, float* y, double* tmp, const int32_t* lengths, const double* b,
+                             const double* a, int order, int rows, int T, int ldx, void* stream) {
+  PTPP_CHECK_ARG(x && y && tmp && b && a, "filtfilt: null pointer");
+  PTPP_CHECK_ARG(order >= 1 && order <= IIR_MAXORD && a[0] != 0.0, "filtfilt: order %d not in 1..%d", order, IIR_MAXORD);
+  PTPP_CHECK_ARG(rows > 0 && T > 0 && ldx >= T, "filtfilt: bad shape rows=%d T=%d ld=%d", rows, T, ldx);
+  IirP f;
+  f.order = order;
+  for (int i = 0; i <= IIR_MAXORD; ++i) {
+    f.b[i] = i <= order ? b[i] / a[0] : 0.0;
+    f.a[i] = i <= order ? a[i] / a[0] : 0.0;
+  }
+  hipLaunchKernelGGL(filtfilt_kernel, dim3((rows + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), x, y, tmp,
+                     lengths, f, rows, T, ldx);
+  PTPP_CHECK_LAUNCH("filtfilt");
   return PTPP_OK;
 }

@@ -503,6 +503,23 @@ def conv_post_tanh(x, w, bias):
     return y
 
 
+def filtfilt(x, b, a, lengths=None):
+    """Zero-phase IIR along the last axis of a contiguous f32 tensor (..., T) on the device (ptpp_filtfilt);
+    b, a: coefficient sequences (host).  No host synchronisation."""
+    _need_gpu(x)
+    x = x.contiguous().float()
+    T = x.shape[-1]
+    rows = x.numel() // T
+    y = torch.empty_like(x)
+    tmp = torch.empty(rows * T, device=x.device, dtype=torch.float64)
+    n = len(b) - 1
+    assert len(a) == len(b)
+    bb, aa = (ctypes.c_double * (n + 1))(*map(float, b)), (ctypes.c_double * (n + 1))(*map(float, a))
+    check(_lib.load().ptpp_filtfilt(_ptr(x), _ptr(y), _ptr(tmp), _ptr(i32(lengths, x.device)) if lengths is not None else None,
+                                    bb, aa, n, rows, T, T, _stream()), "ptpp_filtfilt")
+    return y
+
+
 def bct_to_btc(x, dtype):
     """(B, C, T) f32 -> (B, T, C) ``dtype`` (the boundary transpose)."""
     _need_gpu(x)

@@ -86,7 +86,8 @@ def lowpass_filter(x, fs=100, cutoff=20, N=5):
     (not scipy.signal.filtfilt's edge padding).  torchaudio is an un-vendored,
     absent dependency: that published algorithm is restated here (parity for this
     helper is therefore unpinned); numpy inputs keep
-    scipy.signal.filtfilt like the reference.  (B,1,T) at 100 Hz: host-side.
+    scipy.signal.filtfilt like the reference.  Device tensors are filtered by the
+    ``ptpp_filtfilt`` kernel (double precision, no host synchronisation); CPU tensors by scipy.
     """
     from scipy import signal
 
@@ -95,6 +96,10 @@ def lowpass_filter(x, fs=100, cutoff=20, N=5):
     if x.shape[-1] <= max(len(a), len(b)) * (N // 2 + 1):
         return x  # too short to filter
     if isinstance(x, torch.Tensor):
+        if x.is_cuda:  # on the device, no host round trip / synchronisation (ptpp_filtfilt)
+            from .. import ops
+
+            return ops.filtfilt(x, b, a).to(x.dtype)
         xn = x.detach().double().cpu().numpy()
         y = _lfilter_zero_state(b, a, xn)
         y = _lfilter_zero_state(b, a, y[..., ::-1])[..., ::-1]

@@ -587,3 +587,34 @@ def test_fused_amp_layer_equals_the_four_launch_pipeline_bf16(dev):
         assert float((y.float() - ref.float()).abs().mean() / ref.float().abs().mean()) < 5e-3
         assert torch.equal(y, ops.amp_layer(x, wp[0], b[0], wp[1], b[1], la[0], la[1], taps, taps, ks, d))
         assert torch.equal(y[1:2], ops.amp_layer(x[1:2].contiguous(), wp[0], b[0], wp[1], b[1], la[0], la[1], taps, taps, ks, d))
+
+
+def test_mel_front_end_and_lowpass_on_device(dev):
+    """n1 / n2 on the GPU: the log-mel front-end on the exact-f32 GEMM (windowed DFT and filterbank as two products)
+    and the zero-phase IIR kernel, against the oracle's numpy restatements."""
+    from scipy import signal
+
+    from promptttspp.transforms import MelSpectrogramTransform
+    from promptttspp.utils.model import lowpass_filter
+
+    rng = np.random.default_rng(11)
+    t = MelSpectrogramTransform(sample_rate=24000, n_fft=512, win_length=480, hop_length=240, f_min=63.0, f_max=12000.0,
+                                n_mels=80, norm="slaney", mel_scale="slaney").to(dev)
+    for L in (24000, 7777, 600):
+        wav = (0.3 * rng.standard_normal((2, L))).astype(np.float32)
+        mel = t(torch.from_numpy(wav).to(dev)).cpu()
+        assert mel.shape == (2, 80, 1 + L // 240)
+        for i in range(2):
+            ref = torch.from_numpy(R.mel_spectrogram_np(wav[i]))
+            assert float((mel[i].double() - ref).abs().max()) < 1e-3, L      # log-mel, absolute
+        spec = t.to_spec(torch.from_numpy(wav).to(dev)).cpu()
+        cpu_spec = t.cpu().to_spec(torch.from_numpy(wav))
+        t.to(dev)
+        assert rel_err(spec, cpu_spec) < 1e-4
+
+    b, a = signal.butter(5, [20 / 50], "lowpass")
+    for shape in ((32, 1, 539), (1, 1, 61), (3, 1, 18)):
+        x = (5.2 + 0.3 * rng.standard_normal(shape)).astype(np.float32)
+        y = lowpass_filter(torch.from_numpy(x).to(dev), 100, cutoff=20).cpu()
+        ref = x if shape[-1] <= 18 else R.filtfilt_zero_state(x, b, a)
+        assert float((y.double() - torch.from_numpy(np.ascontiguousarray(ref))).abs().max()) < 2e-6, shape

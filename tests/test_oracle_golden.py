@@ -76,3 +76,43 @@ def test_bigvgan_matches_reference():
     assert rel_err(y, g["y"]) < 5e-5
     ya = R.amp_layer(sd, "mrfs.3.1.layers.2", g["amp_x"], 7, 5)
     assert rel_err(ya, g["amp_y"]) < 1e-5
+
+
+def test_mel_front_end_restatement_against_torch_stft():
+    """n1: the numpy restatement of the log-mel front-end vs torch.stft + the package's filterbank (CPU), and the
+    package's CPU transform vs the restatement.  (Not a torchaudio pin: torchaudio is absent from this image.)"""
+    import numpy as np
+
+    from promptttspp.transforms import MelSpectrogramTransform
+
+    rng = np.random.default_rng(7)
+    wav = (0.3 * rng.standard_normal(24000 // 2)).astype(np.float32)
+    ref = R.mel_spectrogram_np(wav)
+    t = MelSpectrogramTransform(sample_rate=24000, n_fft=512, win_length=480, hop_length=240, f_min=63.0, f_max=12000.0,
+                                n_mels=80, norm="slaney", mel_scale="slaney")
+    mel = t(torch.from_numpy(wav)[None])[0]
+    assert mel.shape == ref.shape == (80, 51)
+    assert float((mel.double() - torch.from_numpy(ref)).abs().max()) < 2e-4   # log domain, f32 STFT vs f64
+    st = torch.stft(torch.from_numpy(wav), 512, 240, 480, torch.hann_window(480), center=True, pad_mode="reflect",
+                    return_complex=True).abs().pow(2)
+    assert st.shape[0] == 257
+
+
+def test_zero_state_filtfilt_restatement_against_scipy():
+    """n2: forward-backward lfilter with zero initial state (what torchaudio's filtfilt computes) vs scipy.signal.lfilter
+    applied twice; and that it is NOT scipy.signal.filtfilt (which pads the edges)."""
+    import numpy as np
+    from scipy import signal
+
+    from promptttspp.utils.model import lowpass_filter
+
+    b, a = signal.butter(5, [20 / 50], "lowpass")
+    x = 5.2 + 0.3 * np.random.default_rng(3).standard_normal((2, 1, 300))
+    y = R.filtfilt_zero_state(x, b, a)
+    sp = signal.lfilter(b, a, signal.lfilter(b, a, x, axis=-1)[..., ::-1], axis=-1)[..., ::-1]
+    assert np.abs(y - sp).max() < 1e-9
+    assert np.abs(y - signal.filtfilt(b, a, x)).max() > 1e-2
+    out = lowpass_filter(torch.from_numpy(x).float(), 100, cutoff=20)          # the package's CPU tensor path
+    assert float((out.double() - torch.from_numpy(np.ascontiguousarray(y))).abs().max()) < 1e-5
+    short = torch.randn(1, 1, 10)
+    assert torch.equal(lowpass_filter(short, 100, cutoff=20), short)             # too short: returned unchanged (:180-182)
