@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "conv1d_common.h"
+#include "conv1d_glds.h"
 
 namespace {
 
@@ -208,8 +209,10 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p) 
     for (int s = 1; s < p.nsplit; ++s) v += *reinterpret_cast<const f32x4*>(p.ws + s * slab + row * p.Cout + co);
     const bool keep = !(p.out_mask && t >= min(p.lengths[b], p.T));
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+    act_dispatch(p.act, [&](auto tag) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = keep ? act_apply(v[e], p.act) * p.out_scale : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = keep ? act_apply_c<decltype(tag)::value>(v[e]) * p.out_scale : 0.f;
+    });
     if (p.drop_thresh16) v *= drop_mask4(p.drop_seed, (uint64_t)(row * p.Cout + co) >> 2, p.drop_thresh16, p.drop_inv_keep);
     if (p.res) v += Elem<T>::ld4(reinterpret_cast<const T*>(p.res) + row * p.ldr + co) * p.res_scale;
     if (p.res2) v += Elem<T>::ld4(reinterpret_cast<const T*>(p.res2) + row * p.ldr2 + co);
@@ -374,18 +377,16 @@ int launch_tiles(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes) {
     if (launch_splitk<T, NCH, 2, 2, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
     return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);
   }
-  // (64 x 128 and 256 x 64 tiles measured 10-45 % slower on the frame-level shapes)
-  static const char* alt = getenv("PTPP_CONV_TILE");  // experiments: wave-tile shapes of the 128-row configurations
-  if (alt) {
-    switch (alt[0]) {
-      case 'b': return launch_cfg<T, NCH, 2, 4, 2, 8>(p, st);   // 128 x 128,  8 waves of 64 x 32
-      case 'c': return launch_cfg<T, NCH, 4, 2, 4, 8>(p, st);   // 128 x 128,  8 waves of 32 x 64
-      case 'd': return launch_cfg<T, NCH, 2, 4, 4, 4>(p, st);   // 128 x 128,  4 waves of 64 x 64
-      case 'e': return launch_cfg<T, NCH, 4, 4, 2, 16>(p, st);  // 256 x 128, 16 waves of 64 x 32
-      case 'f': return launch_cfg<T, NCH, 2, 4, 4, 8>(p, st);   // 128 x 256,  8 waves of 64 x 64
-      default: break;
+  if constexpr (sizeof(T) == 2 && NCH == 8) {
+    // LDS-DMA pipeline, 8 waves of 64 x 32 (conv1d_glds.h); PTPP_CONV_GLDS=0 keeps the register-staged kernel,
+    // A = 4 waves of 64 x 64 (experiments: profiles/r02_conv_glds.txt)
+    static const char* gl = getenv("PTPP_CONV_GLDS");
+    if (glds_ok(p) && !(gl && gl[0] == '0')) {
+      const int rc = (gl && gl[0] == 'A') ? launch_glds<4, 4, 2, 2, 2>(p, st) : launch_glds<4, 2, 2, 4, 2>(p, st);
+      if (rc >= 0) return rc;
     }
   }
+  // (64 x 128 and 256 x 64 tiles measured 10-45 % slower on the frame-level shapes)
   return launch_cfg<T, NCH, 4, 2, 2, 16>(p, st);                       // 128 x 128, 16 waves of 32 x 32
 }
 

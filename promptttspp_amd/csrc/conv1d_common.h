@@ -52,9 +52,9 @@ struct ConvP {
 // Fused epilogue of one (BM x BN) tile: acc[fm][fn] is the MFMA accumulator of the wave's
 // fragment (fm, fn) with the WEIGHTS as the "A" operand, so a lane holds consecutive output
 // channels of output row t0 + (wm*FM + fm)*16 + (lane & 15).
-template <typename T, int FM, int FN>
-__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FM][FN], int b, int t0, int n0, int wm, int wn,
-                                              int lane, int len) {
+template <typename T, int FM, int FN, int ACT>
+__device__ __forceinline__ void conv_epilogue_act(const ConvP& p, f32x4 (&acc)[FM][FN], int b, int t0, int n0, int wm, int wn,
+                                                  int lane, int len) {
   const int lr = lane & 15, lg = lane >> 4;
   // ---- epilogue: lane holds channels co..co+3 of row t for each fragment ----
   T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * p.T * p.ldy;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
   // (epilogue parameters as local scalars: lambdas that capture the by-value argument block
   //  itself make the compiler keep a copy of it in scratch memory)
   const float* const e_bias = p.bias;
-  const int e_act = p.act, e_T = p.T, e_Cout = p.Cout, e_ldy = p.ldy, e_ldr = p.ldr, e_ldr2 = p.ldr2;
+  const int e_T = p.T, e_Cout = p.Cout, e_ldy = p.ldy, e_ldr = p.ldr, e_ldr2 = p.ldr2;
   const float e_scale = p.out_scale, e_rscale = p.res_scale, e_dinv = p.drop_inv_keep;
   const unsigned e_dth = p.drop_thresh16;
   const unsigned long long e_dseed = p.drop_seed;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
   auto finish4 = [&](f32x4 v, int t, int co, bool keep) {
     if (e_bias) v += *reinterpret_cast<const f32x4*>(e_bias + co);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = keep ? act_apply(v[e], e_act) * e_scale : 0.f;
+    for (int e = 0; e < 4; ++e) v[e] = keep ? act_apply_c<ACT>(v[e], p.act) * e_scale : 0.f;
     if (e_dth)
       v *= drop_mask4(e_dseed, (uint64_t)(((int64_t)b * e_T + t) * e_Cout + co) >> 2, e_dth, e_dinv);
     return v;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
       for (int e = 0; e < 4; ++e) {
         if (co + e < e_Cout) {
           float u = acc4[e] + (e_bias ? e_bias[co + e] : 0.f);
-          u = keep ? act_apply(u, e_act) * e_scale : 0.f;
+          u = keep ? act_apply_c<ACT>(u, p.act) * e_scale : 0.f;
           if (rb) u += Elem<T>::ld(rb + (int64_t)t * e_ldr + co + e) * e_rscale;
           if (r2b) u += Elem<T>::ld(r2b + (int64_t)t * e_ldr2 + co + e);
           Elem<T>::st(yb + (int64_t)t * e_ldy + co + e, u);
@@ -128,7 +128,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
               v1[0] += __uint_as_float(r.z << 16); v1[1] += __uint_as_float(r.z & 0xffff0000u);
               v1[2] += __uint_as_float(r.w << 16); v1[3] += __uint_as_float(r.w & 0xffff0000u);
             }
-            if (e_act == PTPP_ACT_GATE) {
+            if constexpr (ACT == PTPP_ACT_GATE) {
               // fused DiffNet gate: the 8 channels are [4 "gate" | their 4 "filter" partners] (weights
               // packed in that interleaved order); y has Cout / 2 channels
               uint2 o;
@@ -172,6 +172,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
         if (t < e_T && co < e_Cout) out4(acc[fm][fn], t, co, keep);
       }
     }
+  }
+}
+
+// the epilogue specialised for the (wave-uniform) activation: see act_apply_c.  bf16 only: the f32 kernels serve the
+// parity mode, where one generic copy keeps the library small and the build short.
+template <typename T, int FM, int FN>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FM][FN], int b, int t0, int n0, int wm, int wn,
+                                              int lane, int len) {
+  if constexpr (sizeof(T) == 2 && FN % 2 == 0) {
+    act_dispatch(p.act, [&](auto tag) {
+      conv_epilogue_act<T, FM, FN, decltype(tag)::value>(p, acc, b, t0, n0, wm, wn, lane, len);
+    });
+  } else {
+    conv_epilogue_act<T, FM, FN, -1>(p, acc, b, t0, n0, wm, wn, lane, len);
   }
 }
 

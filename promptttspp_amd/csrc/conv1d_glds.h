@@ -1,0 +1,305 @@
+// LDS-DMA pipelined variant of the channels-last bf16 Conv1d (included by conv1d_cl.hip).
+//
+// Same GEMM view, LDS images, swizzle, weight-row permutation and epilogue as conv1d_cl_kernel, but
+// the operands travel global -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write
+// pass) one K step ahead of the MFMAs, and a block is 4 (or 8) waves with 64 x 64 (64 x 32) wave
+// tiles instead of 16 waves of 32 x 32: half the LDS read traffic per MFMA
+// (MI355X_MICROARCH.md: the 32 x 32 tiles need 512 LDS cycles per 515 MFMA cycles of a K step).
+//
+//   step s = (Cin chunk ci of 64 channels, tap j);  ring of D weight stages, two x windows
+//     top of step s :  s_waitcnt vmcnt(..)   this wave's pieces of W(s) (and of the x window) have landed
+//                      s_waitcnt lgkmcnt(0)  this wave's LDS reads of step s-1 have returned
+//                      s_barrier             -> everyone's pieces landed, stage (s-1) % D is free
+//     then          :  issue x window of chunk ci+1 (first tap of a chunk only), issue W(s + D - 1)
+//                      MFMAs of step s from stage s % D and window ci & 1
+//
+// The LDS-DMA is issued from inline asm (the compiler neither counts nor drains it, so the plain
+// C++ LDS reads keep their compiler-scheduled lgkmcnt ladders); an LDS-DMA writes 1 KiB
+// lane-linear, so the XOR swizzle and the weight-row permutation are applied to the per-lane
+// SOURCE address.  Rows outside the utterance come from a zero page.
+#pragma once
+#include "conv1d_common.h"
+
+namespace {
+
+__device__ uint4 g_conv_zero_page[64];
+
+// one wave-instruction: lane l's 16 bytes at gsrc -> LDS byte address lds_dst + 16 l (lds_dst wave-uniform)
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void glds_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// inverse of wperm<bf16, FN>: weight-tile row held by LDS row q
+template <int FN>
+__device__ __forceinline__ int wperm_inv(int q) {
+  if constexpr (FN % 2 == 0) {
+    const int u = q % (16 * FN);
+    const int tile = u >> 4, lg = (u >> 2) & 3, r = u & 3;
+    return (q - u) + (tile >> 1) * 32 + lg * 8 + (tile & 1) * 4 + r;
+  } else {
+    return q;
+  }
+}
+
+// Epilogue through an LDS image of the output tile.  The MFMA layout gives a lane 16 bytes of ONE row and its
+// neighbours in lane order other rows, so direct stores / residual loads reach memory as 64 separate 16-byte
+// requests per wave-instruction (measured: 11 us of a 23 us block for 32 KiB in + 32 KiB out, 28 us with 4 waves).
+// Here the residual rows are fetched row-contiguous (16 lanes = one 256-byte row), parked in the tile image,
+// every lane updates its own 16-byte slots in place (same arithmetic and rounding as conv_epilogue), and the block
+// stores the image row-contiguous.  Slot (row, q) = 8 channels n0 + 8q .. of row t0 + row, at chunk q ^ (row & 15).
+template <int FN>
+__device__ __forceinline__ bool tile_epilogue_ok(const ConvP& p) {
+  const bool al16 = ((uintptr_t)p.y & 15) == 0 && (!p.res || ((uintptr_t)p.res & 15) == 0);
+  return FN % 2 == 0 && (p.Cout & 7) == 0 && (p.ldy & 7) == 0 && al16 && (!p.res || (p.ldr & 7) == 0) && !p.res2 &&
+         p.act != PTPP_ACT_GATE;
+}
+template <int FM, int FN, int WR, int WC, int ACT>
+__device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][FN], uint4 (&resv)[WR * FM * WC * FN * 32 / (WR * WC * 64)],
+                                              uint4* O, int b, int t0, int n0, int wm, int wn, int tid, int len) {
+  typedef bf16_raw T;
+  constexpr int NT = WR * WC * 64, BM = WR * FM * 16, BN = WC * FN * 16;
+  constexpr int QPR = BN / 8;  // 16-byte slots per tile row
+  constexpr int NRV = BM * QPR / NT;
+  static_assert(QPR >= 16, "tile rows of at least 256 bytes");
+  const int lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+  const bool has_res = p.res != nullptr;
+  if (has_res) {
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / QPR, q = idx % QPR;
+      O[row * QPR + (q ^ (row & 15))] = resv[i];
+    }
+    __syncthreads();
+  }
+  const float e_scale = p.out_scale, e_rscale = p.res_scale, e_dinv = p.drop_inv_keep;
+  const unsigned e_dth = p.drop_thresh16;
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+    const int row = (wm * FM + fm) * 16 + lr;
+    const int t = t0 + row;
+    const bool keep = !(p.out_mask && t >= len);
+#pragma unroll
+    for (int h = 0; h < FN / 2; ++h) {
+      const int q = wn * FN * 2 + h * 4 + lg;
+      const int co = n0 + q * 8;
+      f32x4 v[2] = {acc[fm][2 * h], acc[fm][2 * h + 1]};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (p.bias && co < p.Cout) v[u] += *reinterpret_cast<const f32x4*>(p.bias + co + 4 * u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[u][e] = keep ? act_apply_c<ACT>(v[u][e]) * e_scale : 0.f;
+        if (e_dth) v[u] *= drop_mask4(p.drop_seed, (uint64_t)(((int64_t)b * p.T + t) * p.Cout + co + 4 * u) >> 2, e_dth, e_dinv);
+      }
+      uint4* slot = O + row * QPR + (q ^ (row & 15));
+      if (has_res) {
+        const uint4 r = *slot;
+        v[0][0] += __uint_as_float(r.x << 16) * e_rscale; v[0][1] += __uint_as_float(r.x & 0xffff0000u) * e_rscale;
+        v[0][2] += __uint_as_float(r.y << 16) * e_rscale; v[0][3] += __uint_as_float(r.y & 0xffff0000u) * e_rscale;
+        v[1][0] += __uint_as_float(r.z << 16) * e_rscale; v[1][1] += __uint_as_float(r.z & 0xffff0000u) * e_rscale;
+        v[1][2] += __uint_as_float(r.w << 16) * e_rscale; v[1][3] += __uint_as_float(r.w & 0xffff0000u) * e_rscale;
+      }
+      uint4 o;
+      o.x = (uint32_t)f32_to_bf16(v[0][0]) | ((uint32_t)f32_to_bf16(v[0][1]) << 16);
+      o.y = (uint32_t)f32_to_bf16(v[0][2]) | ((uint32_t)f32_to_bf16(v[0][3]) << 16);
+      o.z = (uint32_t)f32_to_bf16(v[1][0]) | ((uint32_t)f32_to_bf16(v[1][1]) << 16);
+      o.w = (uint32_t)f32_to_bf16(v[1][2]) | ((uint32_t)f32_to_bf16(v[1][3]) << 16);
+      *slot = o;
+    }
+  }
+  __syncthreads();
+  T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * p.T * p.ldy;
+#pragma unroll
+  for (int i = 0; i < NRV; ++i) {
+    const int idx = tid + i * NT;
+    const int row = idx / QPR, q = idx % QPR;
+    const int t = t0 + row, co = n0 + q * 8;
+    if (t < p.T && co < p.Cout && !(p.nsplit & 2)) *reinterpret_cast<uint4*>(yb + (int64_t)t * p.ldy + co) = O[row * QPR + (q ^ (row & 15))];
+  }
+}
+
+__device__ unsigned long long* g_conv_stamps;  // experiments only (DBG = true): 4 clock stamps per block
+
+template <int FM, int FN, int WR, int WC, int D, bool DBG = false>
+__global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p) {
+  typedef bf16_raw T;
+  constexpr int NW = WR * WC;
+  constexpr int BM = WR * FM * 16, BN = WC * FN * 16;
+  constexpr int LW = BN / 8 / NW;  // 1 KiB pieces (8 rows x 128 B) of a weight stage per wave
+  static_assert(LW * NW * 8 == BN, "weight pieces must divide over the waves");
+  constexpr int WSTAGE = BN * 8;  // uint4 per weight stage
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object
+  unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
+  if constexpr (DBG) stamp0 = wall_clock64();
+  const int xrows = (BM + (p.ks - 1) * p.dil + 7) & ~7;
+  uint4* Ws = reinterpret_cast<uint4*>(smem);  // [D][BN][8]
+  uint4* Xs = Ws + D * WSTAGE;                 // [2][xrows][8]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WC, wn = wave % WC;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = lid % p.nNT;
+  const int mt = (lid / p.nNT) % p.nMT;
+  const int b = lid / (p.nNT * p.nMT);
+  const int t0 = mt * BM, n0 = nt * BN;
+
+  const int len = p.lengths ? min(p.lengths[b], p.T) : p.T;
+  const int Tin = p.in_mask ? len : p.T;
+  const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.T * p.ldx;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nC = p.cinp >> 6;
+  const int steps = (p.out_mask && t0 >= len) ? 0 : nC * p.ks;
+
+  // per-lane source of the wave's weight pieces at (ci = 0, tap 0)
+  const char* wsrc[LW];
+#pragma unroll
+  for (int q = 0; q < LW; ++q) {
+    const int row = (wave * LW + q) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz<8>(row);
+    const int n = min(n0 + wperm_inv<FN>(row), p.Cout - 1);  // rows past Cout: any finite data, never stored
+    wsrc[q] = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.wp) + (int64_t)n * p.ks * p.cinp + c * 8);
+  }
+  const uint32_t ws_lds = lds_addr(Ws) + (uint32_t)wave * LW * 1024u;
+  const uint32_t xs_lds = lds_addr(Xs);
+  const char* zero = reinterpret_cast<const char*>(g_conv_zero_page) + lane * 16;
+
+  auto issue_w = [&](int s, int stage) {
+    const int ci = s / p.ks, j = s - ci * p.ks;
+    const int off = (j * p.cinp + ci * 64) * 2;
+#pragma unroll
+    for (int q = 0; q < LW; ++q)
+      glds16(wsrc[q] + off, __builtin_amdgcn_readfirstlane(ws_lds + (uint32_t)(stage * WSTAGE * 16 + q * 1024)));
+  };
+  auto issue_x = [&](int ci, int buf) {
+    const int np = xrows >> 3;
+    for (int piece = wave; piece < np; piece += NW) {
+      const int r = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz<8>(r);
+      const int ts = t0 - p.pad + r;
+      const char* src = (ts >= 0 && ts < Tin) ? reinterpret_cast<const char*>(xb + (int64_t)ts * p.ldx + ci * 64 + c * 8) : zero;
+      glds16(src, __builtin_amdgcn_readfirstlane(xs_lds + (uint32_t)((buf * xrows + piece * 8) * 128)));
+    }
+  };
+
+  // the residual rows of the tile, fetched row-contiguous (see tile_epilogue) while the first operands travel:
+  // the K loop's first vmcnt(0) retires them together with the first stage
+  const bool tile_epi = tile_epilogue_ok<FN>(p);
+  constexpr int NRV = BM * BN / 8 / (NW * 64);  // 16-byte vectors of the output tile per thread
+  uint4 resv[NRV];
+  if (tile_epi && p.res) {
+    const T* rb = reinterpret_cast<const T*>(p.res) + (int64_t)b * p.T * p.ldr;
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NW * 64;
+      const int row = idx / (BN / 8), q = idx % (BN / 8);
+      const int t = t0 + row, co = n0 + q * 8;
+      resv[i] = (t < p.T && co < p.Cout) ? *reinterpret_cast<const uint4*>(rb + (int64_t)t * p.ldr + co) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  if (steps > 0) {
+    issue_x(0, 0);
+    issue_w(0, 0);
+    if (D > 2 && steps > 1) issue_w(1, 1);
+  }
+  int stage = 0;
+  for (int s = 0; s < steps; ++s) {
+    const int ci = s / p.ks, j = s - ci * p.ks;
+    if (D > 2 && s + 1 < steps) glds_wait<LW>();
+    else glds_wait<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (DBG) {
+      if (s == 0) stamp1 = wall_clock64();
+    }
+    if (j == 0 && ci + 1 < nC) issue_x(ci + 1, (ci + 1) & 1);
+    if (s + D - 1 < steps) issue_w(s + D - 1, stage == 0 ? D - 1 : stage - 1);
+
+    const uint4* Wb = Ws + stage * WSTAGE;
+    const uint4* Xb = Xs + (ci & 1) * xrows * 8;
+    const int rsh = j * p.dil;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = kk * 4 + lg;
+      uint4 wf[FN], xf[FM];
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const int n = (wn * FN + fn) * 16 + lr;
+        wf[fn] = Wb[n * 8 + (c ^ swz<8>(n))];
+      }
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const int r = (wm * FM + fm) * 16 + lr + rsh;
+        xf[fm] = Xb[r * 8 + (c ^ swz<8>(r))];
+      }
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+          acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[fn]),
+                                                                __builtin_bit_cast(bf16x8_t, xf[fm]), acc[fm][fn], 0, 0, 0);
+    }
+    stage = stage + 1 == D ? 0 : stage + 1;
+  }
+  if constexpr (DBG) stamp2 = wall_clock64();
+  if (tile_epi) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the operand stages: their memory becomes the tile
+    act_dispatch(p.act, [&](auto tag) {
+      tile_epilogue<FM, FN, WR, WC, decltype(tag)::value>(p, acc, resv, reinterpret_cast<uint4*>(smem), b, t0, n0, wm, wn, tid, len);
+    });
+  } else {
+    conv_epilogue<T, FM, FN>(p, acc, b, t0, n0, wm, wn, lane, len);
+  }
+  if constexpr (DBG) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      unsigned long long* o = g_conv_stamps + (size_t)blockIdx.x * 4;
+      o[0] = stamp0; o[1] = stamp1; o[2] = stamp2; o[3] = wall_clock64();
+    }
+  }
+}
+
+// bf16, whole 64-channel K chunks and 16-byte aligned rows (the caller has checked alignment of x)
+inline bool glds_ok(const ConvP& p) { return p.cinp == p.Cin && (p.Cin & 63) == 0 && p.Cout >= 64; }
+
+template <int FM, int FN, int WR, int WC, int D>
+int launch_glds(ConvP& p, hipStream_t st) {
+  constexpr int BM = WR * FM * 16, BN = WC * FN * 16;
+  p.nMT = (p.T + BM - 1) / BM;
+  p.nNT = (p.Cout + BN - 1) / BN;
+  const int xrows = (BM + (p.ks - 1) * p.dil + 7) & ~7;
+  const size_t smem = (size_t)(D * BN * 8 + 2 * xrows * 8) * 16;
+  if (smem > 160 * 1024) return -1;
+  auto kern = conv1d_glds_kernel<FM, FN, WR, WC, D>;
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int64_t nblk = (int64_t)p.B * p.nMT * p.nNT;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WR * WC * 64), smem, st, p);
+  PTPP_CHECK_LAUNCH("conv1d_fwd (lds-dma)");
+  return PTPP_OK;
+}
+
+}  // namespace

@@ -106,6 +106,48 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// The activation as a compile-time constant.  A kernel that applies act_apply(v, act) to every element of an
+// unrolled epilogue gets one copy of the whole switch (erff, tanhf, log1pf expansions) per element: the 128 x 128
+// conv kernel was 18 k instructions and the 64 x 64-per-wave variant 110 k, far beyond the 64 KiB instruction cache,
+// and its epilogue ran at instruction-fetch speed (measured 11 us for 64 elements per lane with all memory
+// operations removed).  Dispatch ONCE per wave (act_dispatch) to code specialised for the activation instead.
+template <int ACT>
+__device__ __forceinline__ float act_apply_c(float v, int act_rt = 0) {
+  if constexpr (ACT < 0) {  // not specialised: the run-time switch (paths where speed does not matter)
+    return act_apply(v, act_rt);
+  } else if constexpr (ACT == PTPP_ACT_RELU) {
+    return v > 0.f ? v : 0.f;
+  } else if constexpr (ACT == PTPP_ACT_GELU) {
+    return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  } else if constexpr (ACT == PTPP_ACT_SWISH) {
+    return v / (1.f + __expf(-v));
+  } else if constexpr (ACT == PTPP_ACT_TANH) {
+    return tanhf(v);
+  } else if constexpr (ACT == PTPP_ACT_MISH) {
+    float sp = v > 20.f ? v : log1pf(__expf(v));
+    return v * tanhf(sp);
+  } else {
+    return v;
+  }
+}
+// f(std::integral_constant<int, ACT>) for the run-time activation code (wave-uniform branch)
+template <int A>
+struct ActTag {
+  static constexpr int value = A;
+};
+template <typename F>
+__device__ __forceinline__ void act_dispatch(int act, F&& f) {
+  switch (act) {
+    case PTPP_ACT_RELU: f(ActTag<PTPP_ACT_RELU>()); break;
+    case PTPP_ACT_GELU: f(ActTag<PTPP_ACT_GELU>()); break;
+    case PTPP_ACT_SWISH: f(ActTag<PTPP_ACT_SWISH>()); break;
+    case PTPP_ACT_TANH: f(ActTag<PTPP_ACT_TANH>()); break;
+    case PTPP_ACT_MISH: f(ActTag<PTPP_ACT_MISH>()); break;
+    case PTPP_ACT_GATE: f(ActTag<PTPP_ACT_GATE>()); break;
+    default: f(ActTag<PTPP_ACT_NONE>()); break;
+  }
+}
+
 // ---- wave reductions (wave = 64 lanes) ---------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

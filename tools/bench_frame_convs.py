@@ -9,12 +9,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from promptttspp_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-print("PTPP_CONV_TILE", os.environ.get("PTPP_CONV_TILE"))
+print("PTPP_CONV_TILE", os.environ.get("PTPP_CONV_TILE"), "PTPP_CONV_GLDS", os.environ.get("PTPP_CONV_GLDS"))
+dump = os.environ.get("PTPP_CONV_DUMP")  # directory: save outputs (first run) / compare bit for bit (later runs)
 shapes = [("DiffNet dilated 256->512 k3", 52, 576, 256, 512, 3, 2), ("DiffNet 1x1 256->512", 52, 576, 256, 512, 1, 1),
           ("frame prior 256->256 k17", 52, 576, 256, 256, 17, 1), ("pitch pred 256->256 k5", 52, 576, 256, 256, 5, 1),
           ("dgrad 512->256 k3", 52, 576, 512, 256, 3, 2), ("BigVGAN C=128 k7 d3", 64, 30000, 128, 128, 7, 3),
           ("BigVGAN C=256 k11 d5", 64, 6000, 256, 256, 11, 5), ("BigVGAN C=256 k3", 64, 6000, 256, 256, 3, 1)]
 tot = 0.0
+torch.manual_seed(0)
 for name, B, T, cin, cout, ks, dil in shapes:
     x = torch.randn(B, T, cin, device=dev).bfloat16()
     res = torch.randn(B, T, cout, device=dev).bfloat16()
@@ -26,6 +28,14 @@ for name, B, T, cin, cout, ks, dil in shapes:
     for _ in range(3):
         f()
     torch.cuda.synchronize()
+    if dump:
+        path = os.path.join(dump, name.replace(" ", "_").replace(">", "") + ".pt")
+        if os.path.exists(path):
+            ref = torch.load(path).to(dev)
+            print("   bit-identical to the saved output:", bool(torch.equal(ref, y)), " max |diff|", float((ref.float() - y.float()).abs().max()))
+        else:
+            os.makedirs(dump, exist_ok=True)
+            torch.save(y.cpu(), path)
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(10):
