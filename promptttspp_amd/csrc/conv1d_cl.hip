@@ -378,11 +378,17 @@ int launch_tiles(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes) {
     return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);
   }
   if constexpr (sizeof(T) == 2 && NCH == 8) {
-    // LDS-DMA pipeline, 8 waves of 64 x 32 (conv1d_glds.h); PTPP_CONV_GLDS=0 keeps the register-staged kernel,
-    // A = 4 waves of 64 x 64 (experiments: profiles/r02_conv_glds.txt)
+    // LDS-DMA pipeline (conv1d_glds.h), 4 waves per block.  Large grids (the vocoder: thousands of 128 x 128 tiles,
+    // many rounds over the 256 CUs) take 128 x 128 tiles with 64 x 64 wave tiles -- the highest MFMA : L2-traffic
+    // ratio; the frame-level shapes of the acoustic model (B x 576: about two rounds) take 64 x 128 tiles, three
+    // blocks per CU, finer tail (measured: profiles/r02_conv_glds.txt).  PTPP_CONV_GLDS=0 keeps the register-staged
+    // kernel, A / E force one of the two.
     static const char* gl = getenv("PTPP_CONV_GLDS");
     if (glds_ok(p) && !(gl && gl[0] == '0')) {
-      const int rc = (gl && gl[0] == 'A') ? launch_glds<4, 4, 2, 2, 2>(p, st) : launch_glds<4, 2, 2, 4, 2>(p, st);
+      const long long tiles128 = (long long)p.B * ((p.T + 127) / 128) * ((p.Cout + 127) / 128);
+      static const char* thr = getenv("PTPP_CONV_GLDS_TILES");
+      const bool big = gl && gl[0] == 'A' ? true : gl && gl[0] == 'E' ? false : tiles128 >= (thr ? atoll(thr) : 1536);
+      const int rc = big ? launch_glds<4, 4, 2, 2, 2>(p, st) : launch_glds<2, 4, 2, 2, 2>(p, st);
       if (rc >= 0) return rc;
     }
   }

@@ -2,9 +2,10 @@
 //
 // Same GEMM view, LDS images, swizzle, weight-row permutation and epilogue as conv1d_cl_kernel, but
 // the operands travel global -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write
-// pass) one K step ahead of the MFMAs, and a block is 4 (or 8) waves with 64 x 64 (64 x 32) wave
-// tiles instead of 16 waves of 32 x 32: half the LDS read traffic per MFMA
+// pass) one K step ahead of the MFMAs, and a block is 4 waves with 64 x 64 (large grids) or 32 x 64
+// (small grids) wave tiles instead of 16 waves of 32 x 32: half the LDS read traffic per MFMA
 // (MI355X_MICROARCH.md: the 32 x 32 tiles need 512 LDS cycles per 515 MFMA cycles of a K step).
+// Measurements of the variants: profiles/r02_conv_glds.txt.
 //
 //   step s = (Cin chunk ci of 64 channels, tap j);  ring of D weight stages, two x windows
 //     top of step s :  s_waitcnt vmcnt(..)   this wave's pieces of W(s) (and of the x window) have landed
