@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0
 # HBM traffic comes from PMC passes (bench.py cannot run rocprofv3 on itself): the committed summaries of
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command / of tools/bench_vocoder.py, written by
 # tools/pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md; the JSON line names the file it read.
-TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r02_hbm_traffic_train.json")
-TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r02_hbm_traffic_bigvgan.json")
+TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r02b_hbm_traffic_train.json")
+TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r02b_hbm_traffic_bigvgan.json")
 
 
 def measured_traffic(path, kernel_substr=None):
@@ -115,14 +115,17 @@ def train_setup(model, world):
 
 
 def train_step(model, batch, red, opt, sched):
-    red.zero_grad()
-    out = model(batch)
-    # backward on the calling thread: most nodes are Python autograd Functions, and the engine's worker
-    # thread would take the GIL from this (idle) one for each of them (tools/diag_backward_thread.py)
-    with torch.autograd.set_multithreading_enabled(False):
-        out["loss"].backward()
-    red.finish()
-    opt.step()
+    from promptttspp_amd import ops
+
+    with ops.pinned_stream():  # as trainers/tts.py does: one stream lookup per step, not one per launch
+        red.zero_grad()
+        out = model(batch)
+        # backward on the calling thread: most nodes are Python autograd Functions, and the engine's worker
+        # thread would take the GIL from this (idle) one for each of them (tools/diag_backward_thread.py)
+        with torch.autograd.set_multithreading_enabled(False):
+            out["loss"].backward()
+        red.finish()
+        opt.step()
     sched.step()
     return out
 
@@ -164,16 +167,18 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         torch.cuda.synchronize()
     finally:
         ops.conv1d = orig
-    # the dominant kernel = the 128 x 128-tile instantiation (rocprof: conv1d_cl_kernel<unsigned short, 8, 4,
-    # 2, 2, 16>; profiles/r01_train_step_final.md is the rocprofv3 summary of the training leg of this
-    # command); launches of the same family with smaller tiles are listed there, not averaged in here
+    # the dominant kernel = the LDS-DMA conv kernel these launches take (csrc/conv1d_glds.h; rocprof:
+    # conv1d_glds_kernel<2, 4, 2, 2, 2>, 64 x 128 tiles, and <4, 4, 2, 2, 2>, 128 x 128 tiles, for the few launches
+    # with >= 1536 tiles; profiles/r02b_train_step.md is the rocprofv3 summary of the training leg of this command);
+    # launches of the conv family with smaller tiles / split-K are listed there, not averaged in here
     tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
     tot_flop = sum(f for _, _, f in recs)
     ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else 157.3
-    traffic, traffic_src = measured_traffic(TRAFFIC_TRAIN, "conv1d_cl_kernel<unsigned short, 8, 4, 2, 2, 16") \
+    traffic, traffic_src = measured_traffic(TRAFFIC_TRAIN, "conv1d_glds_kernel<2, 4, 2, 2, 2") \
         if dtype_name == "bf16" else (None, "no PMC pass for the f32 mode")
-    return {"bound": "mfma", "kernel": "conv1d_cl_kernel<%s>, 128x128 tiles (frame-level fwd + dgrad launches of one step)" % dtype_name,
+    kname = "conv1d_glds_kernel<bf16> (LDS-DMA, 64x128 / 128x128 tiles)" if dtype_name == "bf16" else "conv1d_cl_kernel<f32>, 128x128 tiles"
+    return {"bound": "mfma", "kernel": kname + ": frame-level fwd + dgrad launches of one step",
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),

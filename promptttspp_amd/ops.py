@@ -35,11 +35,35 @@ _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 _stream_override = None  # set by functional.wgrad_stream: launch on this raw stream instead of torch's current one
 
 
+_stream_pinned = None  # set by pinned_stream(): the handle looked up once for a whole step
+
+
+class pinned_stream:
+    """Look torch's current stream up ONCE for a region that does not switch streams (a training step: forward,
+    backward -- autograd runs the backward nodes on the forward's stream -- and the optimizer; a sampler loop)
+    instead of once per kernel launch (~2000 launches per step, 0.17 us each way plus the ctypes object).
+    ``functional.wgrad_stream`` still redirects the weight-gradient launches inside the region.  Re-entrant."""
+
+    def __enter__(self):
+        global _stream_pinned
+        self.prev = _stream_pinned
+        if _stream_pinned is None:
+            _stream_pinned = _stream()
+        return self
+
+    def __exit__(self, *exc):
+        global _stream_pinned
+        _stream_pinned = self.prev
+        return False
+
+
 def _stream():
     """torch's current HIP stream as a raw handle (the C calls: ~0.3 us instead of ~7 us for the
     torch.cuda.current_stream() object -- this runs once per kernel launch)."""
     if _stream_override is not None:
         return _stream_override
+    if _stream_pinned is not None:
+        return _stream_pinned
     if _raw_stream is not None and _cur_device is not None:
         return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -179,6 +179,10 @@ class TTSTrainer:
         params = [p for p in model.parameters() if p.requires_grad]
         optimizer = instantiate(cfg.optimizer, params=params)
         fused = isinstance(optimizer, FusedAdamW)
+        import contextlib
+
+        from .. import ops as _ops
+        pin_stream = _ops.pinned_stream if device.type == "cuda" else contextlib.nullcontext
         if fused and optimizer.max_grad_norm <= 0:
             optimizer.max_grad_norm = 1.0  # the trainer's clip_grad_norm_(1.0), fused
         lr_scheduler = instantiate(cfg.train.lr_scheduler, optimizer=optimizer) if "lr_scheduler" in cfg.train else None
@@ -221,18 +225,19 @@ class TTSTrainer:
             pending = []  # device-resident loss dicts since the last read-back
             for batch in train_dl:
                 batch = self._to_device(batch, device)
-                reducer.zero_grad()
-                if bcast_buffers:
-                    reducer.broadcast_buffers(model)  # DDP(broadcast_buffers=True), trainers/tts.py:117
-                loss_dict = model(batch)
-                with torch.autograd.set_multithreading_enabled(False):  # Python-heavy backward: stay on this thread
-                    loss_dict["loss"].backward()
-                reducer.finish()
-                if not fused:
-                    torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
-                optimizer.step()
-                if not fused:
-                    PF.repack_all()  # (FusedAdamW does this itself) refresh the packed operands in one launch
+                with pin_stream():  # one stream lookup per step instead of one per kernel launch
+                    reducer.zero_grad()
+                    if bcast_buffers:
+                        reducer.broadcast_buffers(model)  # DDP(broadcast_buffers=True), trainers/tts.py:117
+                    loss_dict = model(batch)
+                    with torch.autograd.set_multithreading_enabled(False):  # Python-heavy backward: stay on this thread
+                        loss_dict["loss"].backward()
+                    reducer.finish()
+                    if not fused:
+                        torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+                    optimizer.step()
+                    if not fused:
+                        PF.repack_all()  # (FusedAdamW does this itself) refresh the packed operands in one launch
                 if not per_epoch_scheduler and lr_scheduler is not None:
                     lr_scheduler.step()
                 global_step += 1
