@@ -643,6 +643,57 @@ def test_trainer_one_epoch_and_app_synthesis(dev, tmp_path):
         config.set_compute_dtype(torch.float32)
 
 
+def test_trainer_resume_continues_from_checkpoint(dev, tmp_path):
+    """n4, the resume path (reference trainers/tts.py:97-110): a second run with ``ckpt_path=last.ckpt`` restores model,
+    optimizer (fused AdamW moments + step count) and Noam scheduler, starts at epoch 2, APPENDS to loss.csv, and its
+    first update continues the bias-corrected schedule instead of restarting it -- checked against an uninterrupted
+    two-epoch run of the same seed: same step counter, same learning rate, same checkpoint key set."""
+    import os
+
+    from promptttspp.trainers.tts import TTSTrainer
+    from promptttspp_amd import config
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd.hydra_lite import compose
+
+    conf = os.path.join(os.path.dirname(__file__), "..", "egs", "proposed", "bin", "conf")
+    base = ["dataset=synthetic", "optimizer=fused_adamw", "dataset.train.num_utts=16", "dataset.valid.num_utts=4",
+            "dataset.max_tokens=4000", "train.num_workers=0", "train.batch_size=2", "train.save_interval=1"]
+    a, b = tmp_path / "interrupted", tmp_path / "straight"
+    try:
+        TTSTrainer(compose(conf, "train", base + ["train.num_epochs=1", f"output_dir={a}"]))._train(0, 0, 1)
+        ck1 = torch.load(a / "ckpt" / "last.ckpt", map_location="cpu")
+        rows1 = open(a / "logs" / "loss.csv").read().strip().splitlines()
+        TTSTrainer(compose(conf, "train", base + ["train.num_epochs=2", f"output_dir={a}",
+                                                  f"ckpt_path={a / 'ckpt' / 'last.ckpt'}"]))._train(0, 0, 1)
+        ck2 = torch.load(a / "ckpt" / "last.ckpt", map_location="cpu")
+        rows2 = open(a / "logs" / "loss.csv").read().strip().splitlines()
+        assert ck1["epoch"] == 1 and ck2["epoch"] == 2 and (a / "ckpt" / "epoch-2.ckpt").exists()
+        assert rows2[: len(rows1)] == rows1 and len(rows2) > len(rows1)  # appended, header kept, nothing rewritten
+        assert all(np.isfinite(float(x)) for x in rows2[-1].split(",")[1:])
+
+        TTSTrainer(compose(conf, "train", base + ["train.num_epochs=2", f"output_dir={b}"]))._train(0, 0, 1)
+        ref = torch.load(b / "ckpt" / "last.ckpt", map_location="cpu")
+        assert set(ck2) == set(ref) and set(ck2["model"]) == set(ref["model"])
+
+        def steps(ck):  # per-parameter step counters of the optimizer state (torch.optim.AdamW layout)
+            return sorted({int(v["step"]) for v in ck["optimizer"]["state"].values() if "step" in v})
+
+        assert steps(ck2) == steps(ref) and steps(ck2)[0] == 2 * steps(ck1)[0]  # resumed, not restarted
+        assert ck2["lr_scheduler"]["last_epoch"] == ref["lr_scheduler"]["last_epoch"] == 2 * ck1["lr_scheduler"]["last_epoch"]
+        assert ck2["lr_scheduler"]["_last_lr"] == ref["lr_scheduler"]["_last_lr"]
+        # the restored moments were used: after one more epoch the weights moved away from the checkpoint, by a
+        # distance comparable to the uninterrupted run's second epoch (a restart from zero moments at step 1 would
+        # take bias-correction-inflated first steps)
+        k = next(n for n, v in ck1["model"].items() if v.dtype.is_floating_point and v.numel() > 1000 and "bert" not in n)
+        d_res = float((ck2["model"][k] - ck1["model"][k]).norm())
+        ref1 = torch.load(b / "ckpt" / "epoch-1.ckpt", map_location="cpu")
+        d_ref = float((ref["model"][k] - ref1["model"][k]).norm())
+        assert d_res > 0 and 0.3 < d_res / d_ref < 3.0, (d_res, d_ref)
+    finally:
+        PF.enable_direct_grads(False)
+        config.set_compute_dtype(torch.float32)
+
+
 def test_bert_frozen_layers_on_hip_match_library_layers(dev):
     """The 11 frozen BERT layers on the HIP kernels (fused QKV GEMM, PLAIN attention, GELU epilogue,
     fused residual + LayerNorm) vs the same weights through the transformers modules: CLS embedding
