@@ -158,7 +158,20 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         recs.append((e0, e1, 2.0 * rows * x.shape[2] * cout * ks))
         return y
 
+    orig_post = ops.conv1d_diffnet_post
+
+    def timed_post(g, wp, bias, x, skip, dnext, init, lengths=None, out_mask=False, **kw):
+        # the DiffNet output projection with its fused tail: same kernel family, same accounting (2C output channels)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_post(g, wp, bias, x, skip, dnext, init, lengths=lengths, out_mask=out_mask, **kw)
+        e1.record()
+        rows = float(lengths.sum()) if lengths is not None and out_mask else g.shape[0] * g.shape[1]
+        recs.append((e0, e1, 2.0 * rows * g.shape[2] * 2 * x.shape[2]))
+        return r
+
     ops.conv1d = timed
+    ops.conv1d_diffnet_post = timed_post
     try:
         # keep the device busy while the host enqueues the step, so that the events bracket kernel
         # execution and not launch gaps (the instrumented step is host-bound)
@@ -167,6 +180,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         torch.cuda.synchronize()
     finally:
         ops.conv1d = orig
+        ops.conv1d_diffnet_post = orig_post
     # the dominant kernel = the LDS-DMA conv kernel these launches take (csrc/conv1d_glds.h; rocprof:
     # conv1d_glds_kernel<2, 4, 2, 2, 2>, 64 x 128 tiles, and <4, 4, 2, 2, 2>, 128 x 128 tiles, for the few launches
     # with >= 1536 tiles; profiles/r02b_train_step.md is the rocprofv3 summary of the training leg of this command);

@@ -270,6 +270,14 @@ int ptpp_gate_bwd(const void* a, const void* dg, void* da, int64_t rows, int C,
 int ptpp_diffnet_post_fwd(const void* o, const void* x, float* skip,
                           const float* dnext, void* xn, void* yin, int B, int T,
                           int C, int init, int dtype, void* stream);
+/* The layer's 1 x 1 output projection AND the tail above in one launch (bf16): o = conv1x1(a->x) is never stored;
+ * a->Cout = 2C, a->ks = 1; a->res / a->y are ignored (x and xn take their place).  Bit-identical to
+ * ptpp_conv1d_fwd followed by ptpp_diffnet_post_fwd.  _supported: bf16, C % 128 == 0, Cin % 64 == 0.
+ * Reference: modules/denoiser.py:78-83 (output_projection, chunk, residual / skip). */
+int ptpp_conv1d_diffnet_post_supported(int C, int cin, int dtype);
+int ptpp_conv1d_diffnet_post(const ptpp_conv1d_args* a, const void* x, float* skip,
+                             const float* dnext, void* xn, void* yin, int init,
+                             void* stream);
 /* dout (rows, 2C) = [gx/sqrt2 | gskip], masked rows zero */
 int ptpp_diffnet_post_bwd(const void* gx, const void* gskip, void* dout,
                           const int32_t* lengths, int B, int T, int C, int dtype,

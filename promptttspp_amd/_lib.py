@@ -83,6 +83,8 @@ SIGNATURES = {
     "ptpp_gate_fwd": (I, [P, P, I64, I, I, P]),
     "ptpp_gate_bwd": (I, [P, P, P, I64, I, I, I, P]),
     "ptpp_diffnet_post_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "ptpp_conv1d_diffnet_post_supported": (I, [I, I, I]),
+    "ptpp_conv1d_diffnet_post": (I, [POINTER(ConvArgs), P, P, P, P, P, I, P]),
     "ptpp_diffnet_post_bwd": (I, [P, P, P, P, I, I, I, I, P]),
     "ptpp_colsum_batch": (I, [P, P, I, I, I, I, P]),
     "ptpp_col_reduce": (I, [P, P, P, I64, I, I, P, SZ, P]),

@@ -444,6 +444,7 @@ extern "C" int ptpp_conv1d_fwd_ws(const ptpp_conv1d_args* a, const void* res2, i
   p.drop_seed = drop_seed;
   p.ws = nullptr;
   p.nsplit = 1;
+  p.post_skip = nullptr; p.post_dnext = nullptr; p.post_yin = nullptr; p.post_C = 0; p.post_init = 0;
   if (workspace && ((uintptr_t)workspace & 15)) workspace = nullptr;
   // A linear layer without sequence masks does not care where one utterance ends: treat the (B, T) rows
   // as ONE sequence (rows are linear in memory: batches are T consecutive rows) so that short utterances
@@ -468,4 +469,41 @@ extern "C" int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, i
 
 extern "C" int ptpp_conv1d_fwd(const ptpp_conv1d_args* a, void* stream) {
   return ptpp_conv1d_fwd_ex(a, nullptr, 0, 1.0f, 0.f, 0, stream);
+}
+
+// ---- DiffNet output projection with the layer's tail fused into the epilogue (conv1d_glds.h::tile_epilogue_post) ----
+extern "C" int ptpp_conv1d_diffnet_post_supported(int C, int cin, int dtype) {
+  return dtype == PTPP_BF16 && C > 0 && C % 128 == 0 && cin > 0 && cin % 64 == 0;
+}
+
+extern "C" int ptpp_conv1d_diffnet_post(const ptpp_conv1d_args* a, const void* x, float* skip, const float* dnext, void* xn,
+                                        void* yin, int init, void* stream) {
+  PTPP_CHECK_ARG(a && a->x && a->wp && x && skip && xn, "conv1d_diffnet_post: null pointer");
+  const int C = a->Cout / 2;
+  PTPP_CHECK_ARG(a->ks == 1 && a->pad == 0 && a->Cout == 2 * C && ptpp_conv1d_diffnet_post_supported(C, a->Cin, a->dtype),
+                 "conv1d_diffnet_post: needs bf16, a 1 x 1 projection to 2C channels, C %% 128 == 0, Cin %% 64 == 0 (C=%d Cin=%d)", C,
+                 a->Cin);
+  PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->ldx % 8 == 0 && ((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->wp % 16) == 0 &&
+                     ((uintptr_t)x % 16) == 0 && ((uintptr_t)xn % 16) == 0 && ((uintptr_t)yin % 16) == 0 &&
+                     ((uintptr_t)skip % 16) == 0 && ((uintptr_t)dnext % 16) == 0 && (!a->bias || ((uintptr_t)a->bias % 16) == 0),
+                 "conv1d_diffnet_post: operands must be 16-byte aligned");
+  PTPP_CHECK_ARG(!a->out_mask || a->lengths, "conv1d_diffnet_post: masks need lengths");
+  ConvP p;
+  p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.res = x; p.res2 = nullptr; p.y = xn; p.lengths = a->lengths;
+  p.B = a->B; p.T = a->T; p.Cin = a->Cin; p.Cout = a->Cout; p.ks = 1; p.dil = 1; p.pad = 0;
+  p.ldx = a->ldx; p.ldy = C; p.ldr = C; p.ldr2 = 0;
+  p.cinp = a->Cin;
+  p.act = PTPP_ACT_NONE; p.in_mask = a->in_mask; p.out_mask = a->out_mask;
+  p.out_scale = a->out_scale; p.res_scale = 1.f;
+  p.drop_thresh16 = 0; p.drop_inv_keep = 1.f; p.drop_seed = 0;
+  p.ws = nullptr; p.nsplit = 1;
+  p.post_skip = skip; p.post_dnext = dnext; p.post_yin = yin; p.post_C = C; p.post_init = init;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long tiles128 = (long long)p.B * ((p.T + 127) / 128) * ((p.Cout + 127) / 128);
+  const int rc = tiles128 >= 1536 ? launch_glds<4, 4, 2, 2, 2>(p, st) : launch_glds<2, 4, 2, 2, 2>(p, st);
+  if (rc < 0) {
+    ptpp_set_error("conv1d_diffnet_post: tile does not fit LDS");
+    return PTPP_EINVAL;
+  }
+  return rc;
 }

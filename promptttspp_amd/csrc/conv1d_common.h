@@ -47,6 +47,11 @@ struct ConvP {
   unsigned long long drop_seed;
   float* ws;   // split-K: f32 partial sums [nsplit][B][T][Cout] (no epilogue), summed by conv_splitk_finish_kernel
   int nsplit;  // 1 = no split
+  // fused DiffNet "post" epilogue (conv1d_glds.h, ptpp_conv1d_diffnet_post): Cout = 2 * post_C, res = x, y = xn
+  float* post_skip;         // nullptr = ordinary epilogue
+  const float* post_dnext;  // (B, post_C) or nullptr
+  void* post_yin;           // (B, T, post_C) or nullptr
+  int post_C, post_init;
 };
 
 // Fused epilogue of one (BM x BN) tile: acc[fm][fn] is the MFMA accumulator of the wave's

@@ -131,6 +131,135 @@ __device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
   }
 }
 
+// The DiffNet layer's tail fused into its 1 x 1 output projection (modules/denoiser.py:78-83; what diffnet_post_kernel
+// does as a separate pass over o = conv(g)):  channels [0, C) -> xn = (x + o) / sqrt(2), yin = xn + dnext[b];  channels
+// [C, 2C) -> skip (f32) = (init ? 0 : skip) + o.  C is a multiple of the tile width, so a tile is one or the other.
+// o is rounded to bf16 first, exactly as the two-kernel path stores and re-reads it: results are bit-identical to it.
+__device__ __forceinline__ float round_bf16(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+template <int FM, int FN, int WR, int WC>
+__device__ __forceinline__ void tile_epilogue_post(const ConvP& p, f32x4 (&acc)[FM][FN], uint4 (&resv)[FM * FN / 2],
+                                                   uint4 (&resv2)[FM * FN / 2], uint4* O, int b, int t0, int n0, int wm, int wn,
+                                                   int tid, int len) {
+  typedef bf16_raw T;
+  constexpr int NT = WR * WC * 64, BM = WR * FM * 16, BN = WC * FN * 16;
+  constexpr int QPR = BN / 8;
+  constexpr int NRV = BM * QPR / NT;
+  const int lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+  const int C = p.post_C;
+  const float r2 = 0.70710678118654752f;
+  if (n0 < C) {
+    uint4* O2 = O + BM * QPR;  // second image: yin
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / QPR, q = idx % QPR;
+      O[row * QPR + (q ^ (row & 15))] = resv[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < FN / 2; ++h) {
+      const int q = wn * FN * 2 + h * 4 + lg;
+      const int co = n0 + q * 8;
+      f32x4 bias[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dn[2] = {bias[0], bias[0]};
+      if (co < C) {
+        if (p.bias) { bias[0] = *reinterpret_cast<const f32x4*>(p.bias + co); bias[1] = *reinterpret_cast<const f32x4*>(p.bias + co + 4); }
+        if (p.post_dnext) {
+          dn[0] = *reinterpret_cast<const f32x4*>(p.post_dnext + (int64_t)b * C + co);
+          dn[1] = *reinterpret_cast<const f32x4*>(p.post_dnext + (int64_t)b * C + co + 4);
+        }
+      }
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const int row = (wm * FM + fm) * 16 + lr;
+        const bool keep = !(p.out_mask && t0 + row >= len);
+        uint4* slot = O + row * QPR + (q ^ (row & 15));
+        const uint4 r = *slot;
+        const float xv[8] = {__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                             __uint_as_float(r.y & 0xffff0000u), __uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u),
+                             __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+        float xn[8], yi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float o = keep ? round_bf16((acc[fm][2 * h + (e >> 2)][e & 3] + bias[e >> 2][e & 3]) * p.out_scale) : 0.f;
+          xn[e] = (xv[e] + o) * r2;
+          yi[e] = xn[e] + dn[e >> 2][e & 3];
+        }
+        uint4 o1, o2;
+        o1.x = (uint32_t)f32_to_bf16(xn[0]) | ((uint32_t)f32_to_bf16(xn[1]) << 16);
+        o1.y = (uint32_t)f32_to_bf16(xn[2]) | ((uint32_t)f32_to_bf16(xn[3]) << 16);
+        o1.z = (uint32_t)f32_to_bf16(xn[4]) | ((uint32_t)f32_to_bf16(xn[5]) << 16);
+        o1.w = (uint32_t)f32_to_bf16(xn[6]) | ((uint32_t)f32_to_bf16(xn[7]) << 16);
+        o2.x = (uint32_t)f32_to_bf16(yi[0]) | ((uint32_t)f32_to_bf16(yi[1]) << 16);
+        o2.y = (uint32_t)f32_to_bf16(yi[2]) | ((uint32_t)f32_to_bf16(yi[3]) << 16);
+        o2.z = (uint32_t)f32_to_bf16(yi[4]) | ((uint32_t)f32_to_bf16(yi[5]) << 16);
+        o2.w = (uint32_t)f32_to_bf16(yi[6]) | ((uint32_t)f32_to_bf16(yi[7]) << 16);
+        *slot = o1;
+        O2[row * QPR + (q ^ (row & 15))] = o2;
+      }
+    }
+    __syncthreads();
+    T* xnb = reinterpret_cast<T*>(p.y) + (int64_t)b * p.T * C;
+    T* yib = p.post_yin ? reinterpret_cast<T*>(p.post_yin) + (int64_t)b * p.T * C : nullptr;
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / QPR, q = idx % QPR;
+      const int t = t0 + row, co = n0 + q * 8;
+      if (t < p.T && co < C) {
+        *reinterpret_cast<uint4*>(xnb + (int64_t)t * C + co) = O[row * QPR + (q ^ (row & 15))];
+        if (yib) *reinterpret_cast<uint4*>(yib + (int64_t)t * C + co) = O2[row * QPR + (q ^ (row & 15))];
+      }
+    }
+  } else {
+    // f32 image of the skip rows: slot pair (2q, 2q+1) of row = 8 channels; the XOR keeps a pair adjacent
+    constexpr int SPR = 2 * QPR;
+    if (!p.post_init) {
+#pragma unroll
+      for (int i = 0; i < NRV; ++i) {
+        const int idx = tid + i * NT;
+        const int row = idx / QPR, q = idx % QPR;
+        const int s0 = (2 * q) ^ ((row & 15) << 1);
+        O[row * SPR + s0] = resv[i];
+        O[row * SPR + s0 + 1] = resv2[i];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int h = 0; h < FN / 2; ++h) {
+      const int q = wn * FN * 2 + h * 4 + lg;
+      const int co = n0 + q * 8;
+      f32x4 bias[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      if (p.bias && co < p.Cout) { bias[0] = *reinterpret_cast<const f32x4*>(p.bias + co); bias[1] = *reinterpret_cast<const f32x4*>(p.bias + co + 4); }
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const int row = (wm * FM + fm) * 16 + lr;
+        const bool keep = !(p.out_mask && t0 + row >= len);
+        f32x4* slot = reinterpret_cast<f32x4*>(O + row * SPR + ((2 * q) ^ ((row & 15) << 1)));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f32x4 s = p.post_init ? f32x4{0.f, 0.f, 0.f, 0.f} : slot[u];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] = (keep ? round_bf16((acc[fm][2 * h + u][e] + bias[u][e]) * p.out_scale) : 0.f) + s[e];
+          slot[u] = s;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / QPR, q = idx % QPR;
+      const int t = t0 + row, c = n0 - C + q * 8;
+      if (t < p.T && c < C) {
+        float* dst = p.post_skip + ((int64_t)b * p.T + t) * C + c;
+        const int s0 = (2 * q) ^ ((row & 15) << 1);
+        *reinterpret_cast<uint4*>(dst) = O[row * SPR + s0];
+        *reinterpret_cast<uint4*>(dst + 4) = O[row * SPR + s0 + 1];
+      }
+    }
+  }
+}
+
 __device__ unsigned long long* g_conv_stamps;  // experiments only (DBG = true): 4 clock stamps per block
 
 template <int FM, int FN, int WR, int WC, int D, bool DBG = false>
@@ -207,17 +336,32 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
 
   // the residual rows of the tile, fetched row-contiguous (see tile_epilogue) while the first operands travel:
   // the K loop's first vmcnt(0) retires them together with the first stage
-  const bool tile_epi = tile_epilogue_ok<FN>(p);
+  const bool post = p.post_skip != nullptr;
+  const bool tile_epi = post || tile_epilogue_ok<FN>(p);
   constexpr int NRV = BM * BN / 8 / (NW * 64);  // 16-byte vectors of the output tile per thread
-  uint4 resv[NRV];
-  if (tile_epi && p.res) {
+  uint4 resv[NRV], resv2[NRV];
+  if (post && n0 >= p.post_C) {  // "skip" half of the DiffNet output projection: the f32 skip rows, two vectors per slot
+    if (!p.post_init) {
+#pragma unroll
+      for (int i = 0; i < NRV; ++i) {
+        const int idx = tid + i * NW * 64;
+        const int row = idx / (BN / 8), q = idx % (BN / 8);
+        const int t = t0 + row, c = n0 - p.post_C + q * 8;
+        const float* src = p.post_skip + ((int64_t)b * p.T + t) * p.post_C + c;
+        const bool in = t < p.T && c < p.post_C;
+        resv[i] = in ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+        resv2[i] = in ? *reinterpret_cast<const uint4*>(src + 4) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  } else if (tile_epi && p.res) {
     const T* rb = reinterpret_cast<const T*>(p.res) + (int64_t)b * p.T * p.ldr;
 #pragma unroll
     for (int i = 0; i < NRV; ++i) {
       const int idx = tid + i * NW * 64;
       const int row = idx / (BN / 8), q = idx % (BN / 8);
       const int t = t0 + row, co = n0 + q * 8;
-      resv[i] = (t < p.T && co < p.Cout) ? *reinterpret_cast<const uint4*>(rb + (int64_t)t * p.ldr + co) : make_uint4(0, 0, 0, 0);
+      resv[i] = (t < p.T && co < (post ? p.post_C : p.Cout)) ? *reinterpret_cast<const uint4*>(rb + (int64_t)t * p.ldr + co)
+                                                             : make_uint4(0, 0, 0, 0);
     }
   }
   if (steps > 0) {
@@ -268,9 +412,13 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
   if (tile_epi) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with the operand stages: their memory becomes the tile
-    act_dispatch(p.act, [&](auto tag) {
-      tile_epilogue<FM, FN, WR, WC, decltype(tag)::value>(p, acc, resv, reinterpret_cast<uint4*>(smem), b, t0, n0, wm, wn, tid, len);
-    });
+    if (post) {
+      tile_epilogue_post<FM, FN, WR, WC>(p, acc, resv, resv2, reinterpret_cast<uint4*>(smem), b, t0, n0, wm, wn, tid, len);
+    } else {
+      act_dispatch(p.act, [&](auto tag) {
+        tile_epilogue<FM, FN, WR, WC, decltype(tag)::value>(p, acc, resv, reinterpret_cast<uint4*>(smem), b, t0, n0, wm, wn, tid, len);
+      });
+    }
   } else {
     conv_epilogue<T, FM, FN>(p, acc, b, t0, n0, wm, wn, lane, len);
   }

@@ -659,6 +659,9 @@ def diffnet_cond_all(cond, cond_ws, cond_bs, gate_perm=False):
     return ops.conv1d(cond, wp, bp, rows), cond_ws
 
 
+FUSE_DIFFNET_POST = not os.environ.get("PTPP_NO_FUSED_POST")  # (tests compare the fused launch with the two-kernel path)
+
+
 def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
     """weights: per layer (dil_w, dil_b, out_w, out_b).  Returns (skip_sum f32, saved)."""
     L = len(weights)
@@ -670,6 +673,7 @@ def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
     saved = []
     fused = (not save) and lengths is None and diffnet_fused_gate(h0.dtype)  # cond_all is in gate order then
     perm = _gate_perm(2 * C, h0.device) if fused else None
+    fuse_post = FUSE_DIFFNET_POST and h0.is_cuda and ops.conv1d_diffnet_post_supported(C, C, h0.dtype) and h0.is_contiguous()
     for l, (dw, db, ow, ob) in enumerate(weights):
         d = 2 ** (l % cycle)
         if fused:
@@ -683,11 +687,15 @@ def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
             a = ops.conv1d(yin, packed(dw, h0.dtype), _f32c(db), 2 * C, ks=3, dil=d, pad=d,
                            res=cond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
             g = ops.gate_fwd(a)
-        o = ops.conv1d(g, packed(ow, h0.dtype), _f32c(ob), 2 * C, lengths=lengths, out_mask=lengths is not None)
         if save:
             saved.append((yin, a, g))
         nxt = ds[l + 1] if l + 1 < L else None
-        x, yin = ops.diffnet_post_fwd(o, x, skip, nxt, init=(l == 0))
+        if fuse_post:  # output projection + residual / skip / next-input update in one launch (o is never stored)
+            x, yin = ops.conv1d_diffnet_post(g, packed(ow, h0.dtype), _f32c(ob), x, skip, nxt, init=(l == 0), lengths=lengths,
+                                             out_mask=lengths is not None)
+        else:
+            o = ops.conv1d(g, packed(ow, h0.dtype), _f32c(ob), 2 * C, lengths=lengths, out_mask=lengths is not None)
+            x, yin = ops.diffnet_post_fwd(o, x, skip, nxt, init=(l == 0))
     return skip, saved
 
 

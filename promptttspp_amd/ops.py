@@ -442,6 +442,39 @@ def diffnet_post_fwd(o, x, skip, dnext, init, want_yin=True):
     return xn, yin
 
 
+_post_ok = {}
+
+
+def conv1d_diffnet_post_supported(C, cin, dtype):
+    key = (C, cin, dtype)
+    ok = _post_ok.get(key)
+    if ok is None:
+        ok = _post_ok[key] = bool(_lib.load().ptpp_conv1d_diffnet_post_supported(int(C), int(cin), dtype_code(dtype)))
+    return ok
+
+
+def conv1d_diffnet_post(g, wp, bias, x, skip, dnext, init, lengths=None, out_mask=False, want_yin=True):
+    """The DiffNet layer's 1 x 1 output projection of ``g`` with ``diffnet_post_fwd`` fused into its epilogue
+    (ptpp_conv1d_diffnet_post): returns (xn, yin) and updates ``skip`` in place; the 2C-channel projection output is
+    never stored.  Bit-identical to ``conv1d`` followed by ``diffnet_post_fwd``."""
+    B, T, cin = g.shape
+    C = x.shape[2]
+    xn = torch.empty_like(x)
+    yin = torch.empty_like(x) if (want_yin and dnext is not None) else None
+    if lengths is not None:
+        lengths = i32(lengths, g.device)
+    assert x.is_contiguous() and skip.is_contiguous() and skip.dtype == torch.float32
+    assert dnext is None or (dnext.is_contiguous() and dnext.dtype == torch.float32)
+    _CONV_FMT.pack_into(_conv_buf, 0, g.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else 0, 0, 0,
+                        lengths.data_ptr() if lengths is not None else 0, B, T, cin, 2 * C, 1, 1, 0, _ld_fast(g), C, 0,
+                        _ACT[None], 0, 1 if out_mask else 0, 1.0, BF16)
+    check(_lib.load().ptpp_conv1d_diffnet_post(_conv_args_ref, x.data_ptr(), skip.data_ptr(),
+                                               dnext.data_ptr() if dnext is not None else None, xn.data_ptr(),
+                                               yin.data_ptr() if yin is not None else None, 1 if init else 0, _stream()),
+          "ptpp_conv1d_diffnet_post")
+    return xn, yin
+
+
 def diffnet_post_bwd(gx, gskip, lengths):
     B, T, C = gx.shape
     dout = torch.empty((B, T, 2 * C), device=gx.device, dtype=gx.dtype)

@@ -618,3 +618,30 @@ def test_mel_front_end_and_lowpass_on_device(dev):
         y = lowpass_filter(torch.from_numpy(x).to(dev), 100, cutoff=20).cpu()
         ref = x if shape[-1] <= 18 else R.filtfilt_zero_state(x, b, a)
         assert float((y.double() - torch.from_numpy(np.ascontiguousarray(ref))).abs().max()) < 2e-6, shape
+
+
+@pytest.mark.parametrize("B,T,C,masked", [(3, 150, 128, False), (2, 333, 256, True), (5, 40, 256, False), (40, 640, 256, True)])
+def test_conv1d_diffnet_post_fused_is_bit_identical_to_the_two_kernel_path(dev, B, T, C, masked):
+    """ptpp_conv1d_diffnet_post (1 x 1 output projection with the DiffNet layer's residual / skip / next-input update in
+    its epilogue, modules/denoiser.py:78-83) against ptpp_conv1d_fwd + ptpp_diffnet_post_fwd on the same inputs:
+    xn, yin (bf16) and the f32 skip accumulator are equal bit for bit, first layer (init) and later layers, with and
+    without the sequence mask, with and without a next layer (yin)."""
+    from promptttspp_amd import ops
+
+    assert ops.conv1d_diffnet_post_supported(C, C, torch.bfloat16)
+    g = rnd(1, B, T, C).to(dev).bfloat16()
+    x = rnd(2, B, T, C).to(dev).bfloat16()
+    w = (rnd(3, 2 * C, C, 1) * 0.08).to(dev)
+    bias = (rnd(4, 2 * C) * 0.1).to(dev)
+    wp = ops.pack_conv_weight(w, torch.bfloat16)
+    dn = rnd(5, B, C).to(dev).float().contiguous()
+    lengths = torch.tensor([max(1, T - 17 * i) for i in range(B)], device=dev, dtype=torch.int32) if masked else None
+    for init in (True, False):
+        for dnext in (dn, None):
+            skip_a = rnd(6, B, T, C).to(dev).float().contiguous()
+            skip_b = skip_a.clone()
+            o = ops.conv1d(g, wp, bias, 2 * C, lengths=lengths, out_mask=masked)
+            xn_a, yin_a = ops.diffnet_post_fwd(o, x, skip_a, dnext, init=init)
+            xn_b, yin_b = ops.conv1d_diffnet_post(g, wp, bias, x, skip_b, dnext, init=init, lengths=lengths, out_mask=masked)
+            assert torch.equal(xn_a, xn_b) and torch.equal(skip_a, skip_b)
+            assert (yin_a is None) == (yin_b is None) and (yin_a is None or torch.equal(yin_a, yin_b))
