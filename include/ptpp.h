@@ -278,6 +278,14 @@ int ptpp_conv1d_diffnet_post_supported(int C, int cin, int dtype);
 int ptpp_conv1d_diffnet_post(const ptpp_conv1d_args* a, const void* x, float* skip,
                              const float* dnext, void* xn, void* yin, int init,
                              void* stream);
+/* One reverse step of the DDPM sampler (modules/diffusion.py:283-302: predict_start_from_noise, clamp to [-1, 1],
+ * q_posterior, + sigma_t * noise) on (B, per_b) f32 elements; t: (B) int64 step indices ON THE DEVICE; the five
+ * schedule buffers are the module's f32 tables (sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,
+ * posterior_mean_coef1, posterior_mean_coef2, posterior_log_variance_clipped); eps in eps_dtype; noise nullable. */
+int ptpp_ddpm_step(const float* x, const void* eps, const float* noise, const int64_t* t,
+                   const float* sra, const float* srm1, const float* c1, const float* c2,
+                   const float* logvar, float* out, int B, int64_t per_b, int eps_dtype,
+                   void* stream);
 /* dout (rows, 2C) = [gx/sqrt2 | gskip], masked rows zero */
 int ptpp_diffnet_post_bwd(const void* gx, const void* gskip, void* dout,
                           const int32_t* lengths, int B, int T, int C, int dtype,

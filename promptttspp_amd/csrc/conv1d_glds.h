@@ -63,8 +63,7 @@ __device__ __forceinline__ int wperm_inv(int q) {
 template <int FN>
 __device__ __forceinline__ bool tile_epilogue_ok(const ConvP& p) {
   const bool al16 = ((uintptr_t)p.y & 15) == 0 && (!p.res || ((uintptr_t)p.res & 15) == 0);
-  return FN % 2 == 0 && (p.Cout & 7) == 0 && (p.ldy & 7) == 0 && al16 && (!p.res || (p.ldr & 7) == 0) && !p.res2 &&
-         p.act != PTPP_ACT_GATE;
+  return FN % 2 == 0 && (p.Cout & 7) == 0 && (p.ldy & 7) == 0 && al16 && (!p.res || (p.ldr & 7) == 0) && !p.res2;
 }
 template <int FM, int FN, int WR, int WC, int ACT>
 __device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][FN], uint4 (&resv)[WR * FM * WC * FN * 32 / (WR * WC * 64)],
@@ -112,12 +111,24 @@ __device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
         v[1][0] += __uint_as_float(r.z << 16) * e_rscale; v[1][1] += __uint_as_float(r.z & 0xffff0000u) * e_rscale;
         v[1][2] += __uint_as_float(r.w << 16) * e_rscale; v[1][3] += __uint_as_float(r.w & 0xffff0000u) * e_rscale;
       }
-      uint4 o;
-      o.x = (uint32_t)f32_to_bf16(v[0][0]) | ((uint32_t)f32_to_bf16(v[0][1]) << 16);
-      o.y = (uint32_t)f32_to_bf16(v[0][2]) | ((uint32_t)f32_to_bf16(v[0][3]) << 16);
-      o.z = (uint32_t)f32_to_bf16(v[1][0]) | ((uint32_t)f32_to_bf16(v[1][1]) << 16);
-      o.w = (uint32_t)f32_to_bf16(v[1][2]) | ((uint32_t)f32_to_bf16(v[1][3]) << 16);
-      *slot = o;
+      if constexpr (ACT == PTPP_ACT_GATE) {
+        // fused DiffNet gate: the 8 channels are [4 "gate" | their 4 "filter" partners] (weights packed in that
+        // interleaved order); y has Cout / 2 channels -- the 8-byte result takes the first half of the slot
+        float gte[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gte[e] = keep ? tanhf(v[1][e]) / (1.f + __expf(-v[0][e])) : 0.f;
+        uint2 o;
+        o.x = (uint32_t)f32_to_bf16(gte[0]) | ((uint32_t)f32_to_bf16(gte[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(gte[2]) | ((uint32_t)f32_to_bf16(gte[3]) << 16);
+        *reinterpret_cast<uint2*>(slot) = o;
+      } else {
+        uint4 o;
+        o.x = (uint32_t)f32_to_bf16(v[0][0]) | ((uint32_t)f32_to_bf16(v[0][1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(v[0][2]) | ((uint32_t)f32_to_bf16(v[0][3]) << 16);
+        o.z = (uint32_t)f32_to_bf16(v[1][0]) | ((uint32_t)f32_to_bf16(v[1][1]) << 16);
+        o.w = (uint32_t)f32_to_bf16(v[1][2]) | ((uint32_t)f32_to_bf16(v[1][3]) << 16);
+        *slot = o;
+      }
     }
   }
   __syncthreads();
@@ -127,7 +138,12 @@ __device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
     const int idx = tid + i * NT;
     const int row = idx / QPR, q = idx % QPR;
     const int t = t0 + row, co = n0 + q * 8;
-    if (t < p.T && co < p.Cout && !(p.nsplit & 2)) *reinterpret_cast<uint4*>(yb + (int64_t)t * p.ldy + co) = O[row * QPR + (q ^ (row & 15))];
+    if (t < p.T && co < p.Cout && !(p.nsplit & 2)) {
+      if constexpr (ACT == PTPP_ACT_GATE)
+        *reinterpret_cast<uint2*>(yb + (int64_t)t * p.ldy + (co >> 1)) = *reinterpret_cast<const uint2*>(O + row * QPR + (q ^ (row & 15)));
+      else
+        *reinterpret_cast<uint4*>(yb + (int64_t)t * p.ldy + co) = O[row * QPR + (q ^ (row & 15))];
+    }
   }
 }
 

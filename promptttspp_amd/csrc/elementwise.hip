@@ -118,6 +118,36 @@ __global__ void diffnet_post_kernel(const T* __restrict__ o, const T* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------
+// One reverse-diffusion update of the sampler (modules/diffusion.py:283-302 of the reference: predict_start_from_noise,
+// clamp, q_posterior, + sigma * noise) as ONE pass instead of ~20 small tensor ops per step:
+//   x0  = clamp(sra[t] * x - srm1[t] * eps, -1, 1)
+//   out = (c1[t] * x0 + c2[t] * x) + exp(0.5 * logvar[t]) * noise        (t = t[b], the schedule buffers are gathered here)
+// Every product and sum is rounded separately (no fma contraction), as the tensor ops they replace.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const T* __restrict__ eps, const float* __restrict__ noise,
+                                 const long long* __restrict__ t, const float* __restrict__ sra, const float* __restrict__ srm1,
+                                 const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ logvar,
+                                 float* __restrict__ out, int64_t per_b4, int64_t nvec) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const long long tb = t[i / per_b4];
+    const float a = sra[tb], bq = srm1[tb], k1 = c1[tb], k2 = c2[tb], sg = expf(__fmul_rn(0.5f, logvar[tb]));
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4), ev = Elem<T>::ld4(eps + i * 4);
+    f32x4 nv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (noise) nv = *reinterpret_cast<const f32x4*>(noise + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x0 = __fsub_rn(__fmul_rn(a, xv[e]), __fmul_rn(bq, ev[e]));
+      x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      const float mean = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xv[e]));
+      o[e] = __fadd_rn(mean, __fmul_rn(sg, nv[e]));
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = o;
+  }
+}
+
 // backward: do[:, :C] = gx / sqrt(2), do[:, C:] = gskip   (masked rows -> 0)
 template <typename T>
 __global__ void diffnet_post_bwd_kernel(const T* __restrict__ gx, const T* __restrict__ gskip, T* __restrict__ dout,
@@ -331,5 +361,21 @@ extern "C" int ptpp_length_regulate_bwd(const void* dy, const int32_t* cum, void
   DISPATCH_T(dtype, "length_regulate_bwd",
              hipLaunchKernelGGL(length_regulate_bwd_kernel<T>, grid, dim3(256), 0, st, (const T*)dy, cum, (T*)dx, Tp, Tf, C));
   PTPP_CHECK_LAUNCH("length_regulate_bwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_ddpm_step(const float* x, const void* eps, const float* noise, const int64_t* t, const float* sra,
+                              const float* srm1, const float* c1, const float* c2, const float* logvar, float* out, int B,
+                              int64_t per_b, int eps_dtype, void* stream) {
+  PTPP_CHECK_ARG(x && eps && t && sra && srm1 && c1 && c2 && logvar && out && B > 0 && per_b > 0 && per_b % 4 == 0,
+                 "ddpm_step: bad args");
+  PTPP_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)noise % 16) == 0 &&
+                     ((uintptr_t)eps % 8) == 0, "ddpm_step: operands must be vector aligned");
+  const int64_t nvec = (int64_t)B * per_b / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(eps_dtype, "ddpm_step",
+             hipLaunchKernelGGL(ddpm_step_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, x, (const T*)eps, noise,
+                                reinterpret_cast<const long long*>(t), sra, srm1, c1, c2, logvar, out, per_b / 4, nvec));
+  PTPP_CHECK_LAUNCH("ddpm_step");
   return PTPP_OK;
 }

@@ -128,18 +128,23 @@ class GaussianDiffusion(nn.Module):
     def _p_sample_core(self, x, t, cond, cond_all, noise):
         """One reverse step for a device tensor of step indices ``t`` (B,): x_{t-1} = mean + sigma_t * noise
         (reference: diffusion.py:283-302; at t == 0 the caller passes zero noise)."""
-        eps = self.denoise_fn.forward_cl(x.to(cond.dtype), t, cond, None, cond_all=cond_all).float()
+        eps = self.denoise_fn.forward_cl(x.to(cond.dtype), t, cond, None, cond_all=cond_all)
+        if x.is_cuda and x.dtype == torch.float32 and (x.numel() // x.shape[0]) % 4 == 0:
+            from .. import ops
+
+            return ops.ddpm_step(x.contiguous(), eps.contiguous(), None if noise is None else noise.contiguous(), t,
+                                 self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
+                                 self.posterior_mean_coef2, self.posterior_log_variance_clipped)
+        eps = eps.float()
         x0 = self.predict_start_from_noise(x, t, eps).clamp_(-1.0, 1.0)
         mean, _, logvar = self.q_posterior(x0, x, t)
-        return mean + (0.5 * logvar).exp() * noise
+        return mean if noise is None else mean + (0.5 * logvar).exp() * noise
 
     @torch.no_grad()
     def p_sample_cl(self, x, i, cond, cond_all, noise):
         B = x.shape[0]
         t = torch.full((B,), i, device=x.device, dtype=torch.long)
-        if noise is None:  # i == 0: the posterior mean
-            noise = torch.zeros_like(x)
-        return self._p_sample_core(x, t, cond, cond_all, noise)
+        return self._p_sample_core(x, t, cond, cond_all, noise)  # noise None at i == 0: the posterior mean
 
     @torch.no_grad()
     def inference_plms_cl(self, cond, interval, noise_fn=None):

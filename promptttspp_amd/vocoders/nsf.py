@@ -4,8 +4,8 @@ phase by cumulative sum of f0/sr with wrap compensation, U/V-gated noise, then a
 Linear(harmonics+1 -> 1) + tanh merge.
 
 The source is (B, Tf*240, 9) -- 0.1 % of the vocoder's arithmetic -- and is a chain of
-elementwise ops plus ONE prefix scan over time; it stays on torch tensor ops in float32
-(the scan is torch.cumsum).  Same RNG draw order as the reference (rand for the initial
+elementwise ops plus two prefix scans over time; it stays on torch tensor ops in float32
+(the scans are torch.cumsum over the innermost dimension of a (B, dim, L) copy).  Same RNG draw order as the reference (rand for the initial
 phases, randn_like for the additive noise, one unused randn_like in SourceModuleHnNSF),
 so seeding reproduces the reference stream on the same device."""
 import numpy as np
@@ -32,11 +32,14 @@ class SineGen(nn.Module):
         rand_ini = torch.rand(f0_values.shape[0], f0_values.shape[2], device=f0_values.device)
         rand_ini[:, 0] = 0
         rad[:, 0, :] = rad[:, 0, :] + rand_ini
-        wrapped = torch.cumsum(rad, 1) % 1
-        over = (wrapped[:, 1:, :] - wrapped[:, :-1, :]) < 0
+        # the two prefix scans run with time as the INNERMOST dimension: torch's outer-dimension scan of the
+        # (B, L, dim) layout took 24 ms per call at 32 x 141 600 x 9 (48 of the 247 ms of the config-5 app path,
+        # profiles/r02b_app_path.md); the transposed copies cost two 160 MB passes
+        rad = rad.transpose(1, 2).contiguous()  # (B, dim, L)
+        wrapped = torch.cumsum(rad, 2) % 1
         shift = torch.zeros_like(rad)
-        shift[:, 1:, :] = over * -1.0
-        return torch.sin(torch.cumsum(rad + shift, dim=1) * 2 * np.pi)
+        shift[:, :, 1:] = ((wrapped[:, :, 1:] - wrapped[:, :, :-1]) < 0) * -1.0
+        return torch.sin(torch.cumsum(rad + shift, dim=2) * 2 * np.pi).transpose(1, 2)
 
     @torch.no_grad()
     def forward(self, f0):

@@ -645,3 +645,32 @@ def test_conv1d_diffnet_post_fused_is_bit_identical_to_the_two_kernel_path(dev, 
             xn_b, yin_b = ops.conv1d_diffnet_post(g, wp, bias, x, skip_b, dnext, init=init, lengths=lengths, out_mask=masked)
             assert torch.equal(xn_a, xn_b) and torch.equal(skip_a, skip_b)
             assert (yin_a is None) == (yin_b is None) and (yin_a is None or torch.equal(yin_a, yin_b))
+
+
+def test_ddpm_step_matches_the_tensor_ops(dev):
+    """ptpp_ddpm_step against the tensor-op chain it replaces (predict_start_from_noise -> clamp -> q_posterior ->
+    + sigma * noise, reference modules/diffusion.py:283-302) with the module's own schedule buffers: equal to the last
+    bit or two in f32 (every product / sum rounded separately), for bf16 eps, per-utterance step indices, and the
+    noise-free last step."""
+    from promptttspp_amd import ops
+    from promptttspp_amd.modules.diffusion import GaussianDiffusion
+
+    class _Stub(torch.nn.Module):
+        in_dim = 80
+
+    gd = GaussianDiffusion(256, 80, _Stub(), K_step=100).to(dev)
+    B, T, M = 5, 37, 80
+    x = rnd(1, B, T, M).to(dev).float().contiguous() * 1.5
+    noise = rnd(2, B, T, M).to(dev).float().contiguous()
+    t = torch.tensor([99, 0, 17, 50, 3], device=dev, dtype=torch.long)
+    for eps in (rnd(3, B, T, M).to(dev).float().contiguous(), rnd(3, B, T, M).to(dev).bfloat16().contiguous()):
+        for nz in (noise, None):
+            e = eps.float()
+            x0 = gd.predict_start_from_noise(x, t, e).clamp_(-1.0, 1.0)
+            mean, _, logvar = gd.q_posterior(x0, x, t)
+            ref = mean if nz is None else mean + (0.5 * logvar).exp() * nz
+            got = ops.ddpm_step(x, eps, nz, t, gd.sqrt_recip_alphas_cumprod, gd.sqrt_recipm1_alphas_cumprod,
+                                gd.posterior_mean_coef1, gd.posterior_mean_coef2, gd.posterior_log_variance_clipped)
+            d = float((ref - got).abs().max())
+            print("ddpm_step max |diff|", d, "max |ref|", float(ref.abs().max()))
+            assert d <= 2e-6 * max(1.0, float(ref.abs().max())), d  # (a last-bit difference in exp(0.5 * logvar) at most)
