@@ -6,8 +6,12 @@
 // free: tiles are staged row-major [row][channel] with plain 16-byte copies, and each
 // operand fragment is two tr reads (4 rows x 16 channels each).
 //
-// A block owns one (TM co x TN ci) tile of ONE tap and a strided subset of the 32-row
-// K-chunks (split-K).  Wave tile = TM/2 x TN/2 (up to 64x64 = 16 accumulator tiles).
+// A block owns one (TM co x TN ci) tile of a GROUP of up to TG taps and a strided subset of
+// the 32-row K-chunks (split-K).  The taps of a group share the dy chunk and one x window of
+// 32 + (TG-1)*dil rows (each tap reads it at its own row offset): with one tap per block the
+// launch re-read both operands once per tap and was bound by L2 -> LDS traffic (368 MB per
+// 256->512 k=3 launch = 6.6 TB/s at 56 us, profiles/r02b_*), with three taps per block it moves a
+// third of that for the same MFMAs.  Wave tile = TM/2 x TN/2 (up to 64x64 = 16 accumulator tiles).
 // Measured: with one chunk in flight a loop iteration costs a full ~1.2 us memory round
 // trip, 5x its MFMA time, and a register pipeline two chunks deep spills.  So the chunks
 // go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a
@@ -21,6 +25,8 @@
 // ([split][tap][co][ci], coalesced) and a second kernel sums the splits in a fixed order
 // and adds into dw: deterministic, and ~10x cheaper than the atomics.  Without a
 // workspace the partials are combined with atomics (fewer splits).
+#include <stdlib.h>
+
 #include "ptpp_common.h"
 
 namespace {
@@ -82,9 +88,10 @@ __device__ __forceinline__ Frag frag(const bf16_raw* tile, int row0, int c0, int
   const int row = row0 + 8 * g + (i >> 2);
   const int col = c0 + 4 * (i & 3);
   const bf16_raw* p = tile + row * TW + (((col >> 3) ^ sw<CPR>(row)) << 3) + (col & 7);
+  const bf16_raw* q = tile + (row + 4) * TW + (((col >> 3) ^ sw<CPR>(row + 4)) << 3) + (col & 7);  // (== p + 4 TW for row0 % 8 == 0)
   Frag f;
   f.lo = tr_read(p);
-  f.hi = tr_read(p + 4 * TW);  // sw(row + 4) == sw(row)
+  f.hi = tr_read(q);
   return f;
 }
 
@@ -107,16 +114,18 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int FM, int FN, int WR = 2, int WC = 2>
+// XH: extra x rows of a tap group's window, (TG - 1) * dil <= XH
+template <int FM, int FN, int WR = 2, int WC = 2, int TG = 1, int XH = 0>
 __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const WgP p, const int* __restrict__ lengths) {
   constexpr int NW = WR * WC;  // waves per block, WR x WC over (co, ci)
   constexpr int TM = WR * FM * 16, TN = WC * FN * 16;
+  constexpr int XR = KR + XH;                       // x rows per stage
   constexpr int CY = TM / 8, CX = TN / 8;          // 16-byte chunks per row
   constexpr int RY = 64 / CY, RX = 64 / CX;        // rows per 1 KiB piece
-  constexpr int LY = KR / RY / NW, LX = KR / RX / NW;  // pieces per wave and chunk
-  static_assert(LY >= 1 && LX >= 1 && LY * RY * NW == KR && LX * RX * NW == KR, "pieces must divide over the waves");
+  constexpr int LY = KR / RY / NW, LX = XR / RX / NW;  // pieces per wave and chunk
+  static_assert(LY >= 1 && LX >= 1 && LY * RY * NW == KR && LX * RX * NW == XR, "pieces must divide over the waves");
   constexpr int LPW = LY + LX;                     // LDS-DMA instructions per wave and chunk
-  constexpr int STAGE = KR * (TM + TN);            // elements per ring stage
+  constexpr int STAGE = KR * TM + XR * TN;         // elements per ring stage
   extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object (see header)
   bf16_raw* S = reinterpret_cast<bf16_raw*>(smem);  // [NS][dy: KR x TM | x: KR x TN]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,17 +134,21 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int cot = bid % p.nCO; bid /= p.nCO;
   const int cit = bid % p.nCI; bid /= p.nCI;
-  const int j = bid % p.ks;    bid /= p.ks;
+  const int ntg = (p.ks + TG - 1) / TG;
+  const int j = (bid % ntg) * TG; bid /= ntg;  // first tap of this block's group
   const int split = bid;
   const int co0 = cot * TM, ci0 = cit * TN;
   const int shift = j * p.dil - p.pad;
+  const int ntap = min(TG, p.ks - j);  // taps of the group (block-uniform)
 
-  f32x4 acc[FM][FN], accb[FM];
+  f32x4 acc[TG][FM][FN], accb[FM];
 #pragma unroll
   for (int a = 0; a < FM; ++a) {
     accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < FN; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < TG; ++g)
+#pragma unroll
+      for (int c = 0; c < FN; ++c) acc[g][a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const bool do_bias = p.dbias && cit == 0 && j == 0 && wc == 0;  // wave-uniform
   const int total = p.B * p.tchunks;
@@ -173,8 +186,8 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
     }
 #pragma unroll
     for (int q = 0; q < LX; ++q) {
-      const int t = tb + xrow[q], ts = t + shift;
-      const bool ok = t < p.T && ts >= 0 && ts < Tin && ci0 + xcol[q] < p.Cin;
+      const int ts = tb + xrow[q] + shift;  // (rows paired only with dy rows past T meet zeros there)
+      const bool ok = ts >= 0 && ts < Tin && ci0 + xcol[q] < p.Cin;
       const char* src = ok ? reinterpret_cast<const char*>(xb + (int64_t)ts * p.ldx + xcol[q]) : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + KR * TM + (wave * LX + q) * 512), 16, 0, 0);
     }
@@ -196,23 +209,30 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
     if (i + NS - 1 < n) issue(i + NS - 1);  // into the stage chunk i - 1 just vacated
     const bf16_raw* Yb = S + (i % NS) * STAGE;
     const bf16_raw* Xb = Yb + KR * TM;
-    Frag fa[FM], fb[FN];
+    Frag fa[FM];
 #pragma unroll
     for (int a = 0; a < FM; ++a) fa[a] = frag<TM>(Yb, 0, (wr * FM + a) * 16, lane);
-#pragma unroll
-    for (int c = 0; c < FN; ++c) fb[c] = frag<TN>(Xb, 0, (wc * FN + c) * 16, lane);
     lds_fence(fa);
-    lds_fence(fb);
-    bf16x8_t af[FM], bfr[FN];
+    bf16x8_t af[FM];
 #pragma unroll
     for (int a = 0; a < FM; ++a) af[a] = join(fa[a]);
 #pragma unroll
-    for (int c = 0; c < FN; ++c) bfr[c] = join(fb[c]);
+    for (int g = 0; g < TG; ++g) {
+      if (g < ntap) {
+        Frag fb[FN];
 #pragma unroll
-    for (int a = 0; a < FM; ++a)
+        for (int c = 0; c < FN; ++c) fb[c] = frag<TN>(Xb, g * p.dil, (wc * FN + c) * 16, lane);
+        lds_fence(fb);
+        bf16x8_t bfr[FN];
 #pragma unroll
-      for (int c = 0; c < FN; ++c)
-        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[c], acc[a][c], 0, 0, 0);
+        for (int c = 0; c < FN; ++c) bfr[c] = join(fb[c]);
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int c = 0; c < FN; ++c)
+            acc[g][a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[c], acc[g][a][c], 0, 0, 0);
+      }
+    }
     if (do_bias) {
 #pragma unroll
       for (int a = 0; a < FM; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
@@ -222,19 +242,23 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
   // D[i = co (rows 4*(lane>>4) + r)][j = ci (col lane&15)]
   const int lr = lane & 15, lg = lane >> 4;
 #pragma unroll
-  for (int a = 0; a < FM; ++a)
+  for (int g = 0; g < TG; ++g) {
+    if (g >= ntap) break;
 #pragma unroll
-    for (int c = 0; c < FN; ++c) {
-      const int ci = ci0 + (wc * FN + c) * 16 + lr;
+    for (int a = 0; a < FM; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + (wr * FM + a) * 16 + lg * 4 + r;
-        if (co < p.Cout && ci < p.Cin) {
-          if (p.ws) p.ws[(((int64_t)split * p.ks + j) * p.Cout + co) * p.Cin + ci] = acc[a][c][r];
-          else atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * p.ks + j, acc[a][c][r]);
+      for (int c = 0; c < FN; ++c) {
+        const int ci = ci0 + (wc * FN + c) * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + (wr * FM + a) * 16 + lg * 4 + r;
+          if (co < p.Cout && ci < p.Cin) {
+            if (p.ws) p.ws[(((int64_t)split * p.ks + j + g) * p.Cout + co) * p.Cin + ci] = acc[g][a][c][r];
+            else atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * p.ks + j + g, acc[g][a][c][r]);
+          }
         }
       }
-    }
+  }
   if (do_bias && lr == 0) {  // every column of accb holds the row sums
 #pragma unroll
     for (int a = 0; a < FM; ++a)
@@ -261,18 +285,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int k = 0; k < 4; ++k) d[(int64_t)k * ks] += s[k];
 }
 
-template <int FM, int FN, int WR = 2, int WC = 2>
+template <int FM, int FN, int WR = 2, int WC = 2, int TG = 1, int XH = 0>
 int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
   constexpr int TM = WR * FM * 16, TN = WC * FN * 16;
+  constexpr int XR = KR + XH;
   p.nCO = (p.Cout + TM - 1) / TM;
   p.nCI = (p.Cin + TN - 1) / TN;
   p.tchunks = (p.T + KR - 1) / KR;
   const int total = p.B * p.tchunks;
-  const int tiles = p.nCO * p.nCI * p.ks;
+  const int tiles = p.nCO * p.nCI * ((p.ks + TG - 1) / TG);
   const size_t ebytes = (size_t)p.ks * p.Cout * p.Cin * sizeof(float);
   int nsplit;
   if (p.ws && ws_bytes >= ebytes) {
-    nsplit = (384 + tiles - 1) / tiles;  // 1-2 resident blocks per CU (measured optimum 256..512 blocks)
+    nsplit = ((TG > 1 ? 256 : 384) + tiles - 1) / tiles;  // 1-2 resident blocks per CU (measured optimum 256..512 blocks;
+                                                           // a tap-group block fills a CU on its own)
     if (nsplit > 48) nsplit = 48;        // few output tiles: more splits only add partial traffic
     if ((size_t)nsplit * ebytes > ws_bytes) nsplit = (int)(ws_bytes / ebytes);
     if (nsplit > (total + 7) / 8) nsplit = (total + 7) / 8;
@@ -285,9 +311,11 @@ int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
   }
   if (nsplit < 1) nsplit = 1;
   p.nsplit = nsplit;
-  const size_t smem = (size_t)NS * KR * (TM + TN) * sizeof(bf16_raw);
-  hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<FM, FN, WR, WC>), dim3((unsigned)((int64_t)tiles * nsplit)), dim3(WR * WC * 64), smem,
-                     st, p,
+  const size_t smem = (size_t)NS * (KR * TM + XR * TN) * sizeof(bf16_raw);
+  auto kern = conv1d_wgrad_bf16_kernel<FM, FN, WR, WC, TG, XH>;
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)tiles * nsplit)), dim3(WR * WC * 64), smem, st, p,
                      p.in_mask ? p.lengths : nullptr);
   PTPP_CHECK_LAUNCH("conv1d_wgrad(bf16)");
   if (p.ws) {
@@ -312,6 +340,11 @@ int ptpp_wgrad_bf16_launch(const void* x, const void* dy, float* dw, float* dbia
   p.in_mask = in_mask;
   const bool bigM = Cout > 64, bigN = Cin > 64;
   // (8 waves of 32 x 64 / 64 x 32 measured equal to 4 waves of 64 x 64 here: this kernel is not latency-bound)
+  // several taps per block when their common x window fits the stage (see the header); PTPP_WGRAD_TAPS=1 keeps one
+  static const char* tg = getenv("PTPP_WGRAD_TAPS");
+  // (8 waves of 64 x 32 with three taps: 57 us against 87 us for the 256->512 k=3 layer over 30 k rows; 4 waves of
+  //  64 x 64 with two or three taps spend their time moving accumulators between the register files and lose)
+  if (bigM && bigN && ks > 1 && 2 * dil <= 32 && !(tg && tg[0] == '1')) return launch<4, 2, 2, 4, 3, 32>(p, ws_bytes, st);
   if (bigM && bigN) return launch<4, 4>(p, ws_bytes, st);
   if (bigM) return launch<4, 2>(p, ws_bytes, st);
   if (bigN) return launch<2, 4>(p, ws_bytes, st);
