@@ -620,7 +620,8 @@ def test_mel_front_end_and_lowpass_on_device(dev):
         assert float((y.double() - torch.from_numpy(np.ascontiguousarray(ref))).abs().max()) < 2e-6, shape
 
 
-@pytest.mark.parametrize("B,T,C,masked", [(3, 150, 128, False), (2, 333, 256, True), (5, 40, 256, False), (40, 640, 256, True)])
+@pytest.mark.parametrize("B,T,C,masked", [(3, 150, 128, False), (2, 333, 256, True), (5, 40, 256, False), (40, 640, 256, True),
+                                          (64, 800, 256, True)])  # (the last grid takes the 128 x 128 configuration)
 def test_conv1d_diffnet_post_fused_is_bit_identical_to_the_two_kernel_path(dev, B, T, C, masked):
     """ptpp_conv1d_diffnet_post (1 x 1 output projection with the DiffNet layer's residual / skip / next-input update in
     its epilogue, modules/denoiser.py:78-83) against ptpp_conv1d_fwd + ptpp_diffnet_post_fwd on the same inputs:
@@ -674,3 +675,73 @@ def test_ddpm_step_matches_the_tensor_ops(dev):
             d = float((ref - got).abs().max())
             print("ddpm_step max |diff|", d, "max |ref|", float(ref.abs().max()))
             assert d <= 2e-6 * max(1.0, float(ref.abs().max())), d  # (a last-bit difference in exp(0.5 * logvar) at most)
+
+
+GLDS_CASES = [
+    # B, T, Cin, Cout, ks, dil -- grids of >= 192 128-row tiles, i.e. the LDS-DMA kernel (csrc/conv1d_glds.h):
+    (8, 1607, 256, 256, 3, 2),    # 64 x 128 tiles, ragged last tile
+    (6, 1100, 128, 640, 5, 1),
+    (40, 700, 256, 80, 1, 1),     # Cout = 80: one partial channel tile
+    (8, 1500, 64, 192, 7, 3),     # Cout = 192: second channel tile half empty; one 64-channel K chunk
+    (16, 6200, 128, 256, 3, 1),   # >= 1536 tiles: the 128 x 128 configuration
+]
+
+
+@pytest.mark.parametrize("case", GLDS_CASES)
+def test_conv1d_lds_dma_kernel_epilogues(case, dev):
+    """The bf16 LDS-DMA conv kernel at grid sizes that select it (the small cases of test_conv1d_fwd take the register-staged
+    kernels): every activation of the specialised tile epilogue, masks, bias, a STRIDED residual with res_scale,
+    out_scale, partial channel tiles, dropout (deterministic per seed, keep ratio, survivors scaled) -- against
+    torch's own f32 convolution of the same bf16-rounded operands."""
+    from promptttspp_amd import ops
+
+    B, T, Cin, Cout, ks, dil = case
+    pad = (ks - 1) * dil // 2
+    x = rnd(1, B, T, Cin).bfloat16().to(dev)
+    w = (rnd(2, Cout, Cin, ks) / np.sqrt(Cin * ks)).bfloat16().float().to(dev)
+    b = rnd(3, Cout, scale=0.1).to(dev)
+    wide = rnd(4, B, T, Cout + 64).bfloat16().to(dev)
+    res = wide[:, :, 32 : 32 + Cout]  # rows of Cout channels inside a wider tensor (ld = Cout + 64)
+    lens = torch.tensor([max(1, T - 97 * i) for i in range(B)], dtype=torch.int32, device=dev)
+    mask = (torch.arange(T, device=dev)[None, :] < lens[:, None]).float()[:, :, None]
+    wp = ops.pack_conv_weight(w, torch.bfloat16)
+    acts = {"none": lambda v: v, "relu": F.relu, "gelu": F.gelu, "swish": F.silu, "tanh": torch.tanh, "mish": F.mish}
+    z = F.conv1d((x.float() * mask).transpose(1, 2), w, b, padding=pad, dilation=dil).transpose(1, 2)
+    for name, fn in acts.items():
+        ref = 0.7 * res.float() + 0.5 * fn(z) * mask
+        y = ops.conv1d(x, wp, b, Cout, ks=ks, dil=dil, pad=pad, act=name, lengths=lens, in_mask=True, out_mask=True, res=res,
+                       out_scale=0.5, res_scale=0.7)
+        assert rel_err(y.float().cpu(), ref.cpu()) < BF16_TOL, name
+    # no masks / bias / residual
+    ref2 = F.conv1d(x.float().transpose(1, 2), w, None, padding=pad, dilation=dil).transpose(1, 2)
+    y2 = ops.conv1d(x, wp, None, Cout, ks=ks, dil=dil, pad=pad)
+    assert rel_err(y2.float().cpu(), ref2.cpu()) < BF16_TOL
+    if Cout % 4 == 0:
+        d1 = ops.conv1d(x, wp, None, Cout, ks=ks, dil=dil, pad=pad, drop_p=0.25, drop_seed=11)
+        d2 = ops.conv1d(x, wp, None, Cout, ks=ks, dil=dil, pad=pad, drop_p=0.25, drop_seed=11)
+        d3 = ops.conv1d(x, wp, None, Cout, ks=ks, dil=dil, pad=pad, drop_p=0.25, drop_seed=12)
+        assert torch.equal(d1, d2) and not torch.equal(d1, d3)
+        kept = d1 != 0
+        assert abs(float(kept.float().mean()) - 0.75) < 0.01
+        full = (y2.float() / 0.75).bfloat16()
+        assert rel_err(d1[kept].float().cpu(), full[kept].float().cpu()) < BF16_TOL
+
+
+def test_conv1d_lds_dma_kernel_fused_gate(dev):
+    """The fused DiffNet gate through the LDS-DMA kernel's tile epilogue (8-byte results, Cout / 2 output channels) against
+    the two-launch path on the same permuted operands, at a grid size that selects that kernel."""
+    from promptttspp_amd import ops
+
+    B, T, C = 12, 1400, 256
+    x = rnd(1, B, T, C).bfloat16().to(dev)
+    w = (rnd(2, 2 * C, C, 3) / np.sqrt(3 * C)).to(dev)
+    b = rnd(3, 2 * C, scale=0.1).to(dev)
+    cond = rnd(4, B, T, 2 * C).bfloat16().to(dev)
+    a = ops.conv1d(x, ops.pack_conv_weight(w, torch.bfloat16), b, 2 * C, ks=3, dil=2, pad=2, res=cond)
+    g_ref = ops.gate_fwd(a)
+    k = torch.arange(C // 4, device=dev)[:, None] * 4 + torch.arange(4, device=dev)[None, :]
+    perm = torch.cat([k, k + C], dim=1).reshape(-1)  # [4 gate | their 4 filter partners] per 8 channels
+    g = torch.empty(B, T, C, device=dev, dtype=torch.bfloat16)
+    ops.conv1d(x, ops.pack_conv_weight(w[perm], torch.bfloat16), b[perm].contiguous(), 2 * C, ks=3, dil=2, pad=2, act="gate",
+               res=cond[:, :, perm].contiguous(), out=g)
+    assert rel_err(g.float().cpu(), g_ref.float().cpu()) < 2e-2  # (the two-launch path rounds the pre-activation to bf16)
