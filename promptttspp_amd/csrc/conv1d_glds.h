@@ -138,7 +138,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
     const int idx = tid + i * NT;
     const int row = idx / QPR, q = idx % QPR;
     const int t = t0 + row, co = n0 + q * 8;
-    if (t < p.T && co < p.Cout && !(p.nsplit & 2)) {
+    if (t < p.T && co < p.Cout) {
       if constexpr (ACT == PTPP_ACT_GATE)
         *reinterpret_cast<uint2*>(yb + (int64_t)t * p.ldy + (co >> 1)) = *reinterpret_cast<const uint2*>(O + row * QPR + (q ^ (row & 15)));
       else

@@ -148,14 +148,9 @@ int main(int argc, char** argv) {
     printf("%-32s %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f\n", s.name, time_only<4, 2, 2, 4, 2>(p), time_only<4, 2, 2, 4, 3>(p),
            time_only<2, 4, 2, 2, 2>(p), time_only<2, 4, 2, 2, 3>(p), time_only<2, 2, 2, 4, 2>(p), time_only<2, 2, 2, 4, 3>(p),
            time_only<1, 4, 4, 2, 2>(p), time_only<4, 4, 2, 2, 2>(p), time_only<2, 2, 4, 4, 2>(p));
-    if (full) {
-      for (int d : {0, 4, 8, 12, 16}) {
-        p.nsplit = 1 | (d << 4);
-        printf("stagger %d x 0.43 us per slot\n", d);
-        run<2, 4, 2, 2, 2>(s.name, p);
-        run<4, 4, 2, 2, 2>(s.name, p);
-      }
-      p.nsplit = 1;
+    if (full) {  // per-phase clock stamps of the two product configurations
+      run<2, 4, 2, 2, 2>(s.name, p);
+      run<4, 4, 2, 2, 2>(s.name, p);
     }
     hipFree(x); hipFree(y); hipFree(res); hipFree(w); hipFree(bias);
   }
