@@ -246,16 +246,16 @@ class wgrad_stream:
         if self.torch_ops:
             self.ctx = torch.cuda.stream(d["side"])
             self.ctx.__enter__()
-        else:
-            ops._stream_override = side_h
+        # this package's own launches follow the override in both modes (under ops.pinned_stream the handle of the
+        # main stream is cached, so torch's stream context alone would not move them)
+        ops._stream_override = side_h
         return self
 
     def __exit__(self, *exc):
         if self.on:
+            ops._stream_override = None
             if self.ctx is not None:
                 self.ctx.__exit__(*exc)
-            else:
-                ops._stream_override = None
             keep = _direct["keep"]
             keep.extend(self.tensors)
             if len(keep) > 4096:  # nobody joined the streams for a long time: join here
