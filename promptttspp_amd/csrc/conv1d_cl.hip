@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p) 
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
     act_dispatch(p.act, [&](auto tag) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = keep ? act_apply_c<decltype(tag)::value>(v[e]) * p.out_scale : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = keep ? act_apply_c<decltype(tag)::value>(v[e], p.act) * p.out_scale : 0.f;
     });
     if (p.drop_thresh16) v *= drop_mask4(p.drop_seed, (uint64_t)(row * p.Cout + co) >> 2, p.drop_thresh16, p.drop_inv_keep);
     if (p.res) v += Elem<T>::ld4(reinterpret_cast<const T*>(p.res) + row * p.ldr + co) * p.res_scale;

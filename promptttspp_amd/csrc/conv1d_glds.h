@@ -100,7 +100,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
       for (int u = 0; u < 2; ++u) {
         if (p.bias && co < p.Cout) v[u] += *reinterpret_cast<const f32x4*>(p.bias + co + 4 * u);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[u][e] = keep ? act_apply_c<ACT>(v[u][e]) * e_scale : 0.f;
+        for (int e = 0; e < 4; ++e) v[u][e] = keep ? act_apply_c<ACT>(v[u][e], p.act) * e_scale : 0.f;
         if (e_dth) v[u] *= drop_mask4(p.drop_seed, (uint64_t)(((int64_t)b * p.T + t) * p.Cout + co + 4 * u) >> 2, e_dth, e_dinv);
       }
       uint4* slot = O + row * QPR + (q ^ (row & 15));

@@ -135,16 +135,16 @@ template <int A>
 struct ActTag {
   static constexpr int value = A;
 };
+// Specialised: the activations the model's conv / linear epilogues use (none, ReLU, GELU, the DiffNet gate); Swish, tanh
+// and Mish (offered by the ABI, used by no layer's epilogue) share ONE generic copy (ActTag<-1>: run-time switch).
 template <typename F>
 __device__ __forceinline__ void act_dispatch(int act, F&& f) {
   switch (act) {
+    case PTPP_ACT_NONE: f(ActTag<PTPP_ACT_NONE>()); break;
     case PTPP_ACT_RELU: f(ActTag<PTPP_ACT_RELU>()); break;
     case PTPP_ACT_GELU: f(ActTag<PTPP_ACT_GELU>()); break;
-    case PTPP_ACT_SWISH: f(ActTag<PTPP_ACT_SWISH>()); break;
-    case PTPP_ACT_TANH: f(ActTag<PTPP_ACT_TANH>()); break;
-    case PTPP_ACT_MISH: f(ActTag<PTPP_ACT_MISH>()); break;
     case PTPP_ACT_GATE: f(ActTag<PTPP_ACT_GATE>()); break;
-    default: f(ActTag<PTPP_ACT_NONE>()); break;
+    default: f(ActTag<-1>()); break;
   }
 }
 
