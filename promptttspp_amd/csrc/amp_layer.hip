@@ -376,7 +376,92 @@ __global__ __launch_bounds__(256) void amp_layer_kernel(const AmpP p) {
   __syncthreads();
 
   // ---- P4: conv2: A -> y (+ bias, residual x, running mean res2) ----
-  {
+  if constexpr (sizeof(T) == 2) {
+    // bf16: through an LDS image of the output tile in X (free since the barrier above).  The MFMA layout gives a lane
+    // 16 bytes of one row and its neighbours in lane order other rows: direct residual loads / stores are 64 separate
+    // 16-byte requests per instruction, and -- the output may alias the running mean -- a load -> add -> store loop pays
+    // one memory round trip per fragment pair.  Here the residual rows are fetched row-contiguous while the MFMAs run,
+    // parked in the image, updated in place by the MFMA-layout lanes and stored row-contiguous.
+    constexpr int nfr = BT / 16;
+    static_assert((nfr + MG - 1) / MG <= 4, "one fragment group per wave");
+    constexpr int NRV = BT * NCH / NT;  // 16-byte vectors of the tile per thread
+    static_assert(NRV * NT == BT * NCH, "tile vectors must divide over the threads");
+    const int lr = lane & 15, lg = lane >> 4;
+    T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * Tlen * C;
+    const T* r2b = p.res2 ? reinterpret_cast<const T*>(p.res2) + (int64_t)b * Tlen * C : nullptr;
+    const float osc = p.out_scale, rsc = p.res_scale;
+    uint4 rx[NRV];
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx / NCH, ch = idx - r * NCH;
+      const int t = t0 + r;
+      rx[i] = t < Tlen ? *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + ch * KC) : make_uint4(0, 0, 0, 0);
+    }
+    const int mf0 = wave * MG, nmf = min(MG, nfr - mf0);  // this wave's fragment group (none: nmf <= 0)
+    f32x4 acc[MG][NF];
+    uint4 q2[MG][NF / 2];
+    if (nmf > 0) {
+      if (r2b) {  // (two of the nine layers of a stage: the running mean of the AMP blocks)
+#pragma unroll
+        for (int mi = 0; mi < MG; ++mi) {
+          const int t = t0 + (mf0 + mi) * 16 + lr;
+#pragma unroll
+          for (int h = 0; h < NF / 2; ++h)
+            q2[mi][h] = (mi < nmf && t < Tlen) ? *reinterpret_cast<const uint4*>(r2b + (int64_t)t * C + h * 32 + lg * 8)
+                                               : make_uint4(0, 0, 0, 0);
+        }
+      }
+      conv_frags<T, C, MG>(As, reinterpret_cast<const T*>(p.w2p), ks, 1, 0, mf0, nmf, lane, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx / NCH, ch = idx - r * NCH;
+      *reinterpret_cast<uint4*>(Xs + r * ROWB + ((ch ^ aswz<NCH>(r)) << 4)) = rx[i];
+    }
+    __syncthreads();
+    if (nmf > 0) {
+#pragma unroll
+      for (int mi = 0; mi < MG; ++mi) {
+        if (mi < nmf) {
+          const int r = (mf0 + mi) * 16 + lr;
+#pragma unroll
+          for (int h = 0; h < NF / 2; ++h) {
+            const int co = h * 32 + lg * 8;
+            const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b2 + co), bB = *reinterpret_cast<const f32x4*>(p.b2 + co + 4);
+            f32x4 v0 = (acc[mi][2 * h] + bA) * osc, v1 = (acc[mi][2 * h + 1] + bB) * osc;
+            uint4* slot = reinterpret_cast<uint4*>(Xs + r * ROWB + (((co / KC) ^ aswz<NCH>(r)) << 4));
+            const uint4 rr = *slot;
+            v0[0] += __uint_as_float(rr.x << 16) * rsc; v0[1] += __uint_as_float(rr.x & 0xffff0000u) * rsc;
+            v0[2] += __uint_as_float(rr.y << 16) * rsc; v0[3] += __uint_as_float(rr.y & 0xffff0000u) * rsc;
+            v1[0] += __uint_as_float(rr.z << 16) * rsc; v1[1] += __uint_as_float(rr.z & 0xffff0000u) * rsc;
+            v1[2] += __uint_as_float(rr.w << 16) * rsc; v1[3] += __uint_as_float(rr.w & 0xffff0000u) * rsc;
+            if (r2b) {
+              const uint4 q = q2[mi][h];
+              v0[0] += __uint_as_float(q.x << 16); v0[1] += __uint_as_float(q.x & 0xffff0000u);
+              v0[2] += __uint_as_float(q.y << 16); v0[3] += __uint_as_float(q.y & 0xffff0000u);
+              v1[0] += __uint_as_float(q.z << 16); v1[1] += __uint_as_float(q.z & 0xffff0000u);
+              v1[2] += __uint_as_float(q.w << 16); v1[3] += __uint_as_float(q.w & 0xffff0000u);
+            }
+            uint4 o;
+            o.x = Pair<T>::pack(v0[0], v0[1]); o.y = Pair<T>::pack(v0[2], v0[3]);
+            o.z = Pair<T>::pack(v1[0], v1[1]); o.w = Pair<T>::pack(v1[2], v1[3]);
+            *slot = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx / NCH, ch = idx - r * NCH;
+      const int t = t0 + r;
+      if (t < Tlen)
+        *reinterpret_cast<uint4*>(yb + (int64_t)t * C + ch * KC) = *reinterpret_cast<const uint4*>(Xs + r * ROWB + ((ch ^ aswz<NCH>(r)) << 4));
+    }
+  } else {
     constexpr int nfr = BT / 16;
     const int lr = lane & 15, lg = lane >> 4;
     T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * Tlen * C;
@@ -390,38 +475,13 @@ __global__ __launch_bounds__(256) void amp_layer_kernel(const AmpP p) {
       for (int mi = 0; mi < MG; ++mi) {
         const int t = t0 + (mf0 + mi) * 16 + lr;
         if (mi < nmf && t < Tlen) {
-          if constexpr (sizeof(T) == 2) {
 #pragma unroll
-            for (int h = 0; h < NF / 2; ++h) {
-              const int co = h * 32 + lg * 8;
-              const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b2 + co), bB = *reinterpret_cast<const f32x4*>(p.b2 + co + 4);
-              f32x4 v0 = (acc[mi][2 * h] + bA) * osc, v1 = (acc[mi][2 * h + 1] + bB) * osc;
-              const uint4 r = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co);
-              v0[0] += __uint_as_float(r.x << 16) * rsc; v0[1] += __uint_as_float(r.x & 0xffff0000u) * rsc;
-              v0[2] += __uint_as_float(r.y << 16) * rsc; v0[3] += __uint_as_float(r.y & 0xffff0000u) * rsc;
-              v1[0] += __uint_as_float(r.z << 16) * rsc; v1[1] += __uint_as_float(r.z & 0xffff0000u) * rsc;
-              v1[2] += __uint_as_float(r.w << 16) * rsc; v1[3] += __uint_as_float(r.w & 0xffff0000u) * rsc;
-              if (r2b) {
-                const uint4 q = *reinterpret_cast<const uint4*>(r2b + (int64_t)t * C + co);
-                v0[0] += __uint_as_float(q.x << 16); v0[1] += __uint_as_float(q.x & 0xffff0000u);
-                v0[2] += __uint_as_float(q.y << 16); v0[3] += __uint_as_float(q.y & 0xffff0000u);
-                v1[0] += __uint_as_float(q.z << 16); v1[1] += __uint_as_float(q.z & 0xffff0000u);
-                v1[2] += __uint_as_float(q.w << 16); v1[3] += __uint_as_float(q.w & 0xffff0000u);
-              }
-              uint4 o;
-              o.x = Pair<T>::pack(v0[0], v0[1]); o.y = Pair<T>::pack(v0[2], v0[3]);
-              o.z = Pair<T>::pack(v1[0], v1[1]); o.w = Pair<T>::pack(v1[2], v1[3]);
-              *reinterpret_cast<uint4*>(yb + (int64_t)t * C + co) = o;
-            }
-          } else {
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-              const int co = f * 16 + lg * 4;
-              f32x4 v = (acc[mi][f] + *reinterpret_cast<const f32x4*>(p.b2 + co)) * osc;
-              v += *reinterpret_cast<const f32x4*>(xb + (int64_t)t * C + co) * rsc;
-              if (r2b) v += *reinterpret_cast<const f32x4*>(r2b + (int64_t)t * C + co);
-              *reinterpret_cast<f32x4*>(yb + (int64_t)t * C + co) = v;
-            }
+          for (int f = 0; f < NF; ++f) {
+            const int co = f * 16 + lg * 4;
+            f32x4 v = (acc[mi][f] + *reinterpret_cast<const f32x4*>(p.b2 + co)) * osc;
+            v += *reinterpret_cast<const f32x4*>(xb + (int64_t)t * C + co) * rsc;
+            if (r2b) v += *reinterpret_cast<const f32x4*>(r2b + (int64_t)t * C + co);
+            *reinterpret_cast<f32x4*>(yb + (int64_t)t * C + co) = v;
           }
         }
       }
