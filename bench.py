@@ -131,6 +131,32 @@ def train_step(model, batch, red, opt, sched):
 
 
 # ------------------------------------------------------------------------------------------
+def box_calibration(dev):
+    """What THIS box delivers on two library operations that involve none of this repository's kernels: a 2 GiB device
+    copy (GB/s, read + write) and a bf16 8192^3 matmul through hipBLASLt (TFLOP/s).  The boxes of the pool differ by
+    ~20 % on identical code; these two numbers let a reader tell a slow box from a slow commit."""
+    n = 1 << 30
+    x = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    y = torch.empty_like(x)
+    a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    for _ in range(2):
+        y.copy_(x)
+        torch.matmul(a, b)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    for _ in range(10):
+        y.copy_(x)
+    e[1].record()
+    for _ in range(10):
+        torch.matmul(a, b)
+    e[2].record()
+    torch.cuda.synchronize()
+    return {"copy_gbs": round(10 * 2 * 2 * n / (e[0].elapsed_time(e[1]) * 1e-3) / 1e9, 1),
+            "hipblaslt_bf16_8192_tflops": round(10 * 2 * 8192 ** 3 / (e[1].elapsed_time(e[2]) * 1e-3) / 1e12, 1),
+            "device": torch.cuda.get_device_name(dev)}
+
+
 def conv_roofline(model, batch, red, opt, sched, dtype_name):
     """Instrumented extra step: HIP events around every launch of the implicit-GEMM conv
     family (forward, data-gradient) on torch's current stream; algorithmic FLOPs =
@@ -563,6 +589,7 @@ def main():
             "per_gpu_value": round(frames / dt / world, 1),
             "bigvgan": voc,
             "app_path": app,
+            "box": box_calibration(dev),
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

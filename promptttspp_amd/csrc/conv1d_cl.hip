@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p) 
     for (int s = 1; s < p.nsplit; ++s) v += *reinterpret_cast<const f32x4*>(p.ws + s * slab + row * p.Cout + co);
     const bool keep = !(p.out_mask && t >= min(p.lengths[b], p.T));
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
-    act_dispatch(p.act, [&](auto tag) {
+    act_dispatch(p.act, [&](auto tag) __attribute__((always_inline)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = keep ? act_apply_c<decltype(tag)::value>(v[e], p.act) * p.out_scale : 0.f;
     });

@@ -186,7 +186,7 @@ template <typename T, int FM, int FN>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FM][FN], int b, int t0, int n0, int wm, int wn,
                                               int lane, int len) {
   if constexpr (sizeof(T) == 2 && FN % 2 == 0) {
-    act_dispatch(p.act, [&](auto tag) {
+    act_dispatch(p.act, [&](auto tag) __attribute__((always_inline)) {
       conv_epilogue_act<T, FM, FN, decltype(tag)::value>(p, acc, b, t0, n0, wm, wn, lane, len);
     });
   } else {

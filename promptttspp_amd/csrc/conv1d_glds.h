@@ -278,7 +278,10 @@ __device__ __forceinline__ void tile_epilogue_post(const ConvP& p, f32x4 (&acc)[
 
 __device__ unsigned long long* g_conv_stamps;  // experiments only (DBG = true): 4 clock stamps per block
 
-template <int FM, int FN, int WR, int WC, int D, bool DBG = false>
+// POST: the instantiation with the fused DiffNet tail (ptpp_conv1d_diffnet_post) -- separate, because its second set
+// of prefetch registers and epilogue pushed the plain 128 x 128 kernel into scratch memory (576 B per lane; BigVGAN
+// C = 128 k = 7 went from 707 to 1334 us).
+template <int FM, int FN, int WR, int WC, int D, bool DBG = false, bool POST = false>
 __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p) {
   typedef bf16_raw T;
   constexpr int NW = WR * WC;
@@ -352,21 +355,23 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
 
   // the residual rows of the tile, fetched row-contiguous (see tile_epilogue) while the first operands travel:
   // the K loop's first vmcnt(0) retires them together with the first stage
-  const bool post = p.post_skip != nullptr;
+  constexpr bool post = POST;
   const bool tile_epi = post || tile_epilogue_ok<FN>(p);
   constexpr int NRV = BM * BN / 8 / (NW * 64);  // 16-byte vectors of the output tile per thread
-  uint4 resv[NRV], resv2[NRV];
+  uint4 resv[NRV], resv2[POST ? NRV : 1];
   if (post && n0 >= p.post_C) {  // "skip" half of the DiffNet output projection: the f32 skip rows, two vectors per slot
-    if (!p.post_init) {
+    if constexpr (POST) {
+      if (!p.post_init) {
 #pragma unroll
-      for (int i = 0; i < NRV; ++i) {
-        const int idx = tid + i * NW * 64;
-        const int row = idx / (BN / 8), q = idx % (BN / 8);
-        const int t = t0 + row, c = n0 - p.post_C + q * 8;
-        const float* src = p.post_skip + ((int64_t)b * p.T + t) * p.post_C + c;
-        const bool in = t < p.T && c < p.post_C;
-        resv[i] = in ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
-        resv2[i] = in ? *reinterpret_cast<const uint4*>(src + 4) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < NRV; ++i) {
+          const int idx = tid + i * NW * 64;
+          const int row = idx / (BN / 8), q = idx % (BN / 8);
+          const int t = t0 + row, c = n0 - p.post_C + q * 8;
+          const float* src = p.post_skip + ((int64_t)b * p.T + t) * p.post_C + c;
+          const bool in = t < p.T && c < p.post_C;
+          resv[i] = in ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+          resv2[i] = in ? *reinterpret_cast<const uint4*>(src + 4) : make_uint4(0, 0, 0, 0);
+        }
       }
     }
   } else if (tile_epi && p.res) {
@@ -428,10 +433,10 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
   if (tile_epi) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with the operand stages: their memory becomes the tile
-    if (post) {
+    if constexpr (POST) {
       tile_epilogue_post<FM, FN, WR, WC>(p, acc, resv, resv2, reinterpret_cast<uint4*>(smem), b, t0, n0, wm, wn, tid, len);
     } else {
-      act_dispatch(p.act, [&](auto tag) {
+      act_dispatch(p.act, [&](auto tag) __attribute__((always_inline)) {
         tile_epilogue<FM, FN, WR, WC, decltype(tag)::value>(p, acc, resv, reinterpret_cast<uint4*>(smem), b, t0, n0, wm, wn, tid, len);
       });
     }
@@ -458,7 +463,7 @@ int launch_glds(ConvP& p, hipStream_t st) {
   const int xrows = (BM + (p.ks - 1) * p.dil + 7) & ~7;
   const size_t smem = (size_t)(D * BN * 8 + 2 * xrows * 8) * 16;
   if (smem > 160 * 1024) return -1;
-  auto kern = conv1d_glds_kernel<FM, FN, WR, WC, D>;
+  auto kern = p.post_skip ? conv1d_glds_kernel<FM, FN, WR, WC, D, false, true> : conv1d_glds_kernel<FM, FN, WR, WC, D, false, false>;
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int64_t nblk = (int64_t)p.B * p.nMT * p.nNT;
