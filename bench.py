@@ -564,19 +564,20 @@ def main():
     if rank == 0:
         log(f"roofline pass done: {roof['achieved']} TFLOP/s")
         one = not (a.no_cpu_baseline or world > 1)  # the CPU baselines run on rank 0 at N = 1 only
+        # every GPU leg first, the CPU baselines after them: the app leg measured right after the 32-thread CPU legs
+        # came out 15-20 % slower (211 vs 179 ms) than on its own
+        app = None
+        if not a.no_app and world == 1:
+            app, app_model, app_voc = app_leg(dev, dtype)
+            log(f"app leg done: {app['ms_per_batch']} ms")
         cpu = cpu_baseline(model, batches[a.warmup]) if one else None
         log("cpu baseline done")
         if voc is not None and one:
             voc["cpu_baseline"] = vocoder_cpu_baseline(voc_model, a.voc_frames)
             log("vocoder cpu baseline done")
-        app = None
-        if not a.no_app and world == 1:
-            del voc_model
-            app, app_model, app_voc = app_leg(dev, dtype)
-            log(f"app leg done: {app['ms_per_batch']} ms")
-            if one:
-                app["cpu_baseline"] = app_cpu_baseline(app_model, app_voc)
-                log("app cpu baseline done")
+        if app is not None and one:
+            app["cpu_baseline"] = app_cpu_baseline(app_model, app_voc)
+            log("app cpu baseline done")
         B = batches[a.warmup][0].shape[0]
         line = {
             "metric": "mel-frames/sec (train)", "value": round(frames / dt, 1), "unit": "mel-frames/sec",
