@@ -181,7 +181,10 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         y = orig(x, wp, bias, cout, ks=ks, dil=dil, pad=pad, lengths=lengths, **kw)
         e1.record()
         rows = float(lengths.sum()) if lengths is not None and (kw.get("out_mask") or kw.get("in_mask")) else x.shape[0] * x.shape[1]
-        recs.append((e0, e1, 2.0 * rows * x.shape[2] * cout * ks))
+        es = x.element_size()
+        nbytes = x.shape[0] * x.shape[1] * (x.shape[2] + (cout // 2 if kw.get("act") == "gate" else cout)
+                                            + (cout if kw.get("res") is not None else 0)) * es + cout * x.shape[2] * ks * es
+        recs.append((e0, e1, 2.0 * rows * x.shape[2] * cout * ks, nbytes))
         return y
 
     orig_post = ops.conv1d_diffnet_post
@@ -193,7 +196,9 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         r = orig_post(g, wp, bias, x, skip, dnext, init, lengths=lengths, out_mask=out_mask, **kw)
         e1.record()
         rows = float(lengths.sum()) if lengths is not None and out_mask else g.shape[0] * g.shape[1]
-        recs.append((e0, e1, 2.0 * rows * g.shape[2] * 2 * x.shape[2]))
+        C = x.shape[2]  # bytes: g, x in; xn, yin out (bf16); the f32 skip rows read and written; the weights
+        nbytes = g.shape[0] * g.shape[1] * ((g.shape[2] + 3 * C) * 2 + 2 * C * 4) + 2 * C * g.shape[2] * 2
+        recs.append((e0, e1, 2.0 * rows * g.shape[2] * 2 * C, nbytes))
         return r
 
     ops.conv1d = timed
@@ -211,8 +216,26 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
     # conv1d_glds_kernel<2, 4, 2, 2, 2>, 64 x 128 tiles, and <4, 4, 2, 2, 2>, 128 x 128 tiles, for the few launches
     # with >= 1536 tiles; profiles/r02b_train_step.md is the rocprofv3 summary of the training leg of this command);
     # launches of the conv family with smaller tiles / split-K are listed there, not averaged in here
-    tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-    tot_flop = sum(f for _, _, f in recs)
+    tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+    tot_flop = sum(f for _, _, f, _ in recs)
+    # the same launches split by the roof that applies to each (arithmetic intensity of its ALGORITHMIC bytes against the
+    # 2.5 PF / 8 TB/s ridge of 312 FLOP/B): the 1 x 1 projections (64-100 FLOP/B) can never approach the MFMA peak
+    ridge = MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    split = {}
+    for a, b, f, nb in recs:
+        k = "mfma" if f / nb >= ridge else "hbm"
+        d = split.setdefault(k, {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0})
+        d["launches"] += 1; d["ms"] += a.elapsed_time(b); d["flop"] += f; d["bytes"] += nb
+    by_bound = {}
+    for k, d in split.items():
+        if k == "mfma":
+            ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+            by_bound[k] = {"launches": d["launches"], "achieved": round(ach, 1), "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2)}
+        else:
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            by_bound[k] = {"launches": d["launches"], "achieved": round(ach, 1), "unit": "GB/s (algorithmic)",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2)}
     ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else 157.3
     traffic, traffic_src = measured_traffic(TRAFFIC_TRAIN, "conv1d_glds_kernel<2, 4, 2, 2, 2") \
@@ -222,7 +245,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
-            "flop_per_step": tot_flop}
+            "flop_per_step": tot_flop, "by_bound": by_bound}
 
 
 def cpu_baseline(model, batch):
