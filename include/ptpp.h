@@ -286,6 +286,12 @@ int ptpp_ddpm_step(const float* x, const void* eps, const float* noise, const in
                    const float* sra, const float* srm1, const float* c1, const float* c2,
                    const float* logvar, float* out, int B, int64_t per_b, int eps_dtype,
                    void* stream);
+/* Backward of the same layer: dg = conv1x1(a->x = do, a->wp = W_out^T) (a->Cout = C, never stored) with
+ * ptpp_gate_bwd in its epilogue -- da (row stride ldda >= 2C) from the saved pre-activation act (B, T, 2C).
+ * Bit-identical to ptpp_conv1d_fwd followed by ptpp_gate_bwd.  _supported: bf16, C % 8 == 0, Cin % 64 == 0. */
+int ptpp_conv1d_gate_bwd_supported(int C, int cin, int dtype);
+int ptpp_conv1d_gate_bwd(const ptpp_conv1d_args* a, const void* act, void* da, int ldda,
+                         void* stream);
 /* dout (rows, 2C) = [gx/sqrt2 | gskip], masked rows zero */
 int ptpp_diffnet_post_bwd(const void* gx, const void* gskip, void* dout,
                           const int32_t* lengths, int B, int T, int C, int dtype,

@@ -86,6 +86,8 @@ SIGNATURES = {
     "ptpp_conv1d_diffnet_post_supported": (I, [I, I, I]),
     "ptpp_conv1d_diffnet_post": (I, [POINTER(ConvArgs), P, P, P, P, P, I, P]),
     "ptpp_ddpm_step": (I, [P] * 10 + [I, I64, I, P]),
+    "ptpp_conv1d_gate_bwd_supported": (I, [I, I, I]),
+    "ptpp_conv1d_gate_bwd": (I, [POINTER(ConvArgs), P, P, I, P]),
     "ptpp_diffnet_post_bwd": (I, [P, P, P, P, I, I, I, I, P]),
     "ptpp_colsum_batch": (I, [P, P, I, I, I, I, P]),
     "ptpp_col_reduce": (I, [P, P, P, I64, I, I, P, SZ, P]),

@@ -445,6 +445,7 @@ extern "C" int ptpp_conv1d_fwd_ws(const ptpp_conv1d_args* a, const void* res2, i
   p.ws = nullptr;
   p.nsplit = 1;
   p.post_skip = nullptr; p.post_dnext = nullptr; p.post_yin = nullptr; p.post_C = 0; p.post_init = 0;
+  p.gate_a = nullptr; p.gate_da = nullptr; p.gate_ldda = 0;
   if (workspace && ((uintptr_t)workspace & 15)) workspace = nullptr;
   // A linear layer without sequence masks does not care where one utterance ends: treat the (B, T) rows
   // as ONE sequence (rows are linear in memory: batches are T consecutive rows) so that short utterances
@@ -498,11 +499,47 @@ extern "C" int ptpp_conv1d_diffnet_post(const ptpp_conv1d_args* a, const void* x
   p.drop_thresh16 = 0; p.drop_inv_keep = 1.f; p.drop_seed = 0;
   p.ws = nullptr; p.nsplit = 1;
   p.post_skip = skip; p.post_dnext = dnext; p.post_yin = yin; p.post_C = C; p.post_init = init;
+  p.gate_a = nullptr; p.gate_da = nullptr; p.gate_ldda = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long long tiles128 = (long long)p.B * ((p.T + 127) / 128) * ((p.Cout + 127) / 128);
   const int rc = tiles128 >= 1536 ? launch_glds<4, 4, 2, 2, 2>(p, st) : launch_glds<2, 4, 2, 2, 2>(p, st);
   if (rc < 0) {
     ptpp_set_error("conv1d_diffnet_post: tile does not fit LDS");
+    return PTPP_EINVAL;
+  }
+  return rc;
+}
+
+// ---- DiffNet output projection's data gradient with the gate backward fused into the epilogue ----
+extern "C" int ptpp_conv1d_gate_bwd_supported(int C, int cin, int dtype) {
+  return dtype == PTPP_BF16 && C > 0 && C % 8 == 0 && C >= 64 && cin > 0 && cin % 64 == 0;
+}
+
+extern "C" int ptpp_conv1d_gate_bwd(const ptpp_conv1d_args* a, const void* act, void* da, int ldda, void* stream) {
+  PTPP_CHECK_ARG(a && a->x && a->wp && act && da, "conv1d_gate_bwd: null pointer");
+  const int C = a->Cout;
+  PTPP_CHECK_ARG(a->ks == 1 && a->pad == 0 && ptpp_conv1d_gate_bwd_supported(C, a->Cin, a->dtype),
+                 "conv1d_gate_bwd: needs bf16, a 1 x 1 projection, C %% 8 == 0, Cin %% 64 == 0 (C=%d Cin=%d)", C, a->Cin);
+  PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->ldx % 8 == 0 && ldda % 8 == 0 && ldda >= 2 * C && ((uintptr_t)a->x % 16) == 0 &&
+                     ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)act % 16) == 0 && ((uintptr_t)da % 16) == 0 && !a->bias &&
+                     !a->in_mask && !a->out_mask,
+                 "conv1d_gate_bwd: operands must be 16-byte aligned, no bias / masks");
+  ConvP p;
+  p.x = a->x; p.wp = a->wp; p.bias = nullptr; p.res = nullptr; p.res2 = nullptr; p.y = da; p.lengths = nullptr;
+  p.B = a->B; p.T = a->T; p.Cin = a->Cin; p.Cout = C; p.ks = 1; p.dil = 1; p.pad = 0;
+  p.ldx = a->ldx; p.ldy = ldda; p.ldr = 0; p.ldr2 = 0;
+  p.cinp = a->Cin;
+  p.act = PTPP_ACT_NONE; p.in_mask = 0; p.out_mask = 0;
+  p.out_scale = a->out_scale; p.res_scale = 1.f;
+  p.drop_thresh16 = 0; p.drop_inv_keep = 1.f; p.drop_seed = 0;
+  p.ws = nullptr; p.nsplit = 1;
+  p.post_skip = nullptr; p.post_dnext = nullptr; p.post_yin = nullptr; p.post_C = 0; p.post_init = 0;
+  p.gate_a = act; p.gate_da = da; p.gate_ldda = ldda;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long tiles128 = (long long)p.B * ((p.T + 127) / 128) * ((p.Cout + 127) / 128);
+  const int rc = tiles128 >= 1536 ? launch_glds<4, 4, 2, 2, 2>(p, st) : launch_glds<2, 4, 2, 2, 2>(p, st);
+  if (rc < 0) {
+    ptpp_set_error("conv1d_gate_bwd: tile does not fit LDS");
     return PTPP_EINVAL;
   }
   return rc;

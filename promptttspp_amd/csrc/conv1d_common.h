@@ -52,6 +52,11 @@ struct ConvP {
   const float* post_dnext;  // (B, post_C) or nullptr
   void* post_yin;           // (B, T, post_C) or nullptr
   int post_C, post_init;
+  // fused DiffNet gate backward (conv1d_glds.h, ptpp_conv1d_gate_bwd): Cout = C channels of dg, never stored;
+  // da[:, c] / da[:, C + c] (row stride gate_ldda) from the saved pre-activation gate_a (B, T, 2C)
+  const void* gate_a;  // nullptr = not this mode
+  void* gate_da;
+  int gate_ldda;
 };
 
 // Fused epilogue of one (BM x BN) tile: acc[fm][fn] is the MFMA accumulator of the wave's

@@ -276,13 +276,87 @@ __device__ __forceinline__ void tile_epilogue_post(const ConvP& p, f32x4 (&acc)[
   }
 }
 
+// The DiffNet gate backward fused into the output projection's data gradient (what gate_bwd_kernel does as a pass over
+// dg = conv(do, W_out^T)): with s = a[:, c], f = a[:, C + c] (saved pre-activation), sg = sigmoid(s), th = tanh(f):
+//   da[:, c] = dg * th * sg * (1 - sg),   da[:, C + c] = dg * sg * (1 - th^2).
+// dg is rounded to bf16 first, as the two-kernel path stores and re-reads it.
+template <int FM, int FN, int WR, int WC>
+__device__ __forceinline__ void tile_epilogue_gate_bwd(const ConvP& p, f32x4 (&acc)[FM][FN], uint4 (&resv)[FM * FN / 2],
+                                                       uint4 (&resv2)[FM * FN / 2], uint4* O, int b, int t0, int n0, int wm, int wn,
+                                                       int tid) {
+  typedef bf16_raw T;
+  constexpr int NT = WR * WC * 64, BM = WR * FM * 16, BN = WC * FN * 16;
+  constexpr int QPR = BN / 8;
+  constexpr int NRV = BM * QPR / NT;
+  const int lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+  uint4* O2 = O + BM * QPR;
+#pragma unroll
+  for (int i = 0; i < NRV; ++i) {
+    const int idx = tid + i * NT;
+    const int row = idx / QPR, q = idx % QPR;
+    O[row * QPR + (q ^ (row & 15))] = resv[i];
+    O2[row * QPR + (q ^ (row & 15))] = resv2[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+    const int row = (wm * FM + fm) * 16 + lr;
+#pragma unroll
+    for (int h = 0; h < FN / 2; ++h) {
+      const int q = wn * FN * 2 + h * 4 + lg;
+      const int slot = row * QPR + (q ^ (row & 15));
+      const uint4 rs = O[slot], rf = O2[slot];
+      const float sv[8] = {__uint_as_float(rs.x << 16), __uint_as_float(rs.x & 0xffff0000u), __uint_as_float(rs.y << 16),
+                           __uint_as_float(rs.y & 0xffff0000u), __uint_as_float(rs.z << 16), __uint_as_float(rs.z & 0xffff0000u),
+                           __uint_as_float(rs.w << 16), __uint_as_float(rs.w & 0xffff0000u)};
+      const float fv[8] = {__uint_as_float(rf.x << 16), __uint_as_float(rf.x & 0xffff0000u), __uint_as_float(rf.y << 16),
+                           __uint_as_float(rf.y & 0xffff0000u), __uint_as_float(rf.z << 16), __uint_as_float(rf.z & 0xffff0000u),
+                           __uint_as_float(rf.w << 16), __uint_as_float(rf.w & 0xffff0000u)};
+      float ds[8], df[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = round_bf16(acc[fm][2 * h + (e >> 2)][e & 3] * p.out_scale);
+        const float sg = sigmoidf_(sv[e]), th = tanhf(fv[e]);
+        ds[e] = d * th * sg * (1.f - sg);
+        df[e] = d * sg * (1.f - th * th);
+      }
+      uint4 o1, o2;
+      o1.x = (uint32_t)f32_to_bf16(ds[0]) | ((uint32_t)f32_to_bf16(ds[1]) << 16);
+      o1.y = (uint32_t)f32_to_bf16(ds[2]) | ((uint32_t)f32_to_bf16(ds[3]) << 16);
+      o1.z = (uint32_t)f32_to_bf16(ds[4]) | ((uint32_t)f32_to_bf16(ds[5]) << 16);
+      o1.w = (uint32_t)f32_to_bf16(ds[6]) | ((uint32_t)f32_to_bf16(ds[7]) << 16);
+      o2.x = (uint32_t)f32_to_bf16(df[0]) | ((uint32_t)f32_to_bf16(df[1]) << 16);
+      o2.y = (uint32_t)f32_to_bf16(df[2]) | ((uint32_t)f32_to_bf16(df[3]) << 16);
+      o2.z = (uint32_t)f32_to_bf16(df[4]) | ((uint32_t)f32_to_bf16(df[5]) << 16);
+      o2.w = (uint32_t)f32_to_bf16(df[6]) | ((uint32_t)f32_to_bf16(df[7]) << 16);
+      O[slot] = o1;
+      O2[slot] = o2;
+    }
+  }
+  __syncthreads();
+  T* dab = reinterpret_cast<T*>(p.gate_da) + (int64_t)b * p.T * p.gate_ldda;
+#pragma unroll
+  for (int i = 0; i < NRV; ++i) {
+    const int idx = tid + i * NT;
+    const int row = idx / QPR, q = idx % QPR;
+    const int t = t0 + row, co = n0 + q * 8;
+    if (t < p.T && co < p.Cout) {
+      *reinterpret_cast<uint4*>(dab + (int64_t)t * p.gate_ldda + co) = O[row * QPR + (q ^ (row & 15))];
+      *reinterpret_cast<uint4*>(dab + (int64_t)t * p.gate_ldda + p.Cout + co) = O2[row * QPR + (q ^ (row & 15))];
+    }
+  }
+}
+
 __device__ unsigned long long* g_conv_stamps;  // experiments only (DBG = true): 4 clock stamps per block
 
 // POST: the instantiation with the fused DiffNet tail (ptpp_conv1d_diffnet_post) -- separate, because its second set
 // of prefetch registers and epilogue pushed the plain 128 x 128 kernel into scratch memory (576 B per lane; BigVGAN
 // C = 128 k = 7 went from 707 to 1334 us).
-template <int FM, int FN, int WR, int WC, int D, bool DBG = false, bool POST = false>
+// EPI: 0 = the ordinary epilogue, 1 = POST, 2 = the fused DiffNet gate backward (ptpp_conv1d_gate_bwd)
+template <int FM, int FN, int WR, int WC, int D, bool DBG = false, int EPI = 0>
 __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p) {
+  constexpr bool POST = EPI == 1;
+  constexpr bool GBWD = EPI == 2;
   typedef bf16_raw T;
   constexpr int NW = WR * WC;
   constexpr int BM = WR * FM * 16, BN = WC * FN * 16;
@@ -356,9 +430,21 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
   // the residual rows of the tile, fetched row-contiguous (see tile_epilogue) while the first operands travel:
   // the K loop's first vmcnt(0) retires them together with the first stage
   constexpr bool post = POST;
-  const bool tile_epi = post || tile_epilogue_ok<FN>(p);
+  const bool tile_epi = post || GBWD || tile_epilogue_ok<FN>(p);
   constexpr int NRV = BM * BN / 8 / (NW * 64);  // 16-byte vectors of the output tile per thread
-  uint4 resv[NRV], resv2[POST ? NRV : 1];
+  uint4 resv[NRV], resv2[(POST || GBWD) ? NRV : 1];
+  if constexpr (GBWD) {  // the saved pre-activation rows: gate half [c] and filter half [C + c] of this tile's channels
+    const T* ab = reinterpret_cast<const T*>(p.gate_a) + (int64_t)b * p.T * 2 * p.Cout;
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NW * 64;
+      const int row = idx / (BN / 8), q = idx % (BN / 8);
+      const int t = t0 + row, co = n0 + q * 8;
+      const bool in = t < p.T && co < p.Cout;
+      resv[i] = in ? *reinterpret_cast<const uint4*>(ab + (int64_t)t * 2 * p.Cout + co) : make_uint4(0, 0, 0, 0);
+      resv2[i] = in ? *reinterpret_cast<const uint4*>(ab + (int64_t)t * 2 * p.Cout + p.Cout + co) : make_uint4(0, 0, 0, 0);
+    }
+  } else
   if (post && n0 >= p.post_C) {  // "skip" half of the DiffNet output projection: the f32 skip rows, two vectors per slot
     if constexpr (POST) {
       if (!p.post_init) {
@@ -435,6 +521,8 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
     __builtin_amdgcn_s_barrier();  // every wave is done with the operand stages: their memory becomes the tile
     if constexpr (POST) {
       tile_epilogue_post<FM, FN, WR, WC>(p, acc, resv, resv2, reinterpret_cast<uint4*>(smem), b, t0, n0, wm, wn, tid, len);
+    } else if constexpr (GBWD) {
+      tile_epilogue_gate_bwd<FM, FN, WR, WC>(p, acc, resv, resv2, reinterpret_cast<uint4*>(smem), b, t0, n0, wm, wn, tid);
     } else {
       act_dispatch(p.act, [&](auto tag) __attribute__((always_inline)) {
         tile_epilogue<FM, FN, WR, WC, decltype(tag)::value>(p, acc, resv, reinterpret_cast<uint4*>(smem), b, t0, n0, wm, wn, tid, len);
@@ -463,7 +551,9 @@ int launch_glds(ConvP& p, hipStream_t st) {
   const int xrows = (BM + (p.ks - 1) * p.dil + 7) & ~7;
   const size_t smem = (size_t)(D * BN * 8 + 2 * xrows * 8) * 16;
   if (smem > 160 * 1024) return -1;
-  auto kern = p.post_skip ? conv1d_glds_kernel<FM, FN, WR, WC, D, false, true> : conv1d_glds_kernel<FM, FN, WR, WC, D, false, false>;
+  auto kern = p.post_skip ? conv1d_glds_kernel<FM, FN, WR, WC, D, false, 1>
+              : p.gate_a  ? conv1d_glds_kernel<FM, FN, WR, WC, D, false, 2>
+                          : conv1d_glds_kernel<FM, FN, WR, WC, D, false, 0>;
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int64_t nblk = (int64_t)p.B * p.nMT * p.nNT;

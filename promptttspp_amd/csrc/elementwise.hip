@@ -5,8 +5,6 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
-
 // ---------------------------------------------------------------------------
 // backward of the conv epilogue: dz = dy * out_scale * [t < len] * relu'(y) * dropmask
 // ---------------------------------------------------------------------------

@@ -148,6 +148,8 @@ __device__ __forceinline__ void act_dispatch(int act, F&& f) {
   }
 }
 
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
 // ---- wave reductions (wave = 64 lanes) ---------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

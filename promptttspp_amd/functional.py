@@ -730,6 +730,7 @@ class DiffNetStackFn(Function):
         dcond_all = torch.empty((B, T, L * 2 * C), device=gout.device, dtype=dt)
         grads = [None] * (6 * L)
         r2 = 1.0 / math.sqrt(2.0)
+        fuse_gbwd = FUSE_DIFFNET_POST and gout.is_cuda and ops.conv1d_gate_bwd_supported(C, 2 * C, dt)
         for l in reversed(range(L)):
             yin, a, g = ctx.saved[l]
             dil_w, _, _, _, out_w, _ = ws[l]
@@ -738,8 +739,11 @@ class DiffNetStackFn(Function):
             tg = [t.grad if ctx.direct else None for t in ws[l]]
             with wgrad_stream(*((g, do) if ctx.direct else ())):
                 dwo, dbo = ops.conv1d_wgrad(g, do, C, 2 * C, 1, 1, 0, dw_out=tg[4], db_out=tg[5])
-            dg = ops.conv1d(do, packed(out_w, dt, mode=1), None, C)
-            da = ops.gate_bwd(a, dg, dcond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
+            if fuse_gbwd:  # the projection's data gradient with the gate backward in its epilogue (dg is never stored)
+                da = ops.conv1d_gate_bwd(do, packed(out_w, dt, mode=1), a, dcond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
+            else:
+                dg = ops.conv1d(do, packed(out_w, dt, mode=1), None, C)
+                da = ops.gate_bwd(a, dg, dcond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
             with wgrad_stream(*((yin, da) if ctx.direct else ())):
                 dwd, dbd = ops.conv1d_wgrad(yin, da, C, 2 * C, 3, d, d, dw_out=tg[0], db_out=tg[1])
             gx = ops.conv1d(da, packed(dil_w, dt, mode=1), None, C, ks=3, dil=d, pad=d, res=gx, res_scale=r2)

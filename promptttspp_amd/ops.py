@@ -475,6 +475,30 @@ def conv1d_diffnet_post(g, wp, bias, x, skip, dnext, init, lengths=None, out_mas
     return xn, yin
 
 
+_gbwd_ok = {}
+
+
+def conv1d_gate_bwd_supported(C, cin, dtype):
+    key = (C, cin, dtype)
+    ok = _gbwd_ok.get(key)
+    if ok is None:
+        ok = _gbwd_ok[key] = bool(_lib.load().ptpp_conv1d_gate_bwd_supported(int(C), int(cin), dtype_code(dtype)))
+    return ok
+
+
+def conv1d_gate_bwd(do, wpt, a, da):
+    """dg = conv1x1(do, wpt) with ``gate_bwd(a, dg, da)`` fused into its epilogue (ptpp_conv1d_gate_bwd): ``da`` is a
+    (B, T, 2C) view with row stride >= 2C written in place; dg is never stored.  Bit-identical to the two launches."""
+    B, T, cin = do.shape
+    C = a.shape[2] // 2
+    assert a.is_contiguous() and a.dtype == do.dtype == torch.bfloat16
+    _CONV_FMT.pack_into(_conv_buf, 0, do.data_ptr(), wpt.data_ptr(), 0, 0, 0, 0, B, T, cin, C, 1, 1, 0, _ld_fast(do), 0, 0,
+                        _ACT[None], 0, 0, 1.0, BF16)
+    check(_lib.load().ptpp_conv1d_gate_bwd(_conv_args_ref, a.data_ptr(), da.data_ptr(), _ld(da), _stream()),
+          "ptpp_conv1d_gate_bwd")
+    return da
+
+
 def ddpm_step(x, eps, noise, t, sra, srm1, c1, c2, logvar):
     """x (B, ...) f32, eps same shape (f32 / bf16), noise f32 or None, t (B) int64 on the device -> x_{t-1} f32
     (ptpp_ddpm_step: the reverse-diffusion update as one pass)."""

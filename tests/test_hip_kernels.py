@@ -745,3 +745,24 @@ def test_conv1d_lds_dma_kernel_fused_gate(dev):
     ops.conv1d(x, ops.pack_conv_weight(w[perm], torch.bfloat16), b[perm].contiguous(), 2 * C, ks=3, dil=2, pad=2, act="gate",
                res=cond[:, :, perm].contiguous(), out=g)
     assert rel_err(g.float().cpu(), g_ref.float().cpu()) < 2e-2  # (the two-launch path rounds the pre-activation to bf16)
+
+
+@pytest.mark.parametrize("B,T,C", [(3, 150, 128), (2, 333, 256), (40, 640, 256), (64, 1600, 256)])
+def test_conv1d_gate_bwd_fused_is_bit_identical_to_the_two_kernel_path(dev, B, T, C):
+    """ptpp_conv1d_gate_bwd (data gradient of the DiffNet output projection with the gate backward in its epilogue;
+    backward of modules/denoiser.py:72-78) against ptpp_conv1d_fwd + ptpp_gate_bwd: da written into a column slice of a
+    wider tensor, bit for bit; the last grid takes the 128 x 128 configuration."""
+    from promptttspp_amd import ops
+
+    assert ops.conv1d_gate_bwd_supported(C, 2 * C, torch.bfloat16)
+    do = rnd(1, B, T, 2 * C).to(dev).bfloat16()
+    a = rnd(2, B, T, 2 * C).to(dev).bfloat16()
+    w = (rnd(3, 2 * C, C, 1) * 0.06).to(dev)  # the projection C -> 2C; its data gradient maps 2C -> C
+    wpt = ops.pack_conv_weight(w, torch.bfloat16, mode=1)
+    wide_a = torch.zeros(B, T, 3 * 2 * C, device=dev, dtype=torch.bfloat16)
+    wide_b = torch.zeros_like(wide_a)
+    dg = ops.conv1d(do, wpt, None, C)
+    ops.gate_bwd(a, dg, wide_a[:, :, 2 * C : 4 * C])
+    ops.conv1d_gate_bwd(do, wpt, a, wide_b[:, :, 2 * C : 4 * C])
+    assert torch.equal(wide_a, wide_b)
+    assert float(wide_a[:, :, 2 * C : 4 * C].float().abs().max()) > 0
