@@ -201,8 +201,21 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         recs.append((e0, e1, 2.0 * rows * g.shape[2] * 2 * C, nbytes))
         return r
 
+    orig_gbwd = ops.conv1d_gate_bwd
+
+    def timed_gbwd(do, wpt, a, da):
+        # the output projection's data gradient with the fused gate backward: 2C -> C channels; bytes: do and a in, da out
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_gbwd(do, wpt, a, da)
+        e1.record()
+        rows, c2 = do.shape[0] * do.shape[1], do.shape[2]
+        recs.append((e0, e1, 2.0 * rows * c2 * (c2 // 2), rows * 3 * c2 * 2 + c2 * (c2 // 2) * 2))
+        return r
+
     ops.conv1d = timed
     ops.conv1d_diffnet_post = timed_post
+    ops.conv1d_gate_bwd = timed_gbwd
     try:
         # keep the device busy while the host enqueues the step, so that the events bracket kernel
         # execution and not launch gaps (the instrumented step is host-bound)
@@ -212,6 +225,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
     finally:
         ops.conv1d = orig
         ops.conv1d_diffnet_post = orig_post
+        ops.conv1d_gate_bwd = orig_gbwd
     # the dominant kernel = the LDS-DMA conv kernel these launches take (csrc/conv1d_glds.h; rocprof:
     # conv1d_glds_kernel<2, 4, 2, 2, 2>, 64 x 128 tiles, and <4, 4, 2, 2, 2>, 128 x 128 tiles, for the few launches
     # with >= 1536 tiles; profiles/r02b_train_step.md is the rocprofv3 summary of the training leg of this command);
