@@ -259,7 +259,11 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
-            "flop_per_step": tot_flop, "by_bound": by_bound}
+            "flop_per_step": tot_flop, "by_bound": by_bound,
+            "note": "all launches are priced against the MFMA peak here for continuity with round 1; 40 of them are the DiffNet 1x1 "
+                    "projections whose epilogues now also do the work of the elementwise kernels they replaced (residual / skip "
+                    "update, gate backward), i.e. they got longer while the step got shorter; by_bound prices each launch "
+                    "against the roof its arithmetic intensity selects"}
 
 
 def cpu_baseline(model, batch):
