@@ -416,6 +416,18 @@ int ptpp_add3_scale(const void* a, const void* b, const void* c, void* y,
 int ptpp_conv_post_tanh(const void* x, const float* w, float bias, float* y,
                         int B, int T, int C, int ks, int dtype, void* stream);
 
+/* Dimension-wise mixture-density NLL (modules/mdn.py:81-175, `dim_wise`): log_pi / log_sigma / mu (rows, G, D) f32,
+ * target (rows, D), mask (rows) bytes or NULL (0 = masked: loss +inf, zero gradients) -> loss (rows, D) = -logsumexp_g.
+ * _bwd recomputes the component log-likelihoods from the inputs and the saved loss. */
+int ptpp_mdn_nll_fwd(const float* log_pi, const float* log_sigma, const float* mu,
+                     const float* target, const unsigned char* mask, float* loss,
+                     int64_t rows, int G, int D, float log_pi_min, float log_sigma_min,
+                     void* stream);
+int ptpp_mdn_nll_bwd(const float* log_pi, const float* log_sigma, const float* mu,
+                     const float* target, const unsigned char* mask, const float* loss,
+                     const float* gout, float* d_log_pi, float* d_log_sigma, float* d_mu,
+                     int64_t rows, int G, int D, float log_pi_min, float log_sigma_min,
+                     void* stream);
 /* Zero-phase IIR low-pass of the predicted log-F0 tracks (utils/model.py:164-196, called at app.py:77 /
  * synthesize.py:131): y = flip(lfilter(flip(lfilter(x)))) with zero initial state -- the arithmetic of
  * torchaudio.functional.filtfilt(x, a, b, clamp=False), which the reference uses for tensors.

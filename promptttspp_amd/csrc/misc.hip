@@ -153,6 +153,99 @@ extern "C" int ptpp_stream_wait(void* waiter, void* signaler) {
   return PTPP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Dimension-wise mixture-density negative log-likelihood (reference modules/mdn.py:81-175, the `dim_wise` branch):
+//   ls = max(log_sigma, ls_min), lp = max(log_pi, lp_min), sigma = exp(ls), d = clamp(target - mu, -5 sigma, 5 sigma)
+//   ll_g = -0.5 (d / sigma)^2 - ls - 0.5 log(2 pi) + lp;   loss[b,t,dd] = -logsumexp_g ll_g   (+inf where masked out)
+// One thread per (b, t, dd); log_pi / log_sigma / mu are (rows, G, D) f32.  The ~35 tensor ops of the forward and the
+// ~70 of its autograd backward (two MDN heads per training step) become one launch each; the backward recomputes ll.
+// ---------------------------------------------------------------------------
+static __global__ void mdn_nll_fwd_kernel(const float* __restrict__ log_pi, const float* __restrict__ log_sigma,
+                                   const float* __restrict__ mu, const float* __restrict__ target,
+                                   const unsigned char* __restrict__ mask, float* __restrict__ loss, int64_t n, int G, int D,
+                                   float lp_min, float ls_min) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = i / D;
+  const int dd = (int)(i - row * D);
+  if (mask && !mask[row]) {
+    loss[i] = __builtin_inff();
+    return;
+  }
+  const float tg = target[i];
+  const int64_t base = row * G * D + dd;
+  float m = -__builtin_inff(), s = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float ls = fmaxf(log_sigma[base + (int64_t)g * D], ls_min), lp = fmaxf(log_pi[base + (int64_t)g * D], lp_min);
+    const float sg = expf(ls);
+    const float d = fmaxf(fminf(tg - mu[base + (int64_t)g * D], 5.f * sg), -5.f * sg);
+    const float z = d / sg;
+    const float ll = -0.5f * z * z - ls - 0.91893853320467274f + lp;
+    if (ll > m) { s = s * expf(m - ll) + 1.f; m = ll; } else { s += expf(ll - m); }
+  }
+  loss[i] = -(m + logf(s));
+}
+
+static __global__ void mdn_nll_bwd_kernel(const float* __restrict__ log_pi, const float* __restrict__ log_sigma,
+                                   const float* __restrict__ mu, const float* __restrict__ target,
+                                   const unsigned char* __restrict__ mask, const float* __restrict__ loss,
+                                   const float* __restrict__ gout, float* __restrict__ d_log_pi,
+                                   float* __restrict__ d_log_sigma, float* __restrict__ d_mu, int64_t n, int G, int D,
+                                   float lp_min, float ls_min) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = i / D;
+  const int dd = (int)(i - row * D);
+  const int64_t base = row * G * D + dd;
+  const bool off = mask && !mask[row];
+  const float go = off ? 0.f : gout[i], nl = off ? 0.f : loss[i], tg = target[i];
+  for (int g = 0; g < G; ++g) {
+    const int64_t k = base + (int64_t)g * D;
+    float dlp = 0.f, dls = 0.f, dmu = 0.f;
+    if (!off) {
+      const float lsr = log_sigma[k], lpr = log_pi[k];
+      const float ls = fmaxf(lsr, ls_min), lp = fmaxf(lpr, lp_min);
+      const float sg = expf(ls);
+      const float raw = tg - mu[k];
+      const bool clip = fabsf(raw) > 5.f * sg;
+      const float d = fmaxf(fminf(raw, 5.f * sg), -5.f * sg);
+      const float z = d / sg;
+      const float ll = -0.5f * z * z - ls - 0.91893853320467274f + lp;
+      const float dll = -go * expf(ll + nl);  // loss = -logsumexp: d loss / d ll_g = -softmax_g
+      dlp = lpr >= lp_min ? dll : 0.f;
+      dls = lsr >= ls_min ? (clip ? -dll : dll * (z * z - 1.f)) : 0.f;
+      dmu = clip ? 0.f : dll * z / sg;
+    }
+    d_log_pi[k] = dlp;
+    d_log_sigma[k] = dls;
+    d_mu[k] = dmu;
+  }
+}
+
+extern "C" int ptpp_mdn_nll_fwd(const float* log_pi, const float* log_sigma, const float* mu, const float* target,
+                                const unsigned char* mask, float* loss, int64_t rows, int G, int D, float lp_min, float ls_min,
+                                void* stream) {
+  PTPP_CHECK_ARG(log_pi && log_sigma && mu && target && loss && rows > 0 && G > 0 && D > 0, "mdn_nll_fwd: bad args");
+  const int64_t n = rows * D;
+  hipLaunchKernelGGL(mdn_nll_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     log_pi, log_sigma, mu, target, mask, loss, n, G, D, lp_min, ls_min);
+  PTPP_CHECK_LAUNCH("mdn_nll_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_mdn_nll_bwd(const float* log_pi, const float* log_sigma, const float* mu, const float* target,
+                                const unsigned char* mask, const float* loss, const float* gout, float* d_log_pi,
+                                float* d_log_sigma, float* d_mu, int64_t rows, int G, int D, float lp_min, float ls_min,
+                                void* stream) {
+  PTPP_CHECK_ARG(log_pi && log_sigma && mu && target && loss && gout && d_log_pi && d_log_sigma && d_mu && rows > 0 && G > 0 &&
+                     D > 0, "mdn_nll_bwd: bad args");
+  const int64_t n = rows * D;
+  hipLaunchKernelGGL(mdn_nll_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     log_pi, log_sigma, mu, target, mask, loss, gout, d_log_pi, d_log_sigma, d_mu, n, G, D, lp_min, ls_min);
+  PTPP_CHECK_LAUNCH("mdn_nll_bwd");
+  return PTPP_OK;
+}
+
 // b, a: HOST arrays of order + 1 coefficients (a[0] is divided out); tmp: rows * T doubles of device scratch
 extern "C" int ptpp_filtfilt(const float* x, float* y, double* tmp, const int32_t* lengths, const double* b,
                              const double* a, int order, int rows, int T, int ldx, void* stream) {

@@ -6,12 +6,15 @@ on (B, T, G, D) tensors with G*D <= 2560 per row -- a few kB per utterance -- an
 is expressed with torch tensor ops in f32 (no kernel of its own: it is far off
 the roofline-relevant path)."""
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as PF
+
+FUSED_NLL = not os.environ.get("PTPP_NO_FUSED_MDN")  # (tests compare the fused launches with the tensor-op path)
 
 
 class MDNLayer(nn.Module):
@@ -39,11 +42,42 @@ class MDNLayer(nn.Module):
         return log_pi, log_sigma.reshape(B, T, G, D), mu.reshape(B, T, G, D)
 
 
+class _MdnNllFn(torch.autograd.Function):
+    """The dimension-wise NLL as one launch forward and one backward (ptpp_mdn_nll_fwd / _bwd) instead of ~35 + ~70
+    tensor ops; same clamps, same masking (masked positions: +inf, zero gradients)."""
+
+    @staticmethod
+    def forward(ctx, log_pi, log_sigma, mu, target, mask, lp_min, ls_min):
+        from .. import ops
+
+        log_pi, log_sigma, mu = log_pi.contiguous(), log_sigma.contiguous(), mu.contiguous()
+        target = target.contiguous()
+        m8 = mask.contiguous().view(torch.uint8) if mask is not None else None
+        loss = ops.mdn_nll_fwd(log_pi, log_sigma, mu, target, m8, lp_min, ls_min)
+        ctx.save_for_backward(log_pi, log_sigma, mu, target, loss)
+        ctx.m8, ctx.mins = m8, (lp_min, ls_min)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .. import ops
+
+        log_pi, log_sigma, mu, target, loss = ctx.saved_tensors
+        dlp, dls, dmu = ops.mdn_nll_bwd(log_pi, log_sigma, mu, target, ctx.m8, loss, gout.contiguous().float(), *ctx.mins)
+        return dlp, dls, dmu, None, None, None, None
+
+
 def mdn_loss(log_pi, log_sigma, mu, target, log_pi_min=-7.0, log_sigma_min=-7.0, reduce=True, mask=None):
     """Negative log-likelihood of `target` (B,T,D) under the mixture: clamp log_sigma
     / log_pi from below, clamp the centred target to +-5 sigma, Gaussian log-density
     + log weight, -logsumexp over components (mdn.py:81-175)."""
     dim_wise = log_pi.dim() == 4
+    if (dim_wise and mu.is_cuda and FUSED_NLL and log_pi.dtype == log_sigma.dtype == mu.dtype == torch.float32
+            and target.dtype == torch.float32 and target.shape == mu.shape[:2] + mu.shape[3:]
+            and (mask is None or (mask.dtype == torch.bool and mask.numel() == mu.shape[0] * mu.shape[1]))):
+        loss = _MdnNllFn.apply(log_pi, log_sigma, mu, target, None if mask is None else mask.reshape(mu.shape[:2]),
+                               log_pi_min, log_sigma_min)
+        return loss.mean(dim=1) if reduce else loss
     log_sigma = log_sigma.clamp(min=log_sigma_min)
     log_pi = log_pi.clamp(min=log_pi_min)
     sigma = torch.exp(log_sigma)

@@ -499,6 +499,26 @@ def conv1d_gate_bwd(do, wpt, a, da):
     return da
 
 
+def mdn_nll_fwd(log_pi, log_sigma, mu, target, mask, lp_min, ls_min):
+    """(rows.., G, D) f32 x3, target (rows.., D), mask (rows..) bool or None -> loss (rows.., D)."""
+    G, D = mu.shape[-2], mu.shape[-1]
+    loss = torch.empty(target.shape, device=mu.device, dtype=torch.float32)
+    check(_lib.load().ptpp_mdn_nll_fwd(log_pi.data_ptr(), log_sigma.data_ptr(), mu.data_ptr(), target.data_ptr(),
+                                       mask.data_ptr() if mask is not None else None, loss.data_ptr(), loss.numel() // D, G, D,
+                                       float(lp_min), float(ls_min), _stream()), "ptpp_mdn_nll_fwd")
+    return loss
+
+
+def mdn_nll_bwd(log_pi, log_sigma, mu, target, mask, loss, gout, lp_min, ls_min):
+    G, D = mu.shape[-2], mu.shape[-1]
+    dlp, dls, dmu = torch.empty_like(log_pi), torch.empty_like(log_sigma), torch.empty_like(mu)
+    check(_lib.load().ptpp_mdn_nll_bwd(log_pi.data_ptr(), log_sigma.data_ptr(), mu.data_ptr(), target.data_ptr(),
+                                       mask.data_ptr() if mask is not None else None, loss.data_ptr(), gout.data_ptr(),
+                                       dlp.data_ptr(), dls.data_ptr(), dmu.data_ptr(), loss.numel() // D, G, D, float(lp_min),
+                                       float(ls_min), _stream()), "ptpp_mdn_nll_bwd")
+    return dlp, dls, dmu
+
+
 def ddpm_step(x, eps, noise, t, sra, srm1, c1, c2, logvar):
     """x (B, ...) f32, eps same shape (f32 / bf16), noise f32 or None, t (B) int64 on the device -> x_{t-1} f32
     (ptpp_ddpm_step: the reverse-diffusion update as one pass)."""

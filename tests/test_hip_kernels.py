@@ -766,3 +766,38 @@ def test_conv1d_gate_bwd_fused_is_bit_identical_to_the_two_kernel_path(dev, B, T
     ops.conv1d_gate_bwd(do, wpt, a, wide_b[:, :, 2 * C : 4 * C])
     assert torch.equal(wide_a, wide_b)
     assert float(wide_a[:, :, 2 * C : 4 * C].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,T,G,D,masked", [(7, 53, 4, 1, True), (19, 1, 10, 256, False), (3, 40, 6, 5, True)])
+def test_mdn_nll_fused_matches_the_tensor_ops(dev, B, T, G, D, masked):
+    """ptpp_mdn_nll_fwd / _bwd (dimension-wise mixture NLL, reference modules/mdn.py:81-175) against the tensor-op chain
+    and its autograd: every clamp regime is hit (log_sigma and log_pi below their floors, targets beyond 5 sigma),
+    masked positions give +inf and zero gradients."""
+    from promptttspp_amd.modules import mdn as M
+
+    torch.manual_seed(5)
+    lp_raw = rnd(1, B, T, G, D).to(dev) * 3.0
+    ls = (rnd(2, B, T, G, D).to(dev) * 4.0 - 3.0)  # some below -7
+    mu = rnd(3, B, T, G, D).to(dev)
+    tgt = (rnd(4, B, T, D).to(dev) * 2.5).contiguous()  # some beyond 5 sigma of narrow components
+    mask = None
+    if masked:
+        lens = torch.tensor([max(1, T - 7 * i) for i in range(B)], device=dev)
+        mask = (torch.arange(T, device=dev)[None, :] < lens[:, None]).unsqueeze(-1)  # (B, T, 1) as the model passes it
+    outs = []
+    for fused in (False, True):
+        M.FUSED_NLL = fused
+        a, b, c = (t.clone().requires_grad_() for t in (lp_raw, ls, mu))
+        lp = torch.log_softmax(a, dim=2) * 2.0  # (scaled: some weights fall below the -7 floor)
+        nll = M.mdn_loss(lp, b, c, tgt, reduce=False, mask=mask)
+        keep = mask.expand_as(nll) if mask is not None else torch.ones_like(nll, dtype=torch.bool)
+        assert bool(torch.isinf(nll[~keep]).all()) if mask is not None else True
+        w = rnd(9, *nll.shape).to(dev)
+        (torch.where(keep, nll, torch.zeros_like(nll)) * w).sum().backward()
+        outs.append((torch.where(keep, nll, torch.zeros_like(nll)).detach(), a.grad, b.grad, c.grad))
+    M.FUSED_NLL = True
+    ref, got = outs
+    assert rel_err(got[0].cpu(), ref[0].cpu()) < 2e-6
+    for g, r in zip(got[1:], ref[1:]):
+        assert torch.isfinite(g).all()
+        assert rel_err(g.cpu(), r.cpu()) < 2e-5
