@@ -458,6 +458,14 @@ int ptpp_btc_to_bct(const void* x, float* y, int B, int T, int C, int dtype,
 #define PTPP_SUMSQ_SLOTS 64
 int ptpp_grad_sumsq(const void* refs, int nt, const int32_t* block_map,
                     long long total_blocks, float* sumsq, void* stream);
+/* The same sums without atomics: every block stores its partial into `partials`
+ * (total_blocks floats, caller-owned), a second launch adds them per slot in a
+ * fixed order -- bit-reproducible, so that the ranks of a data-parallel job clip
+ * identical gradients by the identical factor (DDP's invariant of identical
+ * parameters on every rank, trainers/tts.py:117,206-211). */
+int ptpp_grad_sumsq_det(const void* refs, int nt, const int32_t* block_map,
+                        long long total_blocks, float* sumsq, float* partials,
+                        void* stream);
 int ptpp_adamw_step(const void* refs, int nt, const int32_t* block_map,
                     long long total_blocks, const float* sumsq, const float* lr,
                     float beta1, float beta2, float eps, float weight_decay,

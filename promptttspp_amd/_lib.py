@@ -113,6 +113,7 @@ SIGNATURES = {
     "ptpp_bct_to_btc": (I, [P, P, I, I, I, I, P]),
     "ptpp_btc_to_bct": (I, [P, P, I, I, I, I, P]),
     "ptpp_grad_sumsq": (I, [P, I, P, c_longlong, P, P]),
+    "ptpp_grad_sumsq_det": (I, [P, I, P, c_longlong, P, P, P]),
     "ptpp_adamw_step": (I, [P, I, P, c_longlong, P, P, F, F, F, F, I, F, P]),
     "ptpp_comm_unique_id": (I, [P]),
     "ptpp_comm_init": (I, [I, I, P, POINTER(c_void_p)]),

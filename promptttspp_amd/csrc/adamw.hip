@@ -58,6 +58,48 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const TensorRef* __rest
   if (threadIdx.x == 0) atomicAdd(out + (blockIdx.x % PTPP_SUMSQ_SLOTS), red[0] + red[1] + red[2] + red[3]);
 }
 
+// Deterministic variant: every block STORES its partial sum (no atomics), a second launch adds the partials of each
+// slot in a fixed order.  With f32 atomics the order of the ~275 additions per slot varies from run to run, the norm --
+// hence the clip factor, hence every parameter -- could differ in the last bit between the ranks of a data-parallel job
+// although their gradients were identical (tests/test_dp_gpu.py).
+__global__ __launch_bounds__(256) void grad_sumsq_partial_kernel(const TensorRef* __restrict__ refs, int nt,
+                                                                 const int* __restrict__ block_map, float* __restrict__ part) {
+  const int ti = find_tensor(refs, nt, blockIdx.x, block_map);
+  const TensorRef r = refs[ti];
+  const long long base = (blockIdx.x - r.block0) * (long long)CHUNK;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + ((long long)k * 256 + threadIdx.x) * 4;
+    if (i + 3 < r.n && (reinterpret_cast<uintptr_t>(r.g) & 15) == 0) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(r.g + i);
+      s += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+    } else {
+      for (long long j = i; j < r.n && j < i + 4; ++j) s += r.g[j] * r.g[j];
+    }
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// slot s = sum of part[b], b = s, s + SLOTS, s + 2 SLOTS, ... : per thread a strided serial sum, then a fixed tree
+__global__ __launch_bounds__(256) void grad_sumsq_finish_kernel(const float* __restrict__ part, long long nblk,
+                                                                float* __restrict__ out) {
+  const int slot = blockIdx.x;
+  float s = 0.f;
+  for (long long b = slot + (long long)threadIdx.x * PTPP_SUMSQ_SLOTS; b < nblk; b += 256LL * PTPP_SUMSQ_SLOTS) s += part[b];
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[slot] = red[0];
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(const TensorRef* __restrict__ refs, int nt,
                                                     const int* __restrict__ block_map,
                                                     const float* __restrict__ sumsq, const float* __restrict__ lr_ptr,
@@ -121,6 +163,18 @@ extern "C" int ptpp_grad_sumsq(const void* refs, int nt, const int32_t* block_ma
   hipLaunchKernelGGL(grad_sumsq_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, (const TensorRef*)refs, nt, block_map,
                      sumsq);
   PTPP_CHECK_LAUNCH("grad_sumsq");
+  return PTPP_OK;
+}
+
+// As ptpp_grad_sumsq, bit-reproducible: `partials` = total_blocks floats of caller-owned scratch.
+extern "C" int ptpp_grad_sumsq_det(const void* refs, int nt, const int32_t* block_map, long long total_blocks, float* sumsq,
+                                   float* partials, void* stream) {
+  PTPP_CHECK_ARG(refs && sumsq && partials && nt > 0 && total_blocks > 0, "grad_sumsq_det: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(grad_sumsq_partial_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, (const TensorRef*)refs, nt,
+                     block_map, partials);
+  hipLaunchKernelGGL(grad_sumsq_finish_kernel, dim3(PTPP_SUMSQ_SLOTS), dim3(256), 0, st, partials, total_blocks, sumsq);
+  PTPP_CHECK_LAUNCH("grad_sumsq_det");
   return PTPP_OK;
 }
 

@@ -24,6 +24,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.stable_grads = False  # set True by callers whose p.grad tensors live for the whole run (see _table)
         self._tables = {}
         self._sumsq = None
+        self._partials = {}
         self._lr_dev = {}
 
     def _bump_list(self, gi, group):
@@ -84,7 +85,12 @@ class FusedAdamW(torch.optim.Optimizer):
             for gi, g in live:
                 tab, nt, nblk, bmap = self._table(gi, g)
                 part = self._sumsq if total is None else torch.zeros_like(self._sumsq)
-                _lib.check(lib.ptpp_grad_sumsq(_ptr(tab), nt, _ptr(bmap), nblk, _ptr(part), _stream()), "ptpp_grad_sumsq")
+                scratch = self._partials.get(gi)
+                if scratch is None or scratch.numel() < nblk:
+                    scratch = self._partials[gi] = torch.empty(nblk, device=dev, dtype=torch.float32)
+                # (the deterministic two-launch form: identical clip factors on every data-parallel rank)
+                _lib.check(lib.ptpp_grad_sumsq_det(_ptr(tab), nt, _ptr(bmap), nblk, _ptr(part), _ptr(scratch), _stream()),
+                           "ptpp_grad_sumsq_det")
                 total = part if total is None else total.add_(part)
             if total is not self._sumsq:
                 self._sumsq.copy_(total)
