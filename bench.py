@@ -478,8 +478,49 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def self_launch(a):
+    """``python bench.py --gpus N`` without a launcher (no WORLD_SIZE in the environment): start the N ranks here, one
+    process per GPU, the way the reference's trainer spawns its workers from a plain ``python train.py``
+    (/root/reference/promptttspp/trainers/tts.py:40-48).  Rank 0 inherits stdout (the ONE JSON line); the other ranks'
+    stdout goes to stderr.  Returns the worst exit status; a rank that dies takes the others down with it."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                st = pr.poll()
+                if st is None:
+                    continue
+                pending.remove(pr)
+                if st != 0:
+                    rc = rc or st
+                    for other in pending:  # a dead rank would leave the others hanging in a collective
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     # stdout carries exactly ONE line (the JSON): native libraries write banners there (RCCL prints its
     # version block on the first collective), so fd 1 points at stderr for the whole run and the result
     # goes to the saved descriptor
@@ -490,6 +531,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if os.environ.get("PTPP_BENCH_LAUNCH_PROBE"):
+        # launcher check for a box without GPUs (tests/test_bench_launch.py): rendezvous + one collective over gloo,
+        # rank 0 answers on the real stdout exactly as the benchmark does; nothing is measured
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29556")
+        if os.environ["PTPP_BENCH_LAUNCH_PROBE"] == f"fail{rank}":
+            sys.exit(3)  # the launcher must notice, stop the ranks left waiting in the rendezvous and report failure
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        print(f"probe rank {rank} of {world}")  # lands on stderr: fd 1 is redirected
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"probe": True, "n_gpus": world, "sum": float(t[0])}) + "\n").encode())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # PTPP_BENCH_SELFTEST=1: all ranks on device 0 over gloo -- exercises the N > 1 code path on a 1-GPU
     # box (RCCL refuses two ranks per device); never set for measurements
     selftest = bool(os.environ.get("PTPP_BENCH_SELFTEST"))
