@@ -213,9 +213,16 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         recs.append((e0, e1, 2.0 * rows * c2 * (c2 // 2), rows * 3 * c2 * 2 + c2 * (c2 // 2) * 2))
         return r
 
+    from promptttspp_amd import functional as PF
+
     ops.conv1d = timed
     ops.conv1d_diffnet_post = timed_post
     ops.conv1d_gate_bwd = timed_gbwd
+    # the timed steps issue whole stacks through the C-side drivers (one call per DiffNet stack / predictor stack); the
+    # instrumented step takes the per-launch path -- the same kernels with the same arguments in the same order (bit-identical,
+    # tests/test_stack_drivers.py) -- so that every launch can be bracketed by its own pair of events
+    drivers = PF.STACK_DRIVERS
+    PF.STACK_DRIVERS = False
     try:
         # keep the device busy while the host enqueues the step, so that the events bracket kernel
         # execution and not launch gaps (the instrumented step is host-bound)
@@ -223,6 +230,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         train_step(model, batch, red, opt, sched)
         torch.cuda.synchronize()
     finally:
+        PF.STACK_DRIVERS = drivers
         ops.conv1d = orig
         ops.conv1d_diffnet_post = orig_post
         ops.conv1d_gate_bwd = orig_gbwd
@@ -260,49 +268,75 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
             "traffic": traffic, "traffic_source": traffic_src,
             "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
             "flop_per_step": tot_flop, "by_bound": by_bound,
-            "note": "all launches are priced against the MFMA peak here for continuity with round 1; 40 of them are the DiffNet 1x1 "
+            "note": "instrumented extra step on the timed batch with the longest utterances, issued launch by launch (the timed "
+                    "steps issue the same kernels through the C-side stack drivers); `traffic` is read from the committed PMC "
+                    "pass named in traffic_source, not measured in this run; "
+                    "all launches are priced against the MFMA peak here for continuity with round 1; 40 of them are the DiffNet 1x1 "
                     "projections whose epilogues now also do the work of the elementwise kernels they replaced (residual / skip "
                     "update, gate backward), i.e. they got longer while the step got shorter; by_bound prices each launch "
                     "against the roof its arithmetic intensity selects"}
 
 
 def cpu_baseline(model, batch):
-    """The oracle (CPU restatement of the reference, fp32 PyTorch) on the host cores:
-    forward + backward + clip + AdamW on a BOUNDED sample (the first 16 utterances of one
-    bench batch, ~8 k frames; one warm-up step + one timed step)."""
+    """The oracle (CPU restatement of the reference, fp32 PyTorch) on the host cores: forward + backward + clip + AdamW
+    on a BOUNDED sample of one bench batch.  SURVEY section 8d asks for all host cores, median of 5 after 2 warm-ups; the
+    bench contract for ~10-30 s of CPU work: so (1) a thread-count sweep on 2 utterances (this many-small-ops workload gets
+    SLOWER beyond a few dozen threads on the 256-thread host; every count tried is reported), (2) at the best count,
+    8 utterances, 1 warm-up + 3 timed steps, median."""
+    import statistics
+
     from oracle import ref_torch as R
 
-    # (more threads than ~32 make this many-small-ops workload SLOWER on the 256-thread GPU host:
-    #  measured 0.35 / 0.59 / 1.30 s per step at 16 / 32 / 64 threads for 2 utterances)
-    nthr, ncores = _cpu_threads()
-    n = min(16, batch[0].shape[0])
-    phon, dur, plen, mel, cf0, vuv, energy, flen, (ids, am) = [x if isinstance(x, tuple) else x[:n].cpu() for x in batch]
-    ids, am = ids[:n].cpu(), am[:n].cpu()
-    Tp, Tf = int(plen.max()), int(flen.max())
-    cb = (phon[:, :Tp], dur[:, :, :Tp], plen, mel[:, :, :Tf], cf0[:, :, :Tf], vuv[:, :, :Tf], flen, ids, am)
+    ncores = os.cpu_count() or 1
     sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
     train_names = [k for k, p in model.named_parameters() if p.requires_grad]
     for k in train_names:
         sd[k].requires_grad_()
     opt = torch.optim.AdamW([sd[k] for k in train_names], lr=1e-3, betas=(0.9, 0.98), weight_decay=0.0)
-    g = torch.Generator().manual_seed(0)
-    t = torch.randint(0, 100, (n,), generator=g)
-    noise = torch.randn(n, 80, Tf, generator=g)
-    times = []
-    for it in range(2):
+
+    def sample(n):
+        phon, dur, plen, mel, cf0, vuv, energy, flen, (ids, am) = [x if isinstance(x, tuple) else x[:n].cpu() for x in batch]
+        ids, am = ids[:n].cpu(), am[:n].cpu()
+        Tp, Tf = int(plen.max()), int(flen.max())
+        cb = (phon[:, :Tp], dur[:, :, :Tp], plen, mel[:, :, :Tf], cf0[:, :, :Tf], vuv[:, :, :Tf], flen, ids, am)
+        g = torch.Generator().manual_seed(0)
+        return cb, torch.randint(0, 100, (n,), generator=g), torch.randn(n, 80, Tf, generator=g), int(flen.sum())
+
+    def step(cb, t, noise):
         t0 = time.perf_counter()
         opt.zero_grad()
         loss = R.model_forward(sd, cb, t, noise, train_bn=True)["loss"]
         loss.backward()
         torch.nn.utils.clip_grad_norm_([sd[k] for k in train_names], 1.0)
         opt.step()
-        times.append(time.perf_counter() - t0)
-        log(f"cpu baseline step {it}: {times[-1]:.2f}s")
-    best = times[-1]
-    frames = int(flen.sum())
-    return {"value": round(frames / best, 1), "unit": "mel-frames/sec", "cores": nthr, "kind": "port",
-            "sample": f"{n} utterances / {frames} valid frames of one bench batch, fp32, dropout off, 1 warm-up + 1 timed step "
-                      f"({best:.2f} s/step; host has {ncores} logical cores)"}
+        return time.perf_counter() - t0
+
+    forced = os.environ.get("PTPP_CPU_THREADS")
+    # ascending thread counts; the sweep stops at the first count that is slower than the best so far (beyond a few dozen
+    # threads this workload of many small ops only adds synchronisation: 0.35 / 0.59 / 1.30 s per step at 16 / 32 / 64
+    # threads in round 2 -- and a 256-thread step did not finish within the bench's time budget)
+    cands = [int(forced)] if forced else [c for c in (8, 16, 32, 64, 128) if c <= ncores]
+    sweep = {}
+    cb2, t2, n2, _ = sample(min(2, batch[0].shape[0]))
+    for c in cands:
+        torch.set_num_threads(c)
+        step(cb2, t2, n2)
+        sweep[c] = step(cb2, t2, n2)
+        log(f"cpu baseline sweep: {c} threads {sweep[c]:.2f}s")
+        if sweep[c] > 1.15 * min(sweep.values()):
+            break
+    nthr = min(sweep, key=sweep.get)
+    torch.set_num_threads(nthr)
+    n = min(8, batch[0].shape[0])
+    cb, t, noise, frames = sample(n)
+    step(cb, t, noise)
+    times = [step(cb, t, noise) for _ in range(3)]
+    med = statistics.median(times)
+    log(f"cpu baseline: {nthr} threads, steps {times}")
+    return {"value": round(frames / med, 1), "unit": "mel-frames/sec", "cores": nthr, "kind": "port",
+            "sample": f"{n} utterances / {frames} valid frames of one bench batch, fp32, dropout off, 1 warm-up + 3 timed steps, median "
+                      f"{med:.2f} s/step (all {[round(x, 2) for x in times]}); threads chosen from an ascending sweep on 2 utterances that "
+                      f"stops when a count gets slower: { {c: round(v, 2) for c, v in sweep.items()} } s/step; host has {ncores} logical cores"}
 
 
 def _tame_gain(voc):

@@ -157,6 +157,24 @@ int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias,
                       int dtype, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* The weight gradients of SEVERAL layers of one shape (the layers of a stack: B, T, Cin, Cout, ks, row strides, mask shared;
+ * operands, dilation, padding and accumulation targets per problem; probs is a HOST array) after the stack's backward has
+ * produced all their operands.  When the tiles of all problems fill the machine (bf16, Cin, Cout > 64) ONE launch computes
+ * them with every dw element owned by exactly one block that walks all rows in a fixed order and adds its total into dw: no
+ * split-K partials, no second pass, bit-reproducible.  Otherwise (f32 parity mode, small shapes) it is a loop of
+ * ptpp_conv1d_wgrad calls with the workspace. */
+typedef struct {
+  const void* x;
+  const void* dy;
+  float* dw;       /* (Cout, Cin, ks) f32, accumulated into */
+  float* dbias;    /* (Cout) f32 or NULL                     */
+  int32_t dil, pad;
+} ptpp_wgrad_problem;
+int ptpp_conv1d_wgrad_batched(const ptpp_wgrad_problem* probs, int nprob, const int32_t* lengths,
+                              int B, int T, int Cin, int Cout, int ks, int ldx, int lddy,
+                              int in_mask, int dtype, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 /* Backward of the conv epilogue (contiguous (B,T,C)):
  *   dz = dy * scale * [t < len] * relu'(y) * dropmask           */
 int ptpp_epilogue_bwd(const void* dy, const void* y, void* dz,
@@ -470,6 +488,152 @@ int ptpp_adamw_step(const void* refs, int nt, const int32_t* block_map,
                     long long total_blocks, const float* sumsq, const float* lr,
                     float beta1, float beta2, float eps, float weight_decay,
                     int step, float max_norm, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Whole-unit drivers: ONE call issues every launch of a unit of the model (host launch work per kernel drops from a
+ * Python / FFI round trip, 9-13 us through ctypes, to the raw launch).  A driver is composed of the entry points above, in
+ * the order the per-launch path issues them, so its results are bit-identical to that path (tests compare the two).
+ * Pointer tables are HOST arrays of L device pointers.  Slabs: layer l uses slab (l % n_slabs) of yin_all / a_all /
+ * g_all -- n_slabs = L keeps every layer's activations for the backward, n_slabs = 2 ping-pongs (inference).
+ * ------------------------------------------------------------------ */
+/* DiffNet residual stack, forward (reference modules/denoiser.py:69-83 per layer, :136-140 the loop):
+ *   yin_0 = h0 + dsteps[0];  per layer l: a = dilconv_l(yin) + cond_all[.., l*2C:(l+1)*2C]; g = sigmoid(a[:C])*tanh(a[C:]);
+ *   o = outproj_l(g) (masked);  x = (x + o[:C]) / sqrt2;  skip += o[C:];  yin = x + dsteps[l+1].
+ * fused_gate (bf16 inference): the dilated conv's weights / bias and cond_all are in the interleaved gate order and the
+ * gate runs in the conv epilogue (PTPP_ACT_GATE); a_all is then unused. */
+typedef struct {
+  const void* h0;           /* (B, T, C) dtype                                        */
+  const void* cond_all;     /* (B, T, L*2C) dtype, row stride L*2C                    */
+  const float* dsteps;      /* (L, B, C) f32 diffusion-step projections               */
+  const int32_t* lengths;   /* (B) or NULL (inference: no masks)                      */
+  float* skip;              /* (B, T, C) f32 out: sum of the skip halves              */
+  const void* const* dil_wp;   /* [L] packed (2C, 3, C) operands (mode 0)             */
+  const float* const* dil_b;   /* [L] (2C) f32                                        */
+  const void* const* out_wp;   /* [L] packed (2C, 1, C) operands                      */
+  const float* const* out_b;   /* [L] (2C) f32                                        */
+  void* yin_all;            /* (n_slabs, B, T, C) dtype                               */
+  void* a_all;              /* (n_slabs, B, T, 2C) dtype, NULL with fused_gate        */
+  void* g_all;              /* (n_slabs, B, T, C) dtype                               */
+  void* x_buf[2];           /* two (B, T, C) dtype scratch tensors for x              */
+  void* o_buf;              /* (B, T, 2C) dtype scratch, only used where the fused tail is unsupported (f32) */
+  int32_t B, T, C, L, cycle, n_slabs, fused_gate, dtype;
+} ptpp_diffnet_stack_fwd_args;
+int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream);
+
+/* Backward of the stack (hand-derived; the per-launch form is functional.DiffNetStackFn.backward).  Weight gradients
+ * ACCUMULATE into the f32 targets (e.g. views of the flat gradient buffer) and run on `side_stream` when it is not NULL
+ * (forked after the producing launch with a pooled event; the CALLER joins the streams and keeps the slabs alive until
+ * then).  Outputs: gx_all[0] = gradient w.r.t. h0;  dcond_all = gradient w.r.t. cond_all;  S[l][b][c] = sum_t
+ * gx_all[l][b][t][c] for l < L (the caller forms the step-projection gradients S[l] - S[l+1] / sqrt2 with S[L] = 0). */
+typedef struct {
+  const void* gS;           /* (B, T, C) dtype: gradient of the skip sum               */
+  const void* yin_all;      /* saved by the forward (n_slabs = L)                      */
+  const void* a_all;
+  const void* g_all;
+  const int32_t* lengths;
+  const void* const* dil_wpt;  /* [L] mode-1 packed operands of the dilated convs     */
+  const void* const* out_wpt;  /* [L] mode-1 packed operands of the output projections */
+  float* const* dw_dil;     /* [L] (2C, C, 3) f32 accumulation targets                */
+  float* const* db_dil;     /* [L] (2C)                                               */
+  float* const* dw_out;     /* [L] (2C, C, 1)                                         */
+  float* const* db_out;     /* [L] (2C)                                               */
+  void* gx_all;             /* (L+1, B, T, C) dtype scratch / out; slab L is zero-filled here */
+  void* do_all;             /* (L, B, T, 2C) dtype scratch                            */
+  void* dg_buf;             /* (B, T, C) dtype scratch, only where the fused gate backward is unsupported (f32) */
+  void* dcond_all;          /* (B, T, L*2C) dtype out                                 */
+  float* S;                 /* (L, B, C) f32 out                                      */
+  void* ws_main; size_t ws_main_bytes;   /* split-K scratch of the main stream        */
+  void* ws_side; size_t ws_side_bytes;   /* ... of the stream the weight gradients run on */
+  void* side_stream;        /* NULL: weight gradients on `stream`                     */
+  int32_t B, T, C, L, cycle, dtype;
+  int32_t batched_wgrad;    /* 1: the 2 L weight gradients as TWO ptpp_conv1d_wgrad_batched calls after the loop (all
+                             * operands are slabs that outlive it): no split-K partials, bit-reproducible; 0: one
+                             * ptpp_conv1d_wgrad per layer inside the loop, exactly as the per-launch path */
+} ptpp_diffnet_stack_bwd_args;
+int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void* stream);
+
+/* A run of post-LN Transformer encoder layers, forward only (the frozen layers of the prompt encoder's BERT: the reference
+ * trains only encoder.layer[-1].attention, modules/prompt_encoder.py:25-38; per layer, transformers BertLayer =
+ * fused q|k|v projection -> plain attention (probability dropout) -> output projection (+ hidden dropout + residual) ->
+ * LayerNorm -> intermediate (exact GELU) -> output (+ dropout + residual) -> LayerNorm).  h (B, T, C) is read from h_in;
+ * the result of the last layer is in h_out.  Tables are HOST arrays of L device pointers; seeds: HOST array of 3 L dropout
+ * seeds (attention, attention-output, output) -- ignored where the matching p is 0.  scratch: >= B*T*(7C + F) elements of
+ * dtype (F = intermediate width); ws: the split-K scratch of ptpp_conv1d_fwd_ws (used exactly where the per-launch path
+ * hands it over: T <= 512 and K >= 2048). */
+typedef struct {
+  const void* h_in;
+  void* h_out;
+  const int32_t* lengths;      /* (B) keys at positions >= length are masked */
+  const void* const* qkv_wp;   /* [L] packed (3C, 1, C) */
+  const float* const* qkv_b;   /* [L] (3C) */
+  const void* const* ao_wp;    /* [L] packed (C, 1, C): attention output projection */
+  const float* const* ao_b;
+  const float* const* ln1_g;
+  const float* const* ln1_b;
+  const void* const* i_wp;     /* [L] packed (F, 1, C) */
+  const float* const* i_b;
+  const void* const* o_wp;     /* [L] packed (C, 1, F) */
+  const float* const* o_b;
+  const float* const* ln2_g;
+  const float* const* ln2_b;
+  const uint64_t* seeds;       /* [3 L] */
+  void* scratch; size_t scratch_bytes;
+  void* ws; size_t ws_bytes;
+  float eps, p_att, p_hid;
+  int32_t B, T, C, F, H, L, dtype;
+} ptpp_encoder_layers_fwd_args;
+int ptpp_encoder_layers_fwd(const ptpp_encoder_layers_fwd_args* a, void* stream);
+
+/* A stack of n [Conv1d (C -> C, kernel ks, "same" padding) -> LayerNorm] layers: the variance predictors
+ * (modules/variance_adaptor.py:23-62: dropout(LN(relu(conv(x)))) * mask) and the frame prior network
+ * (modules/frame_prior.py:76-89: x = LN(x + dropout(gelu(conv(x * mask)))), masked after the last layer).
+ *   z_i = act(conv_i(in_mask ? x_i masked : x_i) + b_i)                          conv_act: PTPP_ACT_NONE | PTPP_ACT_RELU
+ *   x_{i+1} = drop_out(LN(drop_in(act_in(z_i)) + (ln_res ? x_i : 0)) * g_i + b_i) * [mask]
+ * out_mask: 0 none, 1 every layer, 2 the last layer only.  conv_mask: the conv reads lengths and masks its input rows.
+ * Everything the backward needs is kept in slabs: x_all[i] = x_{i+1}, z_all[i], sum_all[i] (the LayerNorm's input; NULL
+ * when ln_res == act_in == drop_in == 0), mean_all / rstd_all (n, B*T).  seeds: HOST [2n] = (drop_in, drop_out) per layer. */
+typedef struct {
+  const void* x0;
+  const int32_t* lengths;
+  const void* const* wp;      /* [n] packed (C, ks, C) forward operands */
+  const float* const* bias;   /* [n] (C) */
+  const float* const* gamma;  /* [n] (C) */
+  const float* const* beta;
+  void* x_all; void* z_all; void* sum_all;
+  float* mean_all; float* rstd_all;
+  const uint64_t* seeds;
+  void* ws; size_t ws_bytes;  /* split-K scratch of ptpp_conv1d_fwd_ws (handed over where the per-launch path does) */
+  float eps, drop_in, drop_out;
+  int32_t B, T, C, n, ks, conv_act, conv_mask, ln_res, act_in, out_mask, dtype;
+} ptpp_conv_ln_stack_fwd_args;
+int ptpp_conv_ln_stack_fwd(const ptpp_conv_ln_stack_fwd_args* a, void* stream);
+
+/* Backward of the stack.  gy: gradient w.r.t. x_n.  gx (nullable): gradient w.r.t. x0.  Weight / bias / gamma / beta
+ * gradients ACCUMULATE into the f32 targets; the conv weight gradients run on side_stream when it is not NULL (per layer
+ * inside the loop, or -- batched_wgrad -- as ONE ptpp_conv1d_wgrad_batched call after it: gz_all keeps every layer's
+ * conv-output gradient).  Scratch: gz_all (n, B, T, C); tmp: 4 (B, T, C) tensors; red_scratch: the zero-filled reduction
+ * scratch of ptpp_layernorm_bwd. */
+typedef struct {
+  const void* gy;
+  const void* x0;
+  const void* x_all; const void* z_all; const void* sum_all;
+  const float* mean_all; const float* rstd_all;
+  const int32_t* lengths;
+  const void* const* wpt;     /* [n] mode-1 packed operands */
+  const float* const* gamma;
+  float* const* dw; float* const* db; float* const* dgamma; float* const* dbeta;
+  void* gz_all;
+  void* tmp;
+  void* gx;
+  const uint64_t* seeds;
+  void* red_scratch; size_t red_bytes;
+  void* ws_main; size_t ws_main_bytes;
+  void* ws_side; size_t ws_side_bytes;
+  void* side_stream;
+  float drop_in, drop_out;
+  int32_t B, T, C, n, ks, conv_act, conv_mask, ln_res, act_in, out_mask, dtype, batched_wgrad;
+} ptpp_conv_ln_stack_bwd_args;
+int ptpp_conv_ln_stack_bwd(const ptpp_conv_ln_stack_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Data-parallel gradient exchange over RCCL / xGMI (reference: DistributedDataParallel set up in

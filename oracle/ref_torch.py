@@ -758,7 +758,7 @@ def model_infer_batch(sd, phoneme, plen, x_init_fn, step_noise_fn, ids=None, am=
 
 
 def mel_spectrogram_np(wav, sample_rate=24000, n_fft=512, win_length=480, hop_length=240, f_min=63.0, f_max=12000.0,
-                       n_mels=80):
+                       n_mels=80, power=2.0, parts=False):
     """log-mel of transforms/mel.py:18-34 with conf/transforms/mel.yaml: numpy restatement (reflect-padded, centred
     periodic-Hann frames -> rfft -> |.|^2 -> slaney filterbank, slaney norm -> log(clamp 1e-5)).  wav (L,) -> (80, F)."""
     import numpy as np
@@ -769,7 +769,7 @@ def mel_spectrogram_np(wav, sample_rate=24000, n_fft=512, win_length=480, hop_le
     off = (n_fft - win_length) // 2
     win[off : off + win_length] = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(win_length) / win_length)  # periodic Hann
     fr = np.stack([x[i * hop_length : i * hop_length + n_fft] * win for i in range(nfr)])
-    spec = np.abs(np.fft.rfft(fr, axis=1)) ** 2                       # (F, bins)
+    spec = np.abs(np.fft.rfft(fr, axis=1)) ** power                   # (F, bins); conf/transforms/mel.yaml: power 1
     # slaney mel scale: linear below 1 kHz (200/3 Hz per mel), logarithmic above (27 steps per factor 6.4)
     def hz2mel(f):
         f = np.asarray(f, dtype=np.float64)
@@ -785,6 +785,8 @@ def mel_spectrogram_np(wav, sample_rate=24000, n_fft=512, win_length=480, hop_le
     slopes = fpts[None, :] - freqs[:, None]
     fb = np.maximum(0.0, np.minimum(-slopes[:, :-2] / fdiff[:-1], slopes[:, 2:] / fdiff[1:]))
     fb = fb * (2.0 / (fpts[2:] - fpts[:-2]))[None, :]
+    if parts:  # (tests: spectrum (bins, F), filterbank (bins, n_mels), band edges in Hz, the two scale maps)
+        return spec.T, fb, fpts, hz2mel, mel2hz
     return np.log(np.maximum(spec @ fb, 1e-5)).T
 
 

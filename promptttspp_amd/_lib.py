@@ -58,6 +58,59 @@ class AmpLayerArgs(Structure):
                [("out_scale", c_float), ("res_scale", c_float), ("dtype", c_int32)]
 
 
+class WgradProblem(Structure):
+    """Mirror of ``ptpp_wgrad_problem`` (include/ptpp.h)."""
+
+    _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("dbias", c_void_p), ("dil", c_int32), ("pad", c_int32)]
+
+
+class DiffNetFwdArgs(Structure):
+    """Mirror of ``ptpp_diffnet_stack_fwd_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("h0", "cond_all", "dsteps", "lengths", "skip", "dil_wp", "dil_b", "out_wp", "out_b",
+                                        "yin_all", "a_all", "g_all", "x_buf0", "x_buf1", "o_buf")] + \
+               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "n_slabs", "fused_gate", "dtype")]
+
+
+class DiffNetBwdArgs(Structure):
+    """Mirror of ``ptpp_diffnet_stack_bwd_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("gS", "yin_all", "a_all", "g_all", "lengths", "dil_wpt", "out_wpt", "dw_dil", "db_dil",
+                                        "dw_out", "db_out", "gx_all", "do_all", "dg_buf", "dcond_all", "S", "ws_main")] + \
+               [("ws_main_bytes", ctypes.c_size_t), ("ws_side", c_void_p), ("ws_side_bytes", ctypes.c_size_t),
+                ("side_stream", c_void_p)] + \
+               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "dtype", "batched_wgrad")]
+
+
+class EncoderLayersFwdArgs(Structure):
+    """Mirror of ``ptpp_encoder_layers_fwd_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("h_in", "h_out", "lengths", "qkv_wp", "qkv_b", "ao_wp", "ao_b", "ln1_g", "ln1_b", "i_wp", "i_b",
+                                        "o_wp", "o_b", "ln2_g", "ln2_b", "seeds", "scratch")] + \
+               [("scratch_bytes", ctypes.c_size_t), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t), ("eps", c_float), ("p_att", c_float), ("p_hid", c_float)] + \
+               [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "dtype")]
+
+
+class ConvLnFwdArgs(Structure):
+    """Mirror of ``ptpp_conv_ln_stack_fwd_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("x0", "lengths", "wp", "bias", "gamma", "beta", "x_all", "z_all", "sum_all", "mean_all",
+                                        "rstd_all", "seeds", "ws")] + \
+               [("ws_bytes", ctypes.c_size_t), ("eps", c_float), ("drop_in", c_float), ("drop_out", c_float)] + \
+               [(n, c_int32) for n in ("B", "T", "C", "n", "ks", "conv_act", "conv_mask", "ln_res", "act_in", "out_mask", "dtype")]
+
+
+class ConvLnBwdArgs(Structure):
+    """Mirror of ``ptpp_conv_ln_stack_bwd_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("gy", "x0", "x_all", "z_all", "sum_all", "mean_all", "rstd_all", "lengths", "wpt", "gamma",
+                                        "dw", "db", "dgamma", "dbeta", "gz_all", "tmp", "gx", "seeds", "red_scratch")] + \
+               [("red_bytes", ctypes.c_size_t), ("ws_main", c_void_p), ("ws_main_bytes", ctypes.c_size_t), ("ws_side", c_void_p),
+                ("ws_side_bytes", ctypes.c_size_t), ("side_stream", c_void_p), ("drop_in", c_float), ("drop_out", c_float)] + \
+               [(n, c_int32) for n in ("B", "T", "C", "n", "ks", "conv_act", "conv_mask", "ln_res", "act_in", "out_mask", "dtype",
+                                       "batched_wgrad")]
+
+
 P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/ptpp.h declares.
@@ -72,6 +125,7 @@ SIGNATURES = {
     "ptpp_conv1d_fwd_ex": (I, [POINTER(ConvArgs), P, I, F, F, U64, P]),
     "ptpp_conv1d_fwd_ws": (I, [POINTER(ConvArgs), P, I, F, F, U64, P, SZ, P]),
     "ptpp_conv1d_wgrad": (I, [P, P, P, P, P] + [I] * 11 + [P, SZ, P]),
+    "ptpp_conv1d_wgrad_batched": (I, [POINTER(WgradProblem), I, P, I, I, I, I, I, I, I, I, I, P, SZ, P]),
     "ptpp_epilogue_bwd": (I, [P, P, P, P, I, I, I, F, I, I, F, U64, I, P]),
     "ptpp_layernorm_fwd": (I, [P] * 9 + [I, I, I, F, I, I, F, U64, F, U64, I, P]),
     "ptpp_layernorm_bwd": (I, [P] * 11 + [I, I, I, I, I, F, U64, F, U64, I, P, SZ, P]),
@@ -115,6 +169,11 @@ SIGNATURES = {
     "ptpp_grad_sumsq": (I, [P, I, P, c_longlong, P, P]),
     "ptpp_grad_sumsq_det": (I, [P, I, P, c_longlong, P, P, P]),
     "ptpp_adamw_step": (I, [P, I, P, c_longlong, P, P, F, F, F, F, I, F, P]),
+    "ptpp_diffnet_stack_fwd": (I, [POINTER(DiffNetFwdArgs), P]),
+    "ptpp_diffnet_stack_bwd": (I, [POINTER(DiffNetBwdArgs), P]),
+    "ptpp_conv_ln_stack_fwd": (I, [POINTER(ConvLnFwdArgs), P]),
+    "ptpp_conv_ln_stack_bwd": (I, [POINTER(ConvLnBwdArgs), P]),
+    "ptpp_encoder_layers_fwd": (I, [POINTER(EncoderLayersFwdArgs), P]),
     "ptpp_comm_unique_id": (I, [P]),
     "ptpp_comm_init": (I, [I, I, P, POINTER(c_void_p)]),
     "ptpp_comm_destroy": (I, [P]),

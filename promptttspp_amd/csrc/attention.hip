@@ -169,6 +169,38 @@ __device__ __forceinline__ float attn_keep(const AttnBwdP& p, uint64_t e) {
 // through the replicated reduction scratch (ptpp_common.h).
 constexpr int ROWS_PER_WAVE = 1;
 
+// dS row i of (b, h) into LDS `ds` (and to global memory when `store`): dS = P * (dP - sum_j P dP) * scale with
+// dP[j] = dctx_i . v_j (times the regenerated dropout keep-scale); `go` receives dctx_i.  Rows i >= len are all zero.
+template <typename T>
+__device__ __forceinline__ void attn_ds_row(const AttnBwdP& p, int b, int h, int i, int len, float* go, float* ds, bool store,
+                                            int lane) {
+  const int Tn = p.T, dk = p.dk, hc = h * dk;
+  const T* vb = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + hc;
+  const T* gb = reinterpret_cast<const T*>(p.dctx) + ((int64_t)b * Tn + i) * p.lddctx + hc;
+  const float* prow = p.probs + (((int64_t)b * p.H + h) * Tn + i) * Tn;
+  float* dsrow = p.dS + (((int64_t)b * p.H + h) * Tn + i) * Tn;
+  __builtin_amdgcn_wave_barrier();  // the previous row's LDS reads are done
+  for (int d = lane * 4; d < dk; d += 256) *reinterpret_cast<f32x4*>(go + d) = Elem<T>::ld4(gb + d);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  float dsum = 0.f;
+  const uint64_t drow = (((uint64_t)b * p.H + h) * Tn + i) * (uint64_t)Tn;
+  for (int j = lane; j < len; j += 64) {
+    float dp = dot_row<T>(go, vb + (int64_t)j * p.ld, dk);  // d(dropped P)
+    if (p.drop_thresh16) dp *= attn_keep(p, drow + j);        // dP = mask/(1-p) * d(dropped P)
+    ds[j] = dp;
+    dsum += prow[j] * dp;
+  }
+  dsum = wave_sum(dsum);
+  for (int j = lane; j < Tn; j += 64) {
+    const float v = j < len ? prow[j] * (ds[j] - dsum) * p.scale : 0.f;
+    ds[j] = v;
+    if (store) dsrow[j] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -176,13 +208,15 @@ __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
   const int h = blockIdx.y, b = blockIdx.z;
   const int Tn = p.T, dk = p.dk;
   const int Tpad = (Tn + 3) & ~3;
-  float* go = lds + w * (dk + Tpad);  // dctx_i
+  const bool legacy = p.variant == VAR_LEGACY;
+  const int per = dk + Tpad + (legacy ? Tpad : 0);
+  float* go = lds + w * per;  // dctx_i
   float* ds = go + dk;
-  float* red = lds + 4 * (dk + Tpad);  // [4 waves][2][dk] partial du / dvb of the block
+  float* ds2 = ds + Tpad;     // legacy: dS row i - 1 (see below)
+  float* red = lds + 4 * per;  // [4 waves][2][dk] partial du / dvb of the block
   const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
   const int hc = h * dk;
   const T* kb = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + hc;
-  const T* vb = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + hc;
   const T* pb = p.pos ? reinterpret_cast<const T*>(p.pos) + hc : nullptr;
   const int nvec = dk >> 2, parts = 64 / nvec;
   const int dv = (lane % nvec) * 4, part = lane / nvec;
@@ -192,41 +226,40 @@ __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
   for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
     const int i = (blockIdx.x * 4 + w) * ROWS_PER_WAVE + rr;
     if (i >= Tn) break;
-    const T* gb = reinterpret_cast<const T*>(p.dctx) + ((int64_t)b * Tn + i) * p.lddctx + hc;
     T* dqr = reinterpret_cast<T*>(p.dq) + ((int64_t)b * Tn + i) * p.lddq + hc;
-    const float* prow = p.probs + (((int64_t)b * p.H + h) * Tn + i) * Tn;
     float* dsrow = p.dS + (((int64_t)b * p.H + h) * Tn + i) * Tn;
+    // legacy: the pad/view shift of the reference (attention.py:142-162) reads row i's positional scores for the keys
+    // j <= i from (q_i + v) . pos[T-1-i+j], and for the keys j >= i+2 from (q_{i+1} + v) . pos[j-i-2] -- so dq_i also
+    // receives dS[i-1, j] pos[j-i-1] for j >= i+1.  Row i-1 of dS belongs to another wave: it is recomputed here
+    // (the legacy table is the demo configuration: simplicity over speed).
+    const bool prev = legacy && i >= 1 && i - 1 < len;
+    if (prev) attn_ds_row<T>(p, b, h, i - 1, len, go, ds2, false, lane);
     if (i >= len) {
-      for (int d = lane * 4; d < dk; d += 256) Elem<T>::st4(dqr + d, f32x4{0.f, 0.f, 0.f, 0.f});
       for (int j = lane; j < Tn; j += 64) dsrow[j] = 0.f;
-      continue;
-    }
-    __builtin_amdgcn_wave_barrier();  // the previous row's LDS reads are done
-    for (int d = lane * 4; d < dk; d += 256) *reinterpret_cast<f32x4*>(go + d) = Elem<T>::ld4(gb + d);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    float dsum = 0.f;
-    const uint64_t drow = (((uint64_t)b * p.H + h) * Tn + i) * (uint64_t)Tn;
-    for (int j = lane; j < len; j += 64) {
-      float dp = dot_row<T>(go, vb + (int64_t)j * p.ld, dk);  // d(dropped P)
-      if (p.drop_thresh16) dp *= attn_keep(p, drow + j);        // dP = mask/(1-p) * d(dropped P)
-      ds[j] = dp;
-      dsum += prow[j] * dp;
-    }
-    dsum = wave_sum(dsum);
-    for (int j = lane; j < Tn; j += 64) {
-      const float v = j < len ? prow[j] * (ds[j] - dsum) * p.scale : 0.f;
-      if (j < len) ds[j] = v;
-      dsrow[j] = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    f32x4 au = f32x4{0.f, 0.f, 0.f, 0.f}, av = au;
-    if (part < parts)
-      for (int j = part; j < len; j += parts) {
-        au += Elem<T>::ld4(kb + (int64_t)j * p.ld + dv) * ds[j];
-        if (p.variant == VAR_NEW) av += Elem<T>::ld4(pb + (int64_t)(Tn - 1 - i + j) * p.ldpos + dv) * ds[j];
+      for (int j = lane; j < Tn; j += 64) ds[j] = 0.f;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (!prev) {
+        for (int d = lane * 4; d < dk; d += 256) Elem<T>::st4(dqr + d, f32x4{0.f, 0.f, 0.f, 0.f});
+        continue;
       }
+    } else {
+      attn_ds_row<T>(p, b, h, i, len, go, ds, true, lane);
+    }
+    f32x4 au = f32x4{0.f, 0.f, 0.f, 0.f}, av = au;
+    if (part < parts) {
+      if (i < len)
+        for (int j = part; j < len; j += parts) {
+          au += Elem<T>::ld4(kb + (int64_t)j * p.ld + dv) * ds[j];
+          if (p.variant == VAR_NEW) av += Elem<T>::ld4(pb + (int64_t)(Tn - 1 - i + j) * p.ldpos + dv) * ds[j];
+        }
+      if (legacy) {
+        if (i < len)
+          for (int j = part; j <= i && j < len; j += parts) av += Elem<T>::ld4(pb + (int64_t)(Tn - 1 - i + j) * p.ldpos + dv) * ds[j];
+        if (prev)
+          for (int j = i + 1 + part; j < len; j += parts) av += Elem<T>::ld4(pb + (int64_t)(j - i - 1) * p.ldpos + dv) * ds2[j];
+      }
+    }
     for (int o = nvec; o < 64; o <<= 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -238,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
     su += au;
     sv += av;
   }
-  if (p.variant == VAR_NEW) {
+  if (p.variant != VAR_PLAIN) {
     if (lane < nvec) {
       *reinterpret_cast<f32x4*>(red + (w * 2 + 0) * dk + dv) = su;
       *reinterpret_cast<f32x4*>(red + (w * 2 + 1) * dk + dv) = sv;
@@ -302,7 +335,7 @@ __global__ __launch_bounds__(256) void attn_bwd_pos_kernel(const AttnBwdP p, flo
   const int m = blockIdx.x * 4 + w, h = blockIdx.y;
   const int nbg = gridDim.z, bper = (p.B + nbg - 1) / nbg;  // batch groups: more blocks than (L/4) x H
   const int b0 = blockIdx.z * bper, b1 = min(p.B, b0 + bper);
-  const int Tn = p.T, dk = p.dk, L = 2 * Tn - 1;
+  const int Tn = p.T, dk = p.dk, L = p.variant == VAR_LEGACY ? Tn : 2 * Tn - 1;
   if (m >= L) return;
   const int hc = h * dk;
   const int nvec = dk >> 2, parts = 64 / nvec;
@@ -319,6 +352,9 @@ __global__ __launch_bounds__(256) void attn_bwd_pos_kernel(const AttnBwdP p, flo
         const int j = m - (Tn - 1) + i;
         acc += (Elem<T>::ld4(qb + (int64_t)i * p.ld + dv) + bv) * dsb[(int64_t)i * Tn + j];
       }
+      if (p.variant == VAR_LEGACY)  // keys j = m + i + 2 of query row i took (q_{i+1} + v) . pos[m] (see attn_bwd_row_kernel)
+        for (int i = part; i <= Tn - 3 - m && i < len; i += parts)
+          acc += (Elem<T>::ld4(qb + (int64_t)(i + 1) * p.ld + dv) + bv) * dsb[(int64_t)i * Tn + m + i + 2];
     }
   for (int o = nvec; o < 64; o <<= 1) {
 #pragma unroll
@@ -372,8 +408,7 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
                                   size_t scratch_bytes, void* stream) {
   PTPP_CHECK_ARG(q && k && v && probs && dctx && dS && dq && dk_out && dv_out, "attention_bwd: null pointer");
   PTPP_CHECK_ARG(shape_ok(B, T_, H, dk), "attention_bwd: unsupported shape");
-  PTPP_CHECK_ARG(variant == VAR_NEW || variant == VAR_PLAIN,
-                 "attention_bwd: only the 'new' rel-pos and plain variants are trainable (legacy is inference-only)");
+  PTPP_CHECK_ARG(variant >= 0 && variant <= 2, "attention_bwd: bad variant");
   PTPP_CHECK_ARG(variant == VAR_PLAIN || (pos && bias_u && bias_v && dpos && du && dvb), "attention_bwd: rel-pos args");
   PTPP_CHECK_ARG(variant == VAR_PLAIN || red_scratch_ok(scratch, scratch_bytes, 2 * H * dk),
                  "attention_bwd: reduction scratch missing or too small");
@@ -386,23 +421,25 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((T_ + 3) / 4, H, B);
   dim3 grid_row((T_ + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), H, B);
-  const size_t smem = (size_t)(4 * (dk + ((T_ + 3) & ~3)) + 8 * dk) * sizeof(float);
-  // dpos: batch groups so that (L/4) x H x groups >= ~1024 blocks; groups > 1 accumulate with atomics
-  // into the buffer zeroed here
-  const int lblk = (2 * T_ - 1 + 3) / 4 * H;
+  const int Tpad = (T_ + 3) & ~3;
+  const size_t smem = (size_t)(4 * (dk + Tpad + (variant == VAR_LEGACY ? Tpad : 0)) + 8 * dk) * sizeof(float);
+  // dpos ((2T-1) rows, legacy: T rows): batch groups so that (L/4) x H x groups >= ~1024 blocks; groups > 1 accumulate
+  // with atomics into the buffer zeroed here
+  const int L = variant == VAR_LEGACY ? T_ : 2 * T_ - 1;
+  const int lblk = (L + 3) / 4 * H;
   int nbg = (1024 + lblk - 1) / lblk;
   if (nbg > B) nbg = B;
-  if (variant == VAR_NEW && nbg > 1) (void)hipMemsetAsync(dpos, 0, (size_t)(2 * T_ - 1) * H * dk * sizeof(float), st);
+  if (variant != VAR_PLAIN && nbg > 1) (void)hipMemsetAsync(dpos, 0, (size_t)L * H * dk * sizeof(float), st);
 #define ATTN_BWD(TT)                                                                                  \
   hipLaunchKernelGGL(attn_bwd_row_kernel<TT>, grid_row, dim3(256), smem, st, p);                      \
   hipLaunchKernelGGL(attn_bwd_col_kernel<TT>, grid, dim3(256), 0, st, p, dk_out, dv_out);             \
-  if (variant == VAR_NEW)                                                                             \
-    hipLaunchKernelGGL(attn_bwd_pos_kernel<TT>, dim3((2 * T_ - 1 + 3) / 4, H, nbg), dim3(256), 0, st, p, dpos);
+  if (variant != VAR_PLAIN)                                                                           \
+    hipLaunchKernelGGL(attn_bwd_pos_kernel<TT>, dim3((L + 3) / 4, H, nbg), dim3(256), 0, st, p, dpos);
   if (dtype == PTPP_F32) { ATTN_BWD(float) }
   else if (dtype == PTPP_BF16) { ATTN_BWD(bf16_raw) }
   else PTPP_CHECK_ARG(false, "attention_bwd: bad dtype");
 #undef ATTN_BWD
-  if (variant == VAR_NEW) red_sum_launch(scratch, 2 * H * dk, du, H * dk, dvb, 1, st);
+  if (variant != VAR_PLAIN) red_sum_launch(scratch, 2 * H * dk, du, H * dk, dvb, 1, st);
   PTPP_CHECK_LAUNCH("attention_bwd");
   return PTPP_OK;
 }

@@ -65,25 +65,25 @@ __device__ __forceinline__ bool tile_epilogue_ok(const ConvP& p) {
   const bool al16 = ((uintptr_t)p.y & 15) == 0 && (!p.res || ((uintptr_t)p.res & 15) == 0);
   return FN % 2 == 0 && (p.Cout & 7) == 0 && (p.ldy & 7) == 0 && al16 && (!p.res || (p.ldr & 7) == 0) && !p.res2;
 }
-template <int FM, int FN, int WR, int WC, int ACT>
-__device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][FN], uint4 (&resv)[WR * FM * WC * FN * 32 / (WR * WC * 64)],
-                                              uint4* O, int b, int t0, int n0, int wm, int wn, int tid, int len) {
-  typedef bf16_raw T;
-  constexpr int NT = WR * WC * 64, BM = WR * FM * 16, BN = WC * FN * 16;
-  constexpr int QPR = BN / 8;  // 16-byte slots per tile row
-  constexpr int NRV = BM * QPR / NT;
-  static_assert(QPR >= 16, "tile rows of at least 256 bytes");
-  const int lane = tid & 63, lr = lane & 15, lg = lane >> 4;
-  const bool has_res = p.res != nullptr;
-  if (has_res) {
+// phase 1: this thread's residual vectors -> image (threads tid < NT of the tile's compute waves)
+template <int BM, int BN, int NT, int NRV>
+__device__ __forceinline__ void tile_epi_put_res(const uint4 (&resv)[NRV], uint4* O, int tid) {
+  constexpr int QPR = BN / 8;
+  static_assert(NRV == BM * QPR / NT, "residual vectors per thread");
 #pragma unroll
-    for (int i = 0; i < NRV; ++i) {
-      const int idx = tid + i * NT;
-      const int row = idx / QPR, q = idx % QPR;
-      O[row * QPR + (q ^ (row & 15))] = resv[i];
-    }
-    __syncthreads();
+  for (int i = 0; i < NRV; ++i) {
+    const int idx = tid + i * NT;
+    const int row = idx / QPR, q = idx % QPR;
+    O[row * QPR + (q ^ (row & 15))] = resv[i];
   }
+}
+
+// phase 2: every lane folds its accumulators into its own 16-byte slots of the image (same arithmetic and rounding as
+// conv_epilogue)
+template <int FM, int FN, int ACT>
+__device__ __forceinline__ void tile_epi_update(const ConvP& p, f32x4 (&acc)[FM][FN], uint4* O, int QPR, bool has_res, int b, int t0,
+                                                int n0, int wm, int wn, int lane, int len) {
+  const int lr = lane & 15, lg = lane >> 4;
   const float e_scale = p.out_scale, e_rscale = p.res_scale, e_dinv = p.drop_inv_keep;
   const unsigned e_dth = p.drop_thresh16;
 #pragma unroll
@@ -131,20 +131,48 @@ __device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
       }
     }
   }
-  __syncthreads();
+}
+
+// phase 3: the image leaves row-contiguous; NV vectors per thread of the NT threads that store
+template <int BM, int BN, int NT, int NV>
+__device__ __forceinline__ void tile_epi_store(const ConvP& p, const uint4* O, int b, int t0, int n0, int tid, bool gate, int i0 = 0) {
+  typedef bf16_raw T;
+  constexpr int QPR = BN / 8;
   T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * p.T * p.ldy;
+  uint4 v[NV];
 #pragma unroll
-  for (int i = 0; i < NRV; ++i) {
-    const int idx = tid + i * NT;
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + (i0 + i) * NT;
+    const int row = idx / QPR, q = idx % QPR;
+    v[i] = O[row * QPR + (q ^ (row & 15))];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + (i0 + i) * NT;
     const int row = idx / QPR, q = idx % QPR;
     const int t = t0 + row, co = n0 + q * 8;
     if (t < p.T && co < p.Cout) {
-      if constexpr (ACT == PTPP_ACT_GATE)
-        *reinterpret_cast<uint2*>(yb + (int64_t)t * p.ldy + (co >> 1)) = *reinterpret_cast<const uint2*>(O + row * QPR + (q ^ (row & 15)));
-      else
-        *reinterpret_cast<uint4*>(yb + (int64_t)t * p.ldy + co) = O[row * QPR + (q ^ (row & 15))];
+      if (gate) *reinterpret_cast<uint2*>(yb + (int64_t)t * p.ldy + (co >> 1)) = make_uint2(v[i].x, v[i].y);
+      else *reinterpret_cast<uint4*>(yb + (int64_t)t * p.ldy + co) = v[i];
     }
   }
+}
+
+template <int FM, int FN, int WR, int WC, int ACT>
+__device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][FN], uint4 (&resv)[WR * FM * WC * FN * 32 / (WR * WC * 64)],
+                                              uint4* O, int b, int t0, int n0, int wm, int wn, int tid, int len) {
+  constexpr int NT = WR * WC * 64, BM = WR * FM * 16, BN = WC * FN * 16;
+  constexpr int QPR = BN / 8;  // 16-byte slots per tile row
+  constexpr int NRV = BM * QPR / NT;
+  static_assert(QPR >= 16, "tile rows of at least 256 bytes");
+  const bool has_res = p.res != nullptr;
+  if (has_res) {
+    tile_epi_put_res<BM, BN, NT, NRV>(resv, O, tid);
+    __syncthreads();
+  }
+  tile_epi_update<FM, FN, ACT>(p, acc, O, QPR, has_res, b, t0, n0, wm, wn, tid & 63, len);
+  __syncthreads();
+  tile_epi_store<BM, BN, NT, NRV>(p, O, b, t0, n0, tid, ACT == PTPP_ACT_GATE);
 }
 
 // The DiffNet layer's tail fused into its 1 x 1 output projection (modules/denoiser.py:78-83; what diffnet_post_kernel

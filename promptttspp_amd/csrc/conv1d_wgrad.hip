@@ -155,3 +155,44 @@ extern "C" int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float
   PTPP_CHECK_LAUNCH("conv1d_wgrad");
   return PTPP_OK;
 }
+
+int ptpp_wgrad_bf16_batched_tiles(int Cin, int Cout, int ks, int max_dil);
+int ptpp_wgrad_bf16_launch_batched(const ptpp_wgrad_problem* probs, int nprob, const int32_t* lengths, int B, int T, int Cin,
+                                   int Cout, int ks, int ldx, int lddy, int in_mask, hipStream_t st);
+
+extern "C" int ptpp_conv1d_wgrad_batched(const ptpp_wgrad_problem* probs, int nprob, const int32_t* lengths, int B, int T, int Cin,
+                                         int Cout, int ks, int ldx, int lddy, int in_mask, int dtype, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  PTPP_CHECK_ARG(probs && nprob > 0, "conv1d_wgrad_batched: no problems");
+  PTPP_CHECK_ARG(B > 0 && T > 0 && Cin > 0 && Cout > 0 && ks > 0, "conv1d_wgrad_batched: bad shape");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "conv1d_wgrad_batched: bad dtype %d", dtype);
+  PTPP_CHECK_ARG(!in_mask || lengths, "conv1d_wgrad_batched: in_mask needs lengths");
+  bool fast = dtype == PTPP_BF16 && ldx % 8 == 0 && lddy % 8 == 0 && Cin % 8 == 0 && Cout % 8 == 0;
+  int max_dil = 1;
+  for (int i = 0; i < nprob; ++i) {
+    PTPP_CHECK_ARG(probs[i].x && probs[i].dy && probs[i].dw && probs[i].dil > 0, "conv1d_wgrad_batched: bad problem %d", i);
+    fast = fast && ((uintptr_t)probs[i].x % 16) == 0 && ((uintptr_t)probs[i].dy % 16) == 0;
+    if (probs[i].dil > max_dil) max_dil = probs[i].dil;
+  }
+  static const char* off = getenv("PTPP_WGRAD_NO_BATCH");
+  const int tiles = fast && !(off && off[0] == '1') ? ptpp_wgrad_bf16_batched_tiles(Cin, Cout, ks, max_dil) : 0;
+  // one owner block per tile walks ALL rows: worth it only when the tiles of the batch occupy most of the 256 CUs
+  if (tiles > 0 && (long long)tiles * nprob >= 128) {
+    int Bf = B, Tf = T;
+    if (ks == 1 && !in_mask && B > 1) { Tf = B * T; Bf = 1; }  // (as ptpp_conv1d_wgrad: one flat row sequence)
+    constexpr int MAXP = 24;
+    for (int i0 = 0; i0 < nprob; i0 += MAXP) {
+      const int n = nprob - i0 < MAXP ? nprob - i0 : MAXP;
+      const int rc = ptpp_wgrad_bf16_launch_batched(probs + i0, n, lengths, Bf, Tf, Cin, Cout, ks, ldx, lddy, in_mask,
+                                                    reinterpret_cast<hipStream_t>(stream));
+      if (rc != PTPP_OK) return rc;
+    }
+    return PTPP_OK;
+  }
+  for (int i = 0; i < nprob; ++i) {
+    const int rc = ptpp_conv1d_wgrad(probs[i].x, probs[i].dy, probs[i].dw, probs[i].dbias, lengths, B, T, Cin, Cout, ks, probs[i].dil,
+                                     probs[i].pad, ldx, lddy, in_mask, dtype, workspace, workspace_bytes, stream);
+    if (rc != PTPP_OK) return rc;
+  }
+  return PTPP_OK;
+}

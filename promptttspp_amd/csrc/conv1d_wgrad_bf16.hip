@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "ptpp_common.h"
+#include "../../include/ptpp.h"
 
 namespace {
 
@@ -35,7 +36,7 @@ typedef __attribute__((ext_vector_type(4))) short v4s;
 typedef __attribute__((ext_vector_type(8))) short v8s;
 
 constexpr int KR = 32;  // rows per K chunk (one MFMA K-step)
-constexpr int NS = 4;   // LDS ring stages (NS - 1 chunks in flight)
+constexpr int NS_DEFAULT = 4;  // LDS ring stages of the split-K kernels (NS - 1 chunks in flight)
 
 __device__ uint4 g_zero_page[64];  // source of out-of-range rows
 
@@ -106,6 +107,22 @@ struct WgP {
   float* ws;  // [nsplit][ks][Cout][Cin] partials, or nullptr -> atomics into dw
 };
 
+// Batched form (ptpp_conv1d_wgrad_batched): up to WG_MAXP problems of ONE shape (the layers of a stack: B, T, Cin, Cout, ks,
+// row strides shared; operands, dilation and targets per problem) in one launch.  With the tiles of all problems the grid
+// fills the machine WITHOUT splitting the rows over blocks: every dw element has exactly one owner block, which walks all
+// rows in a fixed order and adds its total straight into dw -- no partials, no second pass, bit-reproducible.
+constexpr int WG_MAXP = 24;
+struct WgProb {
+  const bf16_raw* x;
+  const bf16_raw* dy;
+  float* dw;
+  float* dbias;
+  int dil, pad;
+};
+struct WgBatch {
+  WgProb pr[WG_MAXP];
+};
+
 typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
 
@@ -115,8 +132,23 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // XH: extra x rows of a tap group's window, (TG - 1) * dil <= XH
+template <int FM, int FN, int WR, int WC, int TG, int XH, bool BATCH, int NS>
+__device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__ lengths, const WgBatch* __restrict__ batch);
+
 template <int FM, int FN, int WR = 2, int WC = 2, int TG = 1, int XH = 0>
 __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const WgP p, const int* __restrict__ lengths) {
+  wgrad_body<FM, FN, WR, WC, TG, XH, false, NS_DEFAULT>(p, lengths, nullptr);
+}
+// NS: a one-owner block walks ALL rows alone on its CU (the grid is <= 1 block per CU), so the ring is as deep as LDS allows:
+// Little's law at ~1-2 us of loaded memory latency wants ~100 KB in flight per CU, the 4-stage ring holds 48-72 KB
+template <int FM, int FN, int WR = 2, int WC = 2, int TG = 1, int XH = 0, int NS = NS_DEFAULT>
+__global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_batched_kernel(const WgP p, const int* __restrict__ lengths,
+                                                                                 const WgBatch batch) {
+  wgrad_body<FM, FN, WR, WC, TG, XH, true, NS>(p, lengths, &batch);
+}
+
+template <int FM, int FN, int WR, int WC, int TG, int XH, bool BATCH, int NS>
+__device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__ lengths, const WgBatch* __restrict__ batch) {
   constexpr int NW = WR * WC;  // waves per block, WR x WC over (co, ci)
   constexpr int TM = WR * FM * 16, TN = WC * FN * 16;
   constexpr int XR = KR + XH;                       // x rows per stage
@@ -136,9 +168,20 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
   const int cit = bid % p.nCI; bid /= p.nCI;
   const int ntg = (p.ks + TG - 1) / TG;
   const int j = (bid % ntg) * TG; bid /= ntg;  // first tap of this block's group
-  const int split = bid;
+  int split = bid;
+  const bf16_raw* px = p.x;
+  const bf16_raw* pdy = p.dy;
+  float* pdw = p.dw;
+  float* pdb = p.dbias;
+  int pdil = p.dil, ppad = p.pad;
+  if constexpr (BATCH) {  // block-uniform problem index: the operands come from the table (scalar loads)
+    const int pi = __builtin_amdgcn_readfirstlane(bid / p.nsplit);
+    split = bid - pi * p.nsplit;
+    px = batch->pr[pi].x; pdy = batch->pr[pi].dy; pdw = batch->pr[pi].dw; pdb = batch->pr[pi].dbias;
+    pdil = batch->pr[pi].dil; ppad = batch->pr[pi].pad;
+  }
   const int co0 = cot * TM, ci0 = cit * TN;
-  const int shift = j * p.dil - p.pad;
+  const int shift = j * pdil - ppad;
   const int ntap = min(TG, p.ks - j);  // taps of the group (block-uniform)
 
   f32x4 acc[TG][FM][FN], accb[FM];
@@ -150,7 +193,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
 #pragma unroll
       for (int c = 0; c < FN; ++c) acc[g][a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bool do_bias = p.dbias && cit == 0 && j == 0 && wc == 0;  // wave-uniform
+  const bool do_bias = pdb && cit == 0 && j == 0 && wc == 0;  // wave-uniform
   const int total = p.B * p.tchunks;
   const int n = split < total ? (total - split + p.nsplit - 1) / p.nsplit : 0;  // chunks of this block
   const char* zero = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
@@ -175,8 +218,8 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
     const int b = ch / p.tchunks, tb = (ch - b * p.tchunks) * KR;
     const int Tin = lengths ? min(lengths[b], p.T) : p.T;
     bf16_raw* st = S + (i % NS) * STAGE;
-    const bf16_raw* dyb = p.dy + (int64_t)b * p.T * p.lddy + co0;
-    const bf16_raw* xb = p.x + (int64_t)b * p.T * p.ldx + ci0;
+    const bf16_raw* dyb = pdy + (int64_t)b * p.T * p.lddy + co0;
+    const bf16_raw* xb = px + (int64_t)b * p.T * p.ldx + ci0;
 #pragma unroll
     for (int q = 0; q < LY; ++q) {
       const int t = tb + yrow[q];
@@ -201,9 +244,16 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
   for (int i = 0; i < n; ++i) {
     // chunk i has landed once at most the loads of the (up to NS - 2) younger chunks are outstanding
     const int younger = min(n - 1 - i, NS - 2);
-    if (younger == 2) wait_vm<2 * LPW>();
-    else if (younger == 1) wait_vm<LPW>();
-    else wait_vm<0>();
+    static_assert((NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
+    if (younger == NS - 2) wait_vm<(NS - 2) * LPW>();  // steady state
+    else if constexpr (NS > 3) {                        // drain at the end of the block's rows
+      if (younger >= 2) wait_vm<2 * LPW>();             // (waits for more than necessary for 2 < younger < NS - 2: tail only)
+      else if (younger == 1) wait_vm<LPW>();
+      else wait_vm<0>();
+    } else {
+      if (younger == 1) wait_vm<LPW>();
+      else wait_vm<0>();
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's pieces of chunk i visible; everyone done reading chunk i - 1
     if (i + NS - 1 < n) issue(i + NS - 1);  // into the stage chunk i - 1 just vacated
@@ -221,7 +271,7 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
       if (g < ntap) {
         Frag fb[FN];
 #pragma unroll
-        for (int c = 0; c < FN; ++c) fb[c] = frag<TN>(Xb, g * p.dil, (wc * FN + c) * 16, lane);
+        for (int c = 0; c < FN; ++c) fb[c] = frag<TN>(Xb, g * pdil, (wc * FN + c) * 16, lane);
         lds_fence(fb);
         bf16x8_t bfr[FN];
 #pragma unroll
@@ -253,8 +303,9 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
         for (int r = 0; r < 4; ++r) {
           const int co = co0 + (wr * FM + a) * 16 + lg * 4 + r;
           if (co < p.Cout && ci < p.Cin) {
-            if (p.ws) p.ws[(((int64_t)split * p.ks + j + g) * p.Cout + co) * p.Cin + ci] = acc[g][a][c][r];
-            else atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * p.ks + j + g, acc[g][a][c][r]);
+            if (BATCH && p.nsplit == 1) pdw[((int64_t)co * p.Cin + ci) * p.ks + j + g] += acc[g][a][c][r];  // the only owner
+            else if (p.ws) p.ws[(((int64_t)split * p.ks + j + g) * p.Cout + co) * p.Cin + ci] = acc[g][a][c][r];
+            else atomicAdd(pdw + ((int64_t)co * p.Cin + ci) * p.ks + j + g, acc[g][a][c][r]);
           }
         }
       }
@@ -265,17 +316,33 @@ __global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const W
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + (wr * FM + a) * 16 + lg * 4 + r;
-        if (co < p.Cout) atomicAdd(p.dbias + co, accb[a][r]);
+        if (co < p.Cout) {
+          if (BATCH && p.nsplit == 1) pdb[co] += accb[a][r];  // one block per (problem, co tile) reaches here
+          else if (p.ws) p.ws[(int64_t)p.nsplit * p.ks * p.Cout * p.Cin + (int64_t)split * p.Cout + co] = accb[a][r];
+          else atomicAdd(pdb + co, accb[a][r]);
+        }
       }
   }
 }
 
-// dw[co][ci][j] += sum_s ws[s][j][co][ci]  (fixed summation order: deterministic)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
-                                                           int Cout, int Cin, int ks) {
+// dw[co][ci][j] += sum_s ws[s][j][co][ci]  (fixed summation order: deterministic); the bias partials [nsplit][Cout] follow
+// the weight partials in the workspace and are summed by the blocks past the weight range (round 2 added them with f32
+// atomics from every split block: the last bits of the bias gradients depended on the arrival order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           float* __restrict__ dbias, int nsplit, int Cout, int Cin, int ks) {
   const int64_t E = (int64_t)ks * Cout * Cin;
   const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (e >= E) return;
+  if (e >= E) {
+    const int64_t co = e - E;
+    if (dbias && co < Cout) {
+      const float* b = ws + (int64_t)nsplit * E + co;
+      f32x4 s = *reinterpret_cast<const f32x4*>(b);
+      for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(b + (int64_t)k * Cout);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dbias[co + k] += s[k];  // (a gradient view may start at any float offset of the flat buffer)
+    }
+    return;
+  }
   f32x4 s = *reinterpret_cast<const f32x4*>(ws + e);
   for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)k * E + e);
   const int j = (int)(e / ((int64_t)Cout * Cin));
@@ -294,9 +361,9 @@ int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
   p.tchunks = (p.T + KR - 1) / KR;
   const int total = p.B * p.tchunks;
   const int tiles = p.nCO * p.nCI * ((p.ks + TG - 1) / TG);
-  const size_t ebytes = (size_t)p.ks * p.Cout * p.Cin * sizeof(float);
+  const size_t ebytes = ((size_t)p.ks * p.Cout * p.Cin + p.Cout) * sizeof(float);  // weight + bias partials of one split
   int nsplit;
-  if (p.ws && ws_bytes >= ebytes) {
+  if (p.ws && ws_bytes >= ebytes && p.Cout % 4 == 0) {
     nsplit = ((TG > 1 ? 256 : 384) + tiles - 1) / tiles;  // 1-2 resident blocks per CU (measured optimum 256..512 blocks;
                                                            // a tap-group block fills a CU on its own)
     if (nsplit > 48) nsplit = 48;        // few output tiles: more splits only add partial traffic
@@ -311,7 +378,7 @@ int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
   }
   if (nsplit < 1) nsplit = 1;
   p.nsplit = nsplit;
-  const size_t smem = (size_t)NS * (KR * TM + XR * TN) * sizeof(bf16_raw);
+  const size_t smem = (size_t)NS_DEFAULT * (KR * TM + XR * TN) * sizeof(bf16_raw);
   auto kern = conv1d_wgrad_bf16_kernel<FM, FN, WR, WC, TG, XH>;
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -319,15 +386,70 @@ int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
                      p.in_mask ? p.lengths : nullptr);
   PTPP_CHECK_LAUNCH("conv1d_wgrad(bf16)");
   if (p.ws) {
-    const int64_t n4 = (int64_t)p.ks * p.Cout * p.Cin / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.ws, p.dw, nsplit, p.Cout,
-                       p.Cin, p.ks);
+    const int64_t n4 = ((int64_t)p.ks * p.Cout * p.Cin + (p.dbias ? p.Cout : 0)) / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.ws, p.dw, p.dbias, nsplit,
+                       p.Cout, p.Cin, p.ks);
     PTPP_CHECK_LAUNCH("conv1d_wgrad(reduce)");
   }
   return PTPP_OK;
 }
 
+template <int FM, int FN, int WR = 2, int WC = 2, int TG = 1, int XH = 0, int NS = NS_DEFAULT>
+int launch_batched(WgP& p, const WgBatch& batch, int nprob, hipStream_t st) {
+  constexpr int TM = WR * FM * 16, TN = WC * FN * 16;
+  constexpr int XR = KR + XH;
+  p.nCO = (p.Cout + TM - 1) / TM;
+  p.nCI = (p.Cin + TN - 1) / TN;
+  p.tchunks = (p.T + KR - 1) / KR;
+  p.nsplit = 1;
+  p.ws = nullptr;
+  const int tiles = p.nCO * p.nCI * ((p.ks + TG - 1) / TG);
+  const size_t smem = (size_t)NS * (KR * TM + XR * TN) * sizeof(bf16_raw);
+  static_assert((size_t)NS * (KR * TM + XR * TN) * sizeof(bf16_raw) <= 160 * 1024, "ring must fit LDS");
+  auto kern = conv1d_wgrad_bf16_batched_kernel<FM, FN, WR, WC, TG, XH, NS>;
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)tiles * nprob)), dim3(WR * WC * 64), smem, st, p,
+                     p.in_mask ? p.lengths : nullptr, batch);
+  PTPP_CHECK_LAUNCH("conv1d_wgrad_batched(bf16)");
+  return PTPP_OK;
+}
+
 }  // namespace
+
+// Tiles per problem of the batched launch (0: shape not served by the batched kernels) -- the caller batches only when
+// nprob * tiles fills the machine without a row split.
+int ptpp_wgrad_bf16_batched_tiles(int Cin, int Cout, int ks, int max_dil) {
+  if (Cout <= 64 || Cin <= 64) return 0;
+  if (ks > 1 && 2 * max_dil <= 32) return ((Cout + 127) / 128) * ((Cin + 127) / 128) * ((ks + 2) / 3);
+  return ((Cout + 127) / 128) * ((Cin + 127) / 128) * ks;
+}
+
+// called by ptpp_conv1d_wgrad_batched for bf16 tensors with 16-byte aligned rows; nprob <= WG_MAXP
+int ptpp_wgrad_bf16_launch_batched(const ptpp_wgrad_problem* probs, int nprob, const int32_t* lengths, int B, int T, int Cin,
+                                   int Cout, int ks, int ldx, int lddy, int in_mask, hipStream_t st) {
+  WgP p;
+  p.x = nullptr; p.dy = nullptr; p.dw = nullptr; p.dbias = nullptr; p.lengths = lengths;
+  p.B = B; p.T = T; p.Cin = Cin; p.Cout = Cout; p.ks = ks; p.dil = 1; p.pad = 0; p.ldx = ldx; p.lddy = lddy;
+  p.in_mask = in_mask;
+  WgBatch batch;
+  int max_dil = 1;
+  for (int i = 0; i < nprob; ++i) {
+    batch.pr[i].x = (const bf16_raw*)probs[i].x; batch.pr[i].dy = (const bf16_raw*)probs[i].dy;
+    batch.pr[i].dw = probs[i].dw; batch.pr[i].dbias = probs[i].dbias;
+    batch.pr[i].dil = probs[i].dil; batch.pr[i].pad = probs[i].pad;
+    if (probs[i].dil > max_dil) max_dil = probs[i].dil;
+  }
+  // (deeper rings for these one-block-per-CU launches -- 6 x 24 KB / 9 x 16 KB instead of 4 stages -- measured equal:
+  //  959 vs 1008 us for the 20 k = 3 layers, 1025 vs 1027 us for k = 1, profiles/r03_wgrad_batched.txt; PTPP_WGRAD_DEEP=1)
+  static const char* deep = getenv("PTPP_WGRAD_DEEP");
+  if (deep && deep[0] == '1') {
+    if (ks > 1 && 2 * max_dil <= 32) return launch_batched<4, 2, 2, 4, 3, 32, 6>(p, batch, nprob, st);
+    return launch_batched<4, 4, 2, 2, 1, 0, 9>(p, batch, nprob, st);
+  }
+  if (ks > 1 && 2 * max_dil <= 32) return launch_batched<4, 2, 2, 4, 3, 32>(p, batch, nprob, st);
+  return launch_batched<4, 4>(p, batch, nprob, st);
+}
 
 // called by ptpp_conv1d_wgrad for bf16 tensors with 16-byte aligned rows
 int ptpp_wgrad_bf16_launch(const void* x, const void* dy, float* dw, float* dbias, const int32_t* lengths, int B, int T,

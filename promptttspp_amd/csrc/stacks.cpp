@@ -1,0 +1,313 @@
+// Whole-unit drivers of the C ABI (include/ptpp.h "Whole-unit drivers"): one call issues every launch of a unit.
+// Host code only: each driver is a sequence of the library's own entry points, in the order the per-launch path
+// (promptttspp_amd/functional.py) issues them, so the results are bit-identical to it.
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/ptpp.h"
+
+void ptpp_set_error(const char* fmt, ...);
+
+#define ST_CHECK_ARG(cond, ...)      \
+  do {                               \
+    if (!(cond)) {                   \
+      ptpp_set_error(__VA_ARGS__);   \
+      return PTPP_EINVAL;            \
+    }                                \
+  } while (0)
+#define ST_TRY(call)                 \
+  do {                               \
+    const int rc_ = (call);          \
+    if (rc_ != PTPP_OK) return rc_;  \
+  } while (0)
+
+namespace {
+
+inline size_t esize(int dtype) { return dtype == PTPP_BF16 ? 2 : 4; }
+inline char* at(void* base, size_t elems, int dtype) { return static_cast<char*>(base) + elems * esize(dtype); }
+inline const char* at(const void* base, size_t elems, int dtype) { return static_cast<const char*>(base) + elems * esize(dtype); }
+
+ptpp_conv1d_args conv_args(const void* x, int ldx, const void* wp, const float* bias, const void* res, int ldr, void* y, int ldy,
+                           const int32_t* lengths, int B, int T, int cin, int cout, int ks, int dil, int pad, int act, int in_mask,
+                           int out_mask, int dtype) {
+  ptpp_conv1d_args c;
+  memset(&c, 0, sizeof(c));
+  c.x = x; c.wp = wp; c.bias = bias; c.res = res; c.y = y; c.lengths = lengths;
+  c.B = B; c.T = T; c.Cin = cin; c.Cout = cout; c.ks = ks; c.dil = dil; c.pad = pad;
+  c.ldx = ldx; c.ldy = ldy; c.ldr = ldr;
+  c.act = act; c.in_mask = in_mask; c.out_mask = out_mask; c.out_scale = 1.0f; c.dtype = dtype;
+  return c;
+}
+
+}  // namespace
+
+extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream) {
+  ST_CHECK_ARG(a && a->h0 && a->cond_all && a->dsteps && a->skip && a->dil_wp && a->dil_b && a->out_wp && a->out_b && a->yin_all &&
+                   a->g_all && a->x_buf[0] && a->x_buf[1],
+               "diffnet_stack_fwd: null pointer");
+  ST_CHECK_ARG(a->B > 0 && a->T > 0 && a->C > 0 && a->L > 0 && a->cycle > 0 && a->n_slabs >= 2, "diffnet_stack_fwd: bad shape");
+  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "diffnet_stack_fwd: bad dtype %d", a->dtype);
+  ST_CHECK_ARG(a->fused_gate || a->a_all, "diffnet_stack_fwd: a_all is needed without the fused gate");
+  ST_CHECK_ARG(!a->fused_gate || (a->dtype == PTPP_BF16 && !a->lengths), "diffnet_stack_fwd: the fused gate is the bf16 inference path");
+  const int B = a->B, T = a->T, C = a->C, L = a->L, dt = a->dtype;
+  const size_t BTC = (size_t)B * T * C;
+  const int ldc = L * 2 * C;
+  const bool fuse_post = ptpp_conv1d_diffnet_post_supported(C, C, dt) != 0;
+  ST_CHECK_ARG(fuse_post || a->o_buf, "diffnet_stack_fwd: o_buf is needed where the fused tail is unsupported");
+  const int masked = a->lengths != nullptr;
+
+  // yin_0 = h0 + dsteps[0]  (x = h0 itself)
+  ST_TRY(ptpp_diffnet_post_fwd(nullptr, a->h0, nullptr, a->dsteps, nullptr, at(a->yin_all, 0, dt), B, T, C, 1, dt, stream));
+  const void* x = a->h0;
+  for (int l = 0; l < L; ++l) {
+    const int d = 1 << (l % a->cycle);
+    const int slab = l % a->n_slabs;
+    const void* yin = at(a->yin_all, slab * BTC, dt);
+    void* g = at(a->g_all, slab * BTC, dt);
+    const void* cond = at(a->cond_all, (size_t)l * 2 * C, dt);
+    if (a->fused_gate) {
+      ptpp_conv1d_args c = conv_args(yin, C, a->dil_wp[l], a->dil_b[l], cond, ldc, g, C, nullptr, B, T, C, 2 * C, 3, d, d,
+                                     PTPP_ACT_GATE, 0, 0, dt);
+      ST_TRY(ptpp_conv1d_fwd(&c, stream));
+    } else {
+      void* act = at(a->a_all, slab * 2 * BTC, dt);
+      ptpp_conv1d_args c = conv_args(yin, C, a->dil_wp[l], a->dil_b[l], cond, ldc, act, 2 * C, nullptr, B, T, C, 2 * C, 3, d, d,
+                                     PTPP_ACT_NONE, 0, 0, dt);
+      ST_TRY(ptpp_conv1d_fwd(&c, stream));
+      ST_TRY(ptpp_gate_fwd(act, g, (int64_t)B * T, C, dt, stream));
+    }
+    const float* dnext = l + 1 < L ? a->dsteps + (size_t)(l + 1) * B * C : nullptr;
+    void* xn = a->x_buf[l & 1];
+    void* yin_next = dnext ? at(a->yin_all, ((l + 1) % a->n_slabs) * BTC, dt) : nullptr;
+    if (fuse_post) {
+      ptpp_conv1d_args c = conv_args(g, C, a->out_wp[l], a->out_b[l], nullptr, 0, nullptr, C, a->lengths, B, T, C, 2 * C, 1, 1, 0,
+                                     PTPP_ACT_NONE, 0, masked, dt);
+      ST_TRY(ptpp_conv1d_diffnet_post(&c, x, a->skip, dnext, xn, yin_next, l == 0, stream));
+    } else {
+      ptpp_conv1d_args c = conv_args(g, C, a->out_wp[l], a->out_b[l], nullptr, 0, a->o_buf, 2 * C, a->lengths, B, T, C, 2 * C, 1, 1, 0,
+                                     PTPP_ACT_NONE, 0, masked, dt);
+      ST_TRY(ptpp_conv1d_fwd(&c, stream));
+      ST_TRY(ptpp_diffnet_post_fwd(a->o_buf, x, a->skip, dnext, xn, yin_next, B, T, C, l == 0, dt, stream));
+    }
+    x = xn;
+  }
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void* stream) {
+  ST_CHECK_ARG(a && a->gS && a->yin_all && a->a_all && a->g_all && a->dil_wpt && a->out_wpt && a->dw_dil && a->db_dil && a->dw_out &&
+                   a->db_out && a->gx_all && a->do_all && a->dcond_all && a->S,
+               "diffnet_stack_bwd: null pointer");
+  ST_CHECK_ARG(a->B > 0 && a->T > 0 && a->C > 0 && a->L > 0 && a->cycle > 0, "diffnet_stack_bwd: bad shape");
+  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "diffnet_stack_bwd: bad dtype %d", a->dtype);
+  const int B = a->B, T = a->T, C = a->C, L = a->L, dt = a->dtype;
+  const size_t BTC = (size_t)B * T * C;
+  const int ldc = L * 2 * C;
+  const bool fuse_gbwd = ptpp_conv1d_gate_bwd_supported(C, 2 * C, dt) != 0;
+  ST_CHECK_ARG(fuse_gbwd || a->dg_buf, "diffnet_stack_bwd: dg_buf is needed where the fused gate backward is unsupported");
+  void* wstream = a->side_stream ? a->side_stream : stream;
+  void* ws_w = a->side_stream ? a->ws_side : a->ws_main;
+  const size_t ws_w_bytes = a->side_stream ? a->ws_side_bytes : a->ws_main_bytes;
+  const float r2 = (float)(1.0 / sqrt(2.0));
+
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(at(a->gx_all, (size_t)L * BTC, dt), 0, BTC * esize(dt), st) != hipSuccess) {
+    ptpp_set_error("diffnet_stack_bwd: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+    return PTPP_ELAUNCH;
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const int d = 1 << (l % a->cycle);
+    const void* gx = at(a->gx_all, (size_t)(l + 1) * BTC, dt);
+    void* dout = at(a->do_all, (size_t)l * 2 * BTC, dt);
+    const void* yin = at(a->yin_all, (size_t)l * BTC, dt);
+    const void* act = at(a->a_all, (size_t)l * 2 * BTC, dt);
+    const void* g = at(a->g_all, (size_t)l * BTC, dt);
+    void* da = at(a->dcond_all, (size_t)l * 2 * C, dt);
+    ST_TRY(ptpp_diffnet_post_bwd(gx, a->gS, dout, a->lengths, B, T, C, dt, stream));
+    if (!a->batched_wgrad) {
+      if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
+      ST_TRY(ptpp_conv1d_wgrad(g, dout, a->dw_out[l], a->db_out[l], nullptr, B, T, C, 2 * C, 1, 1, 0, C, 2 * C, 0, dt, ws_w, ws_w_bytes,
+                               wstream));
+    }
+    if (fuse_gbwd) {
+      ptpp_conv1d_args c = conv_args(dout, 2 * C, a->out_wpt[l], nullptr, nullptr, 0, nullptr, 0, nullptr, B, T, 2 * C, C, 1, 1, 0,
+                                     PTPP_ACT_NONE, 0, 0, dt);
+      ST_TRY(ptpp_conv1d_gate_bwd(&c, act, da, ldc, stream));
+    } else {
+      ptpp_conv1d_args c = conv_args(dout, 2 * C, a->out_wpt[l], nullptr, nullptr, 0, a->dg_buf, C, nullptr, B, T, 2 * C, C, 1, 1, 0,
+                                     PTPP_ACT_NONE, 0, 0, dt);
+      ST_TRY(ptpp_conv1d_fwd(&c, stream));
+      ST_TRY(ptpp_gate_bwd(act, a->dg_buf, da, (int64_t)B * T, C, ldc, dt, stream));
+    }
+    if (!a->batched_wgrad) {
+      if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
+      ST_TRY(ptpp_conv1d_wgrad(yin, da, a->dw_dil[l], a->db_dil[l], nullptr, B, T, C, 2 * C, 3, d, d, C, ldc, 0, dt, ws_w, ws_w_bytes,
+                               wstream));
+    }
+    ptpp_conv1d_args c = conv_args(da, ldc, a->dil_wpt[l], nullptr, gx, C, at(a->gx_all, (size_t)l * BTC, dt), C, nullptr, B, T, 2 * C, C,
+                                   3, d, d, PTPP_ACT_NONE, 0, 0, dt);
+    ST_TRY(ptpp_conv1d_fwd_ex(&c, nullptr, 0, r2, 0.f, 0, stream));
+  }
+  if (a->batched_wgrad) {
+    // every layer's (g, do) and (yin, da) pair is still in its slab: all output-projection gradients in one launch, all
+    // dilated-conv gradients in another, each dw element summed over all rows by ONE block (no split-K partials)
+    ST_CHECK_ARG(L <= 64, "diffnet_stack_bwd: at most 64 layers");
+    ptpp_wgrad_problem po[64], pd[64];
+    for (int l = 0; l < L; ++l) {
+      po[l].x = at(a->g_all, (size_t)l * BTC, dt); po[l].dy = at(a->do_all, (size_t)l * 2 * BTC, dt);
+      po[l].dw = a->dw_out[l]; po[l].dbias = a->db_out[l]; po[l].dil = 1; po[l].pad = 0;
+      const int d = 1 << (l % a->cycle);
+      pd[l].x = at(a->yin_all, (size_t)l * BTC, dt); pd[l].dy = at(a->dcond_all, (size_t)l * 2 * C, dt);
+      pd[l].dw = a->dw_dil[l]; pd[l].dbias = a->db_dil[l]; pd[l].dil = d; pd[l].pad = d;
+    }
+    if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
+    ST_TRY(ptpp_conv1d_wgrad_batched(pd, L, nullptr, B, T, C, 2 * C, 3, C, ldc, 0, dt, ws_w, ws_w_bytes, wstream));
+    ST_TRY(ptpp_conv1d_wgrad_batched(po, L, nullptr, B, T, C, 2 * C, 1, C, 2 * C, 0, dt, ws_w, ws_w_bytes, wstream));
+  }
+  return ptpp_colsum_batch(a->gx_all, a->S, L * B, T, C, dt, stream);
+}
+
+// One conv / linear launch exactly as promptttspp_amd/ops.py::conv1d dispatches it: the split-K scratch is handed over
+// only for few-row long-K shapes.
+static int linear_like_ops(const ptpp_conv1d_args& c, float drop_p, uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
+  if (c.T <= 512 && c.ks * c.Cin >= 2048 && ws) return ptpp_conv1d_fwd_ws(&c, nullptr, 0, 1.0f, drop_p, seed, ws, ws_bytes, stream);
+  return ptpp_conv1d_fwd_ex(&c, nullptr, 0, 1.0f, drop_p, seed, stream);
+}
+
+extern "C" int ptpp_encoder_layers_fwd(const ptpp_encoder_layers_fwd_args* a, void* stream) {
+  ST_CHECK_ARG(a && a->h_in && a->h_out && a->qkv_wp && a->qkv_b && a->ao_wp && a->ao_b && a->ln1_g && a->ln1_b && a->i_wp && a->i_b &&
+                   a->o_wp && a->o_b && a->ln2_g && a->ln2_b && a->scratch && a->seeds,
+               "encoder_layers_fwd: null pointer");
+  ST_CHECK_ARG(a->B > 0 && a->T > 0 && a->C > 0 && a->F > 0 && a->H > 0 && a->C % a->H == 0 && a->L > 0, "encoder_layers_fwd: bad shape");
+  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "encoder_layers_fwd: bad dtype %d", a->dtype);
+  const int B = a->B, T = a->T, C = a->C, F = a->F, dt = a->dtype;
+  const size_t R = (size_t)B * T;
+  ST_CHECK_ARG(a->scratch_bytes >= R * (7 * (size_t)C + F) * esize(dt), "encoder_layers_fwd: scratch too small (%zu bytes, need %zu)",
+               a->scratch_bytes, R * (7 * (size_t)C + F) * esize(dt));
+  char* s0 = static_cast<char*>(a->scratch);
+  void* qkv = s0;
+  void* ctx = at(qkv, R * 3 * C, dt);
+  void* att = at(ctx, R * C, dt);
+  void* h1 = at(att, R * C, dt);
+  void* hbuf = at(h1, R * C, dt);       // layer outputs alternate between hbuf and h_out so that the last lands in h_out
+  void* inter = at(hbuf, R * C, dt);    // (R, F)
+  const void* h = a->h_in;
+  for (int l = 0; l < a->L; ++l) {
+    void* hn = ((a->L - 1 - l) & 1) ? hbuf : a->h_out;
+    const uint64_t* sd = a->seeds + 3 * l;
+    ptpp_conv1d_args c = conv_args(h, C, a->qkv_wp[l], a->qkv_b[l], nullptr, 0, qkv, 3 * C, nullptr, B, T, C, 3 * C, 1, 1, 0, PTPP_ACT_NONE,
+                                   0, 0, dt);
+    ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
+    ST_TRY(ptpp_attention_fwd(qkv, at(qkv, C, dt), at(qkv, 2 * C, dt), nullptr, nullptr, nullptr, ctx, nullptr, a->lengths, B, T, a->H,
+                              C / a->H, 3 * C, 0, C, PTPP_ATTN_PLAIN, a->p_att, a->p_att > 0.f ? sd[0] : 0, dt, stream));
+    c = conv_args(ctx, C, a->ao_wp[l], a->ao_b[l], h, C, att, C, nullptr, B, T, C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
+    ST_TRY(linear_like_ops(c, a->p_hid, a->p_hid > 0.f ? sd[1] : 0, a->ws, a->ws_bytes, stream));
+    ST_TRY(ptpp_layernorm_fwd(att, nullptr, a->ln1_g[l], a->ln1_b[l], h1, nullptr, nullptr, nullptr, nullptr, B, T, C, a->eps, 0,
+                              PTPP_ACT_NONE, 0.f, 0, 0.f, 0, dt, stream));
+    c = conv_args(h1, C, a->i_wp[l], a->i_b[l], nullptr, 0, inter, F, nullptr, B, T, C, F, 1, 1, 0, PTPP_ACT_GELU, 0, 0, dt);
+    ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
+    c = conv_args(inter, F, a->o_wp[l], a->o_b[l], h1, C, att, C, nullptr, B, T, F, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
+    ST_TRY(linear_like_ops(c, a->p_hid, a->p_hid > 0.f ? sd[2] : 0, a->ws, a->ws_bytes, stream));
+    ST_TRY(ptpp_layernorm_fwd(att, nullptr, a->ln2_g[l], a->ln2_b[l], hn, nullptr, nullptr, nullptr, nullptr, B, T, C, a->eps, 0,
+                              PTPP_ACT_NONE, 0.f, 0, 0.f, 0, dt, stream));
+    h = hn;
+  }
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_conv_ln_stack_fwd(const ptpp_conv_ln_stack_fwd_args* a, void* stream) {
+  ST_CHECK_ARG(a && a->x0 && a->wp && a->bias && a->gamma && a->beta && a->x_all && a->z_all && a->mean_all && a->rstd_all,
+               "conv_ln_stack_fwd: null pointer");
+  ST_CHECK_ARG(a->B > 0 && a->T > 0 && a->C > 0 && a->n > 0 && a->ks > 0 && (a->ks & 1), "conv_ln_stack_fwd: bad shape");
+  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "conv_ln_stack_fwd: bad dtype %d", a->dtype);
+  const bool fused_in = a->ln_res || a->act_in != PTPP_ACT_NONE || a->drop_in > 0.f;
+  ST_CHECK_ARG(!fused_in || a->sum_all, "conv_ln_stack_fwd: sum_all is needed with a residual / activation / dropout before the norm");
+  ST_CHECK_ARG((!a->conv_mask && a->out_mask == 0) || a->lengths, "conv_ln_stack_fwd: masks need lengths");
+  ST_CHECK_ARG((a->drop_in <= 0.f && a->drop_out <= 0.f) || a->seeds, "conv_ln_stack_fwd: dropout needs seeds");
+  const int B = a->B, T = a->T, C = a->C, n = a->n, dt = a->dtype;
+  const size_t BTC = (size_t)B * T * C, R = (size_t)B * T;
+  const void* x = a->x0;
+  for (int i = 0; i < n; ++i) {
+    void* z = at(a->z_all, i * BTC, dt);
+    void* y = at(a->x_all, i * BTC, dt);
+    ptpp_conv1d_args c = conv_args(x, C, a->wp[i], a->bias[i], nullptr, 0, z, C, a->conv_mask ? a->lengths : nullptr, B, T, C, C, a->ks, 1,
+                                   a->ks / 2, a->conv_act, a->conv_mask ? 1 : 0, 0, dt);
+    ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
+    const int om = a->out_mask == 1 || (a->out_mask == 2 && i == n - 1);
+    ST_TRY(ptpp_layernorm_fwd(z, a->ln_res ? x : nullptr, a->gamma[i], a->beta[i], y, fused_in ? at(a->sum_all, i * BTC, dt) : nullptr,
+                              a->mean_all + i * R, a->rstd_all + i * R, a->lengths, B, T, C, a->eps, om, a->act_in, a->drop_in,
+                              a->drop_in > 0.f ? a->seeds[2 * i] : 0, a->drop_out, a->drop_out > 0.f ? a->seeds[2 * i + 1] : 0, dt, stream));
+    x = y;
+  }
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_conv_ln_stack_bwd(const ptpp_conv_ln_stack_bwd_args* a, void* stream) {
+  ST_CHECK_ARG(a && a->gy && a->x0 && a->x_all && a->z_all && a->mean_all && a->rstd_all && a->wpt && a->gamma && a->dw && a->db &&
+                   a->dgamma && a->dbeta && a->gz_all && a->tmp && a->red_scratch,
+               "conv_ln_stack_bwd: null pointer");
+  ST_CHECK_ARG(a->B > 0 && a->T > 0 && a->C > 0 && a->n > 0 && a->n <= 64 && a->ks > 0 && (a->ks & 1), "conv_ln_stack_bwd: bad shape");
+  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "conv_ln_stack_bwd: bad dtype %d", a->dtype);
+  const bool fused_in = a->ln_res || a->act_in != PTPP_ACT_NONE || a->drop_in > 0.f;
+  ST_CHECK_ARG(!fused_in || a->sum_all, "conv_ln_stack_bwd: sum_all missing");
+  const bool want_dz = a->act_in != PTPP_ACT_NONE || a->drop_in > 0.f;
+  const bool relu = a->conv_act == PTPP_ACT_RELU;
+  ST_CHECK_ARG(a->conv_act == PTPP_ACT_NONE || relu, "conv_ln_stack_bwd: conv activations none | relu");
+  const int B = a->B, T = a->T, C = a->C, n = a->n, dt = a->dtype, ks = a->ks, pad = ks / 2;
+  const size_t BTC = (size_t)B * T * C, R = (size_t)B * T;
+  void* wstream = a->side_stream ? a->side_stream : stream;
+  void* ws_w = a->side_stream ? a->ws_side : a->ws_main;
+  const size_t ws_w_bytes = a->side_stream ? a->ws_side_bytes : a->ws_main_bytes;
+  const int32_t* clen = a->conv_mask ? a->lengths : nullptr;
+  // scratch tensors: the gradient w.r.t. a layer's output alternates between g[0] and g[1]; dsum; the pre-relu gradient / dx
+  void* g[2] = {at(a->tmp, 0, dt), at(a->tmp, BTC, dt)};
+  void* dsum = at(a->tmp, 2 * BTC, dt);
+  void* aux = at(a->tmp, 3 * BTC, dt);
+  const void* gout = a->gy;
+  for (int i = n - 1; i >= 0; --i) {
+    const void* xi = i == 0 ? a->x0 : at(a->x_all, (size_t)(i - 1) * BTC, dt);
+    const void* z = at(a->z_all, (size_t)i * BTC, dt);
+    void* gz = at(a->gz_all, (size_t)i * BTC, dt);
+    const int om = a->out_mask == 1 || (a->out_mask == 2 && i == n - 1);
+    // LayerNorm backward: dsum = gradient w.r.t. the norm's input (and the residual branch), dz = w.r.t. the conv output
+    // when an activation / dropout sits between them; whichever is the conv-output gradient goes to gz (or aux before relu')
+    void* conv_grad_dst = relu ? aux : gz;
+    void* dsum_dst = want_dz ? dsum : conv_grad_dst;
+    ST_TRY(ptpp_layernorm_bwd(gout, fused_in ? at(a->sum_all, (size_t)i * BTC, dt) : z, a->act_in != PTPP_ACT_NONE ? z : nullptr, a->gamma[i],
+                              a->mean_all + i * R, a->rstd_all + i * R, dsum_dst, want_dz ? conv_grad_dst : nullptr, a->dgamma[i], a->dbeta[i],
+                              a->lengths, B, T, C, om, a->act_in, a->drop_in, a->drop_in > 0.f ? a->seeds[2 * i] : 0, a->drop_out,
+                              a->drop_out > 0.f ? a->seeds[2 * i + 1] : 0, dt, a->red_scratch, a->red_bytes, stream));
+    if (relu) ST_TRY(ptpp_epilogue_bwd(aux, z, gz, nullptr, B, T, C, 1.0f, 1, 0, 0.f, 0, dt, stream));
+    const bool need_dx = i > 0 || a->gx != nullptr;
+    if (need_dx) {
+      void* gnext = i == 0 ? a->gx : g[i & 1];
+      // with a residual around the layer the data gradient lands in aux and is added to dsum exactly as autograd adds the
+      // two branches (rounded separately); without one dsum_dst == gz and the conv writes the next gradient directly
+      void* dx = a->ln_res ? aux : gnext;
+      ptpp_conv1d_args c = conv_args(gz, C, a->wpt[i], nullptr, nullptr, 0, dx, C, clen, B, T, C, C, ks, 1, (ks - 1) - pad, PTPP_ACT_NONE, 0,
+                                     a->conv_mask ? 1 : 0, dt);
+      ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+      if (a->ln_res) ST_TRY(ptpp_add3_scale(dx, want_dz ? dsum : gz, nullptr, gnext, 1.0f, (int64_t)BTC, dt, stream));
+      gout = gnext;
+    }
+    if (!a->batched_wgrad) {
+      if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
+      ST_TRY(ptpp_conv1d_wgrad(xi, gz, a->dw[i], a->db[i], clen, B, T, C, C, ks, 1, pad, C, C, a->conv_mask ? 1 : 0, dt, ws_w, ws_w_bytes,
+                               wstream));
+    }
+  }
+  if (a->batched_wgrad) {
+    ptpp_wgrad_problem pr[64];
+    for (int i = 0; i < n; ++i) {
+      pr[i].x = i == 0 ? a->x0 : at(a->x_all, (size_t)(i - 1) * BTC, dt);
+      pr[i].dy = at(a->gz_all, (size_t)i * BTC, dt);
+      pr[i].dw = a->dw[i]; pr[i].dbias = a->db[i]; pr[i].dil = 1; pr[i].pad = pad;
+    }
+    if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
+    ST_TRY(ptpp_conv1d_wgrad_batched(pr, n, clen, B, T, C, C, ks, C, C, a->conv_mask ? 1 : 0, dt, ws_w, ws_w_bytes, wstream));
+  }
+  return PTPP_OK;
+}

@@ -533,6 +533,138 @@ def layer_norm(x, gamma, beta, eps, res=None, lengths=None, out_mask=False, act_
 
 
 # ----------------------------------------------------------------------------
+# A stack of [Conv1d -> LayerNorm] layers as ONE autograd node issued by two C calls (ptpp_conv_ln_stack_fwd / _bwd):
+# the variance predictors (modules/variance_adaptor.py:23-62) and the frame prior network (modules/frame_prior.py:76-89).
+# Same launches, seeds and order as the chain of Conv1dFn / LayerNormFn nodes it replaces (bit-identical with
+# BATCHED_WGRAD off); with it on, the layers' weight gradients are one batched launch after the stack's backward.
+# ----------------------------------------------------------------------------
+def _u64_table(vals):
+    return (ctypes.c_uint64 * len(vals))(*vals)
+
+
+class ConvLnStackFn(Function):
+    @staticmethod
+    def forward(ctx, x, cfg, *flat):
+        n = len(flat) // 4
+        ws_, bs_, gs_, be_ = flat[:n], flat[n : 2 * n], flat[2 * n : 3 * n], flat[3 * n :]
+        x = x.contiguous()
+        B, T, C = x.shape
+        dt, dev = x.dtype, x.device
+        fused_in = cfg.ln_res or cfg.act_in is not None or cfg.drop_in > 0
+        seeds = []
+        for _ in range(n):  # the draws of LayerNormFn.forward, in its order
+            seeds += [next_seed() if cfg.drop_in > 0 else 0, next_seed() if cfg.drop_out > 0 else 0]
+        x_all = torch.empty((n, B, T, C), device=dev, dtype=dt)
+        z_all = torch.empty((n, B, T, C), device=dev, dtype=dt)
+        sum_all = torch.empty((n, B, T, C), device=dev, dtype=dt) if fused_in else None
+        stats = torch.empty((2, n, B * T), device=dev, dtype=torch.float32)
+        lens = ops.i32(cfg.lengths, dev) if cfg.lengths is not None else None
+        gam = [_f32_param(g).reshape(-1) for g in gs_]
+        bet = [_f32_param(b).reshape(-1) for b in be_]
+        bias = [_f32_param(b) for b in bs_]
+        a = _lib.ConvLnFwdArgs()
+        a.x0 = x.data_ptr()
+        a.lengths = lens.data_ptr() if lens is not None else None
+        tabs = [_ptr_table([packed(w, dt) for w in ws_]), _ptr_table(bias), _ptr_table(gam), _ptr_table(bet)]
+        a.wp, a.bias, a.gamma, a.beta = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
+        a.x_all, a.z_all = x_all.data_ptr(), z_all.data_ptr()
+        a.sum_all = sum_all.data_ptr() if sum_all is not None else None
+        a.mean_all, a.rstd_all = stats[0].data_ptr(), stats[1].data_ptr()
+        sd = _u64_table(seeds)
+        a.seeds = ctypes.cast(sd, ctypes.c_void_p)
+        if not torch.cuda.is_current_stream_capturing():
+            wsb = ops.workspace(dev)
+            a.ws, a.ws_bytes = wsb.data_ptr(), wsb.numel()
+        a.eps, a.drop_in, a.drop_out = cfg.eps, cfg.drop_in, cfg.drop_out
+        a.B, a.T, a.C, a.n, a.ks = B, T, C, n, cfg.ks
+        a.conv_act, a.conv_mask, a.ln_res = ops._ACT[cfg.conv_act], int(cfg.conv_mask), int(cfg.ln_res)
+        a.act_in, a.out_mask, a.dtype = ops._ACT[cfg.act_in], cfg.out_mask, ops.dtype_code(dt)
+        _lib.check(_lib.load().ptpp_conv_ln_stack_fwd(ctypes.byref(a), ops._stream()), "ptpp_conv_ln_stack_fwd")
+        ctx.cfg, ctx.n, ctx.seeds, ctx.params = cfg, n, seeds, flat
+        ctx.slabs = (x, x_all, z_all, sum_all, stats, gam)
+        ctx.direct = all(_sink(t) is not None for t in flat)
+        if ctx.direct:
+            for t in flat:
+                _use(t)
+        return x_all[n - 1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        cfg, n, flat = ctx.cfg, ctx.n, ctx.params
+        x, x_all, z_all, sum_all, stats, gam = ctx.slabs
+        ws_, bs_, gs_, be_ = flat[:n], flat[n : 2 * n], flat[2 * n : 3 * n], flat[3 * n :]
+        B, T, C = x.shape
+        dt, dev = x.dtype, x.device
+        gy = gy.contiguous()
+        need_gx = ctx.needs_input_grad[0]
+        gx = torch.empty_like(x) if need_gx else None
+        gz_all = torch.empty((n, B, T, C), device=dev, dtype=dt)
+        tmp = torch.empty((4, B, T, C), device=dev, dtype=dt)
+        if ctx.direct:
+            tg = [[t.grad for t in grp] for grp in (ws_, bs_, gs_, be_)]
+        else:
+            tg = [[torch.zeros(t.shape, device=dev, dtype=torch.float32) for t in grp] for grp in (ws_, bs_, gs_, be_)]
+        d = _direct
+        side_h = None
+        if ctx.direct and d["async"] and not torch.cuda.is_current_stream_capturing():
+            if d["side_h"] is None:
+                create_side_stream(dev)
+            side_h = d["side_h"]
+        main_h = ops._stream()
+        ws_main = ops.workspace(dev)
+        ws_side = ops.workspace_of(dev, side_h) if side_h is not None else ws_main
+        lens = ops.i32(cfg.lengths, dev) if cfg.lengths is not None else None
+        a = _lib.ConvLnBwdArgs()
+        a.gy, a.x0, a.x_all, a.z_all = gy.data_ptr(), x.data_ptr(), x_all.data_ptr(), z_all.data_ptr()
+        a.sum_all = sum_all.data_ptr() if sum_all is not None else None
+        a.mean_all, a.rstd_all = stats[0].data_ptr(), stats[1].data_ptr()
+        a.lengths = lens.data_ptr() if lens is not None else None
+        tabs = [_ptr_table([packed(w, dt, mode=1) for w in ws_]), _ptr_table(gam)] + [_ptr_table(t) for t in tg]
+        a.wpt, a.gamma, a.dw, a.db, a.dgamma, a.dbeta = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
+        a.gz_all, a.tmp = gz_all.data_ptr(), tmp.data_ptr()
+        a.gx = gx.data_ptr() if gx is not None else None
+        sd = _u64_table(ctx.seeds)
+        a.seeds = ctypes.cast(sd, ctypes.c_void_p)
+        a.red_scratch, a.red_bytes = ops.reduction_scratch(dev)
+        a.ws_main, a.ws_main_bytes = ws_main.data_ptr(), ws_main.numel()
+        a.ws_side, a.ws_side_bytes = ws_side.data_ptr(), ws_side.numel()
+        a.side_stream = side_h
+        a.drop_in, a.drop_out = cfg.drop_in, cfg.drop_out
+        a.B, a.T, a.C, a.n, a.ks = B, T, C, n, cfg.ks
+        a.conv_act, a.conv_mask, a.ln_res = ops._ACT[cfg.conv_act], int(cfg.conv_mask), int(cfg.ln_res)
+        a.act_in, a.out_mask, a.dtype = ops._ACT[cfg.act_in], cfg.out_mask, ops.dtype_code(dt)
+        a.batched_wgrad = int(BATCHED_WGRAD)
+        _lib.check(_lib.load().ptpp_conv_ln_stack_bwd(ctypes.byref(a), main_h), "ptpp_conv_ln_stack_bwd")
+        if side_h is not None:
+            d["keep"].extend((x, x_all, gz_all))
+        ctx.slabs = None
+        if ctx.direct:
+            for t in flat:
+                _done(t)
+            return (gx, None) + (None,) * (4 * n)
+        grads = [g.view_as(p) for grp, ps in zip(tg, (ws_, bs_, gs_, be_)) for g, p in zip(grp, ps)]
+        return (gx, None, *grads)
+
+
+def conv_ln_stack(x, convs, norms, ks, eps, lengths, conv_act=None, conv_mask=False, ln_res=False, act_in=None, drop_in=0.0,
+                  drop_out=0.0, out_mask=0):
+    """convs: nn.Conv1d modules (C -> C, kernel ks, same padding); norms: modules with gamma / beta.  out_mask: 0 | 1 (every
+    layer) | 2 (last layer).  See ptpp_conv_ln_stack_fwd (include/ptpp.h)."""
+    cfg = SimpleNamespace(ks=ks, eps=float(eps), lengths=lengths, conv_act=conv_act, conv_mask=conv_mask, ln_res=ln_res, act_in=act_in,
+                          drop_in=float(drop_in), drop_out=float(drop_out), out_mask=int(out_mask))
+    flat = [c.weight for c in convs] + [c.bias for c in convs] + [m.gamma for m in norms] + [m.beta for m in norms]
+    return ConvLnStackFn.apply(x, cfg, *flat)
+
+
+def conv_ln_stack_ok(x, convs):
+    """The one-call stack serves device tensors whose channel count fills whole 16-byte operand chunks, convs with bias."""
+    C = x.shape[-1]
+    return STACK_DRIVERS and x.is_cuda and C % _kc(x.dtype) == 0 and all(c.bias is not None and c.weight.shape[0] == C and
+                                                                         c.weight.shape[1] == C for c in convs)
+
+
+# ----------------------------------------------------------------------------
 class AttentionFn(Function):
     """Relative-position MHA core on a fused (B, T, 3C) q|k|v projection."""
 
@@ -549,7 +681,7 @@ class AttentionFn(Function):
         ctx.heads, ctx.variant, ctx.lengths, ctx.drop = heads, variant, lengths, (drop_p, seed)
         ctx.ushape = bias_u.shape if bias_u is not None else None
         ctx.direct = None
-        if need_bwd and variant == "new" and _sink(bias_u) is not None and _sink(bias_v) is not None:
+        if need_bwd and variant in ("new", "legacy") and _sink(bias_u) is not None and _sink(bias_v) is not None:
             ctx.direct = (bias_u, bias_v)
             _use(bias_u)
             _use(bias_v)
@@ -662,8 +794,67 @@ def diffnet_cond_all(cond, cond_ws, cond_bs, gate_perm=False):
 FUSE_DIFFNET_POST = not os.environ.get("PTPP_NO_FUSED_POST")  # (tests compare the fused launch with the two-kernel path)
 
 
+# the weight gradients of a stack's layers as one batched launch per shape after the stack's backward (no split-K partials,
+# bit-reproducible) instead of one launch (+ reduce) per layer inside it -- only inside the one-call drivers
+BATCHED_WGRAD = not os.environ.get("PTPP_NO_BATCHED_WGRAD")
+STACK_DRIVERS = not os.environ.get("PTPP_NO_STACK_DRIVERS")  # (tests compare the one-call drivers with the per-launch path)
+
+
+def _ptr_table(tensors):
+    """HOST array of device pointers (an argument of the whole-unit drivers, include/ptpp.h)."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _f32_param(t):
+    """A parameter the kernels read as f32: the tensor itself when it already is contiguous f32 (the usual case)."""
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
+
+
+def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save):
+    """The whole residual stack in ONE C call (ptpp_diffnet_stack_fwd): the same launches in the same order as the loop
+    of ``diffnet_stack_forward`` below (bit-identical), without ~60 Python -> C round trips and ~80 allocations.
+    Returns (skip f32, (yin_all, a_all, g_all) slabs of all layers when ``save``)."""
+    L = len(weights)
+    B, T, C = h0.shape
+    dt, dev = h0.dtype, h0.device
+    fused = (not save) and lengths is None and diffnet_fused_gate(dt)
+    n_slabs = L if save else 2
+    skip = torch.empty((B, T, C), device=dev, dtype=torch.float32)
+    ds = dsteps.transpose(0, 1).contiguous()  # (L, B, C)
+    yin_all = torch.empty((n_slabs, B, T, C), device=dev, dtype=dt)
+    g_all = torch.empty((n_slabs, B, T, C), device=dev, dtype=dt)
+    a_all = None if fused else torch.empty((n_slabs, B, T, 2 * C), device=dev, dtype=dt)
+    xb = torch.empty((2, B, T, C), device=dev, dtype=dt)
+    o_buf = None if ops.conv1d_diffnet_post_supported(C, C, dt) else torch.empty((B, T, 2 * C), device=dev, dtype=dt)
+    if fused:
+        perm = _gate_perm(2 * C, dev)
+        dil_wp = [_cat_cached([dw], ("wg1", dt), lambda dw=dw: ops.pack_conv_weight(dw.detach()[perm], dt)) for dw, _, _, _ in weights]
+        dil_b = [_cat_cached([db], "bg1", lambda db=db: db.detach().float()[perm].contiguous()) for _, db, _, _ in weights]
+    else:
+        dil_wp = [packed(dw, dt) for dw, _, _, _ in weights]
+        dil_b = [_f32_param(db) for _, db, _, _ in weights]
+    out_wp = [packed(ow, dt) for _, _, ow, _ in weights]
+    out_b = [_f32_param(ob) for _, _, _, ob in weights]
+    lens = ops.i32(lengths, dev) if lengths is not None else None
+    assert h0.is_contiguous() and cond_all.is_contiguous() and cond_all.shape[2] == L * 2 * C and ds.dtype == torch.float32
+    a = _lib.DiffNetFwdArgs()
+    a.h0, a.cond_all, a.dsteps, a.skip = h0.data_ptr(), cond_all.data_ptr(), ds.data_ptr(), skip.data_ptr()
+    a.lengths = lens.data_ptr() if lens is not None else None
+    tabs = [_ptr_table(t) for t in (dil_wp, dil_b, out_wp, out_b)]
+    a.dil_wp, a.dil_b, a.out_wp, a.out_b = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
+    a.yin_all, a.g_all = yin_all.data_ptr(), g_all.data_ptr()
+    a.a_all = a_all.data_ptr() if a_all is not None else None
+    a.x_buf0, a.x_buf1 = xb[0].data_ptr(), xb[1].data_ptr()
+    a.o_buf = o_buf.data_ptr() if o_buf is not None else None
+    a.B, a.T, a.C, a.L, a.cycle, a.n_slabs, a.fused_gate, a.dtype = B, T, C, L, cycle, n_slabs, int(fused), ops.dtype_code(dt)
+    _lib.check(_lib.load().ptpp_diffnet_stack_fwd(ctypes.byref(a), ops._stream()), "ptpp_diffnet_stack_fwd")
+    return skip, ((yin_all, a_all, g_all) if save else None)
+
+
 def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
     """weights: per layer (dil_w, dil_b, out_w, out_b).  Returns (skip_sum f32, saved)."""
+    if STACK_DRIVERS and h0.is_cuda and h0.is_contiguous() and cond_all.is_contiguous():
+        return _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save)
     L = len(weights)
     B, T, C = h0.shape
     skip = torch.empty((B, T, C), device=h0.device, dtype=torch.float32)
@@ -726,6 +917,9 @@ class DiffNetStackFn(Function):
         # every layer's gx is kept ((L + 1, B, T, C): 0.3 GB at the bench shape) so that the per-utterance column sums
         # of all layers are ONE launch after the loop instead of one (plus its memset) per layer
         gx_all = torch.empty((L + 1, B, T, C), device=gout.device, dtype=dt)
+        if isinstance(ctx.saved, tuple):  # slabs of the one-call forward: the loop below as ONE C call
+            S, dcond_all, grads = _diffnet_backward_driver(ctx, gS, gx_all)
+            return DiffNetStackFn._backward_tail(ctx, cond, gx_all[0], S, dcond_all, grads)
         gx = gx_all[L].zero_()
         # per-layer column sums of gx land in rows of one buffer; the step-embedding gradients
         # dd[:, l] = S[l] - S[l+1] / sqrt(2) are formed after the loop in two launches (not 3 per layer)
@@ -758,6 +952,14 @@ class DiffNetStackFn(Function):
                 grads[6 * l + 4], grads[6 * l + 5] = dwo.view_as(out_w), dbo
             ctx.saved[l] = None
         ops.colsum_batch(gx_all[:L].view(L * B, T, C), out=S[:L].view(L * B, C))
+        return DiffNetStackFn._backward_tail(ctx, cond, gx, S, dcond_all, grads)
+
+    @staticmethod
+    def _backward_tail(ctx, cond, gx, S, dcond_all, grads):
+        L, ws = ctx.L, ctx.ws
+        C = gx.shape[-1]
+        dt = gx.dtype
+        r2 = 1.0 / math.sqrt(2.0)
         dd = torch.sub(S[:L], S[1:], alpha=r2).transpose(0, 1)  # (B, L, C)
         dcond = None
         if ctx.needs_input_grad[1]:
@@ -781,6 +983,60 @@ class DiffNetStackFn(Function):
                 grads[6 * l + 2] = dwc[l * 2 * C : (l + 1) * 2 * C].view_as(ws[l][2])
                 grads[6 * l + 3] = dbc[l * 2 * C : (l + 1) * 2 * C]
         return (gx, dcond, dd, None, None, *grads)
+
+
+def _diffnet_backward_driver(ctx, gS, gx_all):
+    """ptpp_diffnet_stack_bwd: per layer post_bwd -> output-projection weight gradient (side stream) -> its data gradient
+    with the gate backward fused -> dilated conv weight gradient (side stream) -> dilated conv data gradient, then the
+    column sums of all layers; the launches and their order are those of the per-launch loop (bit-identical)."""
+    L, ws = ctx.L, ctx.ws
+    _, B, T, C = gx_all.shape
+    dt, dev = gS.dtype, gS.device
+    yin_all, a_all, g_all = ctx.saved
+    S = torch.zeros((L + 1, B, C), device=dev, dtype=torch.float32)
+    dcond_all = torch.empty((B, T, L * 2 * C), device=dev, dtype=dt)
+    do_all = torch.empty((L, B, T, 2 * C), device=dev, dtype=dt)
+    dg_buf = None if ops.conv1d_gate_bwd_supported(C, 2 * C, dt) else torch.empty((B, T, C), device=dev, dtype=dt)
+    if ctx.direct:
+        tg = [[w[i].grad for w in ws] for i in (0, 1, 4, 5)]
+    else:
+        tg = [[torch.zeros(w[i].shape, device=dev, dtype=torch.float32) for w in ws] for i in (0, 1, 4, 5)]
+    d = _direct
+    side_h = None
+    if ctx.direct and d["async"] and not torch.cuda.is_current_stream_capturing():
+        if d["side_h"] is None:
+            create_side_stream(dev)
+        side_h = d["side_h"]
+    main_h = ops._stream()
+    ws_main = ops.workspace(dev)
+    ws_side = ops.workspace_of(dev, side_h) if side_h is not None else ws_main
+    lens = ops.i32(ctx.lengths, dev) if ctx.lengths is not None else None
+    a = _lib.DiffNetBwdArgs()
+    a.gS, a.yin_all, a.a_all, a.g_all = gS.data_ptr(), yin_all.data_ptr(), a_all.data_ptr(), g_all.data_ptr()
+    a.lengths = lens.data_ptr() if lens is not None else None
+    tabs = [_ptr_table([packed(w[0], dt, mode=1) for w in ws]), _ptr_table([packed(w[4], dt, mode=1) for w in ws])] + \
+           [_ptr_table(t) for t in tg]
+    a.dil_wpt, a.out_wpt, a.dw_dil, a.db_dil, a.dw_out, a.db_out = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
+    a.gx_all, a.do_all, a.dcond_all, a.S = gx_all.data_ptr(), do_all.data_ptr(), dcond_all.data_ptr(), S.data_ptr()
+    a.dg_buf = dg_buf.data_ptr() if dg_buf is not None else None
+    a.ws_main, a.ws_main_bytes = ws_main.data_ptr(), ws_main.numel()
+    a.ws_side, a.ws_side_bytes = ws_side.data_ptr(), ws_side.numel()
+    a.side_stream = side_h
+    a.B, a.T, a.C, a.L, a.cycle, a.dtype = B, T, C, L, ctx.cycle, ops.dtype_code(dt)
+    a.batched_wgrad = int(BATCHED_WGRAD)
+    _lib.check(_lib.load().ptpp_diffnet_stack_bwd(ctypes.byref(a), main_h), "ptpp_diffnet_stack_bwd")
+    if side_h is not None:  # the side stream still reads these: held until the streams are joined (sync_wgrad_stream)
+        d["keep"].extend((yin_all, a_all, g_all, do_all, dcond_all))
+    ctx.saved = None
+    grads = [None] * (6 * L)
+    if ctx.direct:
+        for l in range(L):
+            for i in (0, 1, 4, 5):
+                _done(ws[l][i])
+    else:
+        for l in range(L):
+            grads[6 * l + 0], grads[6 * l + 1], grads[6 * l + 4], grads[6 * l + 5] = tg[0][l], tg[1][l], tg[2][l], tg[3][l]
+    return S, dcond_all, grads
 
 
 def diffnet_stack(h0, cond, dsteps, lengths, cycle, layer_params):

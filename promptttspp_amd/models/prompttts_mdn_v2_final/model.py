@@ -13,6 +13,8 @@ Deliberate deviations from the reference's side effects (results identical):
   ``to_log_scale`` does, SURVEY.md F10);
 * the prompt may be ``List[str]`` or pre-tokenised ``(input_ids, attention_mask)``.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -25,6 +27,22 @@ from ...modules.esp import ConformerEncoder
 from ...modules.transformer import Transformer
 from ...modules.mdn import mdn_get_most_probable_sigma_and_mu, mdn_loss, mdn_sample_sigma_and_mu
 from ...utils.model import sequence_mask
+
+
+BRANCH_STREAMS = bool(os.environ.get("PTPP_BRANCH_STREAMS"))
+_branch = {}
+
+
+def _branch_stream(dev):
+    """One extra stream per device for the prompt branch, with a slab of its own in the caching allocator (a stream's free
+    blocks serve only that stream: without it every new batch shape grows the pool by hipMalloc inside the step)."""
+    st = _branch.get(dev)
+    if st is None:
+        st = _branch[dev] = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            slab = torch.empty(int(float(os.environ.get("PTPP_BRANCH_RESERVE_GIB", "2")) * (1 << 30)), device=dev, dtype=torch.uint8)
+            del slab
+    return st
 
 
 class PromptTTSMDNDurCFG(nn.Module):
@@ -91,9 +109,19 @@ class PromptTTSMDNDurCFG(nn.Module):
         n_frames = fm1.sum()
 
         style_emb = self._norm_style(self.reference_encoder(mel, frame_lengths))  # (B,C,1) f32
-        prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
-        if self.style_mdn is not None:
-            style_mdn_out = self.style_mdn(prompt_emb.transpose(-1, -2))
+        # The prompt branch (BERT -> adaptor -> style MDN head) feeds nothing but loss_style in training (model.py:147-163):
+        # an independent chain of ~100 short launches.  PTPP_BRANCH_STREAMS=1 issues it -- forward here, backward by
+        # autograd on the same stream -- beside the main chain (experiment)
+        bs = _branch_stream(dev) if (BRANCH_STREAMS and self.training and dev.type == "cuda") else None
+        if bs is not None:
+            bs.wait_stream(torch.cuda.current_stream())
+            with ops.unpinned(), torch.cuda.stream(bs):
+                prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
+                style_mdn_out = self.style_mdn(prompt_emb.transpose(-1, -2)) if self.style_mdn is not None else None
+        else:
+            prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
+            if self.style_mdn is not None:
+                style_mdn_out = self.style_mdn(prompt_emb.transpose(-1, -2))
         x = x + style_emb.transpose(1, 2).to(dt)  # broadcast over every phone, padded ones too (model.py:111)
 
         h, dur_out, cf0_pred, vuv_pred, energy_pred = self.variance_adaptor.forward_cl(
@@ -119,6 +147,11 @@ class PromptTTSMDNDurCFG(nn.Module):
 
         loss_cf0 = (cf0_pred - log_cf0.squeeze(1)).abs().sum() / n_frames
         loss_vuv = (vuv_pred - vuv.squeeze(1)).abs().sum() / n_frames
+        if bs is not None:  # join: the style loss reads both branches
+            main = torch.cuda.current_stream()
+            main.wait_stream(bs)
+            for t in ((prompt_emb,) if style_mdn_out is None else tuple(style_mdn_out)):
+                t.record_stream(main)
         if self.style_mdn is not None:
             loss_style = mdn_loss(*style_mdn_out, style_emb.detach().transpose(-1, -2)).mean()
         else:
@@ -145,6 +178,14 @@ class PromptTTSMDNDurCFG(nn.Module):
 
     def _style(self, style_prompt, reference_mel, ref_lengths, device, use_max, noise_scale):
         assert (style_prompt is not None) ^ (reference_mel is not None), "One of style inputs must not be None."
+        if self.integer_island and not self.training and compute_dtype() != torch.float32:
+            from ...config import use_dtype
+
+            with use_dtype(torch.float32):  # (the durations depend on the style embedding: see integer_island)
+                return self._style_in_dtype(style_prompt, reference_mel, ref_lengths, device, use_max, noise_scale)
+        return self._style_in_dtype(style_prompt, reference_mel, ref_lengths, device, use_max, noise_scale)
+
+    def _style_in_dtype(self, style_prompt, reference_mel, ref_lengths, device, use_max, noise_scale):
         if style_prompt is not None:
             emb = self._norm_style(self.prompt_encoder(style_prompt, device))
             if self.style_mdn is not None:
@@ -153,11 +194,29 @@ class PromptTTSMDNDurCFG(nn.Module):
             return emb
         return self._norm_style(self.reference_encoder(reference_mel, ref_lengths))
 
+    # Integer island of the bf16 mode: everything the INTEGER outputs depend on -- style embedding (prompt or reference
+    # encoder), phoneme embedding, phoneme encoder, duration predictor + MDN head, exp / round -- runs in float32 at
+    # inference, whatever the compute dtype: the durations and frame lengths are then bit for bit those of the f32 mode
+    # (which are the reference's, tests/test_hip_acoustic.py).  Phone-level work: a few thousand rows, ~1 % of a synthesis
+    # call; the frame-level path and the sampler keep the compute dtype.
+    integer_island = True
+
     @torch.no_grad()
     def _synthesize(self, phoneme, phone_lengths, style_emb, zero_padded_durations, noise_fn=None):
-        x, plen, pmask = self._encode(phoneme, phone_lengths)
-        x = x + style_emb.transpose(1, 2).to(x.dtype)
-        h, flen, fm1, cf0, vuv, dur = self.variance_adaptor.infer_cl(x, plen, pmask if zero_padded_durations else None)
+        from ...config import use_dtype
+
+        dt = compute_dtype()
+        dur = None
+        if self.integer_island and dt != torch.float32:
+            with use_dtype(torch.float32):
+                x, plen, pmask = self._encode(phoneme, phone_lengths)
+                x = x + style_emb.transpose(1, 2).to(x.dtype)
+                dur = self.variance_adaptor.durations_cl(x, plen, pmask if zero_padded_durations else None)
+            x = x.to(dt)
+        else:
+            x, plen, pmask = self._encode(phoneme, phone_lengths)
+            x = x + style_emb.transpose(1, 2).to(x.dtype)
+        h, flen, fm1, cf0, vuv, dur = self.variance_adaptor.infer_cl(x, plen, pmask if zero_padded_durations else None, dur=dur)
         if self.conformer_decoder:
             mel = self._decode_conformer(h, flen, fm1).float()
         else:

@@ -52,6 +52,12 @@ class GaussianDiffusion(nn.Module):
         # The reference refuses pndm_speedup in its constructor (diffusion.py:104-105) although the PLMS sampler is
         # written out (:223-277) and reachable through inference(); here it is accepted: inference then walks every
         # pndm_speedup-th step of the schedule.
+        if pndm_speedup:
+            import warnings
+
+            warnings.warn("GaussianDiffusion(pndm_speedup=...) selects the PLMS sampler: an extension beyond the reference, whose "
+                          "constructor raises NotImplementedError for it (modules/diffusion.py:104-105); samples differ from the "
+                          "reference's 100-step ancestral sampler by construction", stacklevel=2)
         if pndm_speedup is not None:
             assert int(pndm_speedup) >= 1
         if betas is not None:
@@ -215,7 +221,7 @@ class GaussianDiffusion(nn.Module):
         torch.cuda.synchronize()
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with ops.unpinned(), torch.cuda.graph(g):  # (the capture runs on its own stream: no pinned handle inside)
                 xs.copy_(self._p_sample_core(xs, ts, cond, cond_all, ns))
                 ts.sub_(1)
         except Exception as e:  # capture refused (driver / allocator state): same kernels, launched eagerly

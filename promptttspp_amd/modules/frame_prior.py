@@ -55,6 +55,10 @@ class FramePriorNetwork(nn.Module):
         if self.use_pos_enc:
             x = self.norm_emb.forward_cl(self.embed.forward_cl(x))
         last = self.n_layers - 1
+        if self.n_layers > 0 and PF.conv_ln_stack_ok(x, self.convs) and len({n.eps for n in self.norms}) == 1:
+            # all layers as one autograd node issued by two C calls (functional.ConvLnStackFn)
+            return PF.conv_ln_stack(x, list(self.convs), list(self.norms), self.kernel_size, self.norms[0].eps, lengths, conv_mask=True,
+                                    ln_res=True, act_in="gelu", drop_in=p, out_mask=2)
         for i, (conv, norm) in enumerate(zip(self.convs, self.norms)):
             z = PF.conv1d(x, conv.weight, conv.bias, ks=self.kernel_size, pad=self.kernel_size // 2, lengths=lengths,
                           in_mask=True)

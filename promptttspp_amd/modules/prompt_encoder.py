@@ -122,8 +122,11 @@ class BertWrapper(nn.Module):
         with torch.no_grad():  # the embeddings are frozen, and nothing upstream of them needs a gradient
             h = self._embeddings(ids)
             n_frozen = self._n_frozen(layers)
-            for layer in layers[:n_frozen]:
-                h = self._frozen_layer(layer, h, lengths)
+            if PF.STACK_DRIVERS and n_frozen > 0:
+                h = self._frozen_layers_driver(layers[:n_frozen], h, lengths)
+            else:
+                for layer in layers[:n_frozen]:
+                    h = self._frozen_layer(layer, h, lengths)
         for layer in layers[n_frozen:]:
             if layer is layers[-1]:
                 return self._last_layer_cls(layer, h, lengths).float()
@@ -218,6 +221,55 @@ class BertWrapper(nn.Module):
                        drop_seed=PF.next_seed() if p_hid > 0 else 0)
         ln2 = layer.output.LayerNorm
         return ops.layernorm_fwd(o, ln2.weight, ln2.bias, ln2.eps)[0]
+
+
+    @torch.no_grad()
+    def _frozen_layers_driver(self, layers, h, lengths):
+        """All frozen layers in ONE C call (ptpp_encoder_layers_fwd): the launches of ``_frozen_layer`` in the same order
+        with the same dropout seeds (bit-identical to the loop), without ~70 Python -> C round trips per step."""
+        import ctypes
+
+        from .. import _lib, ops
+
+        dt, dev = h.dtype, h.device
+        B, T, C = h.shape
+        sa0 = layers[0].attention.self
+        Fi = layers[0].intermediate.dense.out_features
+        tr = self.training
+        p_att = float(sa0.dropout.p) if tr else 0.0
+        p_hid = float(layers[0].attention.output.dropout.p) if tr else 0.0
+        cols = [[] for _ in range(12)]
+        seeds = []
+        for layer in layers:
+            att, sa = layer.attention, layer.attention.self
+            assert sa.num_attention_heads == sa0.num_attention_heads and layer.intermediate.dense.out_features == Fi
+            row = (PF.packed_cat([sa.query.weight, sa.key.weight, sa.value.weight], dt), PF.bias_cat([sa.query.bias, sa.key.bias, sa.value.bias]),
+                   PF.packed(att.output.dense.weight, dt), att.output.dense.bias, att.output.LayerNorm.weight, att.output.LayerNorm.bias,
+                   PF.packed(layer.intermediate.dense.weight, dt), layer.intermediate.dense.bias,
+                   PF.packed(layer.output.dense.weight, dt), layer.output.dense.bias, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias)
+            for c, t in zip(cols, row):
+                assert t.is_contiguous() and (t.dtype == torch.float32 or t.dtype == dt)
+                c.append(t)
+            seeds += [PF.next_seed() if p_att > 0 else 0, PF.next_seed() if p_hid > 0 else 0, PF.next_seed() if p_hid > 0 else 0]
+        h = h.contiguous()
+        out = torch.empty_like(h)
+        scratch = torch.empty(B * T * (7 * C + Fi), device=dev, dtype=dt)
+        ws = ops.workspace(dev)
+        lens = ops.i32(lengths, dev)
+        a = _lib.EncoderLayersFwdArgs()
+        a.h_in, a.h_out, a.lengths = h.data_ptr(), out.data_ptr(), lens.data_ptr()
+        tabs = [PF._ptr_table(c) for c in cols]
+        (a.qkv_wp, a.qkv_b, a.ao_wp, a.ao_b, a.ln1_g, a.ln1_b, a.i_wp, a.i_b, a.o_wp, a.o_b, a.ln2_g, a.ln2_b) = \
+            [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
+        sd = (ctypes.c_uint64 * len(seeds))(*seeds)
+        a.seeds = ctypes.cast(sd, ctypes.c_void_p)
+        a.scratch, a.scratch_bytes = scratch.data_ptr(), scratch.numel() * scratch.element_size()
+        if not torch.cuda.is_current_stream_capturing():  # (as ops.conv1d: no split-K scratch inside a graph capture)
+            a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+        a.eps, a.p_att, a.p_hid = float(layers[0].attention.output.LayerNorm.eps), p_att, p_hid
+        a.B, a.T, a.C, a.F, a.H, a.L, a.dtype = B, T, C, Fi, sa0.num_attention_heads, len(layers), ops.dtype_code(dt)
+        _lib.check(_lib.load().ptpp_encoder_layers_fwd(ctypes.byref(a), ops._stream()), "ptpp_encoder_layers_fwd")
+        return out
 
 
 class PromptEncoder(nn.Module):

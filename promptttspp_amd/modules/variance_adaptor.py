@@ -37,6 +37,20 @@ class PredictorLayer(nn.Module):
         return self.norm.forward_cl(h, lengths=lengths, out_mask=True, drop_out=self.p if self.training else 0.0)
 
 
+def _predictor_layers(layers, x, lengths, training):
+    """All PredictorLayers of a predictor: one autograd node issued by two C calls (functional.ConvLnStackFn) where the
+    layers share kernel size and dropout (every reference config), else layer by layer."""
+    l0 = layers[0]
+    convs = [l.conv for l in layers]
+    if len(layers) > 0 and all(l.kernel_size == l0.kernel_size and l.p == l0.p and l.norm.eps == l0.norm.eps for l in layers) \
+            and PF.conv_ln_stack_ok(x, convs):
+        return PF.conv_ln_stack(x, convs, [l.norm for l in layers], l0.kernel_size, l0.norm.eps, lengths, conv_act="relu",
+                                drop_out=l0.p if training else 0.0, out_mask=1)
+    for layer in layers:
+        x = layer.cl(x, lengths)
+    return x
+
+
 class Predictor(nn.Module):
     def __init__(self, channels, out_channels, kernel_size, dropout, num_layers, detach=False):
         super().__init__()
@@ -48,8 +62,7 @@ class Predictor(nn.Module):
         """(B,T,C) -> (B,T,out_channels) f32, masked."""
         if self.detach:
             x = x.detach()
-        for layer in self.layers:
-            x = layer.cl(x, lengths)
+        x = _predictor_layers(self.layers, x, lengths, self.training)
         return PF.conv1d(x, self.out_layer.weight, self.out_layer.bias, lengths=lengths, out_mask=True).float()
 
     def forward(self, x, mask):
@@ -72,8 +85,7 @@ class MDNPredictor(nn.Module):
     def cl(self, x, lengths):
         if self.detach:
             x = x.detach()
-        for layer in self.layers:
-            x = layer.cl(x, lengths)
+        x = _predictor_layers(self.layers, x, lengths, self.training)
         return self.out_layer(x)  # MDN island: float32 regardless of the compute dtype
 
     def infer_cl(self, x, lengths):
@@ -129,12 +141,19 @@ class VarianceAdaptor(nn.Module):
         h, cf0_p, vuv_p, en_p = self._frames(x, duration, flen, fmask_bt1.shape[1], fmask_bt1, log_cf0, energy)
         return h, dur_out, cf0_p, vuv_p, en_p
 
-    def infer_cl(self, x, plen, pmask_bt):
-        """Inference.  Returns (h, flen (B,) int64, fmask (B,Tf,1), log_cf0 (B,Tf), vuv, durations (B,Tp) int64)."""
+    def durations_cl(self, x, plen, pmask_bt):
+        """Integer durations (B, Tp) int64 of the most probable mixture component (variance_adaptor.py:97-102,178-181)."""
         log_d = self.duration_predictor.infer_cl(x, plen)
         dur = log_d.exp().round().clamp_min(1).long()
         if pmask_bt is not None:
             dur = dur * pmask_bt.to(dur.dtype)
+        return dur
+
+    def infer_cl(self, x, plen, pmask_bt, dur=None):
+        """Inference.  Returns (h, flen (B,) int64, fmask (B,Tf,1), log_cf0 (B,Tf), vuv, durations (B,Tp) int64).
+        ``dur``: durations computed by the caller (the f32 island of the model's bf16 mode)."""
+        if dur is None:
+            dur = self.durations_cl(x, plen, pmask_bt)
         flen = dur.sum(dim=-1)
         Tf = int(flen.max())  # host sync: the output length is data dependent (as in the reference)
         fmask = (torch.arange(Tf, device=x.device)[None, :] < flen[:, None]).unsqueeze(-1).float()

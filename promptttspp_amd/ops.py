@@ -38,16 +38,24 @@ _stream_override = None  # set by functional.wgrad_stream: launch on this raw st
 _stream_pinned = None  # set by pinned_stream(): the handle looked up once for a whole step
 
 
+# PTPP_BRANCH_STREAMS=1 (models/.../model.py): autograd then runs part of the backward on another stream -- no pinning
+_NO_PIN = bool(__import__("os").environ.get("PTPP_BRANCH_STREAMS"))
+
+
 class pinned_stream:
     """Look torch's current stream up ONCE for a region that does not switch streams (a training step: forward,
-    backward -- autograd runs the backward nodes on the forward's stream -- and the optimizer; a sampler loop)
-    instead of once per kernel launch (~2000 launches per step, 0.17 us each way plus the ctypes object).
-    ``functional.wgrad_stream`` still redirects the weight-gradient launches inside the region.  Re-entrant."""
+    backward -- autograd runs the backward nodes on the forward's stream -- and the optimizer) instead of once per
+    kernel launch (~2000 launches per step, 0.17 us each way plus the ctypes object).  ``functional.wgrad_stream`` still
+    redirects the weight-gradient launches inside the region.  Re-entrant.  NOT for regions that switch streams or
+    capture a graph (the sampler's graph capture, the vocoder's per-block side streams): torch ops would follow the
+    switch while this package's launches stayed on the pinned stream -- pinning is skipped while a capture is under way,
+    ``unpinned()`` suspends it for such a region, and ``PTPP_CHECK_PINNED_STREAM=1`` asserts on every launch that the
+    pinned handle still is torch's current stream."""
 
     def __enter__(self):
         global _stream_pinned
         self.prev = _stream_pinned
-        if _stream_pinned is None:
+        if _stream_pinned is None and not _NO_PIN and not torch.cuda.is_current_stream_capturing():
             _stream_pinned = _stream()
         return self
 
@@ -57,12 +65,32 @@ class pinned_stream:
         return False
 
 
+class unpinned:
+    """Suspend ``pinned_stream`` for a region that switches streams or captures a graph."""
+
+    def __enter__(self):
+        global _stream_pinned
+        self.prev = _stream_pinned
+        _stream_pinned = None
+        return self
+
+    def __exit__(self, *exc):
+        global _stream_pinned
+        _stream_pinned = self.prev
+        return False
+
+
+_CHECK_PINNED = bool(__import__("os").environ.get("PTPP_CHECK_PINNED_STREAM"))
+
+
 def _stream():
     """torch's current HIP stream as a raw handle (the C calls: ~0.3 us instead of ~7 us for the
     torch.cuda.current_stream() object -- this runs once per kernel launch)."""
     if _stream_override is not None:
         return _stream_override
     if _stream_pinned is not None:
+        if _CHECK_PINNED:
+            assert _stream_pinned.value == torch.cuda.current_stream().cuda_stream, "pinned_stream: torch switched streams"
         return _stream_pinned
     if _raw_stream is not None and _cur_device is not None:
         return ctypes.c_void_p(_raw_stream(_cur_device()))
@@ -218,6 +246,16 @@ def workspace(device):
     return w
 
 
+def workspace_of(device, stream_handle):
+    """The scratch of ``workspace`` that belongs to the raw stream ``stream_handle`` (a ctypes.c_void_p)."""
+    idx = device.index
+    key = (idx if idx is not None else torch.cuda.current_device(), stream_handle.value)
+    w = _ws.get(key)
+    if w is None:
+        w = _ws[key] = torch.empty(_WS_BYTES, device=device, dtype=torch.uint8)
+    return w
+
+
 _RED_BYTES = 32 * 8 * 1024  # PTPP_RED_SCRATCH_BYTES(1024), the widest supported row
 _red = {}
 
@@ -265,6 +303,28 @@ def conv1d_wgrad(x, dy, cin, cout, ks, dil, pad, lengths=None, in_mask=False, wa
         "ptpp_conv1d_wgrad",
     )
     return dw, db
+
+
+def conv1d_wgrad_batched(problems, cin, cout, ks, lengths=None, in_mask=False):
+    """Weight / bias gradients of several layers of ONE shape in one call (ptpp_conv1d_wgrad_batched).  ``problems``: list of
+    (x (B,T,cin), dy (B,T,cout) view, dw f32 (cout,cin,ks), db f32 (cout) or None, dil, pad); every dw / db is ACCUMULATED
+    into.  x / dy of all problems share their row strides."""
+    x0, dy0 = problems[0][0], problems[0][1]
+    B, T, _ = x0.shape
+    dev = x0.device
+    arr = (_lib.WgradProblem * len(problems))()
+    for i, (x, dy, dw, db, dil, pad) in enumerate(problems):
+        assert x.shape == x0.shape and dy.shape == dy0.shape and _ld_fast(x) == _ld_fast(x0) and _ld_fast(dy) == _ld_fast(dy0)
+        assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * cin * ks
+        arr[i].x, arr[i].dy, arr[i].dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+        arr[i].dbias = db.data_ptr() if db is not None else None
+        arr[i].dil, arr[i].pad = int(dil), int(pad)
+    if lengths is not None:
+        lengths = i32(lengths, dev)
+    ws = workspace(dev)
+    check(_lib.load().ptpp_conv1d_wgrad_batched(arr, len(problems), lengths.data_ptr() if lengths is not None else None, B, T, cin,
+                                                cout, ks, _ld_fast(x0), _ld_fast(dy0), 1 if in_mask else 0, dtype_code(x0.dtype),
+                                                ws.data_ptr(), _WS_BYTES, _stream()), "ptpp_conv1d_wgrad_batched")
 
 
 def epilogue_bwd(dy, y=None, lengths=None, scale=1.0, relu=False, out_mask=False, drop_p=0.0, seed=0):
@@ -363,8 +423,8 @@ def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, var
     dctx = dctx.contiguous()
     dS = torch.empty((B, heads, T, T), device=q.device, dtype=torch.float32)
     dpos = du = dvb = None
-    if variant == "new":
-        dpos = torch.empty((2 * T - 1, C), device=q.device, dtype=torch.float32)
+    if variant in ("new", "legacy"):  # (the legacy table has T rows, the new one 2T - 1)
+        dpos = torch.empty((2 * T - 1 if variant == "new" else T, C), device=q.device, dtype=torch.float32)
         du = _acc_target(du_out, C) if du_out is not None else torch.zeros((C,), device=q.device, dtype=torch.float32)
         dvb = _acc_target(dvb_out, C) if dvb_out is not None else \
             torch.zeros((C,), device=q.device, dtype=torch.float32)

@@ -39,7 +39,8 @@ class NativeComm:
             _lib.check(self.lib.ptpp_comm_unique_id(idbuf), "ptpp_comm_unique_id")
         if world > 1:
             box = [idbuf.raw if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0, group=group)
+            src = dist.get_global_rank(group, 0) if group is not None else 0  # (src is a GLOBAL rank)
+            dist.broadcast_object_list(box, src=src, group=group)
             idbuf = ctypes.create_string_buffer(box[0], 128)
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.ptpp_comm_init(rank, world, idbuf, ctypes.byref(self.handle)), "ptpp_comm_init")
@@ -160,8 +161,10 @@ class FlatGradReducer:
         statistics travel as ONE concatenated tensor (one collective per step instead of ~40)."""
         if self.world == 1:
             return
+        # every floating-point buffer of the BatchNorm layers' owners (running statistics; the integer
+        # num_batches_tracked counters advance identically on all ranks and are left alone)
         bufs = [b for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
-                for b in (m.running_mean, m.running_var) if b is not None]
+                for b in m.buffers(recurse=False) if b is not None and b.is_floating_point()]
         if not bufs:
             return
         with torch.no_grad():
@@ -222,6 +225,12 @@ class FlatGradReducer:
         while self._next < len(self.buckets) and self._pending[self._next] == 0:
             self._launch(self._next)
             self._next += 1
+
+    def close(self):
+        """Release the native RCCL communicator (ncclCommDestroy); the trainer calls it at teardown."""
+        if self.native is not None:
+            self.native.close()
+            self.native = None
 
     def zero_grad(self):
         self.flat.zero_()

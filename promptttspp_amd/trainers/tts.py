@@ -270,6 +270,7 @@ class TTSTrainer:
                 tracker.write(epoch, clear=True)
             if per_epoch_scheduler and lr_scheduler is not None:
                 lr_scheduler.step()
+        reducer.close()  # the native RCCL communicator, when one was opened
         if world > 1:
             dist.barrier()
 

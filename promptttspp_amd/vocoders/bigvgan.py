@@ -262,7 +262,7 @@ class BigVGAN(nn.Module):
             st.wait_stream(main)
         for k, layers in enumerate(blocks):
             st = main if k == 0 else self._streams[k - 1]
-            with torch.cuda.stream(st):
+            with ops.unpinned(), torch.cuda.stream(st):  # (this package's launches must follow the stream switch)
                 xb = h
                 for li, (act1, c1, act2, c2, _) in enumerate(layers):
                     a = act1.forward_cl(xb)

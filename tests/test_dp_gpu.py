@@ -136,15 +136,15 @@ def _worker(rank, world, port):
         dist.all_gather(probes, probe)
         names_all = [n for n, p in model.named_parameters() if p.requires_grad] + \
             ["buf:" + n for n, b in model.named_buffers() if b.is_floating_point()]
-        # bit for bit in the product configuration of a gloo run (one stream).  With the side stream FORCED over gloo
-        # (second test; not a configuration any run uses: gloo stages through the host on its own copy stream) one
-        # of the runs of round 2 differed in the last bits, so that leg bounds the difference instead.
-        strict = not os.environ.get("PTPP_FORCE_ASYNC_WGRAD")
+        # bit for bit, with and without the weight-gradient side stream.  (Round 2 bounded the side-stream leg at 1e-6 after one
+        # run that differed in the last bits; what differed then was the clip factor -- the squared-gradient sum used f32
+        # atomics until ptpp_grad_sumsq_det -- not the exchange: test_no_gradient_kernel_writes_a_bucket_after_its_collective_
+        # was_issued shows that no gradient kernel of either stream runs after its bucket's collective.)
         for r in range(1, world):
-            diff = (sigs[0] - sigs[r]).abs() > (0.0 if strict else 1e-6) * sigs[0].abs().clamp_min(1e-12)
+            diff = sigs[0] != sigs[r]
             bad = [(names_all[i], float(sigs[0][i]), float(sigs[r][i])) for i in diff.nonzero().flatten().tolist()]
             assert not bad, f"rank {r} diverged from rank 0: {len(bad)} tensors, e.g. {bad[:6]}"
-            assert torch.equal(probes[0], probes[r]) if strict else torch.allclose(probes[0], probes[r], rtol=1e-5, atol=1e-7)
+            assert torch.equal(probes[0], probes[r])
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -173,3 +173,68 @@ def test_dp_training_step_two_ranks_with_the_weight_gradient_side_stream():
         _run_two_ranks()
     finally:
         del os.environ["PTPP_FORCE_ASYNC_WGRAD"]
+
+
+def test_no_gradient_kernel_writes_a_bucket_after_its_collective_was_issued():
+    """DDP's invariant (every rank applies the SAME reduced gradients) needs every kernel that writes a bucket to be
+    ordered before that bucket's collective.  One rank, the whole multi-rank machinery on (hooks, per-bucket launches from
+    the weight-gradient side stream, finish()), the collective replaced by a snapshot taken on the stream and at the point
+    the collective would run: after finish() every bucket must still equal its snapshot -- a difference is a gradient
+    kernel (of either stream) that ran after "its" all-reduce, i.e. a contribution the other ranks would never see."""
+    import torch.distributed as dist
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ["PTPP_DP_FORCE_COLLECTIVES"] = "1"
+    os.environ["PTPP_FORCE_ASYNC_WGRAD"] = "1"
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        import test_hip_acoustic as T
+        from promptttspp_amd import config
+        from promptttspp_amd import functional as PF
+        from promptttspp_amd.parallel import FlatGradReducer
+
+        dev = torch.device("cuda:0")
+        for dtype in (torch.float32, torch.bfloat16):
+            config.set_compute_dtype(dtype)
+            model, g = T._model(dev)
+            model.train()
+            batch = T._batch(g, dev)
+            params = [p for p in model.parameters() if p.requires_grad]
+            red = FlatGradReducer(params, bucket_elems=2 * 1024 * 1024)
+            assert red.collective and len(red.buckets) >= 8 and PF._direct["async"]
+            snaps = []
+
+            def fake_reduce(t, snaps=snaps):
+                snaps.append((t, t.clone()))  # on the stream, and at the point in it, where the all-reduce would be enqueued
+
+            red._reduce = fake_reduce
+            names = {id(p): n for n, p in model.named_parameters()}
+            for rep in range(3):
+                snaps.clear()
+                red.zero_grad()
+                model.decoder.injected = {"t": g["t"], "noise": g["noise"]}
+                PF.manual_seed(5 + rep)
+                model(batch)["loss"].backward()
+                red.finish()
+                torch.cuda.synchronize()
+                assert len(snaps) == len(red.buckets)
+                late = []
+                for view, snap in snaps:
+                    if not torch.equal(view, snap):
+                        off = int((view != snap).nonzero()[0]) + view.storage_offset()
+                        owner = [names[id(p)] for p in params if p.grad.storage_offset() <= off < p.grad.storage_offset() + p.numel()]
+                        late.append((owner, int((view != snap).sum())))
+                assert not late, f"{dtype}: gradient writes after the bucket's collective: {late[:8]}"
+            PF.enable_direct_grads(False)
+    finally:
+        from promptttspp_amd import config, functional as PF
+
+        PF.enable_direct_grads(False)
+        config.set_compute_dtype(torch.float32)
+        del os.environ["PTPP_DP_FORCE_COLLECTIVES"], os.environ["PTPP_FORCE_ASYNC_WGRAD"]
+        dist.destroy_process_group()

@@ -79,23 +79,47 @@ def test_bigvgan_matches_reference():
 
 
 def test_mel_front_end_restatement_against_torch_stft():
-    """n1: the numpy restatement of the log-mel front-end vs torch.stft + the package's filterbank (CPU), and the
-    package's CPU transform vs the restatement.  (Not a torchaudio pin: torchaudio is absent from this image.)"""
+    """n1: the numpy restatement of the log-mel front-end (reference transforms/mel.py:18-34 on torchaudio's MelSpectrogram,
+    conf/transforms/mel.yaml: power 1) pinned piece by piece: (1) its spectrum against torch.stft MAGNITUDES, power 1 and 2;
+    (2) its slaney scale and filterbank against the published constants / properties of Slaney's Auditory-Toolbox mel
+    scale (linear 200/3 Hz per mel below 1 kHz, 27 mels per factor 6.4 above; triangles of unit area between neighbouring
+    band edges) -- the package derives its filterbank separately (promptttspp_amd/transforms), so (3) the package's CPU
+    transform against the restatement closes the loop.  (Not a torchaudio pin: torchaudio is absent from this image.)"""
     import numpy as np
 
     from promptttspp.transforms import MelSpectrogramTransform
 
     rng = np.random.default_rng(7)
     wav = (0.3 * rng.standard_normal(24000 // 2)).astype(np.float32)
-    ref = R.mel_spectrogram_np(wav)
-    t = MelSpectrogramTransform(sample_rate=24000, n_fft=512, win_length=480, hop_length=240, f_min=63.0, f_max=12000.0,
-                                n_mels=80, norm="slaney", mel_scale="slaney")
-    mel = t(torch.from_numpy(wav)[None])[0]
-    assert mel.shape == ref.shape == (80, 51)
-    assert float((mel.double() - torch.from_numpy(ref)).abs().max()) < 2e-4   # log domain, f32 STFT vs f64
-    st = torch.stft(torch.from_numpy(wav), 512, 240, 480, torch.hann_window(480), center=True, pad_mode="reflect",
-                    return_complex=True).abs().pow(2)
-    assert st.shape[0] == 257
+    st = torch.stft(torch.from_numpy(wav).double(), 512, 240, 480, torch.hann_window(480, dtype=torch.float64), center=True,
+                    pad_mode="reflect", return_complex=True).abs()
+    for power in (1.0, 2.0):
+        spec, fb, fpts, hz2mel, mel2hz = R.mel_spectrogram_np(wav, power=power, parts=True)
+        assert spec.shape == tuple(st.shape) == (257, 51)
+        assert float((torch.from_numpy(spec) - st.pow(power)).abs().max() / st.pow(power).max()) < 1e-10   # (1) magnitudes
+        ref = R.mel_spectrogram_np(wav, power=power)
+        t = MelSpectrogramTransform(sample_rate=24000, n_fft=512, win_length=480, hop_length=240, f_min=63.0, f_max=12000.0,
+                                    n_mels=80, norm="slaney", mel_scale="slaney", power=power)
+        mel = t(torch.from_numpy(wav)[None])[0]
+        assert mel.shape == ref.shape == (80, 51)
+        assert float((mel.double() - torch.from_numpy(ref)).abs().max()) < 2e-4   # (3) log domain, f32 STFT vs f64
+    # (2) the scale: fixed points of Slaney's definition
+    assert abs(float(hz2mel(1000.0)) - 15.0) < 1e-12 and abs(float(hz2mel(200.0)) - 3.0) < 1e-12
+    assert abs(float(hz2mel(6400.0)) - 42.0) < 1e-9 and abs(float(mel2hz(42.0)) - 6400.0) < 1e-6
+    f = np.array([63.0, 500.0, 999.0, 1000.0, 1001.0, 4000.0, 12000.0])
+    assert np.allclose(mel2hz(hz2mel(f)), f, rtol=1e-12)
+    # band edges: 82 points equally spaced in mel between f_min and f_max
+    assert fpts.shape == (82,) and abs(fpts[0] - 63.0) < 1e-9 and abs(fpts[-1] - 12000.0) < 1e-6
+    assert np.allclose(np.diff(hz2mel(fpts)), np.diff(hz2mel(fpts))[0], rtol=1e-9)
+    # filterbank: non-negative triangles, filter m supported strictly inside (f[m], f[m+2]), peak of height 2 / (f[m+2] - f[m])
+    # at f[m+1] (slaney area normalisation: unit area in Hz)
+    freqs = np.linspace(0, 12000, 257)
+    assert fb.shape == (257, 80) and float(fb.min()) >= 0.0
+    for m in (0, 1, 17, 40, 79):
+        sup = freqs[fb[:, m] > 0]
+        assert sup.min() > fpts[m] and sup.max() < fpts[m + 2]
+        tri = np.interp(freqs, [fpts[m], fpts[m + 1], fpts[m + 2]], [0.0, 2.0 / (fpts[m + 2] - fpts[m]), 0.0], left=0.0, right=0.0)
+        assert np.allclose(fb[:, m], tri, atol=1e-12)
 
 
 def test_zero_state_filtfilt_restatement_against_scipy():

@@ -1,0 +1,323 @@
+"""GPU: the whole-unit drivers of the C ABI (include/ptpp.h "Whole-unit drivers") against the per-launch path they
+replace -- the same kernels in the same order, so every output and gradient must be equal BIT FOR BIT."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy((scale * np.random.default_rng(seed).standard_normal(shape)).astype(np.float32))
+
+
+def _stack_case(dev, B, T, C, L, dtype, masked, seed=0):
+    g = torch.Generator().manual_seed(100 + seed)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    h0 = r(B, T, C).to(dtype)
+    cond = r(B, T, C).to(dtype)
+    dsteps = r(B, L, C).float()
+    lengths = torch.tensor([max(3, T - 13 * i) for i in range(B)], device=dev, dtype=torch.int32) if masked else None
+    params = []
+    for l in range(L):
+        params.append([torch.nn.Parameter(t) for t in (r(2 * C, C, 3, sc=0.05), r(2 * C, sc=0.1), r(2 * C, C, 1, sc=0.06), r(2 * C, sc=0.1),
+                                                      r(2 * C, C, 1, sc=0.06), r(2 * C, sc=0.1))])
+    return h0, cond, dsteps, lengths, params
+
+
+def _run(PF, h0, cond, dsteps, lengths, params, cycle, gout):
+    h0 = h0.clone().requires_grad_(True)
+    cond = cond.clone().requires_grad_(True)
+    ds = dsteps.clone().requires_grad_(True)
+    for lp in params:
+        for p in lp:
+            p.grad = None
+    y = PF.diffnet_stack(h0, cond, ds, lengths, cycle, params)
+    y.backward(gout)
+    torch.cuda.synchronize()
+    return [y.detach(), h0.grad, cond.grad, ds.grad] + [p.grad.clone() for lp in params for p in lp]
+
+
+@pytest.mark.parametrize("B,T,C,L,dtype,masked", [
+    (3, 150, 128, 5, torch.bfloat16, True),
+    (6, 700, 256, 6, torch.bfloat16, True),      # >= 192 128-row tiles: the LDS-DMA kernels and both fused epilogues
+    (2, 97, 64, 4, torch.float32, True),         # f32 parity mode: no fused tail / gate backward, o_buf and dg_buf in use
+    (4, 333, 256, 3, torch.bfloat16, False),
+])
+def test_diffnet_stack_driver_is_bit_identical_to_the_per_launch_path(dev, monkeypatch, B, T, C, L, dtype, masked):
+    """ptpp_diffnet_stack_fwd / _bwd (reference modules/denoiser.py:69-83,136-140 and its autograd) against the loop of
+    single launches in functional.DiffNetStackFn: output, data gradients (h0, cond, step projections) and all 6 L parameter
+    gradients equal bit for bit, through autograd's own accumulation (no direct-gradient mode here)."""
+    from promptttspp_amd import functional as PF
+
+    h0, cond, dsteps, lengths, params = _stack_case(dev, B, T, C, L, dtype, masked)
+    gout = rnd(7, B, T, C).to(dev).to(dtype)
+    monkeypatch.setattr(PF, "BATCHED_WGRAD", False)  # (the batched weight gradient sums in another order: next test)
+    monkeypatch.setattr(PF, "STACK_DRIVERS", False)
+    ref = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    monkeypatch.setattr(PF, "STACK_DRIVERS", True)
+    got = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    assert len(ref) == len(got) == 4 + 6 * L
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        if i >= 4 and dtype == torch.float32:
+            # the exact-f32 weight-gradient kernel combines its row slices with f32 atomics (in both paths): last bits
+            # depend on the arrival order
+            assert torch.allclose(a, b, rtol=1e-5, atol=2e-6 * float(a.abs().max())), i
+        else:
+            assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+    assert float(ref[0].float().abs().max()) > 0 and all(float(t.float().abs().max()) > 0 for t in ref[1:4])
+
+
+@pytest.mark.parametrize("B,T,C,L", [(6, 700, 256, 8), (19, 1500, 256, 20)])
+def test_diffnet_stack_batched_weight_gradients(dev, monkeypatch, B, T, C, L):
+    """The driver's default: the 2 L weight gradients of the stack as two batched launches in which every dw element has ONE
+    owner block (ptpp_conv1d_wgrad_batched; no split-K partials).  Same sums in another order than the per-layer kernels:
+    equal to them within f32 summation noise, and -- unlike them -- bit-reproducible, bias gradients included."""
+    from promptttspp_amd import functional as PF
+
+    h0, cond, dsteps, lengths, params = _stack_case(dev, B, T, C, L, torch.bfloat16, True, seed=11)
+    gout = rnd(8, B, T, C).to(dev).bfloat16()
+    monkeypatch.setattr(PF, "STACK_DRIVERS", True)
+    monkeypatch.setattr(PF, "BATCHED_WGRAD", False)
+    ref = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    monkeypatch.setattr(PF, "BATCHED_WGRAD", True)
+    got = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    again = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    for i, (a, b, c) in enumerate(zip(ref, got, again)):
+        assert torch.equal(b, c), i                      # reproducible
+        if i < 4:
+            assert torch.equal(a, b), i                  # nothing but the weight gradients changes
+        else:
+            err = float((a.double() - b.double()).abs().max() / a.double().abs().max())
+            assert err < 2e-5, (i, err)
+
+
+@pytest.mark.parametrize("cin,cout,ks,dils,masked", [(256, 512, 3, (1, 2, 4, 8, 1, 2), False), (256, 512, 1, (1,) * 16, False),
+                                                     (128, 256, 5, (1, 1, 1, 1, 1, 1, 1, 1), True), (64, 64, 3, (1, 2), False)])
+def test_conv1d_wgrad_batched_against_the_single_problem_kernel(dev, cin, cout, ks, dils, masked):
+    """ptpp_conv1d_wgrad_batched (reference: autograd of nn.Conv1d, e.g. modules/denoiser.py:58-64) on problems of one shape:
+    accumulates into pre-filled targets exactly what ptpp_conv1d_wgrad adds, within f32 summation noise; also against
+    torch's f32 convolution backward of the same bf16-rounded operands.  (The last case is too small to batch: the entry
+    point falls back to the single-problem kernel.)"""
+    from promptttspp_amd import ops
+
+    B, T = 7, 900
+    n = len(dils)
+    lengths = torch.tensor([T - 31 * i for i in range(B)], device=dev, dtype=torch.int32) if masked else None
+    xs = [rnd(20 + i, B, T, cin).to(dev).bfloat16() for i in range(n)]
+    dy_all = rnd(50, B, T, n * cout).to(dev).bfloat16()  # strided dy views, as the DiffNet stack hands them over
+    init_w = [rnd(70 + i, cout, cin, ks).to(dev) * 0.1 for i in range(n)]
+    init_b = [rnd(90 + i, cout).to(dev) * 0.1 for i in range(n)]
+    got_w, got_b = [t.clone() for t in init_w], [t.clone() for t in init_b]
+    probs = []
+    for i, d in enumerate(dils):
+        pad = (ks - 1) * d // 2
+        probs.append((xs[i], dy_all[:, :, i * cout:(i + 1) * cout], got_w[i], got_b[i], d, pad))
+    ops.conv1d_wgrad_batched(probs, cin, cout, ks, lengths=lengths, in_mask=masked)
+    for i, d in enumerate(dils):
+        pad = (ks - 1) * d // 2
+        dy = dy_all[:, :, i * cout:(i + 1) * cout]
+        w1, b1 = init_w[i].clone(), init_b[i].clone()
+        ops.conv1d_wgrad(xs[i], dy, cin, cout, ks, d, pad, lengths, masked, True, dw_out=w1, db_out=b1)
+        for a, b in ((w1, got_w[i]), (b1, got_b[i])):
+            err = float((a.double() - b.double()).abs().max() / a.double().abs().max())
+            assert err < 2e-5, (i, err)
+        if i == 0:  # torch: gradient of conv1d w.r.t. weight / bias for upstream gradient dy
+            x32 = xs[i].float()
+            if masked:
+                x32 = x32 * (torch.arange(T, device=dev)[None, :, None] < lengths[:, None, None])
+            w = torch.zeros(cout, cin, ks, device=dev, requires_grad=True)
+            bb = torch.zeros(cout, device=dev, requires_grad=True)
+            y = torch.nn.functional.conv1d(x32.transpose(1, 2), w, bb, padding=pad, dilation=d)
+            y.backward(dy.float().transpose(1, 2))
+            for ref, g, ini in ((w.grad, got_w[i], init_w[i]), (bb.grad, got_b[i], init_b[i])):
+                err = float(((g - ini).double() - ref.double()).abs().max() / ref.double().abs().max())
+                assert err < 1e-4, err
+
+
+@pytest.mark.parametrize("B,T,dtype", [(3, 200, torch.bfloat16), (20, 640, torch.bfloat16), (2, 50, torch.float32)])
+def test_diffnet_stack_driver_inference_forward(dev, monkeypatch, B, T, dtype):
+    """The no-save form the sampler calls once per reverse-diffusion step (two ping-pong slabs; bf16: the gate fused into
+    the dilated conv's epilogue, conditioner projections in gate order) against the per-launch loop."""
+    from promptttspp_amd import functional as PF
+
+    C, L = 256, 8
+    h0, cond, dsteps, _, params = _stack_case(dev, B, T, C, L, dtype, False, seed=3)
+    with torch.no_grad():
+        ws, bs = [p[2] for p in params], [p[3] for p in params]
+        cond_all, _ = PF.diffnet_cond_all(cond, ws, bs, gate_perm=PF.diffnet_fused_gate(dtype))
+        weights = [(p[0], p[1], p[4], p[5]) for p in params]
+        monkeypatch.setattr(PF, "STACK_DRIVERS", False)
+        ref, _ = PF.diffnet_stack_forward(h0, cond_all, dsteps, weights, None, 4, save=False)
+        monkeypatch.setattr(PF, "STACK_DRIVERS", True)
+        got, saved = PF.diffnet_stack_forward(h0, cond_all, dsteps, weights, None, 4, save=False)
+    assert saved is None and torch.equal(ref, got) and float(ref.abs().max()) > 0
+
+
+def test_diffnet_stack_driver_direct_gradients_on_the_side_stream(dev, monkeypatch):
+    """Direct-accumulation mode (the trainer's): the driver forks the weight-gradient launches onto the side stream and adds
+    into ``p.grad`` views of a flat buffer; equal to the per-launch path in the same mode, and the buffer is complete after
+    the join."""
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd.parallel import FlatGradReducer
+
+    B, T, C, L = 5, 500, 256, 4
+    h0, cond, dsteps, lengths, params = _stack_case(dev, B, T, C, L, torch.bfloat16, True, seed=5)
+    flat_params = [p for lp in params for p in lp]
+    gout = rnd(9, B, T, C).to(dev).bfloat16()
+    outs = []
+    monkeypatch.setattr(PF, "BATCHED_WGRAD", False)  # same summation order as the per-launch path
+    try:
+        red = FlatGradReducer(flat_params)
+        assert PF.direct_grads_enabled()
+        for drivers in (False, True):
+            monkeypatch.setattr(PF, "STACK_DRIVERS", drivers)
+            red.zero_grad()
+            y = PF.diffnet_stack(h0.clone().requires_grad_(True), cond, dsteps, lengths, 4, params)
+            y.backward(gout)
+            red.finish()
+            torch.cuda.synchronize()
+            outs.append((y.detach().clone(), red.flat.clone()))
+    finally:
+        PF.enable_direct_grads(False)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype,train", [(torch.float32, False), (torch.bfloat16, True), (torch.bfloat16, False)])
+def test_frozen_encoder_layers_driver_is_bit_identical(dev, monkeypatch, dtype, train):
+    """ptpp_encoder_layers_fwd (the 11 frozen BERT layers of the prompt encoder, reference modules/prompt_encoder.py:25-38
+    / transformers BertLayer) against the per-launch ``_frozen_layer`` loop: the CLS state is equal bit for bit, in eval mode
+    and in train mode with all three dropout sites on (same seeds), f32 and bf16; f32 eval also against the fixture generated
+    from transformers' BertModel."""
+    from conftest import key_shapes, load_golden, rel_err
+    from test_oracle_golden_am import synth_sd
+
+    from promptttspp_amd import config
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd.modules.prompt_encoder import BertWrapper
+
+    g = load_golden("bert")
+    bw = BertWrapper("bert-base-uncased")
+    bw.model.load_state_dict(synth_sd(key_shapes(g["keys"]), 80), strict=False)
+    bw = bw.to(dev)
+    bw.train(train)
+    ids, am = g["ids"].to(dev), g["am"].to(dev)
+    old = config.compute_dtype()
+    config.set_compute_dtype(dtype)
+    try:
+        outs = []
+        for drivers in (False, True):
+            monkeypatch.setattr(PF, "STACK_DRIVERS", drivers)
+            PF.manual_seed(77)
+            with torch.no_grad():
+                outs.append(bw((ids, am), dev).clone())
+    finally:
+        config.set_compute_dtype(old)
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
+    if dtype == torch.float32 and not train:
+        assert rel_err(outs[1].cpu(), g["cls"]) < 1e-4
+
+
+def _module_grads(mod, run, x, gout):
+    xin = x.clone().requires_grad_(True)
+    for p in mod.parameters():
+        p.grad = None
+    y = run(mod, xin)
+    y.backward(gout)
+    torch.cuda.synchronize()
+    return [y.detach().clone(), xin.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
+
+
+@pytest.mark.parametrize("kind,dtype,B,T", [("pitch", torch.bfloat16, 5, 700), ("pitch", torch.float32, 3, 90),
+                                            ("frame_prior", torch.bfloat16, 5, 700), ("frame_prior", torch.float32, 2, 120),
+                                            ("frame_prior", torch.bfloat16, 3, 300)])
+def test_conv_ln_stack_driver_is_bit_identical(dev, monkeypatch, kind, dtype, B, T):
+    """ptpp_conv_ln_stack_fwd / _bwd against the chains of Conv1dFn / LayerNormFn nodes they replace, in train mode with
+    dropout on (same seeds): the pitch predictor's layers (reference modules/variance_adaptor.py:23-62: conv k5 -> ReLU -> LN ->
+    dropout 0.5 -> mask) and the frame prior network (modules/frame_prior.py:76-89: x = LN(x + dropout(gelu(conv k17(x * mask))))):
+    output, input gradient and every parameter gradient equal bit for bit (exact-f32 weight gradients: atomics, 1e-5)."""
+    from promptttspp_amd import config
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd.modules.frame_prior import FramePriorNetwork
+    from promptttspp_amd.modules.variance_adaptor import Predictor
+
+    torch.manual_seed(3)
+    C = 256
+    if kind == "pitch":
+        mod = Predictor(C, 2, 5, 0.5, 5).to(dev).train()
+        run = lambda m, x: m.cl(x, lengths)  # noqa: E731
+        gout = rnd(5, B, T, 2).to(dev)
+    else:
+        mod = FramePriorNetwork(C, C, 6, 17, 0.1).to(dev).train()
+        run = lambda m, x: m.forward_cl(x, lengths)  # noqa: E731
+        gout = rnd(5, B, T, C).to(dev).to(dtype)
+    for p in mod.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    lengths = torch.tensor([max(8, T - 37 * i) for i in range(B)], device=dev, dtype=torch.int32)
+    x = rnd(6, B, T, C).to(dev).to(dtype)
+    x = x * (torch.arange(T, device=dev)[None, :, None] < lengths[:, None, None])
+    old = config.compute_dtype()
+    config.set_compute_dtype(dtype)
+    monkeypatch.setattr(PF, "BATCHED_WGRAD", False)
+    try:
+        outs = []
+        for drivers in (False, True):
+            monkeypatch.setattr(PF, "STACK_DRIVERS", drivers)
+            PF.manual_seed(99)
+            outs.append(_module_grads(mod, run, x, gout))
+    finally:
+        config.set_compute_dtype(old)
+    names = ["y", "dx"] + [n for n, _ in mod.named_parameters()]
+    assert len(outs[0]) == len(outs[1]) == len(names)
+    for n, a, b in zip(names, *outs):
+        assert a.shape == b.shape and a.dtype == b.dtype and float(a.float().abs().max()) > 0, n
+        if dtype == torch.float32 and n not in ("y", "dx"):
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * float(a.abs().max())), n   # f32 weight-gradient kernel: atomics
+        elif "gamma" in n or "beta" in n:
+            # LayerNorm parameter gradients: per-block totals meet in the 32 replicas of the reduction scratch through f32
+            # atomics (include/ptpp.h "Reduction scratch"), in both paths: last bits depend on the arrival order
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * float(a.abs().max())), n
+        else:
+            assert torch.equal(a, b), (n, float((a.float() - b.float()).abs().max()))
+
+
+def test_conv_ln_stack_batched_weight_gradients(dev, monkeypatch):
+    """Frame prior network at the bench shape with the batched weight gradient (6 layers x 24 tiles: one launch, no split-K
+    partials): everything but the conv weight / bias gradients is unchanged, those agree within f32 summation noise and
+    are bit-reproducible."""
+    from promptttspp_amd import config
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd.modules.frame_prior import FramePriorNetwork
+
+    torch.manual_seed(4)
+    B, T, C = 19, 1500, 256
+    mod = FramePriorNetwork(C, C, 6, 17, 0.1).to(dev).train()
+    lengths = torch.tensor([T - 29 * i for i in range(B)], device=dev, dtype=torch.int32)
+    x = rnd(6, B, T, C).to(dev).bfloat16() * (torch.arange(T, device=dev)[None, :, None] < lengths[:, None, None])
+    gout = rnd(5, B, T, C).to(dev).bfloat16()
+    run = lambda m, xx: m.forward_cl(xx, lengths)  # noqa: E731
+    old = config.compute_dtype()
+    config.set_compute_dtype(torch.bfloat16)
+    monkeypatch.setattr(PF, "STACK_DRIVERS", True)
+    try:
+        outs = []
+        for batched in (False, True, True):
+            monkeypatch.setattr(PF, "BATCHED_WGRAD", batched)
+            PF.manual_seed(99)
+            outs.append(_module_grads(mod, run, x, gout))
+    finally:
+        config.set_compute_dtype(old)
+    names = ["y", "dx"] + [n for n, _ in mod.named_parameters()]
+    for n, a, b, c in zip(names, *outs):
+        if n.startswith("convs"):
+            assert torch.equal(b, c), n                  # reproducible
+            err = float((a.double() - b.double()).abs().max() / a.double().abs().max())
+            assert err < 2e-5, (n, err)
+        elif "gamma" in n or "beta" in n:                # (atomics in the reduction scratch, see above)
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * float(a.abs().max())), n
+        else:
+            assert torch.equal(a, b) and torch.equal(b, c), n

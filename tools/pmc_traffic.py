@@ -32,7 +32,7 @@ for k in sorted(set(fetch) & set(write), key=lambda k: -(fetch[k][0] * fetch[k][
 if len(sys.argv) > 5:
     npass = int(sys.argv[5])
     out["passes_of_the_workload"] = npass
-    out["collected"] = ("round 2, MI355X, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace "
+    out["collected"] = ("MI355X, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace "
                         "(tools/pmc_traffic.py)")
     out["total_traffic_bytes_per_pass"] = round(sum(v["traffic_bytes"] * v["launches"] for v in out["kernels"].values()) / npass)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
