@@ -135,14 +135,19 @@ __device__ __forceinline__ void wait_vm() {
 template <int FM, int FN, int WR, int WC, int TG, int XH, bool BATCH, int NS>
 __device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__ lengths, const WgBatch* __restrict__ batch);
 
+// launch bounds: the second argument (minimum waves per SIMD) caps the allocation at 256 registers per lane.  Without it a
+// 256-thread kernel may use all 512, the compiler then selects the AGPR form of the MFMAs while keeping the accumulator
+// arrays in VGPRs, and EVERY MFMA of the 4-wave kernels was wrapped in four v_accvgpr_write, four v_accvgpr_read and their
+// s_nops (16 moves per MFMA in the disassembly of round 2's <4, 4, 2, 2, 1, 0>: SQ_ACTIVE_INST_ANY 52 % of the wave cycles
+// at 8 % MFMA-busy, profiles/r03_pmc_wgrad.txt) -- the 512-thread tap-group kernel never had them.
 template <int FM, int FN, int WR = 2, int WC = 2, int TG = 1, int XH = 0>
-__global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_kernel(const WgP p, const int* __restrict__ lengths) {
+__global__ __launch_bounds__(WR * WC * 64, 2) void conv1d_wgrad_bf16_kernel(const WgP p, const int* __restrict__ lengths) {
   wgrad_body<FM, FN, WR, WC, TG, XH, false, NS_DEFAULT>(p, lengths, nullptr);
 }
 // NS: a one-owner block walks ALL rows alone on its CU (the grid is <= 1 block per CU), so the ring is as deep as LDS allows:
 // Little's law at ~1-2 us of loaded memory latency wants ~100 KB in flight per CU, the 4-stage ring holds 48-72 KB
 template <int FM, int FN, int WR = 2, int WC = 2, int TG = 1, int XH = 0, int NS = NS_DEFAULT>
-__global__ __launch_bounds__(WR * WC * 64) void conv1d_wgrad_bf16_batched_kernel(const WgP p, const int* __restrict__ lengths,
+__global__ __launch_bounds__(WR * WC * 64, 2) void conv1d_wgrad_bf16_batched_kernel(const WgP p, const int* __restrict__ lengths,
                                                                                  const WgBatch batch) {
   wgrad_body<FM, FN, WR, WC, TG, XH, true, NS>(p, lengths, &batch);
 }

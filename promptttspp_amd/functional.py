@@ -275,14 +275,36 @@ def create_side_stream(device=None):
     return _direct["side"]
 
 
+_grad_streams = []  # streams besides the caller's that run backward nodes (the model's branch streams)
+
+
+def register_gradient_stream(stream):
+    """A stream on which autograd will run part of the backward (a branch of the forward issued on it): a bucket
+    collective must be ordered after the gradient kernels of ALL such streams, not only of the one whose node reported
+    the bucket's last parameter."""
+    if all(s is not stream for s in _grad_streams):
+        _grad_streams.append(stream)
+
+
 def side_stream_for_collective():
-    """The weight-gradient side stream, made to wait for everything enqueued on the current stream so far --
-    or None when it is not in use.  A collective issued under ``torch.cuda.stream(<it>)`` is then ordered
-    after every gradient kernel of both streams without stalling the current one."""
+    """The weight-gradient side stream, made to wait for everything enqueued so far on the current stream and on every
+    registered gradient stream -- or None when it is not in use.  A collective issued under ``torch.cuda.stream(<it>)`` is
+    then ordered after every gradient kernel of all streams without stalling the current one."""
     d = _direct
     if not d["async"] or d["side"] is None:
+        if _grad_streams:  # no side stream: the collective follows the current stream, which then waits for the others
+            cur = torch.cuda.current_stream()
+            for s in _grad_streams + ([d["main"]] if d.get("main") is not None else []):
+                if s != cur:
+                    cur.wait_stream(s)
         return None
-    _lib.check(_lib.load().ptpp_stream_wait(d["side_h"], ops._stream()), "ptpp_stream_wait")
+    lib = _lib.load()
+    _lib.check(lib.ptpp_stream_wait(d["side_h"], ops._stream()), "ptpp_stream_wait")
+    for s in _grad_streams:
+        _lib.check(lib.ptpp_stream_wait(d["side_h"], ctypes.c_void_p(s.cuda_stream)), "ptpp_stream_wait")
+    main = d.get("main_h")
+    if main is not None:
+        _lib.check(lib.ptpp_stream_wait(d["side_h"], main), "ptpp_stream_wait")
     return d["side"]
 
 

@@ -29,19 +29,25 @@ from ...modules.mdn import mdn_get_most_probable_sigma_and_mu, mdn_loss, mdn_sam
 from ...utils.model import sequence_mask
 
 
-BRANCH_STREAMS = bool(os.environ.get("PTPP_BRANCH_STREAMS"))
+# "" / "0" off | "1" prompt branch | "2" prompt branch + reference encoder on their own streams (default; see forward)
+BRANCH_STREAMS = os.environ.get("PTPP_BRANCH_STREAMS", "2")
+if BRANCH_STREAMS in ("0", "off", "no"):
+    BRANCH_STREAMS = ""
 _branch = {}
 
 
-def _branch_stream(dev):
-    """One extra stream per device for the prompt branch, with a slab of its own in the caching allocator (a stream's free
-    blocks serve only that stream: without it every new batch shape grows the pool by hipMalloc inside the step)."""
-    st = _branch.get(dev)
+def _branch_stream(dev, idx=0):
+    """Extra streams per device for the independent branches of the training forward (0: prompt branch, 1: reference
+    encoder), each with a slab of its own in the caching allocator (a stream's free blocks serve only that stream: without
+    it every new batch shape grows the pool by hipMalloc inside the step -- what made round 1's multi-stream forward slower)."""
+    st = _branch.get((dev, idx))
     if st is None:
-        st = _branch[dev] = torch.cuda.Stream(device=dev)
+        st = _branch[(dev, idx)] = torch.cuda.Stream(device=dev)
+        gib = float(os.environ.get("PTPP_BRANCH_RESERVE_GIB", "2" if idx == 0 else "6"))
         with torch.cuda.stream(st):
-            slab = torch.empty(int(float(os.environ.get("PTPP_BRANCH_RESERVE_GIB", "2")) * (1 << 30)), device=dev, dtype=torch.uint8)
+            slab = torch.empty(int(gib * (1 << 30)), device=dev, dtype=torch.uint8)
             del slab
+        PF.register_gradient_stream(st)  # bucket collectives of the data-parallel reducer wait for its gradient kernels too
     return st
 
 
@@ -100,6 +106,19 @@ class PromptTTSMDNDurCFG(nn.Module):
         (phoneme, duration, phone_lengths, mel, log_cf0, vuv, energy, frame_lengths, prompt) = batch
         dev = phoneme.device
         dt = compute_dtype()
+        branches = BRANCH_STREAMS and self.training and dev.type == "cuda"
+        if branches:
+            import ctypes
+
+            PF._direct["main"] = torch.cuda.current_stream()
+            PF._direct["main_h"] = ctypes.c_void_p(PF._direct["main"].cuda_stream)
+        sa = _branch_stream(dev, 1) if (branches and BRANCH_STREAMS != "1") else None
+        if sa is not None:
+            # the reference encoder (mel -> style embedding) and the phoneme encoder are independent until x + style_emb:
+            # two chains of short launches side by side (PTPP_BRANCH_STREAMS=2)
+            sa.wait_stream(torch.cuda.current_stream())
+            with ops.unpinned(), torch.cuda.stream(sa):
+                style_emb = self._norm_style(self.reference_encoder(mel, frame_lengths))  # (B,C,1) f32
         x, plen, pmask = self._encode(phoneme, phone_lengths)
 
         Tf = mel.shape[-1]
@@ -108,11 +127,15 @@ class PromptTTSMDNDurCFG(nn.Module):
         fm1 = fmask.unsqueeze(-1).float()
         n_frames = fm1.sum()
 
-        style_emb = self._norm_style(self.reference_encoder(mel, frame_lengths))  # (B,C,1) f32
+        if sa is not None:
+            torch.cuda.current_stream().wait_stream(sa)
+            style_emb.record_stream(torch.cuda.current_stream())
+        else:
+            style_emb = self._norm_style(self.reference_encoder(mel, frame_lengths))  # (B,C,1) f32
         # The prompt branch (BERT -> adaptor -> style MDN head) feeds nothing but loss_style in training (model.py:147-163):
-        # an independent chain of ~100 short launches.  PTPP_BRANCH_STREAMS=1 issues it -- forward here, backward by
-        # autograd on the same stream -- beside the main chain (experiment)
-        bs = _branch_stream(dev) if (BRANCH_STREAMS and self.training and dev.type == "cuda") else None
+        # an independent chain of ~100 short launches, issued -- forward here, backward by autograd on the same stream --
+        # beside the main chain (PTPP_BRANCH_STREAMS)
+        bs = _branch_stream(dev, 0) if branches else None
         if bs is not None:
             bs.wait_stream(torch.cuda.current_stream())
             with ops.unpinned(), torch.cuda.stream(bs):

@@ -38,8 +38,9 @@ _stream_override = None  # set by functional.wgrad_stream: launch on this raw st
 _stream_pinned = None  # set by pinned_stream(): the handle looked up once for a whole step
 
 
-# PTPP_BRANCH_STREAMS=1 (models/.../model.py): autograd then runs part of the backward on another stream -- no pinning
-_NO_PIN = bool(__import__("os").environ.get("PTPP_BRANCH_STREAMS"))
+# Branch streams (models/.../model.py, PTPP_BRANCH_STREAMS, on by default): autograd runs part of the backward on other
+# streams, so the per-step pinning of the stream handle is off unless they are disabled
+_NO_PIN = __import__("os").environ.get("PTPP_BRANCH_STREAMS", "2") not in ("", "0", "off", "no")
 
 
 class pinned_stream:

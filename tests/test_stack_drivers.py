@@ -321,3 +321,50 @@ def test_conv_ln_stack_batched_weight_gradients(dev, monkeypatch):
             assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * float(a.abs().max())), n
         else:
             assert torch.equal(a, b) and torch.equal(b, c), n
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_branch_streams_give_the_same_losses_and_gradients(dev, monkeypatch, mode):
+    """PTPP_BRANCH_STREAMS: the prompt branch (mode 1) and the reference encoder (mode 2) of the TRAINING forward on their
+    own streams -- forward here, backward by autograd on the same streams -- against the single-stream step on the same
+    weights, batch and dropout seeds (f32, reference model.py:72-183): the six losses are equal bit for bit, every parameter
+    gradient within the noise of the order-dependent reductions (a missed cross-stream dependency would show as a wrong or
+    missing gradient, orders of magnitude above that), three times in a row."""
+    import test_hip_acoustic as T
+
+    from promptttspp_amd import config
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd import ops
+    from promptttspp_amd.models.prompttts_mdn_v2_final import model as M
+
+    old = config.compute_dtype()
+    config.set_compute_dtype(torch.float32)
+    try:
+        m, g = T._model(dev)
+        m.train()
+        batch = T._batch(g, dev)
+
+        def run():
+            for p in m.parameters():
+                p.grad = None
+            m.decoder.injected = {"t": g["t"], "noise": g["noise"]}
+            PF.manual_seed(321)
+            torch.manual_seed(5)
+            out = m(batch)
+            out["loss"].backward()
+            torch.cuda.synchronize()
+            return {k: float(v) for k, v in out.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+        monkeypatch.setattr(M, "BRANCH_STREAMS", "")
+        ref_l, ref_g = run()
+        monkeypatch.setattr(M, "BRANCH_STREAMS", mode)
+        monkeypatch.setattr(ops, "_NO_PIN", True)
+        for rep in range(3):
+            got_l, got_g = run()
+            assert got_l == ref_l, (rep, got_l, ref_l)
+            assert got_g.keys() == ref_g.keys()
+            for n in ref_g:
+                a, b = ref_g[n], got_g[n]
+                assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()) + 1e-12), (rep, n, float((a - b).abs().max()))
+    finally:
+        config.set_compute_dtype(old)
