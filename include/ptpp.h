@@ -635,6 +635,77 @@ typedef struct {
 } ptpp_conv_ln_stack_bwd_args;
 int ptpp_conv_ln_stack_bwd(const ptpp_conv_ln_stack_bwd_args* a, void* stream);
 
+/* y (dtype, n elements, n % 4 == 0) = x (f32), round to nearest even */
+int ptpp_cast_from_f32(const float* x, void* y, int64_t n, int dtype, void* stream);
+
+/* One Conformer encoder block (reference modules/esp/conformer/encoder_layer.py:74-162 with the configuration of
+ * prompttts_mdn_v2_wo_erg_final.yaml: macaron conv1d feed-forward pair, relative-position self-attention, convolution module,
+ * normalize_before, final LayerNorm), forward and hand-derived backward, as TWO calls per block.  The launches, their order,
+ * arguments and dropout seeds are those of the per-launch path (promptttspp_amd/modules/esp/__init__.py::EncoderLayer.cl and
+ * the autograd Functions behind it): results are bit-identical to it.
+ *   x1 = x  + 0.5 drop(ffn_macaron(LN0(x)))        ffn(v) = mask w2(drop'(mask relu(w1(mask v))))   (k = 9 convs)
+ *   x2 = x1 + drop(mask out(attn(qkv(LN1(x1)), pos_w(pos_emb), u, v)))
+ *   x3 = x2 + drop(mask pw2(swish(BN(dwconv(glu(mask pw1(LN2(x2))))))))
+ *   x4 = x3 + 0.5 drop(ffn(LN3(x3)));   y = mask LN4(x4)
+ * Weights: packed operands of the compute dtype (ptpp_pack_conv_weight; qkv = the three projections concatenated), biases /
+ * norm parameters / pos_bias_u, v / depthwise taps (C, ks) in f32.  slab: everything the backward re-reads, laid out by
+ * the library (ptpp_conformer_block_slab_bytes); scratch (backward): ptpp_conformer_block_bwd_scratch_bytes. */
+typedef struct {
+  const float* ln_g[5]; const float* ln_b[5];   /* 0 ff_macaron, 1 mha, 2 conv, 3 ff, 4 final */
+  const void* ffm_w1; const float* ffm_b1; const void* ffm_w2; const float* ffm_b2;
+  const void* ff_w1; const float* ff_b1; const void* ff_w2; const float* ff_b2;
+  const void* qkv_w; const float* qkv_b; const void* pos_w; const void* out_w; const float* out_b;
+  const float* bias_u; const float* bias_v;
+  const void* pw1_w; const float* pw1_b; const void* pw2_w; const float* pw2_b;
+  const float* dw_w; const float* dw_b; const float* bn_g; const float* bn_b;
+  float* bn_rmean; float* bn_rvar;              /* running estimates, updated when bn_train */
+  const float* bn_mean_in; const float* bn_rstd_in;  /* statistics to use when !bn_train */
+} ptpp_conformer_weights;
+
+typedef struct {
+  const void* x; void* y;                       /* (B, T, C) in / out */
+  const void* pos_emb;                          /* (L, C) relative-position table: L = 2T-1 (new) or T (legacy) */
+  const int32_t* lengths;
+  ptpp_conformer_weights w;
+  void* slab; size_t slab_bytes;
+  void* ws; size_t ws_bytes;                    /* split-K scratch of ptpp_conv1d_fwd_ws */
+  void* red_scratch; size_t red_bytes;          /* reduction scratch (BatchNorm statistics) */
+  const uint64_t* seeds;                        /* HOST [6]: ffm w1, ffm w2, attention out, pw2, ff w1, ff w2 */
+  float p_ffn, p_drop, bn_momentum, bn_eps;
+  int32_t B, T, C, F, H, L, ks_ffn, ks_dw, variant, bn_train, save, dtype;
+} ptpp_conformer_block_fwd_args;
+size_t ptpp_conformer_block_slab_bytes(int B, int T, int C, int F, int H, int L, int dtype);
+int ptpp_conformer_block_fwd(const ptpp_conformer_block_fwd_args* a, void* stream);
+
+typedef struct {            /* accumulation targets (f32), one per parameter tensor */
+  float* ln_g[5]; float* ln_b[5];
+  float* ffm_w1; float* ffm_b1; float* ffm_w2; float* ffm_b2;
+  float* ff_w1; float* ff_b1; float* ff_w2; float* ff_b2;
+  float* q_w; float* q_b; float* k_w; float* k_b; float* v_w; float* v_b;
+  float* pos_w; float* out_w; float* out_b; float* bias_u; float* bias_v;
+  float* pw1_w; float* pw1_b; float* pw2_w; float* pw2_b;
+  float* dw_w; float* dw_b;  /* ZERO-FILLED (C, ks) / (C): the depthwise kernel accumulates with atomics */
+  float* bn_sums;            /* (2C) overwritten: [dbeta | dgamma] */
+} ptpp_conformer_grads;
+
+typedef struct {
+  const void* gy; void* gx;                     /* gradient w.r.t. y in, w.r.t. x out */
+  const void* x; const void* pos_emb; const int32_t* lengths;
+  ptpp_conformer_weights w;                     /* forward operands (norm parameters, u, v, depthwise taps) */
+  const void* ffm_w1t; const void* ffm_w2t; const void* ff_w1t; const void* ff_w2t;   /* mode-1 packed operands */
+  const void* qkv_wt; const void* out_wt; const void* pw1_wt; const void* pw2_wt;
+  ptpp_conformer_grads g;
+  const void* slab; void* scratch; size_t scratch_bytes;
+  void* ws_main; size_t ws_main_bytes; void* ws_side; size_t ws_side_bytes;
+  void* red_scratch; size_t red_bytes;
+  void* side_stream;                            /* weight gradients fork onto it when not NULL */
+  const uint64_t* seeds;
+  float p_ffn, p_drop;
+  int32_t B, T, C, F, H, L, ks_ffn, ks_dw, variant, bn_train, dtype;
+} ptpp_conformer_block_bwd_args;
+size_t ptpp_conformer_block_bwd_scratch_bytes(int B, int T, int C, int F, int H, int L, int dtype);
+int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Data-parallel gradient exchange over RCCL / xGMI (reference: DistributedDataParallel set up in
  * trainers/tts.py:52-55 (init_process_group("nccl")) and :117 (DDP(model, device_ids=[rank])), whose

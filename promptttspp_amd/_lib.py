@@ -111,6 +111,53 @@ class ConvLnBwdArgs(Structure):
                                        "batched_wgrad")]
 
 
+_CF_W = ["ln_g0", "ln_g1", "ln_g2", "ln_g3", "ln_g4", "ln_b0", "ln_b1", "ln_b2", "ln_b3", "ln_b4",
+         "ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "ff_w1", "ff_b1", "ff_w2", "ff_b2",
+         "qkv_w", "qkv_b", "pos_w", "out_w", "out_b", "bias_u", "bias_v",
+         "pw1_w", "pw1_b", "pw2_w", "pw2_b", "dw_w", "dw_b", "bn_g", "bn_b", "bn_rmean", "bn_rvar", "bn_mean_in", "bn_rstd_in"]
+
+
+class ConformerWeights(Structure):
+    """Mirror of ``ptpp_conformer_weights`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in _CF_W]
+
+
+_CF_G = ["ln_g0", "ln_g1", "ln_g2", "ln_g3", "ln_g4", "ln_b0", "ln_b1", "ln_b2", "ln_b3", "ln_b4",
+         "ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "ff_w1", "ff_b1", "ff_w2", "ff_b2",
+         "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "pos_w", "out_w", "out_b", "bias_u", "bias_v",
+         "pw1_w", "pw1_b", "pw2_w", "pw2_b", "dw_w", "dw_b", "bn_sums"]
+
+
+class ConformerGrads(Structure):
+    """Mirror of ``ptpp_conformer_grads`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in _CF_G]
+
+
+class ConformerFwdArgs(Structure):
+    """Mirror of ``ptpp_conformer_block_fwd_args`` (include/ptpp.h)."""
+
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("pos_emb", c_void_p), ("lengths", c_void_p), ("w", ConformerWeights),
+                ("slab", c_void_p), ("slab_bytes", ctypes.c_size_t), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t),
+                ("red_scratch", c_void_p), ("red_bytes", ctypes.c_size_t), ("seeds", c_void_p),
+                ("p_ffn", c_float), ("p_drop", c_float), ("bn_momentum", c_float), ("bn_eps", c_float)] + \
+               [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "ks_ffn", "ks_dw", "variant", "bn_train", "save", "dtype")]
+
+
+class ConformerBwdArgs(Structure):
+    """Mirror of ``ptpp_conformer_block_bwd_args`` (include/ptpp.h)."""
+
+    _fields_ = [("gy", c_void_p), ("gx", c_void_p), ("x", c_void_p), ("pos_emb", c_void_p), ("lengths", c_void_p),
+                ("w", ConformerWeights)] + \
+               [(n, c_void_p) for n in ("ffm_w1t", "ffm_w2t", "ff_w1t", "ff_w2t", "qkv_wt", "out_wt", "pw1_wt", "pw2_wt")] + \
+               [("g", ConformerGrads), ("slab", c_void_p), ("scratch", c_void_p), ("scratch_bytes", ctypes.c_size_t),
+                ("ws_main", c_void_p), ("ws_main_bytes", ctypes.c_size_t), ("ws_side", c_void_p), ("ws_side_bytes", ctypes.c_size_t),
+                ("red_scratch", c_void_p), ("red_bytes", ctypes.c_size_t), ("side_stream", c_void_p), ("seeds", c_void_p),
+                ("p_ffn", c_float), ("p_drop", c_float)] + \
+               [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "ks_ffn", "ks_dw", "variant", "bn_train", "dtype")]
+
+
 P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/ptpp.h declares.
@@ -173,6 +220,11 @@ SIGNATURES = {
     "ptpp_diffnet_stack_bwd": (I, [POINTER(DiffNetBwdArgs), P]),
     "ptpp_conv_ln_stack_fwd": (I, [POINTER(ConvLnFwdArgs), P]),
     "ptpp_conv_ln_stack_bwd": (I, [POINTER(ConvLnBwdArgs), P]),
+    "ptpp_cast_from_f32": (I, [P, P, I64, I, P]),
+    "ptpp_conformer_block_slab_bytes": (SZ, [I, I, I, I, I, I, I]),
+    "ptpp_conformer_block_bwd_scratch_bytes": (SZ, [I, I, I, I, I, I, I]),
+    "ptpp_conformer_block_fwd": (I, [POINTER(ConformerFwdArgs), P]),
+    "ptpp_conformer_block_bwd": (I, [POINTER(ConformerBwdArgs), P]),
     "ptpp_encoder_layers_fwd": (I, [POINTER(EncoderLayersFwdArgs), P]),
     "ptpp_comm_unique_id": (I, [P]),
     "ptpp_comm_init": (I, [I, I, P, POINTER(c_void_p)]),

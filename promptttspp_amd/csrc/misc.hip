@@ -15,6 +15,13 @@ __global__ void add3_scale_kernel(const T* __restrict__ a, const T* __restrict__
   }
 }
 
+// y (dtype) = x (f32), 4 elements per thread
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    Elem<T>::st4(y + i * 4, *reinterpret_cast<const f32x4*>(x + i * 4));
+}
+
 // conv_post (Cout = 1) + tanh: one thread per output sample, the ks*C taps live
 // in LDS; x rows are re-read by neighbouring threads out of L1/L2.
 template <typename T>
@@ -59,6 +66,18 @@ extern "C" int ptpp_add3_scale(const void* a, const void* b, const void* c, void
   else
     PTPP_CHECK_ARG(false, "add3_scale: bad dtype");
   PTPP_CHECK_LAUNCH("add3_scale");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_cast_from_f32(const float* x, void* y, int64_t n, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "cast_from_f32: bad args");
+  const int64_t n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PTPP_F32) hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)y, n4);
+  else if (dtype == PTPP_BF16) hipLaunchKernelGGL(cast_from_f32_kernel<bf16_raw>, dim3(grid), dim3(256), 0, st, x, (bf16_raw*)y, n4);
+  else PTPP_CHECK_ARG(false, "cast_from_f32: bad dtype");
+  PTPP_CHECK_LAUNCH("cast_from_f32");
   return PTPP_OK;
 }
 

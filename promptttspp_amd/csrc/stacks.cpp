@@ -311,3 +311,244 @@ extern "C" int ptpp_conv_ln_stack_bwd(const ptpp_conv_ln_stack_bwd_args* a, void
   }
   return PTPP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Conformer encoder block (include/ptpp.h).  Slab / scratch layouts are private to this file.
+namespace {
+
+struct CfLayout {  // byte offsets into the forward slab
+  size_t n1, h1, x1, n2, qkv, pp, ctx, x2, n3, g, u, d, bno, x3, n4, h2, x4, probs, stats, bnstat, total;
+};
+CfLayout cf_layout(int B, int T, int C, int F, int H, int L, int dt) {
+  const size_t R = (size_t)B * T, es = esize(dt);
+  CfLayout o;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at_ = off; off += (bytes + 255) & ~(size_t)255; return at_; };
+  o.n1 = take(R * C * es); o.h1 = take(R * F * es); o.x1 = take(R * C * es); o.n2 = take(R * C * es);
+  o.qkv = take(R * 3 * C * es); o.pp = take((size_t)L * C * es); o.ctx = take(R * C * es); o.x2 = take(R * C * es);
+  o.n3 = take(R * C * es); o.g = take(R * 2 * C * es); o.u = take(R * C * es); o.d = take(R * C * es);
+  o.bno = take(R * C * es); o.x3 = take(R * C * es); o.n4 = take(R * C * es); o.h2 = take(R * F * es); o.x4 = take(R * C * es);
+  o.probs = take((size_t)B * H * T * T * 4); o.stats = take(10 * R * 4); o.bnstat = take(2 * (size_t)C * 4);
+  o.total = off;
+  return o;
+}
+struct CfScratch {  // byte offsets into the backward scratch.  Every tensor a weight-gradient launch reads (dz*) has a region of
+                    // its own: those launches run on the side stream while the main stream moves on, so nothing may overwrite
+                    // their operands before the caller joins the streams
+  size_t gA, gB, gC, t1, t2, gF, dqkv, g2a, dposc, dS, dpos, dz_c[5], dz_f[2], dz_2c, total;
+};
+CfScratch cf_scratch(int B, int T, int C, int F, int H, int L, int dt) {
+  const size_t R = (size_t)B * T, es = esize(dt);
+  CfScratch o;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at_ = off; off += (bytes + 255) & ~(size_t)255; return at_; };
+  o.gA = take(R * C * es); o.gB = take(R * C * es); o.gC = take(R * C * es); o.t1 = take(R * C * es); o.t2 = take(R * C * es);
+  o.gF = take(R * F * es); o.dqkv = take(R * 3 * C * es); o.g2a = take(R * 2 * C * es);
+  o.dposc = take((size_t)L * C * es); o.dS = take((size_t)B * H * T * T * 4);
+  o.dpos = take((size_t)L * C * 4);
+  for (int i = 0; i < 5; ++i) o.dz_c[i] = take(R * C * es);   // ff w2, pw2, attention out, ffm w2 (+1 spare)
+  for (int i = 0; i < 2; ++i) o.dz_f[i] = take(R * F * es);   // ff w1, ffm w1
+  o.dz_2c = take(R * 2 * C * es);                             // pw1
+  o.total = off;
+  return o;
+}
+inline void* sl(void* base, size_t off) { return static_cast<char*>(base) + off; }
+inline const void* sl(const void* base, size_t off) { return static_cast<const char*>(base) + off; }
+
+int ln_fwd_plain(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, const int32_t* lengths, int B, int T,
+                 int C, int out_mask, int dt, void* stream) {
+  return ptpp_layernorm_fwd(x, nullptr, g, b, y, nullptr, mean, rstd, lengths, B, T, C, 1e-12f, out_mask, PTPP_ACT_NONE, 0.f, 0, 0.f, 0,
+                            dt, stream);
+}
+int ln_bwd_plain(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dsum, float* dg, float* db,
+                 const int32_t* lengths, int B, int T, int C, int out_mask, int dt, void* red, size_t red_bytes, void* stream) {
+  return ptpp_layernorm_bwd(dy, x, nullptr, g, mean, rstd, dsum, nullptr, dg, db, lengths, B, T, C, out_mask, PTPP_ACT_NONE, 0.f, 0, 0.f,
+                            0, dt, red, red_bytes, stream);
+}
+
+}  // namespace
+
+extern "C" size_t ptpp_conformer_block_slab_bytes(int B, int T, int C, int F, int H, int L, int dtype) {
+  return cf_layout(B, T, C, F, H, L, dtype).total;
+}
+extern "C" size_t ptpp_conformer_block_bwd_scratch_bytes(int B, int T, int C, int F, int H, int L, int dtype) {
+  return cf_scratch(B, T, C, F, H, L, dtype).total;
+}
+
+extern "C" int ptpp_conformer_block_fwd(const ptpp_conformer_block_fwd_args* a, void* stream) {
+  ST_CHECK_ARG(a && a->x && a->y && a->pos_emb && a->lengths && a->slab && a->red_scratch, "conformer_block_fwd: null pointer");
+  ST_CHECK_ARG(a->B > 0 && a->T > 0 && a->C > 0 && a->F > 0 && a->H > 0 && a->C % a->H == 0 && a->L > 0, "conformer_block_fwd: bad shape");
+  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "conformer_block_fwd: bad dtype %d", a->dtype);
+  ST_CHECK_ARG((a->p_ffn <= 0.f && a->p_drop <= 0.f) || a->seeds, "conformer_block_fwd: dropout needs seeds");
+  const int B = a->B, T = a->T, C = a->C, F = a->F, H = a->H, L = a->L, dt = a->dtype, kf = a->ks_ffn, pf = (a->ks_ffn - 1) / 2;
+  const CfLayout lo = cf_layout(B, T, C, F, H, L, dt);
+  ST_CHECK_ARG(a->slab_bytes >= lo.total, "conformer_block_fwd: slab too small (%zu bytes, need %zu)", a->slab_bytes, lo.total);
+  const ptpp_conformer_weights& w = a->w;
+  const size_t R = (size_t)B * T;
+  void* S = a->slab;
+  float* stats = static_cast<float*>(sl(S, lo.stats));
+  float* bnstat = static_cast<float*>(sl(S, lo.bnstat));
+  const int32_t* len = a->lengths;
+  const uint64_t zero6[6] = {0, 0, 0, 0, 0, 0};
+  const uint64_t* sd = a->seeds ? a->seeds : zero6;
+  auto seed = [&](int i, float p) { return p > 0.f ? sd[i] : (uint64_t)0; };
+
+  // ---- macaron feed-forward: x1 = x + 0.5 drop(mask w2(drop'(mask relu(w1(mask LN0(x)))))) ----
+  ST_TRY(ln_fwd_plain(a->x, w.ln_g[0], w.ln_b[0], sl(S, lo.n1), stats, stats + R, nullptr, B, T, C, 0, dt, stream));
+  ptpp_conv1d_args c = conv_args(sl(S, lo.n1), C, w.ffm_w1, w.ffm_b1, nullptr, 0, sl(S, lo.h1), F, len, B, T, C, F, kf, 1, pf, PTPP_ACT_RELU,
+                                 1, 1, dt);
+  ST_TRY(linear_like_ops(c, a->p_ffn, seed(0, a->p_ffn), a->ws, a->ws_bytes, stream));
+  c = conv_args(sl(S, lo.h1), F, w.ffm_w2, w.ffm_b2, a->x, C, sl(S, lo.x1), C, len, B, T, F, C, kf, 1, pf, PTPP_ACT_NONE, 0, 1, dt);
+  c.out_scale = 0.5f;
+  ST_TRY(linear_like_ops(c, a->p_drop, seed(1, a->p_drop), a->ws, a->ws_bytes, stream));
+  // ---- self-attention: x2 = x1 + drop(mask out(attn(...))) ----
+  ST_TRY(ln_fwd_plain(sl(S, lo.x1), w.ln_g[1], w.ln_b[1], sl(S, lo.n2), stats + 2 * R, stats + 3 * R, nullptr, B, T, C, 0, dt, stream));
+  c = conv_args(sl(S, lo.n2), C, w.qkv_w, w.qkv_b, nullptr, 0, sl(S, lo.qkv), 3 * C, nullptr, B, T, C, 3 * C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
+  ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
+  c = conv_args(a->pos_emb, C, w.pos_w, nullptr, nullptr, 0, sl(S, lo.pp), C, nullptr, 1, L, C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
+  ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
+  ST_TRY(ptpp_attention_fwd(sl(S, lo.qkv), at(sl(S, lo.qkv), C, dt), at(sl(S, lo.qkv), 2 * C, dt), sl(S, lo.pp), w.bias_u, w.bias_v,
+                            sl(S, lo.ctx), a->save ? static_cast<float*>(sl(S, lo.probs)) : nullptr, len, B, T, H, C / H, 3 * C, C, C,
+                            a->variant, 0.f, 0, dt, stream));
+  c = conv_args(sl(S, lo.ctx), C, w.out_w, w.out_b, sl(S, lo.x1), C, sl(S, lo.x2), C, len, B, T, C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 1, dt);
+  ST_TRY(linear_like_ops(c, a->p_drop, seed(2, a->p_drop), a->ws, a->ws_bytes, stream));
+  // ---- convolution module: x3 = x2 + drop(mask pw2(swish(BN(dwconv(glu(mask pw1(LN2(x2)))))))) ----
+  ST_TRY(ln_fwd_plain(sl(S, lo.x2), w.ln_g[2], w.ln_b[2], sl(S, lo.n3), stats + 4 * R, stats + 5 * R, nullptr, B, T, C, 0, dt, stream));
+  c = conv_args(sl(S, lo.n3), C, w.pw1_w, w.pw1_b, nullptr, 0, sl(S, lo.g), 2 * C, len, B, T, C, 2 * C, 1, 1, 0, PTPP_ACT_NONE, 0, 1, dt);
+  ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
+  ST_TRY(ptpp_glu_fwd(sl(S, lo.g), sl(S, lo.u), (int64_t)R, C, dt, stream));
+  ST_TRY(ptpp_dwconv1d(sl(S, lo.u), w.dw_w, w.dw_b, sl(S, lo.d), len, B, T, C, a->ks_dw, 0, dt, stream));
+  const float* bmean = bnstat;
+  const float* brstd = bnstat + C;
+  if (a->bn_train) {
+    ST_TRY(ptpp_bn_stats(sl(S, lo.d), (int64_t)R, C, a->bn_momentum, a->bn_eps, w.bn_rmean, w.bn_rvar, bnstat, bnstat + C, dt,
+                         a->red_scratch, a->red_bytes, stream));
+  } else {
+    ST_CHECK_ARG(w.bn_mean_in && w.bn_rstd_in, "conformer_block_fwd: eval-mode BatchNorm needs its statistics");
+    bmean = w.bn_mean_in;
+    brstd = w.bn_rstd_in;
+  }
+  ST_TRY(ptpp_bn_act_fwd(sl(S, lo.d), bmean, brstd, w.bn_g, w.bn_b, sl(S, lo.bno), (int64_t)R, C, PTPP_ACT_SWISH, dt, stream));
+  c = conv_args(sl(S, lo.bno), C, w.pw2_w, w.pw2_b, sl(S, lo.x2), C, sl(S, lo.x3), C, len, B, T, C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 1, dt);
+  ST_TRY(linear_like_ops(c, a->p_drop, seed(3, a->p_drop), a->ws, a->ws_bytes, stream));
+  // ---- feed-forward ----
+  ST_TRY(ln_fwd_plain(sl(S, lo.x3), w.ln_g[3], w.ln_b[3], sl(S, lo.n4), stats + 6 * R, stats + 7 * R, nullptr, B, T, C, 0, dt, stream));
+  c = conv_args(sl(S, lo.n4), C, w.ff_w1, w.ff_b1, nullptr, 0, sl(S, lo.h2), F, len, B, T, C, F, kf, 1, pf, PTPP_ACT_RELU, 1, 1, dt);
+  ST_TRY(linear_like_ops(c, a->p_ffn, seed(4, a->p_ffn), a->ws, a->ws_bytes, stream));
+  c = conv_args(sl(S, lo.h2), F, w.ff_w2, w.ff_b2, sl(S, lo.x3), C, sl(S, lo.x4), C, len, B, T, F, C, kf, 1, pf, PTPP_ACT_NONE, 0, 1, dt);
+  c.out_scale = 0.5f;
+  ST_TRY(linear_like_ops(c, a->p_drop, seed(5, a->p_drop), a->ws, a->ws_bytes, stream));
+  return ln_fwd_plain(sl(S, lo.x4), w.ln_g[4], w.ln_b[4], a->y, stats + 8 * R, stats + 9 * R, len, B, T, C, 1, dt, stream);
+}
+
+extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, void* stream) {
+  ST_CHECK_ARG(a && a->gy && a->gx && a->x && a->pos_emb && a->lengths && a->slab && a->scratch && a->red_scratch,
+               "conformer_block_bwd: null pointer");
+  ST_CHECK_ARG(a->B > 0 && a->T > 0 && a->C > 0 && a->F > 0 && a->H > 0 && a->C % a->H == 0 && a->L > 0, "conformer_block_bwd: bad shape");
+  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "conformer_block_bwd: bad dtype %d", a->dtype);
+  const int B = a->B, T = a->T, C = a->C, F = a->F, H = a->H, L = a->L, dt = a->dtype, kf = a->ks_ffn, pf = (a->ks_ffn - 1) / 2;
+  const CfLayout lo = cf_layout(B, T, C, F, H, L, dt);
+  const CfScratch sc = cf_scratch(B, T, C, F, H, L, dt);
+  ST_CHECK_ARG(a->scratch_bytes >= sc.total, "conformer_block_bwd: scratch too small (%zu bytes, need %zu)", a->scratch_bytes, sc.total);
+  const ptpp_conformer_weights& w = a->w;
+  const ptpp_conformer_grads& g = a->g;
+  const size_t R = (size_t)B * T;
+  const int64_t RC = (int64_t)R * C;
+  const void* S = a->slab;
+  void* X = a->scratch;
+  const float* stats = static_cast<const float*>(sl(S, lo.stats));
+  const float* bnstat = static_cast<const float*>(sl(S, lo.bnstat));
+  const int32_t* len = a->lengths;
+  const uint64_t zero6[6] = {0, 0, 0, 0, 0, 0};
+  const uint64_t* sd = a->seeds ? a->seeds : zero6;
+  auto seed = [&](int i, float p) { return p > 0.f ? sd[i] : (uint64_t)0; };
+  void* wstream = a->side_stream ? a->side_stream : stream;
+  void* ws_w = a->side_stream ? a->ws_side : a->ws_main;
+  const size_t ws_w_bytes = a->side_stream ? a->ws_side_bytes : a->ws_main_bytes;
+  // weight gradient on the side stream, after everything enqueued on the main one so far (functional.wgrad_stream)
+  auto wgrad = [&](const void* x, int ldx, const void* dy, int lddy, float* dw, float* db, const int32_t* lengths, int Bn, int Tn, int cin,
+                   int cout, int ks, int pad, int in_mask) -> int {
+    if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
+    return ptpp_conv1d_wgrad(x, dy, dw, db, lengths, Bn, Tn, cin, cout, ks, 1, pad, ldx, lddy, in_mask, dt, ws_w, ws_w_bytes, wstream);
+  };
+  void *gA = sl(X, sc.gA), *gB = sl(X, sc.gB), *gC = sl(X, sc.gC), *t1 = sl(X, sc.t1), *t2 = sl(X, sc.t2);
+  void* gF = sl(X, sc.gF);
+
+  // backward of one feed-forward half: gres = gradient w.r.t. res + 0.5 drop(...) ; returns the gradient w.r.t. LN input in t1
+  auto ffn_bwd = [&](const void* gres, const void* h, const void* n, const void* w1t, const void* w2t, float* dw1, float* db1, float* dw2,
+                     float* db2, int s1, int s2, void* dz2, void* dzF) -> int {
+    ST_TRY(ptpp_epilogue_bwd(gres, nullptr, dz2, len, B, T, C, 0.5f, 0, 1, a->p_drop, seed(s2, a->p_drop), dt, stream));
+    ptpp_conv1d_args c = conv_args(dz2, C, w2t, nullptr, nullptr, 0, gF, F, len, B, T, C, F, kf, 1, (kf - 1) - pf, PTPP_ACT_NONE, 0, 0, dt);
+    ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+    ST_TRY(wgrad(h, F, dz2, C, dw2, db2, len, B, T, F, C, kf, pf, 0));
+    ST_TRY(ptpp_epilogue_bwd(gF, h, dzF, len, B, T, F, 1.0f, 1, 1, a->p_ffn, seed(s1, a->p_ffn), dt, stream));
+    c = conv_args(dzF, F, w1t, nullptr, nullptr, 0, t1, C, len, B, T, F, C, kf, 1, (kf - 1) - pf, PTPP_ACT_NONE, 0, 1, dt);
+    ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+    return wgrad(n, C, dzF, F, dw1, db1, len, B, T, C, F, kf, pf, 1);
+  };
+
+  // ---- final LayerNorm ----
+  ST_TRY(ln_bwd_plain(a->gy, sl(S, lo.x4), w.ln_g[4], stats + 8 * R, stats + 9 * R, gA, g.ln_g[4], g.ln_b[4], len, B, T, C, 1, dt,
+                      a->red_scratch, a->red_bytes, stream));
+  // ---- feed-forward ----
+  ST_TRY(ffn_bwd(gA, sl(S, lo.h2), sl(S, lo.n4), a->ff_w1t, a->ff_w2t, g.ff_w1, g.ff_b1, g.ff_w2, g.ff_b2, 4, 5, sl(X, sc.dz_c[0]),
+                 sl(X, sc.dz_f[0])));
+  ST_TRY(ln_bwd_plain(t1, sl(S, lo.x3), w.ln_g[3], stats + 6 * R, stats + 7 * R, t2, g.ln_g[3], g.ln_b[3], nullptr, B, T, C, 0, dt,
+                      a->red_scratch, a->red_bytes, stream));
+  ST_TRY(ptpp_add3_scale(gA, t2, nullptr, gB, 1.0f, RC, dt, stream));  // gradient w.r.t. x3
+  // ---- convolution module ----
+  void* dz_pw2 = sl(X, sc.dz_c[1]);
+  ST_TRY(ptpp_epilogue_bwd(gB, nullptr, dz_pw2, len, B, T, C, 1.0f, 0, 1, a->p_drop, seed(3, a->p_drop), dt, stream));
+  ptpp_conv1d_args c = conv_args(dz_pw2, C, a->pw2_wt, nullptr, nullptr, 0, t2, C, len, B, T, C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
+  ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+  ST_TRY(wgrad(sl(S, lo.bno), C, dz_pw2, C, g.pw2_w, g.pw2_b, len, B, T, C, C, 1, 0, 0));
+  const float* bmean = a->bn_train ? bnstat : w.bn_mean_in;
+  const float* brstd = a->bn_train ? bnstat + C : w.bn_rstd_in;
+  ST_TRY(ptpp_bn_act_bwd(sl(S, lo.d), t2, bmean, brstd, w.bn_g, w.bn_b, g.bn_sums, t1, (int64_t)R, C, PTPP_ACT_SWISH, a->bn_train, dt,
+                         a->red_scratch, a->red_bytes, stream));
+  ST_TRY(ptpp_dwconv1d(t1, w.dw_w, nullptr, t2, len, B, T, C, a->ks_dw, 1, dt, stream));
+  ST_TRY(ptpp_dwconv1d_wgrad(sl(S, lo.u), t1, g.dw_w, g.dw_b, len, B, T, C, a->ks_dw, dt, stream));
+  ST_TRY(ptpp_glu_bwd(sl(S, lo.g), t2, sl(X, sc.g2a), (int64_t)R, C, dt, stream));
+  ST_TRY(ptpp_epilogue_bwd(sl(X, sc.g2a), nullptr, sl(X, sc.dz_2c), len, B, T, 2 * C, 1.0f, 0, 1, 0.f, 0, dt, stream));
+  c = conv_args(sl(X, sc.dz_2c), 2 * C, a->pw1_wt, nullptr, nullptr, 0, t1, C, len, B, T, 2 * C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
+  ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+  ST_TRY(wgrad(sl(S, lo.n3), C, sl(X, sc.dz_2c), 2 * C, g.pw1_w, g.pw1_b, len, B, T, C, 2 * C, 1, 0, 0));
+  ST_TRY(ln_bwd_plain(t1, sl(S, lo.x2), w.ln_g[2], stats + 4 * R, stats + 5 * R, t2, g.ln_g[2], g.ln_b[2], nullptr, B, T, C, 0, dt,
+                      a->red_scratch, a->red_bytes, stream));
+  ST_TRY(ptpp_add3_scale(gB, t2, nullptr, gC, 1.0f, RC, dt, stream));  // gradient w.r.t. x2
+  // ---- self-attention ----
+  void* dz_out = sl(X, sc.dz_c[2]);
+  ST_TRY(ptpp_epilogue_bwd(gC, nullptr, dz_out, len, B, T, C, 1.0f, 0, 1, a->p_drop, seed(2, a->p_drop), dt, stream));
+  c = conv_args(dz_out, C, a->out_wt, nullptr, nullptr, 0, t2, C, len, B, T, C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
+  ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+  ST_TRY(wgrad(sl(S, lo.ctx), C, dz_out, C, g.out_w, g.out_b, len, B, T, C, C, 1, 0, 0));
+  void* dqkv = sl(X, sc.dqkv);
+  float* dpos = static_cast<float*>(sl(X, sc.dpos));
+  const void* qkv = sl(S, lo.qkv);
+  ST_TRY(ptpp_attention_bwd(qkv, at(qkv, C, dt), at(qkv, 2 * C, dt), sl(S, lo.pp), w.bias_u, w.bias_v,
+                            static_cast<const float*>(sl(S, lo.probs)), t2, static_cast<float*>(sl(X, sc.dS)), dqkv, at(dqkv, C, dt),
+                            at(dqkv, 2 * C, dt), dpos, g.bias_u, g.bias_v, len, B, T, H, C / H, 3 * C, C, C, 3 * C, a->variant, 0.f, 0, dt,
+                            a->red_scratch, a->red_bytes, stream));
+  // positional projection (no bias, its input is a constant table): weight gradient only
+  const void* dposc = dpos;
+  if (dt != PTPP_F32) {
+    ST_TRY(ptpp_cast_from_f32(dpos, sl(X, sc.dposc), (int64_t)L * C, dt, stream));
+    dposc = sl(X, sc.dposc);
+  }
+  ST_TRY(wgrad(a->pos_emb, C, dposc, C, g.pos_w, nullptr, nullptr, 1, L, C, C, 1, 0, 0));
+  // fused q | k | v projection
+  c = conv_args(dqkv, 3 * C, a->qkv_wt, nullptr, nullptr, 0, t1, C, nullptr, B, T, 3 * C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
+  ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+  float* const dws[3] = {g.q_w, g.k_w, g.v_w};
+  float* const dbs[3] = {g.q_b, g.k_b, g.v_b};
+  for (int i = 0; i < 3; ++i) ST_TRY(wgrad(sl(S, lo.n2), C, at(dqkv, (size_t)i * C, dt), 3 * C, dws[i], dbs[i], nullptr, B, T, C, C, 1, 0, 0));
+  ST_TRY(ln_bwd_plain(t1, sl(S, lo.x1), w.ln_g[1], stats + 2 * R, stats + 3 * R, t2, g.ln_g[1], g.ln_b[1], nullptr, B, T, C, 0, dt,
+                      a->red_scratch, a->red_bytes, stream));
+  ST_TRY(ptpp_add3_scale(gC, t2, nullptr, gA, 1.0f, RC, dt, stream));  // gradient w.r.t. x1
+  // ---- macaron feed-forward ----
+  ST_TRY(ffn_bwd(gA, sl(S, lo.h1), sl(S, lo.n1), a->ffm_w1t, a->ffm_w2t, g.ffm_w1, g.ffm_b1, g.ffm_w2, g.ffm_b2, 0, 1, sl(X, sc.dz_c[3]),
+                 sl(X, sc.dz_f[1])));
+  ST_TRY(ln_bwd_plain(t1, a->x, w.ln_g[0], stats, stats + R, t2, g.ln_g[0], g.ln_b[0], nullptr, B, T, C, 0, dt, a->red_scratch,
+                      a->red_bytes, stream));
+  return ptpp_add3_scale(gA, t2, nullptr, a->gx, 1.0f, RC, dt, stream);
+}

@@ -155,11 +155,208 @@ class EncoderLayer(nn.Module):
 
     def cl(self, x, pos_emb, lengths, mask_bt1):
         p = self.dropout_rate if self.training else 0.0
+        if _block_driver_ok(self, x):
+            from types import SimpleNamespace
+
+            bn = self.conv_module.norm
+            if bn.training and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            cfg = SimpleNamespace(lengths=lengths, heads=self.self_attn.h, variant=self.self_attn.variant, p=float(p),
+                                  p_ffn=float(self.feed_forward.dropout_rate if self.training else 0.0), bn=bn, training=bn.training)
+            return ConformerBlockFn.apply(x, pos_emb, cfg, *_block_params(self))
         x = self.feed_forward_macaron.cl(self.norm_ff_macaron.cl(x), lengths, x, 0.5, p)
         x = self.self_attn.cl(self.norm_mha.cl(x), pos_emb, lengths, x, p)
         x = self.conv_module.cl(self.norm_conv.cl(x), lengths, mask_bt1, x, p)
         x = self.feed_forward.cl(self.norm_ff.cl(x), lengths, x, 0.5, p)
         return self.norm_final.cl(x, lengths=lengths, out_mask=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# One EncoderLayer as ONE autograd node issued by two C calls (ptpp_conformer_block_fwd / _bwd, include/ptpp.h): the ~25
+# forward and ~45 backward launches of ``EncoderLayer.cl`` in the same order with the same arguments and dropout seeds
+# (bit-identical, tests/test_stack_drivers.py), without their Python -> C round trips, per-launch allocations and ~20
+# autograd nodes per block.
+# ----------------------------------------------------------------------------------------------------------------------
+def _block_params(layer):
+    """The block's parameters in the order of ``ConformerBlockFn``'s flat argument list."""
+    a, cm = layer.self_attn, layer.conv_module
+    ffm, ff = layer.feed_forward_macaron, layer.feed_forward
+    norms = (layer.norm_ff_macaron, layer.norm_mha, layer.norm_conv, layer.norm_ff, layer.norm_final)
+    return ([n.weight for n in norms] + [n.bias for n in norms] +
+            [ffm.w_1.weight, ffm.w_1.bias, ffm.w_2.weight, ffm.w_2.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias,
+             a.linear_q.weight, a.linear_q.bias, a.linear_k.weight, a.linear_k.bias, a.linear_v.weight, a.linear_v.bias,
+             a.linear_pos.weight, a.linear_out.weight, a.linear_out.bias, a.pos_bias_u, a.pos_bias_v,
+             cm.pointwise_conv1.weight, cm.pointwise_conv1.bias, cm.pointwise_conv2.weight, cm.pointwise_conv2.bias,
+             cm.depthwise_conv.weight, cm.depthwise_conv.bias, cm.norm.weight, cm.norm.bias])
+
+
+_N_LN, _I_FF, _I_ATT, _I_CM = 10, 10, 18, 29   # offsets into the flat list: norms, feed-forward pair, attention, conv module
+_VARIANT = {"new": 0, "legacy": 1}
+
+
+def _fill_weights(w, P, dt, bn, training):
+    """ptpp_conformer_weights from the flat parameter list ``P`` (packed operands / f32 parameters)."""
+    import ctypes
+
+    f32 = PF._f32_param
+    keep = []
+
+    def ptr(t):
+        keep.append(t)
+        return t.data_ptr()
+
+    for i in range(5):
+        setattr(w, f"ln_g{i}", ptr(f32(P[i])))
+        setattr(w, f"ln_b{i}", ptr(f32(P[5 + i])))
+    w.ffm_w1, w.ffm_b1 = ptr(PF.packed(P[10], dt)), ptr(f32(P[11]))
+    w.ffm_w2, w.ffm_b2 = ptr(PF.packed(P[12], dt)), ptr(f32(P[13]))
+    w.ff_w1, w.ff_b1 = ptr(PF.packed(P[14], dt)), ptr(f32(P[15]))
+    w.ff_w2, w.ff_b2 = ptr(PF.packed(P[16], dt)), ptr(f32(P[17]))
+    w.qkv_w = ptr(PF.packed_cat((P[18], P[20], P[22]), dt))
+    w.qkv_b = ptr(PF.bias_cat((P[19], P[21], P[23])))
+    w.pos_w = ptr(PF.packed(P[24], dt))
+    w.out_w, w.out_b = ptr(PF.packed(P[25], dt)), ptr(f32(P[26]))
+    w.bias_u, w.bias_v = ptr(f32(P[27])), ptr(f32(P[28]))
+    w.pw1_w, w.pw1_b = ptr(PF.packed(P[29], dt)), ptr(f32(P[30]))
+    w.pw2_w, w.pw2_b = ptr(PF.packed(P[31], dt)), ptr(f32(P[32]))
+    C = P[33].shape[0]
+    w.dw_w, w.dw_b = ptr(f32(P[33]).reshape(C, -1)), ptr(f32(P[34]))
+    w.bn_g, w.bn_b = ptr(f32(P[35])), ptr(f32(P[36]))
+    if training:
+        if bn.running_mean is not None and bn.running_var is not None:
+            w.bn_rmean, w.bn_rvar = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+    else:
+        w.bn_mean_in = ptr(bn.running_mean.float().contiguous())
+        w.bn_rstd_in = ptr(torch.rsqrt(bn.running_var.float() + bn.eps).contiguous())
+    return keep
+
+
+class ConformerBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos, cfg, *P):
+        import ctypes
+
+        from ... import _lib, ops
+
+        x = x.contiguous()
+        pos = pos.contiguous()
+        B, T, C = x.shape
+        dt, dev = x.dtype, x.device
+        F_, H, L = P[10].shape[0], cfg.heads, pos.shape[0]
+        dcode = ops.dtype_code(dt)
+        lib = _lib.load()
+        need_bwd = any(ctx.needs_input_grad)
+        p_ffn, p = cfg.p_ffn, cfg.p
+        seeds = [PF.next_seed() if q > 0 else 0 for q in (p_ffn, p, p, p, p_ffn, p)]  # the draws of the six Conv1dFn.forward calls
+        slab = torch.empty(lib.ptpp_conformer_block_slab_bytes(B, T, C, F_, H, L, dcode), device=dev, dtype=torch.uint8)
+        y = torch.empty_like(x)
+        a = _lib.ConformerFwdArgs()
+        keep = _fill_weights(a.w, P, dt, cfg.bn, cfg.training)
+        lens = ops.i32(cfg.lengths, dev)
+        a.x, a.y, a.pos_emb, a.lengths = x.data_ptr(), y.data_ptr(), pos.data_ptr(), lens.data_ptr()
+        a.slab, a.slab_bytes = slab.data_ptr(), slab.numel()
+        if not torch.cuda.is_current_stream_capturing():
+            ws = ops.workspace(dev)
+            a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+        a.red_scratch, a.red_bytes = ops.reduction_scratch(dev)
+        sd = (ctypes.c_uint64 * 6)(*seeds)
+        a.seeds = ctypes.cast(sd, ctypes.c_void_p)
+        a.p_ffn, a.p_drop = p_ffn, p
+        a.bn_momentum, a.bn_eps = float(cfg.bn.momentum if cfg.bn.momentum is not None else 0.1), float(cfg.bn.eps)
+        a.B, a.T, a.C, a.F, a.H, a.L = B, T, C, F_, H, L
+        a.ks_ffn, a.ks_dw, a.variant = P[10].shape[2], P[33].shape[-1], _VARIANT[cfg.variant]
+        a.bn_train, a.save, a.dtype = int(cfg.training), int(need_bwd), dcode
+        _lib.check(lib.ptpp_conformer_block_fwd(ctypes.byref(a), ops._stream()), "ptpp_conformer_block_fwd")
+        if need_bwd:
+            ctx.cfg, ctx.P, ctx.seeds, ctx.dims = cfg, P, seeds, (B, T, C, F_, H, L)
+            ctx.tensors = (x, pos, lens, slab)
+            ctx.direct = [PF._sink(t) is not None for t in P]
+            # depthwise taps / BatchNorm parameters come back through autograd (their kernels accumulate with atomics into
+            # fresh buffers, as in the per-launch path); everything else accumulates in place when the trainer allows it
+            for i in (33, 34, 35, 36):
+                ctx.direct[i] = False
+            for i, t in enumerate(P):
+                if ctx.direct[i]:
+                    PF._use(t)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        import ctypes
+
+        from ... import _lib, ops
+
+        cfg, P = ctx.cfg, ctx.P
+        B, T, C, F_, H, L = ctx.dims
+        x, pos, lens, slab = ctx.tensors
+        dt, dev = x.dtype, x.device
+        dcode = ops.dtype_code(dt)
+        lib = _lib.load()
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        scratch = torch.empty(lib.ptpp_conformer_block_bwd_scratch_bytes(B, T, C, F_, H, L, dcode), device=dev, dtype=torch.uint8)
+        tg = [t.grad if d else torch.zeros(t.shape, device=dev, dtype=torch.float32) for t, d in zip(P, ctx.direct)]
+        bn_sums = torch.empty(2 * C, device=dev, dtype=torch.float32)
+        a = _lib.ConformerBwdArgs()
+        keep = _fill_weights(a.w, P, dt, cfg.bn, cfg.training)
+        a.gy, a.gx, a.x, a.pos_emb, a.lengths = gy.data_ptr(), gx.data_ptr(), x.data_ptr(), pos.data_ptr(), lens.data_ptr()
+        tr = [PF.packed(P[i], dt, mode=1) for i in (10, 12, 14, 16)] + [PF.packed_cat((P[18], P[20], P[22]), dt, mode=1)] + \
+             [PF.packed(P[i], dt, mode=1) for i in (25, 29, 31)]
+        (a.ffm_w1t, a.ffm_w2t, a.ff_w1t, a.ff_w2t, a.qkv_wt, a.out_wt, a.pw1_wt, a.pw2_wt) = [t.data_ptr() for t in tr]
+        g = a.g
+        for i in range(5):
+            setattr(g, f"ln_g{i}", tg[i].data_ptr())
+            setattr(g, f"ln_b{i}", tg[5 + i].data_ptr())
+        names = ("ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "ff_w1", "ff_b1", "ff_w2", "ff_b2", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b",
+                 "pos_w", "out_w", "out_b", "bias_u", "bias_v", "pw1_w", "pw1_b", "pw2_w", "pw2_b", "dw_w", "dw_b")
+        for n, t in zip(names, tg[10:35]):
+            setattr(g, n, t.data_ptr())
+        g.bn_sums = bn_sums.data_ptr()
+        a.slab, a.scratch, a.scratch_bytes = slab.data_ptr(), scratch.data_ptr(), scratch.numel()
+        d = PF._direct
+        side_h = None
+        if any(ctx.direct) and d["async"] and not torch.cuda.is_current_stream_capturing():
+            if d["side_h"] is None:
+                PF.create_side_stream(dev)
+            side_h = d["side_h"]
+        main_h = ops._stream()
+        ws_main = ops.workspace(dev)
+        ws_side = ops.workspace_of(dev, side_h) if side_h is not None else ws_main
+        a.ws_main, a.ws_main_bytes = ws_main.data_ptr(), ws_main.numel()
+        a.ws_side, a.ws_side_bytes = ws_side.data_ptr(), ws_side.numel()
+        a.red_scratch, a.red_bytes = ops.reduction_scratch(dev)
+        a.side_stream = side_h
+        sd = (ctypes.c_uint64 * 6)(*ctx.seeds)
+        a.seeds = ctypes.cast(sd, ctypes.c_void_p)
+        a.p_ffn, a.p_drop = cfg.p_ffn, cfg.p
+        a.B, a.T, a.C, a.F, a.H, a.L = B, T, C, F_, H, L
+        a.ks_ffn, a.ks_dw, a.variant = P[10].shape[2], P[33].shape[-1], _VARIANT[cfg.variant]
+        a.bn_train, a.dtype = int(cfg.training), dcode
+        _lib.check(lib.ptpp_conformer_block_bwd(ctypes.byref(a), main_h), "ptpp_conformer_block_bwd")
+        if side_h is not None:  # the side stream still reads these: held until the streams are joined
+            d["keep"].extend((x, pos, slab, scratch))
+        ctx.tensors = None
+        grads = []
+        for i, (t, dr) in enumerate(zip(P, ctx.direct)):
+            if dr:
+                PF._done(t)
+                grads.append(None)
+            elif i == 35:
+                grads.append(bn_sums[C:].view_as(t))   # dgamma
+            elif i == 36:
+                grads.append(bn_sums[:C].view_as(t))   # dbeta
+            else:
+                grads.append(tg[i].view_as(t))
+        return (gx, None, None, *grads)
+
+
+def _block_driver_ok(layer, x):
+    cm = layer.conv_module
+    return (PF.STACK_DRIVERS and x.is_cuda and x.shape[-1] % 8 == 0 and cm.depthwise_conv.bias is not None and
+            cm.pointwise_conv1.bias is not None and layer.self_attn.variant in _VARIANT and
+            layer.feed_forward.ks == layer.feed_forward_macaron.ks and
+            layer.feed_forward.dropout_rate == layer.feed_forward_macaron.dropout_rate)
 
 
 class Encoder(nn.Module):

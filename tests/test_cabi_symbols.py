@@ -89,3 +89,28 @@ def test_fused_adamw_state_dict_round_trips_with_torch_adamw():
     back.load_state_dict(fused.state_dict())                       # and the other direction
     assert float(back.state[ps[1]]["step"]) == 3.0
     back.step()                                                    # would raise KeyError('step') without the per-param entry
+
+
+def test_ctypes_structures_match_the_header(tmp_path):
+    """sizeof of every argument block: the C header compiled with gcc against the ctypes mirrors of _lib.py."""
+    import shutil
+    import subprocess
+
+    from promptttspp_amd import _lib
+
+    if shutil.which("gcc") is None:
+        import pytest
+
+        pytest.skip("no gcc")
+    pairs = [("ptpp_conv1d_args", _lib.ConvArgs), ("ptpp_wgrad_problem", _lib.WgradProblem), ("ptpp_diffnet_stack_fwd_args", _lib.DiffNetFwdArgs),
+             ("ptpp_diffnet_stack_bwd_args", _lib.DiffNetBwdArgs), ("ptpp_encoder_layers_fwd_args", _lib.EncoderLayersFwdArgs),
+             ("ptpp_conv_ln_stack_fwd_args", _lib.ConvLnFwdArgs), ("ptpp_conv_ln_stack_bwd_args", _lib.ConvLnBwdArgs),
+             ("ptpp_conformer_weights", _lib.ConformerWeights), ("ptpp_conformer_grads", _lib.ConformerGrads),
+             ("ptpp_conformer_block_fwd_args", _lib.ConformerFwdArgs), ("ptpp_conformer_block_bwd_args", _lib.ConformerBwdArgs)]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(void){%s return 0;}\n' % (
+        os.path.join(ROOT, "include", "ptpp.h"), "".join('printf("%%zu\\n", sizeof(%s));' % n for n, _ in pairs)))
+    subprocess.run(["gcc", str(src), "-o", str(tmp_path / "sz")], check=True)
+    sizes = [int(v) for v in subprocess.run([str(tmp_path / "sz")], check=True, capture_output=True, text=True).stdout.split()]
+    for (name, cls), size in zip(pairs, sizes):
+        assert ctypes.sizeof(cls) == size, (name, ctypes.sizeof(cls), size)

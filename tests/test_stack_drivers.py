@@ -368,3 +368,72 @@ def test_branch_streams_give_the_same_losses_and_gradients(dev, monkeypatch, mod
                 assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()) + 1e-12), (rep, n, float((a - b).abs().max()))
     finally:
         config.set_compute_dtype(old)
+
+
+@pytest.mark.parametrize("variant,dtype,train", [("new", torch.bfloat16, True), ("new", torch.float32, True), ("legacy", torch.bfloat16, True),
+                                                 ("new", torch.bfloat16, False)])
+def test_conformer_block_driver_is_bit_identical(dev, monkeypatch, variant, dtype, train):
+    """ptpp_conformer_block_fwd / _bwd (reference modules/esp/conformer/encoder_layer.py:74-162) against the chain of ~20
+    autograd nodes per block they replace, on the 4-block encoder of the model's config, train mode with every dropout site on
+    (same seeds) and train-mode BatchNorm: output and input gradient equal bit for bit; in bf16 so are all conv / linear weight
+    and bias gradients (fixed-order reductions); LayerNorm / BatchNorm / pos_bias / depthwise gradients and the f32 weight
+    gradients go through f32 atomics in both paths (tolerance 2e-5); the BatchNorm running statistics advance identically."""
+    import copy
+
+    from promptttspp_amd import config
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd.modules.esp import ConformerEncoder
+
+    torch.manual_seed(11)
+    old = config.compute_dtype()
+    config.set_compute_dtype(dtype)
+
+    enc = ConformerEncoder(idim=256, attention_dim=256, attention_heads=2, linear_units=1024, num_blocks=4, dropout_rate=0.2,
+                           positionwise_layer_type="conv1d", positionwise_conv_kernel_size=9, macaron_style=True,
+                           pos_enc_layer_type="rel_pos", selfattention_layer_type="rel_selfattn", activation_type="swish",
+                           use_cnn_module=True, cnn_module_kernel=7, rel_pos_type=variant).to(dev)
+    with torch.no_grad():
+        for n_, p_ in enc.named_parameters():
+            if p_.dim() == 1 and ("norm" in n_ or "bias" in n_):
+                p_.add_(0.1 * torch.randn_like(p_))
+    enc.train(train)
+    B, Tn, C = 5, 77, 256
+    lengths = torch.tensor([77, 60, 33, 12, 1], device=dev, dtype=torch.int32)
+    mask = (torch.arange(Tn, device=dev)[None, :] < lengths[:, None]).unsqueeze(-1).float()
+    x = (rnd(3, B, Tn, C).to(dev) * mask).to(dtype)
+    gout = rnd(4, B, Tn, C).to(dev).to(dtype)
+    state0 = copy.deepcopy(enc.state_dict())
+    monkeypatch.setattr(PF, "BATCHED_WGRAD", False)
+    try:
+        outs, stats = [], []
+        for drivers in (False, True):
+            monkeypatch.setattr(PF, "STACK_DRIVERS", drivers)
+            enc.load_state_dict(state0)
+            PF.manual_seed(99)
+            xin = x.clone().requires_grad_(True)
+            for p_ in enc.parameters():
+                p_.grad = None
+            y = enc.forward_cl(xin, lengths, mask)
+            if train:
+                y.backward(gout)
+            torch.cuda.synchronize()
+            outs.append([y.detach().clone()] + ([xin.grad.clone()] + [p_.grad.clone() for p_ in enc.parameters()] if train else []))
+            stats.append({k: v.clone() for k, v in enc.state_dict().items() if "running" in k or "num_batches" in k})
+    finally:
+        config.set_compute_dtype(old)
+    names = ["y", "dx"] + [n_ for n_, _ in enc.named_parameters()]
+    assert len(outs[0]) == len(outs[1]) == (len(names) if train else 1)
+    for n_, a, b in zip(names, *outs):
+        assert a.shape == b.shape and a.dtype == b.dtype, n_
+        exact = n_ in ("y", "dx") or (dtype == torch.bfloat16 and not any(k in n_ for k in ("norm", "pos_bias", "depthwise", "linear_pos")))
+        if exact:
+            assert torch.equal(a, b), (n_, float((a.float() - b.float()).abs().max()))
+        elif "linear_pos" in n_ and dtype == torch.bfloat16:
+            # its upstream gradient dpos is summed over batch groups with f32 atomics and then rounded to bf16 (in both paths):
+            # a last-bit difference before the rounding moves single elements by one bf16 step
+            err = float((a - b).norm() / a.norm())
+            assert err < 2e-3, (n_, err)
+        else:  # (atol floor: linear_k.bias has a structurally zero gradient -- softmax is shift invariant -- i.e. pure rounding noise)
+            assert torch.allclose(a, b, rtol=2e-5, atol=max(3e-6 * float(a.abs().max()), 1e-7)), (n_, float((a - b).abs().max()))
+    for k in stats[0]:
+        assert torch.equal(stats[0][k], stats[1][k]) or torch.allclose(stats[0][k].float(), stats[1][k].float(), rtol=1e-6, atol=1e-7), k
