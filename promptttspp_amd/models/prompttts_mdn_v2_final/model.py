@@ -29,8 +29,9 @@ from ...modules.mdn import mdn_get_most_probable_sigma_and_mu, mdn_loss, mdn_sam
 from ...utils.model import sequence_mask
 
 
-# "" / "0" off | "1" prompt branch | "2" prompt branch + reference encoder on their own streams (default; see forward)
-BRANCH_STREAMS = os.environ.get("PTPP_BRANCH_STREAMS", "2")
+# "" / "0" off | "1" prompt branch | "2" + reference encoder | "3" (default) + duration and pitch predictors, on two extra
+# streams (see forward)
+BRANCH_STREAMS = os.environ.get("PTPP_BRANCH_STREAMS", "3")
 if BRANCH_STREAMS in ("0", "off", "no"):
     BRANCH_STREAMS = ""
 _branch = {}
@@ -112,7 +113,7 @@ class PromptTTSMDNDurCFG(nn.Module):
 
             PF._direct["main"] = torch.cuda.current_stream()
             PF._direct["main_h"] = ctypes.c_void_p(PF._direct["main"].cuda_stream)
-        sa = _branch_stream(dev, 1) if (branches and BRANCH_STREAMS != "1") else None
+        sa = _branch_stream(dev, 1) if (branches and BRANCH_STREAMS in ("2", "3")) else None
         if sa is not None:
             # the reference encoder (mel -> style embedding) and the phoneme encoder are independent until x + style_emb:
             # two chains of short launches side by side (PTPP_BRANCH_STREAMS=2)
@@ -147,9 +148,12 @@ class PromptTTSMDNDurCFG(nn.Module):
                 style_mdn_out = self.style_mdn(prompt_emb.transpose(-1, -2))
         x = x + style_emb.transpose(1, 2).to(dt)  # broadcast over every phone, padded ones too (model.py:111)
 
+        # "3": also the duration predictor (detached input -> loss_dur only) and the pitch predictor (teacher-forced pitch in
+        # training -> its two losses only) as branches, on the two streams above
+        vb = (bs, sa) if (branches and BRANCH_STREAMS == "3") else None
         h, dur_out, cf0_pred, vuv_pred, energy_pred = self.variance_adaptor.forward_cl(
             x, plen, flen, fm1, duration.squeeze(1), log_cf0.squeeze(1),
-            None if self.variance_adaptor.energy_emb is None else energy.squeeze(1))
+            None if self.variance_adaptor.energy_emb is None else energy.squeeze(1), branch_streams=vb)
 
         mel_cl = mel.transpose(1, 2).float().contiguous()
         if self.conformer_decoder:
@@ -160,6 +164,15 @@ class PromptTTSMDNDurCFG(nn.Module):
             noise, pred = self.decoder.forward_cl(h, mel_cl, flen)
             loss_dec = ((noise - pred) * fm1).abs().sum() / n_frames / self.loss_dec_scale
 
+        if bs is not None:  # join: the losses read the branches' outputs
+            main = torch.cuda.current_stream()
+            main.wait_stream(bs)
+            for t in ((prompt_emb,) if style_mdn_out is None else tuple(style_mdn_out)):
+                t.record_stream(main)
+            if vb is not None:
+                main.wait_stream(sa)
+                for t in tuple(dur_out) + (cf0_pred, vuv_pred):
+                    t.record_stream(main)
         dur = duration.squeeze(1).float()
         log_dur = torch.where(dur != 0, torch.log(dur.clamp_min(1e-30)), dur)  # to_log_scale, out of place
         pmb = pmask.unsqueeze(-1)
@@ -170,11 +183,6 @@ class PromptTTSMDNDurCFG(nn.Module):
 
         loss_cf0 = (cf0_pred - log_cf0.squeeze(1)).abs().sum() / n_frames
         loss_vuv = (vuv_pred - vuv.squeeze(1)).abs().sum() / n_frames
-        if bs is not None:  # join: the style loss reads both branches
-            main = torch.cuda.current_stream()
-            main.wait_stream(bs)
-            for t in ((prompt_emb,) if style_mdn_out is None else tuple(style_mdn_out)):
-                t.record_stream(main)
         if self.style_mdn is not None:
             loss_style = mdn_loss(*style_mdn_out, style_emb.detach().transpose(-1, -2)).mean()
         else:

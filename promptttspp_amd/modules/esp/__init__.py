@@ -270,6 +270,7 @@ class ConformerBlockFn(torch.autograd.Function):
         if need_bwd:
             ctx.cfg, ctx.P, ctx.seeds, ctx.dims = cfg, P, seeds, (B, T, C, F_, H, L)
             ctx.tensors = (x, pos, lens, slab)
+            ctx.w, ctx.w_keep = a.w, keep  # the forward operands: the backward reads the same ones (no second lookup)
             ctx.direct = [PF._sink(t) is not None for t in P]
             # depthwise taps / BatchNorm parameters come back through autograd (their kernels accumulate with atomics into
             # fresh buffers, as in the per-launch path); everything else accumulates in place when the trainer allows it
@@ -299,7 +300,7 @@ class ConformerBlockFn(torch.autograd.Function):
         tg = [t.grad if d else torch.zeros(t.shape, device=dev, dtype=torch.float32) for t, d in zip(P, ctx.direct)]
         bn_sums = torch.empty(2 * C, device=dev, dtype=torch.float32)
         a = _lib.ConformerBwdArgs()
-        keep = _fill_weights(a.w, P, dt, cfg.bn, cfg.training)
+        a.w = ctx.w
         a.gy, a.gx, a.x, a.pos_emb, a.lengths = gy.data_ptr(), gx.data_ptr(), x.data_ptr(), pos.data_ptr(), lens.data_ptr()
         tr = [PF.packed(P[i], dt, mode=1) for i in (10, 12, 14, 16)] + [PF.packed_cat((P[18], P[20], P[22]), dt, mode=1)] + \
              [PF.packed(P[i], dt, mode=1) for i in (25, 29, 31)]

@@ -238,18 +238,30 @@ class BertWrapper(nn.Module):
         tr = self.training
         p_att = float(sa0.dropout.p) if tr else 0.0
         p_hid = float(layers[0].attention.output.dropout.p) if tr else 0.0
-        cols = [[] for _ in range(12)]
+        # the pointer tables of the frozen layers change only when their parameters do: cached on the parameters' versions
+        # and storage (132 packed-operand lookups per step otherwise, ~0.8 ms of host time)
+        srcs = [t for layer in layers for t in layer.parameters()]
+        stamp = (dt, len(layers), PF._pack_gen[0], tuple(t._version for t in srcs), srcs[0].data_ptr())
+        cached = getattr(self, "_frozen_tables", None)
+        if cached is not None and cached[0] == stamp:
+            cols = cached[1]
+        else:
+            cols = [[] for _ in range(12)]
+            for layer in layers:
+                att, sa = layer.attention, layer.attention.self
+                assert sa.num_attention_heads == sa0.num_attention_heads and layer.intermediate.dense.out_features == Fi
+                row = (PF.packed_cat([sa.query.weight, sa.key.weight, sa.value.weight], dt),
+                       PF.bias_cat([sa.query.bias, sa.key.bias, sa.value.bias]),
+                       PF.packed(att.output.dense.weight, dt), att.output.dense.bias, att.output.LayerNorm.weight, att.output.LayerNorm.bias,
+                       PF.packed(layer.intermediate.dense.weight, dt), layer.intermediate.dense.bias,
+                       PF.packed(layer.output.dense.weight, dt), layer.output.dense.bias, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias)
+                for c, t in zip(cols, row):
+                    assert t.is_contiguous() and (t.dtype == torch.float32 or t.dtype == dt)
+                    c.append(t)
+            stamp = (dt, len(layers), PF._pack_gen[0], tuple(t._version for t in srcs), srcs[0].data_ptr())  # (packing may add entries)
+            self._frozen_tables = (stamp, cols)
         seeds = []
-        for layer in layers:
-            att, sa = layer.attention, layer.attention.self
-            assert sa.num_attention_heads == sa0.num_attention_heads and layer.intermediate.dense.out_features == Fi
-            row = (PF.packed_cat([sa.query.weight, sa.key.weight, sa.value.weight], dt), PF.bias_cat([sa.query.bias, sa.key.bias, sa.value.bias]),
-                   PF.packed(att.output.dense.weight, dt), att.output.dense.bias, att.output.LayerNorm.weight, att.output.LayerNorm.bias,
-                   PF.packed(layer.intermediate.dense.weight, dt), layer.intermediate.dense.bias,
-                   PF.packed(layer.output.dense.weight, dt), layer.output.dense.bias, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias)
-            for c, t in zip(cols, row):
-                assert t.is_contiguous() and (t.dtype == torch.float32 or t.dtype == dt)
-                c.append(t)
+        for _ in layers:
             seeds += [PF.next_seed() if p_att > 0 else 0, PF.next_seed() if p_hid > 0 else 0, PF.next_seed() if p_hid > 0 else 0]
         h = h.contiguous()
         out = torch.empty_like(h)

@@ -118,11 +118,18 @@ class VarianceAdaptor(nn.Module):
         w = emb.weight.reshape(1, 1, -1)
         return ((v.unsqueeze(-1) * w + emb.bias.reshape(1, 1, -1)) * fmask_bt1).to(dtype)
 
-    def _frames(self, x, durations, flen, Tf, fmask_bt1, log_cf0_in=None, energy_in=None):
+    def _frames(self, x, durations, flen, Tf, fmask_bt1, log_cf0_in=None, energy_in=None, pitch_stream=None):
         h = PF.length_regulate(x, durations, Tf)
         if self.frame_prior_network is not None:
             h = self.frame_prior_network.forward_cl(h, flen)
-        pv = self.pitch_predictor.cl(h, flen)  # (B,Tf,2) f32
+        if pitch_stream is not None:
+            # training with teacher-forced pitch: the predictor's output feeds only its two losses -- an independent branch,
+            # issued (and by autograd differentiated) on its own stream beside the decoder (model.py, PTPP_BRANCH_STREAMS)
+            pitch_stream.wait_stream(torch.cuda.current_stream())
+            with ops.unpinned(), torch.cuda.stream(pitch_stream):
+                pv = self.pitch_predictor.cl(h, flen)
+        else:
+            pv = self.pitch_predictor.cl(h, flen)  # (B,Tf,2) f32
         log_cf0, vuv = pv[..., 0], pv[..., 1]
         # both predictors read the frame-prior output; the embeddings are added together afterwards
         # (variance_adaptor.py:139-146: energy_predictor(x) runs BEFORE x = x + pitch_emb + energy_emb)
@@ -134,11 +141,20 @@ class VarianceAdaptor(nn.Module):
             h = h + self._embed_scalar(self.energy_emb, energy if energy_in is None else energy_in, fmask_bt1, h.dtype)
         return h, log_cf0, vuv, energy
 
-    def forward_cl(self, x, plen, flen, fmask_bt1, duration, log_cf0, energy=None):
+    def forward_cl(self, x, plen, flen, fmask_bt1, duration, log_cf0, energy=None, branch_streams=None):
         """Training forward.  x (B,Tp,C); duration (B,Tp) frames (integer valued);
         log_cf0 (B,Tf).  Returns (h (B,Tf,C), mdn_out, log_cf0_pred, vuv_pred, energy_pred)."""
-        dur_out = self.duration_predictor.cl(x, plen)
-        h, cf0_p, vuv_p, en_p = self._frames(x, duration, flen, fmask_bt1.shape[1], fmask_bt1, log_cf0, energy)
+        sd, sp = branch_streams if branch_streams is not None else (None, None)
+        if sd is not None and self.duration_predictor.detach:
+            # the duration predictor reads a DETACHED copy of x and feeds only loss_dur: another independent branch
+            sd.wait_stream(torch.cuda.current_stream())
+            with ops.unpinned(), torch.cuda.stream(sd):
+                dur_out = self.duration_predictor.cl(x, plen)
+        else:
+            dur_out = self.duration_predictor.cl(x, plen)
+        teacher_forced = log_cf0 is not None and self.energy_predictor is None
+        h, cf0_p, vuv_p, en_p = self._frames(x, duration, flen, fmask_bt1.shape[1], fmask_bt1, log_cf0, energy,
+                                             pitch_stream=sp if teacher_forced else None)
         return h, dur_out, cf0_p, vuv_p, en_p
 
     def durations_cl(self, x, plen, pmask_bt):
