@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0
 # HBM traffic comes from PMC passes (bench.py cannot run rocprofv3 on itself): the committed summaries of
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command / of tools/bench_vocoder.py, written by
 # tools/pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md; the JSON line names the file it read.
-TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r02c_hbm_traffic_train.json")
-TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r02c_hbm_traffic_bigvgan.json")
+TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r03_hbm_traffic_train.json")
+TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r03_hbm_traffic_bigvgan.json")
 
 
 def measured_traffic(path, kernel_substr=None):
@@ -236,7 +236,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         ops.conv1d_gate_bwd = orig_gbwd
     # the dominant kernel = the LDS-DMA conv kernel these launches take (csrc/conv1d_glds.h; rocprof:
     # conv1d_glds_kernel<2, 4, 2, 2, 2>, 64 x 128 tiles, and <4, 4, 2, 2, 2>, 128 x 128 tiles, for the few launches
-    # with >= 1536 tiles; profiles/r02b_train_step.md is the rocprofv3 summary of the training leg of this command);
+    # with >= 1536 tiles; profiles/r03_train_step.md is the rocprofv3 summary of the training leg of this command);
     # launches of the conv family with smaller tiles / split-K are listed there, not averaged in here
     tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
     tot_flop = sum(f for _, _, f, _ in recs)
