@@ -272,9 +272,10 @@ class ConformerBlockFn(torch.autograd.Function):
             ctx.tensors = (x, pos, lens, slab)
             ctx.w, ctx.w_keep = a.w, keep  # the forward operands: the backward reads the same ones (no second lookup)
             ctx.direct = [PF._sink(t) is not None for t in P]
-            # depthwise taps / BatchNorm parameters come back through autograd (their kernels accumulate with atomics into
-            # fresh buffers, as in the per-launch path); everything else accumulates in place when the trainer allows it
-            for i in (33, 34, 35, 36):
+            # the BatchNorm parameter gradients come back through autograd (their kernel OVERWRITES a (2C) buffer);
+            # everything else accumulates in place when the trainer allows it (the depthwise kernel adds with atomics:
+            # straight into p.grad instead of into a zero-filled buffer that autograd then adds)
+            for i in (35, 36):
                 ctx.direct[i] = False
             for i, t in enumerate(P):
                 if ctx.direct[i]:
