@@ -15,6 +15,8 @@
 // One wave owns one query row: lanes run over keys j for the scores (q+u, q+v in
 // LDS, broadcast reads; k/p rows streamed with 8/16-byte loads out of L2), a
 // shuffle max/sum softmax, then lanes run over 4-channel vectors for P.V.
+#include <stdlib.h>
+
 #include "ptpp_common.h"
 
 namespace {
@@ -139,6 +141,240 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
   }
   if (lane < nvec) Elem<T>::st4(ob + dv, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward on the matrix cores with K and V of one (utterance, head) resident in LDS (round 3; bf16, T <= 256,
+// dk in {64, 128}, the "new" rel-pos table or no table).  One block = 64 query rows of one (b, h), one wave = 16 of them:
+//   K, V (T x dk)                -> LDS once per block (swizzled rows; V in the layout of the transposing LDS read)
+//   S^T  = K_frag  x (q + u)^T   v_mfma_f32_16x16x32_bf16: A = 16 keys x 32 channels from LDS, B = the wave's 16 query rows
+//                                from registers; a lane ends up with ONE query row (lane & 15) and 4 consecutive keys per
+//                                16-key fragment, so the softmax reductions are register loops + two shuffles
+//   bd   : R^T = P_frag x (q + v)^T over the 32 table rows a 16 x 16 (query, key) block can touch (A straight from
+//                                global memory: the table is shared by every block and lives in L2), then the skew
+//                                bd[i, j] = R[i, T-1-i+j] through a 16 x 32 f32 LDS patch per wave
+//   O^T  = V^T_frag x P          A = 16 channels x 32 keys by ds_read_b64_tr_b16 (the transposing read of the weight-
+//                                gradient kernel), B = the lane's own probabilities: the K order inside an MFMA step is
+//                                free, so it is chosen to be the order the lane already holds them in
+// Same masking, probability output (f32, before dropout) and dropout mask as attn_fwd_kernel; q + u / q + v are rounded
+// to bf16 operands (the row kernel keeps them in f32), which is within the bf16 tolerance of the tests.
+constexpr int MF_QT = 64;  // query rows per block
+
+template <int CPR>
+__device__ __forceinline__ int vsw(int row);  // chunk swizzle of the V image (as conv1d_wgrad_bf16.hip::sw)
+template <>
+__device__ __forceinline__ int vsw<16>(int row) { return ((row & 3) | ((row >> 1) & 4)) << 1; }
+template <>
+__device__ __forceinline__ int vsw<8>(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
+template <int CPR>
+__device__ __forceinline__ int ksw(int row);  // chunk swizzle of the K image: the 16 lanes of a b128 group read 16 rows
+template <>
+__device__ __forceinline__ int ksw<16>(int row) { return row & 15; }
+template <>
+__device__ __forceinline__ int ksw<8>(int row) { return (row >> 1) & 7; }
+
+typedef __attribute__((ext_vector_type(4))) short mf_v4s;
+__device__ __forceinline__ mf_v4s mf_tr_read(const bf16_raw* p) {
+  mf_v4s r;
+  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) bf16_raw*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a) : "memory");
+  return r;
+}
+__device__ __forceinline__ uint4 mf_pack8(const float (&v)[8]) {
+  uint4 o;
+  o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+  o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  return o;
+}
+
+template <int DK>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnP p) {
+  typedef bf16_raw T;
+  constexpr int CPR = DK / 8;      // 16-byte chunks per K / V row
+  constexpr int KS = DK / 32;      // MFMA K steps over the channels
+  constexpr int MAXNF = 16;        // key fragments of 16 (T <= 256)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Tn = p.T;
+  const int Tp = (Tn + 31) & ~31;  // keys padded to whole 32-key MFMA steps (zero rows)
+  uint4* Ks = reinterpret_cast<uint4*>(smem);                 // [Tp][CPR] swizzled chunks
+  T* Vs = reinterpret_cast<T*>(Ks + (size_t)Tp * CPR);        // [Tp][DK], chunk-swizzled for the transposing read
+  float* Rs = reinterpret_cast<float*>(Vs + (size_t)Tp * DK); // [4 waves][16][33] skew patches
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int i0 = blockIdx.x * MF_QT + w * 16;  // the wave's first query row
+  const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
+  const int hc = h * DK;
+  const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + hc;
+  const T* kb = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + hc;
+  const T* vb = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + hc;
+  const T* pb = p.pos ? reinterpret_cast<const T*>(p.pos) + hc : nullptr;
+
+  // ---- K, V -> LDS (rows >= len are never used with a non-zero weight, rows >= T are zero) ----
+  for (int idx = tid; idx < Tp * CPR; idx += 256) {
+    const int row = idx / CPR, c = idx % CPR;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
+    if (row < Tn) {
+      kv = *reinterpret_cast<const uint4*>(kb + (int64_t)row * p.ld + c * 8);
+      vv = *reinterpret_cast<const uint4*>(vb + (int64_t)row * p.ld + c * 8);
+    }
+    Ks[row * CPR + (c ^ ksw<CPR>(row))] = kv;
+    *reinterpret_cast<uint4*>(Vs + row * DK + ((c ^ vsw<CPR>(row)) << 3)) = vv;
+  }
+  // ---- the wave's query operands: lane (query lq, channel chunk lg of each K step) ----
+  const int iq = i0 + lq;
+  const bool qvalid = iq < Tn;
+  uint4 qu[KS], qv[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (qvalid) {
+      const int ch = ks * 32 + lg * 8;
+      const uint4 r = *reinterpret_cast<const uint4*>(qb + (int64_t)iq * p.ld + ch);
+      const float qf[8] = {__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u), __uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u),
+                           __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        a[e] = qf[e] + (p.variant != VAR_PLAIN ? p.bias_u[hc + ch + e] : 0.f);
+        c[e] = qf[e] + (p.variant != VAR_PLAIN ? p.bias_v[hc + ch + e] : 0.f);
+      }
+    }
+    qu[ks] = mf_pack8(a);
+    qv[ks] = mf_pack8(c);
+  }
+  __syncthreads();
+  if (i0 >= Tn) return;  // (after the only block-wide barrier)
+
+  // ---- scores: s[nf][r] = score of query iq against key 16 nf + 4 lg + r ----
+  const int nfr = (len + 15) >> 4;  // key fragments that hold unmasked keys
+  f32x4 sc[MAXNF];
+  float* Rw = Rs + w * (16 * 33);
+#pragma unroll
+  for (int nf = 0; nf < MAXNF; ++nf) {
+    sc[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nf < nfr) {
+      const int krow = nf * 16 + lq;  // A operand: lane (key krow, channel chunk lg)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 kf = Ks[krow * CPR + ((ks * 4 + lg) ^ ksw<CPR>(krow))];
+        sc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qu[ks]), sc[nf], 0, 0, 0);
+      }
+      if (p.variant == VAR_NEW) {
+        // table rows this (16 queries x 16 keys) block touches: m = T-1-i+j, i in [i0, i0+15], j in [16 nf, 16 nf + 15]
+        const int m0 = Tn - 1 - (i0 + 15) + nf * 16;  // >= -15 + ... ; rows outside [0, 2T-2] belong to masked / absent pairs
+        f32x4 r0 = f32x4{0.f, 0.f, 0.f, 0.f}, r1 = r0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int ma = m0 + lq, mb = m0 + 16 + lq;
+          uint4 pa = make_uint4(0, 0, 0, 0), pbv = pa;
+          if (ma >= 0 && ma < 2 * Tn - 1) pa = *reinterpret_cast<const uint4*>(pb + (int64_t)ma * p.ldpos + ks * 32 + lg * 8);
+          if (mb >= 0 && mb < 2 * Tn - 1) pbv = *reinterpret_cast<const uint4*>(pb + (int64_t)mb * p.ldpos + ks * 32 + lg * 8);
+          r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa), __builtin_bit_cast(bf16x8_t, qv[ks]), r0, 0, 0, 0);
+          r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pbv), __builtin_bit_cast(bf16x8_t, qv[ks]), r1, 0, 0, 0);
+        }
+        // skew through the wave's LDS patch: R[query lq][c], c = table row - m0 in [0, 32); wanted c = 15 - lq + (4 lg + r)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Rw[lq * 33 + 4 * lg + r] = r0[r];
+          Rw[lq * 33 + 16 + 4 * lg + r] = r1[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[nf][r] += Rw[lq * 33 + 15 - lq + 4 * lg + r];
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  // ---- softmax over the keys of the lane's query row (registers + the 4 lane groups) ----
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int nf = 0; nf < MAXNF; ++nf)
+    if (nf < nfr)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = nf * 16 + 4 * lg + r;
+        sc[nf][r] = j < len ? sc[nf][r] * p.scale : -3.0e38f;
+        mx = fmaxf(mx, sc[nf][r]);
+      }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int nf = 0; nf < MAXNF; ++nf)
+    if (nf < nfr)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = nf * 16 + 4 * lg + r;
+        const float e = j < len ? __expf(sc[nf][r] - mx) : 0.f;
+        sc[nf][r] = e;
+        sum += e;
+      }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const bool row_on = qvalid && iq < len;  // padded query rows: all probabilities zero, output zero
+  const float inv = row_on ? 1.f / sum : 0.f;
+  float* prow = (p.probs && qvalid) ? p.probs + (((int64_t)b * p.H + h) * Tn + iq) * Tn : nullptr;
+  const uint64_t drow = (((uint64_t)b * p.H + h) * Tn + (uint64_t)iq) * (uint64_t)Tn;
+#pragma unroll
+  for (int nf = 0; nf < MAXNF; ++nf) {
+    if (nf * 16 < Tn) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = nf * 16 + 4 * lg + r;
+        float pr = nf < nfr ? sc[nf][r] * inv : 0.f;
+        if (prow && j < Tn) prow[j] = pr;  // the softmax itself (the backward regenerates the dropout mask)
+        if (p.drop_thresh16 && j < len) {
+          const uint64_t e = drow + j;
+          const uint32_t bits = (uint32_t)(drop_hash(p.drop_seed, e >> 2) >> (16 * (e & 3))) & 0xffffu;
+          pr = bits >= p.drop_thresh16 ? pr * p.drop_inv_keep : 0.f;
+        }
+        if (nf < nfr) sc[nf][r] = pr;
+      }
+    }
+  }
+  // ---- context: O^T[channel][query] = sum_j V[j][channel] P[query][j]; the 32 keys of an MFMA step are taken in the order
+  // the lane holds them: slots 0-3 = keys kb0 + 4 lg + (0..3), slots 4-7 = keys kb0 + 16 + 4 lg + (0..3) ----
+  f32x4 oc[DK / 16];
+#pragma unroll
+  for (int mf = 0; mf < DK / 16; ++mf) oc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (nfr + 1) >> 1;
+#pragma unroll
+  for (int st = 0; st < MAXNF / 2; ++st) {
+    if (st < nsteps) {
+      float pv[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pv[r] = sc[2 * st][r];
+        pv[4 + r] = (2 * st + 1 < nfr) ? sc[2 * st + 1][r] : 0.f;
+      }
+      const uint4 pf = mf_pack8(pv);
+      const int kb0 = st * 32;
+#pragma unroll
+      for (int mf = 0; mf < DK / 16; ++mf) {
+        // transposing reads: lane i of a 16-lane group addresses row (base + (i >> 2)), columns mf*16 + 4 (i & 3) .. +3 and
+        // receives column mf*16 + i of the 4 rows base .. base + 3
+        const int col = mf * 16 + 4 * (lq & 3);
+        const int ra = kb0 + 4 * lg + (lq >> 2), rb = ra + 16;
+        const mf_v4s lo = mf_tr_read(Vs + ra * DK + (((col >> 3) ^ vsw<CPR>(ra)) << 3) + (col & 7));
+        const mf_v4s hi = mf_tr_read(Vs + rb * DK + (((col >> 3) ^ vsw<CPR>(rb)) << 3) + (col & 7));
+        typedef __attribute__((ext_vector_type(8))) short v8s_;
+        v8s_ av;
+        av[0] = lo[0]; av[1] = lo[1]; av[2] = lo[2]; av[3] = lo[3];
+        av[4] = hi[0]; av[5] = hi[1]; av[6] = hi[2]; av[7] = hi[3];
+        oc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, pf), oc[mf], 0, 0, 0);
+      }
+    }
+  }
+  if (qvalid) {
+    T* ob = reinterpret_cast<T*>(p.ctx) + ((int64_t)b * Tn + iq) * p.ldctx + hc;
+#pragma unroll
+    for (int mf = 0; mf < DK / 16; ++mf) Elem<T>::st4(ob + mf * 16 + 4 * lg, row_on ? oc[mf] : f32x4{0.f, 0.f, 0.f, 0.f});
+  }
 }
 
 // ---- backward, kernel 1: per query row -> dS row, dq, du, dv ------------------
@@ -390,9 +626,27 @@ extern "C" int ptpp_attention_fwd(const void* q, const void* k, const void* v, c
   p.drop_thresh16 = drop_p > 0.f ? (unsigned)(drop_p * 65536.f + 0.5f) : 0u;
   p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - p.drop_thresh16 / 65536.f) : 1.f;
   p.drop_seed = drop_seed;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // bf16, T <= 256, dk 64 / 128, no legacy table: K / V resident in LDS, products on the matrix cores (PTPP_ATTN_MFMA=0: row kernel)
+  static const char* mfma_env = getenv("PTPP_ATTN_MFMA");
+  if (dtype == PTPP_BF16 && T_ <= 256 && (dk == 64 || dk == 128) && variant != VAR_LEGACY && ld % 8 == 0 && ldctx % 4 == 0 &&
+      (variant == VAR_PLAIN || ldpos % 8 == 0) && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+      (!pos || ((uintptr_t)pos % 16) == 0) && !(mfma_env && mfma_env[0] == '0')) {
+    const int Tp = (T_ + 31) & ~31;
+    const size_t sm = (size_t)Tp * dk * 2 * 2 + 4 * 16 * 33 * sizeof(float);
+    dim3 g((T_ + MF_QT - 1) / MF_QT, H, B);
+    if (dk == 128) {
+      if (sm > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+      hipLaunchKernelGGL(attn_fwd_mfma_kernel<128>, g, dim3(256), sm, st, p);
+    } else {
+      if (sm > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+      hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, g, dim3(256), sm, st, p);
+    }
+    PTPP_CHECK_LAUNCH("attention_fwd (mfma)");
+    return PTPP_OK;
+  }
   const size_t smem = (size_t)4 * (3 * dk + ((T_ + 3) & ~3)) * sizeof(float);
   dim3 grid((T_ + 3) / 4, H, B);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PTPP_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), smem, st, p);
   else if (dtype == PTPP_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_raw>, grid, dim3(256), smem, st, p);
   else PTPP_CHECK_ARG(false, "attention_fwd: bad dtype");

@@ -40,7 +40,7 @@ _stream_pinned = None  # set by pinned_stream(): the handle looked up once for a
 
 # Branch streams (models/.../model.py, PTPP_BRANCH_STREAMS, on by default): autograd runs part of the backward on other
 # streams, so the per-step pinning of the stream handle is off unless they are disabled
-_NO_PIN = __import__("os").environ.get("PTPP_BRANCH_STREAMS", "3") not in ("", "0", "off", "no")
+_NO_PIN = __import__("os").environ.get("PTPP_BRANCH_STREAMS", "2") not in ("", "0", "off", "no")
 
 
 class pinned_stream:

@@ -200,7 +200,7 @@ def test_no_gradient_kernel_writes_a_bucket_after_its_collective_was_issued():
 
         from promptttspp_amd.models.prompttts_mdn_v2_final import model as M
 
-        assert M.BRANCH_STREAMS == "3"  # the default: four branches of the backward run on two extra streams
+        assert M.BRANCH_STREAMS == "2"  # the default: prompt branch and reference encoder backward run on their own streams
         dev = torch.device("cuda:0")
         for dtype in (torch.float32, torch.bfloat16):
             config.set_compute_dtype(dtype)

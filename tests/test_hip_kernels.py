@@ -801,3 +801,39 @@ def test_mdn_nll_fused_matches_the_tensor_ops(dev, B, T, G, D, masked):
     for g, r in zip(got[1:], ref[1:]):
         assert torch.isfinite(g).all()
         assert rel_err(g.cpu(), r.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("variant,B,T,H,dk,drop", [("new", 5, 77, 2, 128, 0.0), ("new", 3, 256, 2, 128, 0.0), ("new", 19, 130, 2, 128, 0.0),
+                                                   ("new", 2, 33, 4, 64, 0.0), ("plain", 19, 48, 12, 64, 0.1), ("plain", 4, 200, 2, 128, 0.0),
+                                                   ("new", 1, 16, 2, 128, 0.0)])
+def test_attention_forward_on_the_matrix_cores(dev, variant, B, T, H, dk, drop):
+    """attn_fwd_mfma_kernel (bf16: K / V of one (utterance, head) resident in LDS, score / positional / context products on
+    the MFMAs, rel-shift as a skewed read; reference esp/transformer/attention.py:63-93,237-305) against the exact-f32 row
+    kernel on the same bf16-rounded operands: probabilities (saved for the backward), context, masked keys and padded query
+    rows, probability dropout with the same (seed, element) mask, ragged lengths, T not a multiple of the tile sizes."""
+    from promptttspp_amd import ops
+
+    C = H * dk
+    qkv = (rnd(1, B, T, 3 * C) * 0.5).to(dev).bfloat16()
+    lens = torch.tensor([max(1, T - 11 * i) for i in range(B)], device=dev, dtype=torch.int32)
+    pos = u = vb = None
+    if variant == "new":
+        pos = (rnd(2, 2 * T - 1, C) * 0.5).to(dev).bfloat16()
+        u, vb = (0.1 * rnd(3, H, dk)).to(dev), (0.1 * rnd(4, H, dk)).to(dev)
+    q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+    ctx, probs = ops.attention_fwd(q, k, v, pos, u, vb, lens, H, variant, save_probs=True, drop_p=drop, drop_seed=1234)
+    qf = qkv.float()
+    ctx_r, probs_r = ops.attention_fwd(qf[:, :, :C], qf[:, :, C:2 * C], qf[:, :, 2 * C:], pos.float() if pos is not None else None, u, vb,
+                                       lens, H, variant, save_probs=True, drop_p=drop, drop_seed=1234)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ctx.float()).all() and torch.isfinite(probs).all()
+    # probabilities: rows sum to 1 over the valid keys, zero on masked keys and padded query rows
+    for bi in range(B):
+        n = int(lens[bi])
+        assert float((probs[bi, :, :n, :n].sum(-1) - 1).abs().max()) < 1e-4
+        assert float(probs[bi, :, :, n:].abs().max() if n < T else 0.0) == 0.0
+        assert float(probs[bi, :, n:, :].abs().max() if n < T else 0.0) == 0.0
+        assert float(ctx[bi, n:].float().abs().max() if n < T else 0.0) == 0.0
+    assert float((probs - probs_r).abs().max()) < 2e-2 * float(probs_r.max())   # q + u / q + v rounded to bf16 operands
+    err = float((ctx.float() - ctx_r).abs().max() / ctx_r.abs().max())
+    assert err < 2e-2, err

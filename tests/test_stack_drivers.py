@@ -323,10 +323,10 @@ def test_conv_ln_stack_batched_weight_gradients(dev, monkeypatch):
             assert torch.equal(a, b) and torch.equal(b, c), n
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "3"])
+@pytest.mark.parametrize("mode", ["1", "2"])
 def test_branch_streams_give_the_same_losses_and_gradients(dev, monkeypatch, mode):
-    """PTPP_BRANCH_STREAMS: the prompt branch (mode 1), the reference encoder (mode 2) and the duration / pitch predictors
-    (mode 3, the default) of the TRAINING forward on their own streams -- forward here, backward by autograd on the same streams -- against the single-stream step on the same
+    """PTPP_BRANCH_STREAMS: the prompt branch (mode 1) and the reference encoder (mode 2, the default) of the TRAINING forward
+    on their own streams -- forward here, backward by autograd on the same streams -- against the single-stream step on the same
     weights, batch and dropout seeds (f32, reference model.py:72-183): the six losses are equal bit for bit, every parameter
     gradient within the noise of the order-dependent reductions (a missed cross-stream dependency would show as a wrong or
     missing gradient, orders of magnitude above that), three times in a row."""
