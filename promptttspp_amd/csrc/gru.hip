@@ -68,6 +68,115 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restri
   dghb[2 * H + j] = dn_pre * r;
 }
 
+
+// ---- the whole recurrence in ONE launch (H = 128) -------------------------------------------------------------------
+// The per-step path costs 2 (forward) / 3 (backward) launches per step of <= 10 us of work each on (B, H) = (~20, 128)
+// operands; with ~24 steps that is ~120 launches per training step.  Here a block owns one sequence for all its steps:
+// thread j keeps row j of W_hh (forward) / a 128-entry column slice of it (backward) in registers, h / dgh travel
+// through LDS, and the pre-activations W_hh h + b_hh and the hidden states are written once for the backward.
+// Steps at or after len[b] are skipped (the packed-sequence semantics: h frozen, zero gradient).
+constexpr int GRU_H = 128;
+
+__global__ __launch_bounds__(3 * GRU_H) void gru_seq_fwd_kernel(const float* __restrict__ gi_all, const float* __restrict__ w_hh,
+                                                                  const float* __restrict__ b_hh, const int* __restrict__ lens,
+                                                                  float* __restrict__ hs_all, float* __restrict__ gh_all,
+                                                                  float* __restrict__ hout, int B, int L) {
+  constexpr int H = GRU_H;
+  __shared__ __attribute__((aligned(16))) float hs[H];
+  __shared__ float ghs[3 * H];
+  const int b = blockIdx.x, j = threadIdx.x;
+  float w[H];
+#pragma unroll
+  for (int k = 0; k < H; k += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(w_hh + (int64_t)j * H + k);
+    w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+  }
+  const float bias = b_hh[j];
+  const int n = lens ? min(max(lens[b], 0), L) : L;
+  float hreg = 0.f;  // threads j < H: h[j]
+  if (j < H) {
+    hs[j] = 0.f;
+    hs_all[(int64_t)b * H + j] = 0.f;
+  }
+  __syncthreads();
+  for (int s = 0; s < n; ++s) {
+    float a0 = bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < H; k += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(hs + k);
+      a0 = fmaf(w[k], hv.x, a0); a1 = fmaf(w[k + 1], hv.y, a1); a2 = fmaf(w[k + 2], hv.z, a2); a3 = fmaf(w[k + 3], hv.w, a3);
+    }
+    const float gh = (a0 + a1) + (a2 + a3);
+    ghs[j] = gh;
+    gh_all[((int64_t)s * B + b) * 3 * H + j] = gh;
+    __syncthreads();
+    if (j < H) {
+      const float* gib = gi_all + ((int64_t)b * L + s) * 3 * H;
+      const float r = sigm(gib[j] + ghs[j]);
+      const float z = sigm(gib[H + j] + ghs[H + j]);
+      const float nn = tanhf(gib[2 * H + j] + r * ghs[2 * H + j]);
+      hreg = (1.f - z) * nn + z * hreg;
+      hs[j] = hreg;
+      hs_all[((int64_t)(s + 1) * B + b) * H + j] = hreg;
+    }
+    __syncthreads();
+  }
+  if (j < H) hout[(int64_t)b * H + j] = hreg;
+}
+
+__global__ __launch_bounds__(3 * GRU_H) void gru_seq_bwd_kernel(const float* __restrict__ gi_all, const float* __restrict__ w_hh,
+                                                                  const int* __restrict__ lens, const float* __restrict__ hs_all,
+                                                                  const float* __restrict__ gh_all, const float* __restrict__ dhout,
+                                                                  float* __restrict__ dgi_all, float* __restrict__ dgh_all, int B,
+                                                                  int L) {
+  constexpr int H = GRU_H;
+  __shared__ __attribute__((aligned(16))) float dghs[3 * H];
+  __shared__ float part[3][H];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int p = tid / H, k = tid % H;
+  float w[H];  // W_hh[p H + i][k]: this thread's slice of column k
+#pragma unroll
+  for (int i = 0; i < H; ++i) w[i] = w_hh[(int64_t)(p * H + i) * H + k];
+  const int n = lens ? min(max(lens[b], 0), L) : L;
+  float d = tid < H ? dhout[(int64_t)b * H + tid] : 0.f;  // threads < H: dL/dh_s[tid]
+  for (int s = L - 1; s >= n; --s) {  // steps after the sequence's end: h passed through, no gradient to the gates
+    dgi_all[((int64_t)b * L + s) * 3 * H + tid] = 0.f;
+    dgh_all[((int64_t)s * B + b) * 3 * H + tid] = 0.f;
+  }
+  for (int s = n - 1; s >= 0; --s) {
+    float direct = 0.f;
+    if (tid < H) {
+      const int j = tid;
+      const float* gib = gi_all + ((int64_t)b * L + s) * 3 * H;
+      const float* ghb = gh_all + ((int64_t)s * B + b) * 3 * H;
+      const float hp = hs_all[((int64_t)s * B + b) * H + j];
+      const float ghn = ghb[2 * H + j];
+      const float r = sigm(gib[j] + ghb[j]);
+      const float z = sigm(gib[H + j] + ghb[H + j]);
+      const float nn = tanhf(gib[2 * H + j] + r * ghn);
+      const float dn_pre = d * (1.f - z) * (1.f - nn * nn);
+      const float dz_pre = d * (hp - nn) * z * (1.f - z);
+      const float dr_pre = dn_pre * ghn * r * (1.f - r);
+      direct = d * z;
+      float* dgib = dgi_all + ((int64_t)b * L + s) * 3 * H;
+      float* dghb = dgh_all + ((int64_t)s * B + b) * 3 * H;
+      dgib[j] = dr_pre; dgib[H + j] = dz_pre; dgib[2 * H + j] = dn_pre;
+      dghb[j] = dr_pre; dghb[H + j] = dz_pre; dghb[2 * H + j] = dn_pre * r;
+      dghs[j] = dr_pre; dghs[H + j] = dz_pre; dghs[2 * H + j] = dn_pre * r;
+    }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < H; i += 4) {
+      const float4 g = *reinterpret_cast<const float4*>(dghs + p * H + i);
+      a0 = fmaf(w[i], g.x, a0); a1 = fmaf(w[i + 1], g.y, a1); a2 = fmaf(w[i + 2], g.z, a2); a3 = fmaf(w[i + 3], g.w, a3);
+    }
+    part[p][k] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tid < H) d = direct + (part[0][tid] + part[1][tid] + part[2][tid]);
+  }
+}
+
 }  // namespace
 
 extern "C" int ptpp_gru_gate_fwd(const float* gi, int64_t ldgi, const float* gh, const float* h, const int32_t* lens,
@@ -90,5 +199,29 @@ extern "C" int ptpp_gru_gate_bwd(const float* gi, int64_t ldgi, const float* gh,
   hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      gi, ldgi, gh, h, lens, step, dhout, dgi, lddgi, dgh, dh, B, H);
   PTPP_CHECK_LAUNCH("gru_gate_bwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_gru_seq_supported(int H) { return H == GRU_H; }
+
+extern "C" int ptpp_gru_seq_fwd(const float* gi_all, const float* w_hh, const float* b_hh, const int32_t* lens, float* hs_all,
+                                float* gh_all, float* hout, int B, int L, int H, void* stream) {
+  PTPP_CHECK_ARG(gi_all && w_hh && b_hh && hs_all && gh_all && hout && B > 0 && L > 0, "gru_seq_fwd: bad args");
+  PTPP_CHECK_ARG(H == GRU_H, "gru_seq_fwd: H = %d (the one-launch recurrence is built for H = %d; use the per-step entry points)", H,
+                 GRU_H);
+  PTPP_CHECK_ARG(((uintptr_t)w_hh & 15) == 0, "gru_seq_fwd: w_hh must be 16-byte aligned");
+  hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3((unsigned)B), dim3(3 * GRU_H), 0, reinterpret_cast<hipStream_t>(stream), gi_all, w_hh,
+                     b_hh, lens, hs_all, gh_all, hout, B, L);
+  PTPP_CHECK_LAUNCH("gru_seq_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_gru_seq_bwd(const float* gi_all, const float* w_hh, const int32_t* lens, const float* hs_all, const float* gh_all,
+                                const float* dhout, float* dgi_all, float* dgh_all, int B, int L, int H, void* stream) {
+  PTPP_CHECK_ARG(gi_all && w_hh && hs_all && gh_all && dhout && dgi_all && dgh_all && B > 0 && L > 0, "gru_seq_bwd: bad args");
+  PTPP_CHECK_ARG(H == GRU_H, "gru_seq_bwd: H = %d (built for H = %d)", H, GRU_H);
+  hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((unsigned)B), dim3(3 * GRU_H), 0, reinterpret_cast<hipStream_t>(stream), gi_all, w_hh,
+                     lens, hs_all, gh_all, dhout, dgi_all, dgh_all, B, L);
+  PTPP_CHECK_LAUNCH("gru_seq_bwd");
   return PTPP_OK;
 }

@@ -189,10 +189,14 @@ def conv2d_3x3s2(x, weight):
     return y.view(B, Ho, Wo, cout)
 
 
+GRU_SEQ = True  # the whole recurrence as one launch (ptpp_gru_seq_*) where the library supports the width
+
+
 class GruFn(Function):
-    """The GRU recurrence with a hand-written backward: per step ONE GEMM (W_hh h + b_hh, exact f32, on
-    the conv kernel) and ONE gate kernel (csrc/gru.hip), forward and backward.  Inputs: gi_all (B, L, 3H)
-    f32 = W_ih x + b_ih for all steps, weight_hh (3H, H), bias_hh (3H), lens (B) int32."""
+    """The GRU recurrence with a hand-written backward.  Inputs: gi_all (B, L, 3H) f32 = W_ih x + b_ih for all steps,
+    weight_hh (3H, H), bias_hh (3H), lens (B) int32.  H = 128 (the reference's gru_units): ONE launch for all steps
+    forward, one for the backward recurrence and one weight-gradient GEMM over all steps (csrc/gru.hip, gru_seq_*).
+    Other widths: per step one GEMM (W_hh h + b_hh, exact f32, on the conv kernel) and one gate kernel."""
 
     @staticmethod
     def forward(ctx, gi_all, weight_hh, bias_hh, lens):
@@ -200,6 +204,22 @@ class GruFn(Function):
         B, L, H3 = gi_all.shape
         Hn = H3 // 3
         lib = _lib.load()
+        ctx.seq = GRU_SEQ and bool(lib.ptpp_gru_seq_supported(Hn))
+        if ctx.seq:
+            dev = gi_all.device
+            w, bh = PF._f32c(weight_hh), PF._f32c(bias_hh)
+            hs_all = torch.empty((L + 1, B, Hn), device=dev, dtype=torch.float32)
+            gh_all = torch.empty((L, B, H3), device=dev, dtype=torch.float32)
+            h = torch.empty((B, Hn), device=dev, dtype=torch.float32)
+            _chk(lib.ptpp_gru_seq_fwd(_ptr(gi_all), _ptr(w), _ptr(bh), _ptr(lens), _ptr(hs_all), _ptr(gh_all), _ptr(h), B, L, Hn,
+                                      _stream()), "ptpp_gru_seq_fwd")
+            ctx.hs, ctx.ghs, ctx.lens, ctx.w, ctx.b, ctx.wf = hs_all, gh_all, lens, weight_hh, bias_hh, w
+            ctx.sink = PF._sink(weight_hh) is not None and PF._sink(bias_hh) is not None
+            if ctx.sink:
+                PF._use(weight_hh)
+                PF._use(bias_hh)
+            ctx.save_for_backward(gi_all)
+            return h
         wp = PF.packed(weight_hh, torch.float32)
         bh = PF._f32c(bias_hh)
         h = torch.zeros((B, Hn), device=gi_all.device, dtype=torch.float32)
@@ -229,7 +249,6 @@ class GruFn(Function):
         Hn = H3 // 3
         lib = _lib.load()
         w = ctx.w
-        wpt = PF.packed(w, torch.float32, mode=1)
         dgi_all = torch.empty_like(gi_all)
         if ctx.sink:
             dw, db = w.grad, ctx.b.grad
@@ -237,6 +256,20 @@ class GruFn(Function):
             dw = torch.zeros((H3, Hn, 1), device=dh.device, dtype=torch.float32)
             db = torch.zeros((H3,), device=dh.device, dtype=torch.float32)
         dh = dh.contiguous().float()
+        if ctx.seq:
+            dgh_all = torch.empty_like(ctx.ghs)
+            _chk(lib.ptpp_gru_seq_bwd(_ptr(gi_all), _ptr(ctx.wf), _ptr(ctx.lens), _ptr(ctx.hs), _ptr(ctx.ghs), _ptr(dh),
+                                      _ptr(dgi_all), _ptr(dgh_all), B, L, Hn, _stream()), "ptpp_gru_seq_bwd")
+            # dW_hh = sum over steps and sequences of dgh^T h_{s-1}, db_hh = sum dgh: one GEMM over L B rows
+            with PF.wgrad_stream(*((ctx.hs, dgh_all) if ctx.sink else ())):
+                ops.conv1d_wgrad(ctx.hs[:L].view(1, L * B, Hn), dgh_all.view(1, L * B, H3), Hn, H3, 1, 1, 0, dw_out=dw, db_out=db)
+            ctx.hs = ctx.ghs = ctx.wf = None
+            if ctx.sink:
+                PF._done(w)
+                PF._done(ctx.b)
+                return dgi_all, None, None, None
+            return dgi_all, dw.view_as(w), db, None
+        wpt = PF.packed(w, torch.float32, mode=1)
         for s in reversed(range(L)):
             h_prev, gh = ctx.hs[s], ctx.ghs[s]
             dgh = torch.empty_like(gh)

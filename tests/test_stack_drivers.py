@@ -437,3 +437,43 @@ def test_conformer_block_driver_is_bit_identical(dev, monkeypatch, variant, dtyp
             assert torch.allclose(a, b, rtol=2e-5, atol=max(3e-6 * float(a.abs().max()), 1e-7)), (n_, float((a - b).abs().max()))
     for k in stats[0]:
         assert torch.equal(stats[0][k], stats[1][k]) or torch.allclose(stats[0][k].float(), stats[1][k].float(), rtol=1e-6, atol=1e-7), k
+
+
+@pytest.mark.parametrize("B,L,I", [(5, 9, 256), (19, 24, 256), (1, 1, 64)])
+def test_gru_whole_sequence_kernels_match_torch_gru(B, L, I):
+    """nn_ops.gru_last_state (one launch for the whole recurrence, H = 128) against torch.nn.GRU on packed sequences
+    (the reference's op, modules/reference_encoder.py:108-123) in f32 on the CPU: last valid hidden state and the gradients of
+    the input, both weight matrices and both biases; and against this package's own per-step path."""
+    from promptttspp_amd import nn_ops as NO
+    from promptttspp_amd import config
+
+    dev = torch.device("cuda:0")
+    H = 128
+    gru = torch.nn.GRU(I, H, 1, batch_first=True)
+    x = rnd(1, B, L, I, scale=0.7)
+    lens = torch.tensor([max(1, L - (3 * i) % L) for i in range(B)], dtype=torch.long)
+    gout = rnd(2, B, H)
+    # reference
+    xr = x.clone().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lens, batch_first=True, enforce_sorted=False)
+    _, hn = gru(packed)
+    (hn[-1] * gout).sum().backward()
+    want = [hn[-1].detach(), xr.grad] + [p.grad.clone() for p in gru.parameters()]
+    outs = {}
+    with config.use_dtype(torch.float32):
+        for seq in (True, False):
+            NO.GRU_SEQ = seq
+            try:
+                g2 = torch.nn.GRU(I, H, 1, batch_first=True).to(dev)
+                g2.load_state_dict(gru.state_dict())
+                xd = x.to(dev).requires_grad_(True)
+                h = NO.gru_last_state(xd, g2.weight_ih_l0, g2.weight_hh_l0, g2.bias_ih_l0, g2.bias_hh_l0, lens.to(dev))
+                (h * gout.to(dev)).sum().backward()
+                torch.cuda.synchronize()
+                outs[seq] = [h.detach().cpu(), xd.grad.cpu()] + [p.grad.cpu() for p in g2.parameters()]
+            finally:
+                NO.GRU_SEQ = True
+    for i, (a, b, c) in enumerate(zip(outs[True], want, outs[False])):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, (i, float((a - b).abs().max()), scale)
+        assert float((a - c).abs().max()) <= 2e-5 * scale + 1e-7, (i, float((a - c).abs().max()), scale)
