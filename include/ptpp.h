@@ -81,6 +81,12 @@ int ptpp_conv_cin_padded(int cin, int dtype);
 int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin, int ks,
                           int mode, int dtype, void* stream);
 
+/* nn.Conv2d weight w[Cout][Cin][3][3] (f32) -> both operands of the im2col GEMM of ptpp_im2col3x3s2 rows
+ * (K index = (kh*3 + kw)*cinq + ci, channels zero-padded from Cin to cinq):  wp_fwd = mode 0 and wp_bwd (nullable) = mode 1
+ * of ptpp_pack_conv_weight applied to that (Cout, 9*cinq) matrix, in one launch (modules/reference_encoder.py:61-82). */
+int ptpp_pack_conv2d_3x3(const float* w, void* wp_fwd, void* wp_bwd, int cout, int cin,
+                         int cinq, int dtype, void* stream);
+
 /* Re-pack MANY operands in one launch (after an optimiser step).  table: device array of n_entries rows
  * of 10 int64: {src f32 (cout,cin,ks), dst base, cout, cin, ks, mode, dtype, innerp of dst,
  * row (mode 0) / column (mode 1) offset inside dst, first block}; block b serves row block_map[b]
@@ -366,6 +372,10 @@ int ptpp_im2col3x3s2(const void* x, void* col, int B, int H, int W, int C,
                      int dtype, void* stream);
 int ptpp_col2im3x3s2(const void* dcol, void* dx, int B, int H, int W, int C,
                      int dtype, void* stream);
+/* x with ONE channel (B, H, W): col rows get the 8-channel granule [x, 0 x 7] per tap (K = 72), i.e. ptpp_im2col3x3s2 of x
+ * zero-padded to 8 channels without materialising the padded input. */
+int ptpp_im2col3x3s2_c1(const void* x, void* col, int B, int H, int W, int dtype,
+                        void* stream);
 
 /* ------------------------------------------------------------------ *
  * GRU cell gate algebra of the GST reference encoder
@@ -720,6 +730,60 @@ typedef struct {
 } ptpp_conformer_block_bwd_args;
 size_t ptpp_conformer_block_bwd_scratch_bytes(int B, int T, int C, int F, int H, int L, int dtype);
 int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, void* stream);
+
+/* The convolution stack of the GST reference encoder, training mode (modules/reference_encoder.py:61-82, 100-106):
+ * nlayer x [Conv2d 3x3 stride 2 pad 1, no bias -> BatchNorm2d (batch statistics, running estimates updated) -> ReLU] on a
+ * channels-last spectrogram.  x: (B, H, W) with ONE channel; layer i maps (B, H_i, W_i, cin_i) -> (B, ceil(H_i/2),
+ * ceil(W_i/2), cout_i) as [weight pack, im2col gather, GEMM with K = 9 cin_i (8 for the first layer's channel), batch
+ * statistics, normalise + ReLU]: 5 launches.  All tables are HOST arrays of nlayer entries; w: the f32 nn.Conv2d weights;
+ * wp_fwd / wp_bwd: device buffers for the packed operands (cout_i x Kp_i and 9 cin_i x coutp_i elements of dtype; wp_bwd[0]
+ * unused).  The slab keeps what the backward reads (col_i, pre-BN z_i, mean / rstd) -- ptpp_refenc_convs_slab_bytes. */
+typedef struct {
+  const void* x;
+  void* y;                      /* (B, H_n, W_n, cout_last) */
+  const int32_t* cout;          /* HOST [nlayer] */
+  const float* const* w;
+  void* const* wp_fwd;
+  void* const* wp_bwd;
+  const float* const* bn_g;
+  const float* const* bn_b;
+  float* const* bn_rmean;       /* entries nullable: no running estimates */
+  float* const* bn_rvar;
+  void* slab;
+  size_t slab_bytes;
+  void* ws;                     /* split-K scratch of ptpp_conv1d_fwd_ws */
+  size_t ws_bytes;
+  void* red_scratch;            /* PTPP_RED_SCRATCH_BYTES(max cout), zero */
+  size_t red_bytes;
+  float bn_momentum, bn_eps;
+  int32_t B, H, W, nlayer, dtype;
+} ptpp_refenc_convs_fwd_args;
+size_t ptpp_refenc_convs_slab_bytes(int B, int H, int W, int nlayer, const int32_t* cout, int dtype);
+int ptpp_refenc_convs_fwd(const ptpp_refenc_convs_fwd_args* a, void* stream);
+
+/* Backward of the same stack from gy (B, H_n, W_n, cout_last): per layer [BatchNorm + ReLU backward, weight gradient,
+ * data gradient GEMM, col2im] (the first layer has no data gradient).  dwg[i]: f32 (cout_i, 9 cinq_i) matrices in the
+ * GEMM's K order, ACCUMULATED into (the caller permutes them into the nn.Conv2d layout); bn_sums[i]: 2 cout_i f32,
+ * overwritten with [dbeta | dgamma].  scratch: ptpp_refenc_convs_bwd_scratch_bytes. */
+typedef struct {
+  const void* gy;
+  const int32_t* cout;
+  void* const* wp_bwd;
+  const float* const* bn_g;
+  const float* const* bn_b;
+  float* const* dwg;
+  float* const* bn_sums;
+  const void* slab;
+  void* scratch;
+  size_t scratch_bytes;
+  void* ws;                     /* workspace of ptpp_conv1d_wgrad / split-K scratch of the data gradient */
+  size_t ws_bytes;
+  void* red_scratch;
+  size_t red_bytes;
+  int32_t B, H, W, nlayer, dtype;
+} ptpp_refenc_convs_bwd_args;
+size_t ptpp_refenc_convs_bwd_scratch_bytes(int B, int H, int W, int nlayer, const int32_t* cout, int dtype);
+int ptpp_refenc_convs_bwd(const ptpp_refenc_convs_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Data-parallel gradient exchange over RCCL / xGMI (reference: DistributedDataParallel set up in

@@ -158,6 +158,24 @@ class ConformerBwdArgs(Structure):
                [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "ks_ffn", "ks_dw", "variant", "bn_train", "dtype")]
 
 
+class RefEncConvsFwdArgs(Structure):
+    """Mirror of ``ptpp_refenc_convs_fwd_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("x", "y", "cout", "w", "wp_fwd", "wp_bwd", "bn_g", "bn_b", "bn_rmean", "bn_rvar", "slab")] + \
+               [("slab_bytes", ctypes.c_size_t), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t), ("red_scratch", c_void_p),
+                ("red_bytes", ctypes.c_size_t), ("bn_momentum", c_float), ("bn_eps", c_float)] + \
+               [(n, c_int32) for n in ("B", "H", "W", "nlayer", "dtype")]
+
+
+class RefEncConvsBwdArgs(Structure):
+    """Mirror of ``ptpp_refenc_convs_bwd_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("gy", "cout", "wp_bwd", "bn_g", "bn_b", "dwg", "bn_sums", "slab", "scratch")] + \
+               [("scratch_bytes", ctypes.c_size_t), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t), ("red_scratch", c_void_p),
+                ("red_bytes", ctypes.c_size_t)] + \
+               [(n, c_int32) for n in ("B", "H", "W", "nlayer", "dtype")]
+
+
 P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/ptpp.h declares.
@@ -167,6 +185,7 @@ SIGNATURES = {
     "ptpp_stream_wait": (I, [P, P]),
     "ptpp_conv_cin_padded": (I, [I, I]),
     "ptpp_pack_conv_weight": (I, [P, P, I, I, I, I, I, P]),
+    "ptpp_pack_conv2d_3x3": (I, [P, P, P, I, I, I, I, P]),
     "ptpp_pack_conv_weights_batched": (I, [P, I, P, I, P]),
     "ptpp_conv1d_fwd": (I, [POINTER(ConvArgs), P]),
     "ptpp_conv1d_fwd_ex": (I, [POINTER(ConvArgs), P, I, F, F, U64, P]),
@@ -202,6 +221,7 @@ SIGNATURES = {
     "ptpp_dwconv1d": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "ptpp_dwconv1d_wgrad": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "ptpp_im2col3x3s2": (I, [P, P, I, I, I, I, I, P]),
+    "ptpp_im2col3x3s2_c1": (I, [P, P, I, I, I, I, P]),
     "ptpp_col2im3x3s2": (I, [P, P, I, I, I, I, I, P]),
     "ptpp_gru_gate_fwd": (I, [P, I64, P, P, P, I, P, I, I, P]),
     "ptpp_gru_gate_bwd": (I, [P, I64, P, P, P, I, P, P, I64, P, P, I, I, P]),
@@ -228,6 +248,10 @@ SIGNATURES = {
     "ptpp_conformer_block_bwd_scratch_bytes": (SZ, [I, I, I, I, I, I, I]),
     "ptpp_conformer_block_fwd": (I, [POINTER(ConformerFwdArgs), P]),
     "ptpp_conformer_block_bwd": (I, [POINTER(ConformerBwdArgs), P]),
+    "ptpp_refenc_convs_slab_bytes": (SZ, [I, I, I, I, P, I]),
+    "ptpp_refenc_convs_bwd_scratch_bytes": (SZ, [I, I, I, I, P, I]),
+    "ptpp_refenc_convs_fwd": (I, [POINTER(RefEncConvsFwdArgs), P]),
+    "ptpp_refenc_convs_bwd": (I, [POINTER(RefEncConvsBwdArgs), P]),
     "ptpp_encoder_layers_fwd": (I, [POINTER(EncoderLayersFwdArgs), P]),
     "ptpp_comm_unique_id": (I, [P]),
     "ptpp_comm_init": (I, [I, I, P, POINTER(c_void_p)]),

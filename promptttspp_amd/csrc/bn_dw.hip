@@ -327,6 +327,24 @@ __global__ void im2col3x3s2_kernel(const T* __restrict__ x, T* __restrict__ col,
   }
 }
 
+// the first layer of the reference encoder: x has ONE channel; col gets the 8-channel granule of the GEMM operand per tap,
+// [x, 0 x 7] -- what im2col3x3s2 makes of x zero-padded to 8 channels, without materialising the padded input
+template <typename T>
+__global__ void im2col3x3s2_c1_kernel(const T* __restrict__ x, T* __restrict__ col, int H, int W, int Ho, int Wo, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t q = i;
+    const int k = (int)(q % 9); q /= 9;
+    const int wo = (int)(q % Wo); q /= Wo;
+    const int ho = (int)(q % Ho);
+    const int b = (int)(q / Ho);
+    const int hi = 2 * ho + k / 3 - 1, wi = 2 * wo + k % 3 - 1;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (hi >= 0 && hi < H && wi >= 0 && wi < W) v[0] = Elem<T>::ld(x + ((int64_t)b * H + hi) * W + wi);
+    Elem<T>::st4(col + i * 8, v);
+    Elem<T>::st4(col + i * 8 + 4, f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+}
+
 // col2im (gather form): dx[b,hi,wi,c] = sum over (ho,kh),(wo,kw) with 2ho+kh-1 == hi, 2wo+kw-1 == wi of dcol[...]
 template <typename T>
 __global__ void col2im3x3s2_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int H, int W, int C, int Ho, int Wo,
@@ -513,6 +531,17 @@ extern "C" int ptpp_im2col3x3s2(const void* x, void* col, int B, int H, int W, i
   DISPATCH_T(dtype, "im2col3x3s2",
              hipLaunchKernelGGL(im2col3x3s2_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)x, (T*)col, H, W, C, Ho, Wo, nvec));
   PTPP_CHECK_LAUNCH("im2col3x3s2");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_im2col3x3s2_c1(const void* x, void* col, int B, int H, int W, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && col && B > 0 && H > 0 && W > 0, "im2col3x3s2_c1: bad args");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t n = (int64_t)B * Ho * Wo * 9;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "im2col3x3s2_c1",
+             hipLaunchKernelGGL(im2col3x3s2_c1_kernel<T>, dim3(grid_for(n)), dim3(256), 0, st, (const T*)x, (T*)col, H, W, Ho, Wo, n));
+  PTPP_CHECK_LAUNCH("im2col3x3s2_c1");
   return PTPP_OK;
 }
 

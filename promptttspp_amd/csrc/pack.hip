@@ -139,7 +139,45 @@ __global__ void transpose_kernel(const TI* __restrict__ x, TO* __restrict__ y, i
   }
 }
 
+// nn.Conv2d weight (Cout, Cin, 3, 3) -> the two operands of the im2col GEMM, K index = (kh 3 + kw) cinq + ci (channels
+// zero-padded to cinq):  wf[co][k] (k < K, else 0; Kp columns) forward, wb[k][co] (co < Cout, else 0; coutp columns) data
+// gradient -- byte for byte ptpp_pack_conv_weight modes 0 / 1 of the (Cout, K) matrix the per-launch path builds with torch ops.
+template <typename T>
+__global__ void pack_conv2d3x3_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int cout, int cin, int cinq,
+                                      int Kp, int coutp) {
+  const int K = 9 * cinq;
+  const int64_t nf = (int64_t)cout * Kp, nb = wb ? (int64_t)K * coutp : 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x) {
+    int co, k;
+    if (i < nf) { co = (int)(i / Kp); k = (int)(i % Kp); }
+    else { k = (int)((i - nf) / coutp); co = (int)((i - nf) % coutp); }
+    float v = 0.f;
+    if (co < cout && k < K) {
+      const int tap = k / cinq, ci = k % cinq;
+      if (ci < cin) v = w[((int64_t)co * cin + ci) * 9 + tap];
+    }
+    if (i < nf) Elem<T>::st(wf + i, v);
+    else Elem<T>::st(wb + (i - nf), v);
+  }
+}
+
 }  // namespace
+
+extern "C" int ptpp_pack_conv2d_3x3(const float* w, void* wp_fwd, void* wp_bwd, int cout, int cin, int cinq, int dtype, void* stream) {
+  PTPP_CHECK_ARG(w && wp_fwd && cout > 0 && cin > 0 && cinq >= cin, "pack_conv2d_3x3: bad args");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "pack_conv2d_3x3: bad dtype");
+  const int Kp = ptpp_conv_cin_padded(9 * cinq, dtype), coutp = ptpp_conv_cin_padded(cout, dtype);
+  const int64_t n = (int64_t)cout * Kp + (wp_bwd ? (int64_t)9 * cinq * coutp : 0);
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PTPP_F32)
+    hipLaunchKernelGGL(pack_conv2d3x3_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)wp_fwd, (float*)wp_bwd, cout, cin, cinq, Kp, coutp);
+  else
+    hipLaunchKernelGGL(pack_conv2d3x3_kernel<bf16_raw>, dim3(grid), dim3(256), 0, st, w, (bf16_raw*)wp_fwd, (bf16_raw*)wp_bwd, cout, cin, cinq,
+                       Kp, coutp);
+  PTPP_CHECK_LAUNCH("pack_conv2d_3x3");
+  return PTPP_OK;
+}
 
 extern "C" int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin, int ks, int mode, int dtype,
                                      void* stream) {

@@ -552,3 +552,122 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
                       a->red_bytes, stream));
   return ptpp_add3_scale(gA, t2, nullptr, a->gx, 1.0f, RC, dt, stream);
 }
+
+
+// ---- reference-encoder convolution stack ----------------------------------------------------------------------------
+namespace {
+
+constexpr int RE_MAX_LAYERS = 16;
+struct ReLayout {  // byte offsets; per layer: geometry, im2col rows, pre-BN output, statistics
+  int H[RE_MAX_LAYERS + 1], W[RE_MAX_LAYERS + 1], cin[RE_MAX_LAYERS], cinq[RE_MAX_LAYERS];
+  int64_t rows[RE_MAX_LAYERS];
+  size_t col[RE_MAX_LAYERS], z[RE_MAX_LAYERS], stat[RE_MAX_LAYERS], ypp[2], total;
+  // backward scratch
+  size_t dz[RE_MAX_LAYERS], g[2], dcol, btotal;
+};
+ReLayout re_layout(int B, int H, int W, int n, const int32_t* cout, int dt) {
+  ReLayout o;
+  memset(&o, 0, sizeof(o));
+  const size_t es = esize(dt);
+  size_t off = 0, boff = 0;
+  auto take = [&](size_t& cur, size_t bytes) { const size_t at_ = cur; cur += (bytes + 255) & ~(size_t)255; return at_; };
+  o.H[0] = H; o.W[0] = W;
+  size_t ymax = 0, dcolmax = 0;
+  for (int i = 0; i < n; ++i) {
+    o.cin[i] = i == 0 ? 1 : cout[i - 1];
+    o.cinq[i] = i == 0 ? 8 : cout[i - 1];
+    o.H[i + 1] = (o.H[i] - 1) / 2 + 1; o.W[i + 1] = (o.W[i] - 1) / 2 + 1;
+    o.rows[i] = (int64_t)B * o.H[i + 1] * o.W[i + 1];
+    o.col[i] = take(off, (size_t)o.rows[i] * 9 * o.cinq[i] * es);
+    o.z[i] = take(off, (size_t)o.rows[i] * cout[i] * es);
+    o.stat[i] = take(off, 2 * (size_t)cout[i] * 4);
+    const size_t yb = (size_t)o.rows[i] * cout[i] * es;
+    if (yb > ymax) ymax = yb;
+    o.dz[i] = take(boff, yb);
+    if (i > 0 && (size_t)o.rows[i] * 9 * o.cinq[i] * es > dcolmax) dcolmax = (size_t)o.rows[i] * 9 * o.cinq[i] * es;
+  }
+  o.ypp[0] = take(off, ymax); o.ypp[1] = take(off, ymax);
+  o.total = off;
+  o.g[0] = take(boff, ymax); o.g[1] = take(boff, ymax);
+  o.dcol = take(boff, dcolmax);
+  o.btotal = boff;
+  return o;
+}
+bool re_shape_ok(int B, int H, int W, int n, const int32_t* cout) {
+  if (!(B > 0 && H > 0 && W > 0 && n > 0 && n <= RE_MAX_LAYERS && cout)) return false;
+  for (int i = 0; i < n; ++i)
+    if (cout[i] <= 0 || cout[i] % 8) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" size_t ptpp_refenc_convs_slab_bytes(int B, int H, int W, int nlayer, const int32_t* cout, int dtype) {
+  return re_shape_ok(B, H, W, nlayer, cout) ? re_layout(B, H, W, nlayer, cout, dtype).total : 0;
+}
+extern "C" size_t ptpp_refenc_convs_bwd_scratch_bytes(int B, int H, int W, int nlayer, const int32_t* cout, int dtype) {
+  return re_shape_ok(B, H, W, nlayer, cout) ? re_layout(B, H, W, nlayer, cout, dtype).btotal : 0;
+}
+
+extern "C" int ptpp_refenc_convs_fwd(const ptpp_refenc_convs_fwd_args* a, void* stream) {
+  ST_CHECK_ARG(a && a->x && a->y && a->cout && a->w && a->wp_fwd && a->wp_bwd && a->bn_g && a->bn_b && a->bn_rmean && a->bn_rvar &&
+                   a->slab && a->red_scratch,
+               "refenc_convs_fwd: null pointer");
+  ST_CHECK_ARG(re_shape_ok(a->B, a->H, a->W, a->nlayer, a->cout), "refenc_convs_fwd: bad shape (channels must be multiples of 8)");
+  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "refenc_convs_fwd: bad dtype %d", a->dtype);
+  const int n = a->nlayer, dt = a->dtype;
+  const ReLayout lo = re_layout(a->B, a->H, a->W, n, a->cout, dt);
+  ST_CHECK_ARG(a->slab_bytes >= lo.total, "refenc_convs_fwd: slab too small (%zu bytes, need %zu)", a->slab_bytes, lo.total);
+  void* S = a->slab;
+  const void* xin = a->x;
+  for (int i = 0; i < n; ++i) {
+    const int co = a->cout[i], K = 9 * lo.cinq[i];
+    ST_TRY(ptpp_pack_conv2d_3x3(a->w[i], a->wp_fwd[i], i > 0 ? a->wp_bwd[i] : nullptr, co, lo.cin[i], lo.cinq[i], dt, stream));
+    if (i == 0) ST_TRY(ptpp_im2col3x3s2_c1(xin, sl(S, lo.col[0]), a->B, lo.H[0], lo.W[0], dt, stream));
+    else ST_TRY(ptpp_im2col3x3s2(xin, sl(S, lo.col[i]), a->B, lo.H[i], lo.W[i], lo.cinq[i], dt, stream));
+    ST_CHECK_ARG(lo.rows[i] <= INT32_MAX, "refenc_convs_fwd: too many rows");
+    ptpp_conv1d_args c = conv_args(sl(S, lo.col[i]), K, a->wp_fwd[i], nullptr, nullptr, 0, sl(S, lo.z[i]), co, nullptr, 1, (int)lo.rows[i], K,
+                                   co, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
+    ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
+    float* st = static_cast<float*>(sl(S, lo.stat[i]));
+    ST_TRY(ptpp_bn_stats(sl(S, lo.z[i]), lo.rows[i], co, a->bn_momentum, a->bn_eps, a->bn_rmean[i], a->bn_rvar[i], st, st + co, dt,
+                         a->red_scratch, a->red_bytes, stream));
+    void* yout = i == n - 1 ? a->y : sl(S, lo.ypp[i & 1]);
+    ST_TRY(ptpp_bn_act_fwd(sl(S, lo.z[i]), st, st + co, a->bn_g[i], a->bn_b[i], yout, lo.rows[i], co, PTPP_ACT_RELU, dt, stream));
+    xin = yout;
+  }
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_refenc_convs_bwd(const ptpp_refenc_convs_bwd_args* a, void* stream) {
+  ST_CHECK_ARG(a && a->gy && a->cout && a->wp_bwd && a->bn_g && a->bn_b && a->dwg && a->bn_sums && a->slab && a->scratch && a->red_scratch,
+               "refenc_convs_bwd: null pointer");
+  ST_CHECK_ARG(re_shape_ok(a->B, a->H, a->W, a->nlayer, a->cout), "refenc_convs_bwd: bad shape");
+  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "refenc_convs_bwd: bad dtype %d", a->dtype);
+  const int n = a->nlayer, dt = a->dtype;
+  const ReLayout lo = re_layout(a->B, a->H, a->W, n, a->cout, dt);
+  ST_CHECK_ARG(a->scratch_bytes >= lo.btotal, "refenc_convs_bwd: scratch too small (%zu bytes, need %zu)", a->scratch_bytes, lo.btotal);
+  const void* S = a->slab;
+  void* X = a->scratch;
+  const void* g = a->gy;
+  for (int i = n - 1; i >= 0; --i) {
+    const int co = a->cout[i], K = 9 * lo.cinq[i];
+    const float* st = static_cast<const float*>(sl(S, lo.stat[i]));
+    void* dz = sl(X, lo.dz[i]);
+    ST_TRY(ptpp_bn_act_bwd(sl(S, lo.z[i]), g, st, st + co, a->bn_g[i], a->bn_b[i], a->bn_sums[i], dz, lo.rows[i], co, PTPP_ACT_RELU, 1, dt,
+                           a->red_scratch, a->red_bytes, stream));
+    if (i > 0) {
+      ptpp_conv1d_args c = conv_args(dz, co, a->wp_bwd[i], nullptr, nullptr, 0, sl(X, lo.dcol), K, nullptr, 1, (int)lo.rows[i], co, K, 1, 1,
+                                     0, PTPP_ACT_NONE, 0, 0, dt);
+      ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
+    }
+    ST_TRY(ptpp_conv1d_wgrad(sl(S, lo.col[i]), dz, a->dwg[i], nullptr, nullptr, 1, (int)lo.rows[i], K, co, 1, 1, 0, K, co, 0, dt, a->ws,
+                             a->ws_bytes, stream));
+    if (i > 0) {
+      void* gx = sl(X, lo.g[i & 1]);
+      ST_TRY(ptpp_col2im3x3s2(sl(X, lo.dcol), gx, a->B, lo.H[i], lo.W[i], lo.cinq[i], dt, stream));
+      g = gx;
+    }
+  }
+  return PTPP_OK;
+}

@@ -824,7 +824,7 @@ STACK_DRIVERS = not os.environ.get("PTPP_NO_STACK_DRIVERS")  # (tests compare th
 
 def _ptr_table(tensors):
     """HOST array of device pointers (an argument of the whole-unit drivers, include/ptpp.h)."""
-    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
 
 
 def _f32_param(t):

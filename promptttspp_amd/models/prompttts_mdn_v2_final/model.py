@@ -233,6 +233,12 @@ class PromptTTSMDNDurCFG(nn.Module):
     # (which are the reference's, tests/test_hip_acoustic.py).  Phone-level work: a few thousand rows, ~1 % of a synthesis
     # call; the frame-level path and the sampler keep the compute dtype.
     integer_island = True
+    # ... and the rest of the conditioning path with it (pitch predictor, frame prior network: ONE pass over the frames,
+    # 2-3 % of a synthesis call whose time is the sampler's 100 denoiser evaluations): the bf16 mode's mel error came from
+    # here -- five / six bf16 ReLU -> LayerNorm layers moved log-F0 by 4 % and the decoder's conditioning with it (mel MSE
+    # 4.9e-3 against the f32 reference), while 100 bf16 denoiser evaluations on an exact conditioning cost 6e-5
+    # (tools/experiments/bf16_sampler_emulation.py).  The decoder and the vocoder keep the compute dtype.
+    f32_conditioning = True
 
     @torch.no_grad()
     def _synthesize(self, phoneme, phone_lengths, style_emb, zero_padded_durations, noise_fn=None):
@@ -240,16 +246,23 @@ class PromptTTSMDNDurCFG(nn.Module):
 
         dt = compute_dtype()
         dur = None
+        pm = lambda pmask: pmask if zero_padded_durations else None  # noqa: E731
         if self.integer_island and dt != torch.float32:
             with use_dtype(torch.float32):
                 x, plen, pmask = self._encode(phoneme, phone_lengths)
                 x = x + style_emb.transpose(1, 2).to(x.dtype)
-                dur = self.variance_adaptor.durations_cl(x, plen, pmask if zero_padded_durations else None)
-            x = x.to(dt)
+                if self.f32_conditioning:
+                    h, flen, fm1, cf0, vuv, dur = self.variance_adaptor.infer_cl(x, plen, pm(pmask))
+                else:
+                    dur = self.variance_adaptor.durations_cl(x, plen, pm(pmask))
+            if self.f32_conditioning:
+                h = h.to(dt)
+            else:
+                h, flen, fm1, cf0, vuv, dur = self.variance_adaptor.infer_cl(x.to(dt), plen, pm(pmask), dur=dur)
         else:
             x, plen, pmask = self._encode(phoneme, phone_lengths)
             x = x + style_emb.transpose(1, 2).to(x.dtype)
-        h, flen, fm1, cf0, vuv, dur = self.variance_adaptor.infer_cl(x, plen, pmask if zero_padded_durations else None, dur=dur)
+            h, flen, fm1, cf0, vuv, dur = self.variance_adaptor.infer_cl(x, plen, pm(pmask))
         if self.conformer_decoder:
             mel = self._decode_conformer(h, flen, fm1).float()
         else:

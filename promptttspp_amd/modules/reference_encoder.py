@@ -17,6 +17,7 @@ copy + pack_padded_sequence host sync (reference_encoder.py:118-121).
 import torch
 import torch.nn as nn
 
+from .. import functional as PF
 from .. import nn_ops as NO
 from ..config import compute_dtype
 
@@ -30,6 +31,7 @@ class ReferenceEncoder(nn.Module):
         if conv_kernel_size != 3 or conv_stride != 2 or gru_layers != 1:
             raise NotImplementedError("promptttspp_amd implements the reference config: 3x3 stride-2 convs, 1 GRU layer")
         self.conv_stride, self.conv_layers = conv_stride, conv_layers
+        self.chans = tuple(conv_chans_list)
         padding = (conv_kernel_size - 1) // 2
         convs = []
         for i in range(conv_layers):
@@ -45,10 +47,14 @@ class ReferenceEncoder(nn.Module):
     def forward(self, speech, in_lens=None):
         """speech (B, idim, T) float -> (B, gru_units, 1) float32."""
         B, _, T = speech.shape
-        x = speech.transpose(1, 2).unsqueeze(-1).to(compute_dtype()).contiguous()  # (B, T, F, 1)
-        for i in range(self.conv_layers):
-            x = NO.conv2d_3x3s2(x, self.convs[3 * i].weight)
-            x = NO.batch_norm_act(x, self.convs[3 * i + 1], act="relu")
+        if self.training and PF.STACK_DRIVERS and speech.is_cuda and all(c % 8 == 0 for c in self.chans):
+            x = NO.refenc_convs(speech.transpose(1, 2).to(compute_dtype()), [self.convs[3 * i] for i in range(self.conv_layers)],
+                                [self.convs[3 * i + 1] for i in range(self.conv_layers)])
+        else:
+            x = speech.transpose(1, 2).unsqueeze(-1).to(compute_dtype()).contiguous()  # (B, T, F, 1)
+            for i in range(self.conv_layers):
+                x = NO.conv2d_3x3s2(x, self.convs[3 * i].weight)
+                x = NO.batch_norm_act(x, self.convs[3 * i + 1], act="relu")
         # reference flattens (B, C, T', F') -> (B, T', C*F'): channel-major features
         hs = x.permute(0, 1, 3, 2).reshape(B, x.shape[1], -1)
         if in_lens is None:

@@ -189,6 +189,103 @@ def conv2d_3x3s2(x, weight):
     return y.view(B, Ho, Wo, cout)
 
 
+class RefEncConvsFn(Function):
+    """The reference encoder's convolution stack in training mode as two C calls (ptpp_refenc_convs_fwd / _bwd): per layer
+    [weight pack, im2col, GEMM, batch statistics, BatchNorm + ReLU] forward and [BatchNorm + ReLU backward, data-gradient GEMM,
+    weight gradient, col2im] backward -- the launches of conv2d_3x3s2 + batch_norm_act per layer, without the ~25 Python-level
+    calls per layer around them.  args: x (B, T, F) in the compute dtype, ``bns`` (the BatchNorm2d modules: running estimates
+    are updated in place), then the n Conv2d weights, n BatchNorm weights, n BatchNorm biases."""
+
+    @staticmethod
+    def forward(ctx, x, bns, *params):
+        n = len(bns)
+        ws, gs, bs = params[:n], params[n:2 * n], params[2 * n:]
+        lib = _lib.load()
+        x = x.contiguous()
+        B, H, W = x.shape
+        dev, dt = x.device, x.dtype
+        couts = [int(w.shape[0]) for w in ws]
+        cinq = [8] + couts[:-1]
+        cout_arr = (ctypes.c_int32 * n)(*couts)
+        code = dtype_code(dt)
+        slab_bytes = lib.ptpp_refenc_convs_slab_bytes(B, H, W, n, cout_arr, code)
+        assert slab_bytes > 0, "reference encoder: channel counts must be multiples of 8"
+        slab = torch.empty(slab_bytes, device=dev, dtype=torch.uint8)
+        Hn, Wn = H, W
+        for _ in range(n):
+            Hn, Wn = (Hn - 1) // 2 + 1, (Wn - 1) // 2 + 1
+        y = torch.empty((B, Hn, Wn, couts[-1]), device=dev, dtype=dt)
+        wpf = [torch.empty((couts[i], ops.cin_padded(9 * cinq[i], dt)), device=dev, dtype=dt) for i in range(n)]
+        wpb = [torch.empty((9 * cinq[i], ops.cin_padded(couts[i], dt)), device=dev, dtype=dt) if i else None for i in range(n)]
+        wf = [PF._f32c(w) for w in ws]
+        gf, bf = [PF._f32c(g) for g in gs], [PF._f32c(b) for b in bs]
+        track = all(bn.running_mean is not None and bn.running_var is not None for bn in bns)
+        a = _lib.RefEncConvsFwdArgs()
+        tabs = [PF._ptr_table(t) for t in (wf, wpf, wpb, gf, bf, [bn.running_mean if track else None for bn in bns],
+                                           [bn.running_var if track else None for bn in bns])]
+        a.x, a.y, a.cout = x.data_ptr(), y.data_ptr(), ctypes.addressof(cout_arr)
+        a.w, a.wp_fwd, a.wp_bwd, a.bn_g, a.bn_b, a.bn_rmean, a.bn_rvar = [ctypes.addressof(t) for t in tabs]
+        a.slab, a.slab_bytes = slab.data_ptr(), slab_bytes
+        wsb = ops.workspace(dev)
+        a.ws, a.ws_bytes = wsb.data_ptr(), ops._WS_BYTES
+        red, red_bytes = ops.reduction_scratch(dev)
+        a.red_scratch, a.red_bytes = red, red_bytes
+        mom = bns[0].momentum
+        a.bn_momentum, a.bn_eps = float(mom if mom is not None else 0.1), float(bns[0].eps)
+        a.B, a.H, a.W, a.nlayer, a.dtype = B, H, W, n, code
+        _chk(lib.ptpp_refenc_convs_fwd(ctypes.byref(a), _stream()), "ptpp_refenc_convs_fwd")
+        ctx.geom = (B, H, W, n, couts, cinq, code)
+        ctx.keep = (slab, wpb, gf, bf, x)
+        ctx.shapes = [w.shape for w in ws]
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        B, H, W, n, couts, cinq, code = ctx.geom
+        slab, wpb, gf, bf, x = ctx.keep
+        lib = _lib.load()
+        dev = gy.device
+        gy = gy.contiguous()
+        cout_arr = (ctypes.c_int32 * n)(*couts)
+        sc_bytes = lib.ptpp_refenc_convs_bwd_scratch_bytes(B, H, W, n, cout_arr, code)
+        scratch = torch.empty(sc_bytes, device=dev, dtype=torch.uint8)
+        sizes = [couts[i] * 9 * cinq[i] for i in range(n)]
+        flat = torch.zeros(sum(sizes) + 2 * sum(couts), device=dev, dtype=torch.float32)
+        dwg, sums, off = [], [], 0
+        for i in range(n):
+            dwg.append(flat[off:off + sizes[i]])
+            off += sizes[i]
+        for i in range(n):
+            sums.append(flat[off:off + 2 * couts[i]])
+            off += 2 * couts[i]
+        a = _lib.RefEncConvsBwdArgs()
+        tabs = [PF._ptr_table(t) for t in (wpb, gf, bf, dwg, sums)]
+        a.gy, a.cout = gy.data_ptr(), ctypes.addressof(cout_arr)
+        a.wp_bwd, a.bn_g, a.bn_b, a.dwg, a.bn_sums = [ctypes.addressof(t) for t in tabs]
+        a.slab, a.scratch, a.scratch_bytes = slab.data_ptr(), scratch.data_ptr(), sc_bytes
+        wsb = ops.workspace(dev)
+        a.ws, a.ws_bytes = wsb.data_ptr(), ops._WS_BYTES
+        red, red_bytes = ops.reduction_scratch(dev)
+        a.red_scratch, a.red_bytes = red, red_bytes
+        a.B, a.H, a.W, a.nlayer, a.dtype = B, H, W, n, code
+        _chk(lib.ptpp_refenc_convs_bwd(ctypes.byref(a), _stream()), "ptpp_refenc_convs_bwd")
+        ctx.keep = None
+        # (cout, 9 cinq) in the GEMM's K order (tap, channel) -> nn.Conv2d layout (cout, cin, 3, 3)
+        gw = [dwg[i].view(couts[i], 3, 3, cinq[i])[..., :ctx.shapes[i][1]].permute(0, 3, 1, 2) for i in range(n)]
+        gg = [sums[i][couts[i]:] for i in range(n)]
+        gb = [sums[i][:couts[i]] for i in range(n)]
+        return (None, None, *gw, *gg, *gb)
+
+
+def refenc_convs(x, convs, bns):
+    """x (B, T, F) -> (B, T', F', C): the training-mode convolution stack of the reference encoder (RefEncConvsFn)."""
+    tracked = [bn.num_batches_tracked for bn in bns if bn.num_batches_tracked is not None]
+    if tracked:
+        torch._foreach_add_(tracked, 1)
+    return RefEncConvsFn.apply(x, bns, *[c.weight for c in convs], *[bn.weight for bn in bns], *[bn.bias for bn in bns])
+
+
 GRU_SEQ = True  # the whole recurrence as one launch (ptpp_gru_seq_*) where the library supports the width
 
 

@@ -106,7 +106,8 @@ def test_ctypes_structures_match_the_header(tmp_path):
              ("ptpp_diffnet_stack_bwd_args", _lib.DiffNetBwdArgs), ("ptpp_encoder_layers_fwd_args", _lib.EncoderLayersFwdArgs),
              ("ptpp_conv_ln_stack_fwd_args", _lib.ConvLnFwdArgs), ("ptpp_conv_ln_stack_bwd_args", _lib.ConvLnBwdArgs),
              ("ptpp_conformer_weights", _lib.ConformerWeights), ("ptpp_conformer_grads", _lib.ConformerGrads),
-             ("ptpp_conformer_block_fwd_args", _lib.ConformerFwdArgs), ("ptpp_conformer_block_bwd_args", _lib.ConformerBwdArgs)]
+             ("ptpp_conformer_block_fwd_args", _lib.ConformerFwdArgs), ("ptpp_conformer_block_bwd_args", _lib.ConformerBwdArgs),
+             ("ptpp_refenc_convs_fwd_args", _lib.RefEncConvsFwdArgs), ("ptpp_refenc_convs_bwd_args", _lib.RefEncConvsBwdArgs)]
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "%s"\nint main(void){%s return 0;}\n' % (
         os.path.join(ROOT, "include", "ptpp.h"), "".join('printf("%%zu\\n", sizeof(%s));' % n for n, _ in pairs)))

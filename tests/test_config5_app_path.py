@@ -145,8 +145,21 @@ def test_bf16_infer_batch_against_reference_golden(dev):
             assert torch.equal(flen.cpu().float(), gi["new_flen_ref"].float())
             mse = float(((mel.cpu() - gi["new_mel_ref"]) ** 2).mean())
             print("bf16 mel MSE vs reference", mse, "cf0 rel err", rel_err(cf0.cpu(), gi["new_cf0_ref"]))
-            assert mse < 1e-2, mse
-            assert mse / float((gi["new_mel_ref"] ** 2).mean()) < 2e-2
-            assert rel_err(cf0.cpu(), gi["new_cf0_ref"]) < 8e-2  # measured 4.1e-2 (five bf16 ReLU->LayerNorm layers)
+            # north_star's bar for the mel (MSE < 1e-3 against the reference) holds in the bf16 mode too: the conditioning path
+            # runs in f32 (model.py `f32_conditioning`), the 100 denoiser evaluations in bf16
+            assert mse < 1e-3, mse
+            assert rel_err(cf0.cpu(), gi["new_cf0_ref"]) < 1e-4
+            assert torch.equal(vuv.cpu() > 0.5, gi["new_vuv_ref"] > 0.5) if "new_vuv_ref" in gi else True
+            # the conditioning path in bf16 as well (round 2's mode), for the record: mel MSE 4.9e-3, log-F0 4.1e-2
+            m.f32_conditioning = False
+            dp.infer_cl = lambda x, plen: torch.log(dur_ref.clamp_min(1).float()).to(dev)
+            try:
+                mel2, cf02, _, _ = m.infer_batch(gi["phon"].to(dev), gi["plen"].to(dev), noise_fn=noise_fn, **kw)
+            finally:
+                dp.infer_cl = orig
+                m.f32_conditioning = True
+            mse2 = float(((mel2.cpu() - gi["new_mel_ref"]) ** 2).mean())
+            print("  conditioning path in bf16: mel MSE", mse2, "cf0 rel err", rel_err(cf02.cpu(), gi["new_cf0_ref"]))
+            assert mse2 < 1e-2 and rel_err(cf02.cpu(), gi["new_cf0_ref"]) < 8e-2
     finally:
         config.set_compute_dtype(torch.float32)

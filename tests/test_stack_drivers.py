@@ -477,3 +477,55 @@ def test_gru_whole_sequence_kernels_match_torch_gru(B, L, I):
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, (i, float((a - b).abs().max()), scale)
         assert float((a - c).abs().max()) <= 2e-5 * scale + 1e-7, (i, float((a - c).abs().max()), scale)
+
+
+@pytest.mark.parametrize("dtype,B,T", [(torch.float32, 3, 203), (torch.bfloat16, 5, 640), (torch.bfloat16, 19, 1500)])
+def test_reference_encoder_conv_stack_driver_matches_the_per_launch_path(dtype, B, T):
+    """modules.reference_encoder in training mode: the two C calls of nn_ops.RefEncConvsFn (+ the one-launch GRU) against the
+    per-launch path (im2col + GEMM + BatchNorm kernels issued from Python): same kernels on the same operands, so the
+    embedding, the running estimates and every gradient agree -- up to the sums the kernels accumulate with f32 atomics
+    (BatchNorm statistics / gamma / beta, f32 weight gradients): 2e-5 of the largest element in f32; in bf16 a statistic that
+    moves by an ulp moves bf16 roundings and ReLU gates downstream, so there the bound is 3 % relative L2 per tensor
+    (tools/diag_refenc.py on MI355X, 19 x 1500 frames: repeated runs of EITHER path fall into two classes that differ by 2.7e-3
+    in the embedding and 5e-5 in the running estimates; within a class the two paths agree bit for bit)."""
+    from promptttspp_amd import config
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd.modules.reference_encoder import ReferenceEncoder
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    ref = ReferenceEncoder().to(dev)
+    mel = (rnd(5, B, 80, T) * 1.5).to(dev)
+    lens = torch.tensor([max(40, T - 37 * i) for i in range(B)], device=dev)
+    gout = rnd(6, B, 128, 1).to(dev)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    outs = {}
+    with config.use_dtype(dtype):
+        for drv in (True, False):
+            ref.load_state_dict(state)
+            ref.train()
+            for p in ref.parameters():
+                p.grad = None
+            PF.STACK_DRIVERS = drv
+            try:
+                y = ref(mel, lens)
+                (y * gout).sum().backward()
+                torch.cuda.synchronize()
+            finally:
+                PF.STACK_DRIVERS = True
+            outs[drv] = ([y.detach()] + [p.grad.clone() for p in ref.parameters()], {k: v.clone() for k, v in ref.state_dict().items()})
+    names = ["y"] + [n for n, _ in ref.named_parameters()]
+    errs = []
+    for n, a, b in zip(names, outs[True][0], outs[False][0]):
+        assert a.shape == b.shape and torch.isfinite(a).all(), n
+        if dtype == torch.float32:
+            errs.append((n, float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)))
+        else:
+            errs.append((n, float((a - b).norm() / (b.norm() + 1e-12))))
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert all(e <= tol for _, e in errs), [x for x in errs if x[1] > tol]
+    for k in state:
+        a, b = outs[True][1][k].float(), outs[False][1][k].float()
+        assert float((a - b).abs().max()) <= (1e-5 if dtype == torch.float32 else 5e-4) * (float(b.abs().max()) + 1e-12), k
+        if "num_batches" in k:
+            assert int(outs[True][1][k]) == int(state[k]) + 1
