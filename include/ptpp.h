@@ -395,17 +395,20 @@ int ptpp_gru_gate_bwd(const float* gi, int64_t ldgi, const float* gh,
                       const float* dhout, float* dgi, int64_t lddgi,
                       float* dgh, float* dh, int B, int H, void* stream);
 
-/* The whole recurrence in ONE launch (H = 128, the reference's gru_units: ptpp_gru_seq_supported(H) != 0): a block owns
- * one sequence for all L steps with its slice of W_hh in registers.
+/* The whole recurrence in ONE launch (H = 128 or 256: ptpp_gru_seq_supported(H) != 0; the reference's gru_units is 256 in
+ * conf/model/prompttts_mdn_v2_wo_erg_final.yaml): a block owns one sequence for all L steps with (the first 128 entries per
+ * thread of) its slice of W_hh in registers.
  *   gi_all (B, L, 3H) = W_ih x + b_ih;  w_hh (3H, H) and b_hh (3H) f32 as stored in the state dict (gru.weight_hh_l0);
+ *   w_hh_t: the transposed copy, (H, ptpp_conv_cin_padded(3H, PTPP_F32)) f32 = ptpp_pack_conv_weight mode 1 of w_hh (read
+ *   only for H = 256, may be NULL for H = 128);
  *   saved for the backward: hs_all (L + 1, B, H) with hs_all[0] = 0, gh_all (L, B, 3H) = W_hh h_s + b_hh (rows of steps
  *   >= lens[b] are not written and not read);  hout (B, H) = the last valid hidden state.
  * Backward: dgi_all (B, L, 3H) and dgh_all (L, B, 3H) (zero at steps >= lens[b]); the caller finishes with ONE weight
  * gradient over all steps, dW_hh = dgh_all^T hs_all[:L], db_hh = column sums of dgh_all (ptpp_conv1d_wgrad, rows = L B). */
 int ptpp_gru_seq_supported(int H);
-int ptpp_gru_seq_fwd(const float* gi_all, const float* w_hh, const float* b_hh,
-                     const int32_t* lens, float* hs_all, float* gh_all, float* hout,
-                     int B, int L, int H, void* stream);
+int ptpp_gru_seq_fwd(const float* gi_all, const float* w_hh, const float* w_hh_t,
+                     const float* b_hh, const int32_t* lens, float* hs_all, float* gh_all,
+                     float* hout, int B, int L, int H, void* stream);
 int ptpp_gru_seq_bwd(const float* gi_all, const float* w_hh, const int32_t* lens,
                      const float* hs_all, const float* gh_all, const float* dhout,
                      float* dgi_all, float* dgh_all, int B, int L, int H, void* stream);

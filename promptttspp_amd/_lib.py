@@ -226,7 +226,7 @@ SIGNATURES = {
     "ptpp_gru_gate_fwd": (I, [P, I64, P, P, P, I, P, I, I, P]),
     "ptpp_gru_gate_bwd": (I, [P, I64, P, P, P, I, P, P, I64, P, P, I, I, P]),
     "ptpp_gru_seq_supported": (I, [I]),
-    "ptpp_gru_seq_fwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    "ptpp_gru_seq_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "ptpp_gru_seq_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "ptpp_aa_snake_fwd": (I, [P, P, P, POINTER(c_float), POINTER(c_float), I, I, I, I, P]),
     "ptpp_amp_layer_supported": (I, [I, I]),

@@ -201,6 +201,9 @@ class GaussianDiffusion(nn.Module):
         if self.pndm_speedup:
             return self.inference_plms_cl(cond, int(self.pndm_speedup), noise_fn)
         B, T, _ = cond.shape
+        if self.split_streams and cond.is_cuda and B >= 4 and B * T >= self.split_min_rows and self.K_step > 3 \
+                and not torch.cuda.is_current_stream_capturing():
+            return self._inference_split(cond, noise_fn)
         shape = (B, T, self.out_dim)
         draw = noise_fn if noise_fn is not None else (lambda i, s: torch.randn(s, device=cond.device))
         x = draw(-1, shape)
@@ -239,6 +242,78 @@ class GaussianDiffusion(nn.Module):
                 ns.zero_()
             g.replay()
         return self._denorm(xs)
+
+    # Large batches: the utterances are independent, so the batch is cut in two halves that run their reverse loops on two
+    # streams, one HIP graph each.  A denoiser launch of the whole batch is 1-2 rounds of workgroups with a ragged last round
+    # and a serial prologue / epilogue per workgroup; two half-size launches side by side fill each other's gaps
+    # (profiles/r03_sampler_split.txt).  Same arithmetic per utterance: the result is bit-identical to the unsplit loop.
+    split_streams = __import__("os").environ.get("PTPP_SAMPLER_SPLIT", "1") not in ("0", "off", "no")
+    split_min_rows = 8192
+    split_ways = int(__import__("os").environ.get("PTPP_SAMPLER_WAYS", "2"))
+
+    def _inference_split(self, cond, noise_fn):
+        B, T, _ = cond.shape
+        dev = cond.device
+        shape = (B, T, self.out_dim)
+        K = self.K_step
+        draw = noise_fn if noise_fn is not None else (lambda i, s: torch.randn(s, device=dev))
+        ways = max(2, min(int(self.split_ways), B))
+        edges = [B * k // ways for k in range(ways + 1)]
+        cuts = list(zip(edges[:-1], edges[1:]))
+        main = torch.cuda.current_stream(dev)
+        extra = getattr(self, "_split_streams", None)
+        if extra is None or len(extra) < ways - 1 or extra[0].device != dev:
+            extra = self._split_streams = [torch.cuda.Stream(device=dev) for _ in range(ways - 1)]
+        streams = [main] + extra[: ways - 1]
+        x0 = draw(-1, shape)
+        n0 = draw(K - 1, shape)
+        st = []
+        with ops.unpinned():
+            for (lo, hi), sm in zip(cuts, streams):
+                c = cond[lo:hi].contiguous()
+                sm.wait_stream(main)
+                with torch.cuda.stream(sm):
+                    cond_all = self.denoise_fn.cond_all(c)
+                    x = self.p_sample_cl(x0[lo:hi].contiguous(), K - 1, c, cond_all, n0[lo:hi].contiguous())  # eager: packs, sizes pools
+                    xs = x.clone()
+                    ts = torch.full((hi - lo,), K - 2, device=dev, dtype=torch.long)
+                    ns = torch.zeros_like(xs)
+                st.append([c, cond_all, xs, ts, ns, None])
+            torch.cuda.synchronize()
+            graphs_ok = self.use_graph
+            if graphs_ok:
+                try:
+                    for h in st:
+                        c, cond_all, xs, ts, ns, _ = h
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            xs.copy_(self._p_sample_core(xs, ts, c, cond_all, ns))
+                            ts.sub_(1)
+                        h[5] = g
+                except Exception as e:
+                    import warnings
+
+                    warnings.warn(f"HIP graph capture of the sampler step failed ({type(e).__name__}: {e}); running eagerly")
+                    graphs_ok = False
+            for i in reversed(range(K - 1)):
+                nz = draw(i, shape) if i > 0 else None
+                for (lo, hi), sm, h in zip(cuts, streams, st):
+                    c, cond_all, xs, ts, ns, g = h
+                    if sm is not main:
+                        sm.wait_stream(main)  # (the noise was drawn on the calling stream)
+                    with torch.cuda.stream(sm):
+                        if nz is not None:
+                            ns.copy_(nz[lo:hi])
+                        else:
+                            ns.zero_()
+                        if graphs_ok:
+                            g.replay()
+                        else:
+                            xs.copy_(self._p_sample_core(xs, ts, c, cond_all, ns))
+                            ts.sub_(1)
+            for sm in streams[1:]:
+                main.wait_stream(sm)
+        return self._denorm(torch.cat([h[2] for h in st], dim=0))
 
     def inference(self, cond, lengths=None, g=None):
         """Reference signature: cond (B,T,Cc) -> (B,T,M)."""

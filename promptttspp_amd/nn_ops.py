@@ -291,7 +291,7 @@ GRU_SEQ = True  # the whole recurrence as one launch (ptpp_gru_seq_*) where the 
 
 class GruFn(Function):
     """The GRU recurrence with a hand-written backward.  Inputs: gi_all (B, L, 3H) f32 = W_ih x + b_ih for all steps,
-    weight_hh (3H, H), bias_hh (3H), lens (B) int32.  H = 128 (the reference's gru_units): ONE launch for all steps
+    weight_hh (3H, H), bias_hh (3H), lens (B) int32.  H = 128 / 256 (the reference's gru_units): ONE launch for all steps
     forward, one for the backward recurrence and one weight-gradient GEMM over all steps (csrc/gru.hip, gru_seq_*).
     Other widths: per step one GEMM (W_hh h + b_hh, exact f32, on the conv kernel) and one gate kernel."""
 
@@ -308,8 +308,9 @@ class GruFn(Function):
             hs_all = torch.empty((L + 1, B, Hn), device=dev, dtype=torch.float32)
             gh_all = torch.empty((L, B, H3), device=dev, dtype=torch.float32)
             h = torch.empty((B, Hn), device=dev, dtype=torch.float32)
-            _chk(lib.ptpp_gru_seq_fwd(_ptr(gi_all), _ptr(w), _ptr(bh), _ptr(lens), _ptr(hs_all), _ptr(gh_all), _ptr(h), B, L, Hn,
-                                      _stream()), "ptpp_gru_seq_fwd")
+            wt = PF.packed(weight_hh, torch.float32, mode=1) if Hn > 128 else None  # (H, 1, 3H): the transposed copy
+            _chk(lib.ptpp_gru_seq_fwd(_ptr(gi_all), _ptr(w), _ptr(wt), _ptr(bh), _ptr(lens), _ptr(hs_all), _ptr(gh_all), _ptr(h),
+                                      B, L, Hn, _stream()), "ptpp_gru_seq_fwd")
             ctx.hs, ctx.ghs, ctx.lens, ctx.w, ctx.b, ctx.wf = hs_all, gh_all, lens, weight_hh, bias_hh, w
             ctx.sink = PF._sink(weight_hh) is not None and PF._sink(bias_hh) is not None
             if ctx.sink:

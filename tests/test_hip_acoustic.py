@@ -899,6 +899,30 @@ def test_sampler_fused_gate_and_graph_consistency(dev):
     assert rel_err(outs["fused+graph"], outs["fused"]) < 1e-6   # the graph replays the same kernels
 
 
+def test_sampler_split_over_two_streams_is_bit_identical(dev):
+    """Large batches: the two halves of the batch run their reverse loops on two streams (GaussianDiffusion._inference_split);
+    per utterance the arithmetic is that of the unsplit loop, so the mel is equal bit for bit (bf16 and f32, odd batch)."""
+    from promptttspp_amd import config
+
+    g = load_golden("diffusion")
+    m, _ = load(node("decoder"), key_shapes(g["keys"]), 90, dev)
+    m.eval()
+    B, T = 5, 300
+    cond = rnd(7, B, T, 256).to(dev)
+    noise_fn = lambda i, s: rnd(3000 + i, *s).to(dev)  # noqa: E731
+    for dt in (torch.bfloat16, torch.float32):
+        with config.use_dtype(dt), torch.no_grad():
+            outs = []
+            for split in (False, True):
+                m.split_streams, m.split_min_rows = split, 1
+                try:
+                    outs.append(m.inference_cl(cond.to(dt), noise_fn).float().cpu())
+                finally:
+                    m.split_streams, m.split_min_rows = True, 8192
+            assert torch.isfinite(outs[0]).all()
+            assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
 def test_model_forward_bench_size_properties(dev):
     """One BASELINE-sized training batch (max_tokens = 30 000 synthetic LibriTTS-R utterances), eval mode, f32:
     the forward is bit-reproducible, and the five losses do not change when the batch is padded with extra

@@ -439,16 +439,15 @@ def test_conformer_block_driver_is_bit_identical(dev, monkeypatch, variant, dtyp
         assert torch.equal(stats[0][k], stats[1][k]) or torch.allclose(stats[0][k].float(), stats[1][k].float(), rtol=1e-6, atol=1e-7), k
 
 
-@pytest.mark.parametrize("B,L,I", [(5, 9, 256), (19, 24, 256), (1, 1, 64)])
-def test_gru_whole_sequence_kernels_match_torch_gru(B, L, I):
-    """nn_ops.gru_last_state (one launch for the whole recurrence, H = 128) against torch.nn.GRU on packed sequences
+@pytest.mark.parametrize("B,L,I,H", [(5, 9, 256, 128), (19, 24, 1024, 256), (1, 1, 64, 128), (3, 7, 64, 256)])
+def test_gru_whole_sequence_kernels_match_torch_gru(B, L, I, H):
+    """nn_ops.gru_last_state (one launch for the whole recurrence, H = 128 / 256) against torch.nn.GRU on packed sequences
     (the reference's op, modules/reference_encoder.py:108-123) in f32 on the CPU: last valid hidden state and the gradients of
     the input, both weight matrices and both biases; and against this package's own per-step path."""
     from promptttspp_amd import nn_ops as NO
     from promptttspp_amd import config
 
     dev = torch.device("cuda:0")
-    H = 128
     gru = torch.nn.GRU(I, H, 1, batch_first=True)
     x = rnd(1, B, L, I, scale=0.7)
     lens = torch.tensor([max(1, L - (3 * i) % L) for i in range(B)], dtype=torch.long)
