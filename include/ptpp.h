@@ -207,6 +207,23 @@ int ptpp_layernorm_fwd(const void* x, const void* res, const float* gamma,
                        uint64_t drop_in_seed, float drop_out_p,
                        uint64_t drop_out_seed, int dtype, void* stream);
 
+/* The weight gradients of SEVERAL layers of DIFFERENT shapes over few rows (the linear / conv layers of one Conformer block
+ * at phone level: a few thousand rows, where one split-K launch + reduction per layer is ~30 us of fixed cost for ~2 us of
+ * arithmetic), each ACCUMULATED into its dw / dbias.  probs is a HOST array.  bf16 problems with Cin, Cout > 64 and at most
+ * 256 row chunks of 32: ONE launch per 16 problems, every dw tile owned by one block that walks all rows of its problem in a
+ * fixed order (no partials, no second pass, bit-reproducible).  Anything else: a loop of ptpp_conv1d_wgrad.
+ * lengths non-NULL = that problem's input mask (x rows at or after lengths[b] count as zero). */
+typedef struct {
+  const void* x;
+  const void* dy;
+  float* dw;       /* (Cout, Cin, ks) f32, accumulated into */
+  float* dbias;    /* (Cout) f32 or NULL                     */
+  const int32_t* lengths;
+  int32_t B, T, Cin, Cout, ks, dil, pad, ldx, lddy;
+} ptpp_wgrad_gproblem;
+int ptpp_conv1d_wgrad_grouped(const ptpp_wgrad_gproblem* probs, int nprob, int dtype,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* Reduction scratch (ptpp_layernorm_bwd, ptpp_col_reduce, ptpp_bn_act_bwd): f32 atomics from
  * many blocks on one cache line serialise on MI355X (~50 ns per block visit), so per-column sums
  * go through a caller-owned scratch: block b adds its totals into replica b % 32, and a small

@@ -158,6 +158,13 @@ class ConformerBwdArgs(Structure):
                [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "ks_ffn", "ks_dw", "variant", "bn_train", "dtype")]
 
 
+class WgradGProblem(Structure):
+    """Mirror of ``ptpp_wgrad_gproblem`` (include/ptpp.h)."""
+
+    _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("dbias", c_void_p), ("lengths", c_void_p)] + \
+               [(n, c_int32) for n in ("B", "T", "Cin", "Cout", "ks", "dil", "pad", "ldx", "lddy")]
+
+
 class RefEncConvsFwdArgs(Structure):
     """Mirror of ``ptpp_refenc_convs_fwd_args`` (include/ptpp.h)."""
 
@@ -192,6 +199,7 @@ SIGNATURES = {
     "ptpp_conv1d_fwd_ws": (I, [POINTER(ConvArgs), P, I, F, F, U64, P, SZ, P]),
     "ptpp_conv1d_wgrad": (I, [P, P, P, P, P] + [I] * 11 + [P, SZ, P]),
     "ptpp_conv1d_wgrad_batched": (I, [POINTER(WgradProblem), I, P, I, I, I, I, I, I, I, I, I, P, SZ, P]),
+    "ptpp_conv1d_wgrad_grouped": (I, [POINTER(WgradGProblem), I, I, P, SZ, P]),
     "ptpp_epilogue_bwd": (I, [P, P, P, P, I, I, I, F, I, I, F, U64, I, P]),
     "ptpp_layernorm_fwd": (I, [P] * 9 + [I, I, I, F, I, I, F, U64, F, U64, I, P]),
     "ptpp_layernorm_bwd": (I, [P] * 11 + [I, I, I, I, I, F, U64, F, U64, I, P, SZ, P]),

@@ -196,3 +196,39 @@ extern "C" int ptpp_conv1d_wgrad_batched(const ptpp_wgrad_problem* probs, int np
   }
   return PTPP_OK;
 }
+
+
+int ptpp_wgrad_bf16_launch_grouped(const ptpp_wgrad_gproblem* probs, int nprob, hipStream_t st);
+
+extern "C" int ptpp_conv1d_wgrad_grouped(const ptpp_wgrad_gproblem* probs, int nprob, int dtype, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  PTPP_CHECK_ARG(probs && nprob > 0, "conv1d_wgrad_grouped: no problems");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "conv1d_wgrad_grouped: bad dtype %d", dtype);
+  static const char* off = getenv("PTPP_WGRAD_NO_GROUP");
+  bool fast = dtype == PTPP_BF16 && !(off && off[0] == '1');
+  long long blocks = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const ptpp_wgrad_gproblem& q = probs[i];
+    PTPP_CHECK_ARG(q.x && q.dy && q.dw && q.B > 0 && q.T > 0 && q.Cin > 0 && q.Cout > 0 && q.ks > 0 && q.dil > 0,
+                   "conv1d_wgrad_grouped: bad problem %d", i);
+    // the one-owner blocks walk ALL rows of their problem: only for short problems (phone level); the tiles are 128 x 128
+    fast = fast && q.ldx % 8 == 0 && q.lddy % 8 == 0 && q.Cin % 8 == 0 && q.Cout % 8 == 0 && ((uintptr_t)q.x % 16) == 0 &&
+           ((uintptr_t)q.dy % 16) == 0 && q.Cin > 64 && q.Cout > 64 && (long long)q.B * ((q.T + 31) / 32) <= 256;
+    blocks += (long long)((q.Cout + 127) / 128) * ((q.Cin + 127) / 128) * q.ks;
+  }
+  if (fast && blocks >= 64) {
+    constexpr int GMAX = 16;
+    for (int i0 = 0; i0 < nprob; i0 += GMAX) {
+      const int rc = ptpp_wgrad_bf16_launch_grouped(probs + i0, nprob - i0 < GMAX ? nprob - i0 : GMAX, reinterpret_cast<hipStream_t>(stream));
+      if (rc != PTPP_OK) return rc;
+    }
+    return PTPP_OK;
+  }
+  for (int i = 0; i < nprob; ++i) {
+    const ptpp_wgrad_gproblem& q = probs[i];
+    const int rc = ptpp_conv1d_wgrad(q.x, q.dy, q.dw, q.dbias, q.lengths, q.B, q.T, q.Cin, q.Cout, q.ks, q.dil, q.pad, q.ldx, q.lddy,
+                                     q.lengths != nullptr, dtype, workspace, workspace_bytes, stream);
+    if (rc != PTPP_OK) return rc;
+  }
+  return PTPP_OK;
+}

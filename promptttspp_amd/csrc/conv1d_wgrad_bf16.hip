@@ -132,8 +132,11 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // XH: extra x rows of a tap group's window, (TG - 1) * dil <= XH
-template <int FM, int FN, int WR, int WC, int TG, int XH, bool BATCH, int NS>
-__device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__ lengths, const WgBatch* __restrict__ batch);
+// OWNER: every dw element of the launch has exactly one owner block (nsplit = 1), which adds its total straight into dw;
+// bid_in >= 0: the block's logical id inside its problem (grouped launch), else derived from blockIdx
+template <int FM, int FN, int WR, int WC, int TG, int XH, bool BATCH, int NS, bool OWNER = false>
+__device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__ lengths, const WgBatch* __restrict__ batch,
+                                           int bid_in = -1);
 
 // launch bounds: the second argument (minimum waves per SIMD) caps the allocation at 256 registers per lane.  Without it a
 // 256-thread kernel may use all 512, the compiler then selects the AGPR form of the MFMAs while keeping the accumulator
@@ -152,8 +155,40 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv1d_wgrad_bf16_batched_ker
   wgrad_body<FM, FN, WR, WC, TG, XH, true, NS>(p, lengths, &batch);
 }
 
-template <int FM, int FN, int WR, int WC, int TG, int XH, bool BATCH, int NS>
-__device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__ lengths, const WgBatch* __restrict__ batch) {
+// Grouped form (ptpp_conv1d_wgrad_grouped): up to WG_GMAX problems of DIFFERENT shapes (the linear / conv layers of one
+// Conformer block: 256 x 256, 256 x 1024 x 9, ...) over few rows (phone level: ~3 k rows, where a split-K launch per layer is
+// 30 us of fixed cost for 2 us of arithmetic) in one launch.  Block -> (problem, tap, ci tile, co tile) through the
+// problems' first-block offsets; every block owns its dw tile and walks all rows of its problem.
+constexpr int WG_GMAX = 16;
+struct WgGProb {
+  const bf16_raw* x;
+  const bf16_raw* dy;
+  float* dw;
+  float* dbias;
+  const int* lengths;  // non-null: rows of x at or after lengths[b] count as zero (in_mask)
+  int B, T, Cin, Cout, ks, dil, pad, ldx, lddy, nCO, nCI, tchunks, blk0;
+};
+struct WgGroup {
+  WgGProb pr[WG_GMAX];
+  int nprob;
+};
+template <int FM, int FN, int WR = 2, int WC = 2>
+__global__ __launch_bounds__(WR * WC * 64, 2) void conv1d_wgrad_bf16_grouped_kernel(const WgGroup g) {
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+  for (int i = 1; i < g.nprob; ++i)
+    if (bid >= g.pr[i].blk0) pi = i;
+  pi = __builtin_amdgcn_readfirstlane(pi);
+  WgP p;
+  p.x = g.pr[pi].x; p.dy = g.pr[pi].dy; p.dw = g.pr[pi].dw; p.dbias = g.pr[pi].dbias; p.lengths = g.pr[pi].lengths;
+  p.B = g.pr[pi].B; p.T = g.pr[pi].T; p.Cin = g.pr[pi].Cin; p.Cout = g.pr[pi].Cout; p.ks = g.pr[pi].ks; p.dil = g.pr[pi].dil;
+  p.pad = g.pr[pi].pad; p.ldx = g.pr[pi].ldx; p.lddy = g.pr[pi].lddy; p.in_mask = g.pr[pi].lengths != nullptr;
+  p.nCO = g.pr[pi].nCO; p.nCI = g.pr[pi].nCI; p.tchunks = g.pr[pi].tchunks; p.nsplit = 1; p.ws = nullptr;
+  wgrad_body<FM, FN, WR, WC, 1, 0, false, NS_DEFAULT, true>(p, p.lengths, nullptr, bid - g.pr[pi].blk0);
+}
+
+template <int FM, int FN, int WR, int WC, int TG, int XH, bool BATCH, int NS, bool OWNER>
+__device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__ lengths, const WgBatch* __restrict__ batch, int bid_in) {
   constexpr int NW = WR * WC;  // waves per block, WR x WC over (co, ci)
   constexpr int TM = WR * FM * 16, TN = WC * FN * 16;
   constexpr int XR = KR + XH;                       // x rows per stage
@@ -168,7 +203,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
 
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int bid = OWNER ? bid_in : xcd_remap(blockIdx.x, gridDim.x);
   const int cot = bid % p.nCO; bid /= p.nCO;
   const int cit = bid % p.nCI; bid /= p.nCI;
   const int ntg = (p.ks + TG - 1) / TG;
@@ -308,7 +343,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__
         for (int r = 0; r < 4; ++r) {
           const int co = co0 + (wr * FM + a) * 16 + lg * 4 + r;
           if (co < p.Cout && ci < p.Cin) {
-            if (BATCH && p.nsplit == 1) pdw[((int64_t)co * p.Cin + ci) * p.ks + j + g] += acc[g][a][c][r];  // the only owner
+            if (OWNER || (BATCH && p.nsplit == 1)) pdw[((int64_t)co * p.Cin + ci) * p.ks + j + g] += acc[g][a][c][r];  // the only owner
             else if (p.ws) p.ws[(((int64_t)split * p.ks + j + g) * p.Cout + co) * p.Cin + ci] = acc[g][a][c][r];
             else atomicAdd(pdw + ((int64_t)co * p.Cin + ci) * p.ks + j + g, acc[g][a][c][r]);
           }
@@ -322,7 +357,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + (wr * FM + a) * 16 + lg * 4 + r;
         if (co < p.Cout) {
-          if (BATCH && p.nsplit == 1) pdb[co] += accb[a][r];  // one block per (problem, co tile) reaches here
+          if (OWNER || (BATCH && p.nsplit == 1)) pdb[co] += accb[a][r];  // one block per (problem, co tile) reaches here
           else if (p.ws) p.ws[(int64_t)p.nsplit * p.ks * p.Cout * p.Cin + (int64_t)split * p.Cout + co] = accb[a][r];
           else atomicAdd(pdb + co, accb[a][r]);
         }
@@ -454,6 +489,32 @@ int ptpp_wgrad_bf16_launch_batched(const ptpp_wgrad_problem* probs, int nprob, c
   }
   if (ks > 1 && 2 * max_dil <= 32) return launch_batched<4, 2, 2, 4, 3, 32>(p, batch, nprob, st);
   return launch_batched<4, 4>(p, batch, nprob, st);
+}
+
+// called by ptpp_conv1d_wgrad_grouped for bf16 problems with 16-byte aligned rows; nprob <= 16
+int ptpp_wgrad_bf16_launch_grouped(const ptpp_wgrad_gproblem* probs, int nprob, hipStream_t st) {
+  constexpr int TM = 128, TN = 128;
+  WgGroup g;
+  g.nprob = nprob;
+  int64_t nblk = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const ptpp_wgrad_gproblem& q = probs[i];
+    WgGProb& d = g.pr[i];
+    d.x = (const bf16_raw*)q.x; d.dy = (const bf16_raw*)q.dy; d.dw = q.dw; d.dbias = q.dbias; d.lengths = q.lengths;
+    d.B = q.B; d.T = q.T;
+    if (q.ks == 1 && !q.lengths && q.B > 1) { d.T = q.B * q.T; d.B = 1; }  // (as ptpp_conv1d_wgrad: one flat row sequence)
+    d.Cin = q.Cin; d.Cout = q.Cout; d.ks = q.ks; d.dil = q.dil; d.pad = q.pad; d.ldx = q.ldx; d.lddy = q.lddy;
+    d.nCO = (q.Cout + TM - 1) / TM; d.nCI = (q.Cin + TN - 1) / TN; d.tchunks = (d.T + KR - 1) / KR;
+    d.blk0 = (int)nblk;
+    nblk += (int64_t)d.nCO * d.nCI * q.ks;
+  }
+  const size_t smem = (size_t)NS_DEFAULT * (KR * TM + KR * TN) * sizeof(bf16_raw);
+  auto kern = conv1d_wgrad_bf16_grouped_kernel<4, 4>;
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, st, g);
+  PTPP_CHECK_LAUNCH("conv1d_wgrad_grouped(bf16)");
+  return PTPP_OK;
 }
 
 // called by ptpp_conv1d_wgrad for bf16 tensors with 16-byte aligned rows

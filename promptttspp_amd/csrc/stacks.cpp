@@ -465,11 +465,18 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
   void* wstream = a->side_stream ? a->side_stream : stream;
   void* ws_w = a->side_stream ? a->ws_side : a->ws_main;
   const size_t ws_w_bytes = a->side_stream ? a->ws_side_bytes : a->ws_main_bytes;
-  // weight gradient on the side stream, after everything enqueued on the main one so far (functional.wgrad_stream)
+  // The block's weight gradients are collected and issued as ONE grouped call at the end (ptpp_conv1d_wgrad_grouped: at phone
+  // level a launch + reduction per layer is fixed cost; 26 launches -> 1), on the side stream after everything enqueued on the
+  // main one (functional.wgrad_stream).  Their operands (slab tensors, dz regions of the scratch) stay untouched until then.
+  ptpp_wgrad_gproblem wg[16];
+  int nwg = 0;
   auto wgrad = [&](const void* x, int ldx, const void* dy, int lddy, float* dw, float* db, const int32_t* lengths, int Bn, int Tn, int cin,
                    int cout, int ks, int pad, int in_mask) -> int {
-    if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
-    return ptpp_conv1d_wgrad(x, dy, dw, db, lengths, Bn, Tn, cin, cout, ks, 1, pad, ldx, lddy, in_mask, dt, ws_w, ws_w_bytes, wstream);
+    ST_CHECK_ARG(nwg < 16, "conformer_block_bwd: too many weight gradients");
+    ptpp_wgrad_gproblem& q = wg[nwg++];
+    q.x = x; q.dy = dy; q.dw = dw; q.dbias = db; q.lengths = in_mask ? lengths : nullptr;
+    q.B = Bn; q.T = Tn; q.Cin = cin; q.Cout = cout; q.ks = ks; q.dil = 1; q.pad = pad; q.ldx = ldx; q.lddy = lddy;
+    return PTPP_OK;
   };
   void *gA = sl(X, sc.gA), *gB = sl(X, sc.gB), *gC = sl(X, sc.gC), *t1 = sl(X, sc.t1), *t2 = sl(X, sc.t2);
   void* gF = sl(X, sc.gF);
@@ -550,7 +557,9 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
                  sl(X, sc.dz_f[1])));
   ST_TRY(ln_bwd_plain(t1, a->x, w.ln_g[0], stats, stats + R, t2, g.ln_g[0], g.ln_b[0], nullptr, B, T, C, 0, dt, a->red_scratch,
                       a->red_bytes, stream));
-  return ptpp_add3_scale(gA, t2, nullptr, a->gx, 1.0f, RC, dt, stream);
+  ST_TRY(ptpp_add3_scale(gA, t2, nullptr, a->gx, 1.0f, RC, dt, stream));
+  if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
+  return ptpp_conv1d_wgrad_grouped(wg, nwg, dt, ws_w, ws_w_bytes, wstream);
 }
 
 

@@ -328,6 +328,30 @@ def conv1d_wgrad_batched(problems, cin, cout, ks, lengths=None, in_mask=False):
                                                 ws.data_ptr(), _WS_BYTES, _stream()), "ptpp_conv1d_wgrad_batched")
 
 
+def conv1d_wgrad_grouped(problems):
+    """Weight / bias gradients of several layers of DIFFERENT shapes in one call (ptpp_conv1d_wgrad_grouped).  ``problems``:
+    list of (x (B,T,cin) view, dy (B,T,cout) view, dw f32 (cout,cin,ks), db f32 (cout) or None, ks, dil, pad, lengths or
+    None (= the input mask)); every dw / db is ACCUMULATED into."""
+    x0 = problems[0][0]
+    dev = x0.device
+    arr = (_lib.WgradGProblem * len(problems))()
+    keep = []
+    for i, (x, dy, dw, db, ks, dil, pad, lengths) in enumerate(problems):
+        B, T, cin = x.shape
+        cout = dy.shape[2]
+        assert dy.shape[:2] == x.shape[:2] and dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * cin * ks
+        a = arr[i]
+        a.x, a.dy, a.dw, a.dbias = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None
+        if lengths is not None:
+            lengths = i32(lengths, dev)
+            keep.append(lengths)
+            a.lengths = lengths.data_ptr()
+        a.B, a.T, a.Cin, a.Cout, a.ks, a.dil, a.pad, a.ldx, a.lddy = B, T, cin, cout, int(ks), int(dil), int(pad), _ld_fast(x), _ld_fast(dy)
+    ws = workspace(dev)
+    check(_lib.load().ptpp_conv1d_wgrad_grouped(arr, len(problems), dtype_code(x0.dtype), ws.data_ptr(), _WS_BYTES, _stream()),
+          "ptpp_conv1d_wgrad_grouped")
+
+
 def epilogue_bwd(dy, y=None, lengths=None, scale=1.0, relu=False, out_mask=False, drop_p=0.0, seed=0):
     _need_gpu(dy)
     dy = dy.contiguous()
