@@ -172,7 +172,7 @@ struct WgGroup {
   WgGProb pr[WG_GMAX];
   int nprob;
 };
-template <int FM, int FN, int WR = 2, int WC = 2>
+template <int FM, int FN, int WR = 2, int WC = 2, int TG = 1, int XH = 0>
 __global__ __launch_bounds__(WR * WC * 64, 2) void conv1d_wgrad_bf16_grouped_kernel(const WgGroup g) {
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int pi = 0;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv1d_wgrad_bf16_grouped_ker
   p.B = g.pr[pi].B; p.T = g.pr[pi].T; p.Cin = g.pr[pi].Cin; p.Cout = g.pr[pi].Cout; p.ks = g.pr[pi].ks; p.dil = g.pr[pi].dil;
   p.pad = g.pr[pi].pad; p.ldx = g.pr[pi].ldx; p.lddy = g.pr[pi].lddy; p.in_mask = g.pr[pi].lengths != nullptr;
   p.nCO = g.pr[pi].nCO; p.nCI = g.pr[pi].nCI; p.tchunks = g.pr[pi].tchunks; p.nsplit = 1; p.ws = nullptr;
-  wgrad_body<FM, FN, WR, WC, 1, 0, false, NS_DEFAULT, true>(p, p.lengths, nullptr, bid - g.pr[pi].blk0);
+  wgrad_body<FM, FN, WR, WC, TG, XH, false, NS_DEFAULT, true>(p, p.lengths, nullptr, bid - g.pr[pi].blk0);
 }
 
 template <int FM, int FN, int WR, int WC, int TG, int XH, bool BATCH, int NS, bool OWNER>
@@ -491,14 +491,17 @@ int ptpp_wgrad_bf16_launch_batched(const ptpp_wgrad_problem* probs, int nprob, c
   return launch_batched<4, 4>(p, batch, nprob, st);
 }
 
-// called by ptpp_conv1d_wgrad_grouped for bf16 problems with 16-byte aligned rows; nprob <= 16
-int ptpp_wgrad_bf16_launch_grouped(const ptpp_wgrad_gproblem* probs, int nprob, hipStream_t st) {
-  constexpr int TM = 128, TN = 128;
+// called by ptpp_conv1d_wgrad_grouped for bf16 problems with 16-byte aligned rows; nprob <= 16.  Two launches at most: the
+// problems with taps go to the tap-group instantiation (three taps share a block's dy chunk and x window: a k = 9 layer
+// moves a third of the operand bytes of nine one-tap blocks), the 1 x 1 problems to the one-tap instantiation.
+template <int FM, int FN, int WR, int WC, int TG, int XH>
+static int launch_grouped(const ptpp_wgrad_gproblem* const* probs, int nprob, hipStream_t st) {
+  constexpr int TM = WR * FM * 16, TN = WC * FN * 16, XR = KR + XH;
   WgGroup g;
   g.nprob = nprob;
   int64_t nblk = 0;
   for (int i = 0; i < nprob; ++i) {
-    const ptpp_wgrad_gproblem& q = probs[i];
+    const ptpp_wgrad_gproblem& q = *probs[i];
     WgGProb& d = g.pr[i];
     d.x = (const bf16_raw*)q.x; d.dy = (const bf16_raw*)q.dy; d.dw = q.dw; d.dbias = q.dbias; d.lengths = q.lengths;
     d.B = q.B; d.T = q.T;
@@ -506,14 +509,29 @@ int ptpp_wgrad_bf16_launch_grouped(const ptpp_wgrad_gproblem* probs, int nprob, 
     d.Cin = q.Cin; d.Cout = q.Cout; d.ks = q.ks; d.dil = q.dil; d.pad = q.pad; d.ldx = q.ldx; d.lddy = q.lddy;
     d.nCO = (q.Cout + TM - 1) / TM; d.nCI = (q.Cin + TN - 1) / TN; d.tchunks = (d.T + KR - 1) / KR;
     d.blk0 = (int)nblk;
-    nblk += (int64_t)d.nCO * d.nCI * q.ks;
+    nblk += (int64_t)d.nCO * d.nCI * ((q.ks + TG - 1) / TG);
   }
-  const size_t smem = (size_t)NS_DEFAULT * (KR * TM + KR * TN) * sizeof(bf16_raw);
-  auto kern = conv1d_wgrad_bf16_grouped_kernel<4, 4>;
+  const size_t smem = (size_t)NS_DEFAULT * (KR * TM + XR * TN) * sizeof(bf16_raw);
+  auto kern = conv1d_wgrad_bf16_grouped_kernel<FM, FN, WR, WC, TG, XH>;
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, st, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WR * WC * 64), smem, st, g);
   PTPP_CHECK_LAUNCH("conv1d_wgrad_grouped(bf16)");
+  return PTPP_OK;
+}
+int ptpp_wgrad_bf16_launch_grouped(const ptpp_wgrad_gproblem* probs, int nprob, hipStream_t st) {
+  const ptpp_wgrad_gproblem* taps[WG_GMAX];
+  const ptpp_wgrad_gproblem* flat[WG_GMAX];
+  int nt = 0, nf = 0;
+  for (int i = 0; i < nprob; ++i) {
+    if (probs[i].ks > 1 && 2 * probs[i].dil <= 32) taps[nt++] = probs + i;
+    else flat[nf++] = probs + i;
+  }
+  if (nt) {
+    const int rc = launch_grouped<4, 2, 2, 4, 3, 32>(taps, nt, st);
+    if (rc != PTPP_OK) return rc;
+  }
+  if (nf) return launch_grouped<4, 4, 2, 2, 1, 0>(flat, nf, st);
   return PTPP_OK;
 }
 
