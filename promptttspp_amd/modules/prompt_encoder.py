@@ -27,20 +27,29 @@ from .. import functional as PF
 from ..config import compute_dtype
 
 
+_allow_random = [0]  # nesting depth of ``allow_random_bert`` (a module-level flag: nothing process-global is mutated)
+
+
 class allow_random_bert:
     """``with allow_random_bert():`` -- constructors inside may fall back to a randomly initialised BERT (the caller
-    loads a checkpoint that holds ``prompt_encoder.bert.model.*``, or asked for a random model explicitly)."""
+    loads a checkpoint that holds ``prompt_encoder.bert.model.*``, or asked for a random model explicitly).  A wrapper
+    built that way carries ``random_init = True`` until a state dict with its keys is loaded (``check_bert_loaded``)."""
 
     def __enter__(self):
-        self.old = os.environ.get("PTPP_ALLOW_RANDOM_BERT")
-        os.environ["PTPP_ALLOW_RANDOM_BERT"] = "1"
+        _allow_random[0] += 1
 
     def __exit__(self, *exc):
-        if self.old is None:
-            os.environ.pop("PTPP_ALLOW_RANDOM_BERT", None)
-        else:
-            os.environ["PTPP_ALLOW_RANDOM_BERT"] = self.old
+        _allow_random[0] -= 1
         return False
+
+
+def check_bert_loaded(model, what="the checkpoint"):
+    """Raise if a BertWrapper under ``model`` still holds its random initialisation: a partial / non-strict load that did
+    not supply ``prompt_encoder.bert.model.*`` would otherwise train on eleven frozen random layers without a word."""
+    for name, m in model.named_modules():
+        if isinstance(m, BertWrapper) and m.random_init:
+            raise RuntimeError(f"{name}: BERT was randomly initialised (pretrained weights unavailable) and {what} did not "
+                               "supply its weights (prompt_encoder.bert.model.*)")
 
 
 class BertWrapper(nn.Module):
@@ -54,11 +63,12 @@ class BertWrapper(nn.Module):
             except Exception:
                 return cls.from_pretrained(class_name)  # the hub, like the reference (prompt_encoder.py:25-26)
 
+        self.random_init = False  # True: weights are a random initialisation until a state dict supplies them
         try:
             self.model = pretrained(BertModel)
         except Exception as e:
             if allow_random_init is None:
-                allow_random_init = os.environ.get("PTPP_ALLOW_RANDOM_BERT", "") not in ("", "0")
+                allow_random_init = _allow_random[0] > 0 or os.environ.get("PTPP_ALLOW_RANDOM_BERT", "") not in ("", "0")
             if not allow_random_init:
                 raise RuntimeError(
                     f"BertModel.from_pretrained({class_name!r}) failed ({type(e).__name__}: {e}) and random "
@@ -68,6 +78,7 @@ class BertWrapper(nn.Module):
             warnings.warn(f"BertModel.from_pretrained({class_name!r}) unavailable ({type(e).__name__}); "
                           "building bert-base from BertConfig() -- weights must come from the model checkpoint")
             self.model = BertModel(BertConfig())
+            self.random_init = True
         try:
             self.tokenizer = pretrained(BertTokenizer)
             if len(self.tokenizer) < 1000:  # transformers may return a stub vocabulary offline
@@ -79,6 +90,11 @@ class BertWrapper(nn.Module):
         for p in self.model.encoder.layer[-1].attention.parameters():
             p.requires_grad = True
         self.hip_frozen_layers = True  # False: every layer through the library modules
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        if any(k.startswith(prefix + "model.encoder.layer.0.") for k in state_dict):
+            self.random_init = False
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def _n_frozen(self, layers):
         """Number of leading encoder layers without a trainable parameter.  Walking ~200 parameters per

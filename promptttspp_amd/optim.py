@@ -5,6 +5,7 @@ HIP launches over ALL parameters with no host synchronisation
 ``torch.optim.AdamW`` (params, lr, betas, eps, weight_decay) plus ``max_grad_norm``;
 LR schedulers keep working through ``param_groups[i]['lr']``."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -22,6 +23,10 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.max_grad_norm = float(max_grad_norm)
         self.stable_grads = False  # set True by callers whose p.grad tensors live for the whole run (see _table)
+        # gradient norm summed in a fixed order (ptpp_grad_sumsq_det).  Kept on for single-GPU runs too: a run is then
+        # reproducible bit for bit, and its checkpoints do not depend on whether it was started with 1 or N ranks; False
+        # selects the one-launch atomic form (ptpp_grad_sumsq)
+        self.deterministic_norm = os.environ.get("PTPP_ADAMW_ATOMIC_NORM", "") in ("", "0")
         self._tables = {}
         self._sumsq = None
         self._partials = {}
@@ -85,12 +90,17 @@ class FusedAdamW(torch.optim.Optimizer):
             for gi, g in live:
                 tab, nt, nblk, bmap = self._table(gi, g)
                 part = self._sumsq if total is None else torch.zeros_like(self._sumsq)
-                scratch = self._partials.get(gi)
-                if scratch is None or scratch.numel() < nblk:
-                    scratch = self._partials[gi] = torch.empty(nblk, device=dev, dtype=torch.float32)
-                # (the deterministic two-launch form: identical clip factors on every data-parallel rank)
-                _lib.check(lib.ptpp_grad_sumsq_det(_ptr(tab), nt, _ptr(bmap), nblk, _ptr(part), _ptr(scratch), _stream()),
-                           "ptpp_grad_sumsq_det")
+                if self.deterministic_norm:
+                    scratch = self._partials.get(gi)
+                    if scratch is None or scratch.numel() < nblk or scratch.device != dev:
+                        scratch = self._partials[gi] = torch.empty(nblk, device=dev, dtype=torch.float32)
+                    # per-block partials summed in a fixed order: identical clip factors on every data-parallel rank and
+                    # from run to run, one small launch more than the atomic form
+                    _lib.check(lib.ptpp_grad_sumsq_det(_ptr(tab), nt, _ptr(bmap), nblk, _ptr(part), _ptr(scratch), _stream()),
+                               "ptpp_grad_sumsq_det")
+                else:
+                    part.zero_()
+                    _lib.check(lib.ptpp_grad_sumsq(_ptr(tab), nt, _ptr(bmap), nblk, _ptr(part), _stream()), "ptpp_grad_sumsq")
                 total = part if total is None else total.add_(part)
             if total is not self._sumsq:
                 self._sumsq.copy_(total)
@@ -135,6 +145,8 @@ class FusedAdamW(torch.optim.Optimizer):
             if steps and not g.get("step"):
                 g["step"] = int(max(steps))  # a torch.optim.AdamW checkpoint: continue its bias correction
         self._tables.clear()  # the moment tensors were replaced: rebuild the pointer tables
+        self._partials.clear()
+        self._lr_dev.clear()
 
     def grad_norm(self):
         """sqrt of the last computed sum of squares (device tensor; no sync)."""

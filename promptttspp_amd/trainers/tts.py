@@ -167,8 +167,9 @@ class TTSTrainer:
             except RuntimeError:  # smaller device / shared GPU: carry on without the reservation
                 pass
         # a run that restores a checkpoint gets the BERT weights from it; generated data is a benchmark / smoke run
-        from ..modules.prompt_encoder import allow_random_bert
         import contextlib
+
+        from ..modules.prompt_encoder import allow_random_bert, check_bert_loaded
 
         restores = _get(cfg, "ckpt_path") is not None or _get(cfg, "pretrained") is not None
         synthetic = "synthetic" in str(_get(cfg.dataset.train, "_target_", ""))
@@ -179,8 +180,6 @@ class TTSTrainer:
         params = [p for p in model.parameters() if p.requires_grad]
         optimizer = instantiate(cfg.optimizer, params=params)
         fused = isinstance(optimizer, FusedAdamW)
-        import contextlib
-
         from .. import ops as _ops
         pin_stream = _ops.pinned_stream if device.type == "cuda" else contextlib.nullcontext
         if fused and optimizer.max_grad_norm <= 0:
@@ -206,6 +205,9 @@ class TTSTrainer:
             except Exception as e:
                 print(f"Failed loading checkpoint: {e}")
 
+        if restores and not synthetic:
+            # the random-BERT fallback was granted because a checkpoint was going to supply the weights: hold it to that
+            check_bert_loaded(model, "neither cfg.pretrained nor cfg.ckpt_path")
         reducer = FlatGradReducer(params)      # p.grad become views of one flat buffer
         if fused:
             optimizer.stable_grads = True      # ... for the whole run: FusedAdamW may skip its per-step pointer scan

@@ -66,7 +66,34 @@ def test_bert_wrapper_refuses_silent_random_init(monkeypatch):
             assert BertWrapper("bert-base-uncased").model.config.hidden_size == 768
     import os
 
-    assert "PTPP_ALLOW_RANDOM_BERT" not in os.environ
+    assert "PTPP_ALLOW_RANDOM_BERT" not in os.environ  # (the context manager is a module-level flag, not the environment)
+
+
+def test_random_bert_must_be_overwritten_by_a_checkpoint(monkeypatch):
+    """A BertWrapper that fell back to random weights says so until a state dict with its keys is loaded; the trainer's
+    check (check_bert_loaded) refuses a partial / non-strict load that left it random."""
+    import warnings
+
+    import pytest
+    import torch
+
+    from promptttspp_amd.modules.prompt_encoder import BertWrapper, allow_random_bert, check_bert_loaded
+
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    with allow_random_bert(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        holder = torch.nn.Module()
+        holder.bert = BertWrapper("bert-base-uncased")
+    assert holder.bert.random_init
+    with pytest.raises(RuntimeError, match="randomly initialised"):
+        check_bert_loaded(holder, "the test checkpoint")
+    sd = holder.state_dict()
+    partial = {k: v for k, v in sd.items() if "encoder.layer" not in k}       # a checkpoint without the encoder
+    holder.load_state_dict(partial, strict=False)
+    assert holder.bert.random_init
+    holder.load_state_dict(sd)
+    assert not holder.bert.random_init
+    check_bert_loaded(holder)
 
 
 def test_fused_adamw_state_dict_round_trips_with_torch_adamw():

@@ -258,6 +258,30 @@ def test_fused_adamw_matches_torch(dev):
             assert rel_err(b.detach().cpu(), a.detach()) < 1e-5, step
 
 
+def test_fused_adamw_norm_reductions_agree(dev):
+    """The fixed-order gradient norm (default) and the one-launch atomic form (deterministic_norm = False, the round-1 path
+    kept in the ABI) clip by the same factor to f32 rounding; the fixed-order one is bit-reproducible."""
+    from promptttspp_amd.optim import FusedAdamW
+
+    torch.manual_seed(1)
+    shapes = [(512, 256, 3), (4099,), (80, 256, 1), (7,)]
+    grads = [torch.randn(s) * 2.0 for s in shapes]
+    outs = []
+    for det in (True, True, False):
+        ps = [torch.ones(s, device=dev).requires_grad_() for s in shapes]
+        o = FusedAdamW(ps, lr=1e-2, betas=(0.9, 0.98), weight_decay=0.0, max_grad_norm=1.0)
+        o.deterministic_norm = det
+        for p, g in zip(ps, grads):
+            p.grad = g.to(dev)
+        o.step()
+        torch.cuda.synchronize()
+        outs.append(([p.detach().cpu() for p in ps], float(o.grad_norm())))
+    want = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0])) and outs[0][1] == outs[1][1]
+    assert abs(outs[0][1] - want) < 1e-5 * want and abs(outs[2][1] - want) < 1e-5 * want
+    assert all(rel_err(a, b) < 1e-6 for a, b in zip(outs[0][0], outs[2][0]))
+
+
 def test_conv_family_at_bench_size_properties(dev):
     """BASELINE-sized shapes (one 30 000-token batch: 19 utterances x 1580 frames, DiffNet's dilated
     256 -> 512, k = 3 conv) through size-independent properties, bf16:
