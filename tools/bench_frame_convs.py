@@ -14,7 +14,10 @@ dump = os.environ.get("PTPP_CONV_DUMP")  # directory: save outputs (first run) /
 shapes = [("DiffNet dilated 256->512 k3", 52, 576, 256, 512, 3, 2), ("DiffNet 1x1 256->512", 52, 576, 256, 512, 1, 1),
           ("frame prior 256->256 k17", 52, 576, 256, 256, 17, 1), ("pitch pred 256->256 k5", 52, 576, 256, 256, 5, 1),
           ("dgrad 512->256 k3", 52, 576, 512, 256, 3, 2), ("BigVGAN C=128 k7 d3", 64, 30000, 128, 128, 7, 3),
-          ("BigVGAN C=256 k11 d5", 64, 6000, 256, 256, 11, 5), ("BigVGAN C=256 k3", 64, 6000, 256, 256, 3, 1)]
+          ("BigVGAN C=256 k11 d5", 64, 6000, 256, 256, 11, 5), ("BigVGAN C=256 k3", 64, 6000, 256, 256, 3, 1),
+          ("DiffNet cond_all 256->10240", 19, 1100, 256, 10240, 1, 1)]
+if os.environ.get("PTPP_BENCH_ONLY"):
+    shapes = [s_ for s_ in shapes if os.environ["PTPP_BENCH_ONLY"] in s_[0]]
 tot = 0.0
 torch.manual_seed(0)
 for name, B, T, cin, cout, ks, dil in shapes:
@@ -24,7 +27,8 @@ for name, B, T, cin, cout, ks, dil in shapes:
     b = torch.zeros(cout, device=dev)
     y = torch.empty(B, T, cout, device=dev, dtype=torch.bfloat16)
     pad = dil * (ks - 1) // 2
-    f = lambda: ops.conv1d(x, wp, b, cout, ks=ks, dil=dil, pad=pad, res=res, out=y)  # noqa: E731
+    f = (lambda: ops.conv1d(x, wp, b, cout, ks=ks, dil=dil, pad=pad, out=y)) if cout > 4096 else \
+        (lambda: ops.conv1d(x, wp, b, cout, ks=ks, dil=dil, pad=pad, res=res, out=y))  # noqa: E731
     for _ in range(3):
         f()
     torch.cuda.synchronize()
