@@ -359,6 +359,13 @@ int launch_tiles(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes) {
     if (launch_splitk<T, NCH, 2, 1, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
     return launch_cfg<T, NCH, 2, 1, 2, 8>(p, st);                      //  32 x 128, 8 waves of 16 x 32
   }
+  if constexpr (sizeof(T) == 2 && NCH == 8) {
+    // few output tiles and a long K (the Conformer feed-forward k = 9 convs at phone level: 1024 -> 256 over ~150 rows per
+    // utterance = 114 tiles, 144 K steps): split-K on the LDS-DMA kernel -- a K step there costs ~0.5 us against ~3 us in
+    // the register-staged 8-wave kernel below.  PTPP_CONV_GLDS_SPLITK=0 keeps the old route.
+    static const char* gsk = getenv("PTPP_CONV_GLDS_SPLITK");
+    if (!(gsk && gsk[0] == '0') && launch_glds_splitk<2, 4, 2, 2, 2>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
+  }
   if (p.T <= 96 || (p.T % 128 != 0 && p.T % 128 <= 64 && p.T < 512)) {
     if (launch_splitk<T, NCH, 2, 2, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
     return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);                      //  64 x 128, 8 waves of 32 x 32

@@ -380,11 +380,14 @@ __device__ unsigned long long* g_conv_stamps;  // experiments only (DBG = true):
 // POST: the instantiation with the fused DiffNet tail (ptpp_conv1d_diffnet_post) -- separate, because its second set
 // of prefetch registers and epilogue pushed the plain 128 x 128 kernel into scratch memory (576 B per lane; BigVGAN
 // C = 128 k = 7 went from 707 to 1334 us).
-// EPI: 0 = the ordinary epilogue, 1 = POST, 2 = the fused DiffNet gate backward (ptpp_conv1d_gate_bwd)
+// EPI: 0 = the ordinary epilogue, 1 = POST, 2 = the fused DiffNet gate backward (ptpp_conv1d_gate_bwd), 3 = split-K: block
+// (b, mt, nt, split) walks its share of the Cin chunks and stores raw f32 partial sums for conv_splitk_finish_kernel (few
+// output tiles, long K: the Conformer feed-forward k = 9 convs at phone level, 1024 -> 256 over ~150 rows per utterance)
 template <int FM, int FN, int WR, int WC, int D, bool DBG = false, int EPI = 0>
 __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p) {
   constexpr bool POST = EPI == 1;
   constexpr bool GBWD = EPI == 2;
+  constexpr bool SK = EPI == 3;
   typedef bf16_raw T;
   constexpr int NW = WR * WC;
   constexpr int BM = WR * FM * 16, BN = WC * FN * 16;
@@ -408,7 +411,9 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int nt = lid % p.nNT;
   const int mt = (lid / p.nNT) % p.nMT;
-  const int b = lid / (p.nNT * p.nMT);
+  const int ball = lid / (p.nNT * p.nMT);
+  const int b = SK ? ball % p.B : ball;
+  const int split = SK ? ball / p.B : 0;
   const int t0 = mt * BM, n0 = nt * BN;
 
   const int len = p.lengths ? min(p.lengths[b], p.T) : p.T;
@@ -422,7 +427,11 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nC = p.cinp >> 6;
-  const int steps = (p.out_mask && t0 >= len) ? 0 : nC * p.ks;
+  int sbeg = 0, steps = (p.out_mask && t0 >= len) ? 0 : nC * p.ks;  // the block's K steps are [sbeg, steps)
+  if constexpr (SK) {  // whole chunks per split, so a split starts at tap 0 of a chunk
+    sbeg = (int)((int64_t)split * nC / p.nsplit) * p.ks;
+    steps = (int)((int64_t)(split + 1) * nC / p.nsplit) * p.ks;
+  }
 
   // per-lane source of the wave's weight pieces at (ci = 0, tap 0)
   const char* wsrc[LW];
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
   // the residual rows of the tile, fetched row-contiguous (see tile_epilogue) while the first operands travel:
   // the K loop's first vmcnt(0) retires them together with the first stage
   constexpr bool post = POST;
-  const bool tile_epi = post || GBWD || tile_epilogue_ok<FN>(p);
+  const bool tile_epi = !SK && (post || GBWD || tile_epilogue_ok<FN>(p));
   constexpr int NRV = BM * BN / 8 / (NW * 64);  // 16-byte vectors of the output tile per thread
   uint4 resv[NRV], resv2[(POST || GBWD) ? NRV : 1];
   if constexpr (GBWD) {  // the saved pre-activation rows: gate half [c] and filter half [C + c] of this tile's channels
@@ -499,13 +508,13 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
                                                              : make_uint4(0, 0, 0, 0);
     }
   }
-  if (steps > 0) {
-    issue_x(0, 0);
-    issue_w(0, 0);
-    if (D > 2 && steps > 1) issue_w(1, 1);
+  if (steps > sbeg) {
+    issue_x(sbeg / p.ks, (sbeg / p.ks) & 1);
+    issue_w(sbeg, 0);
+    if (D > 2 && steps > sbeg + 1) issue_w(sbeg + 1, 1);
   }
   int stage = 0;
-  for (int s = 0; s < steps; ++s) {
+  for (int s = sbeg; s < steps; ++s) {
     const int ci = s / p.ks, j = s - ci * p.ks;
     if (D > 2 && s + 1 < steps) glds_wait<LW>();
     else glds_wait<0>();
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
     if constexpr (DBG) {
       if (s == 0) stamp1 = wall_clock64();
     }
-    if (j == 0 && ci + 1 < nC) issue_x(ci + 1, (ci + 1) & 1);
+    if (j == 0 && (ci + 1) * p.ks < steps) issue_x(ci + 1, (ci + 1) & 1);
     if (s + D - 1 < steps) issue_w(s + D - 1, stage == 0 ? D - 1 : stage - 1);
 
     const uint4* Wb = Ws + stage * WSTAGE;
@@ -544,6 +553,19 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
     stage = stage + 1 == D ? 0 : stage + 1;
   }
   if constexpr (DBG) stamp2 = wall_clock64();
+  if constexpr (SK) {
+    float* wsb = p.ws + ((int64_t)split * p.B + b) * p.T * p.Cout;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+      const int t = t0 + (wm * FM + fm) * 16 + lr;
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const int co = n0 + wn * FN * 16 + (fn >> 1) * 32 + lg * 8 + (fn & 1) * 4;  // (the channel map of conv_epilogue / wperm)
+        if (t < p.T && co < p.Cout) *reinterpret_cast<f32x4*>(wsb + (int64_t)t * p.Cout + co) = acc[fm][fn];
+      }
+    }
+    return;
+  }
   if (tile_epi) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with the operand stages: their memory becomes the tile
@@ -588,6 +610,45 @@ int launch_glds(ConvP& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WR * WC * 64), smem, st, p);
   PTPP_CHECK_LAUNCH("conv1d_fwd (lds-dma)");
   return PTPP_OK;
+}
+
+// split-K launch of the LDS-DMA kernel + conv_splitk_finish_kernel (declared in conv1d_cl.hip): few output tiles, long K
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p);
+template <int FM, int FN, int WR, int WC, int D>
+bool launch_glds_splitk(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes, int* status) {
+  constexpr int BM = WR * FM * 16, BN = WC * FN * 16;
+  static_assert(FN % 2 == 0, "the split-K store uses the paired-fragment channel map");
+  const int nC = p.cinp >> 6;
+  const int nMT = (p.T + BM - 1) / BM, nNT = (p.Cout + BN - 1) / BN;
+  const int64_t blocks = (int64_t)p.B * nMT * nNT;
+  // (thresholds 384 / 768 vs 512 / 1024 / 512: 18.29-18.37 ms per step, all within run-to-run noise)
+  if (!ws || !glds_ok(p) || (p.Cout & 3) || p.act == PTPP_ACT_GATE || p.post_skip || p.gate_a || (int64_t)nC * p.ks < 32 || blocks >= 384)
+    return false;
+  int64_t ns = (768 + blocks - 1) / blocks;  // three resident blocks per CU
+  if (ns > 8) ns = 8;
+  if (ns > nC) ns = nC;
+  const int64_t slab = (int64_t)p.B * p.T * p.Cout * (int64_t)sizeof(float);
+  if (ns * slab > (int64_t)ws_bytes) ns = (int64_t)ws_bytes / slab;
+  if (ns < 2) return false;
+  const int xrows = (BM + (p.ks - 1) * p.dil + 7) & ~7;
+  const size_t smem = (size_t)(D * BN * 8 + 2 * xrows * 8) * 16;
+  if (smem > 160 * 1024) return false;
+  p.ws = reinterpret_cast<float*>(ws);
+  p.nsplit = (int)ns;
+  p.nMT = nMT;
+  p.nNT = nNT;
+  auto kern = conv1d_glds_kernel<FM, FN, WR, WC, D, false, 3>;
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * ns)), dim3(WR * WC * 64), smem, st, p);
+  const int64_t nvec = (int64_t)p.B * p.T * (p.Cout >> 2);
+  int64_t fb = (nvec + 255) / 256;
+  if (fb > 4096) fb = 4096;
+  hipLaunchKernelGGL(conv_splitk_finish_kernel<bf16_raw>, dim3((unsigned)fb), dim3(256), 0, st, p);
+  *status = hipGetLastError() == hipSuccess ? PTPP_OK : PTPP_ELAUNCH;
+  if (*status != PTPP_OK) ptpp_set_error("conv1d_fwd (LDS-DMA split-K): launch failed");
+  return true;
 }
 
 }  // namespace
