@@ -364,7 +364,17 @@ int launch_tiles(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes) {
     // utterance = 114 tiles, 144 K steps): split-K on the LDS-DMA kernel -- a K step there costs ~0.5 us against ~3 us in
     // the register-staged 8-wave kernel below.  PTPP_CONV_GLDS_SPLITK=0 keeps the old route.
     static const char* gsk = getenv("PTPP_CONV_GLDS_SPLITK");
+    // (128 x 128 tiles for the split: 46.3 vs 44.3 us on the 1024 -> 256 k = 9 shape)
     if (!(gsk && gsk[0] == '0') && launch_glds_splitk<2, 4, 2, 2, 2>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
+    // enough 64-row tiles for every CU and a K loop of >= 32 steps (256 -> 1024, k = 9 at phone level: 456 tiles, 36 steps):
+    // the LDS-DMA kernel without a split instead of the 8-wave split-K kernel (18.67 -> 18.52 ms per step;
+    // PTPP_CONV_GLDS_SHORT=0 keeps the old route)
+    static const char* gsh = getenv("PTPP_CONV_GLDS_SHORT");
+    if (!(gsh && gsh[0] == '0') && glds_ok(p) && (p.T <= 96 || (p.T % 128 != 0 && p.T % 128 <= 64 && p.T < 512)) &&
+        (long long)p.B * ((p.T + 63) / 64) * ((p.Cout + 127) / 128) >= 384 && (long long)(p.cinp >> 6) * p.ks >= 32) {
+      const int rc = launch_glds<2, 4, 2, 2, 2>(p, st);
+      if (rc >= 0) return rc;
+    }
   }
   if (p.T <= 96 || (p.T % 128 != 0 && p.T % 128 <= 64 && p.T < 512)) {
     if (launch_splitk<T, NCH, 2, 2, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;

@@ -15,7 +15,9 @@ shapes = [("DiffNet dilated 256->512 k3", 52, 576, 256, 512, 3, 2), ("DiffNet 1x
           ("frame prior 256->256 k17", 52, 576, 256, 256, 17, 1), ("pitch pred 256->256 k5", 52, 576, 256, 256, 5, 1),
           ("dgrad 512->256 k3", 52, 576, 512, 256, 3, 2), ("BigVGAN C=128 k7 d3", 64, 30000, 128, 128, 7, 3),
           ("BigVGAN C=256 k11 d5", 64, 6000, 256, 256, 11, 5), ("BigVGAN C=256 k3", 64, 6000, 256, 256, 3, 1),
-          ("DiffNet cond_all 256->10240", 19, 1100, 256, 10240, 1, 1)]
+          ("DiffNet cond_all 256->10240", 19, 1100, 256, 10240, 1, 1),
+          ("phone FFN 1024->256 k9", 19, 150, 1024, 256, 9, 1), ("phone FFN 256->1024 k9", 19, 150, 256, 1024, 9, 1),
+          ("phone linear 256->768", 19, 150, 256, 768, 1, 1), ("phone linear 256->256", 19, 150, 256, 256, 1, 1)]
 if os.environ.get("PTPP_BENCH_ONLY"):
     shapes = [s_ for s_ in shapes if os.environ["PTPP_BENCH_ONLY"] in s_[0]]
 tot = 0.0
