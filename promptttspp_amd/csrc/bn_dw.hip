@@ -261,6 +261,7 @@ __global__ void dwconv_kernel(const T* __restrict__ u, const float* __restrict__
 }
 
 // dw[c][j] += sum_{b,t<len} dy[b,t,c] * u[b, t + j - pad, c] ; dbias[c] += sum dy
+// Every block ends with (KS + 1) C atomics into the same ~60 cache lines (~50 ns per visit and line).
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ u, const T* __restrict__ dy,
                                                            float* __restrict__ dw, float* __restrict__ dbias,
@@ -298,6 +299,68 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     if (rgi == 0) {
       f32x4 s = v;
       for (int k = 1; k < g.rg; ++k) s += red[k * g.cv + cvi];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (j < KS) atomicAdd(dw + (c + e) * KS + j, s[e]);
+        else if (dbias) atomicAdd(dbias + c + e, s[e]);
+      }
+    }
+  }
+}
+
+// Short inputs (phone level: a few thousand rows).  The kernel above spent 68 us on 3 800 rows: every row of a thread's loop
+// is a chain of two dependent memory latencies (lengths[row / T] -> the row's loads) behind a 64-bit division.  Here a block
+// owns RPT * NT / (C/4) consecutive rows of ONE utterance (utterance index and length are block-uniform, no division), a
+// thread issues all its RPT * (KS + 1) loads at once (512 threads x 4 rows: 160 registers, no scratch).
+template <typename T, int KS, int NT, int RPT>
+__global__ __launch_bounds__(NT) void dwconv_wgrad_short_kernel(const T* __restrict__ u, const T* __restrict__ dy,
+                                                                float* __restrict__ dw, float* __restrict__ dbias,
+                                                                const int* __restrict__ lengths, int Tlen, int C, int nchunk) {
+  const int cv = C >> 2, rg = NT / cv;
+  const int cvi = threadIdx.x % cv, rgi = threadIdx.x / cv;
+  const int c = cvi * 4;
+  constexpr int PAD = KS / 2;
+  constexpr int ITER = 4;  // row windows per block: 4 x fewer blocks queue at the accumulators' cache lines
+  const int b = blockIdx.x / nchunk, tb = (blockIdx.x % nchunk) * (rg * RPT * ITER);
+  const int len = lengths ? min(lengths[b], Tlen) : Tlen;
+  if (tb >= len) return;  // block-uniform
+  const T* ub = u + (int64_t)b * Tlen * C + c;
+  const T* dyb = dy + (int64_t)b * Tlen * C + c;
+  f32x4 aw[KS], ab = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < KS; ++j) aw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < ITER; ++it) {
+  const int t0 = tb + it * (rg * RPT);
+  if (t0 >= len) break;
+  f32x4 d[RPT], uu[RPT][KS];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int t = t0 + rgi + k * rg;
+    const bool valid = t < len;
+    d[k] = valid ? Elem<T>::ld4(dyb + (int64_t)t * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int ts = t + j - PAD;
+      uu[k][j] = (valid && ts >= 0 && ts < Tlen) ? Elem<T>::ld4(ub + (int64_t)ts * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    ab += d[k];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) aw[j] += d[k] * uu[k][j];
+  }
+  }
+  __shared__ f32x4 red[NT];
+#pragma unroll
+  for (int j = 0; j <= KS; ++j) {
+    const f32x4 v = j < KS ? aw[j < KS ? j : 0] : ab;
+    __syncthreads();
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (rgi == 0) {
+      f32x4 s = v;
+      for (int k = 1; k < rg; ++k) s += red[k * cv + cvi];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (j < KS) atomicAdd(dw + (c + e) * KS + j, s[e]);
@@ -507,17 +570,26 @@ extern "C" int ptpp_dwconv1d(const void* u, const float* w, const float* bias, v
 #define DWW_LAUNCH(KS_)                                                                                              \
   hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS_>), dim3(nb), dim3(256), 0, st, (const T*)u, (const T*)dy, dw, dbias, \
                      lengths, T_, C, rows, rpb)
+#define DWW_SHORT(KS_)                                                                                                        \
+  hipLaunchKernelGGL((dwconv_wgrad_short_kernel<T, KS_, 512, 4>), dim3((unsigned)(B * nchunk)), dim3(512), 0, st, (const T*)u, \
+                     (const T*)dy, dw, dbias, lengths, T_, C, nchunk)
 
 extern "C" int ptpp_dwconv1d_wgrad(const void* u, const void* dy, float* dw, float* dbias, const int32_t* lengths, int B,
                                    int T_, int C, int ks, int dtype, void* stream) {
   PTPP_CHECK_ARG(u && dy && dw && B > 0 && T_ > 0 && cgeom_ok(C), "dwconv1d_wgrad: bad args");
   PTPP_CHECK_ARG(ks == 7 || ks == 15 || ks == 31, "dwconv1d_wgrad: kernel size %d not built", ks);
   const int64_t rows = (int64_t)B * T_;
-  // phoneme-level inputs are a few thousand rows: 32 rows per block keeps >100 blocks in flight and
-  // ~100 block visits per accumulator line (atomics on one line serialise at ~50 ns per visit)
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (ks == 7 && rows <= 65536) {  // (the register window of the short kernel is built for the Conformer's k = 7)
+    const int rpb4 = 4 * 4 * (512 / (C >> 2));  // rows per block (ITER x RPT x row groups of a 512-thread block)
+    const int nchunk = (T_ + rpb4 - 1) / rpb4;
+    DISPATCH_T(dtype, "dwconv1d_wgrad", DWW_SHORT(7));
+    PTPP_CHECK_LAUNCH("dwconv1d_wgrad");
+    return PTPP_OK;
+  }
+  // 32 rows per block keeps >100 blocks in flight for inputs of a few thousand rows
   const int rpb = rows > 65536 ? 128 : 32;
   const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   DISPATCH_T(dtype, "dwconv1d_wgrad", if (ks == 7) { DWW_LAUNCH(7); } else if (ks == 15) { DWW_LAUNCH(15); } else { DWW_LAUNCH(31); });
   PTPP_CHECK_LAUNCH("dwconv1d_wgrad");
   return PTPP_OK;
