@@ -77,7 +77,9 @@ int ptpp_conv_cin_padded(int cin, int dtype);
 
 /* torch Conv1d weight w[Cout][Cin][ks] (f32) -> wp[Cout][ks][CinP] (dtype),
  * K-contiguous, zero padded.  mode 0: forward operand.  mode 1: operand of
- * the data-gradient convolution, wp[Cin][ks][CoutP] with taps flipped. */
+ * the data-gradient convolution, wp[Cin][ks][CoutP] with taps flipped.  mode 2: mode 0 for a (gate | filter) weight
+ * (Cout = 2C, Cout % 8 == 0) with its rows in the interleaved order of the fused DiffNet gate epilogue (PTPP_ACT_GATE):
+ * packed row 8g + e = gate row 4g + e (e < 4) / filter row C + 4g + e - 4 (e >= 4). */
 int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin, int ks,
                           int mode, int dtype, void* stream);
 
@@ -333,6 +335,13 @@ int ptpp_ddpm_step(const float* x, const void* eps, const float* noise, const in
 int ptpp_conv1d_gate_bwd_supported(int C, int cin, int dtype);
 int ptpp_conv1d_gate_bwd(const ptpp_conv1d_args* a, const void* act, void* da, int ldda,
                          void* stream);
+
+/* The DiffNet dilated conv (+ conditioner slice as `res`) of the TRAINING forward with the gate in the epilogue and the
+ * pre-activation kept for the backward (modules/denoiser.py:76-79): weights, bias and `res` in the gate-interleaved row order
+ * (ptpp_pack_conv_weight mode 2: rows [4 gate | their 4 filter partners]); y = g (B, T, C) and a_out (B, T, 2C) in the
+ * STANDARD [gate | filter] order, row stride lda -- bit for bit what ptpp_conv1d_fwd followed by ptpp_gate_fwd produce. */
+int ptpp_conv1d_gate_fwd_save_supported(int C, int cin, int dtype);
+int ptpp_conv1d_gate_fwd_save(const ptpp_conv1d_args* a, void* a_out, int lda, void* stream);
 /* dout (rows, 2C) = [gx/sqrt2 | gskip], masked rows zero */
 int ptpp_diffnet_post_bwd(const void* gx, const void* gskip, void* dout,
                           const int32_t* lengths, int B, int T, int C, int dtype,
@@ -544,8 +553,10 @@ int ptpp_adamw_step(const void* refs, int nt, const int32_t* block_map,
 /* DiffNet residual stack, forward (reference modules/denoiser.py:69-83 per layer, :136-140 the loop):
  *   yin_0 = h0 + dsteps[0];  per layer l: a = dilconv_l(yin) + cond_all[.., l*2C:(l+1)*2C]; g = sigmoid(a[:C])*tanh(a[C:]);
  *   o = outproj_l(g) (masked);  x = (x + o[:C]) / sqrt2;  skip += o[C:];  yin = x + dsteps[l+1].
- * fused_gate (bf16 inference): the dilated conv's weights / bias and cond_all are in the interleaved gate order and the
- * gate runs in the conv epilogue (PTPP_ACT_GATE); a_all is then unused. */
+ * fused_gate = 1 (bf16 inference): the dilated conv's weights / bias and cond_all are in the interleaved gate order
+ * (ptpp_pack_conv_weight mode 2) and the gate runs in the conv epilogue (PTPP_ACT_GATE); a_all is then unused.
+ * fused_gate = 2 (bf16 training): the same, and the pre-activation is kept in a_all in the standard channel order
+ * (ptpp_conv1d_gate_fwd_save): one launch per layer less, bit-identical to fused_gate = 0. */
 typedef struct {
   const void* h0;           /* (B, T, C) dtype                                        */
   const void* cond_all;     /* (B, T, L*2C) dtype, row stride L*2C                    */
@@ -557,7 +568,7 @@ typedef struct {
   const void* const* out_wp;   /* [L] packed (2C, 1, C) operands                      */
   const float* const* out_b;   /* [L] (2C) f32                                        */
   void* yin_all;            /* (n_slabs, B, T, C) dtype                               */
-  void* a_all;              /* (n_slabs, B, T, 2C) dtype, NULL with fused_gate        */
+  void* a_all;              /* (n_slabs, B, T, 2C) dtype, NULL with fused_gate = 1    */
   void* g_all;              /* (n_slabs, B, T, C) dtype                               */
   void* x_buf[2];           /* two (B, T, C) dtype scratch tensors for x              */
   void* o_buf;              /* (B, T, 2C) dtype scratch, only used where the fused tail is unsupported (f32) */

@@ -218,6 +218,8 @@ SIGNATURES = {
     "ptpp_mdn_nll_bwd": (I, [P] * 10 + [I64, I, I, F, F, P]),
     "ptpp_conv1d_gate_bwd_supported": (I, [I, I, I]),
     "ptpp_conv1d_gate_bwd": (I, [POINTER(ConvArgs), P, P, I, P]),
+    "ptpp_conv1d_gate_fwd_save_supported": (I, [I, I, I]),
+    "ptpp_conv1d_gate_fwd_save": (I, [POINTER(ConvArgs), P, I, P]),
     "ptpp_diffnet_post_bwd": (I, [P, P, P, P, I, I, I, I, P]),
     "ptpp_colsum_batch": (I, [P, P, I, I, I, I, P]),
     "ptpp_col_reduce": (I, [P, P, P, I64, I, I, P, SZ, P]),

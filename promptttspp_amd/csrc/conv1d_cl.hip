@@ -462,7 +462,7 @@ extern "C" int ptpp_conv1d_fwd_ws(const ptpp_conv1d_args* a, const void* res2, i
   p.ws = nullptr;
   p.nsplit = 1;
   p.post_skip = nullptr; p.post_dnext = nullptr; p.post_yin = nullptr; p.post_C = 0; p.post_init = 0;
-  p.gate_a = nullptr; p.gate_da = nullptr; p.gate_ldda = 0;
+  p.gate_a = nullptr; p.gate_da = nullptr; p.gate_ldda = 0; p.gate_save = nullptr; p.gate_lds = 0;
   if (workspace && ((uintptr_t)workspace & 15)) workspace = nullptr;
   // A linear layer without sequence masks does not care where one utterance ends: treat the (B, T) rows
   // as ONE sequence (rows are linear in memory: batches are T consecutive rows) so that short utterances
@@ -516,7 +516,7 @@ extern "C" int ptpp_conv1d_diffnet_post(const ptpp_conv1d_args* a, const void* x
   p.drop_thresh16 = 0; p.drop_inv_keep = 1.f; p.drop_seed = 0;
   p.ws = nullptr; p.nsplit = 1;
   p.post_skip = skip; p.post_dnext = dnext; p.post_yin = yin; p.post_C = C; p.post_init = init;
-  p.gate_a = nullptr; p.gate_da = nullptr; p.gate_ldda = 0;
+  p.gate_a = nullptr; p.gate_da = nullptr; p.gate_ldda = 0; p.gate_save = nullptr; p.gate_lds = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long long tiles128 = (long long)p.B * ((p.T + 127) / 128) * ((p.Cout + 127) / 128);
   const int rc = tiles128 >= 1536 ? launch_glds<4, 4, 2, 2, 2>(p, st) : launch_glds<2, 4, 2, 2, 2>(p, st);
@@ -551,12 +551,55 @@ extern "C" int ptpp_conv1d_gate_bwd(const ptpp_conv1d_args* a, const void* act, 
   p.drop_thresh16 = 0; p.drop_inv_keep = 1.f; p.drop_seed = 0;
   p.ws = nullptr; p.nsplit = 1;
   p.post_skip = nullptr; p.post_dnext = nullptr; p.post_yin = nullptr; p.post_C = 0; p.post_init = 0;
-  p.gate_a = act; p.gate_da = da; p.gate_ldda = ldda;
+  p.gate_a = act; p.gate_da = da; p.gate_ldda = ldda; p.gate_save = nullptr; p.gate_lds = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long long tiles128 = (long long)p.B * ((p.T + 127) / 128) * ((p.Cout + 127) / 128);
   const int rc = tiles128 >= 1536 ? launch_glds<4, 4, 2, 2, 2>(p, st) : launch_glds<2, 4, 2, 2, 2>(p, st);
   if (rc < 0) {
     ptpp_set_error("conv1d_gate_bwd: tile does not fit LDS");
+    return PTPP_EINVAL;
+  }
+  return rc;
+}
+
+
+// ---- DiffNet dilated conv (+ conditioner slice) with the gate fused into the epilogue AND the pre-activation kept ----
+// Training forward (modules/denoiser.py:76-79): a = conv(yin) + bias + cond slice, g = sigmoid(a[:, :C]) * tanh(a[:, C:]).
+// The weights (and bias, and the cond slice) are in the gate-interleaved row order of PTPP_ACT_GATE (ptpp_pack_conv_weight
+// mode 2); g (B, T, C) and a (B, T, 2C, STANDARD [gate | filter] order, for the backward) leave in one launch, bit for bit
+// what ptpp_conv1d_fwd + ptpp_gate_fwd produce.
+extern "C" int ptpp_conv1d_gate_fwd_save_supported(int C, int cin, int dtype) {
+  return dtype == PTPP_BF16 && C > 0 && C % 64 == 0 && cin > 0 && cin % 64 == 0;
+}
+
+extern "C" int ptpp_conv1d_gate_fwd_save(const ptpp_conv1d_args* a, void* a_out, int lda, void* stream) {
+  PTPP_CHECK_ARG(a && a->x && a->wp && a->y && a_out, "conv1d_gate_fwd_save: null pointer");
+  const int C = a->Cout / 2;
+  PTPP_CHECK_ARG(a->Cout == 2 * C && ptpp_conv1d_gate_fwd_save_supported(C, a->Cin, a->dtype),
+                 "conv1d_gate_fwd_save: needs bf16, 2C output channels with C %% 64 == 0, Cin %% 64 == 0 (C=%d Cin=%d)", C, a->Cin);
+  PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->ks > 0 && a->dil > 0 && a->ldx % 8 == 0 && a->ldy % 8 == 0 && lda % 8 == 0 && lda >= 2 * C &&
+                     (!a->res || a->ldr % 8 == 0) && ((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->wp % 16) == 0 &&
+                     ((uintptr_t)a->y % 16) == 0 && ((uintptr_t)a_out % 16) == 0 && ((uintptr_t)a->res % 16) == 0 &&
+                     (!a->bias || ((uintptr_t)a->bias % 16) == 0),
+                 "conv1d_gate_fwd_save: operands must be 16-byte aligned with row strides in multiples of 8");
+  PTPP_CHECK_ARG(!(a->in_mask || a->out_mask) || a->lengths, "conv1d_gate_fwd_save: masks need lengths");
+  ConvP p;
+  p.x = a->x; p.wp = a->wp; p.bias = a->bias; p.res = a->res; p.res2 = nullptr; p.y = a->y; p.lengths = a->lengths;
+  p.B = a->B; p.T = a->T; p.Cin = a->Cin; p.Cout = a->Cout; p.ks = a->ks; p.dil = a->dil; p.pad = a->pad;
+  p.ldx = a->ldx; p.ldy = a->ldy; p.ldr = a->ldr; p.ldr2 = 0;
+  p.cinp = a->Cin;
+  p.act = PTPP_ACT_GATE; p.in_mask = a->in_mask; p.out_mask = a->out_mask;
+  p.out_scale = a->out_scale; p.res_scale = 1.f;
+  p.drop_thresh16 = 0; p.drop_inv_keep = 1.f; p.drop_seed = 0;
+  p.ws = nullptr; p.nsplit = 1;
+  p.post_skip = nullptr; p.post_dnext = nullptr; p.post_yin = nullptr; p.post_C = 0; p.post_init = 0;
+  p.gate_a = nullptr; p.gate_da = nullptr; p.gate_ldda = 0;
+  p.gate_save = a_out; p.gate_lds = lda;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long tiles128 = (long long)p.B * ((p.T + 127) / 128) * ((p.Cout + 127) / 128);
+  const int rc = tiles128 >= 1536 ? launch_glds<4, 4, 2, 2, 2>(p, st) : launch_glds<2, 4, 2, 2, 2>(p, st);
+  if (rc < 0) {
+    ptpp_set_error("conv1d_gate_fwd_save: tile does not fit LDS");
     return PTPP_EINVAL;
   }
   return rc;

@@ -57,6 +57,11 @@ struct ConvP {
   const void* gate_a;  // nullptr = not this mode
   void* gate_da;
   int gate_ldda;
+  // fused DiffNet gate FORWARD that also keeps the pre-activation for the backward (training; conv1d_glds.h,
+  // ptpp_conv1d_gate_fwd_save): act = PTPP_ACT_GATE, y = g (Cout / 2 channels), gate_save (B, T, Cout) in the STANDARD
+  // [gate | filter] channel order, row stride gate_lds
+  void* gate_save;  // nullptr = not this mode
+  int gate_lds;
 };
 
 // Fused epilogue of one (BM x BN) tile: acc[fm][fn] is the MFMA accumulator of the wave's

@@ -82,7 +82,7 @@ __device__ __forceinline__ void tile_epi_put_res(const uint4 (&resv)[NRV], uint4
 // conv_epilogue)
 template <int FM, int FN, int ACT>
 __device__ __forceinline__ void tile_epi_update(const ConvP& p, f32x4 (&acc)[FM][FN], uint4* O, int QPR, bool has_res, int b, int t0,
-                                                int n0, int wm, int wn, int lane, int len) {
+                                                int n0, int wm, int wn, int lane, int len, uint4* O2 = nullptr) {
   const int lr = lane & 15, lg = lane >> 4;
   const float e_scale = p.out_scale, e_rscale = p.res_scale, e_dinv = p.drop_inv_keep;
   const unsigned e_dth = p.drop_thresh16;
@@ -114,6 +114,25 @@ __device__ __forceinline__ void tile_epi_update(const ConvP& p, f32x4 (&acc)[FM]
       if constexpr (ACT == PTPP_ACT_GATE) {
         // fused DiffNet gate: the 8 channels are [4 "gate" | their 4 "filter" partners] (weights packed in that
         // interleaved order); y has Cout / 2 channels -- the 8-byte result takes the first half of the slot
+        if (O2) {
+          // training: the pre-activation is kept (rounded to bf16, second image) and the gate is computed FROM THE ROUNDED
+          // values with gate_fwd_kernel's expression, so a and g are bit for bit those of the conv + gate_fwd pair
+          uint4 av;
+          av.x = (uint32_t)f32_to_bf16(v[0][0]) | ((uint32_t)f32_to_bf16(v[0][1]) << 16);
+          av.y = (uint32_t)f32_to_bf16(v[0][2]) | ((uint32_t)f32_to_bf16(v[0][3]) << 16);
+          av.z = (uint32_t)f32_to_bf16(v[1][0]) | ((uint32_t)f32_to_bf16(v[1][1]) << 16);
+          av.w = (uint32_t)f32_to_bf16(v[1][2]) | ((uint32_t)f32_to_bf16(v[1][3]) << 16);
+          O2[row * QPR + (q ^ (row & 15))] = av;
+          const float sr[4] = {__uint_as_float(av.x << 16), __uint_as_float(av.x & 0xffff0000u), __uint_as_float(av.y << 16),
+                               __uint_as_float(av.y & 0xffff0000u)};
+          const float fr[4] = {__uint_as_float(av.z << 16), __uint_as_float(av.z & 0xffff0000u), __uint_as_float(av.w << 16),
+                               __uint_as_float(av.w & 0xffff0000u)};
+          uint2 o;
+          o.x = (uint32_t)f32_to_bf16(sigmoidf_(sr[0]) * tanhf(fr[0])) | ((uint32_t)f32_to_bf16(sigmoidf_(sr[1]) * tanhf(fr[1])) << 16);
+          o.y = (uint32_t)f32_to_bf16(sigmoidf_(sr[2]) * tanhf(fr[2])) | ((uint32_t)f32_to_bf16(sigmoidf_(sr[3]) * tanhf(fr[3])) << 16);
+          *reinterpret_cast<uint2*>(slot) = o;
+          continue;
+        }
         float gte[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) gte[e] = keep ? tanhf(v[1][e]) / (1.f + __expf(-v[0][e])) : 0.f;
@@ -170,9 +189,28 @@ __device__ __forceinline__ void tile_epilogue(const ConvP& p, f32x4 (&acc)[FM][F
     tile_epi_put_res<BM, BN, NT, NRV>(resv, O, tid);
     __syncthreads();
   }
-  tile_epi_update<FM, FN, ACT>(p, acc, O, QPR, has_res, b, t0, n0, wm, wn, tid & 63, len);
+  uint4* O2 = (ACT == PTPP_ACT_GATE && p.gate_save) ? O + BM * QPR : nullptr;  // second image: the kept pre-activation
+  tile_epi_update<FM, FN, ACT>(p, acc, O, QPR, has_res, b, t0, n0, wm, wn, tid & 63, len, O2);
   __syncthreads();
   tile_epi_store<BM, BN, NT, NRV>(p, O, b, t0, n0, tid, ACT == PTPP_ACT_GATE);
+  if constexpr (ACT == PTPP_ACT_GATE) {
+    if (O2) {  // slot (row, q) = channels [c0 .. c0+3 | C + c0 .. C + c0+3] of the standard layout, c0 = (n0 + 8 q) / 2
+      typedef bf16_raw T;
+      T* ab = reinterpret_cast<T*>(p.gate_save) + (int64_t)b * p.T * p.gate_lds;
+      const int Ch = p.Cout >> 1;
+#pragma unroll
+      for (int i = 0; i < NRV; ++i) {
+        const int idx = tid + i * NT;
+        const int row = idx / QPR, q = idx % QPR;
+        const int t = t0 + row, co = n0 + q * 8;
+        if (t < p.T && co < p.Cout) {
+          const uint4 v = O2[row * QPR + (q ^ (row & 15))];
+          *reinterpret_cast<uint2*>(ab + (int64_t)t * p.gate_lds + (co >> 1)) = make_uint2(v.x, v.y);
+          *reinterpret_cast<uint2*>(ab + (int64_t)t * p.gate_lds + Ch + (co >> 1)) = make_uint2(v.z, v.w);
+        }
+      }
+    }
+  }
 }
 
 // The DiffNet layer's tail fused into its 1 x 1 output projection (modules/denoiser.py:78-83; what diffnet_post_kernel

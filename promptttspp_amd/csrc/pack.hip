@@ -5,6 +5,16 @@ namespace {
 
 // mode 0: wp[co][j][c]  = w[co][c][j]          (c <  Cin, else 0), rows = Cout, inner = CinP
 // mode 1: wp[ci][j][c]  = w[c][ci][ks-1-j]     (c < Cout, else 0), rows = Cin,  inner = CoutP
+// mode 2: mode 0 with the rows of a (gate | filter) weight (Cout = 2C) in the interleaved order of the fused DiffNet gate
+//         epilogue (PTPP_ACT_GATE): packed row 8g + e (e < 4) = gate row 4g + e, packed row 8g + 4 + e = filter row C + 4g + e
+__device__ __forceinline__ int gate_row_src(int r, int cout) {  // source row of packed row r
+  const int g = r >> 3, e = r & 7;
+  return e < 4 ? 4 * g + e : (cout >> 1) + 4 * g + (e - 4);
+}
+__device__ __forceinline__ int gate_row_dst(int co, int cout) {  // packed row of source row co
+  const int C = cout >> 1;
+  return co < C ? 8 * (co >> 2) + (co & 3) : 8 * ((co - C) >> 2) + 4 + ((co - C) & 3);
+}
 template <typename T>
 __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp, int cout, int cin, int ks,
                                  int mode, int rows, int inner, int innerp) {
@@ -17,6 +27,8 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp
     if (c < inner) {
       if (mode == 0)
         v = w[((int64_t)r * cin + c) * ks + j];
+      else if (mode == 2)
+        v = w[((int64_t)gate_row_src(r, cout) * cin + c) * ks + j];
       else
         v = w[((int64_t)c * cin + r) * ks + (ks - 1 - j)];
     }
@@ -68,11 +80,11 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
     __syncthreads();
     for (int j = 0; j < ks; ++j) {
       for (int r = ty; r < 32; r += 8) {
-        if (mode == 0) {
+        if (mode != 1) {
           const int co = co0 + r, ci = ci0 + tx;
           if (co < cout && ci < cin) {
             const float v = buf[r * pitch + tx * ks + j];
-            const int64_t d = ((off + co) * ks + j) * innerp + ci;
+            const int64_t d = ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
             if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = v;
             else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(v);
           }
@@ -96,11 +108,11 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
       tile[r][tx] = (co < cout && ci < cin) ? src[((int64_t)co * cin + ci) * ks + j] : 0.f;
     }
     __syncthreads();
-    if (mode == 0) {
+    if (mode != 1) {
       for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
         if (co < cout && ci < cin) {
-          const int64_t d = ((off + co) * ks + j) * innerp + ci;
+          const int64_t d = ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
           if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = tile[r][tx];
           else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(tile[r][tx]);
         }
@@ -182,10 +194,10 @@ extern "C" int ptpp_pack_conv2d_3x3(const float* w, void* wp_fwd, void* wp_bwd, 
 extern "C" int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin, int ks, int mode, int dtype,
                                      void* stream) {
   PTPP_CHECK_ARG(w && wp, "pack_conv_weight: null pointer");
-  PTPP_CHECK_ARG(cout > 0 && cin > 0 && ks > 0 && (mode == 0 || mode == 1), "pack_conv_weight: bad args");
+  PTPP_CHECK_ARG(cout > 0 && cin > 0 && ks > 0 && (mode == 0 || mode == 1 || (mode == 2 && cout % 8 == 0)), "pack_conv_weight: bad args");
   PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "pack_conv_weight: bad dtype");
-  const int rows = mode == 0 ? cout : cin;
-  const int inner = mode == 0 ? cin : cout;
+  const int rows = mode != 1 ? cout : cin;
+  const int inner = mode != 1 ? cin : cout;
   const int innerp = ptpp_conv_cin_padded(inner, dtype);
   const int64_t n = (int64_t)rows * ks * innerp;
   const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);

@@ -50,8 +50,12 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
                "diffnet_stack_fwd: null pointer");
   ST_CHECK_ARG(a->B > 0 && a->T > 0 && a->C > 0 && a->L > 0 && a->cycle > 0 && a->n_slabs >= 2, "diffnet_stack_fwd: bad shape");
   ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "diffnet_stack_fwd: bad dtype %d", a->dtype);
-  ST_CHECK_ARG(a->fused_gate || a->a_all, "diffnet_stack_fwd: a_all is needed without the fused gate");
-  ST_CHECK_ARG(!a->fused_gate || (a->dtype == PTPP_BF16 && !a->lengths), "diffnet_stack_fwd: the fused gate is the bf16 inference path");
+  // fused_gate: 0 = conv + gate_fwd, 1 = gate in the conv's epilogue, pre-activation not kept (inference), 2 = gate in the
+  // epilogue AND the pre-activation kept in a_all (training: ptpp_conv1d_gate_fwd_save)
+  ST_CHECK_ARG(a->fused_gate == 1 || a->a_all, "diffnet_stack_fwd: a_all is needed unless the gate is fused without saving");
+  ST_CHECK_ARG(a->fused_gate != 1 || (a->dtype == PTPP_BF16 && !a->lengths), "diffnet_stack_fwd: the fused gate is the bf16 inference path");
+  ST_CHECK_ARG(a->fused_gate != 2 || ptpp_conv1d_gate_fwd_save_supported(a->C, a->C, a->dtype),
+               "diffnet_stack_fwd: the fused gate with the kept pre-activation needs bf16 and C %% 64 == 0");
   const int B = a->B, T = a->T, C = a->C, L = a->L, dt = a->dtype;
   const size_t BTC = (size_t)B * T * C;
   const int ldc = L * 2 * C;
@@ -68,7 +72,11 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
     const void* yin = at(a->yin_all, slab * BTC, dt);
     void* g = at(a->g_all, slab * BTC, dt);
     const void* cond = at(a->cond_all, (size_t)l * 2 * C, dt);
-    if (a->fused_gate) {
+    if (a->fused_gate == 2) {
+      ptpp_conv1d_args c = conv_args(yin, C, a->dil_wp[l], a->dil_b[l], cond, ldc, g, C, nullptr, B, T, C, 2 * C, 3, d, d,
+                                     PTPP_ACT_GATE, 0, 0, dt);
+      ST_TRY(ptpp_conv1d_gate_fwd_save(&c, at(a->a_all, slab * 2 * BTC, dt), 2 * C, stream));
+    } else if (a->fused_gate) {
       ptpp_conv1d_args c = conv_args(yin, C, a->dil_wp[l], a->dil_b[l], cond, ldc, g, C, nullptr, B, T, C, 2 * C, 3, d, d,
                                      PTPP_ACT_GATE, 0, 0, dt);
       ST_TRY(ptpp_conv1d_fwd(&c, stream));

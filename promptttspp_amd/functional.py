@@ -61,6 +61,15 @@ _pack_gen = [0]  # bumped whenever an entry is added to / dropped from _pack_cac
 
 
 def _pack_now(ws, dtype, mode):
+    if mode == 2 and len(ws) > 1:  # the gate interleave is per source: pack each into its rows of the common operand
+        w0 = ws[0].detach().reshape(ws[0].shape[0], ws[0].shape[1], -1)
+        rows = [t.shape[0] for t in ws]
+        wp = torch.empty((sum(rows), w0.shape[2], ops.cin_padded(w0.shape[1], dtype)), device=w0.device, dtype=dtype)
+        off = 0
+        for t, r in zip(ws, rows):
+            ops.pack_conv_weight(t.detach().reshape(r, t.shape[1], -1), dtype, 2, out=wp[off:off + r])
+            off += r
+        return wp
     w = ws[0] if len(ws) == 1 else torch.cat([t.detach().reshape(t.shape[0], -1) for t in ws], dim=0)
     return ops.pack_conv_weight(w, dtype, mode)
 
@@ -133,7 +142,7 @@ def repack_all(bumped=None):
             ks = w0.shape[2] if w0.dim() == 3 else 1
             dcode = ops.dtype_code(ent.dtype)
             total_cout = sum(w.shape[0] for w in ws)
-            innerp = ops.cin_padded(cin if ent.mode == 0 else total_cout, ent.dtype)
+            innerp = ops.cin_padded(cin if ent.mode != 1 else total_cout, ent.dtype)
             off = 0
             for w in ws:
                 assert w.dtype == torch.float32 and w.is_contiguous()
@@ -799,11 +808,37 @@ def _gate_perm(c2, device):
     return p
 
 
-def diffnet_cond_all(cond, cond_ws, cond_bs, gate_perm=False):
+FUSE_GATE_SAVE = not os.environ.get("PTPP_NO_FUSED_GATE_SAVE")  # training: gate in the dilated conv's epilogue, a kept
+
+
+def diffnet_gate_save(dtype, C, cuda):
+    """Training forward in bf16: the DiffNet gate runs in the dilated conv's epilogue and the pre-activation is kept for the
+    backward (ptpp_conv1d_gate_fwd_save) -- one launch per layer less than conv + gate_fwd, bit-identical to them."""
+    return FUSE_GATE_SAVE and cuda and dtype == torch.bfloat16 and ops.conv1d_gate_fwd_save_supported(C, C, dtype)
+
+
+def gate_biases(dil_bs, cond_bs):
+    """Dilated-conv and conditioner biases of all layers in the gate-interleaved order: ONE cat + ONE gather per step
+    (the packed weights get that order from the pack cache, mode 2).  Returns (per-layer dil biases, concatenated cond bias)."""
+    L, c2 = len(dil_bs), dil_bs[0].shape[0]
+    dev = dil_bs[0].device
+    key = ("gateb", L, c2, str(dev))
+    idx = _gate_perm_cache.get(key)
+    if idx is None:
+        perm = _gate_perm(c2, dev)
+        idx = _gate_perm_cache[key] = (torch.arange(2 * L, device=dev)[:, None] * c2 + perm[None, :]).reshape(-1)
+    allb = torch.cat([b.detach().float() for b in list(dil_bs) + list(cond_bs)], dim=0)[idx]
+    return [allb[l * c2:(l + 1) * c2] for l in range(L)], allb[L * c2:]
+
+
+def diffnet_cond_all(cond, cond_ws, cond_bs, gate_perm=False, bias_perm=None):
     """All layers' conditioner projections as ONE GEMM: (B,T,Cc) -> (B,T,L*2C).  ``gate_perm``: each
-    layer's 2C channels in the interleaved order of the fused gate epilogue (inference)."""
+    layer's 2C channels in the interleaved order of the fused gate epilogue (inference; training with ``bias_perm`` =
+    the already permuted concatenated bias of ``gate_biases``: the weights then come from the pack cache, mode 2)."""
     cond_ws, cond_bs = list(cond_ws), list(cond_bs)
     rows = sum(cw.shape[0] for cw in cond_ws)
+    if bias_perm is not None:
+        return ops.conv1d(cond, packed_cat(cond_ws, cond.dtype, mode=2), bias_perm, rows), cond_ws
     if not gate_perm:
         return ops.conv1d(cond, packed_cat(cond_ws, cond.dtype), bias_cat(cond_bs), rows), cond_ws
     perm = _gate_perm(cond_ws[0].shape[0], cond.device)
@@ -832,7 +867,7 @@ def _f32_param(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
 
 
-def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save):
+def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None):
     """The whole residual stack in ONE C call (ptpp_diffnet_stack_fwd): the same launches in the same order as the loop
     of ``diffnet_stack_forward`` below (bit-identical), without ~60 Python -> C round trips and ~80 allocations.
     Returns (skip f32, (yin_all, a_all, g_all) slabs of all layers when ``save``)."""
@@ -840,6 +875,7 @@ def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle,
     B, T, C = h0.shape
     dt, dev = h0.dtype, h0.device
     fused = (not save) and lengths is None and diffnet_fused_gate(dt)
+    gsave = save and gate_b is not None  # (cond_all is in the gate-interleaved order then)
     n_slabs = L if save else 2
     skip = torch.empty((B, T, C), device=dev, dtype=torch.float32)
     ds = dsteps.transpose(0, 1).contiguous()  # (L, B, C)
@@ -848,7 +884,10 @@ def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle,
     a_all = None if fused else torch.empty((n_slabs, B, T, 2 * C), device=dev, dtype=dt)
     xb = torch.empty((2, B, T, C), device=dev, dtype=dt)
     o_buf = None if ops.conv1d_diffnet_post_supported(C, C, dt) else torch.empty((B, T, 2 * C), device=dev, dtype=dt)
-    if fused:
+    if gsave:
+        dil_wp = [packed(dw, dt, mode=2) for dw, _, _, _ in weights]
+        dil_b = gate_b
+    elif fused:
         perm = _gate_perm(2 * C, dev)
         dil_wp = [_cat_cached([dw], ("wg1", dt), lambda dw=dw: ops.pack_conv_weight(dw.detach()[perm], dt)) for dw, _, _, _ in weights]
         dil_b = [_cat_cached([db], "bg1", lambda db=db: db.detach().float()[perm].contiguous()) for _, db, _, _ in weights]
@@ -868,15 +907,17 @@ def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle,
     a.a_all = a_all.data_ptr() if a_all is not None else None
     a.x_buf0, a.x_buf1 = xb[0].data_ptr(), xb[1].data_ptr()
     a.o_buf = o_buf.data_ptr() if o_buf is not None else None
-    a.B, a.T, a.C, a.L, a.cycle, a.n_slabs, a.fused_gate, a.dtype = B, T, C, L, cycle, n_slabs, int(fused), ops.dtype_code(dt)
+    a.B, a.T, a.C, a.L, a.cycle, a.n_slabs, a.fused_gate, a.dtype = B, T, C, L, cycle, n_slabs, 2 if gsave else int(fused), ops.dtype_code(dt)
     _lib.check(_lib.load().ptpp_diffnet_stack_fwd(ctypes.byref(a), ops._stream()), "ptpp_diffnet_stack_fwd")
     return skip, ((yin_all, a_all, g_all) if save else None)
 
 
-def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
-    """weights: per layer (dil_w, dil_b, out_w, out_b).  Returns (skip_sum f32, saved)."""
+def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None):
+    """weights: per layer (dil_w, dil_b, out_w, out_b).  Returns (skip_sum f32, saved).  ``gate_b``: the per-layer dilated-conv
+    biases in the gate-interleaved order (``gate_biases``) -- training with the gate fused into the conv and the
+    pre-activation kept; ``cond_all`` is in that order too."""
     if STACK_DRIVERS and h0.is_cuda and h0.is_contiguous() and cond_all.is_contiguous():
-        return _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save)
+        return _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b)
     L = len(weights)
     B, T, C = h0.shape
     skip = torch.empty((B, T, C), device=h0.device, dtype=torch.float32)
@@ -889,7 +930,12 @@ def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save):
     fuse_post = FUSE_DIFFNET_POST and h0.is_cuda and ops.conv1d_diffnet_post_supported(C, C, h0.dtype) and h0.is_contiguous()
     for l, (dw, db, ow, ob) in enumerate(weights):
         d = 2 ** (l % cycle)
-        if fused:
+        if save and gate_b is not None:
+            g = torch.empty((B, T, C), device=h0.device, dtype=h0.dtype)
+            a = torch.empty((B, T, 2 * C), device=h0.device, dtype=h0.dtype)
+            ops.conv1d_gate_fwd_save(yin, packed(dw, h0.dtype, mode=2), gate_b[l], C, 3, d, d,
+                                     cond_all[:, :, l * 2 * C : (l + 1) * 2 * C], g, a)
+        elif fused:
             wp = _cat_cached([dw], ("wg1", h0.dtype), lambda dw=dw: ops.pack_conv_weight(dw.detach()[perm], h0.dtype))
             bp = _cat_cached([db], "bg1", lambda db=db: db.detach().float()[perm].contiguous())
             g = torch.empty((B, T, C), device=h0.device, dtype=h0.dtype)
@@ -917,9 +963,14 @@ class DiffNetStackFn(Function):
     def forward(ctx, h0, cond, dsteps, lengths, cycle, *flat):
         L = len(flat) // 6
         ws = [flat[6 * l : 6 * l + 6] for l in range(L)]  # dil_w, dil_b, cond_w, cond_b, out_w, out_b
-        cond_all, wc = diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws])
+        gate_b = None
+        if diffnet_gate_save(h0.dtype, h0.shape[2], h0.is_cuda) and h0.is_contiguous():
+            gate_b, cond_b = gate_biases([w[1] for w in ws], [w[3] for w in ws])
+            cond_all, wc = diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws], bias_perm=cond_b)
+        else:
+            cond_all, wc = diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws])
         skip, saved = diffnet_stack_forward(h0, cond_all, dsteps, [(w[0], w[1], w[4], w[5]) for w in ws], lengths,
-                                            cycle, save=True)
+                                            cycle, save=True, gate_b=gate_b)
         ctx.L, ctx.cycle, ctx.lengths, ctx.saved, ctx.ws, ctx.wc = L, cycle, lengths, saved, ws, wc
         ctx.direct = all(_sink(t) is not None for t in flat)
         if ctx.direct:

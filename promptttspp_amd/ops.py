@@ -144,18 +144,20 @@ def cin_padded(cin, dtype):
     return _lib.load().ptpp_conv_cin_padded(int(cin), dtype_code(dtype))
 
 
-def pack_conv_weight(w, dtype, mode=0):
+def pack_conv_weight(w, dtype, mode=0, out=None):
     """``w``: (Cout, Cin, ks) f32 (nn.Conv1d layout; nn.Linear weights are
     viewed as ks=1).  Returns the packed K-contiguous operand in ``dtype``:
     mode 0 -> (Cout, ks, CinP) forward operand, mode 1 -> (Cin, ks, CoutP)
-    data-gradient operand (taps flipped)."""
+    data-gradient operand (taps flipped), mode 2 -> mode 0 with the rows of a (gate | filter) weight in the
+    interleaved order of the fused DiffNet gate epilogue.  ``out``: a (rows, ks, innerP) slice to fill."""
     _need_gpu(w)
     if w.dim() == 2:
         w = w.unsqueeze(-1)
     w = w.detach().contiguous().float()
     cout, cin, ks = w.shape
-    rows, inner = (cout, cin) if mode == 0 else (cin, cout)
-    wp = torch.empty((rows, ks, cin_padded(inner, dtype)), device=w.device, dtype=dtype)
+    rows, inner = (cout, cin) if mode != 1 else (cin, cout)
+    wp = out if out is not None else torch.empty((rows, ks, cin_padded(inner, dtype)), device=w.device, dtype=dtype)
+    assert wp.is_contiguous() and wp.shape == (rows, ks, cin_padded(inner, dtype)) and wp.dtype == dtype
     check(
         _lib.load().ptpp_pack_conv_weight(_ptr(w), _ptr(wp), cout, cin, ks, mode, dtype_code(dtype), _stream()),
         "ptpp_pack_conv_weight",
@@ -558,6 +560,29 @@ def conv1d_diffnet_post(g, wp, bias, x, skip, dnext, init, lengths=None, out_mas
                                                yin.data_ptr() if yin is not None else None, 1 if init else 0, _stream()),
           "ptpp_conv1d_diffnet_post")
     return xn, yin
+
+
+_gsave_ok = {}
+
+
+def conv1d_gate_fwd_save_supported(C, cin, dtype):
+    key = (C, cin, dtype)
+    ok = _gsave_ok.get(key)
+    if ok is None:
+        ok = _gsave_ok[key] = bool(_lib.load().ptpp_conv1d_gate_fwd_save_supported(int(C), int(cin), dtype_code(dtype)))
+    return ok
+
+
+def conv1d_gate_fwd_save(x, wp, bias, C, ks, dil, pad, res, g, a):
+    """DiffNet dilated conv (+ ``res`` = conditioner slice) with the gate in its epilogue and the pre-activation kept
+    (ptpp_conv1d_gate_fwd_save): weights / bias / res in the gate-interleaved row order (pack mode 2); writes ``g`` (B,T,C)
+    and ``a`` (B,T,2C, standard order).  Bit-identical to ``conv1d`` followed by ``gate_fwd``."""
+    B, T, cin = x.shape
+    assert g.is_contiguous() and a.is_contiguous() and a.shape == (B, T, 2 * C) and x.dtype == torch.bfloat16
+    _CONV_FMT.pack_into(_conv_buf, 0, x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                        res.data_ptr() if res is not None else 0, g.data_ptr(), 0, B, T, cin, 2 * C, ks, dil, pad, _ld_fast(x), C,
+                        _ld_fast(res) if res is not None else 0, _ACT["gate"], 0, 0, 1.0, BF16)
+    check(_lib.load().ptpp_conv1d_gate_fwd_save(_conv_args_ref, a.data_ptr(), 2 * C, _stream()), "ptpp_conv1d_gate_fwd_save")
 
 
 _gbwd_ok = {}

@@ -567,3 +567,37 @@ def test_grouped_weight_gradients_match_the_per_layer_launches():
             s = float((dw1 - 0).abs().max())
             assert float((dw - dw1).abs().max()) <= 2e-5 * s + 1e-6, (dw.shape, float((dw - dw1).abs().max()), s)
             assert float((db - db1).abs().max()) <= 2e-5 * float(db1.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("B,T,masked", [(3, 200, True), (19, 1100, False)])
+def test_fused_gate_with_kept_pre_activation_is_bit_identical(B, T, masked, monkeypatch):
+    """Training forward in bf16: the DiffNet gate in the dilated conv's epilogue with the pre-activation kept
+    (ptpp_conv1d_gate_fwd_save; weights from the pack cache in the gate-interleaved order, mode 2; biases and conditioner
+    slice in the same order) against conv + gate_fwd: stack output and every gradient equal bit for bit, on both the driver
+    and the per-launch path; the mode-2 operand of the pack cache equals the permuted pack, also after a batched repack."""
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd import ops
+
+    dev = torch.device("cuda:0")
+    C, L = 256, 4
+    h0, cond, dsteps, lengths, params = _stack_case(dev, B, T, C, L, torch.bfloat16, masked, seed=5)
+    gout = (rnd(9, B, T, C) * 0.1).to(dev).bfloat16()
+    outs = {}
+    for drivers in (True, False):
+        for fused in (True, False):
+            monkeypatch.setattr(PF, "STACK_DRIVERS", drivers)
+            monkeypatch.setattr(PF, "FUSE_GATE_SAVE", fused)
+            outs[(drivers, fused)] = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    ref = outs[(True, False)]
+    for key, got in outs.items():
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b), (key, i, float((a.float() - b.float()).abs().max()))
+    # the pack cache's mode-2 operand
+    w = params[0][0]
+    perm = PF._gate_perm(2 * C, dev)
+    want = ops.pack_conv_weight(w.detach()[perm], torch.bfloat16)
+    assert torch.equal(PF.packed(w, torch.bfloat16, mode=2), want)
+    with torch.no_grad():
+        w.mul_(1.5)
+    PF.repack_all()
+    assert torch.equal(PF.packed(w, torch.bfloat16, mode=2), ops.pack_conv_weight(w.detach()[perm], torch.bfloat16))
