@@ -45,7 +45,7 @@ def _branch_stream(dev, idx=0):
     it every new batch shape grows the pool by hipMalloc inside the step -- what made round 1's multi-stream forward slower)."""
     st = _branch.get((dev, idx))
     if st is None:
-        st = _branch[(dev, idx)] = torch.cuda.Stream(device=dev)
+        st = _branch[(dev, idx)] = ops.aux_stream(dev, idx)
         gib = float(os.environ.get("PTPP_BRANCH_RESERVE_GIB", "2" if idx == 0 else "6"))
         with torch.cuda.stream(st):
             slab = torch.empty(int(gib * (1 << 30)), device=dev, dtype=torch.uint8)

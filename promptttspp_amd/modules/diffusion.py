@@ -257,14 +257,11 @@ class GaussianDiffusion(nn.Module):
         shape = (B, T, self.out_dim)
         K = self.K_step
         draw = noise_fn if noise_fn is not None else (lambda i, s: torch.randn(s, device=dev))
-        ways = max(2, min(int(self.split_ways), B))
+        main = torch.cuda.current_stream(dev)
+        ways = max(2, min(int(self.split_ways), B, 3))  # main + the package's two auxiliary streams (ops.aux_stream)
         edges = [B * k // ways for k in range(ways + 1)]
         cuts = list(zip(edges[:-1], edges[1:]))
-        main = torch.cuda.current_stream(dev)
-        extra = getattr(self, "_split_streams", None)
-        if extra is None or len(extra) < ways - 1 or extra[0].device != dev:
-            extra = self._split_streams = [torch.cuda.Stream(device=dev) for _ in range(ways - 1)]
-        streams = [main] + extra[: ways - 1]
+        streams = [main] + [ops.aux_stream(dev, k) for k in range(ways - 1)]
         x0 = draw(-1, shape)
         n0 = draw(K - 1, shape)
         st = []

@@ -249,6 +249,23 @@ def workspace(device):
     return w
 
 
+# Two auxiliary streams per device, shared by every part of the package that runs something beside the main stream (training
+# branches, BigVGAN's parallel resblocks, the sampler's second half-batch): HIP multiplexes streams onto a few hardware queues
+# in creation order, and with one private stream per user a process that had trained / run the vocoder before sampling put the
+# sampler's second stream on the main stream's queue (sampler 137 -> 187 ms inside bench.py's full run).  main + weight-gradient
+# side stream + these two = four streams in all.
+_aux_streams = {}
+
+
+def aux_stream(device, i):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, int(i) % 2)
+    st = _aux_streams.get(key)
+    if st is None:
+        st = _aux_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def workspace_of(device, stream_handle):
     """The scratch of ``workspace`` that belongs to the raw stream ``stream_handle`` (a ctypes.c_void_p)."""
     idx = device.index

@@ -254,7 +254,7 @@ class BigVGAN(nn.Module):
         (x_k + conv2(...)) / 3 are summed by one kernel."""
         main = torch.cuda.current_stream()
         if self._streams is None:
-            self._streams = [torch.cuda.Stream(device=h.device) for _ in range(2)]
+            self._streams = [ops.aux_stream(h.device, k) for k in range(2)]
         outs = []
         # fork FIRST: a wait recorded after block 0 had been enqueued on the main stream made the two side
         # streams start only when block 0 was done (timeline: 0 ms of the main stream's work overlapped theirs)
