@@ -454,8 +454,8 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
   const int split = SK ? ball / p.B : 0;
   const int t0 = mt * BM, n0 = nt * BN;
 
-  const int len = p.lengths ? min(p.lengths[b], p.T) : p.T;
-  const int Tin = p.in_mask ? len : p.T;
+  const int len_raw = p.lengths ? p.lengths[b] : p.T;  // requested here, consumed after the first weight stage is on its way
+  int len = p.T, Tin = p.T;
   const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.T * p.ldx;
 
   f32x4 acc[FM][FN];
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nC = p.cinp >> 6;
-  int sbeg = 0, steps = (p.out_mask && t0 >= len) ? 0 : nC * p.ks;  // the block's K steps are [sbeg, steps)
+  int sbeg = 0, steps = nC * p.ks;  // the block's K steps are [sbeg, steps); a fully masked tile gets none (below)
   if constexpr (SK) {  // whole chunks per split, so a split starts at tap 0 of a chunk
     sbeg = (int)((int64_t)split * nC / p.nsplit) * p.ks;
     steps = (int)((int64_t)(split + 1) * nC / p.nsplit) * p.ks;
@@ -546,10 +546,18 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
                                                              : make_uint4(0, 0, 0, 0);
     }
   }
+  // The first weight stage does not depend on the utterance length: it leaves before the scalar load of lengths[b] is waited
+  // for (that wait used to sit in front of every load of the block).
+  const bool any = steps > sbeg;
+  if (any) issue_w(sbeg, 0);
+  len = min(len_raw, p.T);
+  Tin = p.in_mask ? len : p.T;
+  if (!SK && p.out_mask && t0 >= len) steps = sbeg;  // all rows masked out: no K loop (the stage in flight is drained)
   if (steps > sbeg) {
     issue_x(sbeg / p.ks, (sbeg / p.ks) & 1);
-    issue_w(sbeg, 0);
     if (D > 2 && steps > sbeg + 1) issue_w(sbeg + 1, 1);
+  } else if (any) {
+    glds_wait<0>();
   }
   int stage = 0;
   for (int s = sbeg; s < steps; ++s) {
