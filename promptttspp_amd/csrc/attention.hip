@@ -521,6 +521,138 @@ __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
   }
 }
 
+// The same for the tables without the legacy shift, FOUR consecutive query rows per wave that share every K / V / pos row
+// they read: with one row per wave each of the B H T rows streams all of K, V and the positional table of its (b, h) through
+// the caches (150 KB per row, 1.2 GB per launch at phone level: the kernel ran at the L2's pace, 125 us).  Row r of the wave
+// reads pos[T-1-(i0+r)+j] for key j, i.e. the rows of a wave walk the SAME table rows one key apart: the loop runs over the
+// table index m and hands pos[m] to every row whose key m - (T-1-i0-r) exists.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_row4_kernel(const AttnBwdP p) {
+  constexpr int R = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int Tn = p.T, dk = p.dk;
+  const int Tpad = (Tn + 3) & ~3;
+  const int per = R * (dk + Tpad);
+  float* go = lds + w * per;       // [R][dk]   dctx rows
+  float* ds = go + R * dk;         // [R][Tpad] dS rows
+  float* red = lds + 4 * per;      // [4 waves][2][dk] partial du / dvb of the block
+  const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
+  const int hc = h * dk;
+  const int i0 = (blockIdx.x * 4 + w) * R;
+  const T* kb = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + hc;
+  const T* vb = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + hc;
+  const T* pb = p.pos ? reinterpret_cast<const T*>(p.pos) + hc : nullptr;
+  const int nvec = dk >> 2, parts = 64 / nvec;
+  const int dv = (lane % nvec) * 4, part = lane / nvec;
+  f32x4 su = f32x4{0.f, 0.f, 0.f, 0.f}, sv = su;
+  if (i0 < Tn) {
+    // rows i0 + r < len are live; rows in [len, T) only get their zeros
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = i0 + r;
+      const bool live = i < len;
+      const T* gb = reinterpret_cast<const T*>(p.dctx) + ((int64_t)b * Tn + min(i, Tn - 1)) * p.lddctx + hc;
+      for (int d = lane * 4; d < dk; d += 256)
+        *reinterpret_cast<f32x4*>(go + r * dk + d) = live ? Elem<T>::ld4(gb + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int64_t prow0 = (((int64_t)b * p.H + h) * Tn + i0) * Tn;  // P / dS row i0 of (b, h); row r follows at + r T
+    float dsum[R] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = lane; j < (i0 < len ? len : 0); j += 64) {
+      const T* vrow = vb + (int64_t)j * p.ld;
+      float acc[R] = {0.f, 0.f, 0.f, 0.f};
+      for (int d = 0; d < dk; d += 4) {
+        const f32x4 vv = Elem<T>::ld4(vrow + d);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(go + r * dk + d);
+          acc[r] += g[0] * vv[0] + g[1] * vv[1] + g[2] * vv[2] + g[3] * vv[3];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float dp = acc[r];
+        if (i0 + r < len) {
+          if (p.drop_thresh16) dp *= attn_keep(p, (uint64_t)(prow0 + (int64_t)r * Tn) + j);
+          dsum[r] += p.probs[prow0 + (int64_t)r * Tn + j] * dp;
+        }
+        ds[r * Tpad + j] = dp;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) dsum[r] = wave_sum(dsum[r]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = i0 + r;
+      if (i >= Tn) break;
+      const bool live = i < len;
+      float* dsrow = p.dS + prow0 + (int64_t)r * Tn;
+      for (int j = lane; j < Tn; j += 64) {
+        const float v = (live && j < len) ? p.probs[prow0 + (int64_t)r * Tn + j] * (ds[r * Tpad + j] - dsum[r]) * p.scale : 0.f;
+        ds[r * Tpad + j] = v;
+        dsrow[j] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    f32x4 au[R], av[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { au[r] = f32x4{0.f, 0.f, 0.f, 0.f}; av[r] = au[r]; }
+    if (part < parts && i0 < len) {
+      for (int j = part; j < len; j += parts) {
+        const f32x4 kv = Elem<T>::ld4(kb + (int64_t)j * p.ld + dv);
+#pragma unroll
+        for (int r = 0; r < R; ++r) au[r] += kv * ds[r * Tpad + j];
+      }
+      if (p.variant == VAR_NEW) {
+        const int mlo = Tn - 1 - i0 - (R - 1), mhi = Tn - 1 - i0 + len - 1;  // table rows any of the R rows reads
+        for (int m = max(mlo, 0) + part; m <= mhi; m += parts) {
+          const f32x4 pv = Elem<T>::ld4(pb + (int64_t)m * p.ldpos + dv);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int j = m - (Tn - 1 - i0 - r);
+            if (j >= 0 && j < len) av[r] += pv * ds[r * Tpad + j];
+          }
+        }
+      }
+    }
+    for (int o = nvec; o < 64; o <<= 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          au[r][e] += __shfl_xor(au[r][e], o, 64);
+          av[r][e] += __shfl_xor(av[r][e], o, 64);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = i0 + r;
+      if (i >= Tn) break;
+      T* dqr = reinterpret_cast<T*>(p.dq) + ((int64_t)b * Tn + i) * p.lddq + hc;
+      if (lane < nvec) Elem<T>::st4(dqr + dv, au[r] + av[r]);
+      su += au[r];
+      sv += av[r];
+    }
+  }
+  if (p.variant != VAR_PLAIN) {
+    if (lane < nvec) {
+      *reinterpret_cast<f32x4*>(red + (w * 2 + 0) * dk + dv) = su;
+      *reinterpret_cast<f32x4*>(red + (w * 2 + 1) * dk + dv) = sv;
+    }
+    __syncthreads();
+    float* rep = p.scratch + (size_t)((blockIdx.x + gridDim.x * blockIdx.z) % PTPP_RED_NREP) * (2 * p.H * dk);
+    for (int c = threadIdx.x; c < 2 * dk; c += 256) {
+      const float v = red[c] + red[2 * dk + c] + red[4 * dk + c] + red[6 * dk + c];
+      atomicAdd(rep + (c < dk ? hc + c : p.H * dk + hc + (c - dk)), v);  // [du (H*dk) | dvb (H*dk)]
+    }
+  }
+}
+
 // ---- backward, kernel 2: per key row -> dK, dV --------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_col_kernel(const AttnBwdP p, void* dk_out, void* dv_out) {
@@ -684,8 +816,19 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
   int nbg = (1024 + lblk - 1) / lblk;
   if (nbg > B) nbg = B;
   if (variant != VAR_PLAIN && nbg > 1) (void)hipMemsetAsync(dpos, 0, (size_t)L * H * dk * sizeof(float), st);
+  // (PTPP_ATTN_BWD_ROW4=0: one query row per wave for every table)
+  static const char* row4_env = getenv("PTPP_ATTN_BWD_ROW4");
+  const bool row4 = variant != VAR_LEGACY && !(row4_env && row4_env[0] == '0');
+  const dim3 grid_row4((T_ + 15) / 16, H, B);
+  const size_t smem4 = (size_t)(4 * 4 * (dk + Tpad) + 8 * dk) * sizeof(float);
 #define ATTN_BWD(TT)                                                                                  \
-  hipLaunchKernelGGL(attn_bwd_row_kernel<TT>, grid_row, dim3(256), smem, st, p);                      \
+  if (row4) {                                                                                         \
+    if (smem4 > 64 * 1024)                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_row4_kernel<TT>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);              \
+    hipLaunchKernelGGL(attn_bwd_row4_kernel<TT>, grid_row4, dim3(256), smem4, st, p);                 \
+  } else                                                                                              \
+    hipLaunchKernelGGL(attn_bwd_row_kernel<TT>, grid_row, dim3(256), smem, st, p);                    \
   hipLaunchKernelGGL(attn_bwd_col_kernel<TT>, grid, dim3(256), 0, st, p, dk_out, dv_out);             \
   if (variant != VAR_PLAIN)                                                                           \
     hipLaunchKernelGGL(attn_bwd_pos_kernel<TT>, dim3((L + 3) / 4, H, nbg), dim3(256), 0, st, p, dpos);
