@@ -203,14 +203,29 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
 
     orig_gbwd = ops.conv1d_gate_bwd
 
-    def timed_gbwd(do, wpt, a, da):
+    def timed_gbwd(do, wpt, a, da, lengths=None):
         # the output projection's data gradient with the fused gate backward: 2C -> C channels; bytes: do and a in, da out
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = orig_gbwd(do, wpt, a, da)
+        r = orig_gbwd(do, wpt, a, da, lengths=lengths)
         e1.record()
         rows, c2 = do.shape[0] * do.shape[1], do.shape[2]
-        recs.append((e0, e1, 2.0 * rows * c2 * (c2 // 2), rows * 3 * c2 * 2 + c2 * (c2 // 2) * 2))
+        valid = float(lengths.sum()) if lengths is not None else rows
+        recs.append((e0, e1, 2.0 * valid * c2 * (c2 // 2), rows * 3 * c2 * 2 + c2 * (c2 // 2) * 2))
+        return r
+
+    orig_gsave = ops.conv1d_gate_fwd_save
+
+    def timed_gsave(x, wp, bias, C, ks, dil, pad, res, g, a, lengths=None):
+        # the dilated conv with the gate in its epilogue and the pre-activation kept: C -> 2C channels; bytes: x and the
+        # conditioner slice in, a (2C) and g (C) out
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_gsave(x, wp, bias, C, ks, dil, pad, res, g, a, lengths=lengths)
+        e1.record()
+        rows = x.shape[0] * x.shape[1]
+        valid = float(lengths.sum()) if lengths is not None else rows
+        recs.append((e0, e1, 2.0 * valid * x.shape[2] * 2 * C * ks, rows * (x.shape[2] + 2 * C + 2 * C + C) * 2 + 2 * C * x.shape[2] * ks * 2))
         return r
 
     from promptttspp_amd import functional as PF
@@ -218,6 +233,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
     ops.conv1d = timed
     ops.conv1d_diffnet_post = timed_post
     ops.conv1d_gate_bwd = timed_gbwd
+    ops.conv1d_gate_fwd_save = timed_gsave
     # the timed steps issue whole stacks through the C-side drivers (one call per DiffNet stack / predictor stack); the
     # instrumented step takes the per-launch path -- the same kernels with the same arguments in the same order (bit-identical,
     # tests/test_stack_drivers.py) -- so that every launch can be bracketed by its own pair of events
@@ -234,6 +250,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         ops.conv1d = orig
         ops.conv1d_diffnet_post = orig_post
         ops.conv1d_gate_bwd = orig_gbwd
+        ops.conv1d_gate_fwd_save = orig_gsave
     # the dominant kernel = the LDS-DMA conv kernel these launches take (csrc/conv1d_glds.h; rocprof:
     # conv1d_glds_kernel<2, 4, 2, 2, 2>, 64 x 128 tiles, and <4, 4, 2, 2, 2>, 128 x 128 tiles, for the few launches
     # with >= 1536 tiles; profiles/r03_train_step.md is the rocprofv3 summary of the training leg of this command);

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NW * 64) void conv1d_cl_kernel(const ConvP p) {
 
   const int nC = p.cinp / BKE;
   // a tile whose rows are all masked out contributes nothing: skip the K loop
-  int sbeg = 0, steps = (p.out_mask && t0 >= len) ? 0 : nC * p.ks;
+  int sbeg = 0, steps = ((p.out_mask && t0 >= len) || (p.in_mask && t0 - p.pad >= len)) ? 0 : nC * p.ks;
   if constexpr (SK) {  // whole chunks per split, so a split starts at tap 0 of a chunk
     sbeg = (int)((int64_t)split * nC / p.nsplit) * p.ks;
     steps = (int)((int64_t)(split + 1) * nC / p.nsplit) * p.ks;
@@ -539,14 +539,14 @@ extern "C" int ptpp_conv1d_gate_bwd(const ptpp_conv1d_args* a, const void* act, 
                  "conv1d_gate_bwd: needs bf16, a 1 x 1 projection, C %% 8 == 0, Cin %% 64 == 0 (C=%d Cin=%d)", C, a->Cin);
   PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->ldx % 8 == 0 && ldda % 8 == 0 && ldda >= 2 * C && ((uintptr_t)a->x % 16) == 0 &&
                      ((uintptr_t)a->wp % 16) == 0 && ((uintptr_t)act % 16) == 0 && ((uintptr_t)da % 16) == 0 && !a->bias &&
-                     !a->in_mask && !a->out_mask,
-                 "conv1d_gate_bwd: operands must be 16-byte aligned, no bias / masks");
+                     !a->out_mask && (!a->in_mask || a->lengths),
+                 "conv1d_gate_bwd: operands must be 16-byte aligned, no bias / output mask; an input mask needs lengths");
   ConvP p;
-  p.x = a->x; p.wp = a->wp; p.bias = nullptr; p.res = nullptr; p.res2 = nullptr; p.y = da; p.lengths = nullptr;
+  p.x = a->x; p.wp = a->wp; p.bias = nullptr; p.res = nullptr; p.res2 = nullptr; p.y = da; p.lengths = a->in_mask ? a->lengths : nullptr;
   p.B = a->B; p.T = a->T; p.Cin = a->Cin; p.Cout = C; p.ks = 1; p.dil = 1; p.pad = 0;
   p.ldx = a->ldx; p.ldy = ldda; p.ldr = 0; p.ldr2 = 0;
   p.cinp = a->Cin;
-  p.act = PTPP_ACT_NONE; p.in_mask = 0; p.out_mask = 0;
+  p.act = PTPP_ACT_NONE; p.in_mask = a->in_mask; p.out_mask = 0;
   p.out_scale = a->out_scale; p.res_scale = 1.f;
   p.drop_thresh16 = 0; p.drop_inv_keep = 1.f; p.drop_seed = 0;
   p.ws = nullptr; p.nsplit = 1;

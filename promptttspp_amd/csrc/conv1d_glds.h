@@ -552,7 +552,10 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
   if (any) issue_w(sbeg, 0);
   len = min(len_raw, p.T);
   Tin = p.in_mask ? len : p.T;
-  if (!SK && p.out_mask && t0 >= len) steps = sbeg;  // all rows masked out: no K loop (the stage in flight is drained)
+  // No K loop for a tile whose output rows are all masked out, or whose whole input window lies past the utterance's end
+  // with a masked input (every operand row is zero: the accumulators stay exactly zero) -- token-bucket batches are padded
+  // to their longest utterance, a third of the row tiles of a frame-level launch.  (The stage in flight is drained.)
+  if (!SK && ((p.out_mask && t0 >= len) || (p.in_mask && t0 - p.pad >= len))) steps = sbeg;
   if (steps > sbeg) {
     issue_x(sbeg / p.ks, (sbeg / p.ks) & 1);
     if (D > 2 && steps > sbeg + 1) issue_w(sbeg + 1, 1);

@@ -72,9 +72,11 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
     const void* yin = at(a->yin_all, slab * BTC, dt);
     void* g = at(a->g_all, slab * BTC, dt);
     const void* cond = at(a->cond_all, (size_t)l * 2 * C, dt);
+    // (training, ragged batch: the dilated conv's output past an utterance's end only meets the masked output projection, so
+    //  it is masked too -- a tile past the end then skips its K loop; a third of the row tiles of a token-bucket batch)
     if (a->fused_gate == 2) {
-      ptpp_conv1d_args c = conv_args(yin, C, a->dil_wp[l], a->dil_b[l], cond, ldc, g, C, nullptr, B, T, C, 2 * C, 3, d, d,
-                                     PTPP_ACT_GATE, 0, 0, dt);
+      ptpp_conv1d_args c = conv_args(yin, C, a->dil_wp[l], a->dil_b[l], cond, ldc, g, C, a->lengths, B, T, C, 2 * C, 3, d, d,
+                                     PTPP_ACT_GATE, 0, masked, dt);
       ST_TRY(ptpp_conv1d_gate_fwd_save(&c, at(a->a_all, slab * 2 * BTC, dt), 2 * C, stream));
     } else if (a->fused_gate) {
       ptpp_conv1d_args c = conv_args(yin, C, a->dil_wp[l], a->dil_b[l], cond, ldc, g, C, nullptr, B, T, C, 2 * C, 3, d, d,
@@ -82,8 +84,8 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
       ST_TRY(ptpp_conv1d_fwd(&c, stream));
     } else {
       void* act = at(a->a_all, slab * 2 * BTC, dt);
-      ptpp_conv1d_args c = conv_args(yin, C, a->dil_wp[l], a->dil_b[l], cond, ldc, act, 2 * C, nullptr, B, T, C, 2 * C, 3, d, d,
-                                     PTPP_ACT_NONE, 0, 0, dt);
+      ptpp_conv1d_args c = conv_args(yin, C, a->dil_wp[l], a->dil_b[l], cond, ldc, act, 2 * C, a->lengths, B, T, C, 2 * C, 3, d, d,
+                                     PTPP_ACT_NONE, 0, masked, dt);
       ST_TRY(ptpp_conv1d_fwd(&c, stream));
       ST_TRY(ptpp_gate_fwd(act, g, (int64_t)B * T, C, dt, stream));
     }
@@ -120,6 +122,7 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
   void* ws_w = a->side_stream ? a->ws_side : a->ws_main;
   const size_t ws_w_bytes = a->side_stream ? a->ws_side_bytes : a->ws_main_bytes;
   const float r2 = (float)(1.0 / sqrt(2.0));
+  const int bmask = a->lengths != nullptr;  // ragged batch: the gradients past an utterance's end are zero
 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (hipMemsetAsync(at(a->gx_all, (size_t)L * BTC, dt), 0, BTC * esize(dt), st) != hipSuccess) {
@@ -141,12 +144,13 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
                                wstream));
     }
     if (fuse_gbwd) {
-      ptpp_conv1d_args c = conv_args(dout, 2 * C, a->out_wpt[l], nullptr, nullptr, 0, nullptr, 0, nullptr, B, T, 2 * C, C, 1, 1, 0,
-                                     PTPP_ACT_NONE, 0, 0, dt);
+      // (do / da are zero past an utterance's end: the input mask changes nothing but lets those row tiles skip their K loops)
+      ptpp_conv1d_args c = conv_args(dout, 2 * C, a->out_wpt[l], nullptr, nullptr, 0, nullptr, 0, a->lengths, B, T, 2 * C, C, 1, 1, 0,
+                                     PTPP_ACT_NONE, bmask, 0, dt);
       ST_TRY(ptpp_conv1d_gate_bwd(&c, act, da, ldc, stream));
     } else {
-      ptpp_conv1d_args c = conv_args(dout, 2 * C, a->out_wpt[l], nullptr, nullptr, 0, a->dg_buf, C, nullptr, B, T, 2 * C, C, 1, 1, 0,
-                                     PTPP_ACT_NONE, 0, 0, dt);
+      ptpp_conv1d_args c = conv_args(dout, 2 * C, a->out_wpt[l], nullptr, nullptr, 0, a->dg_buf, C, a->lengths, B, T, 2 * C, C, 1, 1, 0,
+                                     PTPP_ACT_NONE, bmask, 0, dt);
       ST_TRY(ptpp_conv1d_fwd(&c, stream));
       ST_TRY(ptpp_gate_bwd(act, a->dg_buf, da, (int64_t)B * T, C, ldc, dt, stream));
     }
@@ -155,8 +159,8 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
       ST_TRY(ptpp_conv1d_wgrad(yin, da, a->dw_dil[l], a->db_dil[l], nullptr, B, T, C, 2 * C, 3, d, d, C, ldc, 0, dt, ws_w, ws_w_bytes,
                                wstream));
     }
-    ptpp_conv1d_args c = conv_args(da, ldc, a->dil_wpt[l], nullptr, gx, C, at(a->gx_all, (size_t)l * BTC, dt), C, nullptr, B, T, 2 * C, C,
-                                   3, d, d, PTPP_ACT_NONE, 0, 0, dt);
+    ptpp_conv1d_args c = conv_args(da, ldc, a->dil_wpt[l], nullptr, gx, C, at(a->gx_all, (size_t)l * BTC, dt), C, a->lengths, B, T, 2 * C, C,
+                                   3, d, d, PTPP_ACT_NONE, bmask, 0, dt);
     ST_TRY(ptpp_conv1d_fwd_ex(&c, nullptr, 0, r2, 0.f, 0, stream));
   }
   if (a->batched_wgrad) {

@@ -934,7 +934,7 @@ def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save, g
             g = torch.empty((B, T, C), device=h0.device, dtype=h0.dtype)
             a = torch.empty((B, T, 2 * C), device=h0.device, dtype=h0.dtype)
             ops.conv1d_gate_fwd_save(yin, packed(dw, h0.dtype, mode=2), gate_b[l], C, 3, d, d,
-                                     cond_all[:, :, l * 2 * C : (l + 1) * 2 * C], g, a)
+                                     cond_all[:, :, l * 2 * C : (l + 1) * 2 * C], g, a, lengths=lengths)
         elif fused:
             wp = _cat_cached([dw], ("wg1", h0.dtype), lambda dw=dw: ops.pack_conv_weight(dw.detach()[perm], h0.dtype))
             bp = _cat_cached([db], "bg1", lambda db=db: db.detach().float()[perm].contiguous())
@@ -943,8 +943,10 @@ def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save, g
                        out=g)
             a = None
         else:
+            # (ragged batch: output past an utterance's end only meets the masked output projection -- masked here too, so
+            #  that the row tiles past the end skip their K loops)
             a = ops.conv1d(yin, packed(dw, h0.dtype), _f32c(db), 2 * C, ks=3, dil=d, pad=d,
-                           res=cond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
+                           res=cond_all[:, :, l * 2 * C : (l + 1) * 2 * C], lengths=lengths, out_mask=lengths is not None)
             g = ops.gate_fwd(a)
         if save:
             saved.append((yin, a, g))
@@ -1010,13 +1012,16 @@ class DiffNetStackFn(Function):
             with wgrad_stream(*((g, do) if ctx.direct else ())):
                 dwo, dbo = ops.conv1d_wgrad(g, do, C, 2 * C, 1, 1, 0, dw_out=tg[4], db_out=tg[5])
             if fuse_gbwd:  # the projection's data gradient with the gate backward in its epilogue (dg is never stored)
-                da = ops.conv1d_gate_bwd(do, packed(out_w, dt, mode=1), a, dcond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
+                da = ops.conv1d_gate_bwd(do, packed(out_w, dt, mode=1), a, dcond_all[:, :, l * 2 * C : (l + 1) * 2 * C],
+                                         lengths=ctx.lengths)
             else:
-                dg = ops.conv1d(do, packed(out_w, dt, mode=1), None, C)
+                dg = ops.conv1d(do, packed(out_w, dt, mode=1), None, C, lengths=ctx.lengths, in_mask=ctx.lengths is not None)
                 da = ops.gate_bwd(a, dg, dcond_all[:, :, l * 2 * C : (l + 1) * 2 * C])
             with wgrad_stream(*((yin, da) if ctx.direct else ())):
                 dwd, dbd = ops.conv1d_wgrad(yin, da, C, 2 * C, 3, d, d, dw_out=tg[0], db_out=tg[1])
-            gx = ops.conv1d(da, packed(dil_w, dt, mode=1), None, C, ks=3, dil=d, pad=d, res=gx, res_scale=r2, out=gx_all[l])
+            # (do / da are zero past an utterance's end: the input mask is exact and lets those row tiles skip their K loops)
+            gx = ops.conv1d(da, packed(dil_w, dt, mode=1), None, C, ks=3, dil=d, pad=d, res=gx, res_scale=r2, out=gx_all[l],
+                            lengths=ctx.lengths, in_mask=ctx.lengths is not None)
             if ctx.direct:
                 for i in (0, 1, 4, 5):
                     _done(ws[l][i])

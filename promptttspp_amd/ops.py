@@ -590,15 +590,18 @@ def conv1d_gate_fwd_save_supported(C, cin, dtype):
     return ok
 
 
-def conv1d_gate_fwd_save(x, wp, bias, C, ks, dil, pad, res, g, a):
+def conv1d_gate_fwd_save(x, wp, bias, C, ks, dil, pad, res, g, a, lengths=None):
     """DiffNet dilated conv (+ ``res`` = conditioner slice) with the gate in its epilogue and the pre-activation kept
     (ptpp_conv1d_gate_fwd_save): weights / bias / res in the gate-interleaved row order (pack mode 2); writes ``g`` (B,T,C)
     and ``a`` (B,T,2C, standard order).  Bit-identical to ``conv1d`` followed by ``gate_fwd``."""
     B, T, cin = x.shape
     assert g.is_contiguous() and a.is_contiguous() and a.shape == (B, T, 2 * C) and x.dtype == torch.bfloat16
+    if lengths is not None:  # ragged batch: output rows past an utterance's end are zero (their row tiles skip the K loop)
+        lengths = i32(lengths, x.device)
     _CONV_FMT.pack_into(_conv_buf, 0, x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else 0,
-                        res.data_ptr() if res is not None else 0, g.data_ptr(), 0, B, T, cin, 2 * C, ks, dil, pad, _ld_fast(x), C,
-                        _ld_fast(res) if res is not None else 0, _ACT["gate"], 0, 0, 1.0, BF16)
+                        res.data_ptr() if res is not None else 0, g.data_ptr(), lengths.data_ptr() if lengths is not None else 0,
+                        B, T, cin, 2 * C, ks, dil, pad, _ld_fast(x), C,
+                        _ld_fast(res) if res is not None else 0, _ACT["gate"], 0, 1 if lengths is not None else 0, 1.0, BF16)
     check(_lib.load().ptpp_conv1d_gate_fwd_save(_conv_args_ref, a.data_ptr(), 2 * C, _stream()), "ptpp_conv1d_gate_fwd_save")
 
 
@@ -613,14 +616,16 @@ def conv1d_gate_bwd_supported(C, cin, dtype):
     return ok
 
 
-def conv1d_gate_bwd(do, wpt, a, da):
+def conv1d_gate_bwd(do, wpt, a, da, lengths=None):
     """dg = conv1x1(do, wpt) with ``gate_bwd(a, dg, da)`` fused into its epilogue (ptpp_conv1d_gate_bwd): ``da`` is a
     (B, T, 2C) view with row stride >= 2C written in place; dg is never stored.  Bit-identical to the two launches."""
     B, T, cin = do.shape
     C = a.shape[2] // 2
     assert a.is_contiguous() and a.dtype == do.dtype == torch.bfloat16
-    _CONV_FMT.pack_into(_conv_buf, 0, do.data_ptr(), wpt.data_ptr(), 0, 0, 0, 0, B, T, cin, C, 1, 1, 0, _ld_fast(do), 0, 0,
-                        _ACT[None], 0, 0, 1.0, BF16)
+    if lengths is not None:  # ragged batch: do is zero past an utterance's end -- the (exact) input mask lets those row tiles skip
+        lengths = i32(lengths, do.device)
+    _CONV_FMT.pack_into(_conv_buf, 0, do.data_ptr(), wpt.data_ptr(), 0, 0, 0, lengths.data_ptr() if lengths is not None else 0,
+                        B, T, cin, C, 1, 1, 0, _ld_fast(do), 0, 0, _ACT[None], 1 if lengths is not None else 0, 0, 1.0, BF16)
     check(_lib.load().ptpp_conv1d_gate_bwd(_conv_args_ref, a.data_ptr(), da.data_ptr(), _ld(da), _stream()),
           "ptpp_conv1d_gate_bwd")
     return da
