@@ -320,9 +320,21 @@ def side_stream_for_collective():
 def sync_wgrad_stream():
     """The current stream waits for the weight-gradient kernels enqueued so far; the tensors held for the
     side stream are released (whatever reuses their memory is enqueued after this wait)."""
+    cur = torch.cuda.current_stream()
+    main = _direct.get("main")
     if _direct["side"] is not None:
-        torch.cuda.current_stream().wait_stream(_direct["side"])
+        cur.wait_stream(_direct["side"])
+        if main is not None and main != cur:
+            # called from a backward node that runs on a branch stream (the keep-flush of wgrad_stream): the held tensors
+            # were allocated on the main stream, whose pool gets them back -- it has to wait for the side stream too
+            main.wait_stream(_direct["side"])
         _direct["keep"].clear()
+    # explicit join of the branch streams: their backward kernels write p.grad in place (LayerNorm / BatchNorm / GRU
+    # parameters, the owner-block weight gradients); whatever the caller enqueues next (the optimizer, a collective) must
+    # not rely on autograd's implicit leaf-stream synchronisation for that
+    for s in _grad_streams:
+        if s != cur:
+            cur.wait_stream(s)
 
 
 def reset_direct_uses():
@@ -393,7 +405,7 @@ class Conv1dFn(Function):
         ctx.cfg, ctx.seed, ctx.has_res, ctx.has_b = cfg, seed, res is not None, b is not None
         # in-place gradient targets (None -> autograd accumulates the returned tensors)
         ctx.direct = None
-        if cin % kc == 0 and cout % kc == 0 and _sink(w) is not None and (b is None or _sink(b) is not None):
+        if any(ctx.needs_input_grad) and cin % kc == 0 and cout % kc == 0 and _sink(w) is not None and (b is None or _sink(b) is not None):
             ctx.direct = (w, b)
             _use(w)
             if b is not None:
@@ -462,7 +474,7 @@ class FusedLinearFn(Function):
         ws, bs = params[:n], params[n:]
         ctx.n, ctx.couts = n, [w.shape[0] for w in ws]
         y = ops.conv1d(x, packed_cat(ws, x.dtype), bias_cat(bs), sum(ctx.couts))
-        ctx.direct = all(_sink(p) is not None for p in params)
+        ctx.direct = any(ctx.needs_input_grad) and all(_sink(p) is not None for p in params)
         if ctx.direct:
             for p in params:
                 _use(p)
@@ -530,7 +542,7 @@ class LayerNormFn(Function):
         ctx.cfg, ctx.s_in, ctx.s_out, ctx.has_res, ctx.fused_in = cfg, s_in, s_out, res is not None, fused_in
         ctx.gshape = gamma.shape
         ctx.direct = None
-        if _sink(gamma) is not None and _sink(beta) is not None:
+        if any(ctx.needs_input_grad) and _sink(gamma) is not None and _sink(beta) is not None:
             ctx.direct = (gamma, beta)
             _use(gamma)
             _use(beta)
@@ -613,7 +625,8 @@ class ConvLnStackFn(Function):
         _lib.check(_lib.load().ptpp_conv_ln_stack_fwd(ctypes.byref(a), ops._stream()), "ptpp_conv_ln_stack_fwd")
         ctx.cfg, ctx.n, ctx.seeds, ctx.params = cfg, n, seeds, flat
         ctx.slabs = (x, x_all, z_all, sum_all, stats, gam)
-        ctx.direct = all(_sink(t) is not None for t in flat)
+        # (no backward will run under no_grad / eval: counting uses there would leave them pending until zero_grad)
+        ctx.direct = any(ctx.needs_input_grad) and all(_sink(t) is not None for t in flat)
         if ctx.direct:
             for t in flat:
                 _use(t)
@@ -974,7 +987,7 @@ class DiffNetStackFn(Function):
         skip, saved = diffnet_stack_forward(h0, cond_all, dsteps, [(w[0], w[1], w[4], w[5]) for w in ws], lengths,
                                             cycle, save=True, gate_b=gate_b)
         ctx.L, ctx.cycle, ctx.lengths, ctx.saved, ctx.ws, ctx.wc = L, cycle, lengths, saved, ws, wc
-        ctx.direct = all(_sink(t) is not None for t in flat)
+        ctx.direct = any(ctx.needs_input_grad) and all(_sink(t) is not None for t in flat)
         if ctx.direct:
             for t in flat:
                 _use(t)

@@ -47,9 +47,14 @@ def _branch_stream(dev, idx=0):
     if st is None:
         st = _branch[(dev, idx)] = ops.aux_stream(dev, idx)
         gib = float(os.environ.get("PTPP_BRANCH_RESERVE_GIB", "2" if idx == 0 else "6"))
-        with torch.cuda.stream(st):
-            slab = torch.empty(int(gib * (1 << 30)), device=dev, dtype=torch.uint8)
-            del slab
+        try:  # (a smaller or shared GPU: go without the reservation, the pool then grows on demand)
+            free = torch.cuda.mem_get_info(dev)[0]
+            gib = min(gib, 0.1 * free / (1 << 30))
+            with torch.cuda.stream(st):
+                slab = torch.empty(int(gib * (1 << 30)), device=dev, dtype=torch.uint8)
+                del slab
+        except RuntimeError:
+            pass
         PF.register_gradient_stream(st)  # bucket collectives of the data-parallel reducer wait for its gradient kernels too
     return st
 

@@ -300,6 +300,8 @@ class GaussianDiffusion(nn.Module):
                         sm.wait_stream(main)  # (the noise was drawn on the calling stream)
                     with torch.cuda.stream(sm):
                         if nz is not None:
+                            if sm is not main:
+                                nz.record_stream(sm)  # main's pool may not hand the block out again before this copy ran
                             ns.copy_(nz[lo:hi])
                         else:
                             ns.zero_()

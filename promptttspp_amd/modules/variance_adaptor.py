@@ -40,9 +40,11 @@ class PredictorLayer(nn.Module):
 def _predictor_layers(layers, x, lengths, training):
     """All PredictorLayers of a predictor: one autograd node issued by two C calls (functional.ConvLnStackFn) where the
     layers share kernel size and dropout (every reference config), else layer by layer."""
+    if len(layers) == 0:
+        return x
     l0 = layers[0]
     convs = [l.conv for l in layers]
-    if len(layers) > 0 and all(l.kernel_size == l0.kernel_size and l.p == l0.p and l.norm.eps == l0.norm.eps for l in layers) \
+    if all(l.kernel_size == l0.kernel_size and l.p == l0.p and l.norm.eps == l0.norm.eps for l in layers) \
             and PF.conv_ln_stack_ok(x, convs):
         return PF.conv_ln_stack(x, convs, [l.norm for l in layers], l0.kernel_size, l0.norm.eps, lengths, conv_act="relu",
                                 drop_out=l0.p if training else 0.0, out_mask=1)

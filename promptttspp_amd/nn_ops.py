@@ -305,14 +305,16 @@ class GruFn(Function):
         if ctx.seq:
             dev = gi_all.device
             w, bh = PF._f32c(weight_hh), PF._f32c(bias_hh)
-            hs_all = torch.empty((L + 1, B, Hn), device=dev, dtype=torch.float32)
+            # zeros, not empty: the kernel writes rows 0..lens[b] only and the W_hh weight-gradient GEMM of the backward runs over
+            # ALL L*B rows (dgh = 0 there): 0 * recycled NaN/Inf bits would poison W_hh.grad
+            hs_all = torch.zeros((L + 1, B, Hn), device=dev, dtype=torch.float32)
             gh_all = torch.empty((L, B, H3), device=dev, dtype=torch.float32)
             h = torch.empty((B, Hn), device=dev, dtype=torch.float32)
             wt = PF.packed(weight_hh, torch.float32, mode=1) if Hn > 128 else None  # (H, 1, 3H): the transposed copy
             _chk(lib.ptpp_gru_seq_fwd(_ptr(gi_all), _ptr(w), _ptr(wt), _ptr(bh), _ptr(lens), _ptr(hs_all), _ptr(gh_all), _ptr(h),
                                       B, L, Hn, _stream()), "ptpp_gru_seq_fwd")
             ctx.hs, ctx.ghs, ctx.lens, ctx.w, ctx.b, ctx.wf = hs_all, gh_all, lens, weight_hh, bias_hh, w
-            ctx.sink = PF._sink(weight_hh) is not None and PF._sink(bias_hh) is not None
+            ctx.sink = any(ctx.needs_input_grad) and PF._sink(weight_hh) is not None and PF._sink(bias_hh) is not None
             if ctx.sink:
                 PF._use(weight_hh)
                 PF._use(bias_hh)
@@ -331,7 +333,7 @@ class GruFn(Function):
             hs.append(hn)
             h = hn
         ctx.hs, ctx.ghs, ctx.lens, ctx.w = hs, ghs, lens, weight_hh
-        ctx.sink = PF._sink(weight_hh) is not None and PF._sink(bias_hh) is not None
+        ctx.sink = any(ctx.needs_input_grad) and PF._sink(weight_hh) is not None and PF._sink(bias_hh) is not None
         if ctx.sink:
             PF._use(weight_hh)
             PF._use(bias_hh)
