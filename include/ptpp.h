@@ -342,6 +342,39 @@ int ptpp_conv1d_gate_bwd(const ptpp_conv1d_args* a, const void* act, void* da, i
  * STANDARD [gate | filter] order, row stride lda -- bit for bit what ptpp_conv1d_fwd followed by ptpp_gate_fwd produce. */
 int ptpp_conv1d_gate_fwd_save_supported(int C, int cin, int dtype);
 int ptpp_conv1d_gate_fwd_save(const ptpp_conv1d_args* a, void* a_out, int lda, void* stream);
+/* One DiffNet residual layer as ONE launch (bf16, C = 256; csrc/diffnet_layer.hip; reference modules/denoiser.py:69-83):
+ *   a = dilated_conv_k3(yin) + cond;  g = sigmoid(a[:C]) * tanh(a[C:]);  o = output_projection(g) (masked);
+ *   xn = (x + o[:C]) / sqrt2;  skip = (init ? 0 : skip) + o[C:];  yin_next = xn + dnext[b].
+ * Bit-identical to ptpp_conv1d_gate_fwd_save (a_out / g_out given: training) or ptpp_conv1d_fwd with PTPP_ACT_GATE
+ * (a_out = g_out = NULL: inference) followed by ptpp_conv1d_diffnet_post.  The layer's two weights arrive as ONE operand
+ * stream (ptpp_diffnet_pack_wstream: 64 stages of 16 KiB in consumption order, each already the LDS image of its MFMA
+ * fragments) built from the mode-2 operand of the dilated conv and the mode-0 operand of the output projection; dil_b and
+ * cond (row stride ldc, this layer's 2C channels) are in the gate-interleaved order of mode 2. */
+typedef struct {
+  const void* yin;        /* (B, T, C) bf16: x + diffusion-step projection (input of the dilated conv)   */
+  const void* x;          /* (B, T, C) bf16: residual input                                              */
+  const void* cond;       /* (B, T, .) bf16, row stride ldc: conditioner slice of this layer (2C ch.)    */
+  const void* wstream;    /* ptpp_diffnet_wstream_bytes(C) bytes of this layer                           */
+  const float* dil_b;     /* (2C) f32, gate-interleaved order                                            */
+  const float* out_b;     /* (2C) f32                                                                    */
+  const float* dnext;     /* (B, C) f32 step projection of the NEXT layer, or NULL (then yin_next unused) */
+  float* skip;            /* (B, T, C) f32, accumulated in place                                         */
+  void* xn;               /* (B, T, C) bf16 out                                                          */
+  void* yin_next;         /* (B, T, C) bf16 out or NULL                                                  */
+  void* a_out;            /* (B, T, 2C) bf16 out, STANDARD [gate | filter] order, or NULL (inference)    */
+  void* g_out;            /* (B, T, C) bf16 out, or NULL together with a_out                             */
+  const int32_t* lengths; /* (B) or NULL: rows past an utterance's end have o = 0 (training)             */
+  int32_t B, T, C, dil, ldc, init, dtype;
+} ptpp_diffnet_layer_args;
+int ptpp_diffnet_layer_supported(int C, int dtype);
+int64_t ptpp_diffnet_wstream_bytes(int C);
+/* dil_wp / out_wp: HOST arrays of L device pointers (mode-2 (2C, 3, C) and mode-0 (2C, 1, C) bf16 operands); wstream:
+ * L * ptpp_diffnet_wstream_bytes(C) bytes, layer l at l * that. */
+int ptpp_diffnet_pack_wstream(const void* const* dil_wp, const void* const* out_wp, void* wstream, int L, int C, void* stream);
+int ptpp_diffnet_layer_fwd(const ptpp_diffnet_layer_args* a, void* stream);
+/* diagnostics for tools/ only: dbg bit 0 = per-block clock stamps (6 x uint64 per block: start, first stage landed, end of the
+ * dilated conv, end of the gate epilogue, end of the output projection, end), bits 1-3 switch work off (results invalid). */
+int ptpp_diffnet_layer_fwd_dbg(const ptpp_diffnet_layer_args* a, int dbg, void* stamps, void* stream);
 /* dout (rows, 2C) = [gx/sqrt2 | gskip], masked rows zero */
 int ptpp_diffnet_post_bwd(const void* gx, const void* gskip, void* dout,
                           const int32_t* lengths, int B, int T, int C, int dtype,
@@ -573,6 +606,9 @@ typedef struct {
   void* x_buf[2];           /* two (B, T, C) dtype scratch tensors for x              */
   void* o_buf;              /* (B, T, 2C) dtype scratch, only used where the fused tail is unsupported (f32) */
   int32_t B, T, C, L, cycle, n_slabs, fused_gate, dtype;
+  const void* wstream;      /* L * ptpp_diffnet_wstream_bytes(C) bytes from ptpp_diffnet_pack_wstream, or NULL.  With it (and
+                             * fused_gate = 1 or 2, bf16, C = 256) every layer is ONE launch (ptpp_diffnet_layer_fwd),
+                             * bit-identical to the two launches it replaces */
 } ptpp_diffnet_stack_fwd_args;
 int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream);
 

@@ -69,7 +69,15 @@ class DiffNetFwdArgs(Structure):
 
     _fields_ = [(n, c_void_p) for n in ("h0", "cond_all", "dsteps", "lengths", "skip", "dil_wp", "dil_b", "out_wp", "out_b",
                                         "yin_all", "a_all", "g_all", "x_buf0", "x_buf1", "o_buf")] + \
-               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "n_slabs", "fused_gate", "dtype")]
+               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "n_slabs", "fused_gate", "dtype")] + [("wstream", c_void_p)]
+
+
+class DiffNetLayerArgs(Structure):
+    """Mirror of ``ptpp_diffnet_layer_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("yin", "x", "cond", "wstream", "dil_b", "out_b", "dnext", "skip", "xn", "yin_next", "a_out",
+                                        "g_out", "lengths")] + \
+               [(n, c_int32) for n in ("B", "T", "C", "dil", "ldc", "init", "dtype")]
 
 
 class DiffNetBwdArgs(Structure):
@@ -250,6 +258,11 @@ SIGNATURES = {
     "ptpp_grad_sumsq_det": (I, [P, I, P, c_longlong, P, P, P]),
     "ptpp_adamw_step": (I, [P, I, P, c_longlong, P, P, F, F, F, F, I, F, P]),
     "ptpp_diffnet_stack_fwd": (I, [POINTER(DiffNetFwdArgs), P]),
+    "ptpp_diffnet_layer_supported": (I, [I, I]),
+    "ptpp_diffnet_wstream_bytes": (ctypes.c_int64, [I]),
+    "ptpp_diffnet_pack_wstream": (I, [P, P, P, I, I, P]),
+    "ptpp_diffnet_layer_fwd": (I, [POINTER(DiffNetLayerArgs), P]),
+    "ptpp_diffnet_layer_fwd_dbg": (I, [POINTER(DiffNetLayerArgs), I, P, P]),
     "ptpp_diffnet_stack_bwd": (I, [POINTER(DiffNetBwdArgs), P]),
     "ptpp_conv_ln_stack_fwd": (I, [POINTER(ConvLnFwdArgs), P]),
     "ptpp_conv_ln_stack_bwd": (I, [POINTER(ConvLnBwdArgs), P]),

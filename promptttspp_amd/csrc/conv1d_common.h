@@ -149,7 +149,7 @@ __device__ __forceinline__ void conv_epilogue_act(const ConvP& p, f32x4 (&acc)[F
               uint2 o;
               float gte[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) gte[e] = keep ? tanhf(v1[e]) / (1.f + __expf(-v0[e])) : 0.f;
+              for (int e = 0; e < 4; ++e) gte[e] = keep ? gate_fast(v0[e], v1[e]) : 0.f;
               o.x = (uint32_t)f32_to_bf16(gte[0]) | ((uint32_t)f32_to_bf16(gte[1]) << 16);
               o.y = (uint32_t)f32_to_bf16(gte[2]) | ((uint32_t)f32_to_bf16(gte[3]) << 16);
               *reinterpret_cast<uint2*>(yb + (int64_t)t * e_ldy + (co >> 1)) = o;

@@ -20,27 +20,9 @@
 // SOURCE address.  Rows outside the utterance come from a zero page.
 #pragma once
 #include "conv1d_common.h"
+#include "lds_dma.h"
 
 namespace {
-
-__device__ uint4 g_conv_zero_page[64];
-
-// one wave-instruction: lane l's 16 bytes at gsrc -> LDS byte address lds_dst + 16 l (lds_dst wave-uniform)
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
-}
-template <int N>
-__device__ __forceinline__ void glds_wait() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
-}
 
 // inverse of wperm<bf16, FN>: weight-tile row held by LDS row q
 template <int FN>
@@ -128,14 +110,14 @@ __device__ __forceinline__ void tile_epi_update(const ConvP& p, f32x4 (&acc)[FM]
           const float fr[4] = {__uint_as_float(av.z << 16), __uint_as_float(av.z & 0xffff0000u), __uint_as_float(av.w << 16),
                                __uint_as_float(av.w & 0xffff0000u)};
           uint2 o;
-          o.x = (uint32_t)f32_to_bf16(sigmoidf_(sr[0]) * tanhf(fr[0])) | ((uint32_t)f32_to_bf16(sigmoidf_(sr[1]) * tanhf(fr[1])) << 16);
-          o.y = (uint32_t)f32_to_bf16(sigmoidf_(sr[2]) * tanhf(fr[2])) | ((uint32_t)f32_to_bf16(sigmoidf_(sr[3]) * tanhf(fr[3])) << 16);
+          o.x = (uint32_t)f32_to_bf16(gate_fast(sr[0], fr[0])) | ((uint32_t)f32_to_bf16(gate_fast(sr[1], fr[1])) << 16);
+          o.y = (uint32_t)f32_to_bf16(gate_fast(sr[2], fr[2])) | ((uint32_t)f32_to_bf16(gate_fast(sr[3], fr[3])) << 16);
           *reinterpret_cast<uint2*>(slot) = o;
           continue;
         }
         float gte[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gte[e] = keep ? tanhf(v[1][e]) / (1.f + __expf(-v[0][e])) : 0.f;
+        for (int e = 0; e < 4; ++e) gte[e] = keep ? gate_fast(v[0][e], v[1][e]) : 0.f;
         uint2 o;
         o.x = (uint32_t)f32_to_bf16(gte[0]) | ((uint32_t)f32_to_bf16(gte[1]) << 16);
         o.y = (uint32_t)f32_to_bf16(gte[2]) | ((uint32_t)f32_to_bf16(gte[3]) << 16);
@@ -382,7 +364,8 @@ __device__ __forceinline__ void tile_epilogue_gate_bwd(const ConvP& p, f32x4 (&a
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float d = round_bf16(acc[fm][2 * h + (e >> 2)][e & 3] * p.out_scale);
-        const float sg = sigmoidf_(sv[e]), th = tanhf(fv[e]);
+        float sg, th;
+        gate_fast_parts(sv[e], fv[e], sg, th);
         ds[e] = d * th * sg * (1.f - sg);
         df[e] = d * sg * (1.f - th * th);
       }

@@ -1,0 +1,634 @@
+// One DiffNet residual layer as ONE kernel (reference modules/denoiser.py:69-83):
+//
+//   a   = dilated_conv_k3(yin) + cond_slice            (yin = x + diffusion_step projection, written by the previous layer)
+//   g   = sigmoid(a[:, :C]) * tanh(a[:, C:])
+//   o   = output_projection(g)                          (1 x 1, C -> 2C)
+//   xn  = (x + o[:, :C]) / sqrt(2);   skip += o[:, C:];   yin' = xn + dnext[b]
+//
+// C = 256, bf16 tensors, f32 accumulation.  Bit for bit the results of the two-launch path
+// (ptpp_conv1d_gate_fwd_save / ptpp_conv1d_fwd with PTPP_ACT_GATE, then ptpp_conv1d_diffnet_post): same K order of the
+// accumulation (64-channel chunk, tap, 32-channel MFMA step), same rounding points (a, g, o, xn, yin' to bf16).
+//
+// Structure: a block of 8 waves owns a 128-row tile of one utterance with ALL channels.
+//   * ONE continuous weight stream: the layer's two weights are re-packed once per weight version
+//     (ptpp_diffnet_pack_wstream) into 64 stages of 16 KiB that are already the LDS images the MFMA fragments are read from
+//     (row permutation and XOR swizzle applied), in consumption order; a stage = [256 output channels][32 k] bf16.
+//     The stages travel global -> LDS by LDS-DMA into a ring of NS stages, NS - 2 stages (32-48 KiB) in flight under the
+//     MFMAs of the current one; the stream never drains between the passes (the gate epilogue runs while the first
+//     stages of the output projection land).
+//   * pass A, 48 steps (chunk ci, tap, k-half kh, channel half nh): the wave tile is 64 rows x 64 channels of each
+//     256-channel half; both halves accumulate at once (2 x 16 MFMA tiles = 128 accumulator registers), so the x window
+//     of a 64-channel chunk (128 + 2 dil rows, double-buffered LDS-DMA) is fetched ONCE and each x fragment serves two steps.
+//   * gate epilogue: + bias + conditioner slice, a rounded and stored (training), g -> LDS as the B operand of pass B
+//     ([128 rows][256 channels], XOR-swizzled 16-byte chunks; the region the x windows used) -- g never leaves the CU
+//     (training stores a copy for the weight gradient).
+//   * pass B, 16 steps (k32 step kc, channel half nh): nh = 0 is the residual half, nh = 1 the skip half.
+//   * tail: xn / yin' / skip straight from the accumulators.
+// LDS: NS x 16 KiB ring + 64 KiB = 144 KiB (NS = 5): one block per CU; a 30 000-frame batch is 235 blocks on 256 CUs.
+#include "conv1d_common.h"
+#include "lds_dma.h"
+
+namespace {
+
+constexpr int DN_C = 256;        // residual channels
+constexpr int DN_STEPS = 64;     // 48 (dilated conv) + 16 (output projection)
+constexpr int DN_STAGE_U4 = 1024;  // uint4 per stage (16 KiB)
+
+struct DnLayerP {
+  const bf16_raw* yin;
+  const bf16_raw* x;
+  const bf16_raw* cond;
+  const uint4* wstream;
+  const float* dil_b;
+  const float* out_b;
+  const float* dnext;
+  float* skip;
+  bf16_raw* xn;
+  bf16_raw* yin_next;
+  bf16_raw* a_out;
+  bf16_raw* g_out;
+  const int* lengths;
+  int B, T, dil, ldc, init, nMT;
+  unsigned long long* stamps;  // diagnostics only
+};
+
+__device__ __forceinline__ void lds_barrier() {
+  // LDS reads / writes of this wave have completed, then the workgroup barrier; never waits for the LDS-DMA queue
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// two f32 -> packed bf16 (round to nearest even) in ONE v_cvt_pk_bf16_f32; equal to f32_to_bf16 on every non-NaN input
+typedef __attribute__((ext_vector_type(2))) float dn_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 dn_bf16x2;
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  const dn_f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dn_bf16x2));
+}
+__device__ __forceinline__ float lo_bf16(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float hi_bf16(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ float round_bf16_(float v) { return lo_bf16(pack_bf16x2(v, 0.f)); }
+
+// 16 MFMAs of one step: weights as the A operand, acc[fm][fn] += W[fn] * X[fm]
+template <bool NOMFMA = false, int FM = 4>
+__device__ __forceinline__ void dn_mfma_step(f32x4 (&acc)[FM][4], const uint4 (&wf)[4], const uint4 (&xf)[FM]) {
+  if constexpr (NOMFMA) {  // keep the LDS reads alive without the matrix work
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("" ::"v"(wf[i].x), "v"(wf[i].w), "v"(xf[i % FM].x), "v"(xf[i % FM].w));
+    }
+    return;
+  }
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn)
+      acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[fn]), __builtin_bit_cast(bf16x8_t, xf[fm]),
+                                                            acc[fm][fn], 0, 0, 0);
+}
+
+template <int NS>
+__device__ __forceinline__ void dn_wait_stage(int s) {
+  // top of step s: this wave's pieces of stage s + 1 must have landed.  Issued so far: stages up to min(63, s + NS - 2), two
+  // pieces per stage and wave, so min(NS - 3, 62 - s) younger stages may stay in flight (the x-window pieces issued in
+  // between only make the wait stricter)
+  const int younger = min(NS - 3, DN_STEPS - 2 - s);
+  if (younger >= 3) glds_wait<6>();
+  else if (younger == 2) glds_wait<4>();
+  else if (younger == 1) glds_wait<2>();
+  else glds_wait<0>();
+}
+
+// DBG (tools only, ptpp_diffnet_layer_fwd_dbg): bit 0 = clock stamps per block into p.stamps, bit 1 = no MFMAs, bit 2 = no
+// weight stream (the waits find nothing outstanding), bit 3 = no epilogue loads / stores
+template <int NS, bool SAVE, int DBG = 0, int FM = 4>
+__global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p) {
+  constexpr int BM = 32 * FM;  // rows per block: 2 wave rows x FM MFMA tiles of 16
+  static_assert(NS >= 3 && NS <= 6, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object
+  uint4* Ring = reinterpret_cast<uint4*>(smem);                // [NS][1024]
+  uint4* G = Ring + NS * DN_STAGE_U4;                          // g [BM][32 chunks of 16 bytes]; first the x windows [2][xrows][8]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / p.nMT, mt = blockIdx.x - b * p.nMT;
+  const int t0 = mt * BM;
+  const int dil = p.dil, T = p.T;
+  const int xrows = (BM + 2 * dil + 7) & ~7;
+  const int np = xrows >> 3;
+  const int len_raw = p.lengths ? p.lengths[b] : T;
+
+  const bf16_raw* yb = p.yin + (int64_t)b * T * DN_C;
+  const char* wsrc = reinterpret_cast<const char*>(p.wstream) + wave * 2048 + lane * 16;
+  const uint32_t ring_lds = lds_addr(Ring) + (uint32_t)wave * 2048u;
+  const uint32_t xs_lds = lds_addr(G);
+  const char* zero = reinterpret_cast<const char*>(g_conv_zero_page) + lane * 16;
+
+  auto issue_w = [&](int s, int slot) {
+    if constexpr (DBG & 4) return;
+    const char* src = wsrc + (size_t)s * (DN_STAGE_U4 * 16);
+    const uint32_t dst = ring_lds + (uint32_t)slot * (DN_STAGE_U4 * 16);
+    glds16(src, __builtin_amdgcn_readfirstlane(dst));
+    glds16(src + 1024, __builtin_amdgcn_readfirstlane(dst + 1024u));
+  };
+  auto issue_x_piece = [&](int ci, int piece) {  // 8 rows x 128 bytes of the window of chunk ci
+    const int r = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz<8>(r);
+    const int ts = t0 - dil + r;
+    const char* src = (ts >= 0 && ts < T) ? reinterpret_cast<const char*>(yb + (int64_t)ts * DN_C + ci * 64 + c * 8) : zero;
+    glds16(src, __builtin_amdgcn_readfirstlane(xs_lds + (uint32_t)(((ci & 1) * xrows + piece * 8) * 128)));
+  };
+
+  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (DBG & 1) stamp[0] = wall_clock64();
+  f32x4 acc[2][FM][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: the ring fills while the scalar load of lengths[b] is on its way
+  issue_w(0, 0);
+  const int len = min(len_raw, T);
+  const bool masked = p.lengths != nullptr;
+  // a tile past the utterance's end (token-bucket batches are padded): every output is masked, no MFMA work
+  const bool active = !(masked && t0 >= len);
+
+  // Software pipeline (one step deep, through registers): at the top of step s the wave waits for ITS pieces of stage s + 1
+  // and passes the barrier (-> everyone's pieces of stage s + 1 have landed, everyone is done with stage s - 1), issues the
+  // DMA of stage s + NS - 1 into the slot of stage s - 1, requests the fragments of step s + 1 from LDS and only then
+  // runs the 16 MFMAs of step s on the fragments requested a step earlier: the LDS round trip (all 8 waves read at once
+  // after a barrier: ~0.2 us, as long as the MFMAs themselves) hides under the matrix work instead of preceding it.
+  uint4 wf0[4] = {}, wf1[4] = {}, xa[FM] = {}, xb_[FM] = {};
+  auto ld_w = [&](uint4 (&wf)[4], int slot) {
+    if constexpr ((DBG & 64) != 0) return;  // (timing experiment: no fragment reads)
+    const uint4* Wst = Ring + slot * DN_STAGE_U4;
+    if constexpr ((DBG & 128) != 0) {  // (timing experiment: the x window's 128-byte-row pattern on the ring memory)
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) {
+        const int q = (wn & 1) * 64 + fn * 16 + lr;
+        wf[fn] = Wst[q * 8 + (lg ^ swz<8>(q))];
+      }
+      return;
+    }
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      const int q = wn * 64 + fn * 16 + lr;
+      wf[fn] = Wst[q * 4 + (lg ^ swz<4>(q))];
+    }
+  };
+  // one LDS address per request: the tiles of a wave are 16 rows apart, which leaves both swizzles unchanged, so tile fm
+  // is a compile-time offset (the address arithmetic per step was as long as the MFMA issue itself)
+  const int xrow0 = wm * (16 * FM) + lr;
+  auto ld_x = [&](uint4 (&xf)[FM], int pair) {  // pair = (ci * 3 + tap) * 2 + kh
+    const int ci = pair / 6, tk = pair - ci * 6;
+    const int tap = tk >> 1, kh = tk & 1;
+    if constexpr ((DBG & 64) != 0) return;
+    const int r = xrow0 + tap * dil;
+    const uint4* src = G + (ci & 1) * xrows * 8 + r * 8 + ((kh * 4 + lg) ^ swz<8>(r));
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) xf[fm] = src[fm * 128];
+  };
+  const uint4* gsrc0 = G + xrow0 * 32;
+  auto ld_g = [&](uint4 (&gf)[FM], int kc) {
+    if constexpr ((DBG & 64) != 0) return;
+    const uint4* src = gsrc0 + ((kc * 4 + lg) ^ (xrow0 & 15));
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) gf[fm] = src[fm * 512];
+  };
+  // DBG bit 4: cycle stamps (s_memtime) inside steps 16..19 of waves 0 and 5, parked in LDS behind the g region
+  unsigned long long* ST = reinterpret_cast<unsigned long long*>(G + BM * 32);
+  auto fine_stamp = [&](int s, int k) {
+    if constexpr ((DBG & 16) != 0) {
+      if (s >= 16 && s < 20 && (wave == 0 || wave == 5) && lane == 0) ST[((wave != 0) * 4 + (s - 16)) * 8 + k] = __builtin_readcyclecounter();
+    }
+  };
+
+  // top of step s: stage s + 1 has landed for everyone, stage s - 1 is free; then the next DMA
+  auto step_top = [&](int s, int slot) {
+    fine_stamp(s, 0);
+    if (s + 1 < DN_STEPS) dn_wait_stage<NS>(s);
+    fine_stamp(s, 1);
+    if constexpr ((DBG & 32) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (timing experiment: no barrier, results invalid)
+    else lds_barrier();
+    fine_stamp(s, 2);
+    if (s + NS - 1 < DN_STEPS) issue_w(s + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+    fine_stamp(s, 3);
+  };
+  auto next_slot = [&](int slot) { return slot + 1 == NS ? 0 : slot + 1; };
+  int slot = 0;  // slot of the CURRENT step's stage
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (wave + 8 * k < np) issue_x_piece(0, wave + 8 * k);
+#pragma unroll
+    for (int s = 1; s <= NS - 3; ++s) issue_w(s, s);
+    // pseudo-step -1: stage 0 and the first x window have landed; the first fragments
+    dn_wait_stage<NS>(-1);
+    lds_barrier();
+    issue_w(NS - 2, NS - 2);
+    if constexpr (DBG & 1) stamp[1] = wall_clock64();
+    ld_w(wf0, 0);
+    ld_x(xa, 0);
+
+    // ---- pass A: dilated conv, both channel halves (24 pairs of steps; two pairs per trip so that the x fragments
+    // alternate between two register sets without copies)
+    auto pair_steps = [&](int pr, uint4 (&xcur)[FM], uint4 (&xnext)[FM]) __attribute__((always_inline)) {
+      const int s = 2 * pr;
+      const int ci = pr / 6, tk = pr - ci * 6;
+      // step s: channel half 0
+      step_top(s, slot);
+      if (ci < 3 && tk < 2) {  // the next chunk's window: pieces wave, wave + 8, wave + 16 over three steps
+        const int piece = wave + 16 * tk;
+        if (piece < np) issue_x_piece(ci + 1, piece);
+      }
+      ld_w(wf1, next_slot(slot));
+      fine_stamp(s, 4);
+      __builtin_amdgcn_sched_barrier(0);  // the LDS requests above are issued BEFORE the matrix work ...
+      dn_mfma_step<(DBG & 2) != 0, FM>(acc[0], wf0, xcur);
+      __builtin_amdgcn_sched_barrier(0);  // ... which stays on this side of the next barrier (register-only code moves across asm)
+      fine_stamp(s, 5);
+      slot = next_slot(slot);
+      // step s + 1: channel half 1 (same x fragments)
+      step_top(s + 1, slot);
+      if (ci < 3 && tk == 0) {
+        const int piece = wave + 8;
+        if (piece < np) issue_x_piece(ci + 1, piece);
+      }
+      if (pr < 23) {
+        ld_w(wf0, next_slot(slot));
+        ld_x(xnext, pr + 1);
+      }
+      fine_stamp(s + 1, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      dn_mfma_step<(DBG & 2) != 0, FM>(acc[1], wf1, xcur);
+      __builtin_amdgcn_sched_barrier(0);
+      fine_stamp(s + 1, 5);
+      slot = next_slot(slot);
+    };
+#pragma unroll 1
+    for (int pr = 0; pr < 24; pr += 2) {
+      pair_steps(pr, xa, xb_);
+      pair_steps(pr + 1, xb_, xa);
+    }
+  } else {
+    glds_wait<0>();
+  }
+
+  // ---- gate epilogue: every wave is done with the x windows, their memory becomes g
+  lds_barrier();
+  if constexpr (DBG & 1) stamp[2] = wall_clock64();
+  {
+    const bf16_raw* cb = p.cond + (int64_t)b * T * p.ldc;
+    bf16_raw* ab = SAVE ? p.a_out + (int64_t)b * T * (2 * DN_C) : nullptr;
+    uint2* G2 = reinterpret_cast<uint2*>(G);
+    // every conditioner vector of the wave's tile is requested before the first is used: one memory round trip, not sixteen
+    uint4 cv[2][2][FM];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+          const int t = t0 + wm * (16 * FM) + fm * 16 + lr;
+          cv[nh][h][fm] = make_uint4(0, 0, 0, 0);
+          if (t < T && !(DBG & 8)) cv[nh][h][fm] = *reinterpret_cast<const uint4*>(cb + (int64_t)t * p.ldc + nh * 256 + wn * 64 + h * 32 + lg * 8);
+        }
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pch = nh * 256 + wn * 64 + h * 32 + lg * 8;  // 8 packed channels: [4 gate | their 4 filter partners]
+        const int gch = pch >> 1;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.dil_b + pch), b1 = *reinterpret_cast<const f32x4*>(p.dil_b + pch + 4);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+          const int row = wm * (16 * FM) + fm * 16 + lr;
+          const int t = t0 + row;
+          const bool valid = t < T;
+          const bool keep = !(masked && t >= len);
+          f32x4 v0 = acc[nh][fm][2 * h], v1 = acc[nh][fm][2 * h + 1];
+          v0 += b0;
+          v1 += b1;
+          if (!keep) {
+            v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            v1 = v0;
+          }
+          const uint4 r = cv[nh][h][fm];
+          v0[0] += lo_bf16(r.x); v0[1] += hi_bf16(r.x); v0[2] += lo_bf16(r.y); v0[3] += hi_bf16(r.y);
+          v1[0] += lo_bf16(r.z); v1[1] += hi_bf16(r.z); v1[2] += lo_bf16(r.w); v1[3] += hi_bf16(r.w);
+          uint2 o;
+          if constexpr (SAVE) {
+            // training: the pre-activation is kept (bf16) and the gate is computed FROM THE ROUNDED values, as gate_fwd does
+            const uint2 as = make_uint2(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]));
+            const uint2 af = make_uint2(pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3]));
+            if (valid && !(DBG & 8)) {
+              *reinterpret_cast<uint2*>(ab + (int64_t)t * (2 * DN_C) + gch) = as;
+              *reinterpret_cast<uint2*>(ab + (int64_t)t * (2 * DN_C) + DN_C + gch) = af;
+            }
+            const float sr[4] = {lo_bf16(as.x), hi_bf16(as.x), lo_bf16(as.y), hi_bf16(as.y)};
+            const float fr[4] = {lo_bf16(af.x), hi_bf16(af.x), lo_bf16(af.y), hi_bf16(af.y)};
+            o.x = pack_bf16x2(gate_fast(sr[0], fr[0]), gate_fast(sr[1], fr[1]));
+            o.y = pack_bf16x2(gate_fast(sr[2], fr[2]), gate_fast(sr[3], fr[3]));
+          } else {
+            float gte[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gte[e] = keep ? gate_fast(v0[e], v1[e]) : 0.f;
+            o.x = pack_bf16x2(gte[0], gte[1]);
+            o.y = pack_bf16x2(gte[2], gte[3]);
+          }
+          G2[(row * 32 + ((gch >> 3) ^ (row & 15))) * 2 + ((gch >> 2) & 1)] = o;
+        }
+      }
+    }
+  }
+  lds_barrier();
+  if constexpr (DBG & 1) stamp[3] = wall_clock64();
+
+  // ---- pass B: output projection (k32 step kc, channel half nh), accumulators reused
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    // (stage 48 landed and became visible at the top of step 47; g became visible at the barrier above)
+    ld_w(wf0, slot);
+    ld_g(xa, 0);
+    auto proj_steps = [&](int kc, uint4 (&gcur)[FM], uint4 (&gnext)[FM]) __attribute__((always_inline)) {
+      const int s = 48 + 2 * kc;
+      step_top(s, slot);
+      ld_w(wf1, next_slot(slot));
+      __builtin_amdgcn_sched_barrier(0);
+      dn_mfma_step<(DBG & 2) != 0, FM>(acc[0], wf0, gcur);
+      __builtin_amdgcn_sched_barrier(0);
+      slot = next_slot(slot);
+      step_top(s + 1, slot);
+      if (kc < 7) {
+        ld_w(wf0, next_slot(slot));
+        ld_g(gnext, kc + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      dn_mfma_step<(DBG & 2) != 0, FM>(acc[1], wf1, gcur);
+      __builtin_amdgcn_sched_barrier(0);
+      slot = next_slot(slot);
+    };
+#pragma unroll 1
+    for (int kc = 0; kc < 8; kc += 2) {
+      proj_steps(kc, xa, xb_);
+      proj_steps(kc + 1, xb_, xa);
+    }
+  }
+
+  if constexpr (DBG & 1) stamp[4] = wall_clock64();
+  // ---- tail: residual half -> xn, yin'; skip half -> skip (f32); o is rounded to bf16 first, as the two-kernel path stores it
+  {
+    const float r2 = 0.70710678118654752f;
+    const bf16_raw* xb = p.x + (int64_t)b * T * DN_C;
+    bf16_raw* xnb = p.xn + (int64_t)b * T * DN_C;
+    bf16_raw* yib = p.yin_next ? p.yin_next + (int64_t)b * T * DN_C : nullptr;
+    float* skb = p.skip + (int64_t)b * T * DN_C;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ch = wn * 64 + h * 32 + lg * 8;
+      // the residual and skip rows of this half of the wave's channels are requested together (two memory round trips per
+      // wave instead of eight; all sixteen vectors at once spilled)
+      uint4 xr[FM];
+      f32x4 sk[FM][2];
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const int t = t0 + wm * (16 * FM) + fm * 16 + lr;
+        const bool in = t < T && !((DBG & 8) && t > 0);
+        xr[fm] = make_uint4(0, 0, 0, 0);
+        sk[fm][0] = sk[fm][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (in) {
+          xr[fm] = *reinterpret_cast<const uint4*>(xb + (int64_t)t * DN_C + ch);
+          if (!p.init) {
+            sk[fm][0] = *reinterpret_cast<const f32x4*>(skb + (int64_t)t * DN_C + ch);
+            sk[fm][1] = *reinterpret_cast<const f32x4*>(skb + (int64_t)t * DN_C + ch + 4);
+          }
+        }
+      }
+      f32x4 bo[2], bs[2], dn[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      bo[0] = *reinterpret_cast<const f32x4*>(p.out_b + ch);
+      bo[1] = *reinterpret_cast<const f32x4*>(p.out_b + ch + 4);
+      bs[0] = *reinterpret_cast<const f32x4*>(p.out_b + DN_C + ch);
+      bs[1] = *reinterpret_cast<const f32x4*>(p.out_b + DN_C + ch + 4);
+      if (p.dnext) {
+        dn[0] = *reinterpret_cast<const f32x4*>(p.dnext + (int64_t)b * DN_C + ch);
+        dn[1] = *reinterpret_cast<const f32x4*>(p.dnext + (int64_t)b * DN_C + ch + 4);
+      }
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const int t = t0 + wm * (16 * FM) + fm * 16 + lr;
+        if (t >= T || ((DBG & 8) && t > 0)) continue;
+        const bool keep = !(masked && t >= len);
+        const uint4 xv4 = xr[fm];
+        const float xv[8] = {lo_bf16(xv4.x), hi_bf16(xv4.x), lo_bf16(xv4.y), hi_bf16(xv4.y), lo_bf16(xv4.z), hi_bf16(xv4.z), lo_bf16(xv4.w), hi_bf16(xv4.w)};
+        float xn[8], yi[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {  // (o rounded to bf16 in pairs: one conversion instruction per two values)
+          const uint32_t ob = pack_bf16x2(acc[0][fm][2 * h + (e >> 2)][e & 3] + bo[e >> 2][e & 3],
+                                          acc[0][fm][2 * h + (e >> 2)][(e & 3) + 1] + bo[e >> 2][(e & 3) + 1]);
+          const float o0 = keep ? lo_bf16(ob) : 0.f, o1 = keep ? hi_bf16(ob) : 0.f;
+          xn[e] = (xv[e] + o0) * r2;
+          xn[e + 1] = (xv[e + 1] + o1) * r2;
+          yi[e] = xn[e] + dn[e >> 2][e & 3];
+          yi[e + 1] = xn[e + 1] + dn[e >> 2][(e & 3) + 1];
+        }
+        *reinterpret_cast<uint4*>(xnb + (int64_t)t * DN_C + ch) =
+            make_uint4(pack_bf16x2(xn[0], xn[1]), pack_bf16x2(xn[2], xn[3]), pack_bf16x2(xn[4], xn[5]), pack_bf16x2(xn[6], xn[7]));
+        if (yib)
+          *reinterpret_cast<uint4*>(yib + (int64_t)t * DN_C + ch) =
+              make_uint4(pack_bf16x2(yi[0], yi[1]), pack_bf16x2(yi[2], yi[3]), pack_bf16x2(yi[4], yi[5]), pack_bf16x2(yi[6], yi[7]));
+        float* sp = skb + (int64_t)t * DN_C + ch;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f32x4 sv = sk[fm][u];
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const uint32_t ob = pack_bf16x2(acc[1][fm][2 * h + u][e] + bs[u][e], acc[1][fm][2 * h + u][e + 1] + bs[u][e + 1]);
+            sv[e] = (keep ? lo_bf16(ob) : 0.f) + sv[e];
+            sv[e + 1] = (keep ? hi_bf16(ob) : 0.f) + sv[e + 1];
+          }
+          *reinterpret_cast<f32x4*>(sp + 4 * u) = sv;
+        }
+      }
+    }
+    if constexpr (SAVE) {  // g for the output projection's weight gradient: the LDS image leaves row-contiguous
+      bf16_raw* gb = p.g_out + (int64_t)b * T * DN_C;
+#pragma unroll
+      for (int i = 0; i < BM / 16; ++i) {
+        const int idx = tid + i * 512;
+        const int row = idx >> 5, pos = idx & 31;
+        const int t = t0 + row;
+        if (t < T && !((DBG & 8) && t > 0)) *reinterpret_cast<uint4*>(gb + (int64_t)t * DN_C + (pos ^ (row & 15)) * 8) = G[idx];
+      }
+    }
+  }
+  if constexpr (DBG & 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0 && p.stamps) {
+      stamp[5] = wall_clock64();
+#pragma unroll
+      for (int i = 0; i < 6; ++i) p.stamps[(size_t)blockIdx.x * 6 + i] = stamp[i];
+    }
+    if constexpr ((DBG & 16) != 0) {
+      if (tid < 64 && p.stamps) p.stamps[(size_t)gridDim.x * 6 + (size_t)blockIdx.x * 64 + tid] = ST[tid];
+    }
+  }
+}
+
+// ---- the weight stream ---------------------------------------------------------------------------------------------------
+// stage s of layer l = 1024 x 16 bytes; LDS row q (0..255), chunk position c' (0..3) holds k-chunk c = c' ^ swz<4>(q) of
+// weight row n(q) (the row permutation of the MFMA tiles, conv1d_common.h wperm):
+//   s < 48:  s = ((ci * 3 + tap) * 2 + kh) * 2 + nh  -> dil_wp[nh * 256 + n(q)][tap][ci * 64 + kh * 32 + c * 8 ..]   (mode-2 operand)
+//   s >= 48: s - 48 = kc * 2 + nh                    -> out_wp[nh * 256 + n(q)][0][kc * 32 + c * 8 ..]
+struct DnPackTab {
+  const uint4* dil[32];
+  const uint4* out[32];
+};
+__device__ __forceinline__ int dn_row_of(int q) {
+  const int u = q & 63;
+  const int tile = u >> 4, lgq = (u >> 2) & 3, r = u & 3;
+  return (q - u) + (tile >> 1) * 32 + lgq * 8 + (tile & 1) * 4 + r;
+}
+__global__ __launch_bounds__(256) void diffnet_pack_wstream_kernel(const DnPackTab tab, uint4* __restrict__ ws) {
+  const int l = blockIdx.x >> 6, s = blockIdx.x & 63;
+  uint4* dst = ws + ((size_t)(blockIdx.y * 32 + l) * DN_STEPS + s) * DN_STAGE_U4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int q = idx >> 2, cp = idx & 3;
+    const int c = cp ^ swz<4>(q);
+    const int n = dn_row_of(q);
+    uint4 v;
+    if (s < 48) {
+      const int nh = s & 1, kh = (s >> 1) & 1, ct = s >> 2;  // ct = ci * 3 + tap
+      const int ci = ct / 3, tap = ct - ci * 3;
+      // operand [512][3][256] bf16: 32 uint4 per (row, tap)
+      v = tab.dil[l][((size_t)(nh * 256 + n) * 3 + tap) * 32 + ci * 8 + kh * 4 + c];
+    } else {
+      const int nh = s & 1, kc = (s - 48) >> 1;
+      v = tab.out[l][(size_t)(nh * 256 + n) * 32 + kc * 4 + c];
+    }
+    dst[idx] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int ptpp_diffnet_layer_supported(int C, int dtype) { return C == DN_C && dtype == PTPP_BF16; }
+
+extern "C" int64_t ptpp_diffnet_wstream_bytes(int C) { return C == DN_C ? (int64_t)DN_STEPS * DN_STAGE_U4 * 16 : 0; }
+
+extern "C" int ptpp_diffnet_pack_wstream(const void* const* dil_wp, const void* const* out_wp, void* wstream, int L, int C, void* stream) {
+  PTPP_CHECK_ARG(dil_wp && out_wp && wstream && L > 0, "diffnet_pack_wstream: null pointer / bad layer count");
+  PTPP_CHECK_ARG(C == DN_C, "diffnet_pack_wstream: C = %d is not supported (256)", C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int l0 = 0; l0 < L; l0 += 32) {
+    DnPackTab tab;
+    const int n = L - l0 < 32 ? L - l0 : 32;
+    for (int i = 0; i < 32; ++i) {
+      tab.dil[i] = reinterpret_cast<const uint4*>(dil_wp[l0 + (i < n ? i : 0)]);
+      tab.out[i] = reinterpret_cast<const uint4*>(out_wp[l0 + (i < n ? i : 0)]);
+      PTPP_CHECK_ARG(tab.dil[i] && tab.out[i], "diffnet_pack_wstream: null operand");
+    }
+    uint4* dst = reinterpret_cast<uint4*>(wstream) + (size_t)l0 * DN_STEPS * DN_STAGE_U4;
+    hipLaunchKernelGGL(diffnet_pack_wstream_kernel, dim3((unsigned)(n * DN_STEPS), 1), dim3(256), 0, st, tab, dst);
+  }
+  PTPP_CHECK_LAUNCH("diffnet_pack_wstream");
+  return PTPP_OK;
+}
+
+static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsigned long long* stamps, void* stream);
+
+extern "C" int ptpp_diffnet_layer_fwd(const ptpp_diffnet_layer_args* a, void* stream) { return diffnet_layer_launch(a, 0, nullptr, stream); }
+// diagnostics (tools/bench_diffnet_layer.py): dbg bit 0 = per-block clock stamps (6 x u64 per block, 100 MHz), bit 1 = no
+// MFMAs, bit 2 = no weight stream, bit 3 = no epilogue loads / stores.  Results are only valid for dbg <= 1.
+extern "C" int ptpp_diffnet_layer_fwd_dbg(const ptpp_diffnet_layer_args* a, int dbg, void* stamps, void* stream) {
+  return diffnet_layer_launch(a, dbg | 1, reinterpret_cast<unsigned long long*>(stamps), stream);
+}
+
+static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsigned long long* stamps, void* stream) {
+  PTPP_CHECK_ARG(a && a->yin && a->x && a->cond && a->wstream && a->dil_b && a->out_b && a->skip && a->xn, "diffnet_layer_fwd: null pointer");
+  PTPP_CHECK_ARG(a->C == DN_C && a->dtype == PTPP_BF16, "diffnet_layer_fwd: C = 256 and bf16 only (C %d, dtype %d)", a->C, a->dtype);
+  PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && (a->dil == 1 || a->dil == 2 || a->dil == 4 || a->dil == 8) && a->ldc >= 2 * DN_C && (a->ldc & 7) == 0,
+                 "diffnet_layer_fwd: bad shape (B %d T %d dil %d ldc %d)", a->B, a->T, a->dil, a->ldc);
+  PTPP_CHECK_ARG((a->a_out != nullptr) == (a->g_out != nullptr), "diffnet_layer_fwd: a_out and g_out go together (training) or are both NULL");
+  const uintptr_t al = (uintptr_t)a->yin | (uintptr_t)a->x | (uintptr_t)a->cond | (uintptr_t)a->wstream | (uintptr_t)a->skip | (uintptr_t)a->xn |
+                       (uintptr_t)a->yin_next | (uintptr_t)a->a_out | (uintptr_t)a->g_out | (uintptr_t)a->dil_b | (uintptr_t)a->out_b |
+                       (uintptr_t)a->dnext;
+  PTPP_CHECK_ARG((al & 15) == 0, "diffnet_layer_fwd: every tensor must be 16-byte aligned");
+  DnLayerP p;
+  p.yin = reinterpret_cast<const bf16_raw*>(a->yin);
+  p.x = reinterpret_cast<const bf16_raw*>(a->x);
+  p.cond = reinterpret_cast<const bf16_raw*>(a->cond);
+  p.wstream = reinterpret_cast<const uint4*>(a->wstream);
+  p.dil_b = a->dil_b;
+  p.out_b = a->out_b;
+  p.dnext = a->dnext;
+  p.skip = a->skip;
+  p.xn = reinterpret_cast<bf16_raw*>(a->xn);
+  p.yin_next = reinterpret_cast<bf16_raw*>(a->yin_next);
+  p.a_out = reinterpret_cast<bf16_raw*>(a->a_out);
+  p.g_out = reinterpret_cast<bf16_raw*>(a->g_out);
+  p.lengths = a->lengths;
+  p.B = a->B; p.T = a->T; p.dil = a->dil; p.ldc = a->ldc; p.init = a->init;
+  // 128-row tiles where they fill the chip (a 30 000-frame training batch: 235 blocks); 64-row tiles for smaller batches (the
+  // sampler's 32 x ~400 frames: 128 blocks of 128 rows would leave half of the 256 CUs idle)
+  // (a block holds 112-144 KiB of LDS: one block per CU, so a launch runs in rounds of 256 blocks; 64-row tiles only while they
+  //  fit ONE round -- two rounds of 64-row blocks (2 x 35 us) lose to one round of 128-row blocks (58 us))
+  const int64_t blocks64 = (int64_t)a->B * ((a->T + 63) / 64);
+  const bool small = blocks64 <= 256 && !(dbg & 16);
+  const int bm = small ? 64 : 128;
+  p.nMT = (a->T + bm - 1) / bm;
+  constexpr int NS = 5;
+  const size_t smem = (size_t)(NS * DN_STAGE_U4 + bm * 32) * 16 + ((dbg & 16) ? 1024 : 0);
+  p.stamps = stamps;
+  const bool sv = a->a_out != nullptr;
+  auto kern = sv ? diffnet_layer_kernel<NS, true> : diffnet_layer_kernel<NS, false>;
+  if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 2> : diffnet_layer_kernel<NS, false, 0, 2>;
+  if (dbg) {
+    switch (dbg + (small ? 100 : 0)) {
+      case 1: kern = sv ? diffnet_layer_kernel<NS, true, 1> : diffnet_layer_kernel<NS, false, 1>; break;
+      case 3: kern = sv ? diffnet_layer_kernel<NS, true, 3> : diffnet_layer_kernel<NS, false, 3>; break;
+      case 5: kern = sv ? diffnet_layer_kernel<NS, true, 5> : diffnet_layer_kernel<NS, false, 5>; break;
+      case 7: kern = sv ? diffnet_layer_kernel<NS, true, 7> : diffnet_layer_kernel<NS, false, 7>; break;
+      case 9: kern = sv ? diffnet_layer_kernel<NS, true, 9> : diffnet_layer_kernel<NS, false, 9>; break;
+      case 15: kern = sv ? diffnet_layer_kernel<NS, true, 15> : diffnet_layer_kernel<NS, false, 15>; break;
+      case 17: kern = sv ? diffnet_layer_kernel<NS, true, 17> : diffnet_layer_kernel<NS, false, 17>; break;
+      case 23: kern = sv ? diffnet_layer_kernel<NS, true, 23> : diffnet_layer_kernel<NS, false, 23>; break;
+      case 33: kern = sv ? diffnet_layer_kernel<NS, true, 33> : diffnet_layer_kernel<NS, false, 33>; break;
+      case 65: kern = sv ? diffnet_layer_kernel<NS, true, 65> : diffnet_layer_kernel<NS, false, 65>; break;
+      case 47: kern = sv ? diffnet_layer_kernel<NS, true, 47> : diffnet_layer_kernel<NS, false, 47>; break;
+      case 79: kern = sv ? diffnet_layer_kernel<NS, true, 79> : diffnet_layer_kernel<NS, false, 79>; break;
+      case 143: kern = sv ? diffnet_layer_kernel<NS, true, 143> : diffnet_layer_kernel<NS, false, 143>; break;
+      case 129: kern = sv ? diffnet_layer_kernel<NS, true, 129> : diffnet_layer_kernel<NS, false, 129>; break;
+      case 111: kern = sv ? diffnet_layer_kernel<NS, true, 111> : diffnet_layer_kernel<NS, false, 111>; break;
+      case 101: kern = sv ? diffnet_layer_kernel<NS, true, 1, 2> : diffnet_layer_kernel<NS, false, 1, 2>; break;
+      case 109: kern = sv ? diffnet_layer_kernel<NS, true, 9, 2> : diffnet_layer_kernel<NS, false, 9, 2>; break;
+      case 115: kern = sv ? diffnet_layer_kernel<NS, true, 15, 2> : diffnet_layer_kernel<NS, false, 15, 2>; break;
+      default: ptpp_set_error("diffnet_layer_fwd_dbg: mode %d is not built", dbg); return PTPP_EINVAL;
+    }
+  }
+  {  // once per kernel: the dynamic LDS size is above the 64 KiB default
+    static const void* done[16];
+    static int ndone = 0;
+    const void* kp = reinterpret_cast<const void*>(kern);
+    bool seen = false;
+    for (int i = 0; i < ndone; ++i) seen = seen || done[i] == kp;
+    if (!seen) {
+      (void)hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (ndone < 16) done[ndone++] = kp;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, reinterpret_cast<hipStream_t>(stream), p);
+  PTPP_CHECK_LAUNCH("diffnet_layer_fwd");
+  return PTPP_OK;
+}

@@ -61,7 +61,10 @@ __global__ void gate_fwd_kernel(const T* __restrict__ a, T* __restrict__ g, int 
     const f32x4 s = Elem<T>::ld4(a + row * 2 * C + c), f = Elem<T>::ld4(a + row * 2 * C + C + c);
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = sigmoidf_(s[e]) * tanhf(f[e]);
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (sizeof(T) == 2) o[e] = gate_fast(s[e], f[e]);
+      else o[e] = sigmoidf_(s[e]) * tanhf(f[e]);
+    }
     Elem<T>::st4(g + i * 4, o);
   }
 }
@@ -78,7 +81,9 @@ __global__ void gate_bwd_kernel(const T* __restrict__ a, const T* __restrict__ d
     f32x4 ds, df;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float sg = sigmoidf_(s[e]), th = tanhf(f[e]);
+      float sg, th;
+      if constexpr (sizeof(T) == 2) gate_fast_parts(s[e], f[e], sg, th);
+      else { sg = sigmoidf_(s[e]); th = tanhf(f[e]); }
       ds[e] = d[e] * th * sg * (1.f - sg);
       df[e] = d[e] * sg * (1.f - th * th);
     }

@@ -150,6 +150,22 @@ __device__ __forceinline__ void act_dispatch(int act, F&& f) {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
+// The WaveNet gate of the bf16 kernels (modules/denoiser.py:76-77): two v_exp_f32 + one v_rcp_f32 instead of libm's tanhf and
+// an IEEE division (the fused gate epilogues were VALU-bound: 10 us of a 67 us DiffNet layer launch).  Relative error ~1e-6
+// (absolute 1e-7 near tanh's zero), more than two orders below the bf16 rounding of the result; the f32 parity kernels keep
+// libm.  Every bf16 site (gate_fwd / gate_bwd kernels, the fused conv epilogues, the one-launch layer) uses these same
+// expressions, so the paths stay bit-identical to each other.
+__device__ __forceinline__ float gate_fast(float s, float f) {  // sigmoid(s) * tanh(f)
+  const float e2 = __expf(2.f * fminf(fmaxf(f, -15.f), 15.f));
+  const float es = __expf(-s);
+  return (e2 - 1.f) * __builtin_amdgcn_rcpf((e2 + 1.f) * (1.f + es));
+}
+__device__ __forceinline__ void gate_fast_parts(float s, float f, float& sg, float& th) {  // sigmoid(s), tanh(f)
+  const float e2 = __expf(2.f * fminf(fmaxf(f, -15.f), 15.f));
+  sg = __builtin_amdgcn_rcpf(1.f + __expf(-s));
+  th = (e2 - 1.f) * __builtin_amdgcn_rcpf(e2 + 1.f);
+}
+
 // ---- wave reductions (wave = 64 lanes) ---------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -66,12 +66,30 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
   // yin_0 = h0 + dsteps[0]  (x = h0 itself)
   ST_TRY(ptpp_diffnet_post_fwd(nullptr, a->h0, nullptr, a->dsteps, nullptr, at(a->yin_all, 0, dt), B, T, C, 1, dt, stream));
   const void* x = a->h0;
+  // the whole layer as one launch (csrc/diffnet_layer.hip) where the fused gate is on and the operand stream was handed over
+  const bool one_launch = a->wstream && a->fused_gate && ptpp_diffnet_layer_supported(C, dt) && (1 << ((L - 1) % a->cycle)) <= 8 && a->cycle <= 4;
+  const int64_t wsb = one_launch ? ptpp_diffnet_wstream_bytes(C) : 0;
   for (int l = 0; l < L; ++l) {
     const int d = 1 << (l % a->cycle);
     const int slab = l % a->n_slabs;
     const void* yin = at(a->yin_all, slab * BTC, dt);
     void* g = at(a->g_all, slab * BTC, dt);
     const void* cond = at(a->cond_all, (size_t)l * 2 * C, dt);
+    if (one_launch) {
+      const float* dnext = l + 1 < L ? a->dsteps + (size_t)(l + 1) * B * C : nullptr;
+      ptpp_diffnet_layer_args la;
+      memset(&la, 0, sizeof(la));
+      la.yin = yin; la.x = x; la.cond = cond; la.wstream = static_cast<const char*>(a->wstream) + (size_t)l * wsb;
+      la.dil_b = a->dil_b[l]; la.out_b = a->out_b[l]; la.dnext = dnext; la.skip = a->skip;
+      la.xn = a->x_buf[l & 1];
+      la.yin_next = dnext ? at(a->yin_all, ((l + 1) % a->n_slabs) * BTC, dt) : nullptr;
+      if (a->fused_gate == 2) { la.a_out = at(a->a_all, slab * 2 * BTC, dt); la.g_out = g; }
+      la.lengths = a->lengths;
+      la.B = B; la.T = T; la.C = C; la.dil = d; la.ldc = ldc; la.init = l == 0; la.dtype = dt;
+      ST_TRY(ptpp_diffnet_layer_fwd(&la, stream));
+      x = la.xn;
+      continue;
+    }
     // (training, ragged batch: the dilated conv's output past an utterance's end only meets the masked output projection, so
     //  it is masked too -- a tile past the end then skips its K loop; a third of the row tiles of a token-bucket batch)
     if (a->fused_gate == 2) {

@@ -880,6 +880,31 @@ def _f32_param(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
 
 
+DIFFNET_LAYER_KERNEL = not os.environ.get("PTPP_NO_DIFFNET_LAYER_KERNEL")  # (tests compare with the two-launch path)
+
+
+def diffnet_wstream(weights, dil_wp, out_wp, dt):
+    """The operand stream of csrc/diffnet_layer.hip for all layers ((L, 1 MiB) bytes; ptpp_diffnet_pack_wstream): every
+    layer's dilated-conv (mode 2) and output-projection operands re-laid as the 64 LDS stage images its kernel consumes,
+    cached per version of the 2 L weights (one gather launch per optimiser step in training, one per checkpoint otherwise)."""
+    lib = _lib.load()
+    C = weights[0][2].shape[1]
+    if not (DIFFNET_LAYER_KERNEL and lib.ptpp_diffnet_layer_supported(C, ops.dtype_code(dt))):
+        return None
+    L = len(weights)
+
+    def make():
+        ws = torch.empty((L, lib.ptpp_diffnet_wstream_bytes(C)), device=dil_wp[0].device, dtype=torch.uint8)
+        _lib.check(lib.ptpp_diffnet_pack_wstream(ctypes.cast(_ptr_table(dil_wp), ctypes.c_void_p), ctypes.cast(_ptr_table(out_wp), ctypes.c_void_p),
+                                                 ws.data_ptr(), L, C, ops._stream()), "ptpp_diffnet_pack_wstream")
+        return ws
+
+    srcs = [w[0] for w in weights] + [w[2] for w in weights]
+    if not all(isinstance(t, torch.nn.Parameter) for t in srcs):
+        return make()
+    return _cat_cached(srcs, ("dnws", dt), make)
+
+
 def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None):
     """The whole residual stack in ONE C call (ptpp_diffnet_stack_fwd): the same launches in the same order as the loop
     of ``diffnet_stack_forward`` below (bit-identical), without ~60 Python -> C round trips and ~80 allocations.
@@ -921,6 +946,8 @@ def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle,
     a.x_buf0, a.x_buf1 = xb[0].data_ptr(), xb[1].data_ptr()
     a.o_buf = o_buf.data_ptr() if o_buf is not None else None
     a.B, a.T, a.C, a.L, a.cycle, a.n_slabs, a.fused_gate, a.dtype = B, T, C, L, cycle, n_slabs, 2 if gsave else int(fused), ops.dtype_code(dt)
+    wstream = diffnet_wstream(weights, dil_wp, out_wp, dt) if (gsave or fused) and cycle <= 4 else None
+    a.wstream = wstream.data_ptr() if wstream is not None else None
     _lib.check(_lib.load().ptpp_diffnet_stack_fwd(ctypes.byref(a), ops._stream()), "ptpp_diffnet_stack_fwd")
     return skip, ((yin_all, a_all, g_all) if save else None)
 

@@ -579,6 +579,48 @@ def conv1d_diffnet_post(g, wp, bias, x, skip, dnext, init, lengths=None, out_mas
     return xn, yin
 
 
+def diffnet_layer_supported(C, dtype):
+    return bool(_lib.load().ptpp_diffnet_layer_supported(int(C), dtype_code(dtype)))
+
+
+def diffnet_pack_wstream(dil_wps, out_wps, C):
+    """(L, bytes) uint8 operand stream of ``diffnet_layer_fwd`` from the layers' mode-2 dilated-conv and mode-0
+    output-projection operands (ptpp_diffnet_pack_wstream)."""
+    lib = _lib.load()
+    L = len(dil_wps)
+    ws = torch.empty((L, lib.ptpp_diffnet_wstream_bytes(int(C))), device=dil_wps[0].device, dtype=torch.uint8)
+    t1 = (ctypes.c_void_p * L)(*[t.data_ptr() for t in dil_wps])
+    t2 = (ctypes.c_void_p * L)(*[t.data_ptr() for t in out_wps])
+    check(lib.ptpp_diffnet_pack_wstream(ctypes.cast(t1, ctypes.c_void_p), ctypes.cast(t2, ctypes.c_void_p), ws.data_ptr(), L, int(C),
+                                        _stream()), "ptpp_diffnet_pack_wstream")
+    return ws
+
+
+def diffnet_layer_fwd(yin, x, cond, wstream, dil_b, out_b, dnext, skip, dil, init, lengths=None, save=False, want_yin=True):
+    """One DiffNet residual layer in ONE launch (ptpp_diffnet_layer_fwd, reference modules/denoiser.py:69-83): returns
+    (xn, yin_next, a, g); ``skip`` (f32) is updated in place; ``cond``: this layer's (B, T, 2C) slice (a view with the row
+    stride of the all-layer tensor), gate-interleaved like ``dil_b``.  ``save``: keep a (B,T,2C) and g (B,T,C) (training)."""
+    B, T, C = x.shape
+    assert yin.is_contiguous() and x.is_contiguous() and skip.is_contiguous() and skip.dtype == torch.float32 and cond.stride(2) == 1
+    xn = torch.empty_like(x)
+    yn = torch.empty_like(x) if (want_yin and dnext is not None) else None
+    a = torch.empty((B, T, 2 * C), device=x.device, dtype=x.dtype) if save else None
+    g = torch.empty_like(x) if save else None
+    if lengths is not None:
+        lengths = i32(lengths, x.device)
+    args = _lib.DiffNetLayerArgs()
+    args.yin, args.x, args.cond, args.wstream = yin.data_ptr(), x.data_ptr(), cond.data_ptr(), wstream.data_ptr()
+    args.dil_b, args.out_b, args.skip, args.xn = dil_b.data_ptr(), out_b.data_ptr(), skip.data_ptr(), xn.data_ptr()
+    args.dnext = dnext.data_ptr() if dnext is not None else None
+    args.yin_next = yn.data_ptr() if yn is not None else None
+    args.a_out = a.data_ptr() if save else None
+    args.g_out = g.data_ptr() if save else None
+    args.lengths = lengths.data_ptr() if lengths is not None else None
+    args.B, args.T, args.C, args.dil, args.ldc, args.init, args.dtype = B, T, C, int(dil), cond.stride(1), 1 if init else 0, dtype_code(x.dtype)
+    check(_lib.load().ptpp_diffnet_layer_fwd(ctypes.byref(args), _stream()), "ptpp_diffnet_layer_fwd")
+    return xn, yn, a, g
+
+
 _gsave_ok = {}
 
 

@@ -129,7 +129,7 @@ def test_ctypes_structures_match_the_header(tmp_path):
         import pytest
 
         pytest.skip("no gcc")
-    pairs = [("ptpp_conv1d_args", _lib.ConvArgs), ("ptpp_wgrad_problem", _lib.WgradProblem), ("ptpp_wgrad_gproblem", _lib.WgradGProblem), ("ptpp_diffnet_stack_fwd_args", _lib.DiffNetFwdArgs),
+    pairs = [("ptpp_conv1d_args", _lib.ConvArgs), ("ptpp_wgrad_problem", _lib.WgradProblem), ("ptpp_wgrad_gproblem", _lib.WgradGProblem), ("ptpp_diffnet_stack_fwd_args", _lib.DiffNetFwdArgs), ("ptpp_diffnet_layer_args", _lib.DiffNetLayerArgs),
              ("ptpp_diffnet_stack_bwd_args", _lib.DiffNetBwdArgs), ("ptpp_encoder_layers_fwd_args", _lib.EncoderLayersFwdArgs),
              ("ptpp_conv_ln_stack_fwd_args", _lib.ConvLnFwdArgs), ("ptpp_conv_ln_stack_bwd_args", _lib.ConvLnBwdArgs),
              ("ptpp_conformer_weights", _lib.ConformerWeights), ("ptpp_conformer_grads", _lib.ConformerGrads),

@@ -1,0 +1,154 @@
+"""GPU: the one-launch DiffNet residual layer (csrc/diffnet_layer.hip, ptpp_diffnet_layer_fwd; reference
+modules/denoiser.py:69-83) against (a) the two launches it replaces -- same accumulation order and rounding points, so every
+output must be equal BIT FOR BIT -- and (b) the f32 oracle of the layer."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+C = 256
+
+
+def _case(dev, B, T, seed, ldc_layers=3, layer=1):
+    g = torch.Generator().manual_seed(1000 + seed)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    x = r(B, T, C).bfloat16()
+    dstep = r(B, C).float()
+    yin = (x.float() + dstep[:, None, :]).bfloat16()
+    cond_all = r(B, T, ldc_layers * 2 * C, sc=0.7).bfloat16()  # the layer reads a slice with the row stride of all layers
+    dil_w, dil_b = r(2 * C, C, 3, sc=0.04), r(2 * C, sc=0.1)
+    out_w, out_b = r(2 * C, C, 1, sc=0.06), r(2 * C, sc=0.1)
+    dnext = r(B, C).float()
+    skip0 = r(B, T, C).float()
+    return x, yin, cond_all, cond_all[:, :, layer * 2 * C:(layer + 1) * 2 * C], dil_w, dil_b, out_w, out_b, dnext, skip0
+
+
+def _two_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, skip, dil, init, lengths, save):
+    perm = PF._gate_perm(2 * C, x.device)
+    wp = ops.pack_conv_weight(dil_w[perm], torch.bfloat16)
+    bp = dil_b[perm].contiguous()
+    B, T, _ = x.shape
+    g = torch.empty_like(x)
+    a = None
+    if save:
+        a = torch.empty((B, T, 2 * C), device=x.device, dtype=x.dtype)
+        ops.conv1d_gate_fwd_save(yin, wp, bp, C, 3, dil, dil, cond, g, a, lengths=lengths)
+    else:
+        ops.conv1d(yin, wp, bp, 2 * C, ks=3, dil=dil, pad=dil, act="gate", res=cond, out=g)
+    xn, yn = ops.conv1d_diffnet_post(g, ops.pack_conv_weight(out_w, torch.bfloat16), out_b, x, skip, dnext, init=init, lengths=lengths,
+                                     out_mask=lengths is not None)
+    return xn, yn, a, g
+
+
+def _one_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, skip, dil, init, lengths, save):
+    perm = PF._gate_perm(2 * C, x.device)
+    wp = ops.pack_conv_weight(dil_w, torch.bfloat16, 2)
+    assert torch.equal(wp, ops.pack_conv_weight(dil_w[perm], torch.bfloat16))
+    ws = ops.diffnet_pack_wstream([wp], [ops.pack_conv_weight(out_w, torch.bfloat16)], C)
+    return ops.diffnet_layer_fwd(yin, x, cond, ws[0], dil_b[perm].contiguous(), out_b, dnext, skip, dil, init, lengths=lengths, save=save)
+
+
+@pytest.mark.parametrize("B,T,dil,masked,save,init", [
+    (3, 300, 1, True, True, False),
+    (2, 128, 2, False, True, True),      # exactly one tile per utterance
+    (5, 517, 4, True, True, False),      # a ragged last tile, utterances ending inside and before tiles
+    (4, 1000, 8, False, False, False),   # inference: no a / g, the gate from the unrounded pre-activation
+    (1, 37, 8, False, False, True),      # shorter than the dilated window
+    (7, 260, 8, True, True, True),
+])
+def test_one_launch_layer_is_bit_identical_to_the_two_launches(dev, B, T, dil, masked, save, init):
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd import ops
+
+    if not ops.diffnet_layer_supported(C, torch.bfloat16):
+        pytest.skip("one-launch DiffNet layer not built for this shape")
+    x, yin, _, cond, dil_w, dil_b, out_w, out_b, dnext, skip0 = _case(dev, B, T, seed=dil + T)
+    lengths = None
+    if masked:  # includes an utterance whose last tiles lie wholly past its end
+        lengths = torch.tensor([max(1, T - 150 * i) for i in range(B)], device=dev, dtype=torch.int32)
+    s_ref, s_got = skip0.clone(), skip0.clone()
+    ref = _two_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, s_ref, dil, init, lengths, save)
+    got = _one_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, s_got, dil, init, lengths, save)
+    torch.cuda.synchronize()
+    names = ["xn", "yin_next", "a", "g"]
+    for n, a, b in zip(names, ref, got):
+        if n in ("a", "g") and not save:
+            assert b is None
+            continue
+        assert torch.equal(a, b), (n, float((a.float() - b.float()).abs().max()), int((a != b).sum()))
+    assert torch.equal(s_ref, s_got), float((s_ref - s_got).abs().max())
+    assert float(ref[0].float().abs().max()) > 0 and float(s_ref.abs().max()) > 0
+
+
+def test_one_launch_layer_matches_the_f32_oracle(dev):
+    """The reference arithmetic (modules/denoiser.py:69-83) in f32 on the CPU against the bf16 kernel: conv + conditioner,
+    gate, output projection, residual / skip -- bf16 operand rounding is the only difference (tolerances 2e-2 of the
+    output scale; a transposed fragment or a wrong channel map would be O(1))."""
+    import torch.nn.functional as F
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd import ops
+
+    if not ops.diffnet_layer_supported(C, torch.bfloat16):
+        pytest.skip("one-launch DiffNet layer not built for this shape")
+    B, T, dil = 3, 333, 4
+    x, yin, _, cond, dil_w, dil_b, out_w, out_b, dnext, skip0 = _case(dev, B, T, seed=11)
+    skip = skip0.clone()
+    xn, yn, a, g = _one_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, skip, dil, False, None, True)
+    torch.cuda.synchronize()
+    # oracle: standard channel order; cond is stored gate-interleaved -> undo the permutation
+    perm = PF._gate_perm(2 * C, x.device)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(2 * C, device=perm.device)
+    cond_std = cond.float()[:, :, inv].cpu()
+    bw = lambda w: w.bfloat16().float().cpu()
+    y = F.conv1d(yin.float().cpu().transpose(1, 2), bw(dil_w), dil_b.cpu(), padding=dil, dilation=dil).transpose(1, 2) + cond_std
+    a_ref = y
+    g_ref = torch.sigmoid(y[:, :, :C]) * torch.tanh(y[:, :, C:])
+    o = F.conv1d(g_ref.transpose(1, 2), bw(out_w), out_b.cpu()).transpose(1, 2)
+    xn_ref = (x.float().cpu() + o[:, :, :C]) / math.sqrt(2.0)
+    skip_ref = skip0.cpu() + o[:, :, C:]
+    yn_ref = xn_ref + dnext.cpu()[:, None, :]
+
+    def close(got, ref, tol):
+        err = float((got.float().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < tol, err
+
+    close(a, a_ref, 1e-2)
+    close(g, g_ref, 2e-2)
+    close(xn, xn_ref, 2e-2)
+    close(yn, yn_ref, 2e-2)
+    close(skip, skip_ref, 2e-2)
+
+
+def test_stack_driver_takes_the_one_launch_layer(dev, monkeypatch):
+    """ptpp_diffnet_stack_fwd with the operand stream (training form, 20 layers, all four dilations, ragged batch) against the
+    same driver without it: skip sum and every saved slab bit-identical; the stream follows a weight update."""
+    from promptttspp_amd import functional as PF
+    from test_stack_drivers import _stack_case
+
+    B, T, L = 4, 421, 8
+    h0, cond, dsteps, lengths, params = _stack_case(dev, B, T, C, L, torch.bfloat16, True, seed=21)
+    ws = params
+
+    def run():
+        with torch.no_grad():
+            gate_b, cond_b = PF.gate_biases([w[1] for w in ws], [w[3] for w in ws])
+            cond_all, _ = PF.diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws], bias_perm=cond_b)
+            return PF.diffnet_stack_forward(h0, cond_all, dsteps, [(w[0], w[1], w[4], w[5]) for w in ws], lengths, 4, save=True, gate_b=gate_b)
+
+    for rnd in range(2):
+        monkeypatch.setattr(PF, "DIFFNET_LAYER_KERNEL", False)
+        skip_ref, saved_ref = run()
+        monkeypatch.setattr(PF, "DIFFNET_LAYER_KERNEL", True)
+        skip_got, saved_got = run()
+        torch.cuda.synchronize()
+        assert torch.equal(skip_ref, skip_got)
+        for a, b in zip(saved_ref, saved_got):
+            assert torch.equal(a, b)
+        with torch.no_grad():  # the cached stream must follow the weights
+            for w in ws:
+                w[0].mul_(1.25)
+                w[4].add_(0.01)
