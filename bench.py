@@ -152,9 +152,26 @@ def box_calibration(dev):
         torch.matmul(a, b)
     e[2].record()
     torch.cuda.synchronize()
-    return {"copy_gbs": round(10 * 2 * 2 * n / (e[0].elapsed_time(e[1]) * 1e-3) / 1e9, 1),
-            "hipblaslt_bf16_8192_tflops": round(10 * 2 * 8192 ** 3 / (e[1].elapsed_time(e[2]) * 1e-3) / 1e12, 1),
-            "device": torch.cuda.get_device_name(dev)}
+    out = {"copy_gbs": round(10 * 2 * 2 * n / (e[0].elapsed_time(e[1]) * 1e-3) / 1e9, 1),
+           "hipblaslt_bf16_8192_tflops": round(10 * 2 * 8192 ** 3 / (e[1].elapsed_time(e[2]) * 1e-3) / 1e12, 1),
+           "device": torch.cuda.get_device_name(dev)}
+    del x, y, a, b
+    # what the hot path's own GEMM SHAPES allow on this box (library GEMM with the taps folded into K: an upper bound for a
+    # conv of that shape; tools/bench_gemm_calibration.py has the full table): the DiffNet dilated conv and a phone-level FFN conv
+    for key, (M, K, N) in (("hipblaslt_bf16_30000x768x512_tflops", (30000, 768, 512)),
+                           ("hipblaslt_bf16_2850x2304x1024_tflops", (2850, 2304, 1024))):
+        a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+        b = torch.randn(K, N, device=dev, dtype=torch.bfloat16)
+        for _ in range(3):
+            torch.matmul(a, b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            torch.matmul(a, b)
+        e1.record()
+        torch.cuda.synchronize()
+        out[key] = round(20 * 2.0 * M * K * N / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    return out
 
 
 def conv_roofline(model, batch, red, opt, sched, dtype_name):
@@ -662,6 +679,8 @@ def main():
         train_step(model, batches[i], red, opt, sched)
         torch.cuda.synchronize()
         log(f"warmup step {i} done")
+    if world > 1 or os.environ.get("PTPP_DP_FORCE_COLLECTIVES"):
+        red.enable_timing()  # three event records per step on the main stream: what the exchange costs it (the "dp" object below)
     barrier()
     t0 = time.perf_counter()
     frames = 0
@@ -674,13 +693,26 @@ def main():
     loss = float(out["loss"])
     log(f"timed region done: {dt:.3f}s for {a.steps} steps, loss {loss:.4f}")
 
+    dp = None
+    if getattr(red, "_timing", None) is not None:
+        dp = red.timing_summary()
     if world > 1:
         import torch.distributed as dist
 
         tt = torch.tensor([dt, float(frames)], device=dev, dtype=torch.float64)
-        tmax = tt.clone()
+        tmax, tmin = tt.clone(), tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        ex = torch.tensor([dp["exposed_allreduce_ms"] or 0.0, dp["join_gradient_streams_ms"] or 0.0], device=dev, dtype=torch.float64)
+        exmax = ex.clone()
+        dist.all_reduce(exmax, op=dist.ReduceOp.MAX)
+        # per-rank wall time of the timed region (min / max over ranks, ms per step) and the exchange as the slowest rank saw it
+        dp.update({"rank_ms_per_step_min": round(1e3 * float(tmin[0]) / a.steps, 3),
+                   "rank_ms_per_step_max": round(1e3 * float(tmax[0]) / a.steps, 3),
+                   "frames_per_rank_min": float(tmin[1]), "frames_per_rank_max": float(tmax[1]),
+                   "exposed_allreduce_ms_max_over_ranks": round(float(exmax[0]), 4),
+                   "join_gradient_streams_ms_max_over_ranks": round(float(exmax[1]), 4)})
         dt, frames = float(tmax[0]), float(tt[1])
 
     voc = None
@@ -739,6 +771,7 @@ def main():
                        "utts_per_gpu_batch": int(B), "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
             "roofline": roof, "cpu_baseline": cpu,
             "per_gpu_value": round(frames / dt / world, 1),
+            "dp": dp,
             "bigvgan": voc,
             "app_path": app,
             "box": box_calibration(dev),

@@ -67,9 +67,9 @@ class FlatGradReducer:
     """Knobs for the first multi-GPU sweeps (environment, so the driver's bench command line stays fixed):
     ``PTPP_DP_BUCKET_MB`` (bucket size, default 128), ``PTPP_DP_ALGO`` = ``allreduce`` (default) | ``rs_ag``
     (reduce-scatter + all-gather of each bucket, in place), ``PTPP_DP_BACKEND`` = ``torch`` (default) | ``native``
-    (the C ABI's RCCL communicator), ``PTPP_DP_BROADCAST_BUFFERS=1`` (DDP's per-forward broadcast of the
-    BatchNorm running statistics, trainers/tts.py:117 ``broadcast_buffers=True`` default; off by default: each
-    rank keeps its own statistics and rank 0's are checkpointed -- DESIGN.md section 6)."""
+    (the C ABI's RCCL communicator), ``PTPP_DP_BROADCAST_BUFFERS=0`` (switch OFF DDP's per-forward broadcast of the
+    BatchNorm running statistics, trainers/tts.py:117 ``broadcast_buffers=True`` default; ON by default since round 4, ONE concatenated collective per
+    step; when switched off each rank keeps its own statistics and rank 0's are checkpointed -- DESIGN.md section 6)."""
 
     def __init__(self, params, bucket_elems=None, process_group=None, direct=True, algo=None, backend=None):
         self.params = [p for p in params if p.requires_grad]
@@ -156,7 +156,7 @@ class FlatGradReducer:
 
     def broadcast_buffers(self, module, src=0):
         """DDP's ``broadcast_buffers=True`` (the reference's default, trainers/tts.py:117): before a forward every
-        rank takes rank 0's BatchNorm running statistics.  Opt-in (``PTPP_DP_BROADCAST_BUFFERS=1``): it only changes
+        rank takes rank 0's BatchNorm running statistics.  On by default since round 4 like the reference's DDP (``PTPP_DP_BROADCAST_BUFFERS=0`` switches it off): it only changes
         what eval-mode BatchNorm would see on ranks other than 0, which never evaluate or checkpoint.  All
         statistics travel as ONE concatenated tensor (one collective per step instead of ~40)."""
         if self.world == 1:
@@ -244,13 +244,41 @@ class FlatGradReducer:
         self._seen = set()
         self._next = 0
 
+    # -- diagnostics of the exchange (bench.py --gpus N: the first 2/4/8-GPU run must tell where the time goes) ----------------
+    def enable_timing(self, on=True):
+        """Record three events per ``finish()`` on the calling stream: entry, gradient streams joined, collectives done.
+        ``timing_summary()`` turns them into the time the MAIN stream spent joining and -- beyond that -- waiting for
+        all-reduces that backward did not hide (``exposed``)."""
+        self._timing = [] if (on and self.flat.is_cuda) else None
+
+    def timing_summary(self, skip=0):
+        ev = getattr(self, "_timing", None) or []
+        torch.cuda.synchronize()
+        join = [a.elapsed_time(b) for a, b, _ in ev[skip:]]
+        exposed = [b.elapsed_time(c) for _, b, c in ev[skip:]]
+        mean = lambda v: round(sum(v) / len(v), 4) if v else None
+        be = (dist.get_backend(self.group) if self.collective else None)
+        return {"join_gradient_streams_ms": mean(join), "exposed_allreduce_ms": mean(exposed),
+                "exposed_allreduce_ms_max": round(max(exposed), 4) if exposed else None, "steps": len(join),
+                "buckets": len(self.buckets), "bucket_mb": [round((b - a) * 4 / 2**20, 1) for a, b, _ in self.buckets],
+                "backend": ("native-rccl" if self.native is not None else be), "algo": self.algo, "world": self.world}
+
     def finish(self):
         """Join the weight-gradient side stream, wait for the bucket all-reduces, turn sums into means."""
+        tm = getattr(self, "_timing", None)
+        if tm is not None:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
         if self.flat.is_cuda:
             from . import functional as PF
 
             PF.sync_wgrad_stream()
+        if tm is not None:
+            e1.record()
         if not self.collective:
+            if tm is not None:
+                e2.record()
+                tm.append((e0, e1, e2))
             return
         for bi in range(self._next, len(self.buckets)):  # buckets with parameters that received no gradient
             if not self._launched[bi]:
@@ -258,6 +286,9 @@ class FlatGradReducer:
         self._next = len(self.buckets)
         for w in self._works:
             w.wait()
+        if tm is not None:
+            e2.record()
+            tm.append((e0, e1, e2))
         if self.native is None:
             self.flat.mul_(1.0 / self.world)
         elif self.flat.is_cuda:

@@ -212,7 +212,7 @@ class TTSTrainer:
         if fused:
             optimizer.stable_grads = True      # ... for the whole run: FusedAdamW may skip its per-step pointer scan
         reducer.broadcast_parameters(model)    # DDP constructor semantics
-        bcast_buffers = world > 1 and bool(os.environ.get("PTPP_DP_BROADCAST_BUFFERS"))
+        bcast_buffers = world > 1 and os.environ.get("PTPP_DP_BROADCAST_BUFFERS", "1") not in ("0", "", "off", "no")  # DDP default (tts.py:117)
 
         train_dl, valid_dl, sampler = self._loaders(cfg, rank, world)
         global_step = (start_epoch - 1) * len(train_dl) + 1
