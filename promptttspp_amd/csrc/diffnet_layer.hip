@@ -393,70 +393,86 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     bf16_raw* xnb = p.xn + (int64_t)b * T * DN_C;
     bf16_raw* yib = p.yin_next ? p.yin_next + (int64_t)b * T * DN_C : nullptr;
     float* skb = p.skip + (int64_t)b * T * DN_C;
+    // biases / next step projection of the wave's 2 x 8 channels per lane
+    f32x4 bo[2][2], bs[2][2], dn[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int ch = wn * 64 + h * 32 + lg * 8;
-      // the residual and skip rows of this half of the wave's channels are requested together (two memory round trips per
-      // wave instead of eight; all sixteen vectors at once spilled)
-      uint4 xr[FM];
-      f32x4 sk[FM][2];
 #pragma unroll
-      for (int fm = 0; fm < FM; ++fm) {
-        const int t = t0 + wm * (16 * FM) + fm * 16 + lr;
+      for (int u = 0; u < 2; ++u) {
+        bo[h][u] = *reinterpret_cast<const f32x4*>(p.out_b + ch + 4 * u);
+        bs[h][u] = *reinterpret_cast<const f32x4*>(p.out_b + DN_C + ch + 4 * u);
+        dn[h][u] = p.dnext ? *reinterpret_cast<const f32x4*>(p.dnext + (int64_t)b * DN_C + ch + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    // Two row tiles (fm) at a time, BOTH channel halves of a row together: the wave's 64 channels of a row are one 128-byte
+    // line of x / xn / yin' (two 16-byte pieces per lane, h = 0 and 1) and two lines of skip -- issued back to back they
+    // meet in L1 / the L2 write combiner instead of being half-line accesses microseconds apart.  Twelve vectors per lane
+    // are in flight per round (all sixteen + the accumulators spilled).
+#pragma unroll
+    for (int f0 = 0; f0 < FM; f0 += 2) {
+      uint4 xr[2][2];
+      f32x4 sk[2][2][2];
+#pragma unroll
+      for (int df = 0; df < 2; ++df) {
+        const int t = t0 + wm * (16 * FM) + (f0 + df) * 16 + lr;
         const bool in = t < T && !((DBG & 8) && t > 0);
-        xr[fm] = make_uint4(0, 0, 0, 0);
-        sk[fm][0] = sk[fm][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (in) {
-          xr[fm] = *reinterpret_cast<const uint4*>(xb + (int64_t)t * DN_C + ch);
-          if (!p.init) {
-            sk[fm][0] = *reinterpret_cast<const f32x4*>(skb + (int64_t)t * DN_C + ch);
-            sk[fm][1] = *reinterpret_cast<const f32x4*>(skb + (int64_t)t * DN_C + ch + 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ch = wn * 64 + h * 32 + lg * 8;
+          xr[df][h] = make_uint4(0, 0, 0, 0);
+          sk[df][h][0] = sk[df][h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (in) {
+            xr[df][h] = *reinterpret_cast<const uint4*>(xb + (int64_t)t * DN_C + ch);
+            if (!p.init) {
+              sk[df][h][0] = *reinterpret_cast<const f32x4*>(skb + (int64_t)t * DN_C + ch);
+              sk[df][h][1] = *reinterpret_cast<const f32x4*>(skb + (int64_t)t * DN_C + ch + 4);
+            }
           }
         }
       }
-      f32x4 bo[2], bs[2], dn[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      bo[0] = *reinterpret_cast<const f32x4*>(p.out_b + ch);
-      bo[1] = *reinterpret_cast<const f32x4*>(p.out_b + ch + 4);
-      bs[0] = *reinterpret_cast<const f32x4*>(p.out_b + DN_C + ch);
-      bs[1] = *reinterpret_cast<const f32x4*>(p.out_b + DN_C + ch + 4);
-      if (p.dnext) {
-        dn[0] = *reinterpret_cast<const f32x4*>(p.dnext + (int64_t)b * DN_C + ch);
-        dn[1] = *reinterpret_cast<const f32x4*>(p.dnext + (int64_t)b * DN_C + ch + 4);
-      }
 #pragma unroll
-      for (int fm = 0; fm < FM; ++fm) {
+      for (int df = 0; df < 2; ++df) {
+        const int fm = f0 + df;
         const int t = t0 + wm * (16 * FM) + fm * 16 + lr;
         if (t >= T || ((DBG & 8) && t > 0)) continue;
         const bool keep = !(masked && t >= len);
-        const uint4 xv4 = xr[fm];
-        const float xv[8] = {lo_bf16(xv4.x), hi_bf16(xv4.x), lo_bf16(xv4.y), hi_bf16(xv4.y), lo_bf16(xv4.z), hi_bf16(xv4.z), lo_bf16(xv4.w), hi_bf16(xv4.w)};
-        float xn[8], yi[8];
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {  // (o rounded to bf16 in pairs: one conversion instruction per two values)
-          const uint32_t ob = pack_bf16x2(acc[0][fm][2 * h + (e >> 2)][e & 3] + bo[e >> 2][e & 3],
-                                          acc[0][fm][2 * h + (e >> 2)][(e & 3) + 1] + bo[e >> 2][(e & 3) + 1]);
-          const float o0 = keep ? lo_bf16(ob) : 0.f, o1 = keep ? hi_bf16(ob) : 0.f;
-          xn[e] = (xv[e] + o0) * r2;
-          xn[e + 1] = (xv[e + 1] + o1) * r2;
-          yi[e] = xn[e] + dn[e >> 2][e & 3];
-          yi[e + 1] = xn[e + 1] + dn[e >> 2][(e & 3) + 1];
-        }
-        *reinterpret_cast<uint4*>(xnb + (int64_t)t * DN_C + ch) =
-            make_uint4(pack_bf16x2(xn[0], xn[1]), pack_bf16x2(xn[2], xn[3]), pack_bf16x2(xn[4], xn[5]), pack_bf16x2(xn[6], xn[7]));
-        if (yib)
-          *reinterpret_cast<uint4*>(yib + (int64_t)t * DN_C + ch) =
-              make_uint4(pack_bf16x2(yi[0], yi[1]), pack_bf16x2(yi[2], yi[3]), pack_bf16x2(yi[4], yi[5]), pack_bf16x2(yi[6], yi[7]));
-        float* sp = skb + (int64_t)t * DN_C + ch;
+        for (int h = 0; h < 2; ++h) {
+          const int ch = wn * 64 + h * 32 + lg * 8;
+          const uint4 xv4 = xr[df][h];
+          const float xv[8] = {lo_bf16(xv4.x), hi_bf16(xv4.x), lo_bf16(xv4.y), hi_bf16(xv4.y), lo_bf16(xv4.z), hi_bf16(xv4.z), lo_bf16(xv4.w), hi_bf16(xv4.w)};
+          float xn[8], yi[8];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          f32x4 sv = sk[fm][u];
-#pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const uint32_t ob = pack_bf16x2(acc[1][fm][2 * h + u][e] + bs[u][e], acc[1][fm][2 * h + u][e + 1] + bs[u][e + 1]);
-            sv[e] = (keep ? lo_bf16(ob) : 0.f) + sv[e];
-            sv[e + 1] = (keep ? hi_bf16(ob) : 0.f) + sv[e + 1];
+          for (int e = 0; e < 8; e += 2) {  // (o rounded to bf16 in pairs: one conversion instruction per two values)
+            const uint32_t ob = pack_bf16x2(acc[0][fm][2 * h + (e >> 2)][e & 3] + bo[h][e >> 2][e & 3],
+                                            acc[0][fm][2 * h + (e >> 2)][(e & 3) + 1] + bo[h][e >> 2][(e & 3) + 1]);
+            const float o0 = keep ? lo_bf16(ob) : 0.f, o1 = keep ? hi_bf16(ob) : 0.f;
+            xn[e] = (xv[e] + o0) * r2;
+            xn[e + 1] = (xv[e + 1] + o1) * r2;
+            yi[e] = xn[e] + dn[h][e >> 2][e & 3];
+            yi[e + 1] = xn[e + 1] + dn[h][e >> 2][(e & 3) + 1];
           }
-          *reinterpret_cast<f32x4*>(sp + 4 * u) = sv;
+          *reinterpret_cast<uint4*>(xnb + (int64_t)t * DN_C + ch) =
+              make_uint4(pack_bf16x2(xn[0], xn[1]), pack_bf16x2(xn[2], xn[3]), pack_bf16x2(xn[4], xn[5]), pack_bf16x2(xn[6], xn[7]));
+          if (yib)
+            *reinterpret_cast<uint4*>(yib + (int64_t)t * DN_C + ch) =
+                make_uint4(pack_bf16x2(yi[0], yi[1]), pack_bf16x2(yi[2], yi[3]), pack_bf16x2(yi[4], yi[5]), pack_bf16x2(yi[6], yi[7]));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float* sp = skb + (int64_t)t * DN_C + wn * 64 + h * 32 + lg * 8;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            f32x4 sv = sk[df][h][u];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const uint32_t ob = pack_bf16x2(acc[1][fm][2 * h + u][e] + bs[h][u][e], acc[1][fm][2 * h + u][e + 1] + bs[h][u][e + 1]);
+              sv[e] = (keep ? lo_bf16(ob) : 0.f) + sv[e];
+              sv[e + 1] = (keep ? hi_bf16(ob) : 0.f) + sv[e + 1];
+            }
+            *reinterpret_cast<f32x4*>(sp + 4 * u) = sv;
+          }
         }
       }
     }

@@ -120,7 +120,57 @@ def fine(B, T, dil, save, masked, mode=17):
             print(f"   wave {0 if w == 0 else 5} step {16 + s_}: " + " ".join(f"{rel[w, s_, k]:7.0f}" for k in range(6)))
 
 
+def chains(B, T, save, L=20, delay_us=30.0):
+    """L layer launches in sequence (one chain over the whole batch) against TWO half-batch chains on two streams, the second
+    one started ``delay_us`` later: every block of a launch walks the same phases in lock step (MFMA passes, then HBM-bound
+    epilogues), so two chains half a layer apart keep both the matrix cores and the memory system busy."""
+    def mk(Bh):
+        two, one = case(Bh, T, 8, save, False)
+        return one
+    full = mk(B)
+    h1, h2 = mk(B // 2), mk(B - B // 2)
+    s2 = torch.cuda.Stream()
+
+    def run_full():
+        for _ in range(L):
+            full()
+
+    def run_split(delay):
+        main = torch.cuda.current_stream()
+        s2.wait_stream(main)
+        with torch.cuda.stream(s2):
+            if delay > 0:
+                torch.cuda._sleep(int(delay * 2100))  # cycles at ~2.1 GHz
+            from promptttspp_amd import ops as _o
+            with _o.unpinned():
+                for _ in range(L):
+                    h2()
+        for _ in range(L):
+            h1()
+        main.wait_stream(s2)
+
+    for name, f in (("one chain", run_full), ("two half-batch chains, no delay", lambda: run_split(0.0)),
+                    (f"two half-batch chains, second delayed {delay_us:.0f} us", lambda: run_split(delay_us)),
+                    (f"two half-batch chains, second delayed {2 * delay_us:.0f} us", lambda: run_split(2 * delay_us))):
+        ts = []
+        for _ in range(5):
+            f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            f()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / L)
+        print(f"B {B} T {T} {'train' if save else 'infer'} {name:52s}: {min(ts):7.1f} us per layer", flush=True)
+
+
 def main():
+    if os.environ.get("PTPP_BENCH_CHAINS"):
+        chains(19, 1550, True)
+        chains(19, 1550, False)
+        chains(32, 590, False)
+        return
     if os.environ.get("PTPP_BENCH_FINE"):
         fine(19, 1550, 8, False, False, 17)
         fine(19, 1550, 8, False, False, 23)

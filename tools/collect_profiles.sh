@@ -4,7 +4,7 @@
 #   <tag>_bigvgan.md            ... of tools/bench_vocoder.py
 #   <tag>_hbm_traffic_*.json    FETCH_SIZE / WRITE_SIZE passes (separate, with --kernel-trace only) -> tools/pmc_traffic.py
 #   <tag>_pmc_sq_mfma.txt       SQ wave-state / MFMA-busy counters of the training leg -> tools/pmc_summary.py
-tag=${1:-r03}; out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out
+tag=${1:-r04}; out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TRAIN="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vocoder --no-app"
@@ -12,9 +12,9 @@ TRAIN2="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder -
 VOC="python $R/tools/bench_vocoder.py --iters 2"
 rm -rf /tmp/p_*
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_train -o t -- $TRAIN > $out/train.log 2>&1
-python $R/tools/prof_summary.py /tmp/p_train $out/${tag}_train_step.md "training leg of bench.py (20 timed + 5 warm-up + 1 instrumented step), round 3" > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/p_train $out/${tag}_train_step.md "training leg of bench.py (20 timed + 5 warm-up + 1 instrumented step), round 4" > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_voc -o v -- python $R/tools/bench_vocoder.py --iters 3 > $out/voc.log 2>&1
-python $R/tools/prof_summary.py /tmp/p_voc $out/${tag}_bigvgan.md "tools/bench_vocoder.py --iters 3 (5 forwards of 64 x 1000 frames, bf16), round 3" > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/p_voc $out/${tag}_bigvgan.md "tools/bench_vocoder.py --iters 3 (5 forwards of 64 x 1000 frames, bf16), round 4" > /dev/null 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_ft -- $TRAIN2 > $out/pmc_ft.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_wt -- $TRAIN2 > $out/pmc_wt.log 2>&1
 python $R/tools/pmc_traffic.py /tmp/p_ft /tmp/p_wt $out/${tag}_hbm_traffic_train.json "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-app" 4 > $out/traffic_train.txt 2>&1
