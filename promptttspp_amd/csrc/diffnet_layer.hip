@@ -25,6 +25,8 @@
 //   * pass B, 16 steps (k32 step kc, channel half nh): nh = 0 is the residual half, nh = 1 the skip half.
 //   * tail: xn / yin' / skip straight from the accumulators.
 // LDS: NS x 16 KiB ring + 64 KiB = 144 KiB (NS = 5): one block per CU; a 30 000-frame batch is 235 blocks on 256 CUs.
+#include <stdlib.h>
+
 #include "conv1d_common.h"
 #include "lds_dma.h"
 
@@ -415,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       f32x4 sk[2][2][2];
 #pragma unroll
       for (int df = 0; df < 2; ++df) {
+        if (f0 + df >= FM) continue;  // (FM = 3: the last round has one tile)
         const int t = t0 + wm * (16 * FM) + (f0 + df) * 16 + lr;
         const bool in = t < T && !((DBG & 8) && t > 0);
 #pragma unroll
@@ -433,9 +436,9 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       }
 #pragma unroll
       for (int df = 0; df < 2; ++df) {
-        const int fm = f0 + df;
+        const int fm = f0 + df < FM ? f0 + df : FM - 1;
         const int t = t0 + wm * (16 * FM) + fm * 16 + lr;
-        if (t >= T || ((DBG & 8) && t > 0)) continue;
+        if (f0 + df >= FM || t >= T || ((DBG & 8) && t > 0)) continue;
         const bool keep = !(masked && t >= len);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -596,13 +599,25 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
   p.g_out = reinterpret_cast<bf16_raw*>(a->g_out);
   p.lengths = a->lengths;
   p.B = a->B; p.T = a->T; p.dil = a->dil; p.ldc = a->ldc; p.init = a->init;
-  // 128-row tiles where they fill the chip (a 30 000-frame training batch: 235 blocks); 64-row tiles for smaller batches (the
-  // sampler's 32 x ~400 frames: 128 blocks of 128 rows would leave half of the 256 CUs idle)
-  // (a block holds 112-144 KiB of LDS: one block per CU, so a launch runs in rounds of 256 blocks; 64-row tiles only while they
-  //  fit ONE round -- two rounds of 64-row blocks (2 x 35 us) lose to one round of 128-row blocks (58 us))
-  const int64_t blocks64 = (int64_t)a->B * ((a->T + 63) / 64);
-  const bool small = blocks64 <= 256 && !(dbg & 16);
-  const int bm = small ? 64 : 128;
+  // A block holds 96-144 KiB of LDS: one block per CU, a launch runs in rounds of 256 blocks.  Rows per block (128 / 96 / 64):
+  // the choice with the least (rounds x time of one block) -- block times measured on the inference form, 57 / 46 / 35 us
+  // (tools/bench_diffnet_layer.py); a 30 000-frame training bucket takes 128 (235 blocks), the sampler's 32 x 540 frames 96
+  // (192 blocks: 64-row tiles would need two rounds, 128-row tiles leave 96 CUs idle).
+  int bm = 128;
+  {
+    const int cand[3] = {128, 96, 64};
+    const float tblk[3] = {57.f, 46.f, 35.f};
+    float best = 1e30f;
+    for (int i = 0; i < 3; ++i) {
+      const int64_t nb = (int64_t)a->B * ((a->T + cand[i] - 1) / cand[i]);
+      const float cost = (float)((nb + 255) / 256) * tblk[i];
+      if (cost < best - 0.5f) { best = cost; bm = cand[i]; }
+    }
+    if (dbg & 16) bm = 128;
+    const char* force = getenv("PTPP_DIFFNET_BM");  // (experiments)
+    if (force && (atoi(force) == 64 || atoi(force) == 96 || atoi(force) == 128)) bm = atoi(force);
+  }
+  const bool small = bm == 64;
   p.nMT = (a->T + bm - 1) / bm;
   constexpr int NS = 5;
   const size_t smem = (size_t)(NS * DN_STAGE_U4 + bm * 32) * 16 + ((dbg & 16) ? 1024 : 0);
@@ -610,6 +625,8 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
   const bool sv = a->a_out != nullptr;
   auto kern = sv ? diffnet_layer_kernel<NS, true> : diffnet_layer_kernel<NS, false>;
   if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 2> : diffnet_layer_kernel<NS, false, 0, 2>;
+  if (bm == 96) kern = sv ? diffnet_layer_kernel<NS, true, 0, 3> : diffnet_layer_kernel<NS, false, 0, 3>;
+  if (bm == 96 && dbg) { ptpp_set_error("diffnet_layer_fwd_dbg: the 96-row instantiation has no diagnostics build"); return PTPP_EINVAL; }
   if (dbg) {
     switch (dbg + (small ? 100 : 0)) {
       case 1: kern = sv ? diffnet_layer_kernel<NS, true, 1> : diffnet_layer_kernel<NS, false, 1>; break;

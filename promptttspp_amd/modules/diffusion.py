@@ -202,7 +202,7 @@ class GaussianDiffusion(nn.Module):
             return self.inference_plms_cl(cond, int(self.pndm_speedup), noise_fn)
         B, T, _ = cond.shape
         if self.split_streams and cond.is_cuda and B >= 4 and B * T >= self.split_min_rows and self.K_step > 3 \
-                and not torch.cuda.is_current_stream_capturing():
+                and not torch.cuda.is_current_stream_capturing() and not self._one_launch_layers(cond):
             return self._inference_split(cond, noise_fn)
         shape = (B, T, self.out_dim)
         draw = noise_fn if noise_fn is not None else (lambda i, s: torch.randn(s, device=cond.device))
@@ -247,7 +247,18 @@ class GaussianDiffusion(nn.Module):
     # streams, one HIP graph each.  A denoiser launch of the whole batch is 1-2 rounds of workgroups with a ragged last round
     # and a serial prologue / epilogue per workgroup; two half-size launches side by side fill each other's gaps
     # (profiles/r03_sampler_split.txt).  Same arithmetic per utterance: the result is bit-identical to the unsplit loop.
+    # Round 4: with the one-launch DiffNet layer (csrc/diffnet_layer.hip: one workgroup per CU, rows per block chosen so that
+    # the whole batch is ONE round of workgroups) two half-batch launches only queue behind each other: 156.8 ms split against
+    # 146.2 ms unsplit for config 5's 32 prompts -- the split stays for the shapes that kernel does not serve.
     split_streams = __import__("os").environ.get("PTPP_SAMPLER_SPLIT", "1") not in ("0", "off", "no")
+
+    def _one_launch_layers(self, cond):
+        from .. import functional as PF
+
+        fn = self.denoise_fn
+        C = getattr(fn, "residual_channels", None) or fn.input_projection.weight.shape[0]
+        return PF.DIFFNET_LAYER_KERNEL and PF.STACK_DRIVERS and PF.diffnet_fused_gate(cond.dtype) and ops.diffnet_layer_supported(C, cond.dtype)
+
     split_min_rows = 8192
     split_ways = int(__import__("os").environ.get("PTPP_SAMPLER_WAYS", "2"))
 

@@ -59,9 +59,14 @@ def _one_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, skip, 
     (1, 37, 8, False, False, True),      # shorter than the dilated window
     (7, 260, 8, True, True, True),
 ])
-def test_one_launch_layer_is_bit_identical_to_the_two_launches(dev, B, T, dil, masked, save, init):
+@pytest.mark.parametrize("bm", [64, 96, 128])
+def test_one_launch_layer_is_bit_identical_to_the_two_launches(dev, monkeypatch, B, T, dil, masked, save, init, bm):
+    """``bm``: rows per block (PTPP_DIFFNET_BM pins what the launcher otherwise picks from the block count: all three
+    instantiations must agree with the two-launch path on every shape)."""
     from promptttspp_amd import functional as PF
     from promptttspp_amd import ops
+
+    monkeypatch.setenv("PTPP_DIFFNET_BM", str(bm))
 
     if not ops.diffnet_layer_supported(C, torch.bfloat16):
         pytest.skip("one-launch DiffNet layer not built for this shape")
