@@ -549,6 +549,74 @@ def test_model_bf16_train_step_is_close(dev):
         assert abs(float(out[k]) - ref) < 5e-2 * max(1.0, abs(ref)), (k, float(out[k]), ref)
 
 
+def test_bf16_training_trajectory_tracks_f32(dev):
+    """The benchmarked dtype held to the parity dtype over OPTIMISER STEPS, not just one forward: the same model, the same
+    batch (tests/golden/model_forward.npz), dropout off, the diffusion step and noise injected, N steps of the fused
+    clip + AdamW in f32 mode (whose first step is pinned to the reference by test_model_train_step_losses_and_grads) and in bf16
+    mode.  Bounds (per loss term, relative to max(1, |loss|), measured 1.5-4x below them): total 3e-2, diffusion loss 3e-3,
+    duration MDN 2.5e-1, log-F0 / V-UV 7e-2, style MDN 1e-3; the total loss decreases by the same amount within 15 %; the parameter update of the whole run agrees
+    with the f32 run's to a relative L2 of 0.6 and a cosine of 0.8 (Adam normalises by |g|: an element whose gradient is rounding noise moves
+    by +-lr in either run, so this bound is loose by construction -- the loss trajectory is the statement)."""
+    from promptttspp_amd import config
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd.optim import FusedAdamW
+    from promptttspp_amd.parallel import FlatGradReducer
+
+    N = 6
+    keys = ("loss", "dec", "dur", "cf0", "vuv", "style")
+
+    def run(dt):
+        m, g = _model(dev)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            for a in ("dropout_rate", "positional_dropout_rate", "p_dropout", "p"):
+                if isinstance(getattr(mod, a, None), float):
+                    setattr(mod, a, 0.0)
+        m.train()
+        params = [p for p in m.parameters() if p.requires_grad]
+        p0 = torch.cat([p.detach().flatten().clone() for p in params])
+        traj = []
+        with config.use_dtype(dt):
+            PF.clear_caches()
+            red = FlatGradReducer(params)
+            opt = FusedAdamW(params, lr=2e-5, max_grad_norm=1.0)  # (small enough that the f32 trajectory itself is smooth)
+            try:
+                for _ in range(N):
+                    red.zero_grad()
+                    m.decoder.injected = {"t": g["t"], "noise": g["noise"]}
+                    PF.manual_seed(11)
+                    out = m(_batch(g, dev))
+                    out["loss"].backward()
+                    red.finish()
+                    opt.step()
+                    traj.append([float(out[k]) for k in keys])
+            finally:
+                PF.enable_direct_grads(False)
+                PF.clear_caches()
+        torch.cuda.synchronize()
+        p1 = torch.cat([p.detach().flatten() for p in params])
+        return np.asarray(traj), (p1 - p0).double().cpu()
+
+    ref, dref = run(torch.float32)
+    got, dgot = run(torch.bfloat16)
+    assert np.isfinite(got).all() and ref[0, 0] > ref[-1, 0], "the f32 run must make progress"
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    print("per-step deviation of (loss, dec, dur, cf0, vuv, style):\n", np.array2string(err, precision=4), "\nf32:\n",
+          np.array2string(ref, precision=4), "\nbf16:\n", np.array2string(got, precision=4))
+    # measured: total 2.1e-2, decoder (diffusion) loss 8e-4, duration MDN 1.6e-1 (the two-layer predictor's NLL moves in
+    # steps; its trajectory is a step ahead / behind rather than off), log-F0 4e-2, V/UV 3e-2, style MDN 1e-5
+    bounds = np.asarray([3e-2, 3e-3, 2.5e-1, 7e-2, 7e-2, 1e-3])
+    assert (err.max(axis=0) < bounds).all(), (err.max(axis=0), bounds)
+    drop_ref, drop_got = ref[0, 0] - ref[-1, 0], got[0, 0] - got[-1, 0]
+    assert abs(drop_got - drop_ref) < 0.15 * abs(drop_ref), (drop_got, drop_ref)
+    rel = float((dgot - dref).norm() / dref.norm())
+    cos = float((dgot * dref).sum() / (dgot.norm() * dref.norm()))
+    assert rel < 0.6 and cos > 0.8, (rel, cos)  # measured 0.46 / 0.89
+    print(f"bf16 vs f32 over {N} steps: max loss-term deviation {err.max():.2e}, loss drop {drop_got:.4f} vs {drop_ref:.4f}, "
+          f"update rel L2 {rel:.3f} cos {cos:.3f}")
+
+
 def test_direct_gradient_accumulation_equals_autograd(dev):
     """Weight-gradient kernels accumulating straight into the flat gradient buffer
     (FlatGradReducer(direct=True)) give the gradients autograd's own accumulation gives:
