@@ -79,7 +79,9 @@ int ptpp_conv_cin_padded(int cin, int dtype);
  * K-contiguous, zero padded.  mode 0: forward operand.  mode 1: operand of
  * the data-gradient convolution, wp[Cin][ks][CoutP] with taps flipped.  mode 2: mode 0 for a (gate | filter) weight
  * (Cout = 2C, Cout % 8 == 0) with its rows in the interleaved order of the fused DiffNet gate epilogue (PTPP_ACT_GATE):
- * packed row 8g + e = gate row 4g + e (e < 4) / filter row C + 4g + e - 4 (e >= 4). */
+ * packed row 8g + e = gate row 4g + e (e < 4) / filter row C + 4g + e - 4 (e >= 4).  modes 3 / 4 (bf16, 256 operand rows,
+ * inner % 64 == 0): the elements of mode 0 / 1 re-ordered into the OPERAND STREAM of ptpp_conv1d_rt_fwd -- 2 * ks * inner / 64
+ * stages of 16 KiB in consumption order, each the LDS image of its MFMA fragments (csrc/pack.hip stream_index). */
 int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin, int ks,
                           int mode, int dtype, void* stream);
 
@@ -142,6 +144,15 @@ int ptpp_conv1d_fwd(const ptpp_conv1d_args* a, void* stream);
 int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, int ldr2,
                        float res_scale, float drop_p, uint64_t drop_seed,
                        void* stream);
+/* Row-tile form for the frame-level layers with 256 output channels (bf16, Cin % 64 == 0, ks >= 3, act none / ReLU, no
+ * dropout / second residual; csrc/conv1d_rt.hip): a workgroup owns 64-128 rows of one utterance with all channels, the x
+ * window of a channel chunk is fetched once and the weights arrive as one contiguous operand stream (`wstream`: the weight in
+ * pack mode 3, or mode 4 for the data gradient -- a->wp is ignored).  Bit-identical to ptpp_conv1d_fwd_ex(a, NULL, 0,
+ * res_scale, 0, 0) on the mode-0 / mode-1 operand.  Serves modules/frame_prior.py:85-89 (k = 17), modules/variance_adaptor.py:31-36
+ * (k = 5) and the data gradient of the DiffNet dilated conv, modules/denoiser.py:58-64. */
+int ptpp_conv1d_rt_supported(int cin, int cout, int ks, int dil, int act, int dtype);
+int ptpp_conv1d_rt_fwd(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* stream);
+
 /* The same with an optional scratch (16-byte aligned device memory, NULL = none): layers with few
  * output tiles and a long K (Conformer FFN k = 9, BERT FFN) are then split over K -- f32 partial sums
  * of B*T*Cout elements per split go through the scratch and a second launch adds them and applies the
@@ -641,6 +652,7 @@ typedef struct {
   int32_t batched_wgrad;    /* 1: the 2 L weight gradients as TWO ptpp_conv1d_wgrad_batched calls after the loop (all
                              * operands are slabs that outlive it): no split-K partials, bit-reproducible; 0: one
                              * ptpp_conv1d_wgrad per layer inside the loop, exactly as the per-launch path */
+  const void* const* dil_wst;  /* [L] pack mode 4 operands of the dilated convs or NULL: their data gradients on the row-tile kernel */
 } ptpp_diffnet_stack_bwd_args;
 int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void* stream);
 
@@ -697,6 +709,8 @@ typedef struct {
   void* ws; size_t ws_bytes;  /* split-K scratch of ptpp_conv1d_fwd_ws (handed over where the per-launch path does) */
   float eps, drop_in, drop_out;
   int32_t B, T, C, n, ks, conv_act, conv_mask, ln_res, act_in, out_mask, dtype;
+  const void* const* wstream; /* [n] the same weights in pack mode 3, or NULL: with them the convs of a frame-level stack
+                               * (B * T >= 8192, ptpp_conv1d_rt_supported) run on the row-tile kernel, bit-identically */
 } ptpp_conv_ln_stack_fwd_args;
 int ptpp_conv_ln_stack_fwd(const ptpp_conv_ln_stack_fwd_args* a, void* stream);
 
@@ -724,6 +738,7 @@ typedef struct {
   void* side_stream;
   float drop_in, drop_out;
   int32_t B, T, C, n, ks, conv_act, conv_mask, ln_res, act_in, out_mask, dtype, batched_wgrad;
+  const void* const* wstream_t; /* [n] pack mode 4 operands or NULL: the data gradients on the row-tile kernel */
 } ptpp_conv_ln_stack_bwd_args;
 int ptpp_conv_ln_stack_bwd(const ptpp_conv_ln_stack_bwd_args* a, void* stream);
 

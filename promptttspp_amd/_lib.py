@@ -87,7 +87,7 @@ class DiffNetBwdArgs(Structure):
                                         "dw_out", "db_out", "gx_all", "do_all", "dg_buf", "dcond_all", "S", "ws_main")] + \
                [("ws_main_bytes", ctypes.c_size_t), ("ws_side", c_void_p), ("ws_side_bytes", ctypes.c_size_t),
                 ("side_stream", c_void_p)] + \
-               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "dtype", "batched_wgrad")]
+               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "dtype", "batched_wgrad")] + [("dil_wst", c_void_p)]
 
 
 class EncoderLayersFwdArgs(Structure):
@@ -105,7 +105,8 @@ class ConvLnFwdArgs(Structure):
     _fields_ = [(n, c_void_p) for n in ("x0", "lengths", "wp", "bias", "gamma", "beta", "x_all", "z_all", "sum_all", "mean_all",
                                         "rstd_all", "seeds", "ws")] + \
                [("ws_bytes", ctypes.c_size_t), ("eps", c_float), ("drop_in", c_float), ("drop_out", c_float)] + \
-               [(n, c_int32) for n in ("B", "T", "C", "n", "ks", "conv_act", "conv_mask", "ln_res", "act_in", "out_mask", "dtype")]
+               [(n, c_int32) for n in ("B", "T", "C", "n", "ks", "conv_act", "conv_mask", "ln_res", "act_in", "out_mask", "dtype")] + \
+               [("wstream", c_void_p)]
 
 
 class ConvLnBwdArgs(Structure):
@@ -116,7 +117,7 @@ class ConvLnBwdArgs(Structure):
                [("red_bytes", ctypes.c_size_t), ("ws_main", c_void_p), ("ws_main_bytes", ctypes.c_size_t), ("ws_side", c_void_p),
                 ("ws_side_bytes", ctypes.c_size_t), ("side_stream", c_void_p), ("drop_in", c_float), ("drop_out", c_float)] + \
                [(n, c_int32) for n in ("B", "T", "C", "n", "ks", "conv_act", "conv_mask", "ln_res", "act_in", "out_mask", "dtype",
-                                       "batched_wgrad")]
+                                       "batched_wgrad")] + [("wstream_t", c_void_p)]
 
 
 _CF_W = ["ln_g0", "ln_g1", "ln_g2", "ln_g3", "ln_g4", "ln_b0", "ln_b1", "ln_b2", "ln_b3", "ln_b4",
@@ -258,6 +259,8 @@ SIGNATURES = {
     "ptpp_grad_sumsq_det": (I, [P, I, P, c_longlong, P, P, P]),
     "ptpp_adamw_step": (I, [P, I, P, c_longlong, P, P, F, F, F, F, I, F, P]),
     "ptpp_diffnet_stack_fwd": (I, [POINTER(DiffNetFwdArgs), P]),
+    "ptpp_conv1d_rt_supported": (I, [I, I, I, I, I, I]),
+    "ptpp_conv1d_rt_fwd": (I, [POINTER(ConvArgs), P, ctypes.c_float, P]),
     "ptpp_diffnet_layer_supported": (I, [I, I]),
     "ptpp_diffnet_wstream_bytes": (ctypes.c_int64, [I]),
     "ptpp_diffnet_pack_wstream": (I, [P, P, P, I, I, P]),

@@ -1,0 +1,322 @@
+// Row-tile Conv1d for the frame-level layers with 256 output channels (bf16): the structure of the one-launch DiffNet layer
+// (diffnet_layer.hip) as a general forward / data-gradient convolution
+//
+//   y = res_scale * res + out_scale * mask_out(act(conv(x_masked) + bias))        act in {none, ReLU}
+//
+// for the shapes that dominate the training step's conv time: frame prior network (256 -> 256, k = 17; reference
+// modules/frame_prior.py:85-89), pitch predictor (k = 5; modules/variance_adaptor.py:31-36), the DiffNet dilated conv's data
+// gradient (512 -> 256, k = 3, dilated; modules/denoiser.py:58-64) -- forward operands in pack mode 3, data-gradient operands
+// in mode 4.  Bit-identical to ptpp_conv1d_fwd_ex on the same arguments: same K order (64-channel chunk, tap, 32-channel
+// MFMA step), same epilogue arithmetic.
+//
+// A block of 8 waves owns BM = 128 / 96 / 64 rows of one utterance and ALL 256 output channels:
+//   * the x window of a 64-channel chunk (BM + (ks - 1) dil rows) is fetched ONCE per block (the tile kernel fetched it once
+//     per 128-channel tile) by LDS-DMA, double-buffered;
+//   * the weights arrive as ONE contiguous stream of 16 KiB stages ([256 channels][32 k], already the LDS image: pack modes
+//     3 / 4) through a ring of NS stages, NS - 3 stages in flight under the MFMAs;
+//   * wave tile 64 x 64 (BM = 128): 8 fragment reads per 16 MFMAs -- the LDS -> register return path (~64 B/clk/CU measured,
+//     DESIGN.md section 5e) caps an MFMA kernel at tile-shape-dependent rates: 32 x 64 wave tiles (the tile kernel's choice at
+//     these grid sizes) 33 % of peak, 64 x 64 50 %; fragments are requested one step ahead so the round trip hides under the
+//     previous step's MFMAs.
+#include <stdlib.h>
+
+#include "conv1d_common.h"
+#include "lds_dma.h"
+
+namespace {
+
+constexpr int RT_N = 256;
+constexpr int RT_STAGE_U4 = 1024;
+
+struct RtP {
+  const bf16_raw* x;
+  const uint4* wstream;
+  const float* bias;
+  const bf16_raw* res;
+  bf16_raw* y;
+  const int* lengths;
+  int B, T, Cin, ks, dil, pad, ldx, ldy, ldr;
+  int act, in_mask, out_mask;
+  float out_scale, res_scale;
+  int nMT;
+};
+
+__device__ __forceinline__ void rt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int FM>
+__device__ __forceinline__ void rt_mfma_step(f32x4 (&acc)[FM][4], const uint4 (&wf)[4], const uint4 (&xf)[FM]) {
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn)
+      acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[fn]), __builtin_bit_cast(bf16x8_t, xf[fm]),
+                                                            acc[fm][fn], 0, 0, 0);
+}
+
+template <int NS>
+__device__ __forceinline__ void rt_wait_stage(int s, int S) {
+  // top of step s: this wave's pieces of stage s + 1 must have landed; stages up to min(S - 1, s + NS - 2) are issued
+  const int younger = min(NS - 3, S - 2 - s);
+  if (younger >= 3) glds_wait<6>();
+  else if (younger == 2) glds_wait<4>();
+  else if (younger == 1) glds_wait<2>();
+  else glds_wait<0>();
+}
+
+template <int NS, int FM, int ACT>
+__global__ __launch_bounds__(512, 2) void conv1d_rt_kernel(const RtP p) {
+  constexpr int BM = 32 * FM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object
+  uint4* Ring = reinterpret_cast<uint4*>(smem);                // [NS][1024]
+  uint4* Xw = Ring + NS * RT_STAGE_U4;                         // x windows [2][xrows][8]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / p.nMT, mt = blockIdx.x - b * p.nMT;
+  const int t0 = mt * BM;
+  const int T = p.T, ks = p.ks, dil = p.dil;
+  const int xrows = (BM + (ks - 1) * dil + 7) & ~7;
+  const int np = xrows >> 3;
+  const int nC = p.Cin >> 6;
+  const int S = nC * ks * 2;      // stages = steps
+  const int cs = ks * 2;          // steps per 64-channel chunk
+  const int len_raw = p.lengths ? p.lengths[b] : T;
+
+  const bf16_raw* xb = p.x + (int64_t)b * T * p.ldx;
+  const char* wsrc = reinterpret_cast<const char*>(p.wstream) + wave * 2048 + lane * 16;
+  const uint32_t ring_lds = lds_addr(Ring) + (uint32_t)wave * 2048u;
+  const uint32_t xs_lds = lds_addr(Xw);
+  const char* zero = reinterpret_cast<const char*>(g_conv_zero_page) + lane * 16;
+
+  f32x4 acc[FM][4];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue_w = [&](int s, int slot) {
+    const char* src = wsrc + (size_t)s * (RT_STAGE_U4 * 16);
+    const uint32_t dst = ring_lds + (uint32_t)slot * (RT_STAGE_U4 * 16);
+    glds16(src, __builtin_amdgcn_readfirstlane(dst));
+    glds16(src + 1024, __builtin_amdgcn_readfirstlane(dst + 1024u));
+  };
+  issue_w(0, 0);  // (does not depend on the utterance length: leaves before the scalar load is waited for)
+  const int len = min(len_raw, T);
+  const int Tin = p.in_mask ? len : T;
+  auto issue_x_piece = [&](int ci, int piece) {
+    const int r = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz<8>(r);
+    const int ts = t0 - p.pad + r;
+    const char* src = (ts >= 0 && ts < Tin) ? reinterpret_cast<const char*>(xb + (int64_t)ts * p.ldx + ci * 64 + c * 8) : zero;
+    glds16(src, __builtin_amdgcn_readfirstlane(xs_lds + (uint32_t)(((ci & 1) * xrows + piece * 8) * 128)));
+  };
+  // no K loop for a tile whose output rows are all masked out, or whose whole input window lies past the utterance's end
+  // with a masked input (the accumulators stay exactly zero, as in the tile kernel)
+  const bool active = !((p.out_mask && t0 >= len) || (p.in_mask && t0 - p.pad >= len));
+
+  uint4 wa[4], wb[4], xa[FM], xb_[FM];
+  auto ld_w = [&](uint4 (&wf)[4], int slot) {
+    const uint4* Wst = Ring + slot * RT_STAGE_U4;
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      const int q = wn * 64 + fn * 16 + lr;
+      wf[fn] = Wst[q * 4 + (lg ^ swz<4>(q))];
+    }
+  };
+  const int xrow0 = wm * (16 * FM) + lr;
+  auto ld_x = [&](uint4 (&xf)[FM], int ci, int tk) {  // step (ci * ks + tap) * 2 + kh, tk = tap * 2 + kh
+    const int tap = tk >> 1, kh = tk & 1;
+    const int r = xrow0 + tap * dil;
+    const uint4* src = Xw + (ci & 1) * xrows * 8 + r * 8 + ((kh * 4 + lg) ^ swz<8>(r));
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) xf[fm] = src[fm * 128];
+  };
+  auto next_slot = [&](int slot) { return slot + 1 == NS ? 0 : slot + 1; };
+
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (wave + 8 * k < np) issue_x_piece(0, wave + 8 * k);
+#pragma unroll
+    for (int s = 1; s <= NS - 3; ++s)
+      if (s < S) issue_w(s, s);
+    // pseudo-step -1: stage 0 and the first window have landed; the first fragments
+    rt_wait_stage<NS>(-1, S);
+    rt_barrier();
+    if (NS - 2 < S) issue_w(NS - 2, NS - 2);
+    ld_w(wa, 0);
+    ld_x(xa, 0, 0);
+    int slot = 0;
+    int ci = 0, j = 0;  // chunk and step-in-chunk of the CURRENT step (kept incrementally: no division in the loop)
+    // one step: stage s + 1 landed for everyone (wait + barrier), stage s - 1's slot refilled, the fragments of step s + 1
+    // requested, then the 16 * FM / 4 MFMAs of step s on the fragments requested a step earlier
+    auto step = [&](int s, uint4 (&wc)[4], uint4 (&wn_)[4], uint4 (&xc)[FM], uint4 (&xn_)[FM]) __attribute__((always_inline)) {
+      if (s + 1 < S) rt_wait_stage<NS>(s, S);
+      rt_barrier();
+      if (s + NS - 1 < S) issue_w(s + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+      {  // the next chunk's window: pieces wave, wave + 8 at the chunk's first step, wave + 16 at its second (ks >= 3: they
+         // are retired and published two steps before the first read)
+        if (ci + 1 < nC && j < 2) {
+          if (j == 0) {
+            if (wave < np) issue_x_piece(ci + 1, wave);
+            if (wave + 8 < np) issue_x_piece(ci + 1, wave + 8);
+          } else if (wave + 16 < np) {
+            issue_x_piece(ci + 1, wave + 16);
+          }
+        }
+      }
+      const int nj = j + 1 == cs ? 0 : j + 1, nci = j + 1 == cs ? ci + 1 : ci;
+      if (s + 1 < S) {
+        ld_w(wn_, next_slot(slot));
+        ld_x(xn_, nci, nj);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      rt_mfma_step<FM>(acc, wc, xc);
+      __builtin_amdgcn_sched_barrier(0);
+      slot = next_slot(slot);
+      ci = nci;
+      j = nj;
+    };
+#pragma unroll 1
+    for (int s = 0; s < S; s += 2) {  // (S is even: two k-halves per tap)
+      step(s, wa, wb, xa, xb_);
+      step(s + 1, wb, wa, xb_, xa);
+    }
+  } else {
+    glds_wait<0>();
+  }
+
+  // ---- epilogue, straight from the accumulators (a lane: 8 consecutive channels of one row per fragment pair); the arithmetic
+  // of conv1d_common.h conv_epilogue_act.  Both channel halves of a row together, two row tiles per round.
+  {
+    bf16_raw* yb = p.y + (int64_t)b * T * p.ldy;
+    const bf16_raw* rb = p.res ? p.res + (int64_t)b * T * p.ldr : nullptr;
+    const float e_scale = p.out_scale, e_rscale = p.res_scale;
+    f32x4 bia[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        bia[h][u] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + h * 32 + lg * 8 + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f0 = 0; f0 < FM; f0 += 2) {
+      uint4 rr[2][2];
+#pragma unroll
+      for (int df = 0; df < 2; ++df)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          rr[df][h] = make_uint4(0, 0, 0, 0);
+          const int t = t0 + wm * (16 * FM) + (f0 + df) * 16 + lr;
+          if (rb && f0 + df < FM && t < T) rr[df][h] = *reinterpret_cast<const uint4*>(rb + (int64_t)t * p.ldr + wn * 64 + h * 32 + lg * 8);
+        }
+#pragma unroll
+      for (int df = 0; df < 2; ++df) {
+        const int fm = f0 + df < FM ? f0 + df : FM - 1;
+        const int t = t0 + wm * (16 * FM) + fm * 16 + lr;
+        if (f0 + df >= FM || t >= T) continue;
+        const bool keep = !(p.out_mask && t >= len);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4 v[2] = {acc[fm][2 * h], acc[fm][2 * h + 1]};
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (p.bias) v[u] += bia[h][u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[u][e] = keep ? act_apply_c<ACT>(v[u][e]) * e_scale : 0.f;
+          }
+          if (rb) {
+            const uint4 r = rr[df][h];
+            v[0][0] += __uint_as_float(r.x << 16) * e_rscale; v[0][1] += __uint_as_float(r.x & 0xffff0000u) * e_rscale;
+            v[0][2] += __uint_as_float(r.y << 16) * e_rscale; v[0][3] += __uint_as_float(r.y & 0xffff0000u) * e_rscale;
+            v[1][0] += __uint_as_float(r.z << 16) * e_rscale; v[1][1] += __uint_as_float(r.z & 0xffff0000u) * e_rscale;
+            v[1][2] += __uint_as_float(r.w << 16) * e_rscale; v[1][3] += __uint_as_float(r.w & 0xffff0000u) * e_rscale;
+          }
+          uint4 o;
+          o.x = (uint32_t)f32_to_bf16(v[0][0]) | ((uint32_t)f32_to_bf16(v[0][1]) << 16);
+          o.y = (uint32_t)f32_to_bf16(v[0][2]) | ((uint32_t)f32_to_bf16(v[0][3]) << 16);
+          o.z = (uint32_t)f32_to_bf16(v[1][0]) | ((uint32_t)f32_to_bf16(v[1][1]) << 16);
+          o.w = (uint32_t)f32_to_bf16(v[1][2]) | ((uint32_t)f32_to_bf16(v[1][3]) << 16);
+          *reinterpret_cast<uint4*>(yb + (int64_t)t * p.ldy + wn * 64 + h * 32 + lg * 8) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int FM, int ACT>
+int rt_launch(const RtP& p, hipStream_t st) {
+  constexpr int NS = 5;
+  constexpr int BM = 32 * FM;
+  const int xrows = (BM + (p.ks - 1) * p.dil + 7) & ~7;
+  const size_t smem = (size_t)NS * RT_STAGE_U4 * 16 + (size_t)2 * xrows * 128;
+  auto kern = conv1d_rt_kernel<NS, FM, ACT>;
+  {
+    static const void* done[8];
+    static int ndone = 0;
+    const void* kp = reinterpret_cast<const void*>(kern);
+    bool seen = false;
+    for (int i = 0; i < ndone; ++i) seen = seen || done[i] == kp;
+    if (!seen) {
+      (void)hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (ndone < 8) done[ndone++] = kp;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, st, p);
+  PTPP_CHECK_LAUNCH("conv1d_rt_fwd");
+  return PTPP_OK;
+}
+
+}  // namespace
+
+extern "C" int ptpp_conv1d_rt_supported(int cin, int cout, int ks, int dil, int act, int dtype) {
+  if (dtype != PTPP_BF16 || cout != RT_N || cin <= 0 || (cin & 63) || ks < 3 || dil < 1) return 0;
+  if (act != PTPP_ACT_NONE && act != PTPP_ACT_RELU) return 0;
+  const int xrows = (128 + (ks - 1) * dil + 7) & ~7;
+  return xrows <= 160;  // two windows of 20 KiB beside the 80 KiB ring
+}
+
+extern "C" int ptpp_conv1d_rt_fwd(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* stream) {
+  PTPP_CHECK_ARG(a && a->x && a->y && wstream, "conv1d_rt_fwd: null pointer");
+  PTPP_CHECK_ARG(ptpp_conv1d_rt_supported(a->Cin, a->Cout, a->ks, a->dil, a->act, a->dtype),
+                 "conv1d_rt_fwd: unsupported shape (bf16, Cout = 256, Cin %% 64 == 0, ks >= 3, act none / relu; Cin %d Cout %d ks %d dil %d act %d)",
+                 a->Cin, a->Cout, a->ks, a->dil, a->act);
+  PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->pad >= 0 && a->pad <= (a->ks - 1) * a->dil && (a->ldx & 7) == 0 && (a->ldy & 7) == 0 &&
+                     (!a->res || (a->ldr & 7) == 0),
+                 "conv1d_rt_fwd: bad geometry (B %d T %d pad %d ldx %d ldy %d ldr %d)", a->B, a->T, a->pad, a->ldx, a->ldy, a->ldr);
+  PTPP_CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->res | (uintptr_t)wstream | (uintptr_t)a->bias) & 15) == 0,
+                 "conv1d_rt_fwd: operands must be 16-byte aligned");
+  PTPP_CHECK_ARG(!(a->in_mask || a->out_mask) || a->lengths, "conv1d_rt_fwd: masks need lengths");
+  RtP p;
+  p.x = reinterpret_cast<const bf16_raw*>(a->x);
+  p.wstream = reinterpret_cast<const uint4*>(wstream);
+  p.bias = a->bias;
+  p.res = reinterpret_cast<const bf16_raw*>(a->res);
+  p.y = reinterpret_cast<bf16_raw*>(a->y);
+  p.lengths = a->lengths;
+  p.B = a->B; p.T = a->T; p.Cin = a->Cin; p.ks = a->ks; p.dil = a->dil; p.pad = a->pad;
+  p.ldx = a->ldx; p.ldy = a->ldy; p.ldr = a->ldr;
+  p.act = a->act; p.in_mask = a->in_mask; p.out_mask = a->out_mask;
+  p.out_scale = a->out_scale; p.res_scale = res_scale;
+  // rows per block: least (rounds of 256 one-per-CU blocks) x (time of a block)
+  int bm = 128;
+  {
+    const int cand[3] = {128, 96, 64};
+    const float tblk[3] = {1.f, 0.8f, 0.6f};
+    float best = 1e30f;
+    for (int i = 0; i < 3; ++i) {
+      const int64_t nb = (int64_t)a->B * ((a->T + cand[i] - 1) / cand[i]);
+      const float cost = (float)((nb + 255) / 256) * tblk[i];
+      if (cost < best - 1e-3f) { best = cost; bm = cand[i]; }
+    }
+    const char* force = getenv("PTPP_CONV_RT_BM");  // (experiments / tests)
+    if (force && (atoi(force) == 64 || atoi(force) == 96 || atoi(force) == 128)) bm = atoi(force);
+  }
+  p.nMT = (a->T + bm - 1) / bm;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool relu = a->act == PTPP_ACT_RELU;
+  if (bm == 128) return relu ? rt_launch<4, PTPP_ACT_RELU>(p, st) : rt_launch<4, PTPP_ACT_NONE>(p, st);
+  if (bm == 96) return relu ? rt_launch<3, PTPP_ACT_RELU>(p, st) : rt_launch<3, PTPP_ACT_NONE>(p, st);
+  return relu ? rt_launch<2, PTPP_ACT_RELU>(p, st) : rt_launch<2, PTPP_ACT_NONE>(p, st);
+}

@@ -15,6 +15,18 @@ __device__ __forceinline__ int gate_row_dst(int co, int cout) {  // packed row o
   const int C = cout >> 1;
   return co < C ? 8 * (co >> 2) + (co & 3) : 8 * ((co - C) >> 2) + 4 + ((co - C) & 3);
 }
+// modes 3 / 4: the operand of mode 0 / 1 as the OPERAND STREAM of the row-tile conv kernel (conv1d_rt.hip; 256 operand rows,
+// inner % 64 == 0): stage s = ((k / 64) * ks + tap) * 2 + (k / 32) % 2 holds [256 rows][32 k] as the LDS image the MFMA
+// fragments are read from -- LDS row q = wperm(n) (conv1d_common.h), 16-byte chunk (k / 8) % 4 at position chunk ^ swz4(q) --
+// so that a block's weight traffic is ONE contiguous read in consumption order.  Same elements as modes 0 / 1, another order.
+__device__ __forceinline__ int64_t stream_index(int n, int tap, int k, int ks) {
+  const int ci = k >> 6, kh = (k >> 5) & 1, c = (k >> 3) & 3, e = k & 7;
+  const int u = n & 63;
+  const int q = (n - u) + (2 * (u >> 5) + ((u >> 2) & 1)) * 16 + 4 * ((u >> 3) & 3) + (u & 3);
+  const int cp = c ^ ((-(q >> 2)) & 3);
+  return ((int64_t)(ci * ks + tap) * 2 + kh) * 8192 + (q * 4 + cp) * 8 + e;
+}
+
 template <typename T>
 __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp, int cout, int cin, int ks,
                                  int mode, int rows, int inner, int innerp) {
@@ -25,14 +37,14 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp
     const int r = (int)(i / ((int64_t)innerp * ks));
     float v = 0.f;
     if (c < inner) {
-      if (mode == 0)
+      if (mode == 0 || mode == 3)
         v = w[((int64_t)r * cin + c) * ks + j];
       else if (mode == 2)
         v = w[((int64_t)gate_row_src(r, cout) * cin + c) * ks + j];
       else
         v = w[((int64_t)c * cin + r) * ks + (ks - 1 - j)];
     }
-    Elem<T>::st(wp + i, v);
+    Elem<T>::st(wp + (mode >= 3 ? stream_index(r, j, c, ks) : i), v);
   }
 }
 
@@ -80,11 +92,12 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
     __syncthreads();
     for (int j = 0; j < ks; ++j) {
       for (int r = ty; r < 32; r += 8) {
-        if (mode != 1) {
+        if (mode != 1 && mode != 4) {
           const int co = co0 + r, ci = ci0 + tx;
           if (co < cout && ci < cin) {
             const float v = buf[r * pitch + tx * ks + j];
-            const int64_t d = ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
+            const int64_t d = mode == 3 ? stream_index(co, j, ci, ks)
+                                        : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
             if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = v;
             else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(v);
           }
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
           const int ci = ci0 + r, co = co0 + tx;
           if (co < cout && ci < cin) {
             const float v = buf[tx * pitch + r * ks + j];
-            const int64_t d = ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
+            const int64_t d = mode == 4 ? stream_index(ci, ks - 1 - j, co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
             if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = v;
             else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(v);
           }
@@ -108,11 +121,12 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
       tile[r][tx] = (co < cout && ci < cin) ? src[((int64_t)co * cin + ci) * ks + j] : 0.f;
     }
     __syncthreads();
-    if (mode != 1) {
+    if (mode != 1 && mode != 4) {
       for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
         if (co < cout && ci < cin) {
-          const int64_t d = ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
+          const int64_t d = mode == 3 ? stream_index(co, j, ci, ks)
+                                      : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
           if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = tile[r][tx];
           else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(tile[r][tx]);
         }
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
       for (int r = ty; r < 32; r += 8) {  // r indexes ci here, writes run along co
         const int ci = ci0 + r, co = co0 + tx;
         if (co < cout && ci < cin) {
-          const int64_t d = ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
+          const int64_t d = mode == 4 ? stream_index(ci, ks - 1 - j, co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
           if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = tile[tx][r];
           else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(tile[tx][r]);
         }
@@ -194,10 +208,15 @@ extern "C" int ptpp_pack_conv2d_3x3(const float* w, void* wp_fwd, void* wp_bwd, 
 extern "C" int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin, int ks, int mode, int dtype,
                                      void* stream) {
   PTPP_CHECK_ARG(w && wp, "pack_conv_weight: null pointer");
-  PTPP_CHECK_ARG(cout > 0 && cin > 0 && ks > 0 && (mode == 0 || mode == 1 || (mode == 2 && cout % 8 == 0)), "pack_conv_weight: bad args");
+  PTPP_CHECK_ARG(cout > 0 && cin > 0 && ks > 0 && (mode == 0 || mode == 1 || (mode == 2 && cout % 8 == 0) || mode == 3 || mode == 4),
+                 "pack_conv_weight: bad args");
   PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "pack_conv_weight: bad dtype");
-  const int rows = mode != 1 ? cout : cin;
-  const int inner = mode != 1 ? cin : cout;
+  const bool tr = mode == 1 || mode == 4;
+  const int rows = !tr ? cout : cin;
+  const int inner = !tr ? cin : cout;
+  PTPP_CHECK_ARG(mode < 3 || (dtype == PTPP_BF16 && rows == 256 && inner % 64 == 0),
+                 "pack_conv_weight: the operand stream (modes 3 / 4) needs bf16, 256 operand rows and inner %% 64 == 0 (rows %d, inner %d)",
+                 rows, inner);
   const int innerp = ptpp_conv_cin_padded(inner, dtype);
   const int64_t n = (int64_t)rows * ks * innerp;
   const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);

@@ -44,6 +44,12 @@ ptpp_conv1d_args conv_args(const void* x, int ldx, const void* wp, const float* 
 
 }  // namespace
 
+// A conv launch of a driver: on the row-tile kernel (conv1d_rt.hip) when its operand stream was handed over and the launch is
+// frame-level -- the SAME rule as promptttspp_amd/ops.py::conv1d_rt_ok, so that both paths take the same kernel -- else as before
+static bool rt_takes(const ptpp_conv1d_args& c, const void* wstream) {
+  return wstream && (int64_t)c.B * c.T >= 8192 && ptpp_conv1d_rt_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype);
+}
+
 extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream) {
   ST_CHECK_ARG(a && a->h0 && a->cond_all && a->dsteps && a->skip && a->dil_wp && a->dil_b && a->out_wp && a->out_b && a->yin_all &&
                    a->g_all && a->x_buf[0] && a->x_buf[1],
@@ -179,7 +185,8 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
     }
     ptpp_conv1d_args c = conv_args(da, ldc, a->dil_wpt[l], nullptr, gx, C, at(a->gx_all, (size_t)l * BTC, dt), C, a->lengths, B, T, 2 * C, C,
                                    3, d, d, PTPP_ACT_NONE, bmask, 0, dt);
-    ST_TRY(ptpp_conv1d_fwd_ex(&c, nullptr, 0, r2, 0.f, 0, stream));
+    if (rt_takes(c, a->dil_wst ? a->dil_wst[l] : nullptr)) ST_TRY(ptpp_conv1d_rt_fwd(&c, a->dil_wst[l], r2, stream));
+    else ST_TRY(ptpp_conv1d_fwd_ex(&c, nullptr, 0, r2, 0.f, 0, stream));
   }
   if (a->batched_wgrad) {
     // every layer's (g, do) and (yin, da) pair is still in its slab: all output-projection gradients in one launch, all
@@ -265,7 +272,8 @@ extern "C" int ptpp_conv_ln_stack_fwd(const ptpp_conv_ln_stack_fwd_args* a, void
     void* y = at(a->x_all, i * BTC, dt);
     ptpp_conv1d_args c = conv_args(x, C, a->wp[i], a->bias[i], nullptr, 0, z, C, a->conv_mask ? a->lengths : nullptr, B, T, C, C, a->ks, 1,
                                    a->ks / 2, a->conv_act, a->conv_mask ? 1 : 0, 0, dt);
-    ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
+    if (rt_takes(c, a->wstream ? a->wstream[i] : nullptr)) ST_TRY(ptpp_conv1d_rt_fwd(&c, a->wstream[i], 1.0f, stream));
+    else ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
     const int om = a->out_mask == 1 || (a->out_mask == 2 && i == n - 1);
     ST_TRY(ptpp_layernorm_fwd(z, a->ln_res ? x : nullptr, a->gamma[i], a->beta[i], y, fused_in ? at(a->sum_all, i * BTC, dt) : nullptr,
                               a->mean_all + i * R, a->rstd_all + i * R, a->lengths, B, T, C, a->eps, om, a->act_in, a->drop_in,
@@ -319,7 +327,8 @@ extern "C" int ptpp_conv_ln_stack_bwd(const ptpp_conv_ln_stack_bwd_args* a, void
       void* dx = a->ln_res ? aux : gnext;
       ptpp_conv1d_args c = conv_args(gz, C, a->wpt[i], nullptr, nullptr, 0, dx, C, clen, B, T, C, C, ks, 1, (ks - 1) - pad, PTPP_ACT_NONE, 0,
                                      a->conv_mask ? 1 : 0, dt);
-      ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+      if (rt_takes(c, a->wstream_t ? a->wstream_t[i] : nullptr)) ST_TRY(ptpp_conv1d_rt_fwd(&c, a->wstream_t[i], 1.0f, stream));
+      else ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
       if (a->ln_res) ST_TRY(ptpp_add3_scale(dx, want_dz ? dsum : gz, nullptr, gnext, 1.0f, (int64_t)BTC, dt, stream));
       gout = gnext;
     }

@@ -100,6 +100,14 @@ def packed(w, dtype, mode=0):
     return _packed_entry((w,), dtype, mode).wp
 
 
+def rt_stream(w, x, cout, ks, dil, act, transposed=False):
+    """The weight as the operand stream of the row-tile conv kernel (pack mode 3, or 4 for the data gradient) when the launch
+    ``ops.conv1d(x, ..)`` qualifies for it (ops.conv1d_rt_ok: bf16, 256 output channels, frame-level row count ...), else None."""
+    if not isinstance(w, torch.nn.Parameter) or w.dim() != 3 or not ops.conv1d_rt_ok(x, cout, ks, dil, act):
+        return None
+    return packed(w, x.dtype, mode=4 if transposed else 3)
+
+
 def packed_cat(ws, dtype, mode=0):
     """Packed operand of the row-wise concatenation of several (Cout_i, Cin[,1]) weights."""
     ws = tuple(ws)
@@ -142,7 +150,7 @@ def repack_all(bumped=None):
             ks = w0.shape[2] if w0.dim() == 3 else 1
             dcode = ops.dtype_code(ent.dtype)
             total_cout = sum(w.shape[0] for w in ws)
-            innerp = ops.cin_padded(cin if ent.mode != 1 else total_cout, ent.dtype)
+            innerp = ops.cin_padded(cin if ent.mode not in (1, 4) else total_cout, ent.dtype)
             off = 0
             for w in ws:
                 assert w.dtype == torch.float32 and w.is_contiguous()
@@ -399,9 +407,10 @@ class Conv1dFn(Function):
         if cin % kc:  # tiny channel counts: zero-pad K to the 16-byte operand granule
             xk = torch.nn.functional.pad(x, (0, kc - cin % kc))
             wk = torch.nn.functional.pad(w3.detach(), (0, 0, 0, kc - cin % kc))
-        y = ops.conv1d(xk, packed(wk, x.dtype), _f32c(b), cout, ks=ks, dil=cfg.dil, pad=cfg.pad, act=cfg.act,
+        ws = rt_stream(w, x, cout, ks, cfg.dil, cfg.act) if cfg.drop_p == 0 else None
+        y = ops.conv1d(xk, packed(wk, x.dtype) if ws is None else None, _f32c(b), cout, ks=ks, dil=cfg.dil, pad=cfg.pad, act=cfg.act,
                        lengths=cfg.lengths, in_mask=cfg.in_mask, out_mask=cfg.out_mask, res=res,
-                       out_scale=cfg.out_scale, drop_p=cfg.drop_p, drop_seed=seed)
+                       out_scale=cfg.out_scale, drop_p=cfg.drop_p, drop_seed=seed, wstream=ws)
         ctx.cfg, ctx.seed, ctx.has_res, ctx.has_b = cfg, seed, res is not None, b is not None
         # in-place gradient targets (None -> autograd accumulates the returned tensors)
         ctx.direct = None
@@ -443,8 +452,9 @@ class Conv1dFn(Function):
             dz = torch.nn.functional.pad(dz, (0, coutp - cout))
             wk = torch.nn.functional.pad(w3.detach(), (0, 0, 0, 0, 0, coutp - cout))
         if ctx.needs_input_grad[0]:
-            dx = ops.conv1d(dz, packed(wk, dz.dtype, mode=1), None, cin, ks=ks, dil=cfg.dil,
-                            pad=(ks - 1) * cfg.dil - cfg.pad, lengths=cfg.lengths, out_mask=cfg.in_mask)
+            ws = rt_stream(w, dz, cin, ks, cfg.dil, None, transposed=True) if coutp == cout else None
+            dx = ops.conv1d(dz, packed(wk, dz.dtype, mode=1) if ws is None else None, None, cin, ks=ks, dil=cfg.dil,
+                            pad=(ks - 1) * cfg.dil - cfg.pad, lengths=cfg.lengths, out_mask=cfg.in_mask, wstream=ws)
         if ctx.direct is not None:
             pw, pb = ctx.direct
             with wgrad_stream(x, dz):
@@ -610,6 +620,10 @@ class ConvLnStackFn(Function):
         a.lengths = lens.data_ptr() if lens is not None else None
         tabs = [_ptr_table([packed(w, dt) for w in ws_]), _ptr_table(bias), _ptr_table(gam), _ptr_table(bet)]
         a.wp, a.bias, a.gamma, a.beta = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
+        wst = [rt_stream(w, x, C, cfg.ks, 1, cfg.conv_act) for w in ws_]  # (frame-level stacks: the row-tile conv kernel)
+        if all(t is not None for t in wst):
+            tabs.append(_ptr_table(wst))
+            a.wstream = ctypes.cast(tabs[-1], ctypes.c_void_p)
         a.x_all, a.z_all = x_all.data_ptr(), z_all.data_ptr()
         a.sum_all = sum_all.data_ptr() if sum_all is not None else None
         a.mean_all, a.rstd_all = stats[0].data_ptr(), stats[1].data_ptr()
@@ -666,6 +680,10 @@ class ConvLnStackFn(Function):
         a.lengths = lens.data_ptr() if lens is not None else None
         tabs = [_ptr_table([packed(w, dt, mode=1) for w in ws_]), _ptr_table(gam)] + [_ptr_table(t) for t in tg]
         a.wpt, a.gamma, a.dw, a.db, a.dgamma, a.dbeta = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
+        wst = [rt_stream(w, gy, w.shape[1], cfg.ks, 1, None, transposed=True) for w in ws_]
+        if all(t is not None for t in wst):
+            tabs.append(_ptr_table(wst))
+            a.wstream_t = ctypes.cast(tabs[-1], ctypes.c_void_p)
         a.gz_all, a.tmp = gz_all.data_ptr(), tmp.data_ptr()
         a.gx = gx.data_ptr() if gx is not None else None
         sd = _u64_table(ctx.seeds)
@@ -1060,8 +1078,9 @@ class DiffNetStackFn(Function):
             with wgrad_stream(*((yin, da) if ctx.direct else ())):
                 dwd, dbd = ops.conv1d_wgrad(yin, da, C, 2 * C, 3, d, d, dw_out=tg[0], db_out=tg[1])
             # (do / da are zero past an utterance's end: the input mask is exact and lets those row tiles skip their K loops)
-            gx = ops.conv1d(da, packed(dil_w, dt, mode=1), None, C, ks=3, dil=d, pad=d, res=gx, res_scale=r2, out=gx_all[l],
-                            lengths=ctx.lengths, in_mask=ctx.lengths is not None)
+            wst = rt_stream(dil_w, da, C, 3, d, None, transposed=True)
+            gx = ops.conv1d(da, packed(dil_w, dt, mode=1) if wst is None else None, None, C, ks=3, dil=d, pad=d, res=gx, res_scale=r2,
+                            out=gx_all[l], lengths=ctx.lengths, in_mask=ctx.lengths is not None, wstream=wst)
             if ctx.direct:
                 for i in (0, 1, 4, 5):
                     _done(ws[l][i])
@@ -1135,6 +1154,10 @@ def _diffnet_backward_driver(ctx, gS, gx_all):
     tabs = [_ptr_table([packed(w[0], dt, mode=1) for w in ws]), _ptr_table([packed(w[4], dt, mode=1) for w in ws])] + \
            [_ptr_table(t) for t in tg]
     a.dil_wpt, a.out_wpt, a.dw_dil, a.db_dil, a.dw_out, a.db_out = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
+    wst = [rt_stream(w[0], dcond_all[:, :, :2 * C], C, 3, 2 ** (l % ctx.cycle), None, transposed=True) for l, w in enumerate(ws)]
+    if all(t is not None for t in wst):  # the dilated conv's data gradient on the row-tile kernel
+        tabs.append(_ptr_table(wst))
+        a.dil_wst = ctypes.cast(tabs[-1], ctypes.c_void_p)
     a.gx_all, a.do_all, a.dcond_all, a.S = gx_all.data_ptr(), do_all.data_ptr(), dcond_all.data_ptr(), S.data_ptr()
     a.dg_buf = dg_buf.data_ptr() if dg_buf is not None else None
     a.ws_main, a.ws_main_bytes = ws_main.data_ptr(), ws_main.numel()

@@ -155,7 +155,7 @@ def pack_conv_weight(w, dtype, mode=0, out=None):
         w = w.unsqueeze(-1)
     w = w.detach().contiguous().float()
     cout, cin, ks = w.shape
-    rows, inner = (cout, cin) if mode != 1 else (cin, cout)
+    rows, inner = (cout, cin) if mode not in (1, 4) else (cin, cout)  # (modes 3 / 4: the stream forms of modes 0 / 1, same size)
     wp = out if out is not None else torch.empty((rows, ks, cin_padded(inner, dtype)), device=w.device, dtype=dtype)
     assert wp.is_contiguous() and wp.shape == (rows, ks, cin_padded(inner, dtype)) and wp.dtype == dtype
     check(
@@ -187,10 +187,30 @@ def _ld_fast(t):
     return t.shape[2] if t.is_contiguous() else _ld(t)
 
 
+CONV_RT = not __import__("os").environ.get("PTPP_NO_CONV_RT")  # the row-tile kernel for the frame-level 256-channel layers
+CONV_RT_MIN_ROWS = 8192
+_rt_ok = {}
+
+
+def conv1d_rt_ok(x, cout, ks, dil, act, res2=None, drop_p=0.0):
+    """Whether ``conv1d`` would take the row-tile kernel (csrc/conv1d_rt.hip) for this launch when handed the operand stream
+    (pack mode 3 / 4): bf16, 256 output channels, Cin % 64 == 0, ks >= 3, frame-level row counts, plain epilogue."""
+    if not (CONV_RT and x.is_cuda and x.dtype == torch.bfloat16 and cout == 256 and res2 is None and drop_p == 0.0):
+        return False
+    if x.shape[0] * x.shape[1] < CONV_RT_MIN_ROWS or x.stride(2) != 1:
+        return False
+    key = (x.shape[2], ks, dil, act)
+    ok = _rt_ok.get(key)
+    if ok is None:
+        ok = _rt_ok[key] = act in (None, "relu") and bool(_lib.load().ptpp_conv1d_rt_supported(x.shape[2], cout, ks, dil, _ACT[act], BF16))
+    return ok
+
+
 def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mask=False, out_mask=False, res=None,
-           out_scale=1.0, res2=None, res_scale=1.0, drop_p=0.0, drop_seed=0, out=None):
+           out_scale=1.0, res2=None, res_scale=1.0, drop_p=0.0, drop_seed=0, out=None, wstream=None):
     """Channels-last conv / linear with the fused epilogue (see ptpp.h).
-    x: (B, T, Cin); wp: packed weight; bias: (cout) f32 or None -> (B, T, cout).
+    x: (B, T, Cin); wp: packed weight; bias: (cout) f32 or None -> (B, T, cout).  ``wstream``: the same weight in pack mode
+    3 (forward) / 4 (data gradient): where ``conv1d_rt_ok`` holds the launch goes to the row-tile kernel (bit-identical).
     (Called ~170 times per training step: written for low host overhead.)"""
     if not x.is_cuda:
         _need_gpu(x)
@@ -207,12 +227,15 @@ def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mas
     if res2 is not None:
         assert res2.dtype == x.dtype and res2.shape[0] == B and res2.shape[1] == T and res2.shape[2] == cout
         ldr2 = _ld_fast(res2)
-    _CONV_FMT.pack_into(_conv_buf, 0, x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else 0,
+    _CONV_FMT.pack_into(_conv_buf, 0, x.data_ptr(), wp.data_ptr() if wp is not None else 0, bias.data_ptr() if bias is not None else 0,
                         res.data_ptr() if res is not None else 0, y.data_ptr(),
                         lengths.data_ptr() if lengths is not None else 0, B, T, cin, cout, ks, dil, pad, _ld_fast(x),
                         _ld_fast(y), ldr, _ACT[act], 1 if in_mask else 0, 1 if out_mask else 0, out_scale,
                         BF16 if x.dtype == torch.bfloat16 else dtype_code(x.dtype))
     lib = _lib.load()
+    if wstream is not None and conv1d_rt_ok(x, cout, ks, dil, act, res2, drop_p):
+        check(lib.ptpp_conv1d_rt_fwd(_conv_args_ref, wstream.data_ptr(), float(res_scale), _stream()), "ptpp_conv1d_rt_fwd")
+        return y
     if T <= 512 and ks * cin >= 2048 and not torch.cuda.is_current_stream_capturing():
         # few rows per utterance and a long K: hand the kernel the per-stream scratch so it may split K
         ws = workspace(x.device)

@@ -1,0 +1,61 @@
+"""GPU: the row-tile conv kernel (csrc/conv1d_rt.hip, ptpp_conv1d_rt_fwd) against the tile kernel it replaces on the
+frame-level 256-channel layers -- frame prior network k = 17 (reference modules/frame_prior.py:85-89), pitch predictor k = 5
+(modules/variance_adaptor.py:31-36), the DiffNet dilated conv's data gradient (modules/denoiser.py:58-64): same accumulation
+order and epilogue arithmetic, so outputs must be equal BIT FOR BIT; plus the f32 oracle (torch conv1d on the CPU)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(dev, B, T, cin, ks, seed):
+    g = torch.Generator().manual_seed(500 + seed)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    return r(B, T, cin).bfloat16(), r(256, cin, ks, sc=(cin * ks) ** -0.5), r(256, sc=0.1), r(B, T, 256).bfloat16()
+
+
+@pytest.mark.parametrize("B,T,cin,ks,dil,act,masked,use_res,bm", [
+    (14, 650, 256, 17, 1, None, True, False, 128),    # frame prior forward: conv mask on the input, no activation (T > 512:
+                                                      # below that ops.conv1d hands the tile kernel a split-K scratch)
+    (20, 450, 256, 5, 1, "relu", False, False, 96),   # pitch predictor forward
+    (9, 1000, 512, 3, 8, None, True, True, 128),      # dilated data gradient: residual with scale, masked input
+    (70, 130, 256, 3, 1, "relu", True, True, 64),     # short utterances: ragged last tiles
+    (16, 617, 320, 7, 2, None, False, True, 0),       # Cin not a power of two, launcher's own tile choice
+])
+def test_row_tile_conv_is_bit_identical_to_the_tile_kernel(dev, monkeypatch, B, T, cin, ks, dil, act, masked, use_res, bm):
+    from promptttspp_amd import ops
+
+    if bm:
+        monkeypatch.setenv("PTPP_CONV_RT_BM", str(bm))
+    x, w, b, res = _mk(dev, B, T, cin, ks, ks + dil)
+    pad = dil * (ks - 1) // 2
+    lengths = torch.tensor([max(1, T - 37 * i) for i in range(B)], device=dev, dtype=torch.int32) if masked else None
+    kw = dict(ks=ks, dil=dil, pad=pad, act=act, lengths=lengths, in_mask=masked, out_mask=masked and act is not None,
+              res=res if use_res else None, res_scale=0.7071067811865476 if use_res else 1.0)
+    ref = ops.conv1d(x, ops.pack_conv_weight(w, torch.bfloat16), b, 256, **kw)
+    ws = ops.pack_conv_weight(w, torch.bfloat16, 3)
+    assert ops.conv1d_rt_ok(x, 256, ks, dil, act)
+    got = ops.conv1d(x, None, b, 256, wstream=ws, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(ref, got), (float((ref.float() - got.float()).abs().max()), int((ref != got).sum()))
+    assert float(ref.float().abs().max()) > 0
+
+
+def test_row_tile_data_gradient_operand_and_oracle(dev):
+    """Pack mode 4 (the stream form of the transposed, tap-flipped operand) against mode 1 through the tile kernel, and both
+    against the f32 oracle: the data gradient of a dilated conv is conv_transpose1d."""
+    import torch.nn.functional as F
+    from promptttspp_amd import ops
+
+    B, T, cout, cin, ks, dil = 12, 800, 512, 256, 3, 4  # gradient flows 512 -> 256 channels
+    g = torch.Generator().manual_seed(77)
+    dy = (torch.randn(B, T, cout, generator=g)).to(dev).bfloat16()
+    w = (torch.randn(cout, cin, ks, generator=g) * (cout * ks) ** -0.5).to(dev)
+    pad = dil * (ks - 1) // 2
+    ref = ops.conv1d(dy, ops.pack_conv_weight(w, torch.bfloat16, 1), None, cin, ks=ks, dil=dil, pad=pad)
+    got = ops.conv1d(dy, None, None, cin, ks=ks, dil=dil, pad=pad, wstream=ops.pack_conv_weight(w, torch.bfloat16, 4))
+    torch.cuda.synchronize()
+    assert torch.equal(ref, got)
+    orc = F.conv_transpose1d(dy.float().cpu().transpose(1, 2), w.bfloat16().float().cpu(), padding=pad, dilation=dil).transpose(1, 2)
+    err = float((got.float().cpu() - orc).abs().max() / orc.abs().max())
+    assert err < 1e-2, err
