@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0
 # HBM traffic comes from PMC passes (bench.py cannot run rocprofv3 on itself): the committed summaries of
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command / of tools/bench_vocoder.py, written by
 # tools/pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md; the JSON line names the file it read.
-TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r03_hbm_traffic_train.json")
-TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r03_hbm_traffic_bigvgan.json")
+TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r04_hbm_traffic_train.json")
+TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r04_hbm_traffic_bigvgan.json")
 
 
 def measured_traffic(path, kernel_substr=None):
@@ -270,7 +270,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         ops.conv1d_gate_fwd_save = orig_gsave
     # the dominant kernel = the LDS-DMA conv kernel these launches take (csrc/conv1d_glds.h; rocprof:
     # conv1d_glds_kernel<2, 4, 2, 2, 2>, 64 x 128 tiles, and <4, 4, 2, 2, 2>, 128 x 128 tiles, for the few launches
-    # with >= 1536 tiles; profiles/r03_train_step.md is the rocprofv3 summary of the training leg of this command);
+    # with >= 1536 tiles; profiles/r04_train_step.md is the rocprofv3 summary of the training leg of this command);
     # launches of the conv family with smaller tiles / split-K are listed there, not averaged in here
     tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
     tot_flop = sum(f for _, _, f, _ in recs)
@@ -296,8 +296,47 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
     peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else 157.3
     traffic, traffic_src = measured_traffic(TRAFFIC_TRAIN, "conv1d_glds_kernel<2, 4, 2, 2, 2") \
         if dtype_name == "bf16" else (None, "no PMC pass for the f32 mode")
-    kname = "conv1d_glds_kernel<bf16> (LDS-DMA, 64x128 / 128x128 tiles)" if dtype_name == "bf16" else "conv1d_cl_kernel<f32>, 128x128 tiles"
+    kname = "conv1d_glds_kernel / conv1d_rt_kernel <bf16> (LDS-DMA implicit-GEMM conv family: 64x128 / 128x128 tiles, row tiles " \
+            "for the 256-channel layers)" if dtype_name == "bf16" else "conv1d_cl_kernel<f32>, 128x128 tiles"
+    # The timed steps run the DiffNet forward as ONE launch per layer (csrc/diffnet_layer.hip, issued by the C-side stack
+    # driver: the launch-by-launch step above takes the two launches it replaces).  One more step through the drivers with an
+    # event pair around the driver call: 20 launches of that kernel (+ one elementwise launch), priced per launch.
+    layer = None
+    if dtype_name == "bf16" and drivers:
+        lrec = []
+        orig_drv = PF._diffnet_stack_forward_driver
+
+        def timed_drv(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_drv(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b)
+            e1.record()
+            rows = float(lengths.sum()) if lengths is not None else h0.shape[0] * h0.shape[1]
+            lrec.append((e0, e1, len(weights), rows, h0.shape[0] * h0.shape[1], h0.shape[2]))
+            return r
+
+        PF._diffnet_stack_forward_driver = timed_drv
+        try:
+            torch.cuda._sleep(int(0.08 * 2.4e9))
+            train_step(model, batch, red, opt, sched)
+            torch.cuda.synchronize()
+        finally:
+            PF._diffnet_stack_forward_driver = orig_drv
+        if lrec:
+            e0, e1, L, rows, padded, C = lrec[0]
+            us = 1e3 * e0.elapsed_time(e1) / L
+            flop = 2.0 * rows * C * (3 * 2 * C + 2 * C)          # dilated conv k3 C -> 2C + output projection C -> 2C
+            # algorithmic bytes per launch: yin, x, conditioner slice (2C) in; a (2C), g, xn, yin' out (bf16); skip f32 read + written
+            nbytes = padded * C * (2 + 2 + 4 + 4 + 2 + 2 + 2) + padded * C * 8
+            lay_tf = flop / (us * 1e-6) / 1e12
+            layer = {"kernel": "diffnet_layer_kernel (one launch per DiffNet residual layer, training forward)", "launches": L,
+                     "avg_launch_us": round(us, 2), "achieved": round(lay_tf, 1), "unit": "TFLOP/s",
+                     "frac": round(lay_tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "algorithmic_gbs": round(nbytes / (us * 1e-6) / 1e9, 1), "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "note": "event pair around ptpp_diffnet_stack_fwd of a driver-path step / layers; both roofs are quoted: the "
+                             "launch alternates matrix passes with HBM-bound epilogues (DESIGN.md section 5e)"}
     return {"bound": "mfma", "kernel": kname + ": frame-level fwd + dgrad launches of one step",
+            "diffnet_layer": layer,
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),

@@ -618,12 +618,14 @@ class ConvLnStackFn(Function):
         a = _lib.ConvLnFwdArgs()
         a.x0 = x.data_ptr()
         a.lengths = lens.data_ptr() if lens is not None else None
-        tabs = [_ptr_table([packed(w, dt) for w in ws_]), _ptr_table(bias), _ptr_table(gam), _ptr_table(bet)]
-        a.wp, a.bias, a.gamma, a.beta = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
         wst = [rt_stream(w, x, C, cfg.ks, 1, cfg.conv_act) for w in ws_]  # (frame-level stacks: the row-tile conv kernel)
-        if all(t is not None for t in wst):
-            tabs.append(_ptr_table(wst))
-            a.wstream = ctypes.cast(tabs[-1], ctypes.c_void_p)
+        rt = all(t is not None for t in wst)
+        # (with the stream every conv of the stack takes the row-tile kernel -- same rule on both sides -- so the mode-0 operand
+        #  is never read: it is not packed at all, which keeps the per-step batched repack at its old size)
+        tabs = [_ptr_table(wst if rt else [packed(w, dt) for w in ws_]), _ptr_table(bias), _ptr_table(gam), _ptr_table(bet)]
+        a.wp, a.bias, a.gamma, a.beta = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
+        if rt:
+            a.wstream = a.wp
         a.x_all, a.z_all = x_all.data_ptr(), z_all.data_ptr()
         a.sum_all = sum_all.data_ptr() if sum_all is not None else None
         a.mean_all, a.rstd_all = stats[0].data_ptr(), stats[1].data_ptr()
@@ -678,12 +680,12 @@ class ConvLnStackFn(Function):
         a.sum_all = sum_all.data_ptr() if sum_all is not None else None
         a.mean_all, a.rstd_all = stats[0].data_ptr(), stats[1].data_ptr()
         a.lengths = lens.data_ptr() if lens is not None else None
-        tabs = [_ptr_table([packed(w, dt, mode=1) for w in ws_]), _ptr_table(gam)] + [_ptr_table(t) for t in tg]
-        a.wpt, a.gamma, a.dw, a.db, a.dgamma, a.dbeta = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
         wst = [rt_stream(w, gy, w.shape[1], cfg.ks, 1, None, transposed=True) for w in ws_]
-        if all(t is not None for t in wst):
-            tabs.append(_ptr_table(wst))
-            a.wstream_t = ctypes.cast(tabs[-1], ctypes.c_void_p)
+        rt = all(t is not None for t in wst)
+        tabs = [_ptr_table(wst if rt else [packed(w, dt, mode=1) for w in ws_]), _ptr_table(gam)] + [_ptr_table(t) for t in tg]
+        a.wpt, a.gamma, a.dw, a.db, a.dgamma, a.dbeta = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
+        if rt:
+            a.wstream_t = a.wpt
         a.gz_all, a.tmp = gz_all.data_ptr(), tmp.data_ptr()
         a.gx = gx.data_ptr() if gx is not None else None
         sd = _u64_table(ctx.seeds)
@@ -1151,13 +1153,13 @@ def _diffnet_backward_driver(ctx, gS, gx_all):
     a = _lib.DiffNetBwdArgs()
     a.gS, a.yin_all, a.a_all, a.g_all = gS.data_ptr(), yin_all.data_ptr(), a_all.data_ptr(), g_all.data_ptr()
     a.lengths = lens.data_ptr() if lens is not None else None
-    tabs = [_ptr_table([packed(w[0], dt, mode=1) for w in ws]), _ptr_table([packed(w[4], dt, mode=1) for w in ws])] + \
+    wst = [rt_stream(w[0], dcond_all[:, :, :2 * C], C, 3, 2 ** (l % ctx.cycle), None, transposed=True) for l, w in enumerate(ws)]
+    rt = all(t is not None for t in wst)  # the dilated conv's data gradient on the row-tile kernel (then mode 1 is never read)
+    tabs = [_ptr_table(wst if rt else [packed(w[0], dt, mode=1) for w in ws]), _ptr_table([packed(w[4], dt, mode=1) for w in ws])] + \
            [_ptr_table(t) for t in tg]
     a.dil_wpt, a.out_wpt, a.dw_dil, a.db_dil, a.dw_out, a.db_out = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
-    wst = [rt_stream(w[0], dcond_all[:, :, :2 * C], C, 3, 2 ** (l % ctx.cycle), None, transposed=True) for l, w in enumerate(ws)]
-    if all(t is not None for t in wst):  # the dilated conv's data gradient on the row-tile kernel
-        tabs.append(_ptr_table(wst))
-        a.dil_wst = ctypes.cast(tabs[-1], ctypes.c_void_p)
+    if rt:
+        a.dil_wst = a.dil_wpt
     a.gx_all, a.do_all, a.dcond_all, a.S = gx_all.data_ptr(), do_all.data_ptr(), dcond_all.data_ptr(), S.data_ptr()
     a.dg_buf = dg_buf.data_ptr() if dg_buf is not None else None
     a.ws_main, a.ws_main_bytes = ws_main.data_ptr(), ws_main.numel()
