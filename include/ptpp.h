@@ -710,7 +710,7 @@ typedef struct {
   float eps, drop_in, drop_out;
   int32_t B, T, C, n, ks, conv_act, conv_mask, ln_res, act_in, out_mask, dtype;
   const void* const* wstream; /* [n] the same weights in pack mode 3, or NULL: with them the convs of a frame-level stack
-                               * (B * T >= 8192, ptpp_conv1d_rt_supported) run on the row-tile kernel, bit-identically */
+                               * (B * T >= 24576, ptpp_conv1d_rt_supported) run on the row-tile kernel, bit-identically */
 } ptpp_conv_ln_stack_fwd_args;
 int ptpp_conv_ln_stack_fwd(const ptpp_conv_ln_stack_fwd_args* a, void* stream);
 

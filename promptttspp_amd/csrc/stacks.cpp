@@ -47,7 +47,7 @@ ptpp_conv1d_args conv_args(const void* x, int ldx, const void* wp, const float* 
 // A conv launch of a driver: on the row-tile kernel (conv1d_rt.hip) when its operand stream was handed over and the launch is
 // frame-level -- the SAME rule as promptttspp_amd/ops.py::conv1d_rt_ok, so that both paths take the same kernel -- else as before
 static bool rt_takes(const ptpp_conv1d_args& c, const void* wstream) {
-  return wstream && (int64_t)c.B * c.T >= 8192 && ptpp_conv1d_rt_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype);
+  return wstream && (int64_t)c.B * c.T >= 24576 && ptpp_conv1d_rt_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype);
 }
 
 extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream) {

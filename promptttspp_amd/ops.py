@@ -188,7 +188,7 @@ def _ld_fast(t):
 
 
 CONV_RT = not __import__("os").environ.get("PTPP_NO_CONV_RT")  # the row-tile kernel for the frame-level 256-channel layers
-CONV_RT_MIN_ROWS = 8192
+CONV_RT_MIN_ROWS = 24576  # (below ~200 row tiles of 128 the chip is not filled by one-workgroup-per-CU blocks: the tile kernel wins, 55.6 vs 62.0 us at 32 x 540)
 _rt_ok = {}
 
 

@@ -25,6 +25,7 @@ def _mk(dev, B, T, cin, ks, seed):
 def test_row_tile_conv_is_bit_identical_to_the_tile_kernel(dev, monkeypatch, B, T, cin, ks, dil, act, masked, use_res, bm):
     from promptttspp_amd import ops
 
+    monkeypatch.setattr(ops, "CONV_RT_MIN_ROWS", 1)  # (the product takes the kernel from ~200 row tiles on: small cases here)
     if bm:
         monkeypatch.setenv("PTPP_CONV_RT_BM", str(bm))
     x, w, b, res = _mk(dev, B, T, cin, ks, ks + dil)
@@ -41,12 +42,13 @@ def test_row_tile_conv_is_bit_identical_to_the_tile_kernel(dev, monkeypatch, B, 
     assert float(ref.float().abs().max()) > 0
 
 
-def test_row_tile_data_gradient_operand_and_oracle(dev):
+def test_row_tile_data_gradient_operand_and_oracle(dev, monkeypatch):
     """Pack mode 4 (the stream form of the transposed, tap-flipped operand) against mode 1 through the tile kernel, and both
     against the f32 oracle: the data gradient of a dilated conv is conv_transpose1d."""
     import torch.nn.functional as F
     from promptttspp_amd import ops
 
+    monkeypatch.setattr(ops, "CONV_RT_MIN_ROWS", 1)
     B, T, cout, cin, ks, dil = 12, 800, 512, 256, 3, 4  # gradient flows 512 -> 256 channels
     g = torch.Generator().manual_seed(77)
     dy = (torch.randn(B, T, cout, generator=g)).to(dev).bfloat16()

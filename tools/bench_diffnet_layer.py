@@ -176,7 +176,9 @@ def main():
         fine(19, 1550, 8, False, False, 23)
         return
     if os.environ.get("PTPP_BENCH_PHASES"):
+        phases(19, 1550, 8, True, True)
         phases(19, 1550, 8, False, False)
+        phases(32, 411, 8, False, False)
         return
     shapes = [(19, 1550), (32, 411)] if len(sys.argv) < 3 else [(int(sys.argv[1]), int(sys.argv[2]))]
     for B, T in shapes:
