@@ -98,11 +98,13 @@ class DiffNet(nn.Module):
                                    [l.conditioner_projection.bias for l in ls],
                                    gate_perm=PF.diffnet_fused_gate(cond.dtype))[0]
 
-    def forward_cl(self, x, t, cond, lengths=None, cond_all=None):
+    def forward_cl(self, x, t, cond, lengths=None, cond_all=None, dsteps=None):
         """x (B,T,in_dim), cond (B,T,Cc) channels-last; t (B,) -> (B,T,in_dim).
-        Differentiable unless ``cond_all`` (precomputed, inference) is given."""
+        Differentiable unless ``cond_all`` (precomputed, inference) is given.  ``dsteps``: the step projections (B, L, C) when
+        the caller already has them (the sampler gathers them from a table of all K steps: they depend on t only)."""
         ip, sp, op = self.input_projection, self.skip_projection, self.output_projection
-        dsteps = self.step_embeddings(t)
+        if dsteps is None:
+            dsteps = self.step_embeddings(t)
         h0 = PF.conv1d(x, ip.weight, ip.bias, act="relu")
         ls = self.residual_layers
         if cond_all is None:

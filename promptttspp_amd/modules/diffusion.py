@@ -134,7 +134,11 @@ class GaussianDiffusion(nn.Module):
     def _p_sample_core(self, x, t, cond, cond_all, noise):
         """One reverse step for a device tensor of step indices ``t`` (B,): x_{t-1} = mean + sigma_t * noise
         (reference: diffusion.py:283-302; at t == 0 the caller passes zero noise)."""
-        eps = self.denoise_fn.forward_cl(x.to(cond.dtype), t, cond, None, cond_all=cond_all)
+        # the step-embedding chain (sinusoid, two-layer MLP with Mish, the 20 per-layer projections: ~16 small launches)
+        # depends on t only: the sampler computes it for all K steps at once and gathers a row per utterance here
+        tab = getattr(self, "_dstab", None)
+        dsteps = tab.index_select(0, t) if tab is not None else None
+        eps = self.denoise_fn.forward_cl(x.to(cond.dtype), t, cond, None, cond_all=cond_all, dsteps=dsteps)
         if x.is_cuda and x.dtype == torch.float32 and (x.numel() // x.shape[0]) % 4 == 0:
             from .. import ops
 
@@ -200,6 +204,12 @@ class GaussianDiffusion(nn.Module):
         buffers, writes x back and decrements t itself; the host only refills the noise buffer."""
         if self.pndm_speedup:
             return self.inference_plms_cl(cond, int(self.pndm_speedup), noise_fn)
+        if getattr(self, "_dstab", None) is None and hasattr(self.denoise_fn, "step_embeddings"):
+            self._dstab = self.denoise_fn.step_embeddings(torch.arange(self.K_step, device=cond.device)).contiguous()  # (K, L, C)
+            try:
+                return self.inference_cl(cond, noise_fn, use_graph)
+            finally:
+                self._dstab = None
         B, T, _ = cond.shape
         if self.split_streams and cond.is_cuda and B >= 4 and B * T >= self.split_min_rows and self.K_step > 3 \
                 and not torch.cuda.is_current_stream_capturing() and not self._one_launch_layers(cond):
@@ -212,7 +222,7 @@ class GaussianDiffusion(nn.Module):
         if use_graph is None:
             # replay pays while a step is launch-bound: 1.8x at 1 x 500 frames, 1.2x at 8 x 800, nothing at
             # 32 x 1000 (profiles/r01_app_path_and_sampler_final.txt) -- large batches run eagerly
-            use_graph = self.use_graph and B * T <= 16384
+            use_graph = self.use_graph and B * T <= self.graph_max_rows
         if not (use_graph and cond.is_cuda and K > 3):
             for i in reversed(range(K)):
                 x = self.p_sample_cl(x, i, cond, cond_all, draw(i, shape) if i > 0 else None)
@@ -251,6 +261,7 @@ class GaussianDiffusion(nn.Module):
     # the whole batch is ONE round of workgroups) two half-batch launches only queue behind each other: 156.8 ms split against
     # 146.2 ms unsplit for config 5's 32 prompts -- the split stays for the shapes that kernel does not serve.
     split_streams = __import__("os").environ.get("PTPP_SAMPLER_SPLIT", "1") not in ("0", "off", "no")
+    graph_max_rows = int(__import__("os").environ.get("PTPP_SAMPLER_GRAPH_ROWS", "16384"))
 
     def _one_launch_layers(self, cond):
         from .. import functional as PF
