@@ -376,6 +376,8 @@ typedef struct {
   void* g_out;            /* (B, T, C) bf16 out, or NULL together with a_out                             */
   const int32_t* lengths; /* (B) or NULL: rows past an utterance's end have o = 0 (training)             */
   int32_t B, T, C, dil, ldc, init, dtype;
+  void* skip_scaled;      /* (B, T, C) bf16 out or NULL: bf16(skip * skip_scale) after this layer's update -- on the last  */
+  float skip_scale;       /* layer, the input of the skip projection (sum / sqrt(L), denoiser.py:150) without two launches  */
 } ptpp_diffnet_layer_args;
 int ptpp_diffnet_layer_supported(int C, int dtype);
 int64_t ptpp_diffnet_wstream_bytes(int C);
@@ -620,6 +622,8 @@ typedef struct {
   const void* wstream;      /* L * ptpp_diffnet_wstream_bytes(C) bytes from ptpp_diffnet_pack_wstream, or NULL.  With it (and
                              * fused_gate = 1 or 2, bf16, C = 256) every layer is ONE launch (ptpp_diffnet_layer_fwd),
                              * bit-identical to the two launches it replaces */
+  void* skip_scaled;        /* (B, T, C) dtype out or NULL: dtype(skip * skip_scale) from the last layer's launch (needs the */
+  float skip_scale;         /* one-launch layer, i.e. `wstream`): the input of the skip projection (denoiser.py:150)          */
 } ptpp_diffnet_stack_fwd_args;
 int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream);
 

@@ -69,7 +69,8 @@ class DiffNetFwdArgs(Structure):
 
     _fields_ = [(n, c_void_p) for n in ("h0", "cond_all", "dsteps", "lengths", "skip", "dil_wp", "dil_b", "out_wp", "out_b",
                                         "yin_all", "a_all", "g_all", "x_buf0", "x_buf1", "o_buf")] + \
-               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "n_slabs", "fused_gate", "dtype")] + [("wstream", c_void_p)]
+               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "n_slabs", "fused_gate", "dtype")] + \
+               [("wstream", c_void_p), ("skip_scaled", c_void_p), ("skip_scale", c_float)]
 
 
 class DiffNetLayerArgs(Structure):
@@ -77,7 +78,7 @@ class DiffNetLayerArgs(Structure):
 
     _fields_ = [(n, c_void_p) for n in ("yin", "x", "cond", "wstream", "dil_b", "out_b", "dnext", "skip", "xn", "yin_next", "a_out",
                                         "g_out", "lengths")] + \
-               [(n, c_int32) for n in ("B", "T", "C", "dil", "ldc", "init", "dtype")]
+               [(n, c_int32) for n in ("B", "T", "C", "dil", "ldc", "init", "dtype")] + [("skip_scaled", c_void_p), ("skip_scale", c_float)]
 
 
 class DiffNetBwdArgs(Structure):

@@ -49,7 +49,9 @@ struct DnLayerP {
   bf16_raw* yin_next;
   bf16_raw* a_out;
   bf16_raw* g_out;
+  bf16_raw* skip_scaled;  // optional: bf16(skip * skip_scale), what the skip projection reads (last layer)
   const int* lengths;
+  float skip_scale;
   int B, T, dil, ldc, init, nMT;
   unsigned long long* stamps;  // diagnostics only
 };
@@ -465,6 +467,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           float* sp = skb + (int64_t)t * DN_C + wn * 64 + h * 32 + lg * 8;
+          uint32_t sb[4];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             f32x4 sv = sk[df][h][u];
@@ -475,7 +478,11 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
               sv[e + 1] = (keep ? hi_bf16(ob) : 0.f) + sv[e + 1];
             }
             *reinterpret_cast<f32x4*>(sp + 4 * u) = sv;
+            sb[2 * u] = pack_bf16x2(sv[0] * p.skip_scale, sv[1] * p.skip_scale);
+            sb[2 * u + 1] = pack_bf16x2(sv[2] * p.skip_scale, sv[3] * p.skip_scale);
           }
+          if (p.skip_scaled)
+            *reinterpret_cast<uint4*>(p.skip_scaled + ((int64_t)b * T + t) * DN_C + wn * 64 + h * 32 + lg * 8) = make_uint4(sb[0], sb[1], sb[2], sb[3]);
         }
       }
     }
@@ -582,7 +589,7 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
   PTPP_CHECK_ARG((a->a_out != nullptr) == (a->g_out != nullptr), "diffnet_layer_fwd: a_out and g_out go together (training) or are both NULL");
   const uintptr_t al = (uintptr_t)a->yin | (uintptr_t)a->x | (uintptr_t)a->cond | (uintptr_t)a->wstream | (uintptr_t)a->skip | (uintptr_t)a->xn |
                        (uintptr_t)a->yin_next | (uintptr_t)a->a_out | (uintptr_t)a->g_out | (uintptr_t)a->dil_b | (uintptr_t)a->out_b |
-                       (uintptr_t)a->dnext;
+                       (uintptr_t)a->dnext | (uintptr_t)a->skip_scaled;
   PTPP_CHECK_ARG((al & 15) == 0, "diffnet_layer_fwd: every tensor must be 16-byte aligned");
   DnLayerP p;
   p.yin = reinterpret_cast<const bf16_raw*>(a->yin);
@@ -598,6 +605,8 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
   p.a_out = reinterpret_cast<bf16_raw*>(a->a_out);
   p.g_out = reinterpret_cast<bf16_raw*>(a->g_out);
   p.lengths = a->lengths;
+  p.skip_scaled = reinterpret_cast<bf16_raw*>(a->skip_scaled);
+  p.skip_scale = a->skip_scale;
   p.B = a->B; p.T = a->T; p.dil = a->dil; p.ldc = a->ldc; p.init = a->init;
   // A block holds 96-144 KiB of LDS: one block per CU, a launch runs in rounds of 256 blocks.  Rows per block (128 / 96 / 64):
   // the choice with the least (rounds x time of one block) -- block times measured on the inference form, 57 / 46 / 35 us

@@ -75,6 +75,7 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
   // the whole layer as one launch (csrc/diffnet_layer.hip) where the fused gate is on and the operand stream was handed over
   const bool one_launch = a->wstream && a->fused_gate && ptpp_diffnet_layer_supported(C, dt) && (1 << ((L - 1) % a->cycle)) <= 8 && a->cycle <= 4;
   const int64_t wsb = one_launch ? ptpp_diffnet_wstream_bytes(C) : 0;
+  ST_CHECK_ARG(!a->skip_scaled || one_launch, "diffnet_stack_fwd: skip_scaled needs the one-launch layer (wstream, fused gate, bf16, C = 256)");
   for (int l = 0; l < L; ++l) {
     const int d = 1 << (l % a->cycle);
     const int slab = l % a->n_slabs;
@@ -91,6 +92,7 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
       la.yin_next = dnext ? at(a->yin_all, ((l + 1) % a->n_slabs) * BTC, dt) : nullptr;
       if (a->fused_gate == 2) { la.a_out = at(a->a_all, slab * 2 * BTC, dt); la.g_out = g; }
       la.lengths = a->lengths;
+      if (l == L - 1 && a->skip_scaled) { la.skip_scaled = a->skip_scaled; la.skip_scale = a->skip_scale; }
       la.B = B; la.T = T; la.C = C; la.dil = d; la.ldc = ldc; la.init = l == 0; la.dtype = dt;
       ST_TRY(ptpp_diffnet_layer_fwd(&la, stream));
       x = la.xn;

@@ -925,10 +925,12 @@ def diffnet_wstream(weights, dil_wp, out_wp, dt):
     return _cat_cached(srcs, ("dnws", dt), make)
 
 
-def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None):
+def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None, scaled=False):
     """The whole residual stack in ONE C call (ptpp_diffnet_stack_fwd): the same launches in the same order as the loop
     of ``diffnet_stack_forward`` below (bit-identical), without ~60 Python -> C round trips and ~80 allocations.
-    Returns (skip f32, (yin_all, a_all, g_all) slabs of all layers when ``save``)."""
+    Returns (skip f32, (yin_all, a_all, g_all) slabs of all layers when ``save``); with ``scaled`` the first item is
+    (skip / sqrt(L)).to(dtype) instead (modules/denoiser.py:150) -- written by the last layer's launch where the one-launch
+    layer serves, the same two roundings as the expression."""
     L = len(weights)
     B, T, C = h0.shape
     dt, dev = h0.dtype, h0.device
@@ -968,16 +970,25 @@ def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle,
     a.B, a.T, a.C, a.L, a.cycle, a.n_slabs, a.fused_gate, a.dtype = B, T, C, L, cycle, n_slabs, 2 if gsave else int(fused), ops.dtype_code(dt)
     wstream = diffnet_wstream(weights, dil_wp, out_wp, dt) if (gsave or fused) and cycle <= 4 else None
     a.wstream = wstream.data_ptr() if wstream is not None else None
+    sc = None
+    if scaled and wstream is not None:
+        sc = torch.empty((B, T, C), device=dev, dtype=dt)
+        a.skip_scaled, a.skip_scale = sc.data_ptr(), 1.0 / math.sqrt(L)
     _lib.check(_lib.load().ptpp_diffnet_stack_fwd(ctypes.byref(a), ops._stream()), "ptpp_diffnet_stack_fwd")
+    if scaled:
+        skip = sc if sc is not None else (skip * (1.0 / math.sqrt(L))).to(dt)
     return skip, ((yin_all, a_all, g_all) if save else None)
 
 
-def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None):
+def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None, scaled=False):
     """weights: per layer (dil_w, dil_b, out_w, out_b).  Returns (skip_sum f32, saved).  ``gate_b``: the per-layer dilated-conv
     biases in the gate-interleaved order (``gate_biases``) -- training with the gate fused into the conv and the
-    pre-activation kept; ``cond_all`` is in that order too."""
+    pre-activation kept; ``cond_all`` is in that order too.  ``scaled``: return (skip_sum / sqrt(L)).to(dtype) instead."""
     if STACK_DRIVERS and h0.is_cuda and h0.is_contiguous() and cond_all.is_contiguous():
-        return _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b)
+        return _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b, scaled)
+    if scaled:
+        skip, saved = diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b)
+        return (skip * (1.0 / math.sqrt(len(weights)))).to(h0.dtype), saved
     L = len(weights)
     B, T, C = h0.shape
     skip = torch.empty((B, T, C), device=h0.device, dtype=torch.float32)
@@ -1032,14 +1043,14 @@ class DiffNetStackFn(Function):
         else:
             cond_all, wc = diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws])
         skip, saved = diffnet_stack_forward(h0, cond_all, dsteps, [(w[0], w[1], w[4], w[5]) for w in ws], lengths,
-                                            cycle, save=True, gate_b=gate_b)
+                                            cycle, save=True, gate_b=gate_b, scaled=True)
         ctx.L, ctx.cycle, ctx.lengths, ctx.saved, ctx.ws, ctx.wc = L, cycle, lengths, saved, ws, wc
         ctx.direct = any(ctx.needs_input_grad) and all(_sink(t) is not None for t in flat)
         if ctx.direct:
             for t in flat:
                 _use(t)
         ctx.save_for_backward(cond)
-        return (skip * (1.0 / math.sqrt(L))).to(h0.dtype)
+        return skip
 
     @staticmethod
     @once_differentiable

@@ -114,11 +114,10 @@ class DiffNet(nn.Module):
                   l.conditioner_projection.bias, l.output_projection.weight, l.output_projection.bias) for l in ls])
         else:
             assert lengths is None, "a precomputed cond_all (sampler) is laid out for the unmasked inference path"
-            s, _ = PF.diffnet_stack_forward(
+            skip, _ = PF.diffnet_stack_forward(
                 h0, cond_all, dsteps,
                 [(l.dilated_conv.weight, l.dilated_conv.bias, l.output_projection.weight, l.output_projection.bias)
-                 for l in ls], lengths, self.cycle, save=False)
-            skip = (s * (1.0 / math.sqrt(len(ls)))).to(h0.dtype)
+                 for l in ls], lengths, self.cycle, save=False, scaled=True)
         h = PF.conv1d(skip, sp.weight, sp.bias, act="relu")
         return PF.conv1d(h, op.weight, op.bias)
 

@@ -207,9 +207,12 @@ class GaussianDiffusion(nn.Module):
         if getattr(self, "_dstab", None) is None and hasattr(self.denoise_fn, "step_embeddings"):
             self._dstab = self.denoise_fn.step_embeddings(torch.arange(self.K_step, device=cond.device)).contiguous()  # (K, L, C)
             try:
-                return self.inference_cl(cond, noise_fn, use_graph)
+                return self._inference_cl(cond, noise_fn, use_graph)
             finally:
                 self._dstab = None
+        return self._inference_cl(cond, noise_fn, use_graph)
+
+    def _inference_cl(self, cond, noise_fn, use_graph):
         B, T, _ = cond.shape
         if self.split_streams and cond.is_cuda and B >= 4 and B * T >= self.split_min_rows and self.K_step > 3 \
                 and not torch.cuda.is_current_stream_capturing() and not self._one_launch_layers(cond):

@@ -619,10 +619,12 @@ def diffnet_pack_wstream(dil_wps, out_wps, C):
     return ws
 
 
-def diffnet_layer_fwd(yin, x, cond, wstream, dil_b, out_b, dnext, skip, dil, init, lengths=None, save=False, want_yin=True):
+def diffnet_layer_fwd(yin, x, cond, wstream, dil_b, out_b, dnext, skip, dil, init, lengths=None, save=False, want_yin=True,
+                      skip_scaled=None, skip_scale=1.0):
     """One DiffNet residual layer in ONE launch (ptpp_diffnet_layer_fwd, reference modules/denoiser.py:69-83): returns
     (xn, yin_next, a, g); ``skip`` (f32) is updated in place; ``cond``: this layer's (B, T, 2C) slice (a view with the row
-    stride of the all-layer tensor), gate-interleaved like ``dil_b``.  ``save``: keep a (B,T,2C) and g (B,T,C) (training)."""
+    stride of the all-layer tensor), gate-interleaved like ``dil_b``.  ``save``: keep a (B,T,2C) and g (B,T,C) (training).
+    ``skip_scaled``: optional (B,T,C) tensor of x's dtype that receives (skip * skip_scale) rounded once (last layer)."""
     B, T, C = x.shape
     assert yin.is_contiguous() and x.is_contiguous() and skip.is_contiguous() and skip.dtype == torch.float32 and cond.stride(2) == 1
     xn = torch.empty_like(x)
@@ -639,6 +641,9 @@ def diffnet_layer_fwd(yin, x, cond, wstream, dil_b, out_b, dnext, skip, dil, ini
     args.a_out = a.data_ptr() if save else None
     args.g_out = g.data_ptr() if save else None
     args.lengths = lengths.data_ptr() if lengths is not None else None
+    if skip_scaled is not None:
+        assert skip_scaled.is_contiguous() and skip_scaled.shape == x.shape and skip_scaled.dtype == x.dtype
+        args.skip_scaled, args.skip_scale = skip_scaled.data_ptr(), float(skip_scale)
     args.B, args.T, args.C, args.dil, args.ldc, args.init, args.dtype = B, T, C, int(dil), cond.stride(1), 1 if init else 0, dtype_code(x.dtype)
     check(_lib.load().ptpp_diffnet_layer_fwd(ctypes.byref(args), _stream()), "ptpp_diffnet_layer_fwd")
     return xn, yn, a, g

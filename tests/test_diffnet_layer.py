@@ -43,12 +43,12 @@ def _two_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, skip, 
     return xn, yn, a, g
 
 
-def _one_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, skip, dil, init, lengths, save):
+def _one_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, skip, dil, init, lengths, save, **kw):
     perm = PF._gate_perm(2 * C, x.device)
     wp = ops.pack_conv_weight(dil_w, torch.bfloat16, 2)
     assert torch.equal(wp, ops.pack_conv_weight(dil_w[perm], torch.bfloat16))
     ws = ops.diffnet_pack_wstream([wp], [ops.pack_conv_weight(out_w, torch.bfloat16)], C)
-    return ops.diffnet_layer_fwd(yin, x, cond, ws[0], dil_b[perm].contiguous(), out_b, dnext, skip, dil, init, lengths=lengths, save=save)
+    return ops.diffnet_layer_fwd(yin, x, cond, ws[0], dil_b[perm].contiguous(), out_b, dnext, skip, dil, init, lengths=lengths, save=save, **kw)
 
 
 @pytest.mark.parametrize("B,T,dil,masked,save,init", [
@@ -76,8 +76,11 @@ def test_one_launch_layer_is_bit_identical_to_the_two_launches(dev, monkeypatch,
         lengths = torch.tensor([max(1, T - 150 * i) for i in range(B)], device=dev, dtype=torch.int32)
     s_ref, s_got = skip0.clone(), skip0.clone()
     ref = _two_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, s_ref, dil, init, lengths, save)
-    got = _one_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, s_got, dil, init, lengths, save)
+    sc = torch.full_like(x, float("nan"))  # the skip projection's input, as the last layer of a stack writes it
+    scale = 1.0 / math.sqrt(20)
+    got = _one_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, s_got, dil, init, lengths, save, skip_scaled=sc, skip_scale=scale)
     torch.cuda.synchronize()
+    assert torch.equal(sc, (s_ref * scale).to(x.dtype))
     names = ["xn", "yin_next", "a", "g"]
     for n, a, b in zip(names, ref, got):
         if n in ("a", "g") and not save:
@@ -153,6 +156,12 @@ def test_stack_driver_takes_the_one_launch_layer(dev, monkeypatch):
         assert torch.equal(skip_ref, skip_got)
         for a, b in zip(saved_ref, saved_got):
             assert torch.equal(a, b)
+        with torch.no_grad():  # ... and the scaled form the callers take (one-launch: from the last layer's tail)
+            gate_b, cond_b = PF.gate_biases([w[1] for w in ws], [w[3] for w in ws])
+            cond_all, _ = PF.diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws], bias_perm=cond_b)
+            sc, _ = PF.diffnet_stack_forward(h0, cond_all, dsteps, [(w[0], w[1], w[4], w[5]) for w in ws], lengths, 4, save=True,
+                                             gate_b=gate_b, scaled=True)
+        assert torch.equal(sc, (skip_ref * (1.0 / math.sqrt(L))).to(h0.dtype))
         with torch.no_grad():  # the cached stream must follow the weights
             for w in ws:
                 w[0].mul_(1.25)
