@@ -58,11 +58,114 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp
 // A block owns one 32 (co) x 32 (ci) tile of a source, all taps: reads run along ci, mode-0 writes along
 // ci, mode-1 writes along co after a transpose through LDS (element-wise scattered 2-byte writes made
 // the first version of this kernel 1 ms per step).
+// LDS of a block: 32 rows of up to PB_PITCH_BYTES -- in the operand's own element type, so a bf16 operand needs half the
+// space (eight resident blocks per CU instead of four: the launch is latency-bound, bytes in flight are what it lacks).
+constexpr int PB_PITCH_BYTES = 580;  // 290 bf16 = 32 ci x 9 taps + 2
+constexpr int PB_MAXV = 9;           // float4 loads per thread and pass (32 rows x 288 floats / 256 threads / 4)
+
+template <typename T>
+__device__ __forceinline__ void pack_batched_tile(const int64_t* e, int lb, unsigned char* lds) {
+  const float* src = reinterpret_cast<const float*>(e[0]);
+  T* dst = reinterpret_cast<T*>(e[1]);
+  const int cout = (int)e[2], cin = (int)e[3], ks = (int)e[4], mode = (int)e[5];
+  const int64_t innerp = e[7], off = e[8];
+  const int nci = (cin + 31) / 32;
+  const int co0 = (lb / nci) * 32, ci0 = (lb % nci) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  T* buf = reinterpret_cast<T*>(lds);
+  // ci columns per pass: a source row segment [ci, ci + cw) x all taps is CONTIGUOUS (cw * ks floats) -- copied once, fully
+  // coalesced, every tap then served from LDS (k = 9: one pass of 32 columns; k = 17: two of 16; f32 operands: half of that)
+  constexpr int P = PB_PITCH_BYTES / (int)sizeof(T) - 2;
+  constexpr int PAD = sizeof(T) == 2 ? 2 : 1;  // odd pitch in dwords: the transposed reads below hit distinct banks
+  if (ks > P) {  // (no such conv exists; kept correct: one tap at a time through a 32 x 33 tile)
+    for (int j = 0; j < ks; ++j) {
+      for (int r = ty; r < 32; r += 8)
+        Elem<T>::st(buf + r * 33 + tx, (co0 + r < cout && ci0 + tx < cin) ? src[((int64_t)(co0 + r) * cin + ci0 + tx) * ks + j] : 0.f);
+      __syncthreads();
+      for (int r = ty; r < 32; r += 8) {
+        if (mode != 1 && mode != 4) {
+          const int co = co0 + r, ci = ci0 + tx;
+          if (co < cout && ci < cin)
+            dst[mode == 3 ? stream_index(co, j, ci, ks) : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci] = buf[r * 33 + tx];
+        } else {
+          const int ci = ci0 + r, co = co0 + tx;
+          if (co < cout && ci < cin)
+            dst[mode == 4 ? stream_index(ci, ks - 1 - j, co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co] = buf[tx * 33 + r];
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  int cw = P / ks;
+  cw = cw >= 32 ? 32 : (cw >= 4 ? (cw & ~3) : cw);
+  const bool src_al = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (((int64_t)cin * ks) & 3) == 0;
+  for (int cs = 0; cs < 32 && ci0 + cs < cin; cs += cw) {
+    const int cv = min(cw, cin - ci0 - cs);  // valid columns of this pass
+    const int seg = cv * ks;                 // floats per row
+    const int pitch = cw * ks + PAD;
+    if (cs) __syncthreads();
+    if (src_al && (seg & 3) == 0 && (((ci0 + cs) * ks) & 3) == 0) {
+      const int nv = seg >> 2, items = 32 * nv;  // float4 per row / per pass: all requested before the first is used
+      float4 v[PB_MAXV];
+#pragma unroll
+      for (int i = 0; i < PB_MAXV; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < items) {
+          const int r = idx / nv, q = idx - r * nv;
+          if (co0 + r < cout) v[i] = *reinterpret_cast<const float4*>(src + ((int64_t)(co0 + r) * cin + ci0 + cs) * ks + 4 * q);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PB_MAXV; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (idx < items) {
+          const int r = idx / nv, q = idx - r * nv;
+          T* d = buf + r * pitch + 4 * q;
+          Elem<T>::st(d, v[i].x); Elem<T>::st(d + 1, v[i].y); Elem<T>::st(d + 2, v[i].z); Elem<T>::st(d + 3, v[i].w);
+        }
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < 32 * seg; idx += 256) {
+        const int r = idx / seg, k = idx - r * seg;
+        Elem<T>::st(buf + r * pitch + k, co0 + r < cout ? src[((int64_t)(co0 + r) * cin + ci0 + cs) * ks + k] : 0.f);
+      }
+    }
+    __syncthreads();
+    if (mode != 1 && mode != 4) {  // writes run along ci
+      const int co_w = co0 + ty, ci = ci0 + cs + tx;
+      if (tx < cv) {
+        for (int j = 0; j < ks; ++j) {
+#pragma unroll
+          for (int r = 0; r < 32; r += 8) {
+            const int co = co_w + r;
+            if (co < cout) {
+              const int64_t d = mode == 3 ? stream_index(co, j, ci, ks)
+                                          : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
+              dst[d] = buf[(ty + r) * pitch + tx * ks + j];
+            }
+          }
+        }
+      }
+    } else {  // the tile transposed: r indexes ci, writes run along co
+      const int co = co0 + tx;
+      if (co < cout) {
+        for (int j = 0; j < ks; ++j) {
+          for (int r = ty; r < cv; r += 8) {
+            const int ci = ci0 + cs + r;
+            const int64_t d = mode == 4 ? stream_index(ci, ks - 1 - j, co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
+            dst[d] = buf[tx * pitch + r * ks + j];
+          }
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __restrict__ tab, int n,
                                                            const int* __restrict__ block_map) {
-  constexpr int KS_FAST = 9;                        // taps held at once by the fast path
-  __shared__ float buf[32 * (32 * KS_FAST + 1)];    // 37 KB; the per-tap path uses its first 32 x 33 floats
-  float (*tile)[33] = reinterpret_cast<float (*)[33]>(buf);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[32 * PB_PITCH_BYTES];
   int lo = 0, hi = n - 1;
   if (block_map) lo = hi = block_map[blockIdx.x];
   while (lo < hi) {  // last row whose first block <= blockIdx.x
@@ -71,78 +174,9 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const int64_t* __rest
     else hi = mid - 1;
   }
   const int64_t* e = tab + lo * 10;
-  const float* src = reinterpret_cast<const float*>(e[0]);
-  const int cout = (int)e[2], cin = (int)e[3], ks = (int)e[4], mode = (int)e[5], dtype = (int)e[6];
-  const int64_t innerp = e[7], off = e[8];
   const int lb = (int)((int64_t)blockIdx.x - e[9]);
-  const int nci = (cin + 31) / 32;
-  const int co0 = (lb / nci) * 32, ci0 = (lb % nci) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  if (ks <= KS_FAST) {
-    // fast path: a source row segment [ci0, ci0+32) x all taps is CONTIGUOUS (32*ks floats): copy the 32 rows
-    // once, fully coalesced, then serve every tap from LDS (the per-tap path below re-reads the same cache
-    // lines ks times with a stride of ks floats)
-    const int seg = 32 * ks, pitch = seg + 1;
-    const int kmax = (min(cin, ci0 + 32) - ci0) * ks;  // valid floats of a segment
-    for (int idx = threadIdx.x; idx < 32 * seg; idx += 256) {
-      const int r = idx / seg, k = idx - r * seg;
-      const int co = co0 + r;
-      buf[r * pitch + k] = (co < cout && k < kmax) ? src[((int64_t)co * cin + ci0) * ks + k] : 0.f;
-    }
-    __syncthreads();
-    for (int j = 0; j < ks; ++j) {
-      for (int r = ty; r < 32; r += 8) {
-        if (mode != 1 && mode != 4) {
-          const int co = co0 + r, ci = ci0 + tx;
-          if (co < cout && ci < cin) {
-            const float v = buf[r * pitch + tx * ks + j];
-            const int64_t d = mode == 3 ? stream_index(co, j, ci, ks)
-                                        : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
-            if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = v;
-            else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(v);
-          }
-        } else {  // r indexes ci here, writes run along co
-          const int ci = ci0 + r, co = co0 + tx;
-          if (co < cout && ci < cin) {
-            const float v = buf[tx * pitch + r * ks + j];
-            const int64_t d = mode == 4 ? stream_index(ci, ks - 1 - j, co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
-            if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = v;
-            else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(v);
-          }
-        }
-      }
-    }
-    return;
-  }
-  for (int j = 0; j < ks; ++j) {
-    // tile[co_l][ci_l], reads with ci fastest
-    for (int r = ty; r < 32; r += 8) {
-      const int co = co0 + r, ci = ci0 + tx;
-      tile[r][tx] = (co < cout && ci < cin) ? src[((int64_t)co * cin + ci) * ks + j] : 0.f;
-    }
-    __syncthreads();
-    if (mode != 1 && mode != 4) {
-      for (int r = ty; r < 32; r += 8) {
-        const int co = co0 + r, ci = ci0 + tx;
-        if (co < cout && ci < cin) {
-          const int64_t d = mode == 3 ? stream_index(co, j, ci, ks)
-                                      : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
-          if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = tile[r][tx];
-          else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(tile[r][tx]);
-        }
-      }
-    } else {
-      for (int r = ty; r < 32; r += 8) {  // r indexes ci here, writes run along co
-        const int ci = ci0 + r, co = co0 + tx;
-        if (co < cout && ci < cin) {
-          const int64_t d = mode == 4 ? stream_index(ci, ks - 1 - j, co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
-          if (dtype == PTPP_F32) reinterpret_cast<float*>(e[1])[d] = tile[tx][r];
-          else reinterpret_cast<bf16_raw*>(e[1])[d] = f32_to_bf16(tile[tx][r]);
-        }
-      }
-    }
-    __syncthreads();
-  }
+  if ((int)e[6] == PTPP_F32) pack_batched_tile<float>(e, lb, lds);
+  else pack_batched_tile<bf16_raw>(e, lb, lds);
 }
 
 // 32x32 LDS-tiled transpose of the two inner dims with dtype conversion.

@@ -369,16 +369,33 @@ def test_batched_repack_matches_per_tensor_pack(dtype, dev):
     conv = torch.nn.Conv1d(80, 256, 5).to(dev)
     lin = torch.nn.Linear(256, 104).to(dev)
     qkv = [torch.nn.Linear(64, 64).to(dev) for _ in range(3)]
-    params = [conv.weight, lin.weight] + [m.weight for m in qkv]
+    # the tile shapes of the batched kernel: k = 9 (one pass of 32 columns in bf16, three of 12 in f32), k = 17 (two passes of
+    # 16), a source whose rows are not 16-byte multiples (scalar loads), partial tiles in both directions, the gate-interleaved
+    # and operand-stream orders
+    ffn = torch.nn.Conv1d(96, 160, 9).to(dev)
+    odd = torch.nn.Conv1d(81, 40, 3).to(dev)
+    gate = torch.nn.Conv1d(64, 128, 3).to(dev)
+    wide = torch.nn.Conv1d(256, 256, 17).to(dev)
+    params = [conv.weight, lin.weight, ffn.weight, odd.weight, gate.weight, wide.weight] + [m.weight for m in qkv]
     opt = FusedAdamW(params, lr=0.05)
+    stream = dtype == torch.bfloat16  # (modes 3 / 4 are bf16 operands)
     for step in range(3):
         got = [PF.packed(conv.weight, dtype), PF.packed(conv.weight, dtype, 1), PF.packed(lin.weight, dtype),
                PF.packed(lin.weight, dtype, 1), PF.packed_cat([m.weight for m in qkv], dtype),
-               PF.packed_cat([m.weight for m in qkv], dtype, 1)]
+               PF.packed_cat([m.weight for m in qkv], dtype, 1), PF.packed(ffn.weight, dtype), PF.packed(ffn.weight, dtype, 1),
+               PF.packed(odd.weight, dtype), PF.packed(odd.weight, dtype, 1), PF.packed(gate.weight, dtype, 2)]
         cat = torch.cat([m.weight.detach() for m in qkv], dim=0)
         want = [ops.pack_conv_weight(conv.weight, dtype), ops.pack_conv_weight(conv.weight, dtype, 1),
                 ops.pack_conv_weight(lin.weight, dtype), ops.pack_conv_weight(lin.weight, dtype, 1),
-                ops.pack_conv_weight(cat, dtype), ops.pack_conv_weight(cat, dtype, 1)]
+                ops.pack_conv_weight(cat, dtype), ops.pack_conv_weight(cat, dtype, 1), ops.pack_conv_weight(ffn.weight, dtype),
+                ops.pack_conv_weight(ffn.weight, dtype, 1), ops.pack_conv_weight(odd.weight, dtype),
+                ops.pack_conv_weight(odd.weight, dtype, 1), ops.pack_conv_weight(gate.weight, dtype, 2)]
+        if stream:
+            got += [PF.packed(wide.weight, dtype, 3), PF.packed(wide.weight, dtype, 4)]
+            want += [ops.pack_conv_weight(wide.weight, dtype, 3), ops.pack_conv_weight(wide.weight, dtype, 4)]
+        else:
+            got += [PF.packed(wide.weight, dtype), PF.packed(wide.weight, dtype, 1)]
+            want += [ops.pack_conv_weight(wide.weight, dtype), ops.pack_conv_weight(wide.weight, dtype, 1)]
         for i, (a, b) in enumerate(zip(got, want)):
             assert a.shape == b.shape and torch.equal(a, b), (step, i)
         for p in params:
