@@ -306,10 +306,10 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         lrec = []
         orig_drv = PF._diffnet_stack_forward_driver
 
-        def timed_drv(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None):
+        def timed_drv(h0, cond_all, dsteps, weights, lengths, *rest, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = orig_drv(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b)
+            r = orig_drv(h0, cond_all, dsteps, weights, lengths, *rest, **kw)
             e1.record()
             rows = float(lengths.sum()) if lengths is not None else h0.shape[0] * h0.shape[1]
             lrec.append((e0, e1, len(weights), rows, h0.shape[0] * h0.shape[1], h0.shape[2]))

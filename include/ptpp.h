@@ -152,6 +152,11 @@ int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, int ldr2,
  * (k = 5) and the data gradient of the DiffNet dilated conv, modules/denoiser.py:58-64. */
 int ptpp_conv1d_rt_supported(int cin, int cout, int ks, int dil, int act, int dtype);
 int ptpp_conv1d_rt_fwd(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* stream);
+/* ... with a second output from the same epilogue: aux[row * ldaux + n] = dtype(y[row][n] * aux_scale) computed from the ROUNDED
+ * y, zero on rows past an utterance's end when a->lengths is given (the DiffNet backward takes the next layer's
+ * output-projection gradient operand gx / sqrt2 from here instead of a separate pass over gx). */
+int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* aux, int ldaux, float aux_scale,
+                           void* stream);
 
 /* The same with an optional scratch (16-byte aligned device memory, NULL = none): layers with few
  * output tiles and a long K (Conformer FFN k = 9, BERT FFN) are then split over K -- f32 partial sums
@@ -392,6 +397,10 @@ int ptpp_diffnet_layer_fwd_dbg(const ptpp_diffnet_layer_args* a, int dbg, void* 
 int ptpp_diffnet_post_bwd(const void* gx, const void* gskip, void* dout,
                           const int32_t* lengths, int B, int T, int C, int dtype,
                           void* stream);
+/* The skip halves of ALL layers' dout in one launch: do_all[l][row][C:] = gskip[row] (masked) for l < L, and the residual half
+ * of the LAST layer (whose incoming gx is zero) cleared; the other residual halves come from ptpp_conv1d_rt_fwd_aux. */
+int ptpp_diffnet_post_bwd_fill(const void* gskip, void* do_all, const int32_t* lengths, int B, int T, int C, int L, int dtype,
+                               void* stream);
 /* out[b,c] = sum_t x[b,t,c] (f32) */
 int ptpp_colsum_batch(const void* x, float* out, int B, int T, int C, int dtype,
                       void* stream);

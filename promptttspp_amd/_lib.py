@@ -231,6 +231,7 @@ SIGNATURES = {
     "ptpp_conv1d_gate_fwd_save_supported": (I, [I, I, I]),
     "ptpp_conv1d_gate_fwd_save": (I, [POINTER(ConvArgs), P, I, P]),
     "ptpp_diffnet_post_bwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "ptpp_diffnet_post_bwd_fill": (I, [P, P, P, I, I, I, I, I, P]),
     "ptpp_colsum_batch": (I, [P, P, I, I, I, I, P]),
     "ptpp_col_reduce": (I, [P, P, P, I64, I, I, P, SZ, P]),
     "ptpp_bn_stats": (I, [P, I64, I, F, F, P, P, P, P, I, P, SZ, P]),
@@ -262,6 +263,7 @@ SIGNATURES = {
     "ptpp_diffnet_stack_fwd": (I, [POINTER(DiffNetFwdArgs), P]),
     "ptpp_conv1d_rt_supported": (I, [I, I, I, I, I, I]),
     "ptpp_conv1d_rt_fwd": (I, [POINTER(ConvArgs), P, ctypes.c_float, P]),
+    "ptpp_conv1d_rt_fwd_aux": (I, [POINTER(ConvArgs), P, ctypes.c_float, P, I, ctypes.c_float, P]),
     "ptpp_diffnet_layer_supported": (I, [I, I]),
     "ptpp_diffnet_wstream_bytes": (ctypes.c_int64, [I]),
     "ptpp_diffnet_pack_wstream": (I, [P, P, P, I, I, P]),

@@ -39,6 +39,9 @@ struct RtP {
   int act, in_mask, out_mask;
   float out_scale, res_scale;
   int nMT;
+  bf16_raw* aux;  // optional second output: bf16(y * aux_scale), row stride ldaux, rows past an utterance's end zero
+  int ldaux;
+  float aux_scale;
 };
 
 __device__ __forceinline__ void rt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -239,6 +242,15 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_kernel(const RtP p) {
           o.z = (uint32_t)f32_to_bf16(v[1][0]) | ((uint32_t)f32_to_bf16(v[1][1]) << 16);
           o.w = (uint32_t)f32_to_bf16(v[1][2]) | ((uint32_t)f32_to_bf16(v[1][3]) << 16);
           *reinterpret_cast<uint4*>(yb + (int64_t)t * p.ldy + wn * 64 + h * 32 + lg * 8) = o;
+          if (p.aux) {  // from the ROUNDED output, like a separate pass over y would compute it
+            const float sc = t < len ? p.aux_scale : 0.f;
+            uint4 q;
+            q.x = (uint32_t)f32_to_bf16(__uint_as_float(o.x << 16) * sc) | ((uint32_t)f32_to_bf16(__uint_as_float(o.x & 0xffff0000u) * sc) << 16);
+            q.y = (uint32_t)f32_to_bf16(__uint_as_float(o.y << 16) * sc) | ((uint32_t)f32_to_bf16(__uint_as_float(o.y & 0xffff0000u) * sc) << 16);
+            q.z = (uint32_t)f32_to_bf16(__uint_as_float(o.z << 16) * sc) | ((uint32_t)f32_to_bf16(__uint_as_float(o.z & 0xffff0000u) * sc) << 16);
+            q.w = (uint32_t)f32_to_bf16(__uint_as_float(o.w << 16) * sc) | ((uint32_t)f32_to_bf16(__uint_as_float(o.w & 0xffff0000u) * sc) << 16);
+            *reinterpret_cast<uint4*>(p.aux + ((int64_t)b * T + t) * p.ldaux + wn * 64 + h * 32 + lg * 8) = q;
+          }
         }
       }
     }
@@ -278,7 +290,13 @@ extern "C" int ptpp_conv1d_rt_supported(int cin, int cout, int ks, int dil, int 
 }
 
 extern "C" int ptpp_conv1d_rt_fwd(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* stream) {
+  return ptpp_conv1d_rt_fwd_aux(a, wstream, res_scale, nullptr, 0, 0.f, stream);
+}
+
+extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* aux, int ldaux, float aux_scale,
+                                      void* stream) {
   PTPP_CHECK_ARG(a && a->x && a->y && wstream, "conv1d_rt_fwd: null pointer");
+  PTPP_CHECK_ARG(!aux || ((ldaux & 7) == 0 && ldaux >= RT_N && ((uintptr_t)aux & 15) == 0), "conv1d_rt_fwd: bad aux output (ld %d)", ldaux);
   PTPP_CHECK_ARG(ptpp_conv1d_rt_supported(a->Cin, a->Cout, a->ks, a->dil, a->act, a->dtype),
                  "conv1d_rt_fwd: unsupported shape (bf16, Cout = 256, Cin %% 64 == 0, ks >= 3, act none / relu; Cin %d Cout %d ks %d dil %d act %d)",
                  a->Cin, a->Cout, a->ks, a->dil, a->act);
@@ -299,6 +317,7 @@ extern "C" int ptpp_conv1d_rt_fwd(const ptpp_conv1d_args* a, const void* wstream
   p.ldx = a->ldx; p.ldy = a->ldy; p.ldr = a->ldr;
   p.act = a->act; p.in_mask = a->in_mask; p.out_mask = a->out_mask;
   p.out_scale = a->out_scale; p.res_scale = res_scale;
+  p.aux = reinterpret_cast<bf16_raw*>(aux); p.ldaux = ldaux; p.aux_scale = aux_scale;
   // rows per block: least (rounds of 256 one-per-CU blocks) x (time of a block)
   int bm = 128;
   {

@@ -169,6 +169,26 @@ __global__ void diffnet_post_bwd_kernel(const T* __restrict__ gx, const T* __res
   }
 }
 
+// do_all[l][row][C:] = gskip[row] (masked) for every layer; do_all[L-1][row][:C] = 0
+template <typename T>
+__global__ void diffnet_post_bwd_fill_kernel(const T* __restrict__ gskip, T* __restrict__ do_all, const int* __restrict__ lengths, int Tlen,
+                                             int C, int L, int64_t nvec) {
+  const int cv = C >> 2;
+  const int64_t lstride = nvec * 8;  // elements per layer: rows x 2C
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cv;
+    const int c = (int)(i % cv) * 4;
+    f32x4 s = Elem<T>::ld4(gskip + i * 4);
+    if (lengths) {
+      const int b = (int)(row / Tlen), t = (int)(row % Tlen);
+      if (t >= lengths[b]) s = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    T* d = do_all + row * 2 * C + c;
+    for (int l = 0; l < L; ++l) Elem<T>::st4(d + l * lstride + C, s);
+    Elem<T>::st4(d + (L - 1) * lstride, f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+}
+
 // per-utterance column sums: out[b, c] = sum_t x[b, t, c]   (f32)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_batch_kernel(const T* __restrict__ x, float* __restrict__ out, int Tlen,
@@ -329,6 +349,18 @@ extern "C" int ptpp_diffnet_post_bwd(const void* gx, const void* gskip, void* do
              hipLaunchKernelGGL(diffnet_post_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)gx,
                                 (const T*)gskip, (T*)dout, lengths, T_, C, nvec));
   PTPP_CHECK_LAUNCH("diffnet_post_bwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_diffnet_post_bwd_fill(const void* gskip, void* do_all, const int32_t* lengths, int B, int T_, int C, int L, int dtype,
+                                          void* stream) {
+  PTPP_CHECK_ARG(gskip && do_all && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && L > 0, "diffnet_post_bwd_fill: bad args");
+  const int64_t nvec = (int64_t)B * T_ * C / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, "diffnet_post_bwd_fill",
+             hipLaunchKernelGGL(diffnet_post_bwd_fill_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)gskip, (T*)do_all, lengths,
+                                T_, C, L, nvec));
+  PTPP_CHECK_LAUNCH("diffnet_post_bwd_fill");
   return PTPP_OK;
 }
 

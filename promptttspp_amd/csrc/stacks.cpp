@@ -3,6 +3,7 @@
 // (promptttspp_amd/functional.py) issues them, so the results are bit-identical to it.
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <hip/hip_runtime.h>
@@ -47,7 +48,9 @@ ptpp_conv1d_args conv_args(const void* x, int ldx, const void* wp, const float* 
 // A conv launch of a driver: on the row-tile kernel (conv1d_rt.hip) when its operand stream was handed over and the launch is
 // frame-level -- the SAME rule as promptttspp_amd/ops.py::conv1d_rt_ok, so that both paths take the same kernel -- else as before
 static bool rt_takes(const ptpp_conv1d_args& c, const void* wstream) {
-  return wstream && (int64_t)c.B * c.T >= 24576 && ptpp_conv1d_rt_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype);
+  int64_t min_rows = 24576;
+  if (const char* e = getenv("PTPP_CONV_RT_MIN_ROWS")) min_rows = atoll(e);  // (tests run the row-tile paths at small shapes)
+  return wstream && (int64_t)c.B * c.T >= min_rows && ptpp_conv1d_rt_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype);
 }
 
 extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream) {
@@ -155,6 +158,16 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
     ptpp_set_error("diffnet_stack_bwd: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
     return PTPP_ELAUNCH;
   }
+  // Where the row-tile kernel runs every dilated data gradient, its epilogue also writes the NEXT iteration's residual half of
+  // dout (gx / sqrt2, masked) and one launch fills the skip halves of all layers: no per-layer pass over gx and gS.
+  bool fold = a->dil_wst != nullptr;
+  for (int l = 0; l < L && fold; ++l) {
+    const int d = 1 << (l % a->cycle);
+    ptpp_conv1d_args c = conv_args(a->dcond_all, ldc, a->dil_wpt[l], nullptr, a->gx_all, C, a->gx_all, C, a->lengths, B, T, 2 * C, C, 3, d, d,
+                                   PTPP_ACT_NONE, bmask, 0, dt);
+    fold = rt_takes(c, a->dil_wst[l]);
+  }
+  if (fold) ST_TRY(ptpp_diffnet_post_bwd_fill(a->gS, a->do_all, a->lengths, B, T, C, L, dt, stream));
   for (int l = L - 1; l >= 0; --l) {
     const int d = 1 << (l % a->cycle);
     const void* gx = at(a->gx_all, (size_t)(l + 1) * BTC, dt);
@@ -163,7 +176,7 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
     const void* act = at(a->a_all, (size_t)l * 2 * BTC, dt);
     const void* g = at(a->g_all, (size_t)l * BTC, dt);
     void* da = at(a->dcond_all, (size_t)l * 2 * C, dt);
-    ST_TRY(ptpp_diffnet_post_bwd(gx, a->gS, dout, a->lengths, B, T, C, dt, stream));
+    if (!fold) ST_TRY(ptpp_diffnet_post_bwd(gx, a->gS, dout, a->lengths, B, T, C, dt, stream));
     if (!a->batched_wgrad) {
       if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
       ST_TRY(ptpp_conv1d_wgrad(g, dout, a->dw_out[l], a->db_out[l], nullptr, B, T, C, 2 * C, 1, 1, 0, C, 2 * C, 0, dt, ws_w, ws_w_bytes,
@@ -187,7 +200,8 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
     }
     ptpp_conv1d_args c = conv_args(da, ldc, a->dil_wpt[l], nullptr, gx, C, at(a->gx_all, (size_t)l * BTC, dt), C, a->lengths, B, T, 2 * C, C,
                                    3, d, d, PTPP_ACT_NONE, bmask, 0, dt);
-    if (rt_takes(c, a->dil_wst ? a->dil_wst[l] : nullptr)) ST_TRY(ptpp_conv1d_rt_fwd(&c, a->dil_wst[l], r2, stream));
+    if (fold) ST_TRY(ptpp_conv1d_rt_fwd_aux(&c, a->dil_wst[l], r2, l > 0 ? at(a->do_all, (size_t)(l - 1) * 2 * BTC, dt) : nullptr, 2 * C, r2, stream));
+    else if (rt_takes(c, a->dil_wst ? a->dil_wst[l] : nullptr)) ST_TRY(ptpp_conv1d_rt_fwd(&c, a->dil_wst[l], r2, stream));
     else ST_TRY(ptpp_conv1d_fwd_ex(&c, nullptr, 0, r2, 0.f, 0, stream));
   }
   if (a->batched_wgrad) {

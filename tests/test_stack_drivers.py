@@ -71,6 +71,36 @@ def test_diffnet_stack_driver_is_bit_identical_to_the_per_launch_path(dev, monke
     assert float(ref[0].float().abs().max()) > 0 and all(float(t.float().abs().max()) > 0 for t in ref[1:4])
 
 
+@pytest.mark.parametrize("B,T,L,masked", [(6, 700, 6, True), (3, 333, 5, False), (5, 130, 9, True)])
+def test_diffnet_stack_backward_takes_dout_from_the_data_gradient_epilogue(dev, monkeypatch, B, T, L, masked):
+    """Where the row-tile kernel runs the dilated data gradients (frame-level row counts; forced here), the driver has no
+    per-layer pass over gx / gS: the residual half of each layer's dout leaves the epilogue of the layer above
+    (ptpp_conv1d_rt_fwd_aux) and one launch fills all skip halves (ptpp_diffnet_post_bwd_fill).  Everything equal bit for bit
+    to the per-launch path, whose dout comes from ptpp_diffnet_post_bwd."""
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd import ops
+
+    monkeypatch.setattr(ops, "CONV_RT_MIN_ROWS", 1)
+    monkeypatch.setenv("PTPP_CONV_RT_MIN_ROWS", "1")
+    C = 256
+    h0, cond, dsteps, lengths, params = _stack_case(dev, B, T, C, L, torch.bfloat16, masked, seed=31)
+    gout = rnd(9, B, T, C).to(dev).bfloat16()
+    monkeypatch.setattr(PF, "BATCHED_WGRAD", False)
+    monkeypatch.setattr(PF, "STACK_DRIVERS", False)
+    ref = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    monkeypatch.setattr(PF, "STACK_DRIVERS", True)
+    got = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+    monkeypatch.setattr(PF, "BATCHED_WGRAD", True)  # the batched weight gradients read the same dout slabs
+    bat = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    for i, (a, b) in enumerate(zip(ref, bat)):
+        if i < 4:
+            assert torch.equal(a, b), i
+        else:
+            assert float((a.double() - b.double()).abs().max() / a.double().abs().max()) < 2e-5, i
+
+
 @pytest.mark.parametrize("B,T,C,L", [(6, 700, 256, 8), (19, 1500, 256, 20)])
 def test_diffnet_stack_batched_weight_gradients(dev, monkeypatch, B, T, C, L):
     """The driver's default: the 2 L weight gradients of the stack as two batched launches in which every dw element has ONE
