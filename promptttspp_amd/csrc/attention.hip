@@ -737,6 +737,361 @@ __global__ __launch_bounds__(256) void attn_bwd_pos_kernel(const AttnBwdP p, flo
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward on the matrix cores (round 4; bf16, dk in {64, 128}, the "new" rel-pos table or no table, T small enough for the
+// LDS images below).  Same tiling idiom as attn_fwd_mfma_kernel -- a wave owns 16 rows, the "other" sequence dimension is
+// the MFMA K or N -- three kernels replacing attn_bwd_row4 / col / pos:
+//   q  (64 query rows per block): dP^T = V_frag x dctx^T, dS from the saved probabilities in the softmax layout of the
+//      forward (a lane: one query row, 4 consecutive keys per fragment), dq^T = K^T_frag x dS (transposing LDS reads, as the
+//      forward's context product) + Pos^T_frag x D with D[i][m] = dS[i][m - (T-1) + i] -- the inverse of the forward's skew,
+//      through the same 16 x 32 f32 patch per wave; du / dvb = column sums of the two dq parts.
+//   k  (64 keys per block): dK^T = (q+u)^T_frag x dS, dV^T = dctx^T_frag x P_dropped; the B operands (a key, 8 query rows)
+//      come straight from global memory (coalesced over the keys).
+//   pos (16 table rows per block, all utterances of a batch group): dpos^T = (q+v)^T_frag x D.
+// dS / P enter the MFMAs rounded to bf16 (the row kernels keep them in f32): within the bf16 tolerance of the tests.
+template <int DK>
+__device__ __forceinline__ bf16x8_t mf_tr_frag(const bf16_raw* img, int base, int mf, int lq, int lg) {
+  // A operand [16 channels mf*16 ..][32 rows base ..] of a row-major [row][DK] image with the vsw swizzle: slots 0-3 = rows
+  // base + 4 lg + (0..3), slots 4-7 = rows base + 16 + 4 lg + (0..3)
+  constexpr int CPR = DK / 8;
+  const int col = mf * 16 + 4 * (lq & 3);
+  const int ra = base + 4 * lg + (lq >> 2), rb = ra + 16;
+  const mf_v4s lo = mf_tr_read(img + ra * DK + (((col >> 3) ^ vsw<CPR>(ra)) << 3) + (col & 7));
+  const mf_v4s hi = mf_tr_read(img + rb * DK + (((col >> 3) ^ vsw<CPR>(rb)) << 3) + (col & 7));
+  typedef __attribute__((ext_vector_type(8))) short v8s_;
+  v8s_ av;
+  av[0] = lo[0]; av[1] = lo[1]; av[2] = lo[2]; av[3] = lo[3];
+  av[4] = hi[0]; av[5] = hi[1]; av[6] = hi[2]; av[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, av);
+}
+
+constexpr int BQ_MAXNF = 16;  // key fragments of 16 held in registers: T <= 256
+
+template <int DK>
+__global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(const AttnBwdP p) {
+  typedef bf16_raw T;
+  constexpr int CPR = DK / 8, KS = DK / 32, MAXNF = BQ_MAXNF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Tn = p.T, Tp = (Tn + 31) & ~31, PW = Tp + 64;
+  // LDS: region A = max(Tp, PW) rows -- V for the dP product, then (after a barrier) the block's window of the positional
+  // table; region B = K (Tp rows).  All three at once would be 208 KB at T = 256, dk = 128.
+  const int rowsA = p.variant == VAR_NEW ? PW : Tp;
+  uint4* Vk = reinterpret_cast<uint4*>(smem);                   // V  [Tp][CPR], row reads (ksw swizzle)
+  T* Pt = reinterpret_cast<T*>(smem);                           // table rows mlo .. mlo + PW - 1, transposing reads (vsw swizzle)
+  T* Kt = reinterpret_cast<T*>(smem) + (size_t)rowsA * DK;      // K  [Tp][DK], transposing reads
+  float* Rs = reinterpret_cast<float*>(Kt + (size_t)Tp * DK);   // [4 waves][16][33]
+  float* red = Rs + 4 * 16 * 33;                                // [4 waves][2][DK]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int ib0 = blockIdx.x * 64, i0 = ib0 + w * 16;
+  const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
+  const int hc = h * DK;
+  const T* kb = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + hc;
+  const T* vb = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + hc;
+  const T* pb = p.pos ? reinterpret_cast<const T*>(p.pos) + hc : nullptr;
+  const int mlo = Tn - 1 - (ib0 + 63);
+  for (int idx = tid; idx < Tp * CPR; idx += 256) {
+    const int row = idx / CPR, c = idx % CPR;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
+    if (row < len) {
+      kv = *reinterpret_cast<const uint4*>(kb + (int64_t)row * p.ld + c * 8);
+      vv = *reinterpret_cast<const uint4*>(vb + (int64_t)row * p.ld + c * 8);
+    }
+    Vk[row * CPR + (c ^ ksw<CPR>(row))] = vv;
+    *reinterpret_cast<uint4*>(Kt + row * DK + ((c ^ vsw<CPR>(row)) << 3)) = kv;
+  }
+  const int iq = i0 + lq;
+  const bool qvalid = iq < Tn, live = iq < len;
+  uint4 g[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    g[ks] = make_uint4(0, 0, 0, 0);
+    if (live) g[ks] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.dctx) + ((int64_t)b * Tn + iq) * p.lddctx + hc + ks * 32 + lg * 8);
+  }
+  __syncthreads();
+  f32x4 oc[DK / 16], op[DK / 16];
+#pragma unroll
+  for (int mf = 0; mf < DK / 16; ++mf) oc[mf] = op[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 ds[MAXNF];
+#pragma unroll
+  for (int nf = 0; nf < MAXNF; ++nf) ds[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nfr = (i0 < Tn && i0 < len) ? (len + 15) >> 4 : 0;
+  if (i0 < Tn) {
+    // ---- dP, dS ----
+    f32x4 pr[MAXNF];
+    const int64_t prow = (((int64_t)b * p.H + h) * Tn + iq) * Tn;
+    float dsum = 0.f;
+#pragma unroll
+    for (int nf = 0; nf < MAXNF; ++nf) {
+      pr[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (nf < nfr) {
+        const int krow = nf * 16 + lq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint4 vf = Vk[krow * CPR + ((ks * 4 + lg) ^ ksw<CPR>(krow))];
+          ds[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, g[ks]), ds[nf], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = nf * 16 + 4 * lg + r;
+          if (live && j < len) {
+            pr[nf][r] = p.probs[prow + j];
+            if (p.drop_thresh16) ds[nf][r] *= attn_keep(p, (uint64_t)prow + j);
+            dsum += pr[nf][r] * ds[nf][r];
+          }
+        }
+      }
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+#pragma unroll
+    for (int nf = 0; nf < MAXNF; ++nf) {
+      if (nf * 16 < Tn) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = nf * 16 + 4 * lg + r;
+          const float v = (nf < nfr && live && j < len) ? pr[nf][r] * (ds[nf][r] - dsum) * p.scale : 0.f;
+          ds[nf][r] = v;
+          if (qvalid && j < Tn) p.dS[prow + j] = v;
+        }
+      }
+    }
+    // ---- dq, content part: K^T_frag x dS ----
+    const int nsteps = (nfr + 1) >> 1;
+#pragma unroll
+    for (int st = 0; st < MAXNF / 2; ++st) {
+      if (st < nsteps) {
+        float pv[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pv[r] = ds[2 * st][r];
+          pv[4 + r] = ds[2 * st + 1][r];
+        }
+        const uint4 pf = mf_pack8(pv);
+#pragma unroll
+        for (int mf = 0; mf < DK / 16; ++mf)
+          oc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_tr_frag<DK>(Kt, st * 32, mf, lq, lg), __builtin_bit_cast(bf16x8_t, pf), oc[mf], 0, 0, 0);
+      }
+    }
+  }
+  // ---- dq, positional part: the table window takes V's place; per key fragment the 16 x 32 patch
+  // D[query][table row - m0], m0 = T-1-(i0+15) + 16 nf ----
+  if (p.variant == VAR_NEW) {
+    __syncthreads();  // every wave is done with V
+    for (int idx = tid; idx < PW * CPR; idx += 256) {
+      const int row = idx / CPR, c = idx % CPR, m = mlo + row;
+      uint4 pv = make_uint4(0, 0, 0, 0);
+      if (m >= 0 && m < 2 * Tn - 1) pv = *reinterpret_cast<const uint4*>(pb + (int64_t)m * p.ldpos + c * 8);
+      *reinterpret_cast<uint4*>(Pt + row * DK + ((c ^ vsw<CPR>(row)) << 3)) = pv;
+    }
+    __syncthreads();
+  }
+  if (i0 < Tn) {
+    if (p.variant == VAR_NEW) {
+      float* Rw = Rs + w * (16 * 33);
+#pragma unroll
+      for (int nf = 0; nf < MAXNF; ++nf) {
+        if (nf < nfr) {
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 15 - lq + 4 * lg + r;  // in [0, 31)
+            Rw[lq * 33 + c] = ds[nf][r];
+            Rw[lq * 33 + ((c + 16) & 31)] = 0.f;
+          }
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          float dv[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dv[r] = Rw[lq * 33 + 4 * lg + r];
+            dv[4 + r] = Rw[lq * 33 + 16 + 4 * lg + r];
+          }
+          const uint4 df = mf_pack8(dv);
+          const int r0 = 48 - 16 * w + 16 * nf;  // window row of table row m0
+#pragma unroll
+          for (int mf = 0; mf < DK / 16; ++mf)
+            op[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_tr_frag<DK>(Pt, r0, mf, lq, lg), __builtin_bit_cast(bf16x8_t, df), op[mf], 0, 0, 0);
+        }
+      }
+    }
+    if (qvalid) {
+      T* dqr = reinterpret_cast<T*>(p.dq) + ((int64_t)b * Tn + iq) * p.lddq + hc;
+#pragma unroll
+      for (int mf = 0; mf < DK / 16; ++mf) Elem<T>::st4(dqr + mf * 16 + 4 * lg, oc[mf] + op[mf]);
+    }
+  }
+  // ---- du / dvb: column sums of the two parts over the block's query rows ----
+  if (p.variant != VAR_PLAIN) {
+#pragma unroll
+    for (int mf = 0; mf < DK / 16; ++mf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = oc[mf][r], c = op[mf][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          c += __shfl_xor(c, o, 64);
+        }
+        if (lq == 0) {
+          red[(w * 2 + 0) * DK + mf * 16 + 4 * lg + r] = a;
+          red[(w * 2 + 1) * DK + mf * 16 + 4 * lg + r] = c;
+        }
+      }
+    __syncthreads();
+    float* rep = p.scratch + (size_t)((blockIdx.x + gridDim.x * blockIdx.z) % PTPP_RED_NREP) * (2 * p.H * DK);
+    for (int c = tid; c < 2 * DK; c += 256) {
+      const float v = red[c] + red[2 * DK + c] + red[4 * DK + c] + red[6 * DK + c];
+      atomicAdd(rep + (c < DK ? hc + c : p.H * DK + hc + (c - DK)), v);
+    }
+  }
+}
+
+template <int DK>
+__global__ __launch_bounds__(256) void attn_bwd_k_mfma_kernel(const AttnBwdP p, void* dk_out, void* dv_out) {
+  typedef bf16_raw T;
+  constexpr int CPR = DK / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Tn = p.T, Tp = (Tn + 31) & ~31;
+  T* Qt = reinterpret_cast<T*>(smem);   // (q + u) [Tp][DK], transposing reads
+  T* Gt = Qt + (size_t)Tp * DK;         // dctx    [Tp][DK]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int j0 = blockIdx.x * 64 + w * 16, jq = j0 + lq;
+  const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
+  const int hc = h * DK;
+  const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + hc;
+  const T* gb = reinterpret_cast<const T*>(p.dctx) + (int64_t)b * Tn * p.lddctx + hc;
+  for (int idx = tid; idx < Tp * CPR; idx += 256) {
+    const int row = idx / CPR, c = idx % CPR;
+    uint4 qv = make_uint4(0, 0, 0, 0), gv = qv;
+    if (row < len) {
+      qv = *reinterpret_cast<const uint4*>(qb + (int64_t)row * p.ld + c * 8);
+      gv = *reinterpret_cast<const uint4*>(gb + (int64_t)row * p.lddctx + c * 8);
+      if (p.variant != VAR_PLAIN) {
+        const float qf[8] = {__uint_as_float(qv.x << 16), __uint_as_float(qv.x & 0xffff0000u), __uint_as_float(qv.y << 16),
+                             __uint_as_float(qv.y & 0xffff0000u), __uint_as_float(qv.z << 16), __uint_as_float(qv.z & 0xffff0000u),
+                             __uint_as_float(qv.w << 16), __uint_as_float(qv.w & 0xffff0000u)};
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = qf[e] + p.bias_u[hc + c * 8 + e];
+        qv = mf_pack8(a);
+      }
+    }
+    *reinterpret_cast<uint4*>(Qt + row * DK + ((c ^ vsw<CPR>(row)) << 3)) = qv;
+    *reinterpret_cast<uint4*>(Gt + row * DK + ((c ^ vsw<CPR>(row)) << 3)) = gv;
+  }
+  __syncthreads();
+  if (j0 >= Tn) return;
+  f32x4 ak[DK / 16], av[DK / 16];
+#pragma unroll
+  for (int mf = 0; mf < DK / 16; ++mf) ak[mf] = av[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t base = ((int64_t)b * p.H + h) * Tn * Tn;
+  const int nsteps = j0 < len ? (len + 31) >> 5 : 0;
+  for (int st = 0; st < nsteps; ++st) {
+    float dsv[8], pv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int i = st * 32 + (s >> 2) * 16 + 4 * lg + (s & 3);
+      dsv[s] = pv[s] = 0.f;
+      if (i < len && jq < len) {
+        const int64_t e = base + (int64_t)i * Tn + jq;
+        dsv[s] = p.dS[e];
+        pv[s] = p.probs[e];
+        if (p.drop_thresh16) pv[s] *= attn_keep(p, (uint64_t)e);
+      }
+    }
+    const uint4 dsf = mf_pack8(dsv), pf = mf_pack8(pv);
+#pragma unroll
+    for (int mf = 0; mf < DK / 16; ++mf) {
+      ak[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_tr_frag<DK>(Qt, st * 32, mf, lq, lg), __builtin_bit_cast(bf16x8_t, dsf), ak[mf], 0, 0, 0);
+      av[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_tr_frag<DK>(Gt, st * 32, mf, lq, lg), __builtin_bit_cast(bf16x8_t, pf), av[mf], 0, 0, 0);
+    }
+  }
+  if (jq < Tn) {
+    T* dkr = reinterpret_cast<T*>(dk_out) + ((int64_t)b * Tn + jq) * p.lddq + hc;
+    T* dvr = reinterpret_cast<T*>(dv_out) + ((int64_t)b * Tn + jq) * p.lddq + hc;
+#pragma unroll
+    for (int mf = 0; mf < DK / 16; ++mf) {
+      Elem<T>::st4(dkr + mf * 16 + 4 * lg, ak[mf]);
+      Elem<T>::st4(dvr + mf * 16 + 4 * lg, av[mf]);
+    }
+  }
+}
+
+template <int DK>
+__global__ __launch_bounds__(256) void attn_bwd_pos_mfma_kernel(const AttnBwdP p, float* dpos) {
+  typedef bf16_raw T;
+  constexpr int CPR = DK / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Tn = p.T, Tp = (Tn + 31) & ~31;
+  T* Qv = reinterpret_cast<T*>(smem);  // (q + v) of the current utterance [Tp][DK]; afterwards the waves' partial tiles (f32)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int h = blockIdx.y, hc = h * DK;
+  const int m0 = blockIdx.x * 16, m = m0 + lq;
+  const int nbg = gridDim.z, bper = (p.B + nbg - 1) / nbg;
+  const int b0 = blockIdx.z * bper, b1 = min(p.B, b0 + bper);
+  f32x4 acc[DK / 16];
+#pragma unroll
+  for (int mf = 0; mf < DK / 16; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // query rows that meet this block's table rows: 0 <= j = m - (T-1) + i < T
+  const int ilo = max(0, Tn - 1 - (m0 + 15)), ihi = min(Tn - 1, 2 * Tn - 2 - m0);
+  for (int b = b0; b < b1; ++b) {
+    const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
+    const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + hc;
+    __syncthreads();  // the previous utterance's reads are done
+    for (int idx = tid; idx < Tp * CPR; idx += 256) {
+      const int row = idx / CPR, c = idx % CPR;
+      uint4 qv = make_uint4(0, 0, 0, 0);
+      if (row < len && row >= (ilo & ~31) && row <= ihi) {
+        qv = *reinterpret_cast<const uint4*>(qb + (int64_t)row * p.ld + c * 8);
+        const float qf[8] = {__uint_as_float(qv.x << 16), __uint_as_float(qv.x & 0xffff0000u), __uint_as_float(qv.y << 16),
+                             __uint_as_float(qv.y & 0xffff0000u), __uint_as_float(qv.z << 16), __uint_as_float(qv.z & 0xffff0000u),
+                             __uint_as_float(qv.w << 16), __uint_as_float(qv.w & 0xffff0000u)};
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = qf[e] + p.bias_v[hc + c * 8 + e];
+        qv = mf_pack8(a);
+      }
+      *reinterpret_cast<uint4*>(Qv + row * DK + ((c ^ vsw<CPR>(row)) << 3)) = qv;
+    }
+    __syncthreads();
+    const float* dsb = p.dS + ((int64_t)b * p.H + h) * Tn * Tn;
+    const int s_lo = ilo >> 5, s_hi = min(ihi, len - 1) >> 5;
+    for (int st = s_lo + w; st <= s_hi; st += 4) {
+      float dv[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int i = st * 32 + (s >> 2) * 16 + 4 * lg + (s & 3);
+        const int j = m - (Tn - 1) + i;
+        dv[s] = (i < len && j >= 0 && j < len) ? dsb[(int64_t)i * Tn + j] : 0.f;
+      }
+      const uint4 df = mf_pack8(dv);
+#pragma unroll
+      for (int mf = 0; mf < DK / 16; ++mf)
+        acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_tr_frag<DK>(Qv, st * 32, mf, lq, lg), __builtin_bit_cast(bf16x8_t, df), acc[mf], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* part = reinterpret_cast<float*>(smem);  // [4 waves][16 table rows][DK]
+#pragma unroll
+  for (int mf = 0; mf < DK / 16; ++mf)
+    *reinterpret_cast<f32x4*>(part + ((w * 16 + lq) * DK) + mf * 16 + 4 * lg) = acc[mf];
+  __syncthreads();
+  const int L = 2 * Tn - 1;
+  for (int idx = tid; idx < 16 * DK; idx += 256) {
+    const int r = idx / DK, c = idx % DK;
+    if (m0 + r >= L) continue;
+    const float v = part[idx] + part[16 * DK + idx] + part[2 * 16 * DK + idx] + part[3 * 16 * DK + idx];
+    float* d = dpos + (int64_t)(m0 + r) * (p.H * DK) + hc + c;
+    if (nbg == 1) *d = v;
+    else atomicAdd(d, v);
+  }
+}
+
 bool shape_ok(int B, int T, int H, int dk) {
   return B > 0 && T > 0 && T <= 2048 && H > 0 && (dk == 64 || dk == 128 || dk == 256);
 }
@@ -812,6 +1167,42 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
   // dpos ((2T-1) rows, legacy: T rows): batch groups so that (L/4) x H x groups >= ~1024 blocks; groups > 1 accumulate
   // with atomics into the buffer zeroed here
   const int L = variant == VAR_LEGACY ? T_ : 2 * T_ - 1;
+  // bf16, dk 64 / 128, no legacy table, the LDS images fit: the three products on the matrix cores (PTPP_ATTN_BWD_MFMA=0: the
+  // row / column kernels below)
+  {
+    static const char* bm_env = getenv("PTPP_ATTN_BWD_MFMA");
+    const int Tp = (T_ + 31) & ~31;
+    const size_t sm_q = (size_t)((variant == VAR_NEW ? Tp + 64 : Tp) + Tp) * dk * 2 + (4 * 16 * 33 + 8 * dk) * sizeof(float);
+    const size_t sm_k = (size_t)Tp * dk * 2 * 2;
+    const size_t sm_p = (size_t)Tp * dk * 2 > (size_t)4 * 16 * dk * 4 ? (size_t)Tp * dk * 2 : (size_t)4 * 16 * dk * 4;
+    const uintptr_t al = (uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dctx | (uintptr_t)pos;
+    if (dtype == PTPP_BF16 && (dk == 64 || dk == 128) && variant != VAR_LEGACY && T_ <= 16 * BQ_MAXNF && sm_q <= 160 * 1024 && ld % 8 == 0 &&
+        lddctx % 8 == 0 && lddq % 4 == 0 && (variant == VAR_PLAIN || ldpos % 8 == 0) && (al & 15) == 0 && !(bm_env && bm_env[0] == '0')) {
+      const dim3 gq((T_ + 63) / 64, H, B);
+      int nbg2 = (256 + ((L + 15) / 16) * H - 1) / (((L + 15) / 16) * H);
+      if (nbg2 > B) nbg2 = B;
+      if (variant != VAR_PLAIN && nbg2 > 1) (void)hipMemsetAsync(dpos, 0, (size_t)L * H * dk * sizeof(float), st);
+#define ATTN_BWD_MF(DKV)                                                                                                              \
+  {                                                                                                                                   \
+    static bool attr_done = false;                                                                                                    \
+    if (!attr_done) {                                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_mfma_kernel<DKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_k_mfma_kernel<DKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_pos_mfma_kernel<DKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_done = true;                                                                                                               \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL(attn_bwd_q_mfma_kernel<DKV>, gq, dim3(256), sm_q, st, p);                                                      \
+    hipLaunchKernelGGL(attn_bwd_k_mfma_kernel<DKV>, gq, dim3(256), sm_k, st, p, dk_out, dv_out);                                      \
+    if (variant != VAR_PLAIN)                                                                                                         \
+      hipLaunchKernelGGL(attn_bwd_pos_mfma_kernel<DKV>, dim3((L + 15) / 16, H, nbg2), dim3(256), sm_p, st, p, dpos);                  \
+  }
+      if (dk == 128) ATTN_BWD_MF(128) else ATTN_BWD_MF(64)
+#undef ATTN_BWD_MF
+      if (variant != VAR_PLAIN) red_sum_launch(scratch, 2 * H * dk, du, H * dk, dvb, 1, st);
+      PTPP_CHECK_LAUNCH("attention_bwd (mfma)");
+      return PTPP_OK;
+    }
+  }
   const int lblk = (L + 3) / 4 * H;
   int nbg = (1024 + lblk - 1) / lblk;
   if (nbg > B) nbg = B;

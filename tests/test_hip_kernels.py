@@ -878,3 +878,45 @@ def test_attention_forward_on_the_matrix_cores(dev, variant, B, T, H, dk, drop):
     assert float((probs - probs_r).abs().max()) < 2e-2 * float(probs_r.max())   # q + u / q + v rounded to bf16 operands
     err = float((ctx.float() - ctx_r).abs().max() / ctx_r.abs().max())
     assert err < 2e-2, err
+
+
+@pytest.mark.parametrize("variant,B,T,H,dk,drop", [("new", 5, 77, 2, 128, 0.0), ("new", 19, 150, 4, 128, 0.1), ("new", 3, 176, 2, 128, 0.0), ("new", 3, 256, 2, 128, 0.0),
+                                                   ("new", 4, 230, 4, 128, 0.1),
+                                                   ("new", 2, 33, 4, 64, 0.0), ("plain", 6, 48, 4, 64, 0.1), ("plain", 4, 190, 2, 128, 0.0),
+                                                   ("new", 1, 16, 2, 128, 0.0), ("new", 4, 65, 2, 64, 0.0)])
+def test_attention_backward_on_the_matrix_cores(dev, variant, B, T, H, dk, drop):
+    """attn_bwd_{q,k,pos}_mfma_kernel (bf16; reference esp/transformer/attention.py:63-93,237-305 under autograd) against the
+    exact-f32 row / column kernels on the same bf16-rounded operands and the same dropout mask: dq, dk, dv, the positional
+    table's gradient and the two bias gradients; ragged lengths (an utterance of one phone included), T not a multiple of any
+    tile, gradients of padded rows exactly zero."""
+    from promptttspp_amd import ops
+
+    C = H * dk
+    qkv = (rnd(1, B, T, 3 * C) * 0.5).to(dev).bfloat16()
+    dctx = (rnd(5, B, T, C) * 0.5).to(dev).bfloat16()
+    lens = torch.tensor([max(1, T - 17 * i) for i in range(B)], device=dev, dtype=torch.int32)
+    pos = u = vb = None
+    if variant == "new":
+        pos = (rnd(2, 2 * T - 1, C) * 0.5).to(dev).bfloat16()
+        u, vb = (0.1 * rnd(3, H, dk)).to(dev), (0.1 * rnd(4, H, dk)).to(dev)
+
+    def run(dt):
+        x, g = qkv.to(dt), dctx.to(dt)
+        ps = pos.to(dt) if pos is not None else None
+        q, k, v = x[:, :, :C], x[:, :, C:2 * C], x[:, :, 2 * C:]
+        _, probs = ops.attention_fwd(q, k, v, ps, u, vb, lens, H, variant, save_probs=True, drop_p=drop, drop_seed=77)
+        d = torch.full((B, T, 3 * C), float("nan"), device=dev, dtype=dt)
+        dpos, du, dvb = ops.attention_bwd(q, k, v, ps, u, vb, probs, g, lens, H, variant, d[:, :, :C], d[:, :, C:2 * C], d[:, :, 2 * C:],
+                                          drop_p=drop, drop_seed=77)
+        torch.cuda.synchronize()
+        return [d.float()] + ([dpos, du, dvb] if variant == "new" else [])
+
+    got, ref = run(torch.bfloat16), run(torch.float32)
+    for i, (a, r) in enumerate(zip(got, ref)):
+        assert torch.isfinite(a).all(), i
+        err = float((a - r).abs().max() / r.abs().max())
+        assert err < 2e-2, (i, err)
+    for bi in range(B):
+        n = int(lens[bi])
+        if n < T:
+            assert float(got[0][bi, n:].abs().max()) == 0.0
