@@ -264,6 +264,17 @@ int ptpp_layernorm_bwd(const void* dy, const void* xsum, const void* z,
                        int act_in, float drop_in_p, uint64_t drop_in_seed,
                        float drop_out_p, uint64_t drop_out_seed, int dtype,
                        void* scratch, size_t scratch_bytes, void* stream);
+/* ... with the neighbouring elementwise passes of a pre-norm residual block folded in (bit for bit what the separate
+ * launches produce): dsum = add + T(dL/ds) (`add` = gradient of the residual branch, may be NULL; the LayerNorm input
+ * gradient is rounded to the storage type first, like a stored intermediate), and dz = the backward of the epilogue that FED
+ * the block (ptpp_epilogue_bwd on dsum as stored): dz = dsum * dz_scale * [t < len when dz_mask] * dropmask_in * act_in'(z). */
+int ptpp_layernorm_bwd_add(const void* dy, const void* xsum, const void* z,
+                           const float* gamma, const float* mean, const float* rstd,
+                           void* dsum, void* dz, const void* add, float dz_scale, int dz_mask, float* dgamma, float* dbeta,
+                           const int32_t* lengths, int B, int T, int C, int out_mask,
+                           int act_in, float drop_in_p, uint64_t drop_in_seed,
+                           float drop_out_p, uint64_t drop_out_seed, int dtype,
+                           void* scratch, size_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Relative-position multi-head attention for short sequences

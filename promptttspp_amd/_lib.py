@@ -213,6 +213,7 @@ SIGNATURES = {
     "ptpp_epilogue_bwd": (I, [P, P, P, P, I, I, I, F, I, I, F, U64, I, P]),
     "ptpp_layernorm_fwd": (I, [P] * 9 + [I, I, I, F, I, I, F, U64, F, U64, I, P]),
     "ptpp_layernorm_bwd": (I, [P] * 11 + [I, I, I, I, I, F, U64, F, U64, I, P, SZ, P]),
+    "ptpp_layernorm_bwd_add": (I, [P] * 9 + [F, I, P, P, P, I, I, I, I, I, F, U64, F, U64, I, P, SZ, P]),
     "ptpp_attention_fwd": (I, [P] * 9 + [I] * 8 + [F, U64, I, P]),
     "ptpp_attention_bwd": (I, [P] * 16 + [I] * 9 + [F, U64, I, P, SZ, P]),
     "ptpp_length_regulate_fwd": (I, [P, P, P, I, I, I, I, I, P]),

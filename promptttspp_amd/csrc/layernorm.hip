@@ -16,6 +16,10 @@ struct LnDrop {
   unsigned in_thresh, out_thresh;
   float in_inv, out_inv;
   unsigned long long in_seed, out_seed;
+  const void* add;  // backward only: dsum = add + (the LayerNorm input gradient rounded to the storage type), or NULL
+  float dz_scale;   // backward only: dz = dsum * dz_scale * [t < len if dz_mask] * dropmask_in * act_in'(z)
+  int dz_mask;
+  int dz_stored;    // dz from dsum AS STORED (rounded to T) -- what a separate pass over dsum would read
 };
 
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
@@ -146,8 +150,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (d[i][e] * g[i][e] - m1 - xh[i][e] * m2);
+        if (dp.add) {  // the residual branch's gradient joins here: rounded first, like a separate add over the stored dsum
+          f32x4 r = o;
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = bf16_to_f32(f32_to_bf16(o[e]));
+          }
+          o = r + Elem<T>::ld4(reinterpret_cast<const T*>(dp.add) + row * C + c);
+        }
         if (dsum) Elem<T>::st4(dsum + row * C + c, o);
         if (dz) {
+          if constexpr (sizeof(T) == 2) {
+            if (dp.dz_stored) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = bf16_to_f32(f32_to_bf16(o[e]));
+            }
+          }
+          o *= dp.dz_scale;
+          if (dp.dz_mask) {
+            const int b = (int)(row / Tlen), t = (int)(row % Tlen);
+            if (t >= lengths[b]) o = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
           if (dp.in_thresh) o *= drop_mask4(dp.in_seed, (uint64_t)(row * C + c) >> 2, dp.in_thresh, dp.in_inv);
           if (act_in == PTPP_ACT_GELU) {
             const f32x4 zv = Elem<T>::ld4(z + row * C + c);
@@ -188,6 +211,10 @@ LnDrop make_drop(float pin, uint64_t sin_, float pout, uint64_t sout) {
   d.out_inv = pout > 0.f ? 1.f / (1.f - d.out_thresh / 65536.f) : 1.f;
   d.in_seed = sin_;
   d.out_seed = sout;
+  d.add = nullptr;
+  d.dz_scale = 1.f;
+  d.dz_mask = 0;
+  d.dz_stored = 0;
   return d;
 }
 
@@ -265,18 +292,46 @@ extern "C" int ptpp_layernorm_fwd(const void* x, const void* res, const float* g
   PTPP_CHECK_ARG(false, "layernorm_fwd: bad dtype %d", dtype);
 }
 
+static int ln_bwd_entry(const void* dy, const void* xsum, const void* z, const float* gamma, const float* mean, const float* rstd, void* dsum,
+                        void* dz, const void* add, float dz_scale, int dz_mask, int dz_stored, float* dgamma, float* dbeta,
+                        const int32_t* lengths, int B, int T, int C, int out_mask, int act_in, float drop_in_p, uint64_t drop_in_seed,
+                        float drop_out_p, uint64_t drop_out_seed, int dtype, void* scratch, size_t scratch_bytes, void* stream);
+
 extern "C" int ptpp_layernorm_bwd(const void* dy, const void* xsum, const void* z, const float* gamma,
                                   const float* mean, const float* rstd, void* dsum, void* dz, float* dgamma,
                                   float* dbeta, const int32_t* lengths, int B, int T, int C, int out_mask, int act_in,
                                   float drop_in_p, uint64_t drop_in_seed, float drop_out_p, uint64_t drop_out_seed,
                                   int dtype, void* scratch, size_t scratch_bytes, void* stream) {
+  return ln_bwd_entry(dy, xsum, z, gamma, mean, rstd, dsum, dz, nullptr, 1.f, 0, 0, dgamma, dbeta, lengths, B, T, C, out_mask, act_in,
+                      drop_in_p, drop_in_seed, drop_out_p, drop_out_seed, dtype, scratch, scratch_bytes, stream);
+}
+
+extern "C" int ptpp_layernorm_bwd_add(const void* dy, const void* xsum, const void* z, const float* gamma,
+                                      const float* mean, const float* rstd, void* dsum, void* dz, const void* add, float dz_scale,
+                                      int dz_mask, float* dgamma, float* dbeta, const int32_t* lengths, int B, int T, int C, int out_mask, int act_in,
+                                      float drop_in_p, uint64_t drop_in_seed, float drop_out_p, uint64_t drop_out_seed,
+                                      int dtype, void* scratch, size_t scratch_bytes, void* stream) {
+  return ln_bwd_entry(dy, xsum, z, gamma, mean, rstd, dsum, dz, add, dz_scale, dz_mask, 1, dgamma, dbeta, lengths, B, T, C, out_mask, act_in,
+                      drop_in_p, drop_in_seed, drop_out_p, drop_out_seed, dtype, scratch, scratch_bytes, stream);
+}
+
+static int ln_bwd_entry(const void* dy, const void* xsum, const void* z, const float* gamma, const float* mean, const float* rstd, void* dsum,
+                        void* dz, const void* add, float dz_scale, int dz_mask, int dz_stored, float* dgamma, float* dbeta,
+                        const int32_t* lengths, int B, int T, int C, int out_mask, int act_in, float drop_in_p, uint64_t drop_in_seed,
+                        float drop_out_p, uint64_t drop_out_seed, int dtype, void* scratch, size_t scratch_bytes, void* stream) {
   PTPP_CHECK_ARG(dy && xsum && gamma && mean && rstd && (dsum || dz), "layernorm_bwd: null pointer");
+  PTPP_CHECK_ARG(!add || (dsum && add != dsum), "layernorm_bwd: `add` needs a dsum output that is another buffer");
+  PTPP_CHECK_ARG(!dz_mask || lengths, "layernorm_bwd: dz_mask needs lengths");
   PTPP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0, "layernorm_bwd: bad shape");
   PTPP_CHECK_ARG(!out_mask || lengths, "layernorm_bwd: out_mask needs lengths");
   PTPP_CHECK_ARG(act_in == PTPP_ACT_NONE || (act_in == PTPP_ACT_GELU && z && dz), "layernorm_bwd: gelu needs z and dz");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t rows = (int64_t)B * T;
-  const LnDrop dp = make_drop(drop_in_p, drop_in_seed, drop_out_p, drop_out_seed);
+  LnDrop dp = make_drop(drop_in_p, drop_in_seed, drop_out_p, drop_out_seed);
+  dp.add = add;
+  dp.dz_scale = dz_scale;
+  dp.dz_mask = dz_mask;
+  dp.dz_stored = dz_stored;
   if (dtype == PTPP_F32)
     return ln_bwd_dispatch<float>(dy, xsum, z, gamma, mean, rstd, dsum, dz, dgamma, dbeta, scratch, scratch_bytes, lengths, rows, T, C,
                                   out_mask, act_in, dp, st);

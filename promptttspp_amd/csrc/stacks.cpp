@@ -416,9 +416,11 @@ int ln_fwd_plain(const void* x, const float* g, const float* b, void* y, float* 
                             dt, stream);
 }
 int ln_bwd_plain(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dsum, float* dg, float* db,
-                 const int32_t* lengths, int B, int T, int C, int out_mask, int dt, void* red, size_t red_bytes, void* stream) {
-  return ptpp_layernorm_bwd(dy, x, nullptr, g, mean, rstd, dsum, nullptr, dg, db, lengths, B, T, C, out_mask, PTPP_ACT_NONE, 0.f, 0, 0.f,
-                            0, dt, red, red_bytes, stream);
+                 const int32_t* lengths, int B, int T, int C, int out_mask, int dt, void* red, size_t red_bytes, void* stream,
+                 const void* add = nullptr, void* dz = nullptr, float dz_scale = 1.f, float dz_drop = 0.f, uint64_t dz_seed = 0) {
+  // dz (optional): the backward of the dropout / scale / length mask that fed this block (ptpp_epilogue_bwd on dsum), same pass
+  return ptpp_layernorm_bwd_add(dy, x, nullptr, g, mean, rstd, dsum, dz, add, dz_scale, dz != nullptr, dg, db, lengths, B, T, C, out_mask,
+                                PTPP_ACT_NONE, dz_drop, dz_seed, 0.f, 0, dt, red, red_bytes, stream);
 }
 
 }  // namespace
@@ -539,7 +541,7 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
   // backward of one feed-forward half: gres = gradient w.r.t. res + 0.5 drop(...) ; returns the gradient w.r.t. LN input in t1
   auto ffn_bwd = [&](const void* gres, const void* h, const void* n, const void* w1t, const void* w2t, float* dw1, float* db1, float* dw2,
                      float* db2, int s1, int s2, void* dz2, void* dzF) -> int {
-    ST_TRY(ptpp_epilogue_bwd(gres, nullptr, dz2, len, B, T, C, 0.5f, 0, 1, a->p_drop, seed(s2, a->p_drop), dt, stream));
+    // (dz2 = gres * 0.5 * dropout mask s2, masked rows zero: written by the LayerNorm backward that produced gres)
     ptpp_conv1d_args c = conv_args(dz2, C, w2t, nullptr, nullptr, 0, gF, F, len, B, T, C, F, kf, 1, (kf - 1) - pf, PTPP_ACT_NONE, 0, 0, dt);
     ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
     ST_TRY(wgrad(h, F, dz2, C, dw2, db2, len, B, T, F, C, kf, pf, 0));
@@ -551,16 +553,15 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
 
   // ---- final LayerNorm ----
   ST_TRY(ln_bwd_plain(a->gy, sl(S, lo.x4), w.ln_g[4], stats + 8 * R, stats + 9 * R, gA, g.ln_g[4], g.ln_b[4], len, B, T, C, 1, dt,
-                      a->red_scratch, a->red_bytes, stream));
+                      a->red_scratch, a->red_bytes, stream, nullptr, sl(X, sc.dz_c[0]), 0.5f, a->p_drop, seed(5, a->p_drop)));
   // ---- feed-forward ----
   ST_TRY(ffn_bwd(gA, sl(S, lo.h2), sl(S, lo.n4), a->ff_w1t, a->ff_w2t, g.ff_w1, g.ff_b1, g.ff_w2, g.ff_b2, 4, 5, sl(X, sc.dz_c[0]),
                  sl(X, sc.dz_f[0])));
-  ST_TRY(ln_bwd_plain(t1, sl(S, lo.x3), w.ln_g[3], stats + 6 * R, stats + 7 * R, t2, g.ln_g[3], g.ln_b[3], nullptr, B, T, C, 0, dt,
-                      a->red_scratch, a->red_bytes, stream));
-  ST_TRY(ptpp_add3_scale(gA, t2, nullptr, gB, 1.0f, RC, dt, stream));  // gradient w.r.t. x3
-  // ---- convolution module ----
+  // gradient w.r.t. x3 = gA + LayerNorm input gradient, and the pointwise conv's dropout backward, one pass
   void* dz_pw2 = sl(X, sc.dz_c[1]);
-  ST_TRY(ptpp_epilogue_bwd(gB, nullptr, dz_pw2, len, B, T, C, 1.0f, 0, 1, a->p_drop, seed(3, a->p_drop), dt, stream));
+  ST_TRY(ln_bwd_plain(t1, sl(S, lo.x3), w.ln_g[3], stats + 6 * R, stats + 7 * R, gB, g.ln_g[3], g.ln_b[3], len, B, T, C, 0, dt,
+                      a->red_scratch, a->red_bytes, stream, gA, dz_pw2, 1.0f, a->p_drop, seed(3, a->p_drop)));
+  // ---- convolution module ----
   ptpp_conv1d_args c = conv_args(dz_pw2, C, a->pw2_wt, nullptr, nullptr, 0, t2, C, len, B, T, C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
   ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
   ST_TRY(wgrad(sl(S, lo.bno), C, dz_pw2, C, g.pw2_w, g.pw2_b, len, B, T, C, C, 1, 0, 0));
@@ -575,12 +576,10 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
   c = conv_args(sl(X, sc.dz_2c), 2 * C, a->pw1_wt, nullptr, nullptr, 0, t1, C, len, B, T, 2 * C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
   ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
   ST_TRY(wgrad(sl(S, lo.n3), C, sl(X, sc.dz_2c), 2 * C, g.pw1_w, g.pw1_b, len, B, T, C, 2 * C, 1, 0, 0));
-  ST_TRY(ln_bwd_plain(t1, sl(S, lo.x2), w.ln_g[2], stats + 4 * R, stats + 5 * R, t2, g.ln_g[2], g.ln_b[2], nullptr, B, T, C, 0, dt,
-                      a->red_scratch, a->red_bytes, stream));
-  ST_TRY(ptpp_add3_scale(gB, t2, nullptr, gC, 1.0f, RC, dt, stream));  // gradient w.r.t. x2
-  // ---- self-attention ----
   void* dz_out = sl(X, sc.dz_c[2]);
-  ST_TRY(ptpp_epilogue_bwd(gC, nullptr, dz_out, len, B, T, C, 1.0f, 0, 1, a->p_drop, seed(2, a->p_drop), dt, stream));
+  ST_TRY(ln_bwd_plain(t1, sl(S, lo.x2), w.ln_g[2], stats + 4 * R, stats + 5 * R, gC, g.ln_g[2], g.ln_b[2], len, B, T, C, 0, dt,
+                      a->red_scratch, a->red_bytes, stream, gB, dz_out, 1.0f, a->p_drop, seed(2, a->p_drop)));  // gradient w.r.t. x2
+  // ---- self-attention ----
   c = conv_args(dz_out, C, a->out_wt, nullptr, nullptr, 0, t2, C, len, B, T, C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
   ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
   ST_TRY(wgrad(sl(S, lo.ctx), C, dz_out, C, g.out_w, g.out_b, len, B, T, C, C, 1, 0, 0));
@@ -604,15 +603,13 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
   float* const dws[3] = {g.q_w, g.k_w, g.v_w};
   float* const dbs[3] = {g.q_b, g.k_b, g.v_b};
   for (int i = 0; i < 3; ++i) ST_TRY(wgrad(sl(S, lo.n2), C, at(dqkv, (size_t)i * C, dt), 3 * C, dws[i], dbs[i], nullptr, B, T, C, C, 1, 0, 0));
-  ST_TRY(ln_bwd_plain(t1, sl(S, lo.x1), w.ln_g[1], stats + 2 * R, stats + 3 * R, t2, g.ln_g[1], g.ln_b[1], nullptr, B, T, C, 0, dt,
-                      a->red_scratch, a->red_bytes, stream));
-  ST_TRY(ptpp_add3_scale(gC, t2, nullptr, gA, 1.0f, RC, dt, stream));  // gradient w.r.t. x1
+  ST_TRY(ln_bwd_plain(t1, sl(S, lo.x1), w.ln_g[1], stats + 2 * R, stats + 3 * R, gA, g.ln_g[1], g.ln_b[1], len, B, T, C, 0, dt,
+                      a->red_scratch, a->red_bytes, stream, gC, sl(X, sc.dz_c[3]), 0.5f, a->p_drop, seed(1, a->p_drop)));  // gradient w.r.t. x1
   // ---- macaron feed-forward ----
   ST_TRY(ffn_bwd(gA, sl(S, lo.h1), sl(S, lo.n1), a->ffm_w1t, a->ffm_w2t, g.ffm_w1, g.ffm_b1, g.ffm_w2, g.ffm_b2, 0, 1, sl(X, sc.dz_c[3]),
                  sl(X, sc.dz_f[1])));
-  ST_TRY(ln_bwd_plain(t1, a->x, w.ln_g[0], stats, stats + R, t2, g.ln_g[0], g.ln_b[0], nullptr, B, T, C, 0, dt, a->red_scratch,
-                      a->red_bytes, stream));
-  ST_TRY(ptpp_add3_scale(gA, t2, nullptr, a->gx, 1.0f, RC, dt, stream));
+  ST_TRY(ln_bwd_plain(t1, a->x, w.ln_g[0], stats, stats + R, a->gx, g.ln_g[0], g.ln_b[0], nullptr, B, T, C, 0, dt, a->red_scratch,
+                      a->red_bytes, stream, gA));
   if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
   return ptpp_conv1d_wgrad_grouped(wg, nwg, dt, ws_w, ws_w_bytes, wstream);
 }

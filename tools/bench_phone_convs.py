@@ -9,7 +9,7 @@ from promptttspp_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 print("PTPP_NO_T64", os.environ.get("PTPP_NO_T64"))
-for (B, T, cin, cout, ks) in [(32, 100, 1024, 256, 9), (32, 100, 256, 1024, 9), (60, 55, 1024, 256, 9), (19, 199, 1024, 256, 9),
+for (B, T, cin, cout, ks) in [(19, 230, 256, 1024, 9), (19, 230, 1024, 256, 9), (19, 150, 256, 1024, 9), (19, 150, 1024, 256, 9), (32, 100, 1024, 256, 9), (32, 100, 256, 1024, 9), (60, 55, 1024, 256, 9), (19, 199, 1024, 256, 9),
                               (96, 44, 1024, 256, 9), (32, 100, 256, 256, 1), (32, 100, 256, 512, 1)]:
     x = torch.randn(B, T, cin, device=dev).bfloat16()
     w = torch.randn(cout, cin, ks, device=dev) * 0.02
