@@ -356,6 +356,11 @@ int ptpp_ddpm_step(const float* x, const void* eps, const float* noise, const in
                    const float* sra, const float* srm1, const float* c1, const float* c2,
                    const float* logvar, float* out, int B, int64_t per_b, int eps_dtype,
                    void* stream);
+/* ... also writing out_lp = out rounded to eps_dtype (nullable): the denoiser's input of the next reverse step. */
+int ptpp_ddpm_step_lp(const float* x, const void* eps, const float* noise, const int64_t* t,
+                      const float* sra, const float* srm1, const float* c1, const float* c2,
+                      const float* logvar, float* out, void* out_lp, int B, int64_t per_b, int eps_dtype,
+                      void* stream);
 /* Backward of the same layer: dg = conv1x1(a->x = do, a->wp = W_out^T) (a->Cout = C, never stored) with
  * ptpp_gate_bwd in its epilogue -- da (row stride ldda >= 2C) from the saved pre-activation act (B, T, 2C).
  * Bit-identical to ptpp_conv1d_fwd followed by ptpp_gate_bwd.  _supported: bf16, C % 8 == 0, Cin % 64 == 0. */

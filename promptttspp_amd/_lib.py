@@ -225,6 +225,7 @@ SIGNATURES = {
     "ptpp_conv1d_diffnet_post_supported": (I, [I, I, I]),
     "ptpp_conv1d_diffnet_post": (I, [POINTER(ConvArgs), P, P, P, P, P, I, P]),
     "ptpp_ddpm_step": (I, [P] * 10 + [I, I64, I, P]),
+    "ptpp_ddpm_step_lp": (I, [P] * 11 + [I, I64, I, P]),
     "ptpp_mdn_nll_fwd": (I, [P] * 6 + [I64, I, I, F, F, P]),
     "ptpp_mdn_nll_bwd": (I, [P] * 10 + [I64, I, I, F, F, P]),
     "ptpp_conv1d_gate_bwd_supported": (I, [I, I, I]),

@@ -489,442 +489,6 @@ __global__ __launch_bounds__(256) void amp_layer_kernel(const AmpP p) {
   }
 }
 
-// =====================================================================================================
-// bf16: the two FIR stages of the anti-aliased Snake on the matrix cores.
-//
-// Measured on the kernel above (rocprofv3 PMC, profiles/r02_pmc_amp_valu.txt): SQ_ACTIVE_INST_VALU covers ~99 % of
-// the launch -- the layer is VALU-bound by the Snake, 24 of whose ~45 VALU operations per output element are the
-// two 12-tap FIRs (a wave64 VALU instruction issues in 4 cycles on gfx950).  Both FIRs are contractions over TIME
-// with constant coefficients, i.e. small Toeplitz GEMMs:
-//   up   (16 upsampled samples x 16 channels):  U[m, c] = sum_q Fup[m, q] X[q, c]      K = 16 input rows
-//   down (16 output rows x 16 channels):        Y[c, t] = sum_m S[c, m] Fdn[m, t]      K = 48 upsampled samples
-// One v_mfma_f32_16x16x16_bf16 per up tile and a K = 32 + a K = 16 MFMA per output cell replace 24 x 256 VALU FMAs.
-// The operand layouts chain without any data movement: the X fragment comes out of LDS through the transposing
-// read ds_read_b64_tr_b16; the up MFMA is oriented D[m][c] so that a lane ends up holding 4 consecutive samples m of
-// ONE channel -- exactly the "A" fragment the down MFMA wants (the order of the contraction slots is free as long
-// as the constant Toeplitz operand uses the same order), and the down MFMA is oriented D[c][t] so that a lane holds
-// 4 consecutive channels of one row: one 8-byte LDS store.  What stays on the VALU is the Snake itself
-// (mul, v_sin, mul, fma per upsampled sample) and the bf16 packs.  The f32 taps enter as hi + lo bf16 pairs (two
-// MFMAs), so the filters carry no bf16 coefficient error; the upsampled Snake values are rounded to bf16 before the
-// low-pass (they are f32 registers in the VALU version).
-// Sequence edges: the replicate padding of x is in the tile (rows are stored time-clamped), and the clamped s
-// index of the low-pass folds the outer taps onto s[0] / s[2T-1]: a different constant operand for the few cells
-// at the ends of an utterance, computed on the fly from prefix / suffix sums of the taps.
-// =====================================================================================================
-typedef __attribute__((ext_vector_type(4))) short v4s_t;
-typedef __attribute__((ext_vector_type(8))) short v8s_t;
-
-// Wait states between a CHAIN of dependent MFMAs on one accumulator and the first VALU read of it.  Measured
-// (tools/diag_amp_det*.py, profiles/r02_amp_mfma_result_hazard.txt): with the s_nop the compiler derives from the LAST
-// MFMA of the chain alone, the first two accumulator registers read after a K=32, K=32, K=16, K=16 chain came back
-// stale in ~0.5 % of the elements whenever a second workgroup shared the SIMD (never on an otherwise idle CU) -- the
-// outputs were then not run-to-run reproducible.  The asm ties the accumulator so nothing is scheduled across it.
-#define MFMA_SETTLE(acc) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc))
-
-__device__ __forceinline__ v4s_t tr16_read(const char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)(p));
-}
-__device__ __forceinline__ void split_bf16(float v, short& hi, short& lo) {
-  const bf16_raw h = f32_to_bf16(v);
-  hi = (short)h;
-  lo = (short)f32_to_bf16(v - bf16_to_f32(h));
-}
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
-}
-
-// taps table in LDS, per activation: [0,12) 2*up, [12,24) down, [24,36) prefix sums of down, [36,48) suffix sums
-constexpr int TAB = 48;
-
-struct SnakeOps {
-  v4s_t up_hi, up_lo;   // up stage "A": [m_local = lane & 15][k = 4 kg + e]
-  v8s_t d1_hi, d1_lo;   // down stage "B", K = 32: slots e < 4 -> tile 2b sample 4 kg + e, e >= 4 -> tile 2b+1
-  v4s_t d2_hi, d2_lo;   // down stage "B", K = 16: tile 2b+2
-};
-
-// coefficient of upsampled sample m (cell-relative offset moff, cell base sample mb) in output row j of the cell
-// (time t = tcell + j): sum of the taps fdn[jj] with clamp(2t + jj - 5, 0, mlast) == m
-__device__ __forceinline__ float down_coef(const float* tab, int moff, int j, int mb, int mlast, bool edge) {
-  const int j0 = moff - 2 * j - 3;  // the tap that reads sample m for row t when nothing is clamped
-  if (!edge) return (j0 >= 0 && j0 < 12) ? tab[12 + j0] : 0.f;
-  const int m = mb + moff;
-  if (m < 0 || m > mlast) return 0.f;
-  if (m == 0) return j0 >= 0 ? tab[24 + min(j0, 11)] : 0.f;
-  if (m == mlast) return j0 <= 11 ? tab[36 + max(j0, 0)] : 0.f;
-  return (j0 >= 0 && j0 < 12) ? tab[12 + j0] : 0.f;
-}
-
-__device__ __forceinline__ void down_ops(const float* tab, int lane, int mb, int mlast, bool edge, SnakeOps& k) {
-  const int j = lane & 15, kg = lane >> 4;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int moff = e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4);
-    short hi, lo;
-    split_bf16(down_coef(tab, moff, j, mb, mlast, edge), hi, lo);
-    k.d1_hi[e] = hi;
-    k.d1_lo[e] = lo;
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    short hi, lo;
-    split_bf16(down_coef(tab, 32 + 4 * kg + e, j, mb, mlast, edge), hi, lo);
-    k.d2_hi[e] = hi;
-    k.d2_lo[e] = lo;
-  }
-}
-
-__device__ __forceinline__ void up_ops(const float* tab, int lane, SnakeOps& k) {
-  const int i = lane & 15, kg = lane >> 4;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int kk = 4 * kg + e;
-    // u[m0 + i] = sum_a x[q0 + kk] * f2[...]:  i even: kk = i/2 + a, tap 11 - 2a;  i odd: kk = (i+1)/2 + a, tap 10 - 2a
-    const int a = (i & 1) ? kk - (i + 1) / 2 : kk - i / 2;
-    const int idx = (i & 1) ? 10 - 2 * a : 11 - 2 * a;
-    short hi, lo;
-    split_bf16((a >= 0 && a < 6) ? tab[idx] : 0.f, hi, lo);
-    k.up_hi[e] = hi;
-    k.up_lo[e] = lo;
-  }
-}
-
-// Snake of 16-row cells [b0, b1) x the 16 channels of group cg: src rows [8n, 8n + 16) feed up-tile n (src row 0
-// is 7 rows before dst row 0 in time); dst row i is time tdst0 + i; rows outside [0, T) are written as zeros.
-template <int NCH>
-__device__ __forceinline__ void snake_cells(const char* src, char* dst, const float* tab, int tdst0, int b0, int b1,
-                                            int cg, int Tlen, int lane, float w, float inv, const SnakeOps& kin) {
-  constexpr int ROWB = NCH * 16;
-  const int i16 = lane & 15, kg = lane >> 4;
-  const int mlast = 2 * Tlen - 1;
-  // transposing read: lane i of a 16-lane group points at row (i >> 2), 4 channels (i & 3) of the 4 x 16 block
-  const int rrow = 4 * kg + (i16 >> 2);
-  const int rcol = cg * 16 + 4 * (i16 & 3);           // channel of the 8-byte piece
-  const int rchunk = rcol >> 3, roff = (rcol & 7) * 2;
-  auto tile = [&](int n) {  // Snake of up-tile n: 4 consecutive samples of this lane's channel, bf16
-    const int row = 8 * n + rrow;
-    const v4s_t xb = tr16_read(src + row * ROWB + ((rchunk ^ aswz<NCH>(row)) << 4) + roff);
-    f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
-    u = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kin.up_hi, xb, u, 0, 0, 0);
-    u = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kin.up_lo, xb, u, 0, 0, 0);
-    MFMA_SETTLE(u);
-    float sv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float sn = __builtin_amdgcn_sinf(u[e] * w);
-      sv[e] = fmaf(inv, sn * sn, u[e]);
-    }
-    return make_uint2(pack_bf16x2(sv[0], sv[1]), pack_bf16x2(sv[2], sv[3]));
-  };
-  // store: lane holds channels cg*16 + 4 kg .. +3 of row (16 b + i16)
-  const int wcol = cg * 16 + 4 * kg;
-  const int wchunk = wcol >> 3, woff = (wcol & 7) * 2;
-  uint2 s0 = tile(2 * b0);
-  for (int b = b0; b < b1; ++b) {
-    const uint2 s1 = tile(2 * b + 1), s2 = tile(2 * b + 2);
-    const int tcell = tdst0 + 16 * b, mb = 2 * tcell - 8;
-    const bool edge = mb <= 0 || mb + 47 >= mlast;
-    SnakeOps ke;
-    if (edge) down_ops(tab, lane, mb, mlast, true, ke);
-    const v8s_t d1h = edge ? ke.d1_hi : kin.d1_hi, d1l = edge ? ke.d1_lo : kin.d1_lo;
-    const v4s_t d2h = edge ? ke.d2_hi : kin.d2_hi, d2l = edge ? ke.d2_lo : kin.d2_lo;
-    const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, uint4{s0.x, s0.y, s1.x, s1.y});
-    const v4s_t a2 = __builtin_bit_cast(v4s_t, s2);
-    f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
-    y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8_t, d1h), y, 0, 0, 0);
-    y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8_t, d1l), y, 0, 0, 0);
-    y = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, d2h, y, 0, 0, 0);
-    y = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, d2l, y, 0, 0, 0);
-    MFMA_SETTLE(y);
-    const int row = 16 * b + i16, t = tcell + i16;
-    const bool ok = t >= 0 && t < Tlen;
-    uint2 o;
-    o.x = ok ? pack_bf16x2(y[0], y[1]) : 0u;
-    o.y = ok ? pack_bf16x2(y[2], y[3]) : 0u;
-    *reinterpret_cast<uint2*>(dst + row * ROWB + ((wchunk ^ aswz<NCH>(row)) << 4) + woff) = o;
-    s0 = s2;
-  }
-}
-
-// Persistent blocks: a block walks a contiguous range of tiles.  Measured on the one-tile-per-block form of this
-// kernel (profiles/r02_amp_layer_ablation.txt): with every compute phase switched off the launch still took 45 % of
-// its time -- 60 000 short-lived blocks, each paying its own chain of dependent memory round trips (tile load ->
-// ... -> residual load -> store).  Here the next tile's x rows are requested at the top of a tile into registers
-// and written to the second X slot after the first Snake (their HBM latency hides behind it), the tap tables and
-// Toeplitz operands are built once per block, and a block's consecutive tiles share their halo rows in L2.
-template <int C, int BT, int MG1, int MG2, bool PS>
-__global__ __launch_bounds__(256) void amp_layer_mfma_kernel(const AmpP p) {
-  typedef bf16_raw T;
-  constexpr int NT = 256;
-  constexpr int KC = 8;
-  constexpr int NCH = C / KC;
-  constexpr int ROWB = NCH * 16;
-  constexpr int NF = C / 16;
-  constexpr int NCG = C / 16;          // 16-channel groups
-  constexpr int WPG = 4 / NCG > 0 ? 4 / NCG : 1;  // waves sharing one channel group (time split)
-  constexpr int PF = C == 32 ? 6 : 8;  // 16-byte chunks of the x tile per thread (largest halo: ks = 11, dil = 5)
-  static_assert(NCG <= 4 && BT % 16 == 0, "geometry");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int ks = p.ks, dil = p.dil, Tlen = p.T;
-  const int pad1 = dil * (ks - 1) / 2, pad2 = (ks - 1) / 2;
-  const int nc2 = (BT + 2 * pad2 + 15) >> 4;   // 16-row cells of a2 (dst of snake 2, rows t0 - pad2 + i)
-  const int M1 = 16 * nc2 + 16;                // c1 rows snake 2 reads: times [t0 - pad2 - 7, ...)
-  const int n_a1 = M1 + 2 * pad1;              // a1 rows conv1 reads
-  const int nc1 = (n_a1 + 15) >> 4;
-  const int rowsX = 16 * nc1 + 16;             // x rows snake 1 reads (>= M1)
-  const int rowsA = 16 * max(nc1, nc2);
-  char* Xbuf = smem;                                             // PS: 2 slots of rowsX rows, else 1
-  char* As = smem + (PS ? 2 : 1) * rowsX * ROWB;
-  float* tab = reinterpret_cast<float*>(As + rowsA * ROWB);      // 2 x TAB floats
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ntiles = p.B * p.nMT;
-  const int tile_lo = (int)((int64_t)blockIdx.x * ntiles / gridDim.x), tile_hi = (int)((int64_t)(blockIdx.x + 1) * ntiles / gridDim.x);
-  if (tile_lo >= tile_hi) return;
-  if (p.skip & 256) {  // diagnostics: zero the whole allocation first
-    const int total = ((PS ? 2 : 1) * rowsX + rowsA) * ROWB;
-    for (int i = tid * 16; i < total; i += NT * 16) *reinterpret_cast<uint4*>(smem + i) = uint4{0u, 0u, 0u, 0u};
-    __syncthreads();
-  }
-
-  if (tid < 24) {
-    const int a = tid / 12, i = tid % 12;
-    const float* up = a ? p.up2 : p.up1;
-    const float* dn = a ? p.dn2 : p.dn1;
-    float ps = 0.f, ss = 0.f;
-    for (int q = 0; q <= i; ++q) ps += dn[q];
-    for (int q = i; q < 12; ++q) ss += dn[q];
-    float* tb = tab + a * TAB;
-    tb[i] = 2.0f * up[i];
-    tb[12 + i] = dn[i];
-    tb[24 + i] = ps;
-    tb[36 + i] = ss;
-  }
-  // x rows of a tile, time index clamped (replicate padding), as PF 16-byte chunks per thread
-  auto fetch = [&](int tile, uint4 (&v)[PS ? PF : 1]) {
-    const int mt = tile % p.nMT, b = tile / p.nMT;
-    const int tx0 = mt * BT - pad2 - 7 - pad1 - 7;
-    const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * Tlen * C;
-#pragma unroll
-    for (int q = 0; q < (PS ? PF : 1); ++q) {
-      const int idx = tid + q * NT;
-      const int r = idx / NCH, ch = idx - r * NCH;
-      const int t = min(max(tx0 + min(r, rowsX - 1), 0), Tlen - 1);
-      v[q] = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + ch * KC);
-    }
-  };
-  auto put = [&](char* Xs, const uint4 (&v)[PS ? PF : 1]) {
-#pragma unroll
-    for (int q = 0; q < (PS ? PF : 1); ++q) {
-      const int idx = tid + q * NT;
-      const int r = idx / NCH, ch = idx - r * NCH;
-      if (r < rowsX) *reinterpret_cast<uint4*>(Xs + r * ROWB + ((ch ^ aswz<NCH>(r)) << 4)) = v[q];
-    }
-  };
-  uint4 pf[PS ? PF : 1];
-  if constexpr (PS) {
-    fetch(tile_lo, pf);
-    put(Xbuf, pf);
-  } else {  // one tile per block: straight copy, no registers held
-    const int mt = tile_lo % p.nMT, b = tile_lo / p.nMT;
-    const int tx0 = mt * BT - pad2 - 7 - pad1 - 7;
-    const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * Tlen * C;
-    for (int idx = tid; idx < rowsX * NCH; idx += NT) {
-      const int r = idx / NCH, ch = idx - r * NCH;
-      const int t = min(max(tx0 + r, 0), Tlen - 1);
-      *reinterpret_cast<uint4*>(Xbuf + r * ROWB + ((ch ^ aswz<NCH>(r)) << 4)) =
-          *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + ch * KC);
-    }
-  }
-  // this wave's channel group and time share in the Snake phases; its Snake constants and FIR operands
-  const int cg = wave % NCG, part = wave / NCG;
-  const int chl = cg * 16 + (lane & 15);
-  constexpr float INV2PI = 0.15915494309189535f;
-  const float al1 = __expf(p.la1[chl]), al2 = __expf(p.la2[chl]);
-  __syncthreads();
-  const int lr = lane & 15, lg = lane >> 4;
-  const float osc = p.out_scale, rsc = p.res_scale;
-
-  int tile = tile_lo;
-  do {
-    char* Xs = Xbuf + (PS ? ((tile - tile_lo) & 1) * rowsX * ROWB : 0);
-    char* Xn = Xbuf + (PS ? ((tile - tile_lo + 1) & 1) * rowsX * ROWB : 0);
-    const int mt = tile % p.nMT, b = tile / p.nMT;
-    const int t0 = mt * BT;
-    const int ta2 = t0 - pad2;         // time of a2 row 0
-    const int tc0 = ta2 - 7;           // time of c1 row 0
-    const int ta0 = tc0 - pad1;        // time of a1 row 0 (x row 0 is 7 rows earlier)
-    const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * Tlen * C;
-
-    auto dump = [&](const char* buf, int row_of_t0) {  // diagnostics (PTPP_AMP_SKIP = 101..103): an intermediate -> y
-      T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * Tlen * C;
-      for (int idx = tid; idx < BT * NCH; idx += NT) {
-        const int m = idx / NCH, ch = idx - m * NCH, r = row_of_t0 + m;
-        if (t0 + m < Tlen)
-          *reinterpret_cast<uint4*>(yb + (int64_t)(t0 + m) * C + ch * KC) = *reinterpret_cast<const uint4*>(buf + r * ROWB + ((ch ^ aswz<NCH>(r)) << 4));
-      }
-    };
-    const bool more = PS && tile + 1 < tile_hi;
-    if constexpr (PS) {
-      if (more) fetch(tile + 1, pf);   // in flight during the first Snake
-    }
-
-    // ---- P1: snake 1: X -> a1 cells [0, nc1) ----
-    {
-      SnakeOps k1;  // (rebuilt per tile: ~100 instructions, instead of 16 registers held across all phases)
-      up_ops(tab, lane, k1);
-      down_ops(tab, lane, 0, 0, false, k1);
-      const int per = (nc1 + WPG - 1) / WPG;
-      const int c0 = part * per, c1 = min(nc1, c0 + per);
-      if (part < WPG && c0 < c1) snake_cells<NCH>(Xs, As, tab, ta0, c0, c1, cg, Tlen, lane, al1 * INV2PI, 1.0f / (al1 + 1e-9f), k1);
-    }
-    if constexpr (PS) {
-      if (more) put(Xn, pf);           // (slot last read by the second Snake of the previous tile)
-    }
-    __syncthreads();
-    if (p.skip == 101) { dump(As, t0 - ta0); return; }
-
-    // ---- P2: conv1 (dilated): a1 -> c1 rows [0, M1) in X ----
-    {
-      const int nfr = M1 / 16;
-      for (int g = wave; g * MG1 < nfr; g += 4) {
-        const int mf0 = g * MG1, nmf = min(MG1, nfr - mf0);
-        f32x4 acc[MG1][NF];
-        conv_frags<T, C, MG1>(As, reinterpret_cast<const T*>(p.w1p), ks, dil, 0, mf0, nmf, lane, acc);
-#pragma unroll
-        for (int mi = 0; mi < MG1; ++mi) {
-          if (mi < nmf) {
-            const int row = (mf0 + mi) * 16 + lr;
-#pragma unroll
-            for (int h = 0; h < NF / 2; ++h) {
-              const int co = h * 32 + lg * 8;
-              const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + co), bB = *reinterpret_cast<const f32x4*>(p.b1 + co + 4);
-              const f32x4 v0 = acc[mi][2 * h] + bA, v1 = acc[mi][2 * h + 1] + bB;
-              uint4 o;
-              o.x = pack_bf16x2(v0[0], v0[1]); o.y = pack_bf16x2(v0[2], v0[3]);
-              o.z = pack_bf16x2(v1[0], v1[1]); o.w = pack_bf16x2(v1[2], v1[3]);
-              *reinterpret_cast<uint4*>(Xs + row * ROWB + (((h * 4 + lg) ^ aswz<NCH>(row)) << 4)) = o;
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // c1 rows whose time lies outside [0, T) hold sums over the zero padding: the second Snake replicates the edge
-    // rows instead (only tiles at the ends of an utterance)
-    if (tc0 < 0 || tc0 + M1 > Tlen) {
-      for (int idx = tid; idx < M1 * NCH; idx += NT) {
-        const int r = idx / NCH, ch = idx - r * NCH;
-        const int t = tc0 + r;
-        if (t < 0 || t >= Tlen) {
-          const int rs = min(max(t, 0), Tlen - 1) - tc0;
-          *reinterpret_cast<uint4*>(Xs + r * ROWB + ((ch ^ aswz<NCH>(r)) << 4)) =
-              *reinterpret_cast<const uint4*>(Xs + rs * ROWB + ((ch ^ aswz<NCH>(rs)) << 4));
-        }
-      }
-      __syncthreads();
-    }
-
-    if (p.skip == 102) { dump(Xs, t0 - tc0); return; }
-    // ---- P3: snake 2: c1 (X) -> a2 cells [0, nc2) in A ----
-    {
-      SnakeOps k2;
-      up_ops(tab + TAB, lane, k2);
-      down_ops(tab + TAB, lane, 0, 0, false, k2);
-      const int per = (nc2 + WPG - 1) / WPG;
-      const int c0 = part * per, c1 = min(nc2, c0 + per);
-      if (part < WPG && c0 < c1) snake_cells<NCH>(Xs, As, tab + TAB, ta2, c0, c1, cg, Tlen, lane, al2 * INV2PI, 1.0f / (al2 + 1e-9f), k2);
-    }
-    __syncthreads();
-
-    if (p.skip == 103) { dump(As, t0 - ta2); return; }
-    // ---- P4: conv2: a2 -> y (+ bias, residual x, running mean res2) ----
-    {
-      constexpr int nfr = BT / 16;
-      T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * Tlen * C;
-      const T* r2b = p.res2 ? reinterpret_cast<const T*>(p.res2) + (int64_t)b * Tlen * C : nullptr;
-      for (int g = wave; g * MG2 < nfr; g += 4) {
-        const int mf0 = g * MG2, nmf = min(MG2, nfr - mf0);
-        // the residual rows (an L2 hit: fetched for this tile a few microseconds ago) are requested BEFORE the K
-        // loop; loaded in the epilogue, each row group paid a full memory round trip in sequence
-        uint4 rx[PS ? MG2 : 1][NF / 2];
-        if constexpr (PS) {
-#pragma unroll
-          for (int mi = 0; mi < MG2; ++mi) {
-            const int t = min(t0 + (mf0 + mi) * 16 + lr, Tlen - 1);
-#pragma unroll
-            for (int h = 0; h < NF / 2; ++h) rx[mi][h] = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + h * 32 + lg * 8);
-          }
-        }
-        f32x4 acc[MG2][NF];
-        conv_frags<T, C, MG2>(As, reinterpret_cast<const T*>(p.w2p), ks, 1, 0, mf0, nmf, lane, acc);
-#pragma unroll
-        for (int mi = 0; mi < MG2; ++mi) {
-          const int t = t0 + (mf0 + mi) * 16 + lr;
-          if (mi < nmf && t < Tlen) {
-#pragma unroll
-            for (int h = 0; h < NF / 2; ++h) {
-              const int co = h * 32 + lg * 8;
-              const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b2 + co), bB = *reinterpret_cast<const f32x4*>(p.b2 + co + 4);
-              f32x4 v0 = (acc[mi][2 * h] + bA) * osc, v1 = (acc[mi][2 * h + 1] + bB) * osc;
-              const uint4 r = PS ? rx[PS ? mi : 0][h] : *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + co);
-              v0[0] += __uint_as_float(r.x << 16) * rsc; v0[1] += __uint_as_float(r.x & 0xffff0000u) * rsc;
-              v0[2] += __uint_as_float(r.y << 16) * rsc; v0[3] += __uint_as_float(r.y & 0xffff0000u) * rsc;
-              v1[0] += __uint_as_float(r.z << 16) * rsc; v1[1] += __uint_as_float(r.z & 0xffff0000u) * rsc;
-              v1[2] += __uint_as_float(r.w << 16) * rsc; v1[3] += __uint_as_float(r.w & 0xffff0000u) * rsc;
-              if (r2b) {  // (the last layer of a block only: 3 of 9 launches)
-                const uint4 q = *reinterpret_cast<const uint4*>(r2b + (int64_t)t * C + co);
-                v0[0] += __uint_as_float(q.x << 16); v0[1] += __uint_as_float(q.x & 0xffff0000u);
-                v0[2] += __uint_as_float(q.y << 16); v0[3] += __uint_as_float(q.y & 0xffff0000u);
-                v1[0] += __uint_as_float(q.z << 16); v1[1] += __uint_as_float(q.z & 0xffff0000u);
-                v1[2] += __uint_as_float(q.w << 16); v1[3] += __uint_as_float(q.w & 0xffff0000u);
-              }
-              uint4 o;
-              o.x = pack_bf16x2(v0[0], v0[1]); o.y = pack_bf16x2(v0[2], v0[3]);
-              o.z = pack_bf16x2(v1[0], v1[1]); o.w = pack_bf16x2(v1[2], v1[3]);
-              *reinterpret_cast<uint4*>(yb + (int64_t)t * C + co) = o;
-            }
-          }
-        }
-      }
-    }
-    if constexpr (PS) __syncthreads();  // the next tile's first Snake overwrites A
-  } while (PS && ++tile < tile_hi);
-}
-
-template <int C, int BT, int MG1, int MG2, bool PS>
-int launch_amp_mfma(AmpP& p, hipStream_t st) {
-  constexpr int ROWB = (C / 8) * 16;
-  const int pad1 = p.dil * (p.ks - 1) / 2, pad2 = (p.ks - 1) / 2;
-  const int nc2 = (BT + 2 * pad2 + 15) >> 4, M1 = 16 * nc2 + 16;
-  const int nc1 = (M1 + 2 * pad1 + 15) >> 4;
-  const int rowsX = 16 * nc1 + 16, rowsA = 16 * (nc1 > nc2 ? nc1 : nc2);
-  constexpr int PF = C == 32 ? 6 : 8;
-  if (rowsX * (C / 8) > PF * 256) {
-    ptpp_set_error("amp_layer: halo of ks=%d dil=%d exceeds the built prefetch depth", p.ks, p.dil);
-    return PTPP_ENOTSUP;
-  }
-  const size_t smem = (size_t)((PS ? 2 : 1) * rowsX + rowsA) * ROWB + 2 * TAB * sizeof(float);
-  if (smem > 160 * 1024) {
-    ptpp_set_error("amp_layer: LDS tile too large (%zu B)", smem);
-    return PTPP_ENOTSUP;
-  }
-  auto kern = amp_layer_mfma_kernel<C, BT, MG1, MG2, PS>;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  p.nMT = (p.T + BT - 1) / BT;
-  const int64_t ntiles = (int64_t)p.B * p.nMT;
-  const int per_cu = (int)((160 * 1024) / smem) > 0 ? (int)((160 * 1024) / smem) : 1;
-  const char* g = getenv("PTPP_AMP_GRID");
-  int64_t grid = !PS ? ntiles : (g ? atoi(g) : 256 * (int64_t)per_cu);  // PS: as many blocks as fit the 256 CUs at once
-  if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, p);
-  PTPP_CHECK_LAUNCH("amp_layer_fwd");
-  return PTPP_OK;
-}
-
 template <typename T, int C, int BT, int MG>
 int launch_amp(AmpP& p, hipStream_t st) {
   constexpr int KC = 16 / (int)sizeof(T);
@@ -981,22 +545,8 @@ extern "C" int ptpp_amp_layer_fwd(const ptpp_amp_layer_args* a, void* stream) {
   p.skip = getenv("PTPP_AMP_SKIP") ? atoi(getenv("PTPP_AMP_SKIP")) : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == PTPP_BF16) {
-    // The product path is the VALU-FIR kernel (amp_layer_kernel): bit-reproducible and the faster one for C = 64.
-    // EXPERIMENTAL, opt-in (PTPP_AMP_VARIANT = mfma | persist): the FIRs on the matrix cores.  Measured
-    // (profiles/r02_amp_layer_variants.txt): 5-10 % faster than the VALU form at C = 32, slower at C = 64, and the
-    // persistent form is slower than one tile per block (the phases are latency-bound: more resident waves win).
-    // It matches the oracle, but whenever two workgroups share a CU its output is NOT run-to-run reproducible
-    // (1-ulp bf16 differences in ~1 % of the elements; tools/diag_amp_det*.py; not an LDS-initialisation, barrier
-    // or MFMA-result wait-state effect -- cause not found in round 2), which rules it out for the product.
-    const char* var = getenv("PTPP_AMP_VARIANT");
-    if (var && !strcmp(var, "persist")) {
-      if (a->C == 32) return launch_amp_mfma<32, 256, 5, 4, true>(p, st);
-      return launch_amp_mfma<64, 128, 3, 2, true>(p, st);
-    }
-    if (var && !strcmp(var, "mfma")) {
-      if (a->C == 32) return launch_amp_mfma<32, 256, 5, 4, false>(p, st);
-      return launch_amp_mfma<64, 128, 3, 2, false>(p, st);
-    }
+    // (the FIRs-on-MFMA experiment of round 2 -- not run-to-run reproducible with two workgroups per CU -- left the library in
+    //  round 4: tools/experiments/r02_amp_layer_mfma.hip.txt)
     if (a->C == 32) return launch_amp<bf16_raw, 32, 256, 5>(p, st);
     return launch_amp<bf16_raw, 64, 128, 3>(p, st);
   }

@@ -132,7 +132,7 @@ template <typename T>
 __global__ void ddpm_step_kernel(const float* __restrict__ x, const T* __restrict__ eps, const float* __restrict__ noise,
                                  const long long* __restrict__ t, const float* __restrict__ sra, const float* __restrict__ srm1,
                                  const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ logvar,
-                                 float* __restrict__ out, int64_t per_b4, int64_t nvec) {
+                                 float* __restrict__ out, T* __restrict__ out_lp, int64_t per_b4, int64_t nvec) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     const long long tb = t[i / per_b4];
     const float a = sra[tb], bq = srm1[tb], k1 = c1[tb], k2 = c2[tb], sg = expf(__fmul_rn(0.5f, logvar[tb]));
@@ -148,6 +148,7 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const T* __restric
       o[e] = __fadd_rn(mean, __fmul_rn(sg, nv[e]));
     }
     *reinterpret_cast<f32x4*>(out + i * 4) = o;
+    if (out_lp) Elem<T>::st4(out_lp + i * 4, o);  // the denoiser's input of the next step (x cast to the compute dtype)
   }
 }
 
@@ -400,15 +401,21 @@ extern "C" int ptpp_length_regulate_bwd(const void* dy, const int32_t* cum, void
 extern "C" int ptpp_ddpm_step(const float* x, const void* eps, const float* noise, const int64_t* t, const float* sra,
                               const float* srm1, const float* c1, const float* c2, const float* logvar, float* out, int B,
                               int64_t per_b, int eps_dtype, void* stream) {
+  return ptpp_ddpm_step_lp(x, eps, noise, t, sra, srm1, c1, c2, logvar, out, nullptr, B, per_b, eps_dtype, stream);
+}
+
+extern "C" int ptpp_ddpm_step_lp(const float* x, const void* eps, const float* noise, const int64_t* t, const float* sra,
+                                 const float* srm1, const float* c1, const float* c2, const float* logvar, float* out, void* out_lp,
+                                 int B, int64_t per_b, int eps_dtype, void* stream) {
   PTPP_CHECK_ARG(x && eps && t && sra && srm1 && c1 && c2 && logvar && out && B > 0 && per_b > 0 && per_b % 4 == 0,
                  "ddpm_step: bad args");
   PTPP_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)noise % 16) == 0 &&
-                     ((uintptr_t)eps % 8) == 0, "ddpm_step: operands must be vector aligned");
+                     ((uintptr_t)eps % 8) == 0 && ((uintptr_t)out_lp % 8) == 0, "ddpm_step: operands must be vector aligned");
   const int64_t nvec = (int64_t)B * per_b / 4;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   DISPATCH_T(eps_dtype, "ddpm_step",
              hipLaunchKernelGGL(ddpm_step_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, x, (const T*)eps, noise,
-                                reinterpret_cast<const long long*>(t), sra, srm1, c1, c2, logvar, out, per_b / 4, nvec));
+                                reinterpret_cast<const long long*>(t), sra, srm1, c1, c2, logvar, out, (T*)out_lp, per_b / 4, nvec));
   PTPP_CHECK_LAUNCH("ddpm_step");
   return PTPP_OK;
 }

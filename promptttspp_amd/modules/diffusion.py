@@ -131,17 +131,20 @@ class GaussianDiffusion(nn.Module):
 
     # -- sampling ----------------------------------------------------------------------
     @torch.no_grad()
-    def _p_sample_core(self, x, t, cond, cond_all, noise):
+    def _p_sample_core(self, x, t, cond, cond_all, noise, dsteps=None):
         """One reverse step for a device tensor of step indices ``t`` (B,): x_{t-1} = mean + sigma_t * noise
         (reference: diffusion.py:283-302; at t == 0 the caller passes zero noise)."""
         # the step-embedding chain (sinusoid, two-layer MLP with Mish, the 20 per-layer projections: ~16 small launches)
         # depends on t only: the sampler computes it for all K steps at once and gathers a row per utterance here
         tab = getattr(self, "_dstab", None)
-        dsteps = tab.index_select(0, t) if tab is not None else None
+        if dsteps is None and tab is not None:
+            dsteps = tab.index_select(0, t)
         eps = self.denoise_fn.forward_cl(x.to(cond.dtype), t, cond, None, cond_all=cond_all, dsteps=dsteps)
         if x.is_cuda and x.dtype == torch.float32 and (x.numel() // x.shape[0]) % 4 == 0:
             from .. import ops
 
+            # (ops.ddpm_step(want_lp=True) can hand back x_{t-1} in the compute dtype too; measured: the separate cast of a
+            #  (B, T, 80) tensor is not on the critical path -- 135.0 vs 135.0 ms app path -- so the loop keeps the plain form)
             return ops.ddpm_step(x.contiguous(), eps.contiguous(), None if noise is None else noise.contiguous(), t,
                                  self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
                                  self.posterior_mean_coef2, self.posterior_log_variance_clipped)
@@ -154,7 +157,32 @@ class GaussianDiffusion(nn.Module):
     def p_sample_cl(self, x, i, cond, cond_all, noise):
         B = x.shape[0]
         t = torch.full((B,), i, device=x.device, dtype=torch.long)
-        return self._p_sample_core(x, t, cond, cond_all, noise)  # noise None at i == 0: the posterior mean
+        # every utterance is at step i: the table row broadcast over the batch, laid out (L, B, C) as the stack driver reads it
+        # (a view: no gather, no transpose copy)
+        lbc = getattr(self, "_dstab_lbc", None)
+        ds = lbc[i].transpose(0, 1) if lbc is not None and lbc.shape[2] == B else None
+        return self._p_sample_core(x, t, cond, cond_all, noise, ds)  # noise None at i == 0: the posterior mean
+
+    @staticmethod
+    def _chunked_noise(device, shape, chunk=16):
+        """The default noise source of the reverse loop: standard normal draws, ``chunk`` steps per generator launch (one
+        launch per step was ~5 us of a ~1 ms step; the draws stay i.i.d. N(0, 1), only their position in the generator's stream
+        differs from a per-step ``randn``)."""
+        if device.type != "cuda":
+            return lambda i, s: torch.randn(s, device=device)
+        state = {"buf": None, "k": 0}
+
+        def draw(i, s):
+            if tuple(s) != tuple(shape) or i < 0:
+                return torch.randn(s, device=device)
+            if state["buf"] is None or state["k"] >= state["buf"].shape[0]:
+                state["buf"] = torch.randn((max(1, min(chunk, i)),) + tuple(shape), device=device)
+                state["k"] = 0
+            out = state["buf"][state["k"]]
+            state["k"] += 1
+            return out
+
+        return draw
 
     @torch.no_grad()
     def inference_plms_cl(self, cond, interval, noise_fn=None):
@@ -206,10 +234,14 @@ class GaussianDiffusion(nn.Module):
             return self.inference_plms_cl(cond, int(self.pndm_speedup), noise_fn)
         if getattr(self, "_dstab", None) is None and hasattr(self.denoise_fn, "step_embeddings"):
             self._dstab = self.denoise_fn.step_embeddings(torch.arange(self.K_step, device=cond.device)).contiguous()  # (K, L, C)
+            K, L, C = self._dstab.shape
+            if K * L * cond.shape[0] * C * 4 <= (256 << 20):  # 66 MB at 100 steps x 20 layers x 32 utterances
+                self._dstab_lbc = self._dstab[:, :, None, :].expand(K, L, cond.shape[0], C).contiguous()
             try:
                 return self._inference_cl(cond, noise_fn, use_graph)
             finally:
                 self._dstab = None
+                self._dstab_lbc = None
         return self._inference_cl(cond, noise_fn, use_graph)
 
     def _inference_cl(self, cond, noise_fn, use_graph):
@@ -218,7 +250,7 @@ class GaussianDiffusion(nn.Module):
                 and not torch.cuda.is_current_stream_capturing() and not self._one_launch_layers(cond):
             return self._inference_split(cond, noise_fn)
         shape = (B, T, self.out_dim)
-        draw = noise_fn if noise_fn is not None else (lambda i, s: torch.randn(s, device=cond.device))
+        draw = noise_fn if noise_fn is not None else self._chunked_noise(cond.device, shape)
         x = draw(-1, shape)
         cond_all = self.denoise_fn.cond_all(cond)
         K = self.K_step

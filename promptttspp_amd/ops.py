@@ -721,20 +721,23 @@ def mdn_nll_bwd(log_pi, log_sigma, mu, target, mask, loss, gout, lp_min, ls_min)
     return dlp, dls, dmu
 
 
-def ddpm_step(x, eps, noise, t, sra, srm1, c1, c2, logvar):
+def ddpm_step(x, eps, noise, t, sra, srm1, c1, c2, logvar, want_lp=False):
     """x (B, ...) f32, eps same shape (f32 / bf16), noise f32 or None, t (B) int64 on the device -> x_{t-1} f32
-    (ptpp_ddpm_step: the reverse-diffusion update as one pass)."""
+    (ptpp_ddpm_step: the reverse-diffusion update as one pass).  ``want_lp``: also return x_{t-1} in eps's dtype (what the
+    next step feeds the denoiser) from the same launch -> (out, out_lp)."""
     _need_gpu(x)
     assert x.dtype == torch.float32 and x.is_contiguous() and eps.is_contiguous() and eps.shape == x.shape
     assert t.dtype == torch.int64 and t.is_contiguous() and t.numel() == x.shape[0]
     assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape == x.shape)
     out = torch.empty_like(x)
+    lp = torch.empty_like(eps) if want_lp else None
     B = x.shape[0]
-    check(_lib.load().ptpp_ddpm_step(x.data_ptr(), eps.data_ptr(), noise.data_ptr() if noise is not None else None,
-                                     t.data_ptr(), sra.data_ptr(), srm1.data_ptr(), c1.data_ptr(), c2.data_ptr(),
-                                     logvar.data_ptr(), out.data_ptr(), B, x.numel() // B, dtype_code(eps.dtype), _stream()),
+    check(_lib.load().ptpp_ddpm_step_lp(x.data_ptr(), eps.data_ptr(), noise.data_ptr() if noise is not None else None,
+                                        t.data_ptr(), sra.data_ptr(), srm1.data_ptr(), c1.data_ptr(), c2.data_ptr(),
+                                        logvar.data_ptr(), out.data_ptr(), lp.data_ptr() if lp is not None else None, B,
+                                        x.numel() // B, dtype_code(eps.dtype), _stream()),
           "ptpp_ddpm_step")
-    return out
+    return (out, lp) if want_lp else out
 
 
 def diffnet_post_bwd(gx, gskip, lengths):
