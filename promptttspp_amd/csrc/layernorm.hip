@@ -121,18 +121,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     const float mu = mean[row], rs = rstd[row];
     f32x4 d[NV], xh[NV];
+    unsigned pos[NV];  // sign bits of the norm's input (act_in = relu: the input IS relu's output, positive <=> passed)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = i * 256 + lane * 4;
       d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pos[i] = 0u;
       if (c < C && keep) {
         d[i] = Elem<T>::ld4(dy + row * C + c);
         if (dp.out_thresh) d[i] *= drop_mask4(dp.out_seed, (uint64_t)(row * C + c) >> 2, dp.out_thresh, dp.out_inv);
         const f32x4 xv = Elem<T>::ld4(xs + row * C + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          pos[i] |= (xv[e] > 0.f ? 1u : 0u) << e;
           xh[i][e] = (xv[e] - mu) * rs;
           const float dg = d[i][e] * g[i][e];
           s1 += dg;
@@ -176,6 +179,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             const f32x4 zv = Elem<T>::ld4(z + row * C + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] *= gelu_grad(zv[e]);
+          } else if (act_in == PTPP_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ((pos[i] >> e) & 1u) ? o[e] : 0.f;
           }
           Elem<T>::st4(dz + row * C + c, o);
         }
@@ -324,7 +330,8 @@ static int ln_bwd_entry(const void* dy, const void* xsum, const void* z, const f
   PTPP_CHECK_ARG(!dz_mask || lengths, "layernorm_bwd: dz_mask needs lengths");
   PTPP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0, "layernorm_bwd: bad shape");
   PTPP_CHECK_ARG(!out_mask || lengths, "layernorm_bwd: out_mask needs lengths");
-  PTPP_CHECK_ARG(act_in == PTPP_ACT_NONE || (act_in == PTPP_ACT_GELU && z && dz), "layernorm_bwd: gelu needs z and dz");
+  PTPP_CHECK_ARG(act_in == PTPP_ACT_NONE || (act_in == PTPP_ACT_GELU && z && dz) || (act_in == PTPP_ACT_RELU && dz),
+                 "layernorm_bwd: gelu needs z and dz; relu (the norm's input is the relu output) needs dz");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t rows = (int64_t)B * T;
   LnDrop dp = make_drop(drop_in_p, drop_in_seed, drop_out_p, drop_out_seed);

@@ -330,11 +330,18 @@ extern "C" int ptpp_conv_ln_stack_bwd(const ptpp_conv_ln_stack_bwd_args* a, void
     // when an activation / dropout sits between them; whichever is the conv-output gradient goes to gz (or aux before relu')
     void* conv_grad_dst = relu ? aux : gz;
     void* dsum_dst = want_dz ? dsum : conv_grad_dst;
-    ST_TRY(ptpp_layernorm_bwd(gout, fused_in ? at(a->sum_all, (size_t)i * BTC, dt) : z, a->act_in != PTPP_ACT_NONE ? z : nullptr, a->gamma[i],
-                              a->mean_all + i * R, a->rstd_all + i * R, dsum_dst, want_dz ? conv_grad_dst : nullptr, a->dgamma[i], a->dbeta[i],
-                              a->lengths, B, T, C, om, a->act_in, a->drop_in, a->drop_in > 0.f ? a->seeds[2 * i] : 0, a->drop_out,
-                              a->drop_out > 0.f ? a->seeds[2 * i + 1] : 0, dt, a->red_scratch, a->red_bytes, stream));
-    if (relu) ST_TRY(ptpp_epilogue_bwd(aux, z, gz, nullptr, B, T, C, 1.0f, 1, 0, 0.f, 0, dt, stream));
+    if (relu && !want_dz && !fused_in) {
+      // the norm's input is the relu output itself: relu' comes from its sign in the same pass (no dsum tensor, no second launch)
+      ST_TRY(ptpp_layernorm_bwd_add(gout, z, nullptr, a->gamma[i], a->mean_all + i * R, a->rstd_all + i * R, nullptr, gz, nullptr, 1.0f, 0,
+                                    a->dgamma[i], a->dbeta[i], a->lengths, B, T, C, om, PTPP_ACT_RELU, 0.f, 0, a->drop_out,
+                                    a->drop_out > 0.f ? a->seeds[2 * i + 1] : 0, dt, a->red_scratch, a->red_bytes, stream));
+    } else {
+      ST_TRY(ptpp_layernorm_bwd(gout, fused_in ? at(a->sum_all, (size_t)i * BTC, dt) : z, a->act_in != PTPP_ACT_NONE ? z : nullptr,
+                                a->gamma[i], a->mean_all + i * R, a->rstd_all + i * R, dsum_dst, want_dz ? conv_grad_dst : nullptr, a->dgamma[i],
+                                a->dbeta[i], a->lengths, B, T, C, om, a->act_in, a->drop_in, a->drop_in > 0.f ? a->seeds[2 * i] : 0, a->drop_out,
+                                a->drop_out > 0.f ? a->seeds[2 * i + 1] : 0, dt, a->red_scratch, a->red_bytes, stream));
+      if (relu) ST_TRY(ptpp_epilogue_bwd(aux, z, gz, nullptr, B, T, C, 1.0f, 1, 0, 0.f, 0, dt, stream));
+    }
     const bool need_dx = i > 0 || a->gx != nullptr;
     if (need_dx) {
       void* gnext = i == 0 ? a->gx : g[i & 1];
