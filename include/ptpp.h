@@ -399,12 +399,21 @@ typedef struct {
   int32_t B, T, C, dil, ldc, init, dtype;
   void* skip_scaled;      /* (B, T, C) bf16 out or NULL: bf16(skip * skip_scale) after this layer's update -- on the last  */
   float skip_scale;       /* layer, the input of the skip projection (sum / sqrt(L), denoiser.py:150) without two launches  */
+  const void* condx;      /* NULL, or the conditioner INPUT (B, T, 256) bf16, row stride ldcx: its 1 x 1 projection           */
+  int32_t ldcx;           /* (denoiser.py:76) then runs inside the launch as 16 more stages of the first matrix pass --       */
+                          /* `cond` is unused, `wstream` is the ptpp_diffnet_pack_wstream_cond form (80 stages) and `dil_b`   */
+                          /* the SUM of the dilated-conv and conditioner biases.  The pre-activation is then accumulated in   */
+                          /* f32 before its single rounding (the precomputed slice was rounded to bf16 first).                */
 } ptpp_diffnet_layer_args;
 int ptpp_diffnet_layer_supported(int C, int dtype);
 int64_t ptpp_diffnet_wstream_bytes(int C);
 /* dil_wp / out_wp: HOST arrays of L device pointers (mode-2 (2C, 3, C) and mode-0 (2C, 1, C) bf16 operands); wstream:
  * L * ptpp_diffnet_wstream_bytes(C) bytes, layer l at l * that. */
 int ptpp_diffnet_pack_wstream(const void* const* dil_wp, const void* const* out_wp, void* wstream, int L, int C, void* stream);
+/* ... with the conditioner projection's weights (mode-2 (2C, 1, 256) operands) as stages 48-63: the `condx` form of the layer */
+int64_t ptpp_diffnet_wstream_bytes_cond(int C);
+int ptpp_diffnet_pack_wstream_cond(const void* const* dil_wp, const void* const* cond_wp, const void* const* out_wp, void* wstream, int L,
+                                   int C, void* stream);
 int ptpp_diffnet_layer_fwd(const ptpp_diffnet_layer_args* a, void* stream);
 /* diagnostics for tools/ only: dbg bit 0 = per-block clock stamps (6 x uint64 per block: start, first stage landed, end of the
  * dilated conv, end of the gate epilogue, end of the output projection, end), bits 1-3 switch work off (results invalid). */
@@ -649,6 +658,9 @@ typedef struct {
                              * bit-identical to the two launches it replaces */
   void* skip_scaled;        /* (B, T, C) dtype out or NULL: dtype(skip * skip_scale) from the last layer's launch (needs the */
   float skip_scale;         /* one-launch layer, i.e. `wstream`): the input of the skip projection (denoiser.py:150)          */
+  const void* condx;        /* NULL, or the conditioner input (B, T, 256) dtype, row stride ldcx: every layer projects it     */
+  int32_t ldcx;             /* inside its launch (ptpp_diffnet_layer_args.condx) -- cond_all may then be NULL, `wstream` is   */
+                            /* the _cond form and dil_b[l] the summed biases; needs the one-launch layer                      */
 } ptpp_diffnet_stack_fwd_args;
 int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream);
 

@@ -70,7 +70,7 @@ class DiffNetFwdArgs(Structure):
     _fields_ = [(n, c_void_p) for n in ("h0", "cond_all", "dsteps", "lengths", "skip", "dil_wp", "dil_b", "out_wp", "out_b",
                                         "yin_all", "a_all", "g_all", "x_buf0", "x_buf1", "o_buf")] + \
                [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "n_slabs", "fused_gate", "dtype")] + \
-               [("wstream", c_void_p), ("skip_scaled", c_void_p), ("skip_scale", c_float)]
+               [("wstream", c_void_p), ("skip_scaled", c_void_p), ("skip_scale", c_float), ("condx", c_void_p), ("ldcx", c_int32)]
 
 
 class DiffNetLayerArgs(Structure):
@@ -78,7 +78,8 @@ class DiffNetLayerArgs(Structure):
 
     _fields_ = [(n, c_void_p) for n in ("yin", "x", "cond", "wstream", "dil_b", "out_b", "dnext", "skip", "xn", "yin_next", "a_out",
                                         "g_out", "lengths")] + \
-               [(n, c_int32) for n in ("B", "T", "C", "dil", "ldc", "init", "dtype")] + [("skip_scaled", c_void_p), ("skip_scale", c_float)]
+               [(n, c_int32) for n in ("B", "T", "C", "dil", "ldc", "init", "dtype")] + \
+               [("skip_scaled", c_void_p), ("skip_scale", c_float), ("condx", c_void_p), ("ldcx", c_int32)]
 
 
 class DiffNetBwdArgs(Structure):
@@ -269,6 +270,8 @@ SIGNATURES = {
     "ptpp_diffnet_layer_supported": (I, [I, I]),
     "ptpp_diffnet_wstream_bytes": (ctypes.c_int64, [I]),
     "ptpp_diffnet_pack_wstream": (I, [P, P, P, I, I, P]),
+    "ptpp_diffnet_wstream_bytes_cond": (ctypes.c_int64, [I]),
+    "ptpp_diffnet_pack_wstream_cond": (I, [P, P, P, P, I, I, P]),
     "ptpp_diffnet_layer_fwd": (I, [POINTER(DiffNetLayerArgs), P]),
     "ptpp_diffnet_layer_fwd_dbg": (I, [POINTER(DiffNetLayerArgs), I, P, P]),
     "ptpp_diffnet_stack_bwd": (I, [POINTER(DiffNetBwdArgs), P]),

@@ -50,6 +50,8 @@ struct DnLayerP {
   bf16_raw* a_out;
   bf16_raw* g_out;
   bf16_raw* skip_scaled;  // optional: bf16(skip * skip_scale), what the skip projection reads (last layer)
+  const bf16_raw* condx;  // COND instantiation: the conditioner INPUT (B, T, 256), row stride ldcx -- its projection is 16 more
+  int ldcx;               // stages of pass A instead of a precomputed (B, T, 2C) slice added in the gate epilogue
   const int* lengths;
   float skip_scale;
   int B, T, dil, ldc, init, nMT;
@@ -90,12 +92,12 @@ __device__ __forceinline__ void dn_mfma_step(f32x4 (&acc)[FM][4], const uint4 (&
                                                             acc[fm][fn], 0, 0, 0);
 }
 
-template <int NS>
+template <int NS, int NSTEPS = DN_STEPS>
 __device__ __forceinline__ void dn_wait_stage(int s) {
   // top of step s: this wave's pieces of stage s + 1 must have landed.  Issued so far: stages up to min(63, s + NS - 2), two
   // pieces per stage and wave, so min(NS - 3, 62 - s) younger stages may stay in flight (the x-window pieces issued in
   // between only make the wait stricter)
-  const int younger = min(NS - 3, DN_STEPS - 2 - s);
+  const int younger = min(NS - 3, NSTEPS - 2 - s);
   if (younger >= 3) glds_wait<6>();
   else if (younger == 2) glds_wait<4>();
   else if (younger == 1) glds_wait<2>();
@@ -104,9 +106,15 @@ __device__ __forceinline__ void dn_wait_stage(int s) {
 
 // DBG (tools only, ptpp_diffnet_layer_fwd_dbg): bit 0 = clock stamps per block into p.stamps, bit 1 = no MFMAs, bit 2 = no
 // weight stream (the waits find nothing outstanding), bit 3 = no epilogue loads / stores
-template <int NS, bool SAVE, int DBG = 0, int FM = 4>
+template <int NS, bool SAVE, int DBG = 0, int FM = 4, bool COND = false>
 __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p) {
   constexpr int BM = 32 * FM;  // rows per block: 2 wave rows x FM MFMA tiles of 16
+  // COND: the conditioner projection (1 x 1, 256 -> 2C) joins pass A as four more 64-channel chunks with one tap each
+  // (8 more pairs of steps); the gate epilogue then has no conditioner slice to read
+  constexpr int NA = COND ? 32 : 24;        // pairs of steps of pass A
+  constexpr int SB = 2 * NA;                // first stage of pass B
+  constexpr int NSTEPS = SB + 16;
+  constexpr int LASTC = COND ? 7 : 3;       // last x chunk
   static_assert(NS >= 3 && NS <= 6, "ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object
   uint4* Ring = reinterpret_cast<uint4*>(smem);                // [NS][1024]
@@ -125,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
   const int len_raw = p.lengths ? p.lengths[b] : T;
 
   const bf16_raw* yb = p.yin + (int64_t)b * T * DN_C;
+  const bf16_raw* cxb = COND ? p.condx + (int64_t)b * T * p.ldcx : nullptr;
   const char* wsrc = reinterpret_cast<const char*>(p.wstream) + wave * 2048 + lane * 16;
   const uint32_t ring_lds = lds_addr(Ring) + (uint32_t)wave * 2048u;
   const uint32_t xs_lds = lds_addr(G);
@@ -141,7 +150,8 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     const int r = piece * 8 + (lane >> 3);
     const int c = (lane & 7) ^ swz<8>(r);
     const int ts = t0 - dil + r;
-    const char* src = (ts >= 0 && ts < T) ? reinterpret_cast<const char*>(yb + (int64_t)ts * DN_C + ci * 64 + c * 8) : zero;
+    const bf16_raw* row = (COND && ci >= 4) ? cxb + (int64_t)ts * p.ldcx + (ci - 4) * 64 : yb + (int64_t)ts * DN_C + ci * 64;
+    const char* src = (ts >= 0 && ts < T) ? reinterpret_cast<const char*>(row + c * 8) : zero;
     glds16(src, __builtin_amdgcn_readfirstlane(xs_lds + (uint32_t)(((ci & 1) * xrows + piece * 8) * 128)));
   };
 
@@ -188,9 +198,14 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
   // one LDS address per request: the tiles of a wave are 16 rows apart, which leaves both swizzles unchanged, so tile fm
   // is a compile-time offset (the address arithmetic per step was as long as the MFMA issue itself)
   const int xrow0 = wm * (16 * FM) + lr;
-  auto ld_x = [&](uint4 (&xf)[FM], int pair) {  // pair = (ci * 3 + tap) * 2 + kh
-    const int ci = pair / 6, tk = pair - ci * 6;
-    const int tap = tk >> 1, kh = tk & 1;
+  auto ld_x = [&](uint4 (&xf)[FM], int pair) {  // pair = (ci * 3 + tap) * 2 + kh; conditioner chunks: 24 + (ci - 4) * 2 + kh, centre tap
+    int ci = pair / 6, tk = pair - ci * 6;
+    int tap = tk >> 1, kh = tk & 1;
+    if (COND && pair >= 24) {
+      ci = 4 + ((pair - 24) >> 1);
+      tap = 1;
+      kh = pair & 1;
+    }
     if constexpr ((DBG & 64) != 0) return;
     const int r = xrow0 + tap * dil;
     const uint4* src = G + (ci & 1) * xrows * 8 + r * 8 + ((kh * 4 + lg) ^ swz<8>(r));
@@ -215,12 +230,12 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
   // top of step s: stage s + 1 has landed for everyone, stage s - 1 is free; then the next DMA
   auto step_top = [&](int s, int slot) {
     fine_stamp(s, 0);
-    if (s + 1 < DN_STEPS) dn_wait_stage<NS>(s);
+    if (s + 1 < NSTEPS) dn_wait_stage<NS, NSTEPS>(s);
     fine_stamp(s, 1);
     if constexpr ((DBG & 32) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (timing experiment: no barrier, results invalid)
     else lds_barrier();
     fine_stamp(s, 2);
-    if (s + NS - 1 < DN_STEPS) issue_w(s + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+    if (s + NS - 1 < NSTEPS) issue_w(s + NS - 1, slot == 0 ? NS - 1 : slot - 1);
     fine_stamp(s, 3);
   };
   auto next_slot = [&](int slot) { return slot + 1 == NS ? 0 : slot + 1; };
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
 #pragma unroll
     for (int s = 1; s <= NS - 3; ++s) issue_w(s, s);
     // pseudo-step -1: stage 0 and the first x window have landed; the first fragments
-    dn_wait_stage<NS>(-1);
+    dn_wait_stage<NS, NSTEPS>(-1);
     lds_barrier();
     issue_w(NS - 2, NS - 2);
     if constexpr (DBG & 1) stamp[1] = wall_clock64();
@@ -243,10 +258,14 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     // alternate between two register sets without copies)
     auto pair_steps = [&](int pr, uint4 (&xcur)[FM], uint4 (&xnext)[FM]) __attribute__((always_inline)) {
       const int s = 2 * pr;
-      const int ci = pr / 6, tk = pr - ci * 6;
+      int ci = pr / 6, tk = pr - ci * 6;
+      if (COND && pr >= 24) {
+        ci = 4 + ((pr - 24) >> 1);
+        tk = pr & 1;
+      }
       // step s: channel half 0
       step_top(s, slot);
-      if (ci < 3 && tk < 2) {  // the next chunk's window: pieces wave, wave + 8, wave + 16 over three steps
+      if (ci < LASTC && tk < 2) {  // the next chunk's window: pieces wave, wave + 8, wave + 16 over three steps
         const int piece = wave + 16 * tk;
         if (piece < np) issue_x_piece(ci + 1, piece);
       }
@@ -259,11 +278,11 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       slot = next_slot(slot);
       // step s + 1: channel half 1 (same x fragments)
       step_top(s + 1, slot);
-      if (ci < 3 && tk == 0) {
+      if (ci < LASTC && tk == 0) {
         const int piece = wave + 8;
         if (piece < np) issue_x_piece(ci + 1, piece);
       }
-      if (pr < 23) {
+      if (pr < NA - 1) {
         ld_w(wf0, next_slot(slot));
         ld_x(xnext, pr + 1);
       }
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       slot = next_slot(slot);
     };
 #pragma unroll 1
-    for (int pr = 0; pr < 24; pr += 2) {
+    for (int pr = 0; pr < NA; pr += 2) {
       pair_steps(pr, xa, xb_);
       pair_steps(pr + 1, xb_, xa);
     }
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
         for (int fm = 0; fm < FM; ++fm) {
           const int t = t0 + wm * (16 * FM) + fm * 16 + lr;
           cv[nh][h][fm] = make_uint4(0, 0, 0, 0);
-          if (t < T && !(DBG & 8)) cv[nh][h][fm] = *reinterpret_cast<const uint4*>(cb + (int64_t)t * p.ldc + nh * 256 + wn * 64 + h * 32 + lg * 8);
+          if (!COND && t < T && !(DBG & 8)) cv[nh][h][fm] = *reinterpret_cast<const uint4*>(cb + (int64_t)t * p.ldc + nh * 256 + wn * 64 + h * 32 + lg * 8);
         }
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
@@ -365,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     ld_w(wf0, slot);
     ld_g(xa, 0);
     auto proj_steps = [&](int kc, uint4 (&gcur)[FM], uint4 (&gnext)[FM]) __attribute__((always_inline)) {
-      const int s = 48 + 2 * kc;
+      const int s = SB + 2 * kc;
       step_top(s, slot);
       ld_w(wf1, next_slot(slot));
       __builtin_amdgcn_sched_barrier(0);
@@ -518,15 +537,17 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
 struct DnPackTab {
   const uint4* dil[32];
   const uint4* out[32];
+  const uint4* cond[32];  // the with-conditioner stream (80 stages): [48, 64) = (cc * 2 + kh) * 2 + nh -> cond_wp[nh * 256 + n(q)][cc * 64 + kh * 32 + c * 8 ..]
 };
 __device__ __forceinline__ int dn_row_of(int q) {
   const int u = q & 63;
   const int tile = u >> 4, lgq = (u >> 2) & 3, r = u & 3;
   return (q - u) + (tile >> 1) * 32 + lgq * 8 + (tile & 1) * 4 + r;
 }
-__global__ __launch_bounds__(256) void diffnet_pack_wstream_kernel(const DnPackTab tab, uint4* __restrict__ ws) {
-  const int l = blockIdx.x >> 6, s = blockIdx.x & 63;
-  uint4* dst = ws + ((size_t)(blockIdx.y * 32 + l) * DN_STEPS + s) * DN_STAGE_U4;
+__global__ __launch_bounds__(256) void diffnet_pack_wstream_kernel(const DnPackTab tab, uint4* __restrict__ ws, int nsteps) {
+  const int l = blockIdx.x / nsteps, s = blockIdx.x - l * nsteps;
+  const int sb = nsteps - 16;  // first stage of the output projection
+  uint4* dst = ws + ((size_t)l * nsteps + s) * DN_STAGE_U4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = threadIdx.x + i * 256;
@@ -539,8 +560,11 @@ __global__ __launch_bounds__(256) void diffnet_pack_wstream_kernel(const DnPackT
       const int ci = ct / 3, tap = ct - ci * 3;
       // operand [512][3][256] bf16: 32 uint4 per (row, tap)
       v = tab.dil[l][((size_t)(nh * 256 + n) * 3 + tap) * 32 + ci * 8 + kh * 4 + c];
+    } else if (s < sb) {
+      const int nh = s & 1, kh = (s >> 1) & 1, cc = (s - 48) >> 2;
+      v = tab.cond[l][(size_t)(nh * 256 + n) * 32 + cc * 8 + kh * 4 + c];  // operand [512][1][256] bf16, gate-interleaved rows
     } else {
-      const int nh = s & 1, kc = (s - 48) >> 1;
+      const int nh = s & 1, kc = (s - sb) >> 1;
       v = tab.out[l][(size_t)(nh * 256 + n) * 32 + kc * 4 + c];
     }
     dst[idx] = v;
@@ -552,24 +576,35 @@ __global__ __launch_bounds__(256) void diffnet_pack_wstream_kernel(const DnPackT
 extern "C" int ptpp_diffnet_layer_supported(int C, int dtype) { return C == DN_C && dtype == PTPP_BF16; }
 
 extern "C" int64_t ptpp_diffnet_wstream_bytes(int C) { return C == DN_C ? (int64_t)DN_STEPS * DN_STAGE_U4 * 16 : 0; }
+extern "C" int64_t ptpp_diffnet_wstream_bytes_cond(int C) { return C == DN_C ? (int64_t)(DN_STEPS + 16) * DN_STAGE_U4 * 16 : 0; }
 
-extern "C" int ptpp_diffnet_pack_wstream(const void* const* dil_wp, const void* const* out_wp, void* wstream, int L, int C, void* stream) {
+static int dn_pack(const void* const* dil_wp, const void* const* cond_wp, const void* const* out_wp, void* wstream, int L, int C, void* stream) {
   PTPP_CHECK_ARG(dil_wp && out_wp && wstream && L > 0, "diffnet_pack_wstream: null pointer / bad layer count");
   PTPP_CHECK_ARG(C == DN_C, "diffnet_pack_wstream: C = %d is not supported (256)", C);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nsteps = cond_wp ? DN_STEPS + 16 : DN_STEPS;
   for (int l0 = 0; l0 < L; l0 += 32) {
     DnPackTab tab;
     const int n = L - l0 < 32 ? L - l0 : 32;
     for (int i = 0; i < 32; ++i) {
       tab.dil[i] = reinterpret_cast<const uint4*>(dil_wp[l0 + (i < n ? i : 0)]);
       tab.out[i] = reinterpret_cast<const uint4*>(out_wp[l0 + (i < n ? i : 0)]);
-      PTPP_CHECK_ARG(tab.dil[i] && tab.out[i], "diffnet_pack_wstream: null operand");
+      tab.cond[i] = cond_wp ? reinterpret_cast<const uint4*>(cond_wp[l0 + (i < n ? i : 0)]) : nullptr;
+      PTPP_CHECK_ARG(tab.dil[i] && tab.out[i] && (!cond_wp || tab.cond[i]), "diffnet_pack_wstream: null operand");
     }
-    uint4* dst = reinterpret_cast<uint4*>(wstream) + (size_t)l0 * DN_STEPS * DN_STAGE_U4;
-    hipLaunchKernelGGL(diffnet_pack_wstream_kernel, dim3((unsigned)(n * DN_STEPS), 1), dim3(256), 0, st, tab, dst);
+    uint4* dst = reinterpret_cast<uint4*>(wstream) + (size_t)l0 * nsteps * DN_STAGE_U4;
+    hipLaunchKernelGGL(diffnet_pack_wstream_kernel, dim3((unsigned)(n * nsteps), 1), dim3(256), 0, st, tab, dst, nsteps);
   }
   PTPP_CHECK_LAUNCH("diffnet_pack_wstream");
   return PTPP_OK;
+}
+extern "C" int ptpp_diffnet_pack_wstream(const void* const* dil_wp, const void* const* out_wp, void* wstream, int L, int C, void* stream) {
+  return dn_pack(dil_wp, nullptr, out_wp, wstream, L, C, stream);
+}
+extern "C" int ptpp_diffnet_pack_wstream_cond(const void* const* dil_wp, const void* const* cond_wp, const void* const* out_wp, void* wstream,
+                                             int L, int C, void* stream) {
+  PTPP_CHECK_ARG(cond_wp, "diffnet_pack_wstream_cond: null pointer");
+  return dn_pack(dil_wp, cond_wp, out_wp, wstream, L, C, stream);
 }
 
 static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsigned long long* stamps, void* stream);
@@ -582,9 +617,13 @@ extern "C" int ptpp_diffnet_layer_fwd_dbg(const ptpp_diffnet_layer_args* a, int 
 }
 
 static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsigned long long* stamps, void* stream) {
-  PTPP_CHECK_ARG(a && a->yin && a->x && a->cond && a->wstream && a->dil_b && a->out_b && a->skip && a->xn, "diffnet_layer_fwd: null pointer");
+  PTPP_CHECK_ARG(a && a->yin && a->x && (a->cond || a->condx) && a->wstream && a->dil_b && a->out_b && a->skip && a->xn,
+                 "diffnet_layer_fwd: null pointer");
+  PTPP_CHECK_ARG(!a->condx || (a->ldcx >= DN_C && (a->ldcx & 7) == 0 && ((uintptr_t)a->condx & 15) == 0 && !dbg),
+                 "diffnet_layer_fwd: bad conditioner input (ldcx %d; 256 channels, 16-byte aligned, no diagnostics build)", a->ldcx);
   PTPP_CHECK_ARG(a->C == DN_C && a->dtype == PTPP_BF16, "diffnet_layer_fwd: C = 256 and bf16 only (C %d, dtype %d)", a->C, a->dtype);
-  PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && (a->dil == 1 || a->dil == 2 || a->dil == 4 || a->dil == 8) && a->ldc >= 2 * DN_C && (a->ldc & 7) == 0,
+  PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && (a->dil == 1 || a->dil == 2 || a->dil == 4 || a->dil == 8) &&
+                     (a->condx || (a->ldc >= 2 * DN_C && (a->ldc & 7) == 0)),
                  "diffnet_layer_fwd: bad shape (B %d T %d dil %d ldc %d)", a->B, a->T, a->dil, a->ldc);
   PTPP_CHECK_ARG((a->a_out != nullptr) == (a->g_out != nullptr), "diffnet_layer_fwd: a_out and g_out go together (training) or are both NULL");
   const uintptr_t al = (uintptr_t)a->yin | (uintptr_t)a->x | (uintptr_t)a->cond | (uintptr_t)a->wstream | (uintptr_t)a->skip | (uintptr_t)a->xn |
@@ -607,6 +646,8 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
   p.lengths = a->lengths;
   p.skip_scaled = reinterpret_cast<bf16_raw*>(a->skip_scaled);
   p.skip_scale = a->skip_scale;
+  p.condx = reinterpret_cast<const bf16_raw*>(a->condx);
+  p.ldcx = a->ldcx;
   p.B = a->B; p.T = a->T; p.dil = a->dil; p.ldc = a->ldc; p.init = a->init;
   // A block holds 96-144 KiB of LDS: one block per CU, a launch runs in rounds of 256 blocks.  Rows per block (128 / 96 / 64):
   // the choice with the least (rounds x time of one block) -- block times measured on the inference form, 57 / 46 / 35 us
@@ -635,6 +676,11 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
   auto kern = sv ? diffnet_layer_kernel<NS, true> : diffnet_layer_kernel<NS, false>;
   if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 2> : diffnet_layer_kernel<NS, false, 0, 2>;
   if (bm == 96) kern = sv ? diffnet_layer_kernel<NS, true, 0, 3> : diffnet_layer_kernel<NS, false, 0, 3>;
+  if (a->condx) {  // the conditioner projection inside pass A (80-stage operand stream)
+    kern = sv ? diffnet_layer_kernel<NS, true, 0, 4, true> : diffnet_layer_kernel<NS, false, 0, 4, true>;
+    if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 2, true> : diffnet_layer_kernel<NS, false, 0, 2, true>;
+    if (bm == 96) kern = sv ? diffnet_layer_kernel<NS, true, 0, 3, true> : diffnet_layer_kernel<NS, false, 0, 3, true>;
+  }
   if (bm == 96 && dbg) { ptpp_set_error("diffnet_layer_fwd_dbg: the 96-row instantiation has no diagnostics build"); return PTPP_EINVAL; }
   if (dbg) {
     switch (dbg + (small ? 100 : 0)) {
@@ -660,14 +706,14 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
     }
   }
   {  // once per kernel: the dynamic LDS size is above the 64 KiB default
-    static const void* done[16];
+    static const void* done[24];
     static int ndone = 0;
     const void* kp = reinterpret_cast<const void*>(kern);
     bool seen = false;
     for (int i = 0; i < ndone; ++i) seen = seen || done[i] == kp;
     if (!seen) {
       (void)hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (ndone < 16) done[ndone++] = kp;
+      if (ndone < 24) done[ndone++] = kp;
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, reinterpret_cast<hipStream_t>(stream), p);

@@ -54,7 +54,7 @@ static bool rt_takes(const ptpp_conv1d_args& c, const void* wstream) {
 }
 
 extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream) {
-  ST_CHECK_ARG(a && a->h0 && a->cond_all && a->dsteps && a->skip && a->dil_wp && a->dil_b && a->out_wp && a->out_b && a->yin_all &&
+  ST_CHECK_ARG(a && a->h0 && (a->cond_all || a->condx) && a->dsteps && a->skip && a->dil_wp && a->dil_b && a->out_wp && a->out_b && a->yin_all &&
                    a->g_all && a->x_buf[0] && a->x_buf[1],
                "diffnet_stack_fwd: null pointer");
   ST_CHECK_ARG(a->B > 0 && a->T > 0 && a->C > 0 && a->L > 0 && a->cycle > 0 && a->n_slabs >= 2, "diffnet_stack_fwd: bad shape");
@@ -77,14 +77,15 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
   const void* x = a->h0;
   // the whole layer as one launch (csrc/diffnet_layer.hip) where the fused gate is on and the operand stream was handed over
   const bool one_launch = a->wstream && a->fused_gate && ptpp_diffnet_layer_supported(C, dt) && (1 << ((L - 1) % a->cycle)) <= 8 && a->cycle <= 4;
-  const int64_t wsb = one_launch ? ptpp_diffnet_wstream_bytes(C) : 0;
+  const int64_t wsb = one_launch ? (a->condx ? ptpp_diffnet_wstream_bytes_cond(C) : ptpp_diffnet_wstream_bytes(C)) : 0;
+  ST_CHECK_ARG(!a->condx || one_launch, "diffnet_stack_fwd: condx needs the one-launch layer (wstream, fused gate, bf16, C = 256)");
   ST_CHECK_ARG(!a->skip_scaled || one_launch, "diffnet_stack_fwd: skip_scaled needs the one-launch layer (wstream, fused gate, bf16, C = 256)");
   for (int l = 0; l < L; ++l) {
     const int d = 1 << (l % a->cycle);
     const int slab = l % a->n_slabs;
     const void* yin = at(a->yin_all, slab * BTC, dt);
     void* g = at(a->g_all, slab * BTC, dt);
-    const void* cond = at(a->cond_all, (size_t)l * 2 * C, dt);
+    const void* cond = a->cond_all ? at(a->cond_all, (size_t)l * 2 * C, dt) : nullptr;
     if (one_launch) {
       const float* dnext = l + 1 < L ? a->dsteps + (size_t)(l + 1) * B * C : nullptr;
       ptpp_diffnet_layer_args la;
@@ -96,6 +97,7 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
       if (a->fused_gate == 2) { la.a_out = at(a->a_all, slab * 2 * BTC, dt); la.g_out = g; }
       la.lengths = a->lengths;
       if (l == L - 1 && a->skip_scaled) { la.skip_scaled = a->skip_scaled; la.skip_scale = a->skip_scale; }
+      la.condx = a->condx; la.ldcx = a->ldcx;
       la.B = B; la.T = T; la.C = C; la.dil = d; la.ldc = ldc; la.init = l == 0; la.dtype = dt;
       ST_TRY(ptpp_diffnet_layer_fwd(&la, stream));
       x = la.xn;

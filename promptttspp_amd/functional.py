@@ -903,7 +903,10 @@ def _f32_param(t):
 DIFFNET_LAYER_KERNEL = not os.environ.get("PTPP_NO_DIFFNET_LAYER_KERNEL")  # (tests compare with the two-launch path)
 
 
-def diffnet_wstream(weights, dil_wp, out_wp, dt):
+DIFFNET_FOLD_COND = not os.environ.get("PTPP_NO_DIFFNET_FOLD_COND")  # training: the conditioner projection inside the layer launch
+
+
+def diffnet_wstream(weights, dil_wp, out_wp, dt, cond_ws=None):
     """The operand stream of csrc/diffnet_layer.hip for all layers ((L, 1 MiB) bytes; ptpp_diffnet_pack_wstream): every
     layer's dilated-conv (mode 2) and output-projection operands re-laid as the 64 LDS stage images its kernel consumes,
     cached per version of the 2 L weights (one gather launch per optimiser step in training, one per checkpoint otherwise)."""
@@ -914,18 +917,21 @@ def diffnet_wstream(weights, dil_wp, out_wp, dt):
     L = len(weights)
 
     def make():
-        ws = torch.empty((L, lib.ptpp_diffnet_wstream_bytes(C)), device=dil_wp[0].device, dtype=torch.uint8)
-        _lib.check(lib.ptpp_diffnet_pack_wstream(ctypes.cast(_ptr_table(dil_wp), ctypes.c_void_p), ctypes.cast(_ptr_table(out_wp), ctypes.c_void_p),
-                                                 ws.data_ptr(), L, C, ops._stream()), "ptpp_diffnet_pack_wstream")
-        return ws
+        cwp = None
+        if cond_ws is not None:  # (2C, 256[, 1]) each -> one mode-2 operand of all layers, layer l at row l * 2C
+            allc = packed_cat(cond_ws, dt, mode=2)
+            per = allc.shape[0] // L
+            cwp = [allc[l * per:(l + 1) * per] for l in range(L)]
+        return ops.diffnet_pack_wstream(dil_wp, out_wp, C, cond_wps=cwp)
 
-    srcs = [w[0] for w in weights] + [w[2] for w in weights]
+    srcs = [w[0] for w in weights] + [w[2] for w in weights] + (list(cond_ws) if cond_ws is not None else [])
     if not all(isinstance(t, torch.nn.Parameter) for t in srcs):
         return make()
-    return _cat_cached(srcs, ("dnws", dt), make)
+    return _cat_cached(srcs, ("dnws", dt, cond_ws is not None), make)
 
 
-def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None, scaled=False):
+def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None, scaled=False, condx=None,
+                                  cond_ws=None):
     """The whole residual stack in ONE C call (ptpp_diffnet_stack_fwd): the same launches in the same order as the loop
     of ``diffnet_stack_forward`` below (bit-identical), without ~60 Python -> C round trips and ~80 allocations.
     Returns (skip f32, (yin_all, a_all, g_all) slabs of all layers when ``save``); with ``scaled`` the first item is
@@ -957,9 +963,11 @@ def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle,
     out_wp = [packed(ow, dt) for _, _, ow, _ in weights]
     out_b = [_f32_param(ob) for _, _, _, ob in weights]
     lens = ops.i32(lengths, dev) if lengths is not None else None
-    assert h0.is_contiguous() and cond_all.is_contiguous() and cond_all.shape[2] == L * 2 * C and ds.dtype == torch.float32
+    assert h0.is_contiguous() and ds.dtype == torch.float32
+    assert condx is not None or (cond_all.is_contiguous() and cond_all.shape[2] == L * 2 * C)
     a = _lib.DiffNetFwdArgs()
-    a.h0, a.cond_all, a.dsteps, a.skip = h0.data_ptr(), cond_all.data_ptr(), ds.data_ptr(), skip.data_ptr()
+    a.h0, a.dsteps, a.skip = h0.data_ptr(), ds.data_ptr(), skip.data_ptr()
+    a.cond_all = cond_all.data_ptr() if cond_all is not None else None
     a.lengths = lens.data_ptr() if lens is not None else None
     tabs = [_ptr_table(t) for t in (dil_wp, dil_b, out_wp, out_b)]
     a.dil_wp, a.dil_b, a.out_wp, a.out_b = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
@@ -968,8 +976,11 @@ def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle,
     a.x_buf0, a.x_buf1 = xb[0].data_ptr(), xb[1].data_ptr()
     a.o_buf = o_buf.data_ptr() if o_buf is not None else None
     a.B, a.T, a.C, a.L, a.cycle, a.n_slabs, a.fused_gate, a.dtype = B, T, C, L, cycle, n_slabs, 2 if gsave else int(fused), ops.dtype_code(dt)
-    wstream = diffnet_wstream(weights, dil_wp, out_wp, dt) if (gsave or fused) and cycle <= 4 else None
+    wstream = diffnet_wstream(weights, dil_wp, out_wp, dt, cond_ws if condx is not None else None) if (gsave or fused) and cycle <= 4 else None
     a.wstream = wstream.data_ptr() if wstream is not None else None
+    if condx is not None:  # the layers project the conditioner input themselves (gate_b = dilated-conv + conditioner biases)
+        assert wstream is not None and condx.stride(2) == 1 and condx.shape[2] == 256 and condx.dtype == dt
+        a.condx, a.ldcx = condx.data_ptr(), condx.stride(1)
     sc = None
     if scaled and wstream is not None:
         sc = torch.empty((B, T, C), device=dev, dtype=dt)
@@ -978,6 +989,15 @@ def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle,
     if scaled:
         skip = sc if sc is not None else (skip * (1.0 / math.sqrt(L))).to(dt)
     return skip, ((yin_all, a_all, g_all) if save else None)
+
+
+def diffnet_fold_cond_ok(h0, cond, cycle):
+    """Training forward: can every layer project the conditioner input inside its own launch (csrc/diffnet_layer.hip, COND
+    instantiation) instead of reading a slice of the (B, T, L * 2C) tensor of all layers' projections?  Saves that tensor's
+    GEMM (0.46 ms at the bench shape), its 0.6 GB write and the 0.6 GB the layers read back per forward."""
+    return (DIFFNET_FOLD_COND and DIFFNET_LAYER_KERNEL and STACK_DRIVERS and h0.is_cuda and h0.is_contiguous() and cycle <= 4
+            and cond.dim() == 3 and cond.shape[2] == 256 and cond.stride(2) == 1 and cond.dtype == h0.dtype
+            and diffnet_gate_save(h0.dtype, h0.shape[2], True) and ops.diffnet_layer_supported(h0.shape[2], h0.dtype))
 
 
 def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None, scaled=False):
@@ -1037,13 +1057,23 @@ class DiffNetStackFn(Function):
         L = len(flat) // 6
         ws = [flat[6 * l : 6 * l + 6] for l in range(L)]  # dil_w, dil_b, cond_w, cond_b, out_w, out_b
         gate_b = None
-        if diffnet_gate_save(h0.dtype, h0.shape[2], h0.is_cuda) and h0.is_contiguous():
+        if diffnet_fold_cond_ok(h0, cond, cycle):
+            # no (B, T, L * 2C) tensor of conditioner projections: each layer's launch projects `cond` itself (f32 accumulation
+            # with the dilated conv, one rounding); its bias joins the dilated conv's
             gate_b, cond_b = gate_biases([w[1] for w in ws], [w[3] for w in ws])
-            cond_all, wc = diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws], bias_perm=cond_b)
+            c2 = ws[0][1].shape[0]
+            allb = torch.cat(gate_b) + cond_b
+            wc = [w[2] for w in ws]
+            skip, saved = _diffnet_stack_forward_driver(h0, None, dsteps, [(w[0], w[1], w[4], w[5]) for w in ws], lengths, cycle, True,
+                                                        [allb[l * c2:(l + 1) * c2] for l in range(L)], True, condx=cond, cond_ws=wc)
         else:
-            cond_all, wc = diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws])
-        skip, saved = diffnet_stack_forward(h0, cond_all, dsteps, [(w[0], w[1], w[4], w[5]) for w in ws], lengths,
-                                            cycle, save=True, gate_b=gate_b, scaled=True)
+            if diffnet_gate_save(h0.dtype, h0.shape[2], h0.is_cuda) and h0.is_contiguous():
+                gate_b, cond_b = gate_biases([w[1] for w in ws], [w[3] for w in ws])
+                cond_all, wc = diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws], bias_perm=cond_b)
+            else:
+                cond_all, wc = diffnet_cond_all(cond, [w[2] for w in ws], [w[3] for w in ws])
+            skip, saved = diffnet_stack_forward(h0, cond_all, dsteps, [(w[0], w[1], w[4], w[5]) for w in ws], lengths,
+                                                cycle, save=True, gate_b=gate_b, scaled=True)
         ctx.L, ctx.cycle, ctx.lengths, ctx.saved, ctx.ws, ctx.wc = L, cycle, lengths, saved, ws, wc
         ctx.direct = any(ctx.needs_input_grad) and all(_sink(t) is not None for t in flat)
         if ctx.direct:

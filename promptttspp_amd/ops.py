@@ -606,27 +606,38 @@ def diffnet_layer_supported(C, dtype):
     return bool(_lib.load().ptpp_diffnet_layer_supported(int(C), dtype_code(dtype)))
 
 
-def diffnet_pack_wstream(dil_wps, out_wps, C):
+def diffnet_pack_wstream(dil_wps, out_wps, C, cond_wps=None):
     """(L, bytes) uint8 operand stream of ``diffnet_layer_fwd`` from the layers' mode-2 dilated-conv and mode-0
-    output-projection operands (ptpp_diffnet_pack_wstream)."""
+    output-projection operands (ptpp_diffnet_pack_wstream); with ``cond_wps`` (mode-2 (2C, 1, 256) operands of the
+    conditioner projections) the 80-stage form of the layer that projects the conditioner input itself."""
     lib = _lib.load()
     L = len(dil_wps)
-    ws = torch.empty((L, lib.ptpp_diffnet_wstream_bytes(int(C))), device=dil_wps[0].device, dtype=torch.uint8)
+    nbytes = lib.ptpp_diffnet_wstream_bytes_cond(int(C)) if cond_wps is not None else lib.ptpp_diffnet_wstream_bytes(int(C))
+    ws = torch.empty((L, nbytes), device=dil_wps[0].device, dtype=torch.uint8)
     t1 = (ctypes.c_void_p * L)(*[t.data_ptr() for t in dil_wps])
     t2 = (ctypes.c_void_p * L)(*[t.data_ptr() for t in out_wps])
+    if cond_wps is not None:
+        t3 = (ctypes.c_void_p * L)(*[t.data_ptr() for t in cond_wps])
+        check(lib.ptpp_diffnet_pack_wstream_cond(ctypes.cast(t1, ctypes.c_void_p), ctypes.cast(t3, ctypes.c_void_p),
+                                                 ctypes.cast(t2, ctypes.c_void_p), ws.data_ptr(), L, int(C), _stream()),
+              "ptpp_diffnet_pack_wstream_cond")
+        return ws
     check(lib.ptpp_diffnet_pack_wstream(ctypes.cast(t1, ctypes.c_void_p), ctypes.cast(t2, ctypes.c_void_p), ws.data_ptr(), L, int(C),
                                         _stream()), "ptpp_diffnet_pack_wstream")
     return ws
 
 
 def diffnet_layer_fwd(yin, x, cond, wstream, dil_b, out_b, dnext, skip, dil, init, lengths=None, save=False, want_yin=True,
-                      skip_scaled=None, skip_scale=1.0):
+                      skip_scaled=None, skip_scale=1.0, condx=None):
     """One DiffNet residual layer in ONE launch (ptpp_diffnet_layer_fwd, reference modules/denoiser.py:69-83): returns
     (xn, yin_next, a, g); ``skip`` (f32) is updated in place; ``cond``: this layer's (B, T, 2C) slice (a view with the row
     stride of the all-layer tensor), gate-interleaved like ``dil_b``.  ``save``: keep a (B,T,2C) and g (B,T,C) (training).
-    ``skip_scaled``: optional (B,T,C) tensor of x's dtype that receives (skip * skip_scale) rounded once (last layer)."""
+    ``skip_scaled``: optional (B,T,C) tensor of x's dtype that receives (skip * skip_scale) rounded once (last layer).
+    ``condx``: the conditioner INPUT (B,T,256) instead of ``cond`` (None then): the layer projects it itself (``wstream`` in the
+    80-stage form, ``dil_b`` = dilated-conv + conditioner biases)."""
     B, T, C = x.shape
-    assert yin.is_contiguous() and x.is_contiguous() and skip.is_contiguous() and skip.dtype == torch.float32 and cond.stride(2) == 1
+    assert yin.is_contiguous() and x.is_contiguous() and skip.is_contiguous() and skip.dtype == torch.float32
+    assert (cond is not None and cond.stride(2) == 1) or (condx is not None and condx.stride(2) == 1 and condx.shape[2] == 256)
     xn = torch.empty_like(x)
     yn = torch.empty_like(x) if (want_yin and dnext is not None) else None
     a = torch.empty((B, T, 2 * C), device=x.device, dtype=x.dtype) if save else None
@@ -634,7 +645,10 @@ def diffnet_layer_fwd(yin, x, cond, wstream, dil_b, out_b, dnext, skip, dil, ini
     if lengths is not None:
         lengths = i32(lengths, x.device)
     args = _lib.DiffNetLayerArgs()
-    args.yin, args.x, args.cond, args.wstream = yin.data_ptr(), x.data_ptr(), cond.data_ptr(), wstream.data_ptr()
+    args.yin, args.x, args.wstream = yin.data_ptr(), x.data_ptr(), wstream.data_ptr()
+    args.cond = cond.data_ptr() if cond is not None else None
+    if condx is not None:
+        args.condx, args.ldcx = condx.data_ptr(), condx.stride(1)
     args.dil_b, args.out_b, args.skip, args.xn = dil_b.data_ptr(), out_b.data_ptr(), skip.data_ptr(), xn.data_ptr()
     args.dnext = dnext.data_ptr() if dnext is not None else None
     args.yin_next = yn.data_ptr() if yn is not None else None
@@ -644,7 +658,8 @@ def diffnet_layer_fwd(yin, x, cond, wstream, dil_b, out_b, dnext, skip, dil, ini
     if skip_scaled is not None:
         assert skip_scaled.is_contiguous() and skip_scaled.shape == x.shape and skip_scaled.dtype == x.dtype
         args.skip_scaled, args.skip_scale = skip_scaled.data_ptr(), float(skip_scale)
-    args.B, args.T, args.C, args.dil, args.ldc, args.init, args.dtype = B, T, C, int(dil), cond.stride(1), 1 if init else 0, dtype_code(x.dtype)
+    args.B, args.T, args.C, args.dil, args.init, args.dtype = B, T, C, int(dil), 1 if init else 0, dtype_code(x.dtype)
+    args.ldc = cond.stride(1) if cond is not None else 0
     check(_lib.load().ptpp_diffnet_layer_fwd(ctypes.byref(args), _stream()), "ptpp_diffnet_layer_fwd")
     return xn, yn, a, g
 

@@ -131,6 +131,81 @@ def test_one_launch_layer_matches_the_f32_oracle(dev):
     close(skip, skip_ref, 2e-2)
 
 
+@pytest.mark.parametrize("B,T,dil,masked,bm", [(3, 333, 4, False, 128), (4, 517, 8, True, 96), (2, 100, 1, True, 64), (5, 260, 2, False, 128)])
+def test_layer_with_the_conditioner_projection_inside(dev, monkeypatch, B, T, dil, masked, bm):
+    """The COND instantiation (the 1 x 1 conditioner projection as 16 more stages of the first matrix pass, 80-stage operand
+    stream, summed biases) against the launch that reads the precomputed slice: same arithmetic except that the projection is no
+    longer rounded to bf16 before it joins the dilated conv -- pre-activation within one bf16 ulp of its scale, everything
+    downstream within the bf16 tolerance; and against the f32 oracle at least as close as the slice form."""
+    import torch.nn.functional as F
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd import ops
+
+    monkeypatch.setenv("PTPP_DIFFNET_BM", str(bm))
+    x, yin, _, _, dil_w, dil_b, out_w, out_b, dnext, skip0 = _case(dev, B, T, seed=40 + dil)
+    g = torch.Generator().manual_seed(77)
+    condx = torch.randn(B, T, 256, generator=g).to(dev).bfloat16()
+    cw, cb = (torch.randn(2 * C, 256, 1, generator=g) * 0.05).to(dev), (torch.randn(2 * C, generator=g) * 0.1).to(dev)
+    lengths = torch.tensor([max(1, T - 90 * i) for i in range(B)], device=dev, dtype=torch.int32) if masked else None
+    perm = PF._gate_perm(2 * C, x.device)
+    dwp, owp = ops.pack_conv_weight(dil_w, torch.bfloat16, 2), ops.pack_conv_weight(out_w, torch.bfloat16)
+    cwp = ops.pack_conv_weight(cw, torch.bfloat16, 2)
+    # reference form: the slice (B, T, 2C) in the gate-interleaved order, rounded to bf16, bias included
+    cond = ops.conv1d(condx, cwp, cb[perm].contiguous(), 2 * C)
+    ws_ref = ops.diffnet_pack_wstream([dwp], [owp], C)
+    s_ref, s_got = skip0.clone(), skip0.clone()
+    ref = ops.diffnet_layer_fwd(yin, x, cond, ws_ref[0], dil_b[perm].contiguous(), out_b, dnext, s_ref, dil, False, lengths=lengths, save=True)
+    ws = ops.diffnet_pack_wstream([dwp], [owp], C, cond_wps=[cwp])
+    assert ws.shape[1] == ws_ref.shape[1] * 80 // 64
+    got = ops.diffnet_layer_fwd(yin, x, None, ws[0], (dil_b + cb)[perm].contiguous(), out_b, dnext, s_got, dil, False, lengths=lengths,
+                                save=True, condx=condx)
+    torch.cuda.synchronize()
+    # f32 oracle of the pre-activation and the gate
+    bw = lambda w: w.bfloat16().float().cpu()
+    a_or = (F.conv1d(yin.float().cpu().transpose(1, 2), bw(dil_w), dil_b.cpu(), padding=dil, dilation=dil)
+            + F.conv1d(condx.float().cpu().transpose(1, 2), bw(cw), cb.cpu())).transpose(1, 2)
+    if masked:
+        keep = (torch.arange(T)[None, :] < lengths.cpu()[:, None])[:, :, None]
+    names = ["xn", "yin_next", "a", "g"]
+    for n, r, o in zip(names, ref, got):
+        r, o = r.float(), o.float()
+        if masked and n in ("a", "g"):
+            # past an utterance's end the slice form keeps the bare conditioner value in a (and its gate in g), this form zeros:
+            # both only ever meet the masked output projection / zero gradients
+            r, o = r * keep.to(dev), o * keep.to(dev)
+        scale = float(r.abs().max())
+        err = float((r - o).abs().max()) / scale
+        assert err < (1.2e-2 if n == "a" else 2.5e-2), (n, err)
+    assert float((s_ref - s_got).abs().max() / s_ref.abs().max()) < 2.5e-2
+    a_ref_err = (ref[2].float().cpu() - a_or).abs()
+    a_got_err = (got[2].float().cpu() - a_or).abs()
+    if masked:  # rows past an utterance's end hold the conditioner-only value in both forms; compare the valid rows
+        a_ref_err, a_got_err = a_ref_err * keep, a_got_err * keep
+    assert float(a_got_err.max()) <= float(a_ref_err.max()) * 1.05 + 1e-6  # one rounding instead of two
+    assert float(a_got_err.mean()) < float(a_ref_err.mean())
+
+
+def test_stack_with_folded_conditioner_matches_the_slice_form(dev, monkeypatch):
+    """DiffNetStackFn in training, conditioner projected inside the layer launches (the default) against the (B, T, L * 2C)
+    slice form: output and every gradient within the bf16 tolerance of one another."""
+    from promptttspp_amd import functional as PF
+    from test_stack_drivers import _run, _stack_case
+
+    B, T, L = 4, 421, 6
+    h0, cond, dsteps, lengths, params = _stack_case(dev, B, T, C, L, torch.bfloat16, True, seed=23)
+    gout = (torch.randn(B, T, C, generator=torch.Generator().manual_seed(5)) * 0.5).to(dev).bfloat16()
+    monkeypatch.setattr(PF, "DIFFNET_FOLD_COND", False)
+    ref = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    monkeypatch.setattr(PF, "DIFFNET_FOLD_COND", True)
+    assert PF.diffnet_fold_cond_ok(h0, cond, 4)
+    got = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    again = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    for i, (a, b, c) in enumerate(zip(ref, got, again)):
+        assert torch.equal(b, c), i  # reproducible
+        err = float((a.float() - b.float()).abs().max() / a.float().abs().max())
+        assert err < 3e-2, (i, err)
+
+
 def test_stack_driver_takes_the_one_launch_layer(dev, monkeypatch):
     """ptpp_diffnet_stack_fwd with the operand stream (training form, 20 layers, all four dilations, ragged batch) against the
     same driver without it: skip sum and every saved slab bit-identical; the stream follows a weight update."""
