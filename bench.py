@@ -202,8 +202,11 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         nbytes = x.shape[0] * x.shape[1] * (x.shape[2] + (cout // 2 if kw.get("act") == "gate" else cout)
                                             + (cout if kw.get("res") is not None else 0)) * es + cout * x.shape[2] * ks * es
         recs.append((e0, e1, 2.0 * rows * x.shape[2] * cout * ks, nbytes))
+        if ks == 1 and cout >= 4096 and lengths is None:
+            dn_fwd.add(len(recs) - 1)  # the (B, T, L * 2C) conditioner projection of all DiffNet layers (timed path: inside the layers)
         return y
 
+    dn_fwd = set()  # records of the DiffNet training forward on the launch-by-launch path (2 per layer + the conditioner GEMM)
     orig_post = ops.conv1d_diffnet_post
 
     def timed_post(g, wp, bias, x, skip, dnext, init, lengths=None, out_mask=False, **kw):
@@ -216,6 +219,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         C = x.shape[2]  # bytes: g, x in; xn, yin out (bf16); the f32 skip rows read and written; the weights
         nbytes = g.shape[0] * g.shape[1] * ((g.shape[2] + 3 * C) * 2 + 2 * C * 4) + 2 * C * g.shape[2] * 2
         recs.append((e0, e1, 2.0 * rows * g.shape[2] * 2 * C, nbytes))
+        dn_fwd.add(len(recs) - 1)
         return r
 
     orig_gbwd = ops.conv1d_gate_bwd
@@ -243,6 +247,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         rows = x.shape[0] * x.shape[1]
         valid = float(lengths.sum()) if lengths is not None else rows
         recs.append((e0, e1, 2.0 * valid * x.shape[2] * 2 * C * ks, rows * (x.shape[2] + 2 * C + 2 * C + C) * 2 + 2 * C * x.shape[2] * ks * 2))
+        dn_fwd.add(len(recs) - 1)
         return r
 
     from promptttspp_amd import functional as PF
@@ -272,32 +277,37 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
     # conv1d_glds_kernel<2, 4, 2, 2, 2>, 64 x 128 tiles, and <4, 4, 2, 2, 2>, 128 x 128 tiles, for the few launches
     # with >= 1536 tiles; profiles/r04_train_step.md is the rocprofv3 summary of the training leg of this command);
     # launches of the conv family with smaller tiles / split-K are listed there, not averaged in here
-    tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
-    tot_flop = sum(f for _, _, f, _ in recs)
-    # the same launches split by the roof that applies to each (arithmetic intensity of its ALGORITHMIC bytes against the
-    # 2.5 PF / 8 TB/s ridge of 312 FLOP/B): the 1 x 1 projections (64-100 FLOP/B) can never approach the MFMA peak
     ridge = MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-    split = {}
-    for a, b, f, nb in recs:
-        k = "mfma" if f / nb >= ridge else "hbm"
-        d = split.setdefault(k, {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0})
-        d["launches"] += 1; d["ms"] += a.elapsed_time(b); d["flop"] += f; d["bytes"] += nb
-    by_bound = {}
-    for k, d in split.items():
-        if k == "mfma":
-            ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
-            by_bound[k] = {"launches": d["launches"], "achieved": round(ach, 1), "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2)}
-        else:
-            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            by_bound[k] = {"launches": d["launches"], "achieved": round(ach, 1), "unit": "GB/s (algorithmic)",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2)}
+
+    def summarize(entries):
+        """entries: (ms, flop, algorithmic bytes) per launch -> (total ms, total flop, by_bound): the launches split by the roof
+        that applies to each (arithmetic intensity of its ALGORITHMIC bytes against the 2.5 PF / 8 TB/s ridge of 312 FLOP/B):
+        the 1 x 1 projections (64-100 FLOP/B) can never approach the MFMA peak."""
+        split = {}
+        for ms, f, nb in entries:
+            k = "mfma" if f / nb >= ridge else "hbm"
+            d = split.setdefault(k, {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0})
+            d["launches"] += 1; d["ms"] += ms; d["flop"] += f; d["bytes"] += nb
+        out = {}
+        for k, d in split.items():
+            if k == "mfma":
+                a_ = d["flop"] / (d["ms"] * 1e-3) / 1e12
+                out[k] = {"launches": d["launches"], "achieved": round(a_, 1), "unit": "TFLOP/s",
+                          "frac": round(a_ / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2)}
+            else:
+                a_ = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                out[k] = {"launches": d["launches"], "achieved": round(a_, 1), "unit": "GB/s (algorithmic)",
+                          "frac": round(a_ / HBM_PEAK_GBS, 4), "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2)}
+        return sum(e[0] for e in entries), sum(e[1] for e in entries), out
+
+    all_entries = [(a.elapsed_time(b), f, nb) for a, b, f, nb in recs]
+    tot_ms, tot_flop, by_bound = summarize(all_entries)
     ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else 157.3
     traffic, traffic_src = measured_traffic(TRAFFIC_TRAIN, "conv1d_glds_kernel<2, 4, 2, 2, 2") \
         if dtype_name == "bf16" else (None, "no PMC pass for the f32 mode")
-    kname = "conv1d_glds_kernel / conv1d_rt_kernel <bf16> (LDS-DMA implicit-GEMM conv family: 64x128 / 128x128 tiles, row tiles " \
-            "for the 256-channel layers)" if dtype_name == "bf16" else "conv1d_cl_kernel<f32>, 128x128 tiles"
+    kname = "conv1d_glds_kernel / conv1d_rt_kernel / diffnet_layer_kernel <bf16> (LDS-DMA implicit-GEMM conv family: 64x128 / 128x128 " \
+            "tiles, row tiles for the 256-channel layers, one launch per DiffNet layer)" if dtype_name == "bf16" else "conv1d_cl_kernel<f32>, 128x128 tiles"
     # The timed steps run the DiffNet forward as ONE launch per layer (csrc/diffnet_layer.hip, issued by the C-side stack
     # driver: the launch-by-launch step above takes the two launches it replaces).  One more step through the drivers with an
     # event pair around the driver call: 20 launches of that kernel (+ one elementwise launch), priced per launch.
@@ -312,7 +322,8 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
             r = orig_drv(h0, cond_all, dsteps, weights, lengths, *rest, **kw)
             e1.record()
             rows = float(lengths.sum()) if lengths is not None else h0.shape[0] * h0.shape[1]
-            lrec.append((e0, e1, len(weights), rows, h0.shape[0] * h0.shape[1], h0.shape[2]))
+            cx = kw.get("condx")
+            lrec.append((e0, e1, len(weights), rows, h0.shape[0] * h0.shape[1], h0.shape[2], 0 if cx is None else cx.shape[2]))
             return r
 
         PF._diffnet_stack_forward_driver = timed_drv
@@ -323,26 +334,44 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
         finally:
             PF._diffnet_stack_forward_driver = orig_drv
         if lrec:
-            e0, e1, L, rows, padded, C = lrec[0]
+            e0, e1, L, rows, padded, C, Cc = lrec[0]
             us = 1e3 * e0.elapsed_time(e1) / L
-            flop = 2.0 * rows * C * (3 * 2 * C + 2 * C)          # dilated conv k3 C -> 2C + output projection C -> 2C
-            # algorithmic bytes per launch: yin, x, conditioner slice (2C) in; a (2C), g, xn, yin' out (bf16); skip f32 read + written
-            nbytes = padded * C * (2 + 2 + 4 + 4 + 2 + 2 + 2) + padded * C * 8
+            # dilated conv k3 C -> 2C + output projection C -> 2C (+ the conditioner projection Cc -> 2C where the layer does it)
+            flop = 2.0 * rows * C * (3 * 2 * C + 2 * C) + 2.0 * rows * Cc * 2 * C
+            # algorithmic bytes per launch: yin, x, conditioner (its 2C slice, or the Cc-channel input) in; a (2C), g, xn, yin' out
+            # (bf16); skip f32 read + written
+            nbytes = padded * C * (2 + 2 + 4 + 2 + 2 + 2) + padded * (2 * Cc if Cc else 4 * C) + padded * C * 8
+            layer_flop, layer_bytes = flop, nbytes
             lay_tf = flop / (us * 1e-6) / 1e12
-            layer = {"kernel": "diffnet_layer_kernel (one launch per DiffNet residual layer, training forward)", "launches": L,
+            layer = {"kernel": "diffnet_layer_kernel (one launch per DiffNet residual layer, training forward"
+                               + (", conditioner projection inside)" if Cc else ")"), "launches": L,
                      "avg_launch_us": round(us, 2), "achieved": round(lay_tf, 1), "unit": "TFLOP/s",
                      "frac": round(lay_tf / MFMA_BF16_PEAK_TFLOPS, 4),
                      "algorithmic_gbs": round(nbytes / (us * 1e-6) / 1e9, 1), "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                      "note": "event pair around ptpp_diffnet_stack_fwd of a driver-path step / layers; both roofs are quoted: the "
                              "launch alternates matrix passes with HBM-bound epilogues (DESIGN.md section 5e)"}
+    per_launch = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches": len(recs), "by_bound": by_bound,
+                  "note": "every launch of the instrumented step as issued there: the DiffNet forward as two launches per layer + one "
+                          "(B, T, L * 2C) conditioner GEMM (the form of rounds 1-3, kept for continuity)"}
+    if layer is not None and dn_fwd:
+        # AS TIMED: the steps `value` is measured on run the DiffNet forward as ONE launch per layer (conditioner projection
+        # inside) -- those launches, measured above through the driver, take the place of the launch-by-launch records
+        ent = [e for i, e in enumerate(all_entries) if i not in dn_fwd] + [(layer["avg_launch_us"] * 1e-3, layer_flop, layer_bytes)] * layer["launches"]
+        tot_ms, tot_flop, by_bound = summarize(ent)
+        ach = tot_flop / (tot_ms * 1e-3) / 1e12
+        n_launch = len(ent)
+    else:
+        n_launch = len(recs)
     return {"bound": "mfma", "kernel": kname + ": frame-level fwd + dgrad launches of one step",
-            "diffnet_layer": layer,
+            "diffnet_layer": layer, "launch_by_launch_path": per_launch,
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src,
-            "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
+            "launches": n_launch, "avg_launch_us": round(1e3 * tot_ms / max(n_launch, 1), 2),
             "flop_per_step": tot_flop, "by_bound": by_bound,
             "note": "instrumented extra step on the timed batch with the longest utterances, issued launch by launch (the timed "
-                    "steps issue the same kernels through the C-side stack drivers); `traffic` is read from the committed PMC "
+                    "steps issue the same kernels through the C-side stack drivers, except the DiffNet forward: there ONE launch "
+                    "per layer, measured through the driver and substituted here -- launch_by_launch_path keeps the old mix); "
+                    "`traffic` is read from the committed PMC "
                     "pass named in traffic_source, not measured in this run; "
                     "all launches are priced against the MFMA peak here for continuity with round 1; 40 of them are the DiffNet 1x1 "
                     "projections whose epilogues now also do the work of the elementwise kernels they replaced (residual / skip "
