@@ -750,6 +750,7 @@ def main():
     if world > 1 or os.environ.get("PTPP_DP_FORCE_COLLECTIVES"):
         red.enable_timing()  # three event records per step on the main stream: what the exchange costs it (the "dp" object below)
     barrier()
+    nalloc0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     frames = 0
     for i in range(a.steps):
@@ -759,7 +760,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     loss = float(out["loss"])
-    log(f"timed region done: {dt:.3f}s for {a.steps} steps, loss {loss:.4f}")
+    log(f"timed region done: {dt:.3f}s for {a.steps} steps, loss {loss:.4f}; device allocations inside it: "
+        f"{torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - nalloc0}, reserved {torch.cuda.memory_reserved(dev) / 2**30:.1f} GiB")
 
     dp = None
     if getattr(red, "_timing", None) is not None:

@@ -410,7 +410,7 @@ CfScratch cf_scratch(int B, int T, int C, int F, int H, int L, int dt) {
   o.gF = take(R * F * es); o.dqkv = take(R * 3 * C * es); o.g2a = take(R * 2 * C * es);
   o.dposc = take((size_t)L * C * es); o.dS = take((size_t)B * H * T * T * 4);
   o.dpos = take((size_t)L * C * 4);
-  for (int i = 0; i < 5; ++i) o.dz_c[i] = take(R * C * es);   // ff w2, pw2, attention out, ffm w2 (+1 spare)
+  for (int i = 0; i < 5; ++i) o.dz_c[i] = take(R * C * es);   // ff w2, pw2, attention out, ffm w2, depthwise conv
   for (int i = 0; i < 2; ++i) o.dz_f[i] = take(R * F * es);   // ff w1, ffm w1
   o.dz_2c = take(R * 2 * C * es);                             // pw1
   o.total = off;
@@ -576,10 +576,12 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
   ST_TRY(wgrad(sl(S, lo.bno), C, dz_pw2, C, g.pw2_w, g.pw2_b, len, B, T, C, C, 1, 0, 0));
   const float* bmean = a->bn_train ? bnstat : w.bn_mean_in;
   const float* brstd = a->bn_train ? bnstat + C : w.bn_rstd_in;
-  ST_TRY(ptpp_bn_act_bwd(sl(S, lo.d), t2, bmean, brstd, w.bn_g, w.bn_b, g.bn_sums, t1, (int64_t)R, C, PTPP_ACT_SWISH, a->bn_train, dt,
+  // (the depthwise conv's output gradient gets a region of its own: its weight gradient joins the block's other weight
+  //  gradients on the side stream at the end instead of sitting on the main one -- 60 us per block of a serial, atomics-bound kernel)
+  void* dz_dw = sl(X, sc.dz_c[4]);
+  ST_TRY(ptpp_bn_act_bwd(sl(S, lo.d), t2, bmean, brstd, w.bn_g, w.bn_b, g.bn_sums, dz_dw, (int64_t)R, C, PTPP_ACT_SWISH, a->bn_train, dt,
                          a->red_scratch, a->red_bytes, stream));
-  ST_TRY(ptpp_dwconv1d(t1, w.dw_w, nullptr, t2, len, B, T, C, a->ks_dw, 1, dt, stream));
-  ST_TRY(ptpp_dwconv1d_wgrad(sl(S, lo.u), t1, g.dw_w, g.dw_b, len, B, T, C, a->ks_dw, dt, stream));
+  ST_TRY(ptpp_dwconv1d(dz_dw, w.dw_w, nullptr, t2, len, B, T, C, a->ks_dw, 1, dt, stream));
   ST_TRY(ptpp_glu_bwd(sl(S, lo.g), t2, sl(X, sc.g2a), (int64_t)R, C, dt, stream));
   ST_TRY(ptpp_epilogue_bwd(sl(X, sc.g2a), nullptr, sl(X, sc.dz_2c), len, B, T, 2 * C, 1.0f, 0, 1, 0.f, 0, dt, stream));
   c = conv_args(sl(X, sc.dz_2c), 2 * C, a->pw1_wt, nullptr, nullptr, 0, t1, C, len, B, T, 2 * C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
@@ -620,6 +622,7 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
   ST_TRY(ln_bwd_plain(t1, a->x, w.ln_g[0], stats, stats + R, a->gx, g.ln_g[0], g.ln_b[0], nullptr, B, T, C, 0, dt, a->red_scratch,
                       a->red_bytes, stream, gA));
   if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
+  ST_TRY(ptpp_dwconv1d_wgrad(sl(S, lo.u), dz_dw, g.dw_w, g.dw_b, len, B, T, C, a->ks_dw, dt, wstream));
   return ptpp_conv1d_wgrad_grouped(wg, nwg, dt, ws_w, ws_w_bytes, wstream);
 }
 
