@@ -22,5 +22,5 @@ timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tm
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_wv -- $VOC > $out/pmc_wv.log 2>&1
 python $R/tools/pmc_traffic.py /tmp/p_fv /tmp/p_wv $out/${tag}_hbm_traffic_bigvgan.json "python tools/bench_vocoder.py --iters 2" 4 > $out/traffic_voc.txt 2>&1
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_sq -- $TRAIN2 > $out/pmc_sq.log 2>&1
-(echo "# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-app"; echo "# round 4; mean per dispatch (tools/pmc_summary.py); same counters as profiles/r02b_pmc_sq_mfma.txt"; python $R/tools/pmc_summary.py /tmp/p_sq | head -120) > $out/${tag}_pmc_sq_mfma.txt 2>&1
+(echo "# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-app"; echo "# round 4; mean per dispatch (tools/pmc_summary.py); same counters as profiles/r02b_pmc_sq_mfma.txt"; python $R/tools/pmc_summary.py /tmp/p_sq | head -400) > $out/${tag}_pmc_sq_mfma.txt 2>&1
 ls -la $out
