@@ -307,6 +307,17 @@ int ptpp_attention_bwd(const void* q, const void* k, const void* v,
                        int dk, int ld, int ldpos, int lddctx, int lddq,
                        int variant, float drop_p, uint64_t drop_seed, int dtype,
                        void* scratch, size_t scratch_bytes, void* stream);
+/* Windowed relative-position attention of the FFT-block encoder plug-in (modules/transformer.py:59-137, Shaw et al.):
+ *   score[i,j] = (q_i . k_j + [|j-i| <= w] q_i . emb_k[j-i+w]) / sqrt(dk);  ctx_i = sum_j P[i,j] v_j + sum_r P[i,i+r-w] emb_v[r]
+ * emb_k / emb_v: (2w+1, dk) f32, shared by the heads.  Masking, probability output and dropout as ptpp_attention_fwd (PLAIN).
+ * Backward: dS (B,H,T,T) f32 scratch/out, dq / dk / dv as ptpp_attention_bwd, demb_k / demb_v (2w+1, dk) f32 OVERWRITTEN. */
+int ptpp_attention_win_fwd(const void* q, const void* k, const void* v, const float* emb_k, const float* emb_v, void* ctx,
+                           float* probs, const int32_t* lengths, int B, int T, int H, int dk, int ld, int ldctx, int window,
+                           float drop_p, uint64_t drop_seed, int dtype, void* stream);
+int ptpp_attention_win_bwd(const void* q, const void* k, const void* v, const float* emb_k, const float* emb_v, const float* probs,
+                           const void* dctx, float* dS, void* dq, void* dk_out, void* dv_out, float* demb_k, float* demb_v,
+                           const int32_t* lengths, int B, int T, int H, int dk, int ld, int lddctx, int lddq, int window,
+                           float drop_p, uint64_t drop_seed, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Length regulator as a gather / segment-sum instead of the reference's

@@ -217,6 +217,8 @@ SIGNATURES = {
     "ptpp_layernorm_bwd_add": (I, [P] * 9 + [F, I, P, P, P, I, I, I, I, I, F, U64, F, U64, I, P, SZ, P]),
     "ptpp_attention_fwd": (I, [P] * 9 + [I] * 8 + [F, U64, I, P]),
     "ptpp_attention_bwd": (I, [P] * 16 + [I] * 9 + [F, U64, I, P, SZ, P]),
+    "ptpp_attention_win_fwd": (I, [P] * 8 + [I] * 7 + [F, U64, I, P]),
+    "ptpp_attention_win_bwd": (I, [P] * 14 + [I] * 8 + [F, U64, I, P]),
     "ptpp_length_regulate_fwd": (I, [P, P, P, I, I, I, I, I, P]),
     "ptpp_length_regulate_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "ptpp_posenc_fwd": (I, [P, P, P, I, I, I, F, F, U64, I, P]),

@@ -21,7 +21,18 @@
 
 namespace {
 
-enum { VAR_NEW = 0, VAR_LEGACY = 1, VAR_PLAIN = 2 };
+enum { VAR_NEW = 0, VAR_LEGACY = 1, VAR_PLAIN = 2, VAR_WINDOW = 3 };
+// VAR_WINDOW (modules/transformer.py:59-137, the FFT-block encoder plug-in): scores += q_i . emb_k[j - i + w] and
+// ctx_i += sum_r P[i, i + r - w] emb_v[r] for |j - i| <= w; emb_k / emb_v: (2w + 1, dk) f32, shared by the heads; no u / v biases.
+__device__ __forceinline__ bool has_uv(int variant) { return variant == VAR_NEW || variant == VAR_LEGACY; }
+__device__ __forceinline__ float dot_f32(const float* __restrict__ a, const float* __restrict__ row, int dk) {
+  float s = 0.f;
+  for (int d = 0; d < dk; d += 4) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(row + d), av = *reinterpret_cast<const f32x4*>(a + d);
+    s += av[0] * r[0] + av[1] * r[1] + av[2] * r[2] + av[3] * r[3];
+  }
+  return s;
+}
 
 struct AttnP {
   const void *q, *k, *v, *pos;
@@ -34,6 +45,8 @@ struct AttnP {
   unsigned drop_thresh16;  // attention-probability dropout, 0 = off
   float drop_inv_keep;
   unsigned long long drop_seed;
+  const float *emb_k, *emb_v;  // VAR_WINDOW
+  int window;
 };
 
 template <typename T>
@@ -76,7 +89,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
   for (int d = lane * 4; d < dk; d += 256) {
     const f32x4 qi = Elem<T>::ld4(qb + (int64_t)i * p.ld + d);
     f32x4 bu = f32x4{0.f, 0.f, 0.f, 0.f}, bv = bu;
-    if (p.variant != VAR_PLAIN) {
+    if (has_uv(p.variant)) {
       bu = *reinterpret_cast<const f32x4*>(p.bias_u + hc + d);
       bv = *reinterpret_cast<const f32x4*>(p.bias_v + hc + d);
     }
@@ -100,6 +113,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
       const int flat = (i + 1) * Tn + j;
       const int r = flat / (Tn + 1), c = flat - r * (Tn + 1);
       if (c != 0) s += dot_row<T>(r == i ? qv : qv2, pb + (int64_t)(c - 1) * p.ldpos, dk);
+    } else if (p.variant == VAR_WINDOW) {
+      const int r = j - i + p.window;
+      if (r >= 0 && r <= 2 * p.window) s += dot_f32(qu, p.emb_k + (int64_t)r * dk, dk);
     }
     s *= p.scale;
     sc[j] = s;
@@ -136,6 +152,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   if (part < parts)
     for (int j = part; j < len; j += parts) acc += Elem<T>::ld4(vb + (int64_t)j * p.ld + dv) * sc[j];
+  if (p.variant == VAR_WINDOW && part == 0)  // + sum_r P[i, i + r - w] emb_v[r]
+    for (int r = 0; r <= 2 * p.window; ++r) {
+      const int j = i + r - p.window;
+      if (j >= 0 && j < len) acc += *reinterpret_cast<const f32x4*>(p.emb_v + (int64_t)r * dk + dv) * sc[j];
+    }
   for (int o = nvec; o < 64; o <<= 1) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
@@ -391,6 +412,8 @@ struct AttnBwdP {
   unsigned drop_thresh16;  // the forward's probability dropout (0 = off): the mask is regenerated here
   float drop_inv_keep;
   unsigned long long drop_seed;
+  const float *emb_k, *emb_v;  // VAR_WINDOW
+  int window;
 };
 
 // keep-scale of element (b, h, i, j) of the attention probabilities: 1/(1-p) if kept, 0 if dropped (as the forward)
@@ -423,6 +446,10 @@ __device__ __forceinline__ void attn_ds_row(const AttnBwdP& p, int b, int h, int
   const uint64_t drow = (((uint64_t)b * p.H + h) * Tn + i) * (uint64_t)Tn;
   for (int j = lane; j < len; j += 64) {
     float dp = dot_row<T>(go, vb + (int64_t)j * p.ld, dk);  // d(dropped P)
+    if (p.variant == VAR_WINDOW) {
+      const int r = j - i + p.window;
+      if (r >= 0 && r <= 2 * p.window) dp += dot_f32(go, p.emb_v + (int64_t)r * dk, dk);
+    }
     if (p.drop_thresh16) dp *= attn_keep(p, drow + j);        // dP = mask/(1-p) * d(dropped P)
     ds[j] = dp;
     dsum += prow[j] * dp;
@@ -489,6 +516,11 @@ __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
           au += Elem<T>::ld4(kb + (int64_t)j * p.ld + dv) * ds[j];
           if (p.variant == VAR_NEW) av += Elem<T>::ld4(pb + (int64_t)(Tn - 1 - i + j) * p.ldpos + dv) * ds[j];
         }
+      if (p.variant == VAR_WINDOW && i < len && part == 0)
+        for (int r = 0; r <= 2 * p.window; ++r) {
+          const int j = i + r - p.window;
+          if (j >= 0 && j < len) av += *reinterpret_cast<const f32x4*>(p.emb_k + (int64_t)r * dk + dv) * ds[j];
+        }
       if (legacy) {
         if (i < len)
           for (int j = part; j <= i && j < len; j += parts) av += Elem<T>::ld4(pb + (int64_t)(Tn - 1 - i + j) * p.ldpos + dv) * ds[j];
@@ -507,7 +539,7 @@ __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
     su += au;
     sv += av;
   }
-  if (p.variant != VAR_PLAIN) {
+  if (has_uv(p.variant)) {
     if (lane < nvec) {
       *reinterpret_cast<f32x4*>(red + (w * 2 + 0) * dk + dv) = su;
       *reinterpret_cast<f32x4*>(red + (w * 2 + 1) * dk + dv) = sv;
@@ -517,6 +549,56 @@ __global__ __launch_bounds__(256) void attn_bwd_row_kernel(const AttnBwdP p) {
     for (int c = threadIdx.x; c < 2 * dk; c += 256) {
       const float v = red[c] + red[2 * dk + c] + red[4 * dk + c] + red[6 * dk + c];
       atomicAdd(rep + (c < dk ? hc + c : p.H * dk + hc + (c - dk)), v);  // [du (H*dk) | dvb (H*dk)]
+    }
+  }
+}
+
+// VAR_WINDOW: gradients of the two relative-position tables, summed over utterances, heads and query rows:
+//   demb_k[r] = sum dS[b,h,i,i+r-w] q[b,i,h]      demb_v[r] = sum P_dropped[b,h,i,i+r-w] dctx[b,i,h]
+// grid (2w + 1, H, batch groups); the 4 waves of a block split the rows, lanes = (row part) x (4-channel vector)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_win_emb_kernel(const AttnBwdP p, float* __restrict__ demb_k, float* __restrict__ demb_v) {
+  __shared__ f32x4 red[2][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = blockIdx.x, h = blockIdx.y;
+  const int nbg = gridDim.z, bper = (p.B + nbg - 1) / nbg;
+  const int b0 = blockIdx.z * bper, b1 = min(p.B, b0 + bper);
+  const int Tn = p.T, dk = p.dk, hc = h * dk;
+  const int nvec = dk >> 2, parts = 64 / nvec;
+  const int dv = (lane % nvec) * 4, part = lane / nvec;
+  f32x4 ak = f32x4{0.f, 0.f, 0.f, 0.f}, av = ak;
+  if (part < parts)
+    for (int b = b0; b < b1; ++b) {
+      const int len = p.lengths ? min(p.lengths[b], Tn) : Tn;
+      const T* qb = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + hc;
+      const T* gb = reinterpret_cast<const T*>(p.dctx) + (int64_t)b * Tn * p.lddctx + hc;
+      const int64_t base = ((int64_t)b * p.H + h) * Tn * Tn;
+      for (int i = w * parts + part; i < len; i += 4 * parts) {
+        const int j = i + r - p.window;
+        if (j < 0 || j >= len) continue;
+        const int64_t e = base + (int64_t)i * Tn + j;
+        float pv = p.probs[e];
+        if (p.drop_thresh16) pv *= attn_keep(p, (uint64_t)e);
+        ak += Elem<T>::ld4(qb + (int64_t)i * p.ld + dv) * p.dS[e];
+        av += Elem<T>::ld4(gb + (int64_t)i * p.lddctx + dv) * pv;
+      }
+    }
+  for (int o = nvec; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ak[e] += __shfl_xor(ak[e], o, 64);
+      av[e] += __shfl_xor(av[e], o, 64);
+    }
+  }
+  if (lane < nvec) { red[0][w][lane] = ak; red[1][w][lane] = av; }
+  __syncthreads();
+  if (w == 0 && lane < nvec) {
+    const f32x4 sk = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    const f32x4 sv = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(demb_k + (int64_t)r * dk + dv + e, sk[e]);
+      atomicAdd(demb_v + (int64_t)r * dk + dv + e, sv[e]);
     }
   }
 }
@@ -673,7 +755,7 @@ __global__ __launch_bounds__(256) void attn_bwd_col_kernel(const AttnBwdP p, voi
   f32x4 ak = f32x4{0.f, 0.f, 0.f, 0.f}, av = ak;
   if (j < len && part < parts) {
     f32x4 bu = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.variant != VAR_PLAIN) bu = *reinterpret_cast<const f32x4*>(p.bias_u + hc + dv);
+    if (has_uv(p.variant)) bu = *reinterpret_cast<const f32x4*>(p.bias_u + hc + dv);
     for (int i = part; i < len; i += parts) {
       const float dsv = dcol[(int64_t)i * Tn];
       float pv = pcol[(int64_t)i * Tn];
@@ -1229,5 +1311,64 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
 #undef ATTN_BWD
   if (variant != VAR_PLAIN) red_sum_launch(scratch, 2 * H * dk, du, H * dk, dvb, 1, st);
   PTPP_CHECK_LAUNCH("attention_bwd");
+  return PTPP_OK;
+}
+
+// ---- windowed relative-position attention (modules/transformer.py:59-137): the row kernels with VAR_WINDOW ----------------
+extern "C" int ptpp_attention_win_fwd(const void* q, const void* k, const void* v, const float* emb_k, const float* emb_v, void* ctx,
+                                      float* probs, const int32_t* lengths, int B, int T_, int H, int dk, int ld, int ldctx, int window,
+                                      float drop_p, uint64_t drop_seed, int dtype, void* stream) {
+  PTPP_CHECK_ARG(q && k && v && ctx && emb_k && emb_v, "attention_win_fwd: null pointer");
+  PTPP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "attention_win_fwd: bad dropout p");
+  PTPP_CHECK_ARG(shape_ok(B, T_, H, dk) && window >= 0 && window <= 64, "attention_win_fwd: unsupported shape B=%d T=%d H=%d dk=%d window=%d", B,
+                 T_, H, dk, window);
+  PTPP_CHECK_ARG(ld % 4 == 0 && ldctx % 4 == 0 && (((uintptr_t)emb_k | (uintptr_t)emb_v) & 15) == 0, "attention_win_fwd: strides / alignment");
+  AttnP p{q, k, v, nullptr, nullptr, nullptr, ctx, probs, lengths, B, T_, H, dk, ld, 0, ldctx, VAR_WINDOW, 1.0f / sqrtf((float)dk)};
+  p.drop_thresh16 = drop_p > 0.f ? (unsigned)(drop_p * 65536.f + 0.5f) : 0u;
+  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - p.drop_thresh16 / 65536.f) : 1.f;
+  p.drop_seed = drop_seed;
+  p.emb_k = emb_k; p.emb_v = emb_v; p.window = window;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t smem = (size_t)4 * (3 * dk + ((T_ + 3) & ~3)) * sizeof(float);
+  dim3 grid((T_ + 3) / 4, H, B);
+  if (dtype == PTPP_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), smem, st, p);
+  else if (dtype == PTPP_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_raw>, grid, dim3(256), smem, st, p);
+  else PTPP_CHECK_ARG(false, "attention_win_fwd: bad dtype");
+  PTPP_CHECK_LAUNCH("attention_win_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_attention_win_bwd(const void* q, const void* k, const void* v, const float* emb_k, const float* emb_v, const float* probs,
+                                      const void* dctx, float* dS, void* dq, void* dk_out, void* dv_out, float* demb_k, float* demb_v,
+                                      const int32_t* lengths, int B, int T_, int H, int dk, int ld, int lddctx, int lddq, int window,
+                                      float drop_p, uint64_t drop_seed, int dtype, void* stream) {
+  PTPP_CHECK_ARG(q && k && v && emb_k && emb_v && probs && dctx && dS && dq && dk_out && dv_out && demb_k && demb_v,
+                 "attention_win_bwd: null pointer");
+  PTPP_CHECK_ARG(shape_ok(B, T_, H, dk) && window >= 0 && window <= 64, "attention_win_bwd: unsupported shape");
+  PTPP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "attention_win_bwd: bad dropout p");
+  AttnBwdP p{q, k, v, nullptr, dctx, nullptr, nullptr, probs, dS, dq, nullptr, nullptr, nullptr, lengths,
+             B, T_, H, dk, ld, 0, lddctx, lddq, VAR_WINDOW, 1.0f / sqrtf((float)dk)};
+  p.drop_thresh16 = drop_p > 0.f ? (unsigned)(drop_p * 65536.f + 0.5f) : 0u;
+  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - p.drop_thresh16 / 65536.f) : 1.f;
+  p.drop_seed = drop_seed;
+  p.emb_k = emb_k; p.emb_v = emb_v; p.window = window;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nr = 2 * window + 1;
+  (void)hipMemsetAsync(demb_k, 0, (size_t)nr * dk * sizeof(float), st);
+  (void)hipMemsetAsync(demb_v, 0, (size_t)nr * dk * sizeof(float), st);
+  const int Tpad = (T_ + 3) & ~3;
+  const size_t smem = (size_t)(4 * (dk + Tpad) + 8 * dk) * sizeof(float);
+  dim3 grid((T_ + 3) / 4, H, B);
+  int nbg = (256 + nr * H - 1) / (nr * H);
+  if (nbg > B) nbg = B;
+#define ATTN_WIN_BWD(TT)                                                                                  \
+  hipLaunchKernelGGL(attn_bwd_row_kernel<TT>, grid, dim3(256), smem, st, p);                              \
+  hipLaunchKernelGGL(attn_bwd_col_kernel<TT>, grid, dim3(256), 0, st, p, dk_out, dv_out);                 \
+  hipLaunchKernelGGL(attn_bwd_win_emb_kernel<TT>, dim3(nr, H, nbg), dim3(256), 0, st, p, demb_k, demb_v);
+  if (dtype == PTPP_F32) { ATTN_WIN_BWD(float) }
+  else if (dtype == PTPP_BF16) { ATTN_WIN_BWD(bf16_raw) }
+  else PTPP_CHECK_ARG(false, "attention_win_bwd: bad dtype");
+#undef ATTN_WIN_BWD
+  PTPP_CHECK_LAUNCH("attention_win_bwd");
   return PTPP_OK;
 }

@@ -776,6 +776,39 @@ class AttentionFn(Function):
         return dqkv, dpos, du, dvb, None, None, None, None
 
 
+class AttentionWinFn(Function):
+    """Windowed relative-position MHA core (reference modules/transformer.py:59-137) on a fused (B, T, 3C) q|k|v projection."""
+
+    @staticmethod
+    def forward(ctx, qkv, emb_k, emb_v, lengths, heads, window, drop_p=0.0):
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        ek, ev = _f32c(emb_k), _f32c(emb_v)
+        need_bwd = any(ctx.needs_input_grad)
+        seed = next_seed() if drop_p > 0 else 0
+        octx, probs = ops.attention_win_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], ek, ev, lengths, heads, window,
+                                            save_probs=need_bwd, drop_p=drop_p, drop_seed=seed)
+        ctx.heads, ctx.window, ctx.lengths, ctx.drop = heads, window, lengths, (drop_p, seed)
+        ctx.save_for_backward(qkv, ek, ev, probs)
+        return octx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dctx):
+        qkv, ek, ev, probs = ctx.saved_tensors
+        C = qkv.shape[2] // 3
+        dqkv = torch.empty_like(qkv)
+        dek, dev_ = ops.attention_win_bwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], ek, ev, probs, dctx, ctx.lengths, ctx.heads,
+                                          ctx.window, dqkv[:, :, :C], dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:], drop_p=ctx.drop[0],
+                                          drop_seed=ctx.drop[1])
+        return dqkv, dek, dev_, None, None, None, None
+
+
+def attention_window(qkv, emb_k, emb_v, lengths, heads, window, drop_p=0.0):
+    """emb_k / emb_v: (2 * window + 1, C / heads) relative-position tables (shared by the heads)."""
+    return AttentionWinFn.apply(qkv, emb_k, emb_v, lengths, heads, window, drop_p)
+
+
 def attention(qkv, pos, bias_u, bias_v, lengths, heads, variant, drop_p=0.0):
     """``drop_p``: dropout on the attention probabilities (the plain / BERT variant in train mode)."""
     return AttentionFn.apply(qkv, pos, bias_u, bias_v, lengths, heads, variant, drop_p)

@@ -6,8 +6,8 @@ package's kernels, channels-last: the fused q|k|v projection and the output proj
 plain multi-head attention core incl. probability dropout (``ptpp_attention_fwd/bwd``, PLAIN variant), the
 k-tap / 1x1 feed-forward convolutions with ReLU, masks and dropout fused, and the residual + dropout + LayerNorm of
 every sub-layer (``ptpp_layernorm_fwd/bwd``).  The windowed relative-position attention core (``use_rel=True``,
-Shaw et al. window of +-4) is torch tensor algebra on the device around those projections: its band gathers have no
-kernel of their own yet.
+Shaw et al. window of +-4) is one launch forward and three backward since round 4 (``ptpp_attention_win_fwd/bwd``: the row
+kernels with the band terms as index arithmetic); the tensor-op form it replaced stays as the test's second opinion.
 
 Masking note: the reference fills masked scores with -1e4 (not -inf), which gives PADDED query rows a uniform
 attention over all positions; every layer ends in ``x * mask`` and every convolution reads ``x * mask``, so padded
@@ -79,7 +79,22 @@ class RelativeMultiHeadAttention(nn.Module):
         nn.init.xavier_uniform_(self.conv_k.weight)
         nn.init.xavier_uniform_(self.conv_v.weight)
 
+    WINDOW_KERNEL = not __import__("os").environ.get("PTPP_NO_WINDOW_ATTN_KERNEL")  # (tests compare with the tensor-op form)
+
     def forward_cl(self, x, lengths):
+        B, T, C = x.shape
+        H, D, w = self.n_heads, self.inter_channels, self.window_size
+        if self.WINDOW_KERNEL and x.is_cuda and D in (64, 128, 256) and T <= 2048:
+            # the core as one launch (ptpp_attention_win_fwd / _bwd): band terms as index arithmetic, softmax in registers;
+            # padded query rows come out zero (the tensor-op form below gives them a uniform attention that the layer's
+            # mask removes: identical layer outputs)
+            qkv = PF.linear_fused(x, [self.conv_q, self.conv_k, self.conv_v]).contiguous()
+            ctx = PF.attention_window(qkv, self.emb_rel_k[0], self.emb_rel_v[0], lengths, H, w,
+                                      drop_p=float(self.drop.p) if self.training else 0.0)
+            return PF.conv1d(ctx, self.conv_o.weight, self.conv_o.bias)
+        return self._forward_cl_tensor_ops(x, lengths)
+
+    def _forward_cl_tensor_ops(self, x, lengths):
         B, T, C = x.shape
         H, D, w = self.n_heads, self.inter_channels, self.window_size
         qkv = PF.linear_fused(x, [self.conv_q, self.conv_k, self.conv_v]).float()

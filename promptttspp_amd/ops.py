@@ -508,6 +508,41 @@ def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, var
     return dpos, du, dvb
 
 
+def attention_win_fwd(q, k, v, emb_k, emb_v, lengths, heads, window, save_probs=False, drop_p=0.0, drop_seed=0):
+    """Windowed relative-position attention core (ptpp_attention_win_fwd; reference modules/transformer.py:59-137): q, k, v
+    (B,T,C) views with a common row stride, emb_k / emb_v (2w+1, C/heads) f32 -> (ctx (B,T,C), probs)."""
+    _need_gpu(q)
+    B, T, C = q.shape
+    assert _ld(k) == _ld(q) == _ld(v)
+    dk = C // heads
+    assert emb_k.shape == emb_v.shape == (2 * window + 1, dk) and emb_k.dtype == emb_v.dtype == torch.float32
+    assert emb_k.is_contiguous() and emb_v.is_contiguous()
+    ctx = torch.empty((B, T, C), device=q.device, dtype=q.dtype)
+    probs = torch.empty((B, heads, T, T), device=q.device, dtype=torch.float32) if save_probs else None
+    lengths = i32(lengths, q.device)
+    check(_lib.load().ptpp_attention_win_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(emb_k), _ptr(emb_v), _ptr(ctx), _ptr(probs), _ptr(lengths), B, T,
+                                             heads, dk, _ld(q), C, int(window), float(drop_p), int(drop_seed), dtype_code(q.dtype),
+                                             _stream()), "ptpp_attention_win_fwd")
+    return ctx, probs
+
+
+def attention_win_bwd(q, k, v, emb_k, emb_v, probs, dctx, lengths, heads, window, dq, dk_, dv, drop_p=0.0, drop_seed=0):
+    """Backward of ``attention_win_fwd``: fills the preallocated dq / dk_ / dv views, returns (demb_k, demb_v) f32."""
+    _need_gpu(q)
+    B, T, C = q.shape
+    dkh = C // heads
+    dctx = dctx.contiguous()
+    dS = torch.empty((B, heads, T, T), device=q.device, dtype=torch.float32)
+    dek = torch.empty((2 * window + 1, dkh), device=q.device, dtype=torch.float32)
+    dev_ = torch.empty_like(dek)
+    lengths = i32(lengths, q.device)
+    check(_lib.load().ptpp_attention_win_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(emb_k), _ptr(emb_v), _ptr(probs), _ptr(dctx), _ptr(dS), _ptr(dq),
+                                             _ptr(dk_), _ptr(dv), _ptr(dek), _ptr(dev_), _ptr(lengths), B, T, heads, dkh, _ld(q), C, _ld(dq),
+                                             int(window), float(drop_p), int(drop_seed), dtype_code(q.dtype), _stream()),
+          "ptpp_attention_win_bwd")
+    return dek, dev_
+
+
 # ----------------------------------------------------------------------------
 # length regulator, positional encoding, DiffNet glue
 # ----------------------------------------------------------------------------

