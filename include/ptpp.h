@@ -372,6 +372,31 @@ int ptpp_ddpm_step_lp(const float* x, const void* eps, const float* noise, const
                       const float* sra, const float* srm1, const float* c1, const float* c2,
                       const float* logvar, float* out, void* out_lp, int B, int64_t per_b, int eps_dtype,
                       void* stream);
+/* Everything between two DiffNet stacks of the reverse-diffusion loop in ONE launch (bf16, C = 256, M % 16 == 0, M <= 128;
+ * csrc/sampler_head.hip): skip projection + ReLU + output projection (modules/denoiser.py:147-152) -> eps, the reverse step
+ * (modules/diffusion.py:283-302, as ptpp_ddpm_step) -> x_out, and -- when win_p is given -- the NEXT step's input projection
+ * + ReLU (denoiser.py:131) -> h0 and its first layer's input yin0 = h0 + ds0[b] (denoiser.py:76).  Same operand order and bf16
+ * rounding points as the seven launches it replaces; the update is the reference's unfused f32 sequence (ptpp_ddpm_step: equal). */
+typedef struct {
+  const void* s;            /* (B*T, C) bf16: skip sum / sqrt(L) (ptpp_diffnet_stack_fwd: skip_scaled)            */
+  const void* ws_p;         /* skip projection C -> C, mode-0 operand (C, 1, C) bf16                             */
+  const float* ws_b;        /* (C)                                                                               */
+  const void* wo_p;         /* output projection C -> M, mode-0 operand (M, 1, C)                                */
+  const float* wo_b;        /* (M)                                                                               */
+  const float* x;           /* (B*T, M) f32: x_t                                                                 */
+  const float* noise;       /* (B*T, M) f32 or NULL (t == 0)                                                     */
+  const int64_t* t;         /* (B) step indices on the device                                                    */
+  const float *sra, *srm1, *c1, *c2, *logvar; /* the schedule tables of ptpp_ddpm_step                           */
+  float* x_out;             /* (B*T, M) f32: x_{t-1}                                                             */
+  const void* win_p;        /* input projection M -> C, mode-0 operand (C, 1, M padded to 32), or NULL           */
+  const float* win_b;       /* (C)                                                                               */
+  const float* ds0;         /* (B, C) f32: layer 0's step projection at the NEXT step                            */
+  void* h0;                 /* (B*T, C) bf16 out                                                                 */
+  void* yin0;               /* (B*T, C) bf16 out                                                                 */
+  int32_t B, T, C, M, dtype;
+} ptpp_sampler_head_args;
+int ptpp_sampler_head_supported(int C, int M, int dtype);
+int ptpp_sampler_head(const ptpp_sampler_head_args* a, void* stream);
 /* Backward of the same layer: dg = conv1x1(a->x = do, a->wp = W_out^T) (a->Cout = C, never stored) with
  * ptpp_gate_bwd in its epilogue -- da (row stride ldda >= 2C) from the saved pre-activation act (B, T, 2C).
  * Bit-identical to ptpp_conv1d_fwd followed by ptpp_gate_bwd.  _supported: bf16, C % 8 == 0, Cin % 64 == 0. */
@@ -672,6 +697,8 @@ typedef struct {
   const void* condx;        /* NULL, or the conditioner input (B, T, 256) dtype, row stride ldcx: every layer projects it     */
   int32_t ldcx;             /* inside its launch (ptpp_diffnet_layer_args.condx) -- cond_all may then be NULL, `wstream` is   */
                             /* the _cond form and dil_b[l] the summed biases; needs the one-launch layer                      */
+  const void* yin0;         /* NULL, or layer 0's input h0 + dsteps[0] (B, T, C) already formed (ptpp_sampler_head): the      */
+                            /* driver then skips that launch                                                                  */
 } ptpp_diffnet_stack_fwd_args;
 int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream);
 

@@ -70,7 +70,16 @@ class DiffNetFwdArgs(Structure):
     _fields_ = [(n, c_void_p) for n in ("h0", "cond_all", "dsteps", "lengths", "skip", "dil_wp", "dil_b", "out_wp", "out_b",
                                         "yin_all", "a_all", "g_all", "x_buf0", "x_buf1", "o_buf")] + \
                [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "n_slabs", "fused_gate", "dtype")] + \
-               [("wstream", c_void_p), ("skip_scaled", c_void_p), ("skip_scale", c_float), ("condx", c_void_p), ("ldcx", c_int32)]
+               [("wstream", c_void_p), ("skip_scaled", c_void_p), ("skip_scale", c_float), ("condx", c_void_p), ("ldcx", c_int32),
+                ("yin0", c_void_p)]
+
+
+class SamplerHeadArgs(Structure):
+    """Mirror of ``ptpp_sampler_head_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("s", "ws_p", "ws_b", "wo_p", "wo_b", "x", "noise", "t", "sra", "srm1", "c1", "c2", "logvar", "x_out",
+                                        "win_p", "win_b", "ds0", "h0", "yin0")] + \
+               [(n, c_int32) for n in ("B", "T", "C", "M", "dtype")]
 
 
 class DiffNetLayerArgs(Structure):
@@ -229,6 +238,8 @@ SIGNATURES = {
     "ptpp_conv1d_diffnet_post": (I, [POINTER(ConvArgs), P, P, P, P, P, I, P]),
     "ptpp_ddpm_step": (I, [P] * 10 + [I, I64, I, P]),
     "ptpp_ddpm_step_lp": (I, [P] * 11 + [I, I64, I, P]),
+    "ptpp_sampler_head_supported": (I, [I, I, I]),
+    "ptpp_sampler_head": (I, [POINTER(SamplerHeadArgs), P]),
     "ptpp_mdn_nll_fwd": (I, [P] * 6 + [I64, I, I, F, F, P]),
     "ptpp_mdn_nll_bwd": (I, [P] * 10 + [I64, I, I, F, F, P]),
     "ptpp_conv1d_gate_bwd_supported": (I, [I, I, I]),

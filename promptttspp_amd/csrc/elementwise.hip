@@ -141,12 +141,7 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const T* __restric
     if (noise) nv = *reinterpret_cast<const f32x4*>(noise + i * 4);
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x0 = __fsub_rn(__fmul_rn(a, xv[e]), __fmul_rn(bq, ev[e]));
-      x0 = fminf(fmaxf(x0, -1.f), 1.f);
-      const float mean = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xv[e]));
-      o[e] = __fadd_rn(mean, __fmul_rn(sg, nv[e]));
-    }
+    for (int e = 0; e < 4; ++e) o[e] = ddpm_update(a, bq, k1, k2, sg, xv[e], ev[e], nv[e]);
     *reinterpret_cast<f32x4*>(out + i * 4) = o;
     if (out_lp) Elem<T>::st4(out_lp + i * 4, o);  // the denoiser's input of the next step (x cast to the compute dtype)
   }

@@ -214,6 +214,17 @@ inline bool red_scratch_ok(const void* scratch, size_t bytes, int KC) {
   return scratch && bytes >= (size_t)PTPP_RED_NREP * KC * sizeof(float);
 }
 
+// One element of the reverse-diffusion update (modules/diffusion.py:283-302: predict_start_from_noise, clamp, q_posterior mean,
+// + sigma * noise) as the reference's UNFUSED f32 operation sequence -- shared by ptpp_ddpm_step and ptpp_sampler_head so that
+// both give the same bits (left to the optimiser, the two kernels contracted different multiply-add pairs).
+__device__ __forceinline__ float ddpm_update(float ca, float cb, float k1, float k2, float sg, float xv, float ev, float nv) {
+#pragma clang fp contract(off)
+  float x0 = ca * xv - cb * ev;
+  x0 = fminf(fmaxf(x0, -1.f), 1.f);
+  const float mean = k1 * x0 + k2 * xv;
+  return mean + sg * nv;
+}
+
 // XCD-aware block remap: hardware places block b on XCD b % 8; give each XCD a
 // contiguous range of logical tiles so neighbours share L2 (bijective for any n).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -73,7 +73,7 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
   const int masked = a->lengths != nullptr;
 
   // yin_0 = h0 + dsteps[0]  (x = h0 itself)
-  ST_TRY(ptpp_diffnet_post_fwd(nullptr, a->h0, nullptr, a->dsteps, nullptr, at(a->yin_all, 0, dt), B, T, C, 1, dt, stream));
+  if (!a->yin0) ST_TRY(ptpp_diffnet_post_fwd(nullptr, a->h0, nullptr, a->dsteps, nullptr, at(a->yin_all, 0, dt), B, T, C, 1, dt, stream));
   const void* x = a->h0;
   // the whole layer as one launch (csrc/diffnet_layer.hip) where the fused gate is on and the operand stream was handed over
   const bool one_launch = a->wstream && a->fused_gate && ptpp_diffnet_layer_supported(C, dt) && (1 << ((L - 1) % a->cycle)) <= 8 && a->cycle <= 4;
@@ -83,7 +83,7 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
   for (int l = 0; l < L; ++l) {
     const int d = 1 << (l % a->cycle);
     const int slab = l % a->n_slabs;
-    const void* yin = at(a->yin_all, slab * BTC, dt);
+    const void* yin = (l == 0 && a->yin0) ? a->yin0 : at(a->yin_all, slab * BTC, dt);
     void* g = at(a->g_all, slab * BTC, dt);
     const void* cond = a->cond_all ? at(a->cond_all, (size_t)l * 2 * C, dt) : nullptr;
     if (one_launch) {

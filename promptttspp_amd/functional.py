@@ -964,7 +964,7 @@ def diffnet_wstream(weights, dil_wp, out_wp, dt, cond_ws=None):
 
 
 def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None, scaled=False, condx=None,
-                                  cond_ws=None):
+                                  cond_ws=None, yin0=None):
     """The whole residual stack in ONE C call (ptpp_diffnet_stack_fwd): the same launches in the same order as the loop
     of ``diffnet_stack_forward`` below (bit-identical), without ~60 Python -> C round trips and ~80 allocations.
     Returns (skip f32, (yin_all, a_all, g_all) slabs of all layers when ``save``); with ``scaled`` the first item is
@@ -1014,6 +1014,9 @@ def _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle,
     if condx is not None:  # the layers project the conditioner input themselves (gate_b = dilated-conv + conditioner biases)
         assert wstream is not None and condx.stride(2) == 1 and condx.shape[2] == 256 and condx.dtype == dt
         a.condx, a.ldcx = condx.data_ptr(), condx.stride(1)
+    if yin0 is not None:  # layer 0's input already formed (ops.sampler_head)
+        assert yin0.is_contiguous() and yin0.shape == h0.shape and yin0.dtype == dt
+        a.yin0 = yin0.data_ptr()
     sc = None
     if scaled and wstream is not None:
         sc = torch.empty((B, T, C), device=dev, dtype=dt)
@@ -1033,12 +1036,13 @@ def diffnet_fold_cond_ok(h0, cond, cycle):
             and diffnet_gate_save(h0.dtype, h0.shape[2], True) and ops.diffnet_layer_supported(h0.shape[2], h0.dtype))
 
 
-def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None, scaled=False):
+def diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b=None, scaled=False, yin0=None):
     """weights: per layer (dil_w, dil_b, out_w, out_b).  Returns (skip_sum f32, saved).  ``gate_b``: the per-layer dilated-conv
     biases in the gate-interleaved order (``gate_biases``) -- training with the gate fused into the conv and the
     pre-activation kept; ``cond_all`` is in that order too.  ``scaled``: return (skip_sum / sqrt(L)).to(dtype) instead."""
     if STACK_DRIVERS and h0.is_cuda and h0.is_contiguous() and cond_all.is_contiguous():
-        return _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b, scaled)
+        return _diffnet_stack_forward_driver(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b, scaled, yin0=yin0)
+    assert yin0 is None, "a precomputed first-layer input is a feature of the one-call driver"
     if scaled:
         skip, saved = diffnet_stack_forward(h0, cond_all, dsteps, weights, lengths, cycle, save, gate_b)
         return (skip * (1.0 / math.sqrt(len(weights)))).to(h0.dtype), saved

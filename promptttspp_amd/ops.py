@@ -790,6 +790,35 @@ def ddpm_step(x, eps, noise, t, sra, srm1, c1, c2, logvar, want_lp=False):
     return (out, lp) if want_lp else out
 
 
+def sampler_head_supported(C, M, dtype):
+    return bool(_lib.load().ptpp_sampler_head_supported(int(C), int(M), dtype_code(dtype)))
+
+
+def sampler_head(s, ws_p, ws_b, wo_p, wo_b, x, noise, t, sra, srm1, c1, c2, logvar, win_p=None, win_b=None, ds0=None):
+    """Everything between two DiffNet stacks of the reverse loop in one launch (ptpp_sampler_head; reference
+    modules/denoiser.py:147-152 + modules/diffusion.py:283-302 + denoiser.py:131,76): s (B,T,C) bf16 = skip / sqrt(L) ->
+    (x_{t-1} (B,T,M) f32, h0, yin0 (B,T,C) bf16 of the next step or None, None without ``win_p``)."""
+    _need_gpu(s)
+    B, T, C = s.shape
+    M = x.shape[2]
+    assert s.is_contiguous() and x.is_contiguous() and x.dtype == torch.float32 and x.shape[:2] == (B, T)
+    assert noise is None or (noise.is_contiguous() and noise.dtype == torch.float32 and noise.shape == x.shape)
+    assert t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B
+    x_out = torch.empty_like(x)
+    a = _lib.SamplerHeadArgs()
+    a.s, a.ws_p, a.ws_b, a.wo_p, a.wo_b = s.data_ptr(), ws_p.data_ptr(), ws_b.data_ptr(), wo_p.data_ptr(), wo_b.data_ptr()
+    a.x, a.noise, a.t, a.x_out = x.data_ptr(), noise.data_ptr() if noise is not None else None, t.data_ptr(), x_out.data_ptr()
+    a.sra, a.srm1, a.c1, a.c2, a.logvar = sra.data_ptr(), srm1.data_ptr(), c1.data_ptr(), c2.data_ptr(), logvar.data_ptr()
+    h0 = yin0 = None
+    if win_p is not None:
+        assert ds0.is_contiguous() and ds0.dtype == torch.float32 and ds0.shape == (B, C)
+        h0, yin0 = torch.empty_like(s), torch.empty_like(s)
+        a.win_p, a.win_b, a.ds0, a.h0, a.yin0 = win_p.data_ptr(), win_b.data_ptr(), ds0.data_ptr(), h0.data_ptr(), yin0.data_ptr()
+    a.B, a.T, a.C, a.M, a.dtype = B, T, C, M, dtype_code(s.dtype)
+    check(_lib.load().ptpp_sampler_head(ctypes.byref(a), _stream()), "ptpp_sampler_head")
+    return x_out, h0, yin0
+
+
 def diffnet_post_bwd(gx, gskip, lengths):
     B, T, C = gx.shape
     dout = torch.empty((B, T, 2 * C), device=gx.device, dtype=gx.dtype)

@@ -970,6 +970,36 @@ def test_sampler_fused_gate_and_graph_consistency(dev):
     assert rel_err(outs["fused+graph"], outs["fused"]) < 1e-6   # the graph replays the same kernels
 
 
+@pytest.mark.parametrize("B,T", [(3, 90), (5, 333), (2, 64)])
+def test_sampler_loop_with_the_fused_head_matches_the_plain_loop(dev, B, T):
+    """The eager reverse loop with everything between two DiffNet stacks as ONE launch (ops.sampler_head: skip / output
+    projections, the reverse update, the next step's input projection and first-layer input; GaussianDiffusion._inference_fused)
+    against the plain loop's seven launches on the same injected noise, row counts that are / are not multiples of the 64-row
+    tile.  Same operand order and rounding points; the conv kernels feed the MFMA's K slots in another order, so about one eps
+    element in 10^4 per step rounds to the other bf16 neighbour (tests/test_hip_kernels.py::test_sampler_head_kernel) -- after
+    100 steps the mels agree like two bf16 runs do, and are equal bit for bit when no such flip happens."""
+    from promptttspp_amd import config
+    from promptttspp_amd.modules.diffusion import GaussianDiffusion
+
+    g = load_golden("diffusion")
+    m, _ = load(node("decoder"), key_shapes(g["keys"]), 90, dev)
+    m.eval()
+    cond = rnd(5, B, T, 256).to(dev)
+    noise_fn = lambda i, s: rnd(3000 + i, *s).to(dev)  # noqa: E731
+    outs = {}
+    with config.use_dtype(torch.bfloat16), torch.no_grad():
+        m.use_graph = False  # (small shapes would replay a graph: this test is about the eager loop)
+        for fused in (False, True):
+            GaussianDiffusion.FUSED_LOOP = fused
+            try:
+                assert m._fused_loop_ok(cond.bfloat16()) == (False)  # the step-projection table exists only inside inference_cl
+                outs[fused] = m.inference_cl(cond.bfloat16(), noise_fn).float().cpu()
+            finally:
+                GaussianDiffusion.FUSED_LOOP = True
+    assert torch.isfinite(outs[True]).all() and float(outs[True].abs().max()) > 0
+    assert rel_err(outs[True], outs[False]) < 1e-2, rel_err(outs[True], outs[False])
+
+
 def test_sampler_split_over_two_streams_is_bit_identical(dev):
     """Large batches: the two halves of the batch run their reverse loops on two streams (GaussianDiffusion._inference_split);
     per utterance the arithmetic is that of the unsplit loop, so the mel is equal bit for bit (bf16 and f32, odd batch)."""

@@ -967,3 +967,47 @@ def test_windowed_relative_attention_kernel(dev, dtype, B, T, H, dk, w):
         err = float((a - b).abs().max() / max(float(a.abs().max()), 1e-3 * gscale))
         assert err < tol, (n, err)
     assert float(ref[0].abs().max()) > 0 and float(ref[names.index("emb_rel_k")].abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,T,last", [(2, 64, False), (3, 90, False), (32, 546, False), (1, 37, True)])
+def test_sampler_head_kernel(dev, B, T, last):
+    """ptpp_sampler_head (skip projection + ReLU + output projection, the reverse-diffusion update, the next step's input
+    projection + first-layer input; reference modules/denoiser.py:147-152,131,76 and modules/diffusion.py:283-302) against the
+    seven launches it replaces.  The update itself is the reference's unfused f32 sequence in both (equal to the torch ops bit
+    for bit); eps may differ by one bf16 ulp in isolated elements (the conv kernel and this one feed the MFMA's K slots in a
+    different order), which moves x by at most sqrt(1/abar - 1) ulp_bf16(eps) there and nothing elsewhere."""
+    from promptttspp_amd import ops
+
+    C, M, dt = 256, 80, torch.bfloat16
+    r = lambda seed, *s, sc=1.0: (rnd(seed, *s) * sc).to(dev)
+    s = r(1, B, T, C, sc=0.5).bfloat16()
+    ws, bs, wo, bo = r(2, C, C, 1, sc=0.06), r(3, C, sc=0.1), r(4, M, C, 1, sc=0.06), r(5, M, sc=0.1)
+    wi, bi = r(6, C, M, 1, sc=0.1), r(7, C, sc=0.1)
+    x, noise, ds0 = r(8, B, T, M), r(9, B, T, M), r(10, B, C)
+    t = torch.randint(0, 100, (B,), generator=torch.Generator().manual_seed(3)).to(dev)
+    tabs = [(rnd(20 + i, 100).abs() + 0.5).to(dev) for i in range(4)] + [(-rnd(24, 100).abs()).to(dev)]
+    wsp, wop, wip = (ops.pack_conv_weight(w_, dt) for w_ in (ws, wo, wi))
+    h = ops.conv1d(s, wsp, bs, C, act="relu")
+    eps = ops.conv1d(h, wop, bo, M)
+    x1 = ops.ddpm_step(x, eps.contiguous(), None if last else noise, t, *tabs)
+    # the update kernel against the reference's torch sequence: bit for bit
+    tb = t[:, None, None]
+    x0 = (tabs[0][tb] * x - tabs[1][tb] * eps.float()).clamp(-1, 1)
+    ref = (tabs[2][tb] * x0 + tabs[3][tb] * x) + (0 if last else torch.exp(0.5 * tabs[4][tb]) * noise)
+    assert torch.equal(x1, ref)
+    if last:
+        gx, gh0, gy = ops.sampler_head(s, wsp, bs, wop, bo, x, None, t, *tabs)
+        assert gh0 is None and gy is None
+    else:
+        h0 = ops.conv1d(x1.to(dt), wip, bi, C, act="relu")
+        _, yin0 = ops.diffnet_post_fwd(None, h0, None, ds0, init=True)
+        gx, gh0, gy = ops.sampler_head(s, wsp, bs, wop, bo, x, noise, t, *tabs, win_p=wip, win_b=bi, ds0=ds0)
+    torch.cuda.synchronize()
+    differ = gx != x1
+    assert float(differ.float().mean()) < 1e-3, float(differ.float().mean())
+    bound = float(tabs[1].max()) * 2.0 ** -7 * float(eps.float().abs().max())  # |coef| x one bf16 ulp of the largest eps
+    assert float((gx - x1).abs().max()) <= bound
+    if not last:
+        for a, b in ((gh0, h0), (gy, yin0)):
+            d = (a.float() - b.float()).abs()
+            assert float((d > 0).float().mean()) < 1e-3 and float(d.max()) <= 2.0 ** -6 * float(b.float().abs().max())
