@@ -372,7 +372,7 @@ int ptpp_ddpm_step_lp(const float* x, const void* eps, const float* noise, const
                       const float* sra, const float* srm1, const float* c1, const float* c2,
                       const float* logvar, float* out, void* out_lp, int B, int64_t per_b, int eps_dtype,
                       void* stream);
-/* Everything between two DiffNet stacks of the reverse-diffusion loop in ONE launch (bf16, C = 256, M % 16 == 0, M <= 128;
+/* Everything between two DiffNet stacks of the reverse-diffusion loop in ONE launch (bf16, C = 256, M % 16 == 0, M <= 96;
  * csrc/sampler_head.hip): skip projection + ReLU + output projection (modules/denoiser.py:147-152) -> eps, the reverse step
  * (modules/diffusion.py:283-302, as ptpp_ddpm_step) -> x_out, and -- when win_p is given -- the NEXT step's input projection
  * + ReLU (denoiser.py:131) -> h0 and its first layer's input yin0 = h0 + ds0[b] (denoiser.py:76).  Same operand order and bf16

@@ -1,5 +1,5 @@
 // Everything between two DiffNet stacks of the reverse-diffusion loop, as ONE launch (bf16, 256 residual channels, mel
-// dimension a multiple of 16 up to 128):
+// dimension a multiple of 16 up to 96):
 //   h     = relu(W_s s + b_s)                    skip projection          modules/denoiser.py:147-150
 //   eps   = W_o h + b_o                          output projection        modules/denoiser.py:151-152
 //   x'    = mean(x, clamp(x0(x, eps))) + sigma_t * noise                  modules/diffusion.py:283-302  (ptpp_ddpm_step)
@@ -228,14 +228,14 @@ __global__ __launch_bounds__(256, 2) void sampler_head_kernel(const ShP p) {
 }  // namespace
 
 extern "C" int ptpp_sampler_head_supported(int C, int M, int dtype) {
-  return dtype == PTPP_BF16 && C == SH_C && M > 0 && M % 16 == 0 && M <= 128;
+  return dtype == PTPP_BF16 && C == SH_C && M > 0 && M % 16 == 0 && M <= 96;  // (wider mels: the W_o prefetch spills)
 }
 
 extern "C" int ptpp_sampler_head(const ptpp_sampler_head_args* a, void* stream) {
   PTPP_CHECK_ARG(a && a->s && a->ws_p && a->ws_b && a->wo_p && a->wo_b && a->x && a->t && a->sra && a->srm1 && a->c1 && a->c2 &&
                      a->logvar && a->x_out,
                  "sampler_head: null pointer");
-  PTPP_CHECK_ARG(ptpp_sampler_head_supported(a->C, a->M, a->dtype), "sampler_head: bf16, C = 256, M %% 16 == 0, M <= 128 (C %d M %d dtype %d)",
+  PTPP_CHECK_ARG(ptpp_sampler_head_supported(a->C, a->M, a->dtype), "sampler_head: bf16, C = 256, M %% 16 == 0, M <= 96 (C %d M %d dtype %d)",
                  a->C, a->M, a->dtype);
   PTPP_CHECK_ARG(a->B > 0 && a->T > 0, "sampler_head: bad shape");
   PTPP_CHECK_ARG(!a->win_p || (a->win_b && a->ds0 && a->h0 && a->yin0), "sampler_head: the next step's outputs need win_b, ds0, h0, yin0");
@@ -261,9 +261,7 @@ extern "C" int ptpp_sampler_head(const ptpp_sampler_head_args* a, void* stream) 
     case 3: hipLaunchKernelGGL(sampler_head_kernel<3>, grid, blk, 0, st, p); break;
     case 4: hipLaunchKernelGGL(sampler_head_kernel<4>, grid, blk, 0, st, p); break;
     case 5: hipLaunchKernelGGL(sampler_head_kernel<5>, grid, blk, 0, st, p); break;
-    case 6: hipLaunchKernelGGL(sampler_head_kernel<6>, grid, blk, 0, st, p); break;
-    case 7: hipLaunchKernelGGL(sampler_head_kernel<7>, grid, blk, 0, st, p); break;
-    default: hipLaunchKernelGGL(sampler_head_kernel<8>, grid, blk, 0, st, p); break;
+    default: hipLaunchKernelGGL(sampler_head_kernel<6>, grid, blk, 0, st, p); break;
   }
   PTPP_CHECK_LAUNCH("sampler_head");
   return PTPP_OK;
