@@ -1061,6 +1061,41 @@ def test_model_forward_bench_size_properties(dev):
         assert abs(a[k] - b2[k]) <= 2e-5 * max(1.0, abs(a[k])), (k, a[k], b2[k])
 
 
+def test_train_mode_forward_is_bit_reproducible_at_bench_size(dev, monkeypatch):
+    """bf16, TRAIN mode (BatchNorm batch statistics of the Conformer conv modules and the reference encoder, dropout from the
+    counter-based generator with a fixed seed): five forwards of one BASELINE-sized batch give the same five losses bit for bit.
+    Round 3 summed the statistics' block totals into 32 replicas by f32 atomics in arrival order and repeated runs fell into
+    two classes (2.7e-3 apart in the style embedding); with PTPP_BN_DET=1 every replica has one writer (csrc/bn_dw.hip
+    det_grid: opt-in, it costs 1.6 ms per training step)."""
+    import sys
+
+    monkeypatch.setenv("PTPP_BN_DET", "1")
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from promptttspp_amd import config
+    from promptttspp_amd import functional as PF
+
+    torch.manual_seed(0)
+    with config.use_dtype(torch.bfloat16):
+        model = bench.build_model(dev).train()
+        batch = bench.make_batches(0, 1, 1, 30000, dev)[0]
+        B, Tf = batch[3].shape[0], batch[3].shape[2]
+        g = torch.Generator().manual_seed(5)
+        inj = {"t": torch.randint(0, 100, (B,), generator=g), "noise": torch.randn(B, 80, Tf, generator=g)}
+        runs = []
+        for _ in range(5):
+            model.decoder.injected = dict(inj)
+            PF.manual_seed(123)
+            with torch.no_grad():
+                out = model(batch)
+            torch.cuda.synchronize()
+            runs.append({k: float(v) for k, v in out.items()})
+    assert all(np.isfinite(v) for v in runs[0].values())
+    for r in runs[1:]:
+        assert r == runs[0], (r, runs[0])
+
+
 def _confdec_model(dev):
     """PromptTTSMDNDurCFG with the non-diffusion decoder branch (reference model.py:123-126): the final
     config with ``decoder`` = a 2-block ConformerEncoder and ``out_conv`` = Conv1d(256, 80, 1), weights
