@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preheat", type=int, default=60,
+                    help="untimed steps on the warm-up batches BEFORE the W warm-up steps (a count, so that every rank runs the same "
+                         "collectives): a box that comes out of idle needs ~1 s of load to reach its steady clocks (the first bench "
+                         "process on a fresh box measured 3-10 %% slow in 2 of 6 trials, a second one never)")
     ap.add_argument("--max-tokens", type=int, default=30000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-vocoder", action="store_true")
@@ -743,6 +747,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.preheat > 0 and a.warmup > 0 and not os.environ.get("PTPP_BENCH_SELFTEST"):  # setup, not measurement: the same steps as the warm-up, until the clocks have settled
+        tp = time.perf_counter()
+        for k in range(a.preheat):
+            train_step(model, batches[k % a.warmup], red, opt, sched)
+        torch.cuda.synchronize()
+        log(f"preheat: {a.preheat} untimed steps in {time.perf_counter() - tp:.2f} s")
     for i in range(a.warmup):
         train_step(model, batches[i], red, opt, sched)
         torch.cuda.synchronize()
@@ -838,7 +848,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "train.py model=prompttts_mdn_v2_wo_erg_final, dataset.max_tokens=%d per GPU, synthetic "
                                    "LibriTTS-R-shaped utterances, fwd+bwd+clip+AdamW+Noam, train mode (dropout on)" % a.max_tokens,
-                       "utts_per_gpu_batch": int(B), "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
+                       "utts_per_gpu_batch": int(B), "parallelism": f"dp{world}", "final_loss": round(loss, 4),
+                       "preheat_steps": a.preheat},
             "roofline": roof, "cpu_baseline": cpu,
             "per_gpu_value": round(frames / dt / world, 1),
             "dp": dp,
