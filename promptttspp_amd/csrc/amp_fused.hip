@@ -1,0 +1,558 @@
+// One BigVGAN AMP layer in ONE kernel, 16-bit tensors, second generation (round 5).  Same arithmetic, rounding points and
+// results (bit for bit) as amp_layer_kernel (amp_layer.hip, which stays the exact-f32 parity path):
+//
+//   y = res_scale * x + out_scale * (conv2(snake2(conv1(snake1(x)))) + b2) [+ res2]
+//   (vocoders/bigvgan.py:42-47, layers/activations.py:22-44, 74-138)
+//
+// What changed, and the measurement behind each change (tools/experiments/valu_rate.hip, lds_read_rate.hip,
+// profiles/r05_valu_rate.txt, r05_lds_read_rate.txt):
+//   * 8 waves per workgroup, two workgroups per CU.  One wave alone issues a VALU instruction every ~4.7 cycles; v_fma_f32 /
+//     v_mul_f32 / v_add_f32 retire in 2.4 once two waves of a SIMD feed it.  The Snake is ~50 FMAs per element pair: the
+//     4-wave blocks of round 2 ran it at half rate whenever only one of the three resident blocks was in a Snake phase.
+//   * LDS rows are PADDED (stride = row bytes + 16), not XOR-swizzled: addresses are affine, the Snake walks its rows with
+//     immediate offsets (the swizzle cost ~16 integer instructions of 4.2 cycles per step), and interior tiles take a
+//     clamp-free, select-free copy of the loop (v_cndmask_b32 measured at 16-20 cycles; the replicate padding only exists
+//     in the first and last tile of an utterance).
+//   * every run of the Snake has the same length (uniform control flow), x rows are requested one 6-step group ahead.
+//   * conv phases: a wave owns TWO 16-channel fragments of the output and MG row fragments (round 2: all four channel
+//     fragments and three row fragments, waves 3,3,3,1 / 3,3,2,0): weight fragments come straight from L2 (1 KiB per
+//     fragment per wave per K step through the 64 B/clk texture path: 0.33 KB per MFMA then, 0.25-0.2 now), activation
+//     fragments from LDS (0.5 KB per MFMA = half the 256 B/clk the LDS delivers), the row fragments divide evenly.
+// Phases of a block (8 waves, __syncthreads between phases):
+//   P0  global -> LDS X: rows [t0 - H, t0 + BT + H) of x, time index clamped into [0, T)
+//   P1  Snake 1 (VALU): X -> A          P2  conv1 (MFMA): A -> c1 (+ bias) in X
+//   P3  Snake 2: X -> A                 P4  conv2; epilogue through an LDS image of the output tile (bias, residual x, running
+//                                           AMP-block mean res2, 16-byte coalesced stores)
+#include <stdlib.h>
+#include <string.h>
+
+#include "ptpp_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+
+// element kinds of the 16-bit tensors
+struct EB16 {  // bfloat16
+  static __device__ __forceinline__ void unpack(uint32_t r, float& a, float& b) {
+    a = __uint_as_float(r << 16);
+    b = __uint_as_float(r & 0xffff0000u);
+  }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {  // v_cvt_pk_bf16_f32: round to nearest even
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+  }
+  static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+  }
+};
+struct EF16 {  // IEEE half
+  static __device__ __forceinline__ void unpack(uint32_t r, float& a, float& b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, r);
+    a = (float)h[0];
+    b = (float)h[1];
+  }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {  // round to nearest even
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    return __builtin_bit_cast(uint32_t, f16x2_t{(_Float16)a, (_Float16)b});
+  }
+  static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+  }
+};
+
+struct AmpF {
+  const void* x;
+  void* y;
+  const void* res2;
+  const void* w1p;
+  const void* w2p;
+  const float* b1;
+  const float* b2;
+  const float* la1;
+  const float* la2;
+  float up1[12], dn1[12], up2[12], dn2[12];
+  int B, T, ks, dil;
+  float out_scale, res_scale;
+  int nMT;
+  int R1, R2;     // rows per Snake run (phase 1 / phase 3), the same for every thread
+  int rowsX;      // rows of the X image (the A image follows it)
+  int skip;       // diagnostics (PTPP_AMP_SKIP): bit 0 P1, 1 P2, 2 P3, 3 P4 MFMA loop
+};
+
+__device__ __forceinline__ float snake_val16(float u, float w, float inv) {  // w = e^alpha / (2 pi): v_sin_f32 takes revolutions
+  const float s = __builtin_amdgcn_sinf(u * w);
+  return fmaf(inv, s * s, u);
+}
+
+// One Snake step for a channel pair.  Step K of a 6-step group replaces the oldest x by the row just loaded, pushes
+// s[2tp+7], s[2tp+8] into the 12-deep window and (EMIT) writes row tp+1 = sum_j s[2tp-3+j] fdn[j].  (the FMA order is that of
+// amp_layer.hip's AMP_SNAKE_STEP: results are bit-identical)
+#define AF_STEP_CORE(K, RAW)                                                                \
+  {                                                                                         \
+    E::unpack(RAW, xa[(K) % 6], xb[(K) % 6]);                                               \
+    float uoa = 0.f, uea = 0.f, uob = 0.f, ueb = 0.f;                                       \
+    _Pragma("unroll") for (int a = 0; a < 6; ++a) {                                         \
+      const float va = xa[((K) + 1 + a) % 6], vb = xb[((K) + 1 + a) % 6];                   \
+      uoa = fmaf(va, fup2[10 - 2 * a], uoa);                                                \
+      uea = fmaf(va, fup2[11 - 2 * a], uea);                                                \
+      uob = fmaf(vb, fup2[10 - 2 * a], uob);                                                \
+      ueb = fmaf(vb, fup2[11 - 2 * a], ueb);                                                \
+    }                                                                                       \
+    soa = snake_val16(uoa, w0, inv0); sea = snake_val16(uea, w0, inv0);                     \
+    sob = snake_val16(uob, w1, inv1); seb = snake_val16(ueb, w1, inv1);                     \
+  }
+#define AF_STEP_PUSH(K)                                                                     \
+  {                                                                                         \
+    sa[(2 * (K)) % 12] = soa; sb[(2 * (K)) % 12] = sob;                                     \
+    sa[(2 * (K) + 1) % 12] = sea; sb[(2 * (K) + 1) % 12] = seb;                             \
+  }
+#define AF_STEP_DOWN(K, YA, YB)                                                             \
+  {                                                                                         \
+    float ya = 0.f, yb = 0.f, za = 0.f, zb = 0.f;                                           \
+    _Pragma("unroll") for (int j = 0; j < 12; j += 2) {                                     \
+      ya = fmaf(sa[(2 * (K) + 2 + j) % 12], fdn[j], ya);                                    \
+      yb = fmaf(sb[(2 * (K) + 2 + j) % 12], fdn[j], yb);                                    \
+      za = fmaf(sa[(2 * (K) + 3 + j) % 12], fdn[j + 1], za);                                \
+      zb = fmaf(sb[(2 * (K) + 3 + j) % 12], fdn[j + 1], zb);                                \
+    }                                                                                       \
+    YA = ya + za; YB = yb + zb;                                                             \
+  }
+
+// Interior tile: no clamps, no selects.  The thread's run covers dst rows [o0, o0 + R); src row of time t is dst row + 6.
+// Step s = 0 .. R + 4 loads src row o0 + 6 + s and (s >= 5) writes dst row o0 + s - 5.
+template <typename E, int S>
+__device__ __forceinline__ void snake_fast(const char* src, char* dst, int o0, int R, int c2, const float (&fup2)[12],
+                                           const float (&fdn)[12], float w0, float w1, float inv0, float inv1) {
+  float xa[6], xb[6], sa[12], sb[12];
+  float soa, sea, sob, seb;
+  const char* px = src + o0 * S + c2;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) E::unpack(*reinterpret_cast<const uint32_t*>(px + a * S), xa[a], xb[a]);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
+  px += 6 * S;
+  char* pd = dst + (o0 - 5) * S + c2;
+  uint32_t cur[6], nxt[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) cur[k] = *reinterpret_cast<const uint32_t*>(px + k * S);
+  const int NS = R + 5;
+  const int G = NS / 6, rem = NS - G * 6;
+  // group 0: five warm-up steps, the sixth emits the run's first row
+#pragma unroll
+  for (int k = 0; k < 6; ++k) nxt[k] = *reinterpret_cast<const uint32_t*>(px + (6 + k) * S);
+#define AF_FAST(K, EMIT)                                                          \
+  {                                                                               \
+    AF_STEP_CORE(K, cur[K])                                                       \
+    AF_STEP_PUSH(K)                                                               \
+    if (EMIT) {                                                                   \
+      float oa, ob;                                                               \
+      AF_STEP_DOWN(K, oa, ob)                                                     \
+      *reinterpret_cast<uint32_t*>(pd + (K) * S) = E::pack(oa, ob);               \
+    }                                                                             \
+  }
+  AF_FAST(0, false) AF_FAST(1, false) AF_FAST(2, false) AF_FAST(3, false) AF_FAST(4, false) AF_FAST(5, true)
+  for (int g = 1; g < G; ++g) {
+    px += 6 * S;
+    pd += 6 * S;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cur[k] = nxt[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) nxt[k] = *reinterpret_cast<const uint32_t*>(px + (6 + k) * S);
+    AF_FAST(0, true) AF_FAST(1, true) AF_FAST(2, true) AF_FAST(3, true) AF_FAST(4, true) AF_FAST(5, true)
+  }
+  if (rem) {  // (uniform: R is the same for every thread)
+    pd += 6 * S;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cur[k] = nxt[k];
+    AF_FAST(0, true)
+    if (rem > 1) AF_FAST(1, true)
+    if (rem > 2) AF_FAST(2, true)
+    if (rem > 3) AF_FAST(3, true)
+    if (rem > 4) AF_FAST(4, true)
+  }
+#undef AF_FAST
+}
+
+// First / last tiles of an utterance (and utterances shorter than a tile): rows read at clamp(t, 0, T-1), s read at
+// clamp(m, 0, 2T-1), rows outside [0, T) written as zeros (the conv's zero padding).  dst rows [o0, o0 + n).
+template <typename E, int S>
+__device__ __forceinline__ void snake_edge(const char* src, char* dst, int tsrc0, int tdst0, int o0, int n, int Tlen, int c2,
+                                           const float (&fup2)[12], const float (&fdn)[12], float w0, float w1, float inv0,
+                                           float inv1) {
+  auto ldx = [&](int t, float& a, float& b) {
+    const int row = min(max(t, 0), Tlen - 1) - tsrc0;
+    E::unpack(*reinterpret_cast<const uint32_t*>(src + row * S + c2), a, b);
+  };
+  auto st = [&](int i, float a, float b) { *reinterpret_cast<uint32_t*>(dst + i * S + c2) = E::pack(a, b); };
+  const int ta = tdst0 + o0, tb = ta + n;
+  const int tv0 = max(ta, 0), tv1 = min(tb, Tlen);
+  for (int t = ta; t < min(tb, tv0); ++t) st(t - tdst0, 0.f, 0.f);
+  for (int t = max(ta, tv1); t < tb; ++t) st(t - tdst0, 0.f, 0.f);
+  if (tv1 <= tv0) return;
+  float xa[6], xb[6], sa[12], sb[12];
+  float soa, sea, sob, seb;
+  const int tp0 = max(tv0 - 6, -3);
+  float pa = 0.f, pb = 0.f;
+  if (tv0 < 3) {  // s[0] = snake(u[0]), u[0] = sum_a x[clamp(a-3)] * 2 f[11-2a]
+    float ua = 0.f, ub = 0.f;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      float va, vb;
+      ldx(a - 3, va, vb);
+      ua = fmaf(va, fup2[11 - 2 * a], ua);
+      ub = fmaf(vb, fup2[11 - 2 * a], ub);
+    }
+    pa = snake_val16(ua, w0, inv0);
+    pb = snake_val16(ub, w1, inv1);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { sa[i] = pa; sb[i] = pb; }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) ldx(tp0 + a, xa[a], xb[a]);
+  const int mlast = 2 * Tlen - 1;
+#define AF_EDGE(K)                                                                          \
+  {                                                                                         \
+    const int tp = tg + (K);                                                                \
+    const int rowc = min(max(tp + 6, 0), Tlen - 1) - tsrc0;                                 \
+    const uint32_t raw = *reinterpret_cast<const uint32_t*>(src + rowc * S + c2);           \
+    AF_STEP_CORE(K, raw)                                                                    \
+    const int m1 = 2 * tp + 7;                                                              \
+    if (m1 > mlast) { soa = sa[(2 * (K) + 11) % 12]; sob = sb[(2 * (K) + 11) % 12]; }       \
+    if (m1 + 1 > mlast) { sea = soa; seb = sob; }                                           \
+    AF_STEP_PUSH(K)                                                                         \
+    const int t = tp + 1;                                                                   \
+    if (t >= tv0 && t < tv1) {                                                              \
+      float oa, ob;                                                                         \
+      AF_STEP_DOWN(K, oa, ob)                                                               \
+      st(t - tdst0, oa, ob);                                                                \
+    }                                                                                       \
+  }
+  for (int tg = tp0; tg + 1 < tv1; tg += 6) {
+    AF_EDGE(0) AF_EDGE(1) AF_EDGE(2) AF_EDGE(3) AF_EDGE(4) AF_EDGE(5)
+  }
+#undef AF_EDGE
+}
+
+// out channel held by MFMA "A" row i of fragment f (a lane's accumulators of a fragment PAIR are one 16-byte chunk)
+__device__ __forceinline__ int frag_channel16(int f, int i) { return (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3); }
+
+// Implicit-GEMM conv over the LDS-resident activation image for the wave's MG row fragments x the fragment pair h:
+//   acc[mi][u] = sum_{j, ci} W[co(2h + u, .), j, ci] * act[(mf0 + mi) * 16 + lr + j * dil][ci]
+// Weight fragments straight from global memory (two 16-byte loads per lane per K step, requested two steps ahead),
+// activation fragments from LDS.
+template <typename E, int C, int S, int MG>
+__device__ __forceinline__ void conv_pair(const char* act, const uint16_t* __restrict__ wp, int ks, int dil, int mf0, int nmf,
+                                          int h, int lane, f32x4 (&acc)[MG][2]) {
+  constexpr int NKC = C / 32;
+  const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < MG; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const uint16_t* wr0 = wp + (int64_t)frag_channel16(2 * h, lr) * ks * C + lg * 8;
+  const uint16_t* wr1 = wp + (int64_t)frag_channel16(2 * h + 1, lr) * ks * C + lg * 8;
+  const int steps = ks * NKC;  // step s = (tap j, 32-channel block kc): weight offset j * C + kc * 32 = 32 s
+  const char* abase[MG];
+#pragma unroll
+  for (int mi = 0; mi < MG; ++mi) abase[mi] = act + ((mf0 + (mi < nmf ? mi : 0)) * 16 + lr) * S + lg * 16;
+  const int dS = dil * S;
+  // three weight register sets in rotation, no moves: step s reads set s % 3 and requests step s + 2 into set (s + 2) % 3
+  uint4 w[3][2];
+  w[0][0] = *reinterpret_cast<const uint4*>(wr0);
+  w[0][1] = *reinterpret_cast<const uint4*>(wr1);
+  w[1][0] = w[0][0]; w[1][1] = w[0][1];
+  if (steps > 1) {
+    w[1][0] = *reinterpret_cast<const uint4*>(wr0 + 32);
+    w[1][1] = *reinterpret_cast<const uint4*>(wr1 + 32);
+  }
+  w[2][0] = w[0][0]; w[2][1] = w[0][1];
+#define AF_CONV_STEP(CUR, NXT, SI)                                                                  \
+  {                                                                                                 \
+    const int s_ = (SI);                                                                            \
+    if (s_ + 2 < steps) {                                                                           \
+      w[NXT][0] = *reinterpret_cast<const uint4*>(wr0 + (s_ + 2) * 32);                             \
+      w[NXT][1] = *reinterpret_cast<const uint4*>(wr1 + (s_ + 2) * 32);                             \
+    }                                                                                               \
+    const int off = (s_ / NKC) * dS + (s_ % NKC) * 64;                                              \
+    uint4 xf[MG];                                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < MG; ++mi) xf[mi] = *reinterpret_cast<const uint4*>(abase[mi] + off); \
+    _Pragma("unroll") for (int mi = 0; mi < MG; ++mi) {                                             \
+      E::mma(acc[mi][0], w[CUR][0], xf[mi]);                                                        \
+      E::mma(acc[mi][1], w[CUR][1], xf[mi]);                                                        \
+    }                                                                                               \
+  }
+  for (int s = 0; s < steps; s += 3) {
+    AF_CONV_STEP(0, 2, s)
+    if (s + 1 < steps) AF_CONV_STEP(1, 0, s + 1)
+    if (s + 2 < steps) AF_CONV_STEP(2, 1, s + 2)
+  }
+#undef AF_CONV_STEP
+}
+
+template <typename E, int C, int BT, int S, int MG1, int MG2>
+__global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
+  constexpr int NT = 512;
+  constexpr int NCH = C / 8;          // 16-byte chunks per row
+  constexpr int CP = C / 2;           // channel pairs
+  constexpr int NRUN = NT / CP;       // row runs per Snake phase
+  constexpr int WN = C / 32;          // waves along the output channels (a wave owns 32 of them)
+  constexpr int WM = 8 / WN;          // waves along the rows
+  static_assert(NT % CP == 0 && BT % 16 == 0 && S % 16 == 0 && S >= C * 2, "geometry");
+  static_assert(MG2 * WM * 16 >= BT, "conv2: one fragment group per wave");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ks = p.ks, dil = p.dil, Tlen = p.T;
+  const int pad1 = dil * (ks - 1) / 2, pad2 = (ks - 1) / 2;
+  const int n_c1 = BT + 2 * pad2 + 12;          // conv1 output rows snake 2 reads
+  const int M1 = (n_c1 + 15) & ~15;             // ... rounded up to whole MFMA fragments
+  const int n_a1 = n_c1 + 2 * pad1;             // snake-1 rows conv1 reads (without the fragment overhang)
+  const int n_x = n_a1 + 12;
+  char* Xs = smem;
+  char* As = smem + p.rowsX * S;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid % p.nMT, b = lid / p.nMT;
+  const int t0 = mt * BT;
+  const int tc0 = t0 - pad2 - 6;     // time of c1 row 0
+  const int ta0 = tc0 - pad1;        // time of a1 row 0
+  const int tx0 = ta0 - 6;           // time of X row 0
+  const bool interior = tx0 >= 0 && tx0 + n_x <= Tlen;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)b * Tlen * C;
+
+  // ---- P0: x tile -> LDS (time index clamped: replicate padding of the first Snake) ----
+  for (int idx = tid; idx < n_x * NCH; idx += NT) {
+    const int r = idx / NCH, ch = idx - r * NCH;
+    const int t = min(max(tx0 + r, 0), Tlen - 1);
+    const uint4 v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + ch * 8);
+    *reinterpret_cast<uint4*>(Xs + r * S + ch * 16) = v;
+  }
+  const int cpair = tid % CP, run = tid / CP;
+  constexpr float WSC = 0.15915494309189535f;  // v_sin_f32 takes revolutions
+  float ea0, ea1, inv0, inv1;
+  {
+    const float a0 = __expf(p.la1[2 * cpair]), a1 = __expf(p.la1[2 * cpair + 1]);
+    ea0 = a0 * WSC; ea1 = a1 * WSC; inv0 = 1.0f / (a0 + 1e-9f); inv1 = 1.0f / (a1 + 1e-9f);
+  }
+  __syncthreads();
+
+  // ---- P1: snake 1: X -> A (a1 rows [0, n_a1); time ta0 + i) ----
+  if (!(p.skip & 1)) {
+    float fu[12], fd[12];  // the taps as scalars (a pointer into the by-value argument block would spill it)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { fu[i] = 2.0f * p.up1[i]; fd[i] = p.dn1[i]; }
+    const int o0 = run * p.R1;
+    if (interior) {
+      snake_fast<E, S>(Xs, As, o0, p.R1, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+    } else {
+      const int n = min(p.R1, n_a1 - o0);
+      if (n > 0) snake_edge<E, S>(Xs, As, tx0, ta0, o0, n, Tlen, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+    }
+  }
+  __syncthreads();
+
+  const int wn = wave % WN, wm = wave / WN;
+  const int lr = lane & 15, lg = lane >> 4;
+  // ---- P2: conv1 (dilated): A -> c1 rows [0, M1) in X ----
+  if (!(p.skip & 2)) {
+    const int nfr = M1 / 16;
+    const int per = (nfr + WM - 1) / WM;  // <= MG1 (host)
+    const int mf0 = wm * per, nmf = min(per, nfr - mf0);
+    if (nmf > 0) {
+      f32x4 acc[MG1][2];
+      conv_pair<E, C, S, MG1>(As, reinterpret_cast<const uint16_t*>(p.w1p), ks, dil, mf0, nmf, wn, lane, acc);
+      const int co = wn * 32 + lg * 8;
+      const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + co), bB = *reinterpret_cast<const f32x4*>(p.b1 + co + 4);
+#pragma unroll
+      for (int mi = 0; mi < MG1; ++mi) {
+        if (mi < nmf) {
+          const int row = (mf0 + mi) * 16 + lr;
+          const f32x4 v0 = acc[mi][0] + bA, v1 = acc[mi][1] + bB;
+          uint4 o;
+          o.x = E::pack(v0[0], v0[1]); o.y = E::pack(v0[2], v0[3]);
+          o.z = E::pack(v1[0], v1[1]); o.w = E::pack(v1[2], v1[3]);
+          *reinterpret_cast<uint4*>(Xs + row * S + (wn * 4 + lg) * 16) = o;
+        }
+      }
+    }
+  }
+  {
+    const float a0 = __expf(p.la2[2 * cpair]), a1 = __expf(p.la2[2 * cpair + 1]);
+    ea0 = a0 * WSC; ea1 = a1 * WSC; inv0 = 1.0f / (a0 + 1e-9f); inv1 = 1.0f / (a1 + 1e-9f);
+  }
+  __syncthreads();
+
+  // ---- P3: snake 2: c1 (X) -> a2 rows [0, BT + 2 pad2) in A; time t0 - pad2 + i ----
+  if (!(p.skip & 4)) {
+    const int n_a2 = BT + 2 * pad2;
+    float fu[12], fd[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { fu[i] = 2.0f * p.up2[i]; fd[i] = p.dn2[i]; }
+    const int o0 = run * p.R2;
+    if (interior) {
+      snake_fast<E, S>(Xs, As, o0, p.R2, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+    } else {
+      const int n = min(p.R2, n_a2 - o0);
+      if (n > 0) snake_edge<E, S>(Xs, As, tc0, t0 - pad2, o0, n, Tlen, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+    }
+  }
+  __syncthreads();
+
+  // ---- P4: conv2: A -> y (+ bias, residual x, running mean res2) through an LDS image of the output tile in X ----
+  {
+    constexpr int nfr = BT / 16;
+    constexpr int per = (nfr + WM - 1) / WM;
+    static_assert(per <= MG2, "conv2 fragment groups");
+    constexpr int NRV = (BT * NCH + NT - 1) / NT;  // 16-byte vectors of the tile per thread
+    uint16_t* yb = reinterpret_cast<uint16_t*>(p.y) + (int64_t)b * Tlen * C;
+    const uint16_t* r2b = p.res2 ? reinterpret_cast<const uint16_t*>(p.res2) + (int64_t)b * Tlen * C : nullptr;
+    const float osc = p.out_scale, rsc = p.res_scale;
+    uint4 rx[NRV];
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx / NCH, ch = idx - r * NCH;
+      const int t = t0 + r;
+      rx[i] = (idx < BT * NCH && t < Tlen) ? *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + ch * 8) : make_uint4(0, 0, 0, 0);
+    }
+    const int mf0 = wm * per, nmf = min(per, nfr - mf0);
+    const int co = wn * 32 + lg * 8;
+    f32x4 acc[MG2][2];
+    uint4 q2[MG2];
+    if (nmf > 0) {
+      if (r2b) {  // (two of the nine layers of a stage: the running mean of the AMP blocks)
+#pragma unroll
+        for (int mi = 0; mi < MG2; ++mi) {
+          const int t = t0 + (mf0 + mi) * 16 + lr;
+          q2[mi] = (mi < nmf && t < Tlen) ? *reinterpret_cast<const uint4*>(r2b + (int64_t)t * C + co) : make_uint4(0, 0, 0, 0);
+        }
+      }
+      if (!(p.skip & 8)) conv_pair<E, C, S, MG2>(As, reinterpret_cast<const uint16_t*>(p.w2p), ks, 1, mf0, nmf, wn, lane, acc);
+      else {
+#pragma unroll
+        for (int mi = 0; mi < MG2; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx / NCH, ch = idx - r * NCH;
+      if (idx < BT * NCH) *reinterpret_cast<uint4*>(Xs + r * S + ch * 16) = rx[i];
+    }
+    __syncthreads();
+    if (nmf > 0) {
+      const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b2 + co), bB = *reinterpret_cast<const f32x4*>(p.b2 + co + 4);
+#pragma unroll
+      for (int mi = 0; mi < MG2; ++mi) {
+        if (mi < nmf) {
+          const int r = (mf0 + mi) * 16 + lr;
+          f32x4 v0 = (acc[mi][0] + bA) * osc, v1 = (acc[mi][1] + bB) * osc;
+          uint4* slot = reinterpret_cast<uint4*>(Xs + r * S + (wn * 4 + lg) * 16);
+          const uint4 rr = *slot;
+          float e0, e1;
+          E::unpack(rr.x, e0, e1); v0[0] += e0 * rsc; v0[1] += e1 * rsc;
+          E::unpack(rr.y, e0, e1); v0[2] += e0 * rsc; v0[3] += e1 * rsc;
+          E::unpack(rr.z, e0, e1); v1[0] += e0 * rsc; v1[1] += e1 * rsc;
+          E::unpack(rr.w, e0, e1); v1[2] += e0 * rsc; v1[3] += e1 * rsc;
+          if (r2b) {
+            const uint4 q = q2[mi];
+            E::unpack(q.x, e0, e1); v0[0] += e0; v0[1] += e1;
+            E::unpack(q.y, e0, e1); v0[2] += e0; v0[3] += e1;
+            E::unpack(q.z, e0, e1); v1[0] += e0; v1[1] += e1;
+            E::unpack(q.w, e0, e1); v1[2] += e0; v1[3] += e1;
+          }
+          uint4 o;
+          o.x = E::pack(v0[0], v0[1]); o.y = E::pack(v0[2], v0[3]);
+          o.z = E::pack(v1[0], v1[1]); o.w = E::pack(v1[2], v1[3]);
+          *slot = o;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx / NCH, ch = idx - r * NCH;
+      const int t = t0 + r;
+      if (idx < BT * NCH && t < Tlen)
+        *reinterpret_cast<uint4*>(yb + (int64_t)t * C + ch * 8) = *reinterpret_cast<const uint4*>(Xs + r * S + ch * 16);
+    }
+  }
+}
+
+template <typename E, int C, int BT, int S, int MG1, int MG2>
+int launch_amp_fused(AmpF& p, hipStream_t st) {
+  constexpr int NRUN = 512 / (C / 2);
+  constexpr int WM = 8 / (C / 32);
+  const int pad1 = p.dil * (p.ks - 1) / 2, pad2 = (p.ks - 1) / 2;
+  const int n_c1 = BT + 2 * pad2 + 12, M1 = (n_c1 + 15) & ~15;
+  const int n_a1 = n_c1 + 2 * pad1, n_x = n_a1 + 12, n_a2 = BT + 2 * pad2;
+  if ((M1 / 16 + WM - 1) / WM > MG1) {
+    ptpp_set_error("amp_fused: ks=%d needs %d conv1 row fragments per wave (built for %d)", p.ks, (M1 / 16 + WM - 1) / WM, MG1);
+    return PTPP_ENOTSUP;
+  }
+  p.R1 = (n_a1 + NRUN - 1) / NRUN;
+  p.R2 = (n_a2 + NRUN - 1) / NRUN;
+  // interior tiles walk NRUN equal runs: the last run may overhang the image by up to NRUN - 1 rows it reads (+ 12 rows of
+  // halo + one prefetched group) and writes
+  int rowsX = n_x > M1 ? n_x : M1;
+  const int need1 = NRUN * p.R1 + 24, need2 = NRUN * p.R2 + 24;
+  if (rowsX < need1) rowsX = need1;
+  if (rowsX < need2) rowsX = need2;
+  int rowsA = M1 + 2 * pad1;
+  if (rowsA < n_a2) rowsA = n_a2;
+  if (rowsA < NRUN * p.R1) rowsA = NRUN * p.R1;
+  if (rowsA < NRUN * p.R2) rowsA = NRUN * p.R2;
+  p.rowsX = rowsX;
+  const size_t smem = (size_t)(rowsX + rowsA) * S;
+  if (smem > 160 * 1024) {
+    ptpp_set_error("amp_fused: LDS tile too large (%zu B)", smem);
+    return PTPP_ENOTSUP;
+  }
+  auto kern = amp_fused_kernel<E, C, BT, S, MG1, MG2>;
+  if (smem > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+      ptpp_set_error("amp_fused: cannot raise the dynamic LDS limit to %zu B: %s", smem, hipGetErrorString(e));
+      return PTPP_ELAUNCH;
+    }
+  }
+  p.nMT = (p.T + BT - 1) / BT;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, st, p);
+  PTPP_CHECK_LAUNCH("amp_layer_fwd (fused, 16-bit)");
+  return PTPP_OK;
+}
+
+}  // namespace
+
+// called by ptpp_amp_layer_fwd (amp_layer.hip) for 16-bit tensors; variant: PTPP_AMP_VARIANT (experiments)
+int amp_fused_launch_16bit(const ptpp_amp_layer_args* a, void* stream) {
+  AmpF p;
+  p.x = a->x; p.y = a->y; p.res2 = a->res2; p.w1p = a->w1p; p.w2p = a->w2p; p.b1 = a->b1; p.b2 = a->b2;
+  p.la1 = a->log_alpha1; p.la2 = a->log_alpha2;
+  for (int i = 0; i < 12; ++i) {
+    p.up1[i] = a->up1[i]; p.dn1[i] = a->dn1[i]; p.up2[i] = a->up2[i]; p.dn2[i] = a->dn2[i];
+  }
+  p.B = a->B; p.T = a->T; p.ks = a->ks; p.dil = a->dil;
+  p.out_scale = a->out_scale; p.res_scale = a->res_scale;
+  p.nMT = 0; p.R1 = p.R2 = 0; p.rowsX = 0;
+  const int skip = getenv("PTPP_AMP_SKIP") ? atoi(getenv("PTPP_AMP_SKIP")) : 0;
+  const int variant = getenv("PTPP_AMP_VARIANT") ? atoi(getenv("PTPP_AMP_VARIANT")) : 0;
+  p.skip = skip;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == PTPP_BF16) {
+    if (a->C == 64) {
+      if (variant == 1) return launch_amp_fused<EB16, 64, 160, 160, 3, 3>(p, st);
+      if (variant == 2) return launch_amp_fused<EB16, 64, 128, 144, 3, 2>(p, st);
+      return launch_amp_fused<EB16, 64, 192, 144, 4, 3>(p, st);
+    }
+    if (a->C == 32) {
+      if (variant == 1) return launch_amp_fused<EB16, 32, 320, 96, 3, 3>(p, st);
+      if (variant == 2) return launch_amp_fused<EB16, 32, 256, 80, 3, 2>(p, st);
+      return launch_amp_fused<EB16, 32, 384, 80, 4, 3>(p, st);
+    }
+  }
+  ptpp_set_error("amp_fused: C=%d dtype=%d not built", a->C, a->dtype);
+  return PTPP_ENOTSUP;
+}

@@ -515,6 +515,8 @@ int launch_amp(AmpP& p, hipStream_t st) {
 
 }  // namespace
 
+int amp_fused_launch_16bit(const ptpp_amp_layer_args* a, void* stream);  // amp_fused.hip
+
 extern "C" int ptpp_amp_layer_supported(int C, int dtype) {
   if (dtype == PTPP_BF16) return C == 32 || C == 64;
   if (dtype == PTPP_F32) return C == 32 || C == 64;
@@ -544,6 +546,8 @@ extern "C" int ptpp_amp_layer_fwd(const ptpp_amp_layer_args* a, void* stream) {
   p.nMT = 0;
   p.skip = getenv("PTPP_AMP_SKIP") ? atoi(getenv("PTPP_AMP_SKIP")) : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool old16 = getenv("PTPP_AMP_OLD") && atoi(getenv("PTPP_AMP_OLD"));  // A/B: the round-2 kernel
+  if (a->dtype == PTPP_BF16 && !old16) return amp_fused_launch_16bit(a, stream);
   if (a->dtype == PTPP_BF16) {
     // (the FIRs-on-MFMA experiment of round 2 -- not run-to-run reproducible with two workgroups per CU -- left the library in
     //  round 4: tools/experiments/r02_amp_layer_mfma.hip.txt)

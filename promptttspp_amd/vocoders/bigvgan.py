@@ -212,25 +212,27 @@ class BigVGAN(nn.Module):
             h = self._conv(h, up).view(B, T * u, up.cout // u)
             if source_hook is not None:
                 h = source_hook(s, h)
-            if all(l[4] is not None for blk in blocks for l in blk):
-                h = self._mrf_fused(h.contiguous(), blocks, inv)
-                continue
-            if self.parallel_blocks and h.is_cuda and len(blocks) == 3 and not torch.cuda.is_current_stream_capturing():
-                h = self._mrf_parallel(h, blocks, inv)
-                continue
-            acc = None
-            for layers in blocks:
-                xb = h
-                for li, (act1, c1, act2, c2, _) in enumerate(layers):
-                    a = act1.forward_cl(xb)
-                    a = self._conv(a, c1)
-                    a = act2.forward_cl(a)
-                    if li + 1 < len(layers):
-                        xb = self._conv(a, c2, res=xb)
-                    else:  # acc += (xb + conv2(a)) / num_kernels
-                        acc = self._conv(a, c2, res=xb, res_scale=inv, out_scale=inv, res2=acc)
-            h = acc
+            h = self._mrf(h, blocks, inv)
         return h, pk
+
+    def _mrf(self, h, blocks, inv):
+        """Multi-receptive-field fusion of one stage: mean over the AMP blocks (bigvgan.py:124-128)."""
+        if all(l[4] is not None for blk in blocks for l in blk):
+            return self._mrf_fused(h.contiguous(), blocks, inv)
+        if self.parallel_blocks and h.is_cuda and len(blocks) == 3 and not torch.cuda.is_current_stream_capturing():
+            return self._mrf_parallel(h, blocks, inv)
+        acc = None
+        for layers in blocks:
+            xb = h
+            for li, (act1, c1, act2, c2, _) in enumerate(layers):
+                a = act1.forward_cl(xb)
+                a = self._conv(a, c1)
+                a = act2.forward_cl(a)
+                if li + 1 < len(layers):
+                    xb = self._conv(a, c2, res=xb)
+                else:  # acc += (xb + conv2(a)) / num_kernels
+                    acc = self._conv(a, c2, res=xb, res_scale=inv, out_scale=inv, res2=acc)
+        return acc
 
     @staticmethod
     def _mrf_fused(h, blocks, inv):

@@ -630,6 +630,38 @@ def test_fused_amp_layer_equals_the_four_launch_pipeline_bf16(dev):
         assert torch.equal(y[1:2], ops.amp_layer(x[1:2].contiguous(), wp[0], b[0], wp[1], b[1], la[0], la[1], taps, taps, ks, d))
 
 
+def test_fused_amp_layer_second_generation_is_bit_identical(dev, monkeypatch):
+    """amp_fused_kernel (csrc/amp_fused.hip: 8 waves, padded LDS rows, clamp-free interior tiles, two channel fragments per
+    wave) keeps every FMA order and rounding point of the round-2 kernel (amp_layer_kernel, still the f32 path): bit-identical
+    on interior tiles, edge tiles, utterances shorter than the halo, ragged last tiles, with and without the block mean --
+    for every tile-height variant."""
+    from promptttspp_amd import ops
+
+    g = load_golden("aa_snake")
+    taps = (ops._taps(g["f_up"]), ops._taps(g["f_dn"]))
+    gen = torch.Generator(dev).manual_seed(11)
+    for C in (32, 64):
+        for ks, d, T in ((3, 1, 1500), (7, 3, 2100), (11, 5, 4000), (11, 1, 777), (3, 5, 5), (7, 1, 61), (11, 3, 385)):
+            B = 2
+            x = torch.randn(B, T, C, device=dev, generator=gen).bfloat16()
+            acc = torch.randn(B, T, C, device=dev, generator=gen).bfloat16()
+            w = [ops.pack_conv_weight(torch.randn(C, C, ks, device=dev, generator=gen) / (C * ks) ** 0.5, torch.bfloat16) for _ in range(2)]
+            b = [0.1 * torch.randn(C, device=dev, generator=gen) for _ in range(2)]
+            la = [0.3 * torch.randn(C, device=dev, generator=gen) for _ in range(2)]
+
+            def run(**kw):
+                return ops.amp_layer(x, w[0], b[0], w[1], b[1], la[0], la[1], taps, taps, ks, d, **kw)
+
+            monkeypatch.setenv("PTPP_AMP_OLD", "1")
+            ref, ref2 = run(), run(res2=acc, out_scale=1 / 3, res_scale=1 / 3)
+            monkeypatch.delenv("PTPP_AMP_OLD")
+            for variant in ("0", "1", "2"):
+                monkeypatch.setenv("PTPP_AMP_VARIANT", variant)
+                assert torch.equal(run(), ref), (C, ks, d, T, variant)
+                assert torch.equal(run(res2=acc, out_scale=1 / 3, res_scale=1 / 3), ref2), (C, ks, d, T, variant, "res2")
+            monkeypatch.delenv("PTPP_AMP_VARIANT")
+
+
 def test_mel_front_end_and_lowpass_on_device(dev):
     """n1 / n2 on the GPU: the log-mel front-end on the exact-f32 GEMM (windowed DFT and filterbank as two products)
     and the zero-phase IIR kernel, against the oracle's numpy restatements."""
