@@ -575,7 +575,9 @@ int ptpp_aa_snake_fwd(const void* x, void* y, const float* log_alpha,
  * parameter in the log domain); up* / dn*: the 12-tap anti-alias filters of act1 / act2 (HOST values, by value).
  * res2 (nullable): the running mean of the AMP blocks (bigvgan.py:124-128).  The x tile and its halo stay in
  * LDS: x is read once and y written once (9 tensor passes when the four stages are separate launches).
- * Built for C in {32, 64}: ptpp_amp_layer_supported(C, dtype) != 0; otherwise PTPP_ENOTSUP. */
+ * Built for C in {32, 64}: ptpp_amp_layer_supported(C, dtype) != 0; otherwise PTPP_ENOTSUP.
+ * 16-bit dtypes take the conv weights as FRAGMENT STREAMS w1s / w2s (ptpp_amp_pack_wstream of w1p / w2p: the MFMA weight
+ * fragments in consumption order, a wave reads 2 KiB contiguous per K step); w1p / w2p are then unused and may be NULL. */
 typedef struct {
   const void* x;
   void* y;
@@ -590,9 +592,37 @@ typedef struct {
   int32_t B, T, C, ks, dil;
   float out_scale, res_scale;
   int32_t dtype;
+  const void* w1s;
+  const void* w2s;
 } ptpp_amp_layer_args;
 int ptpp_amp_layer_supported(int C, int dtype);
 int ptpp_amp_layer_fwd(const ptpp_amp_layer_args* a, void* stream);
+/* (C, ks, C) packed operand `wp` (ptpp_pack_conv_weight mode 0, no channel padding: C in {32, 64, 128, 256}) -> fragment
+ * stream `out` (same number of bytes) for the 16-bit fused AMP layer / ptpp_snake_conv1d_fwd (vocoders/bigvgan.py:24-47: the
+ * layer's two weight-normed Conv1d). */
+int ptpp_amp_pack_wstream(const void* wp, void* out, int C, int ks, int dtype, void* stream);
+
+/* One half of an AMP layer in the WIDE stages of BigVGAN (C = 128, 256; vocoders/bigvgan.py:42-47 with
+ * layers/activations.py:22-44, 74-138): the anti-aliased Snake applied while the conv's input tile is staged,
+ *   y = res_scale * res + out_scale * (conv(snake(x)) + bias) [+ res2]
+ * x, y, res, res2: (B, T, C) channels-last 16-bit, contiguous (res, res2 nullable); conv: C -> C, ks taps, dilation dil,
+ * padding dil*(ks-1)/2; ws: ptpp_amp_pack_wstream of the packed weight; bias (C) f32; log_alpha (C) f32; up / dn: the 12-tap
+ * anti-alias filters (HOST values).  The activated tensor never exists in HBM (ptpp_aa_snake_fwd + ptpp_conv1d_fwd: + 2 passes). */
+typedef struct {
+  const void* x;
+  void* y;
+  const void* res;
+  const void* res2;
+  const void* ws;
+  const float* bias;
+  const float* log_alpha;
+  float up[12], dn[12];
+  int32_t B, T, C, ks, dil;
+  float out_scale, res_scale;
+  int32_t dtype;
+} ptpp_snake_conv_args;
+int ptpp_snake_conv1d_supported(int C, int dtype);
+int ptpp_snake_conv1d_fwd(const ptpp_snake_conv_args* a, void* stream);
 
 /* y = (a + b + c) * scale  (b, c nullable) */
 int ptpp_add3_scale(const void* a, const void* b, const void* c, void* y,

@@ -55,6 +55,15 @@ class AmpLayerArgs(Structure):
     _fields_ = [(n, c_void_p) for n in ("x", "y", "res2", "w1p", "w2p", "b1", "b2", "log_alpha1", "log_alpha2")] + \
                [(n, c_float * 12) for n in ("up1", "dn1", "up2", "dn2")] + \
                [(n, c_int32) for n in ("B", "T", "C", "ks", "dil")] + \
+               [("out_scale", c_float), ("res_scale", c_float), ("dtype", c_int32), ("w1s", c_void_p), ("w2s", c_void_p)]
+
+
+class SnakeConvArgs(Structure):
+    """Mirror of ``ptpp_snake_conv_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("x", "y", "res", "res2", "ws", "bias", "log_alpha")] + \
+               [(n, c_float * 12) for n in ("up", "dn")] + \
+               [(n, c_int32) for n in ("B", "T", "C", "ks", "dil")] + \
                [("out_scale", c_float), ("res_scale", c_float), ("dtype", c_int32)]
 
 
@@ -268,6 +277,9 @@ SIGNATURES = {
     "ptpp_aa_snake_fwd": (I, [P, P, P, POINTER(c_float), POINTER(c_float), I, I, I, I, P]),
     "ptpp_amp_layer_supported": (I, [I, I]),
     "ptpp_amp_layer_fwd": (I, [POINTER(AmpLayerArgs), P]),
+    "ptpp_amp_pack_wstream": (I, [P, P, I, I, I, P]),
+    "ptpp_snake_conv1d_supported": (I, [I, I]),
+    "ptpp_snake_conv1d_fwd": (I, [POINTER(SnakeConvArgs), P]),
     "ptpp_add3_scale": (I, [P, P, P, P, F, I64, I, P]),
     "ptpp_conv_post_tanh": (I, [P, P, F, P, I, I, I, I, I, P]),
     "ptpp_filtfilt": (I, [P, P, P, P, POINTER(ctypes.c_double), POINTER(ctypes.c_double), I, I, I, I, P]),

@@ -80,7 +80,17 @@ struct AmpF {
   int R1, R2;     // rows per Snake run (phase 1 / phase 3), the same for every thread
   int rowsX;      // rows of the X image (the A image follows it)
   int skip;       // diagnostics (PTPP_AMP_SKIP): bit 0 P1, 1 P2, 2 P3, 3 P4 MFMA loop
+  int stagger;    // s_sleep(127) periods the second resident block of every CU waits before its first tile
 };
+
+// A wave-uniform value parked in a VGPR the compiler cannot move back to an SGPR: v_fmac_f32 / v_mul_f32 / v_add_f32 with an
+// SGPR (or literal) operand issue in 4.2-4.4 cycles, with VGPR operands only in 2.3 (profiles/r05_valu_rate.txt: FMA_S, FMAAK
+// against FMA, FMAC) -- the Snake's 48 FMAs per step all multiply by a filter tap.
+__device__ __forceinline__ float in_vgpr(float s) {
+  float v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(s));
+  return v;
+}
 
 __device__ __forceinline__ float snake_val16(float u, float w, float inv) {  // w = e^alpha / (2 pi): v_sin_f32 takes revolutions
   const float s = __builtin_amdgcn_sinf(u * w);
@@ -123,26 +133,26 @@ __device__ __forceinline__ float snake_val16(float u, float w, float inv) {  // 
 
 // Interior tile: no clamps, no selects.  The thread's run covers dst rows [o0, o0 + R); src row of time t is dst row + 6.
 // Step s = 0 .. R + 4 loads src row o0 + 6 + s and (s >= 5) writes dst row o0 + s - 5.
-template <typename E, int S>
+template <typename E, int SS, int S>
 __device__ __forceinline__ void snake_fast(const char* src, char* dst, int o0, int R, int c2, const float (&fup2)[12],
                                            const float (&fdn)[12], float w0, float w1, float inv0, float inv1) {
   float xa[6], xb[6], sa[12], sb[12];
   float soa, sea, sob, seb;
-  const char* px = src + o0 * S + c2;
+  const char* px = src + o0 * SS + c2;
 #pragma unroll
-  for (int a = 0; a < 6; ++a) E::unpack(*reinterpret_cast<const uint32_t*>(px + a * S), xa[a], xb[a]);
+  for (int a = 0; a < 6; ++a) E::unpack(*reinterpret_cast<const uint32_t*>(px + a * SS), xa[a], xb[a]);
 #pragma unroll
   for (int i = 0; i < 12; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
-  px += 6 * S;
+  px += 6 * SS;
   char* pd = dst + (o0 - 5) * S + c2;
   uint32_t cur[6], nxt[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) cur[k] = *reinterpret_cast<const uint32_t*>(px + k * S);
+  for (int k = 0; k < 6; ++k) cur[k] = *reinterpret_cast<const uint32_t*>(px + k * SS);
   const int NS = R + 5;
   const int G = NS / 6, rem = NS - G * 6;
   // group 0: five warm-up steps, the sixth emits the run's first row
 #pragma unroll
-  for (int k = 0; k < 6; ++k) nxt[k] = *reinterpret_cast<const uint32_t*>(px + (6 + k) * S);
+  for (int k = 0; k < 6; ++k) nxt[k] = *reinterpret_cast<const uint32_t*>(px + (6 + k) * SS);
 #define AF_FAST(K, EMIT)                                                          \
   {                                                                               \
     AF_STEP_CORE(K, cur[K])                                                       \
@@ -155,12 +165,12 @@ __device__ __forceinline__ void snake_fast(const char* src, char* dst, int o0, i
   }
   AF_FAST(0, false) AF_FAST(1, false) AF_FAST(2, false) AF_FAST(3, false) AF_FAST(4, false) AF_FAST(5, true)
   for (int g = 1; g < G; ++g) {
-    px += 6 * S;
+    px += 6 * SS;
     pd += 6 * S;
 #pragma unroll
     for (int k = 0; k < 6; ++k) cur[k] = nxt[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) nxt[k] = *reinterpret_cast<const uint32_t*>(px + (6 + k) * S);
+    for (int k = 0; k < 6; ++k) nxt[k] = *reinterpret_cast<const uint32_t*>(px + (6 + k) * SS);
     AF_FAST(0, true) AF_FAST(1, true) AF_FAST(2, true) AF_FAST(3, true) AF_FAST(4, true) AF_FAST(5, true)
   }
   if (rem) {  // (uniform: R is the same for every thread)
@@ -178,13 +188,13 @@ __device__ __forceinline__ void snake_fast(const char* src, char* dst, int o0, i
 
 // First / last tiles of an utterance (and utterances shorter than a tile): rows read at clamp(t, 0, T-1), s read at
 // clamp(m, 0, 2T-1), rows outside [0, T) written as zeros (the conv's zero padding).  dst rows [o0, o0 + n).
-template <typename E, int S>
+template <typename E, int SS, int S>
 __device__ __forceinline__ void snake_edge(const char* src, char* dst, int tsrc0, int tdst0, int o0, int n, int Tlen, int c2,
                                            const float (&fup2)[12], const float (&fdn)[12], float w0, float w1, float inv0,
                                            float inv1) {
   auto ldx = [&](int t, float& a, float& b) {
     const int row = min(max(t, 0), Tlen - 1) - tsrc0;
-    E::unpack(*reinterpret_cast<const uint32_t*>(src + row * S + c2), a, b);
+    E::unpack(*reinterpret_cast<const uint32_t*>(src + (int64_t)row * SS + c2), a, b);
   };
   auto st = [&](int i, float a, float b) { *reinterpret_cast<uint32_t*>(dst + i * S + c2) = E::pack(a, b); };
   const int ta = tdst0 + o0, tb = ta + n;
@@ -217,7 +227,7 @@ __device__ __forceinline__ void snake_edge(const char* src, char* dst, int tsrc0
   {                                                                                         \
     const int tp = tg + (K);                                                                \
     const int rowc = min(max(tp + 6, 0), Tlen - 1) - tsrc0;                                 \
-    const uint32_t raw = *reinterpret_cast<const uint32_t*>(src + rowc * S + c2);           \
+    const uint32_t raw = *reinterpret_cast<const uint32_t*>(src + (int64_t)rowc * SS + c2);  \
     AF_STEP_CORE(K, raw)                                                                    \
     const int m1 = 2 * tp + 7;                                                              \
     if (m1 > mlast) { soa = sa[(2 * (K) + 11) % 12]; sob = sb[(2 * (K) + 11) % 12]; }       \
@@ -241,40 +251,45 @@ __device__ __forceinline__ int frag_channel16(int f, int i) { return (f >> 1) * 
 
 // Implicit-GEMM conv over the LDS-resident activation image for the wave's MG row fragments x the fragment pair h:
 //   acc[mi][u] = sum_{j, ci} W[co(2h + u, .), j, ci] * act[(mf0 + mi) * 16 + lr + j * dil][ci]
-// Weight fragments straight from global memory (two 16-byte loads per lane per K step, requested two steps ahead),
-// activation fragments from LDS.
+// Weight fragments straight from global memory into registers, requested two K steps ahead, from the FRAGMENT STREAM
+// (ptpp_amp_pack_wstream): vector (s * C/16 + f) * 64 + lane of the stream is lane's 16 bytes of the MFMA "A" fragment f of
+// K step s = (tap j, 32-channel block kc) -- a wave reads 2 KiB contiguous per step.  (Reading the same fragments from the
+// [Cout][ks][Cin] operand touches 32 separate 64-byte pieces per wave-load, half a cache line each, which the 32 KiB L1 has
+// evicted before the next K step asks for the other half: measured 2.8 ms of a 3.9 ms layer at C = 64, k = 11, against
+// 0.98 ms with the loads removed -- profiles/r05_amp_phases.txt.)  Activation fragments from LDS.
 template <typename E, int C, int S, int MG>
-__device__ __forceinline__ void conv_pair(const char* act, const uint16_t* __restrict__ wp, int ks, int dil, int mf0, int nmf,
-                                          int h, int lane, f32x4 (&acc)[MG][2]) {
+__device__ __forceinline__ void conv_pair(const char* act, const uint4* __restrict__ ws, int ks, int dil, int mf0, int nmf,
+                                          int h, int lane, f32x4 (&acc)[MG][2], int dbg = 0) {
   constexpr int NKC = C / 32;
+  constexpr int NF = C / 16;
   const int lr = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int mi = 0; mi < MG; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  const uint16_t* wr0 = wp + (int64_t)frag_channel16(2 * h, lr) * ks * C + lg * 8;
-  const uint16_t* wr1 = wp + (int64_t)frag_channel16(2 * h + 1, lr) * ks * C + lg * 8;
-  const int steps = ks * NKC;  // step s = (tap j, 32-channel block kc): weight offset j * C + kc * 32 = 32 s
+  if (dbg & 128) __builtin_amdgcn_s_setprio(3);
+  const uint4* wr = ws + 2 * h * 64 + lane;  // + s * NF * 64 per step; the pair's second fragment 64 vectors on
+  const int steps = ks * NKC;
   const char* abase[MG];
 #pragma unroll
   for (int mi = 0; mi < MG; ++mi) abase[mi] = act + ((mf0 + (mi < nmf ? mi : 0)) * 16 + lr) * S + lg * 16;
   const int dS = dil * S;
   // three weight register sets in rotation, no moves: step s reads set s % 3 and requests step s + 2 into set (s + 2) % 3
   uint4 w[3][2];
-  w[0][0] = *reinterpret_cast<const uint4*>(wr0);
-  w[0][1] = *reinterpret_cast<const uint4*>(wr1);
+  w[0][0] = wr[0];
+  w[0][1] = wr[64];
   w[1][0] = w[0][0]; w[1][1] = w[0][1];
   if (steps > 1) {
-    w[1][0] = *reinterpret_cast<const uint4*>(wr0 + 32);
-    w[1][1] = *reinterpret_cast<const uint4*>(wr1 + 32);
+    w[1][0] = wr[NF * 64];
+    w[1][1] = wr[NF * 64 + 64];
   }
   w[2][0] = w[0][0]; w[2][1] = w[0][1];
 #define AF_CONV_STEP(CUR, NXT, SI)                                                                  \
   {                                                                                                 \
     const int s_ = (SI);                                                                            \
-    if (s_ + 2 < steps) {                                                                           \
-      w[NXT][0] = *reinterpret_cast<const uint4*>(wr0 + (s_ + 2) * 32);                             \
-      w[NXT][1] = *reinterpret_cast<const uint4*>(wr1 + (s_ + 2) * 32);                             \
+    if (s_ + 2 < steps && !(dbg & 16)) {                                                            \
+      w[NXT][0] = wr[(s_ + 2) * NF * 64];                                                           \
+      w[NXT][1] = wr[(s_ + 2) * NF * 64 + 64];                                                      \
     }                                                                                               \
-    const int off = (s_ / NKC) * dS + (s_ % NKC) * 64;                                              \
+    const int off = (dbg & 32) ? 0 : (s_ / NKC) * dS + (s_ % NKC) * 64;                             \
     uint4 xf[MG];                                                                                   \
     _Pragma("unroll") for (int mi = 0; mi < MG; ++mi) xf[mi] = *reinterpret_cast<const uint4*>(abase[mi] + off); \
     _Pragma("unroll") for (int mi = 0; mi < MG; ++mi) {                                             \
@@ -288,6 +303,19 @@ __device__ __forceinline__ void conv_pair(const char* act, const uint16_t* __res
     if (s + 2 < steps) AF_CONV_STEP(2, 1, s + 2)
   }
 #undef AF_CONV_STEP
+  if (dbg & 128) __builtin_amdgcn_s_setprio(0);
+}
+
+// [Cout][ks][Cin] operand -> fragment stream (one 16-byte vector per thread)
+__global__ __launch_bounds__(256) void amp_wstream_kernel(const uint16_t* __restrict__ wp, uint4* __restrict__ out, int C, int ks) {
+  const int NKC = C / 32, NF = C / 16;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= ks * NKC * NF * 64) return;
+  const int lane = q & 63, f = (q >> 6) % NF, s = (q >> 6) / NF;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int j = s / NKC, kc = s - j * NKC;
+  const int co = frag_channel16(f, lr);
+  out[q] = *reinterpret_cast<const uint4*>(wp + ((int64_t)co * ks + j) * C + kc * 32 + lg * 8);
 }
 
 template <typename E, int C, int BT, int S, int MG1, int MG2>
@@ -312,6 +340,14 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
   char* As = smem + p.rowsX * S;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Two workgroups share a CU and walk the same phases: started together they stay in lock step (both in a VALU phase, then
+  // both in an MFMA phase).  The second block of every CU starts half a tile late; the offset persists, one block's Snake
+  // then runs beside the other's conv.
+  const int slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) >> 1;  // HW_ID.wave_id / 2: 0 = first, 1 = second block of the CU
+  if (p.stagger && slot && blockIdx.x < 512)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  int skip = p.skip;
+  if (skip & 64) skip = slot ? (skip | 5) : (skip | 10);  // experiment: one block of the CU only Snakes, the other only convs
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = lid % p.nMT, b = lid / p.nMT;
   const int t0 = mt * BT;
@@ -338,16 +374,16 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
   __syncthreads();
 
   // ---- P1: snake 1: X -> A (a1 rows [0, n_a1); time ta0 + i) ----
-  if (!(p.skip & 1)) {
-    float fu[12], fd[12];  // the taps as scalars (a pointer into the by-value argument block would spill it)
+  if (!(skip & 1)) {
+    float fu[12], fd[12];  // the taps in VECTOR registers (in_vgpr)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { fu[i] = 2.0f * p.up1[i]; fd[i] = p.dn1[i]; }
+    for (int i = 0; i < 12; ++i) { fu[i] = in_vgpr(2.0f * p.up1[i]); fd[i] = in_vgpr(p.dn1[i]); }
     const int o0 = run * p.R1;
     if (interior) {
-      snake_fast<E, S>(Xs, As, o0, p.R1, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+      snake_fast<E, S, S>(Xs, As, o0, p.R1, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
     } else {
       const int n = min(p.R1, n_a1 - o0);
-      if (n > 0) snake_edge<E, S>(Xs, As, tx0, ta0, o0, n, Tlen, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+      if (n > 0) snake_edge<E, S, S>(Xs, As, tx0, ta0, o0, n, Tlen, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
     }
   }
   __syncthreads();
@@ -355,13 +391,13 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
   const int wn = wave % WN, wm = wave / WN;
   const int lr = lane & 15, lg = lane >> 4;
   // ---- P2: conv1 (dilated): A -> c1 rows [0, M1) in X ----
-  if (!(p.skip & 2)) {
+  if (!(skip & 2)) {
     const int nfr = M1 / 16;
     const int per = (nfr + WM - 1) / WM;  // <= MG1 (host)
     const int mf0 = wm * per, nmf = min(per, nfr - mf0);
     if (nmf > 0) {
       f32x4 acc[MG1][2];
-      conv_pair<E, C, S, MG1>(As, reinterpret_cast<const uint16_t*>(p.w1p), ks, dil, mf0, nmf, wn, lane, acc);
+      conv_pair<E, C, S, MG1>(As, reinterpret_cast<const uint4*>(p.w1p), ks, dil, mf0, nmf, wn, lane, acc, skip);
       const int co = wn * 32 + lg * 8;
       const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + co), bB = *reinterpret_cast<const f32x4*>(p.b1 + co + 4);
 #pragma unroll
@@ -384,17 +420,17 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
   __syncthreads();
 
   // ---- P3: snake 2: c1 (X) -> a2 rows [0, BT + 2 pad2) in A; time t0 - pad2 + i ----
-  if (!(p.skip & 4)) {
+  if (!(skip & 4)) {
     const int n_a2 = BT + 2 * pad2;
     float fu[12], fd[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { fu[i] = 2.0f * p.up2[i]; fd[i] = p.dn2[i]; }
+    for (int i = 0; i < 12; ++i) { fu[i] = in_vgpr(2.0f * p.up2[i]); fd[i] = in_vgpr(p.dn2[i]); }
     const int o0 = run * p.R2;
     if (interior) {
-      snake_fast<E, S>(Xs, As, o0, p.R2, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+      snake_fast<E, S, S>(Xs, As, o0, p.R2, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
     } else {
       const int n = min(p.R2, n_a2 - o0);
-      if (n > 0) snake_edge<E, S>(Xs, As, tc0, t0 - pad2, o0, n, Tlen, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+      if (n > 0) snake_edge<E, S, S>(Xs, As, tc0, t0 - pad2, o0, n, Tlen, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
     }
   }
   __syncthreads();
@@ -428,7 +464,7 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
           q2[mi] = (mi < nmf && t < Tlen) ? *reinterpret_cast<const uint4*>(r2b + (int64_t)t * C + co) : make_uint4(0, 0, 0, 0);
         }
       }
-      if (!(p.skip & 8)) conv_pair<E, C, S, MG2>(As, reinterpret_cast<const uint16_t*>(p.w2p), ks, 1, mf0, nmf, wn, lane, acc);
+      if (!(skip & 8)) conv_pair<E, C, S, MG2>(As, reinterpret_cast<const uint4*>(p.w2p), ks, 1, mf0, nmf, wn, lane, acc, skip);
       else {
 #pragma unroll
         for (int mi = 0; mi < MG2; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
@@ -481,23 +517,202 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
   }
 }
 
-template <typename E, int C, int BT, int S, int MG1, int MG2>
-int launch_amp_fused(AmpF& p, hipStream_t st) {
+// ---- wide stages (C = 128, 256): the anti-aliased Snake applied while the conv's input tile is staged ----------------------
+//   y = res_scale * res + out_scale * (conv(snake(x)) + bias) [+ res2]      (bigvgan.py:42-47, one of the two convs of a layer)
+// The Snake reads x STRAIGHT FROM GLOBAL MEMORY (a wave-load is two 128-byte row pieces, fully used; the next 6-step group is
+// requested one group ahead) and writes its output rows into the LDS image the MFMAs read: no x image, no separate Snake launch,
+// the activated tensor never exists in HBM (round 4: 37 aa_snake launches x 822 MB).  Full fusion of the layer (amp_fused_kernel)
+// does not pay here: the conv1 halo would be recomputed on the matrix cores (x 1.5 at 64-row tiles) and the weights (0.4-1.4 MB per
+// conv) stream from L2 either way.
+struct SnkP {
+  const void* x;
+  void* y;
+  const void* res;
+  const void* res2;
+  const void* ws;      // fragment stream of the conv weights
+  const float* bias;
+  const float* la;
+  float up[12], dn[12];
+  int B, T, ks, dil;
+  float out_scale, res_scale;
+  int nMT, R, rowsA;
+  int skip;
+};
+
+template <typename E, int C, int BT, int S, int MG>
+__global__ __launch_bounds__(512, 4) void snake_conv_kernel(const SnkP p) {
+  constexpr int NT = 512;
+  constexpr int NCH = C / 8;
+  constexpr int CP = C / 2;
+  constexpr int NRUN = NT / CP;       // row runs of the Snake (C = 128: 8, C = 256: 4)
+  constexpr int WN = C / 32 > 8 ? 8 : C / 32;   // waves along the output channels
+  constexpr int WM = 8 / WN;          // waves along the rows
+  constexpr int NPW = C / 32 / WN;    // channel-fragment pairs per wave (1)
+  static_assert(NPW == 1 && MG * WM * 16 == BT && S % 16 == 0 && S >= C * 2, "geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;
+  const int ks = p.ks, dil = p.dil, Tlen = p.T;
+  const int pad = dil * (ks - 1) / 2;
+  const int n_a = BT + 2 * pad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid % p.nMT, b = lid / p.nMT;
+  const int t0 = mt * BT;
+  const int ta0 = t0 - pad;          // time of A row 0
+  const int tx0 = ta0 - 6;           // time of the first x row the Snake reads
+  // interior: every row a run reads (its overhang and the prefetched group included) lies inside the utterance
+  const bool interior = tx0 >= 0 && tx0 + NRUN * p.R + 17 <= Tlen;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)b * Tlen * C;
+  const int cpair = tid % CP, run = tid / CP;
+  constexpr float WSC = 0.15915494309189535f;
+  float ea0, ea1, inv0, inv1;
+  {
+    const float a0 = __expf(p.la[2 * cpair]), a1 = __expf(p.la[2 * cpair + 1]);
+    ea0 = a0 * WSC; ea1 = a1 * WSC; inv0 = 1.0f / (a0 + 1e-9f); inv1 = 1.0f / (a1 + 1e-9f);
+  }
+  // ---- P1: Snake: global x -> A rows [0, n_a) ----
+  if (!(p.skip & 1)) {
+    float fu[12], fd[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { fu[i] = in_vgpr(2.0f * p.up[i]); fd[i] = in_vgpr(p.dn[i]); }
+    const int o0 = run * p.R;
+    const char* src = reinterpret_cast<const char*>(xb) + (int64_t)tx0 * (C * 2);
+    if (interior) {
+      snake_fast<E, C * 2, S>(src, As, o0, p.R, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+    } else {
+      const int n = min(p.R, n_a - o0);
+      if (n > 0) snake_edge<E, C * 2, S>(src, As, tx0, ta0, o0, n, Tlen, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+    }
+  }
+  // the residual rows of the tile, row-contiguous, requested before the MFMAs and parked in the output image after them
+  constexpr int NRV = BT * NCH / NT;
+  static_assert(NRV * NT == BT * NCH, "tile vectors must divide over the threads");
+  uint4 rx[NRV];
+  if (p.res) {
+    const uint16_t* rb = reinterpret_cast<const uint16_t*>(p.res) + (int64_t)b * Tlen * C;
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx / NCH, ch = idx - r * NCH;
+      const int t = t0 + r;
+      rx[i] = t < Tlen ? *reinterpret_cast<const uint4*>(rb + (int64_t)t * C + ch * 8) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- P2: conv on the matrix cores ----
+  const int wn = wave % WN, wm = wave / WN;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int mf0 = wm * MG;
+  const int co = wn * 32 + lg * 8;
+  const uint16_t* r2b = p.res2 ? reinterpret_cast<const uint16_t*>(p.res2) + (int64_t)b * Tlen * C : nullptr;
+  uint4 q2[MG];
+  if (r2b) {
+#pragma unroll
+    for (int mi = 0; mi < MG; ++mi) {
+      const int t = t0 + (mf0 + mi) * 16 + lr;
+      q2[mi] = t < Tlen ? *reinterpret_cast<const uint4*>(r2b + (int64_t)t * C + co) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  f32x4 acc[MG][2];
+  if (!(p.skip & 2)) conv_pair<E, C, S, MG>(As, reinterpret_cast<const uint4*>(p.ws), ks, dil, mf0, MG, wn, lane, acc, p.skip);
+  else {
+#pragma unroll
+    for (int mi = 0; mi < MG; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
+  }
+  __syncthreads();  // every wave is done with the A image: it becomes the output tile
+
+  // ---- P3: epilogue through the LDS image of the output tile ----
+  if (p.res) {
+#pragma unroll
+    for (int i = 0; i < NRV; ++i) {
+      const int idx = tid + i * NT;
+      const int r = idx / NCH, ch = idx - r * NCH;
+      *reinterpret_cast<uint4*>(As + r * S + ch * 16) = rx[i];
+    }
+    __syncthreads();
+  }
+  {
+    const float osc = p.out_scale, rsc = p.res_scale;
+    const f32x4 bA = *reinterpret_cast<const f32x4*>(p.bias + co), bB = *reinterpret_cast<const f32x4*>(p.bias + co + 4);
+#pragma unroll
+    for (int mi = 0; mi < MG; ++mi) {
+      const int r = (mf0 + mi) * 16 + lr;
+      f32x4 v0 = (acc[mi][0] + bA) * osc, v1 = (acc[mi][1] + bB) * osc;
+      uint4* slot = reinterpret_cast<uint4*>(As + r * S + (wn * 4 + lg) * 16);
+      float e0, e1;
+      if (p.res) {
+        const uint4 rr = *slot;
+        E::unpack(rr.x, e0, e1); v0[0] += e0 * rsc; v0[1] += e1 * rsc;
+        E::unpack(rr.y, e0, e1); v0[2] += e0 * rsc; v0[3] += e1 * rsc;
+        E::unpack(rr.z, e0, e1); v1[0] += e0 * rsc; v1[1] += e1 * rsc;
+        E::unpack(rr.w, e0, e1); v1[2] += e0 * rsc; v1[3] += e1 * rsc;
+      }
+      if (r2b) {
+        const uint4 q = q2[mi];
+        E::unpack(q.x, e0, e1); v0[0] += e0; v0[1] += e1;
+        E::unpack(q.y, e0, e1); v0[2] += e0; v0[3] += e1;
+        E::unpack(q.z, e0, e1); v1[0] += e0; v1[1] += e1;
+        E::unpack(q.w, e0, e1); v1[2] += e0; v1[3] += e1;
+      }
+      uint4 o;
+      o.x = E::pack(v0[0], v0[1]); o.y = E::pack(v0[2], v0[3]);
+      o.z = E::pack(v1[0], v1[1]); o.w = E::pack(v1[2], v1[3]);
+      *slot = o;
+    }
+  }
+  __syncthreads();
+  uint16_t* yb = reinterpret_cast<uint16_t*>(p.y) + (int64_t)b * Tlen * C;
+#pragma unroll
+  for (int i = 0; i < NRV; ++i) {
+    const int idx = tid + i * NT;
+    const int r = idx / NCH, ch = idx - r * NCH;
+    const int t = t0 + r;
+    if (t < Tlen) *reinterpret_cast<uint4*>(yb + (int64_t)t * C + ch * 8) = *reinterpret_cast<const uint4*>(As + r * S + ch * 16);
+  }
+}
+
+template <typename E, int C, int BT, int S, int MG>
+int launch_snake_conv(SnkP& p, hipStream_t st) {
   constexpr int NRUN = 512 / (C / 2);
-  constexpr int WM = 8 / (C / 32);
+  const int pad = p.dil * (p.ks - 1) / 2;
+  const int n_a = BT + 2 * pad;
+  p.R = (n_a + NRUN - 1) / NRUN;
+  int rowsA = n_a > NRUN * p.R ? n_a : NRUN * p.R;
+  if (rowsA < BT) rowsA = BT;
+  p.rowsA = rowsA;
+  const size_t smem = (size_t)rowsA * S;
+  if (smem > 160 * 1024) {
+    ptpp_set_error("snake_conv: LDS tile too large (%zu B)", smem);
+    return PTPP_ENOTSUP;
+  }
+  auto kern = snake_conv_kernel<E, C, BT, S, MG>;
+  if (smem > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+      ptpp_set_error("snake_conv: cannot raise the dynamic LDS limit to %zu B: %s", smem, hipGetErrorString(e));
+      return PTPP_ELAUNCH;
+    }
+  }
+  p.nMT = (p.T + BT - 1) / BT;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, st, p);
+  PTPP_CHECK_LAUNCH("snake_conv1d_fwd");
+  return PTPP_OK;
+}
+
+// LDS geometry of one block (shared by the size query and the launch)
+template <int C, int BT, int S>
+size_t amp_fused_geometry(AmpF& p) {
+  constexpr int NRUN = 512 / (C / 2);
   const int pad1 = p.dil * (p.ks - 1) / 2, pad2 = (p.ks - 1) / 2;
   const int n_c1 = BT + 2 * pad2 + 12, M1 = (n_c1 + 15) & ~15;
   const int n_a1 = n_c1 + 2 * pad1, n_x = n_a1 + 12, n_a2 = BT + 2 * pad2;
-  if ((M1 / 16 + WM - 1) / WM > MG1) {
-    ptpp_set_error("amp_fused: ks=%d needs %d conv1 row fragments per wave (built for %d)", p.ks, (M1 / 16 + WM - 1) / WM, MG1);
-    return PTPP_ENOTSUP;
-  }
   p.R1 = (n_a1 + NRUN - 1) / NRUN;
   p.R2 = (n_a2 + NRUN - 1) / NRUN;
-  // interior tiles walk NRUN equal runs: the last run may overhang the image by up to NRUN - 1 rows it reads (+ 12 rows of
-  // halo + one prefetched group) and writes
+  // interior tiles walk NRUN equal runs: the last run may overhang the image (rows it reads: up to o0 + R + 16 with the
+  // prefetched group; rows it writes: up to NRUN * R)
   int rowsX = n_x > M1 ? n_x : M1;
-  const int need1 = NRUN * p.R1 + 24, need2 = NRUN * p.R2 + 24;
+  const int need1 = NRUN * p.R1 + 17, need2 = NRUN * p.R2 + 17;
   if (rowsX < need1) rowsX = need1;
   if (rowsX < need2) rowsX = need2;
   int rowsA = M1 + 2 * pad1;
@@ -505,7 +720,20 @@ int launch_amp_fused(AmpF& p, hipStream_t st) {
   if (rowsA < NRUN * p.R1) rowsA = NRUN * p.R1;
   if (rowsA < NRUN * p.R2) rowsA = NRUN * p.R2;
   p.rowsX = rowsX;
-  const size_t smem = (size_t)(rowsX + rowsA) * S;
+  return (size_t)(rowsX + rowsA) * S;
+}
+
+template <typename E, int C, int BT, int S, int MG1, int MG2>
+int launch_amp_fused(AmpF& p, hipStream_t st) {
+  constexpr int WM = 8 / (C / 32);
+  const int pad2 = (p.ks - 1) / 2;
+  const int n_c1 = BT + 2 * pad2 + 12, M1 = (n_c1 + 15) & ~15;
+  if ((M1 / 16 + WM - 1) / WM > MG1) {
+    ptpp_set_error("amp_fused: ks=%d needs %d conv1 row fragments per wave (built for %d)", p.ks, (M1 / 16 + WM - 1) / WM, MG1);
+    return PTPP_ENOTSUP;
+  }
+  size_t smem = amp_fused_geometry<C, BT, S>(p);
+  if (getenv("PTPP_AMP_ONE_BLOCK")) smem = 100 * 1024;  // experiment: one workgroup per CU
   if (smem > 160 * 1024) {
     ptpp_set_error("amp_fused: LDS tile too large (%zu B)", smem);
     return PTPP_ENOTSUP;
@@ -524,12 +752,23 @@ int launch_amp_fused(AmpF& p, hipStream_t st) {
   return PTPP_OK;
 }
 
+// the tallest tile whose LDS image leaves room for a second workgroup on the CU (2 x 80 KiB)
+template <typename E, int C, int S, int BT0, int BT1, int BT2, int MGA0, int MGB0, int MGA1, int MGB1, int MGA2, int MGB2>
+int launch_amp_fused_pick(AmpF& p, hipStream_t st, int variant) {
+  constexpr size_t HALF = 80 * 1024;
+  if (variant == 0 || variant == 1)
+    if (variant == 1 || amp_fused_geometry<C, BT0, S>(p) <= HALF) return launch_amp_fused<E, C, BT0, S, MGA0, MGB0>(p, st);
+  if (variant == 0 || variant == 2)
+    if (variant == 2 || amp_fused_geometry<C, BT1, S>(p) <= HALF) return launch_amp_fused<E, C, BT1, S, MGA1, MGB1>(p, st);
+  return launch_amp_fused<E, C, BT2, S, MGA2, MGB2>(p, st);
+}
+
 }  // namespace
 
 // called by ptpp_amp_layer_fwd (amp_layer.hip) for 16-bit tensors; variant: PTPP_AMP_VARIANT (experiments)
 int amp_fused_launch_16bit(const ptpp_amp_layer_args* a, void* stream) {
   AmpF p;
-  p.x = a->x; p.y = a->y; p.res2 = a->res2; p.w1p = a->w1p; p.w2p = a->w2p; p.b1 = a->b1; p.b2 = a->b2;
+  p.x = a->x; p.y = a->y; p.res2 = a->res2; p.w1p = a->w1s; p.w2p = a->w2s; p.b1 = a->b1; p.b2 = a->b2;
   p.la1 = a->log_alpha1; p.la2 = a->log_alpha2;
   for (int i = 0; i < 12; ++i) {
     p.up1[i] = a->up1[i]; p.dn1[i] = a->dn1[i]; p.up2[i] = a->up2[i]; p.dn2[i] = a->dn2[i];
@@ -541,18 +780,53 @@ int amp_fused_launch_16bit(const ptpp_amp_layer_args* a, void* stream) {
   const int variant = getenv("PTPP_AMP_VARIANT") ? atoi(getenv("PTPP_AMP_VARIANT")) : 0;
   p.skip = skip;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  p.stagger = getenv("PTPP_AMP_STAGGER") ? atoi(getenv("PTPP_AMP_STAGGER")) : 0;
+  // variant 0: tallest tile that keeps two workgroups per CU; 1 / 2 / 3: force the first / second / third height
   if (a->dtype == PTPP_BF16) {
-    if (a->C == 64) {
-      if (variant == 1) return launch_amp_fused<EB16, 64, 160, 160, 3, 3>(p, st);
-      if (variant == 2) return launch_amp_fused<EB16, 64, 128, 144, 3, 2>(p, st);
-      return launch_amp_fused<EB16, 64, 192, 144, 4, 3>(p, st);
+    if (variant >= 4) {  // conflict-free row strides (16 (4 n + 2) bytes): more LDS per row, shorter tiles
+      if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 160, 176, 160, 128, 4, 3, 3, 3, 3, 2>(p, st, variant - 4);
+      if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 96, 320, 288, 256, 3, 3, 3, 3, 3, 2>(p, st, variant - 4);
     }
-    if (a->C == 32) {
-      if (variant == 1) return launch_amp_fused<EB16, 32, 320, 96, 3, 3>(p, st);
-      if (variant == 2) return launch_amp_fused<EB16, 32, 256, 80, 3, 2>(p, st);
-      return launch_amp_fused<EB16, 32, 384, 80, 4, 3>(p, st);
-    }
+    if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 144, 192, 160, 128, 4, 3, 3, 3, 3, 2>(p, st, variant);
+    if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 80, 384, 320, 256, 4, 3, 3, 3, 3, 2>(p, st, variant);
   }
   ptpp_set_error("amp_fused: C=%d dtype=%d not built", a->C, a->dtype);
   return PTPP_ENOTSUP;
+}
+
+extern "C" int ptpp_snake_conv1d_supported(int C, int dtype) { return dtype == PTPP_BF16 && (C == 128 || C == 256); }
+
+extern "C" int ptpp_snake_conv1d_fwd(const ptpp_snake_conv_args* a, void* stream) {
+  PTPP_CHECK_ARG(a && a->x && a->y && a->ws && a->bias && a->log_alpha, "snake_conv: null pointer");
+  PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->ks >= 1 && (a->ks & 1) && a->ks <= 15 && a->dil >= 1 && a->dil <= 8,
+                 "snake_conv: bad shape B=%d T=%d ks=%d dil=%d", a->B, a->T, a->ks, a->dil);
+  PTPP_CHECK_ARG(a->x != a->y, "snake_conv: in-place not supported (neighbouring tiles read the halo)");
+  PTPP_CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->res | (uintptr_t)a->res2 | (uintptr_t)a->ws | (uintptr_t)a->bias) & 15) == 0,
+                 "snake_conv: pointers must be 16-byte aligned");
+  if (!ptpp_snake_conv1d_supported(a->C, a->dtype)) {
+    ptpp_set_error("snake_conv: C=%d dtype=%d not built (C in {128, 256}, 16-bit)", a->C, a->dtype);
+    return PTPP_ENOTSUP;
+  }
+  SnkP p;
+  p.x = a->x; p.y = a->y; p.res = a->res; p.res2 = a->res2; p.ws = a->ws; p.bias = a->bias; p.la = a->log_alpha;
+  for (int i = 0; i < 12; ++i) { p.up[i] = a->up[i]; p.dn[i] = a->dn[i]; }
+  p.B = a->B; p.T = a->T; p.ks = a->ks; p.dil = a->dil;
+  p.out_scale = a->out_scale; p.res_scale = a->res_scale;
+  p.nMT = 0; p.R = 0; p.rowsA = 0;
+  p.skip = getenv("PTPP_AMP_SKIP") ? atoi(getenv("PTPP_AMP_SKIP")) : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->C == 128) return launch_snake_conv<EB16, 128, 128, 272, 4>(p, st);
+  return launch_snake_conv<EB16, 256, 64, 528, 4>(p, st);
+}
+
+extern "C" int ptpp_amp_pack_wstream(const void* wp, void* out, int C, int ks, int dtype, void* stream) {
+  PTPP_CHECK_ARG(wp && out && wp != out, "amp_pack_wstream: null / aliased pointer");
+  PTPP_CHECK_ARG(dtype == PTPP_BF16 && (C == 32 || C == 64 || C == 128 || C == 256) && ks >= 1 && ks <= 15,
+                 "amp_pack_wstream: C=%d ks=%d dtype=%d not built", C, ks, dtype);
+  PTPP_CHECK_ARG((((uintptr_t)wp | (uintptr_t)out) & 15) == 0, "amp_pack_wstream: pointers must be 16-byte aligned");
+  const int n = ks * (C / 32) * (C / 16) * 64;
+  hipLaunchKernelGGL(amp_wstream_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const uint16_t*>(wp), reinterpret_cast<uint4*>(out), C, ks);
+  PTPP_CHECK_LAUNCH("amp_pack_wstream");
+  return PTPP_OK;
 }

@@ -524,12 +524,15 @@ extern "C" int ptpp_amp_layer_supported(int C, int dtype) {
 }
 
 extern "C" int ptpp_amp_layer_fwd(const ptpp_amp_layer_args* a, void* stream) {
-  PTPP_CHECK_ARG(a && a->x && a->y && a->w1p && a->w2p && a->b1 && a->b2 && a->log_alpha1 && a->log_alpha2,
-                 "amp_layer: null pointer");
+  PTPP_CHECK_ARG(a && a->x && a->y && a->b1 && a->b2 && a->log_alpha1 && a->log_alpha2, "amp_layer: null pointer");
+  const bool old16 = getenv("PTPP_AMP_OLD") && atoi(getenv("PTPP_AMP_OLD"));  // A/B: the round-2 kernel for 16-bit tensors
+  const bool fused16 = a->dtype == PTPP_BF16 && !old16;
+  PTPP_CHECK_ARG(fused16 ? (a->w1s && a->w2s) : (a->w1p && a->w2p), "amp_layer: null weight operand (%s)",
+                 fused16 ? "16-bit tensors take the fragment streams w1s / w2s" : "w1p / w2p");
   PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->ks >= 1 && (a->ks & 1) && a->ks <= 15 && a->dil >= 1 && a->dil <= 8,
                  "amp_layer: bad shape B=%d T=%d ks=%d dil=%d", a->B, a->T, a->ks, a->dil);
   PTPP_CHECK_ARG(a->x != a->y, "amp_layer: in-place not supported (neighbouring tiles read the halo)");
-  PTPP_CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->res2 | (uintptr_t)a->w1p | (uintptr_t)a->w2p |
+  PTPP_CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->res2 | (uintptr_t)a->w1p | (uintptr_t)a->w2p | (uintptr_t)a->w1s | (uintptr_t)a->w2s |
                    (uintptr_t)a->b1 | (uintptr_t)a->b2) & 15) == 0, "amp_layer: pointers must be 16-byte aligned");
   if (!ptpp_amp_layer_supported(a->C, a->dtype)) {
     ptpp_set_error("amp_layer: C=%d dtype=%d not built (C in {32, 64})", a->C, a->dtype);
@@ -546,8 +549,7 @@ extern "C" int ptpp_amp_layer_fwd(const ptpp_amp_layer_args* a, void* stream) {
   p.nMT = 0;
   p.skip = getenv("PTPP_AMP_SKIP") ? atoi(getenv("PTPP_AMP_SKIP")) : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool old16 = getenv("PTPP_AMP_OLD") && atoi(getenv("PTPP_AMP_OLD"));  // A/B: the round-2 kernel
-  if (a->dtype == PTPP_BF16 && !old16) return amp_fused_launch_16bit(a, stream);
+  if (fused16) return amp_fused_launch_16bit(a, stream);
   if (a->dtype == PTPP_BF16) {
     // (the FIRs-on-MFMA experiment of round 2 -- not run-to-run reproducible with two workgroups per CU -- left the library in
     //  round 4: tools/experiments/r02_amp_layer_mfma.hip.txt)

@@ -864,17 +864,50 @@ def amp_layer_supported(C, dtype):
     return bool(_lib.load().ptpp_amp_layer_supported(int(C), dtype_code(dtype)))
 
 
+def amp_pack_wstream(wp, C, ks):
+    """Packed (C, ks, C) conv operand -> the fragment stream the 16-bit fused AMP layer reads (ptpp_amp_pack_wstream)."""
+    _need_gpu(wp)
+    assert wp.is_contiguous() and wp.numel() == C * ks * C
+    out = torch.empty_like(wp)
+    check(_lib.load().ptpp_amp_pack_wstream(wp.data_ptr(), out.data_ptr(), int(C), int(ks), dtype_code(wp.dtype), _stream()),
+          "ptpp_amp_pack_wstream")
+    return out
+
+
+_AMP_WSTREAMS = {}
+
+
+def _amp_wstream(wp, C, ks):
+    """Fragment stream of a packed operand, cached per (storage, version) -- callers that hold their own copy (BigVGAN._prepare)
+    pass it as ``ws1`` / ``ws2`` instead."""
+    key = (wp.data_ptr(), wp._version, int(C), int(ks), wp.dtype)
+    hit = _AMP_WSTREAMS.get(key)
+    if hit is None or hit[0]() is None:
+        import weakref
+
+        if len(_AMP_WSTREAMS) > 256:
+            _AMP_WSTREAMS.clear()
+        hit = (weakref.ref(wp), amp_pack_wstream(wp, C, ks))
+        _AMP_WSTREAMS[key] = hit
+    return hit[1]
+
+
 def amp_layer(x, w1p, b1, w2p, b2, log_alpha1, log_alpha2, taps1, taps2, ks, dil, res2=None, out_scale=1.0,
-              res_scale=1.0, out=None):
+              res_scale=1.0, out=None, ws1=None, ws2=None):
     """One fused AMP layer (ptpp_amp_layer_fwd): x (B,T,C) -> res_scale*x + out_scale*(conv2(act2(conv1(act1(x))))
-    + b2) [+ res2].  taps1 / taps2: (up, down) ctypes float[12] pairs of act1 / act2 (``_taps``)."""
+    + b2) [+ res2].  taps1 / taps2: (up, down) ctypes float[12] pairs of act1 / act2 (``_taps``).  16-bit tensors read the
+    weights as fragment streams (``ws1`` / ``ws2`` = amp_pack_wstream(w1p / w2p); built and cached here when not given)."""
     _need_gpu(x)
     assert x.is_contiguous() and x.dim() == 3
     B, T, C = x.shape
+    if x.dtype != torch.float32:
+        ws1 = ws1 if ws1 is not None else _amp_wstream(w1p, C, ks)
+        ws2 = ws2 if ws2 is not None else _amp_wstream(w2p, C, ks)
     y = out if out is not None else torch.empty_like(x)
     a = _lib.AmpLayerArgs()
     a.x, a.y, a.res2 = x.data_ptr(), y.data_ptr(), _ptr(res2)
     a.w1p, a.w2p, a.b1, a.b2 = w1p.data_ptr(), w2p.data_ptr(), b1.data_ptr(), b2.data_ptr()
+    a.w1s, a.w2s = _ptr(ws1), _ptr(ws2)
     a.log_alpha1, a.log_alpha2 = log_alpha1.data_ptr(), log_alpha2.data_ptr()
     a.up1, a.dn1 = taps1
     a.up2, a.dn2 = taps2
@@ -883,6 +916,29 @@ def amp_layer(x, w1p, b1, w2p, b2, log_alpha1, log_alpha2, taps1, taps2, ks, dil
     if res2 is not None:
         assert res2.is_contiguous() and res2.shape == x.shape and res2.dtype == x.dtype
     check(_lib.load().ptpp_amp_layer_fwd(ctypes.byref(a), _stream()), "ptpp_amp_layer_fwd")
+    return y
+
+
+def snake_conv1d_supported(C, dtype):
+    return bool(_lib.load().ptpp_snake_conv1d_supported(int(C), dtype_code(dtype)))
+
+
+def snake_conv1d(x, ws, bias, log_alpha, taps, ks, dil, res=None, res2=None, out_scale=1.0, res_scale=1.0, out=None):
+    """res_scale * res + out_scale * (conv(aa_snake(x)) + bias) [+ res2] in one launch (ptpp_snake_conv1d_fwd; wide BigVGAN
+    stages).  ws: amp_pack_wstream of the packed (C, ks, C) weight; taps: the (up, down) ctypes float[12] pair (``_taps``)."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dim() == 3
+    B, T, C = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    a = _lib.SnakeConvArgs()
+    a.x, a.y, a.res, a.res2 = x.data_ptr(), y.data_ptr(), _ptr(res), _ptr(res2)
+    a.ws, a.bias, a.log_alpha = ws.data_ptr(), bias.data_ptr(), log_alpha.data_ptr()
+    a.up, a.dn = taps
+    a.B, a.T, a.C, a.ks, a.dil = B, T, C, int(ks), int(dil)
+    a.out_scale, a.res_scale, a.dtype = float(out_scale), float(res_scale), dtype_code(x.dtype)
+    for t in (res, res2):
+        assert t is None or (t.is_contiguous() and t.shape == x.shape and t.dtype == x.dtype)
+    check(_lib.load().ptpp_snake_conv1d_fwd(ctypes.byref(a), _stream()), "ptpp_snake_conv1d_fwd")
     return y
 
 

@@ -134,6 +134,8 @@ class BigVGAN(nn.Module):
         self._packed_key = None
         self.parallel_blocks = True  # the 3 AMP blocks of a stage on 3 streams (stages without the fused layer kernel)
         self.fuse_amp_layers = True  # one kernel per AMP layer where ptpp_amp_layer_fwd is built (C = 32, 64)
+        self.fuse_wide_layers = True  # Snake + conv in one launch in the wide stages (C = 128, 256)
+        self.wide_streams = False    # the three AMP blocks of a wide stage on three streams (fused Snake + conv launches)
         self._streams = None
 
     # -- drop-in helpers ------------------------------------------------------
@@ -155,7 +157,7 @@ class BigVGAN(nn.Module):
 
     # -- weight cache -----------------------------------------------------------
     def _weights_key(self):
-        return (self.compute_dtype, self.fuse_amp_layers) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.compute_dtype, self.fuse_amp_layers, self.fuse_wide_layers) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     @torch.no_grad()
     def _prepare(self):
@@ -180,11 +182,20 @@ class BigVGAN(nn.Module):
                     c1 = _PackedConv(folded_weight(l.conv1), l.conv1.bias, l.conv1.dilation[0], l.conv1.padding[0], dt)
                     c2 = _PackedConv(folded_weight(l.conv2), l.conv2.bias, 1, l.conv2.padding[0], dt)
                     fused = None
-                    if self.fuse_amp_layers and c1.bias is not None and c2.bias is not None and c1.ks == c2.ks and \
-                            c1.pad == c1.dil * (c1.ks - 1) // 2 and c2.pad == (c2.ks - 1) // 2 and \
-                            ops.amp_layer_supported(c1.cout, dt):
+                    plain = c1.bias is not None and c2.bias is not None and c1.ks == c2.ks and \
+                        c1.pad == c1.dil * (c1.ks - 1) // 2 and c2.pad == (c2.ks - 1) // 2
+                    if self.fuse_amp_layers and plain and dt != torch.float32 and \
+                            (ops.amp_layer_supported(c1.cout, dt) or ops.snake_conv1d_supported(c1.cout, dt)):
+                        # 16-bit kernels read the weights as fragment streams; kind "amp": the whole layer is one launch
+                        # (C = 32, 64), "wide": one launch per conv with the Snake applied while its input is staged
+                        kind = "amp" if ops.amp_layer_supported(c1.cout, dt) else "wide"
+                        fused = None if (kind == "wide" and not self.fuse_wide_layers) else (l.act1.act.alpha.detach().reshape(-1).float().contiguous(),
+                                 l.act2.act.alpha.detach().reshape(-1).float().contiguous(), l.act1.taps(), l.act2.taps(),
+                                 ops.amp_pack_wstream(c1.wp, c1.cout, c1.ks), ops.amp_pack_wstream(c2.wp, c2.cout, c2.ks), kind)
+                    elif self.fuse_amp_layers and plain and ops.amp_layer_supported(c1.cout, dt):
                         fused = (l.act1.act.alpha.detach().reshape(-1).float().contiguous(),
-                                 l.act2.act.alpha.detach().reshape(-1).float().contiguous(), l.act1.taps(), l.act2.taps())
+                                 l.act2.act.alpha.detach().reshape(-1).float().contiguous(), l.act1.taps(), l.act2.taps(),
+                                 None, None, "amp")
                     layers.append((l.act1, c1, l.act2, c2, fused))
                 blocks.append(layers)
             pk["mrfs"].append(blocks)
@@ -217,8 +228,10 @@ class BigVGAN(nn.Module):
 
     def _mrf(self, h, blocks, inv):
         """Multi-receptive-field fusion of one stage: mean over the AMP blocks (bigvgan.py:124-128)."""
-        if all(l[4] is not None for blk in blocks for l in blk):
+        if all(l[4] is not None and l[4][6] == "amp" for blk in blocks for l in blk):
             return self._mrf_fused(h.contiguous(), blocks, inv)
+        if all(l[4] is not None and l[4][6] == "wide" for blk in blocks for l in blk):
+            return self._mrf_wide(h.contiguous(), blocks, inv)
         if self.parallel_blocks and h.is_cuda and len(blocks) == 3 and not torch.cuda.is_current_stream_capturing():
             return self._mrf_parallel(h, blocks, inv)
         acc = None
@@ -241,13 +254,54 @@ class BigVGAN(nn.Module):
         acc = None
         for layers in blocks:
             xb = h
-            for li, (_, c1, _, c2, (la1, la2, t1, t2)) in enumerate(layers):
+            for li, (_, c1, _, c2, (la1, la2, t1, t2, ws1, ws2, _k)) in enumerate(layers):
                 if li + 1 < len(layers):
-                    xb = ops.amp_layer(xb, c1.wp, c1.bias, c2.wp, c2.bias, la1, la2, t1, t2, c1.ks, c1.dil)
+                    xb = ops.amp_layer(xb, c1.wp, c1.bias, c2.wp, c2.bias, la1, la2, t1, t2, c1.ks, c1.dil, ws1=ws1, ws2=ws2)
                 else:
                     acc = ops.amp_layer(xb, c1.wp, c1.bias, c2.wp, c2.bias, la1, la2, t1, t2, c1.ks, c1.dil, res2=acc,
-                                        out_scale=inv, res_scale=inv)
+                                        out_scale=inv, res_scale=inv, ws1=ws1, ws2=ws2)
         return acc
+
+    def _mrf_wide(self, h, blocks, inv):
+        """Wide stages (C = 128, 256): two launches per AMP layer (ptpp_snake_conv1d_fwd), each = anti-aliased Snake on the
+        conv's input tile + conv + bias (+ residual, + the block's share of the mean over the blocks in the last layer)."""
+        if self.wide_streams and h.is_cuda and len(blocks) == 3 and not torch.cuda.is_current_stream_capturing():
+            return self._mrf_wide_parallel(h, blocks, inv)
+        acc = None
+        for layers in blocks:
+            acc = self._wide_block(h, layers, inv, acc)
+        return acc
+
+    @staticmethod
+    def _wide_block(h, layers, inv, acc, scaled_only=False):
+        xb = h
+        for li, (_, c1, _, c2, (la1, la2, t1, t2, ws1, ws2, _k)) in enumerate(layers):
+            a = ops.snake_conv1d(xb, ws1, c1.bias, la1, t1, c1.ks, c1.dil)
+            if li + 1 < len(layers):
+                xb = ops.snake_conv1d(a, ws2, c2.bias, la2, t2, c2.ks, 1, res=xb)
+            else:
+                xb = ops.snake_conv1d(a, ws2, c2.bias, la2, t2, c2.ks, 1, res=xb, res2=None if scaled_only else acc,
+                                      out_scale=inv, res_scale=inv)
+        return xb
+
+    def _mrf_wide_parallel(self, h, blocks, inv):
+        """The three AMP blocks on three streams (as _mrf_parallel), partial results summed by one kernel."""
+        main = torch.cuda.current_stream()
+        if self._streams is None:
+            self._streams = [ops.aux_stream(h.device, k) for k in range(2)]
+        for st in self._streams:
+            st.wait_stream(main)
+        outs = []
+        for k, layers in enumerate(blocks):
+            st = main if k == 0 else self._streams[k - 1]
+            with ops.unpinned(), torch.cuda.stream(st):
+                outs.append(self._wide_block(h, layers, inv, None, scaled_only=True))
+            if st is not main:
+                h.record_stream(st)
+        for k in (1, 2):
+            main.wait_stream(self._streams[k - 1])
+            outs[k].record_stream(main)
+        return ops.add3_scale(outs[0], outs[1], outs[2], 1.0)
 
     def _mrf_parallel(self, h, blocks, inv):
         """The three AMP blocks of a stage read the same input and are independent until their mean

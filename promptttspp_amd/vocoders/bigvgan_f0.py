@@ -51,6 +51,8 @@ class F0AwareBigVGAN(BigVGAN):
         self._packed_key = None
         self.parallel_blocks = True
         self.fuse_amp_layers = True
+        self.fuse_wide_layers = True
+        self.wide_streams = False
         self._streams = None
 
     def _source_term(self, s, h, src):

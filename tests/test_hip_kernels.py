@@ -655,11 +655,53 @@ def test_fused_amp_layer_second_generation_is_bit_identical(dev, monkeypatch):
             monkeypatch.setenv("PTPP_AMP_OLD", "1")
             ref, ref2 = run(), run(res2=acc, out_scale=1 / 3, res_scale=1 / 3)
             monkeypatch.delenv("PTPP_AMP_OLD")
-            for variant in ("0", "1", "2"):
+            for variant in ("0", "1", "2", "3"):
                 monkeypatch.setenv("PTPP_AMP_VARIANT", variant)
                 assert torch.equal(run(), ref), (C, ks, d, T, variant)
                 assert torch.equal(run(res2=acc, out_scale=1 / 3, res_scale=1 / 3), ref2), (C, ks, d, T, variant, "res2")
             monkeypatch.delenv("PTPP_AMP_VARIANT")
+
+
+@pytest.mark.parametrize("C", [128, 256])
+def test_snake_conv1d_wide_stage_kernel(C, dev):
+    """ptpp_snake_conv1d_fwd (csrc/amp_fused.hip: the anti-aliased Snake applied while the conv's input tile is staged, C = 128 /
+    256) against the oracle's aa_snake + conv (layers/activations.py:22-44, 74-138; vocoders/bigvgan.py:42-47) on bf16-rounded
+    inputs, and against the two launches it replaces (ptpp_aa_snake_fwd + ptpp_conv1d_fwd: the same rounding points, a different
+    accumulation order): interior and edge tiles, utterances shorter than the halo, ragged last tiles, with residual, scales
+    and the running block mean; batch entries independent; a run repeats bit for bit."""
+    import torch.nn.functional as F
+
+    from promptttspp_amd import ops
+
+    g = load_golden("aa_snake")
+    taps = (ops._taps(g["f_up"]), ops._taps(g["f_dn"]))
+    gen = torch.Generator(dev).manual_seed(C)
+    for ks, d, T in ((3, 1, 700), (7, 3, 1000), (11, 5, 1537), (11, 1, 333), (3, 5, 5), (7, 5, 61), (11, 3, 129)):
+        B = 2
+        x = torch.randn(B, T, C, device=dev, generator=gen).bfloat16()
+        res = torch.randn(B, T, C, device=dev, generator=gen).bfloat16()
+        acc = torch.randn(B, T, C, device=dev, generator=gen).bfloat16()
+        w = (torch.randn(C, C, ks, device=dev, generator=gen) / (C * ks) ** 0.5).bfloat16().float()
+        b = 0.1 * torch.randn(C, device=dev, generator=gen)
+        la = 0.3 * torch.randn(C, device=dev, generator=gen)
+        wp = ops.pack_conv_weight(w, torch.bfloat16)
+        ws = ops.amp_pack_wstream(wp, C, ks)
+        pad = d * (ks - 1) // 2
+        # oracle, f32 from the same bf16-rounded inputs
+        a_ref = R.aa_snake(x.float().cpu().transpose(1, 2), la.cpu(), g["f_up"], g["f_dn"])
+        c_ref = F.conv1d(a_ref, w.cpu(), b.cpu(), padding=pad, dilation=d).transpose(1, 2)
+        y = ops.snake_conv1d(x, ws, b, la, taps, ks, d)
+        assert rel_err(y.float().cpu(), c_ref) < 2e-2, (ks, d, T, rel_err(y.float().cpu(), c_ref))
+        a = ops.aa_snake(x, la, *taps)
+        two = ops.conv1d(a, wp, b, C, ks=ks, dil=d, pad=pad)
+        assert rel_err(y.float(), two.float()) < 1e-2, (ks, d, T)
+        assert float((y.float() - two.float()).abs().mean() / two.float().abs().mean()) < 2e-3, (ks, d, T)
+        # residual, scales, running mean
+        y2 = ops.snake_conv1d(x, ws, b, la, taps, ks, d, res=res, res2=acc, out_scale=1 / 3, res_scale=1 / 3)
+        ref2 = acc.float().cpu() + (res.float().cpu() + c_ref) / 3
+        assert rel_err(y2.float().cpu(), ref2) < 2e-2, (ks, d, T, "res")
+        assert torch.equal(y, ops.snake_conv1d(x, ws, b, la, taps, ks, d))
+        assert torch.equal(y[1:2], ops.snake_conv1d(x[1:2].contiguous(), ws, b, la, taps, ks, d))
 
 
 def test_mel_front_end_and_lowpass_on_device(dev):

@@ -17,6 +17,8 @@ dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[os.env
 m = BigVGAN(80, 512, [6, 5, 4, 2], [12, 10, 8, 4], [3, 7, 11], [[1, 3, 5]] * 3)
 fill_state_dict(m, seed=5, overrides={"weight_g": 0.4})
 m = m.to(dev).eval().set_compute_dtype(dt)
+m.fuse_wide_layers = os.environ.get('WIDE', '1') == '1'
+m.wide_streams = os.environ.get('WIDE_STREAMS', '0') == '1'
 x = torch.clamp(-5.5 + 2.1 * torch.randn(B, 80, T, device=dev), -11.5, 2.0)
 
 
