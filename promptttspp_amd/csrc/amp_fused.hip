@@ -43,6 +43,8 @@ struct EB16 {  // bfloat16
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
   }
+  static __device__ __forceinline__ float unpack1(uint32_t r) { return __uint_as_float(r << 16); }
+  static __device__ __forceinline__ uint16_t pack1(float a) { return (uint16_t)pack(a, a); }
   static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
   }
@@ -58,6 +60,8 @@ struct EF16 {  // IEEE half
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
     return __builtin_bit_cast(uint32_t, f16x2_t{(_Float16)a, (_Float16)b});
   }
+  static __device__ __forceinline__ float unpack1(uint32_t r) { return (float)__builtin_bit_cast(_Float16, (uint16_t)r); }
+  static __device__ __forceinline__ uint16_t pack1(float a) { return __builtin_bit_cast(uint16_t, (_Float16)a); }
   static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
   }
@@ -102,57 +106,73 @@ __device__ __forceinline__ float snake_val16(float u, float w, float inv) {  // 
 // amp_layer.hip's AMP_SNAKE_STEP: results are bit-identical)
 #define AF_STEP_CORE(K, RAW)                                                                \
   {                                                                                         \
-    E::unpack(RAW, xa[(K) % 6], xb[(K) % 6]);                                               \
+    if constexpr (PAIR) E::unpack(RAW, xa[(K) % 6], xb[(K) % 6]);                           \
+    else xa[(K) % 6] = E::unpack1(RAW);                                                     \
     float uoa = 0.f, uea = 0.f, uob = 0.f, ueb = 0.f;                                       \
     _Pragma("unroll") for (int a = 0; a < 6; ++a) {                                         \
-      const float va = xa[((K) + 1 + a) % 6], vb = xb[((K) + 1 + a) % 6];                   \
+      const float va = xa[((K) + 1 + a) % 6];                                               \
       uoa = fmaf(va, fup2[10 - 2 * a], uoa);                                                \
       uea = fmaf(va, fup2[11 - 2 * a], uea);                                                \
-      uob = fmaf(vb, fup2[10 - 2 * a], uob);                                                \
-      ueb = fmaf(vb, fup2[11 - 2 * a], ueb);                                                \
+      if constexpr (PAIR) {                                                                 \
+        const float vb = xb[((K) + 1 + a) % 6];                                             \
+        uob = fmaf(vb, fup2[10 - 2 * a], uob);                                              \
+        ueb = fmaf(vb, fup2[11 - 2 * a], ueb);                                              \
+      }                                                                                     \
     }                                                                                       \
     soa = snake_val16(uoa, w0, inv0); sea = snake_val16(uea, w0, inv0);                     \
-    sob = snake_val16(uob, w1, inv1); seb = snake_val16(ueb, w1, inv1);                     \
+    if constexpr (PAIR) { sob = snake_val16(uob, w1, inv1); seb = snake_val16(ueb, w1, inv1); } \
   }
 #define AF_STEP_PUSH(K)                                                                     \
   {                                                                                         \
-    sa[(2 * (K)) % 12] = soa; sb[(2 * (K)) % 12] = sob;                                     \
-    sa[(2 * (K) + 1) % 12] = sea; sb[(2 * (K) + 1) % 12] = seb;                             \
+    sa[(2 * (K)) % 12] = soa; sa[(2 * (K) + 1) % 12] = sea;                                 \
+    if constexpr (PAIR) { sb[(2 * (K)) % 12] = sob; sb[(2 * (K) + 1) % 12] = seb; }         \
   }
 #define AF_STEP_DOWN(K, YA, YB)                                                             \
   {                                                                                         \
     float ya = 0.f, yb = 0.f, za = 0.f, zb = 0.f;                                           \
     _Pragma("unroll") for (int j = 0; j < 12; j += 2) {                                     \
       ya = fmaf(sa[(2 * (K) + 2 + j) % 12], fdn[j], ya);                                    \
-      yb = fmaf(sb[(2 * (K) + 2 + j) % 12], fdn[j], yb);                                    \
       za = fmaf(sa[(2 * (K) + 3 + j) % 12], fdn[j + 1], za);                                \
-      zb = fmaf(sb[(2 * (K) + 3 + j) % 12], fdn[j + 1], zb);                                \
+      if constexpr (PAIR) {                                                                 \
+        yb = fmaf(sb[(2 * (K) + 2 + j) % 12], fdn[j], yb);                                  \
+        zb = fmaf(sb[(2 * (K) + 3 + j) % 12], fdn[j + 1], zb);                              \
+      }                                                                                     \
     }                                                                                       \
     YA = ya + za; YB = yb + zb;                                                             \
+  }
+// one row position of a thread's channel pair (PAIR) or single channel: 4 / 2 bytes at byte offset c2 of the row
+#define AF_LD(PTR) (PAIR ? *reinterpret_cast<const uint32_t*>(PTR) : (uint32_t)*reinterpret_cast<const uint16_t*>(PTR))
+#define AF_ST(PTR, A, B)                                                        \
+  {                                                                             \
+    if constexpr (PAIR) *reinterpret_cast<uint32_t*>(PTR) = E::pack(A, B);      \
+    else *reinterpret_cast<uint16_t*>(PTR) = E::pack1(A);                       \
   }
 
 // Interior tile: no clamps, no selects.  The thread's run covers dst rows [o0, o0 + R); src row of time t is dst row + 6.
 // Step s = 0 .. R + 4 loads src row o0 + 6 + s and (s >= 5) writes dst row o0 + s - 5.
-template <typename E, int SS, int S>
+template <typename E, int SS, int S, bool PAIR = true>
 __device__ __forceinline__ void snake_fast(const char* src, char* dst, int o0, int R, int c2, const float (&fup2)[12],
                                            const float (&fdn)[12], float w0, float w1, float inv0, float inv1) {
   float xa[6], xb[6], sa[12], sb[12];
-  float soa, sea, sob, seb;
+  float soa, sea, sob = 0.f, seb = 0.f;
   const char* px = src + o0 * SS + c2;
 #pragma unroll
-  for (int a = 0; a < 6; ++a) E::unpack(*reinterpret_cast<const uint32_t*>(px + a * SS), xa[a], xb[a]);
+  for (int a = 0; a < 6; ++a) {
+    if constexpr (PAIR) E::unpack(AF_LD(px + a * SS), xa[a], xb[a]);
+    else xa[a] = E::unpack1(AF_LD(px + a * SS));
+  }
 #pragma unroll
   for (int i = 0; i < 12; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
   px += 6 * SS;
   char* pd = dst + (o0 - 5) * S + c2;
   uint32_t cur[6], nxt[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) cur[k] = *reinterpret_cast<const uint32_t*>(px + k * SS);
+  for (int k = 0; k < 6; ++k) cur[k] = AF_LD(px + k * SS);
   const int NS = R + 5;
   const int G = NS / 6, rem = NS - G * 6;
   // group 0: five warm-up steps, the sixth emits the run's first row
 #pragma unroll
-  for (int k = 0; k < 6; ++k) nxt[k] = *reinterpret_cast<const uint32_t*>(px + (6 + k) * SS);
+  for (int k = 0; k < 6; ++k) nxt[k] = AF_LD(px + (6 + k) * SS);
 #define AF_FAST(K, EMIT)                                                          \
   {                                                                               \
     AF_STEP_CORE(K, cur[K])                                                       \
@@ -160,7 +180,7 @@ __device__ __forceinline__ void snake_fast(const char* src, char* dst, int o0, i
     if (EMIT) {                                                                   \
       float oa, ob;                                                               \
       AF_STEP_DOWN(K, oa, ob)                                                     \
-      *reinterpret_cast<uint32_t*>(pd + (K) * S) = E::pack(oa, ob);               \
+      AF_ST(pd + (K) * S, oa, ob)                                                 \
     }                                                                             \
   }
   AF_FAST(0, false) AF_FAST(1, false) AF_FAST(2, false) AF_FAST(3, false) AF_FAST(4, false) AF_FAST(5, true)
@@ -170,7 +190,7 @@ __device__ __forceinline__ void snake_fast(const char* src, char* dst, int o0, i
 #pragma unroll
     for (int k = 0; k < 6; ++k) cur[k] = nxt[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) nxt[k] = *reinterpret_cast<const uint32_t*>(px + (6 + k) * SS);
+    for (int k = 0; k < 6; ++k) nxt[k] = AF_LD(px + (6 + k) * SS);
     AF_FAST(0, true) AF_FAST(1, true) AF_FAST(2, true) AF_FAST(3, true) AF_FAST(4, true) AF_FAST(5, true)
   }
   if (rem) {  // (uniform: R is the same for every thread)
@@ -188,22 +208,23 @@ __device__ __forceinline__ void snake_fast(const char* src, char* dst, int o0, i
 
 // First / last tiles of an utterance (and utterances shorter than a tile): rows read at clamp(t, 0, T-1), s read at
 // clamp(m, 0, 2T-1), rows outside [0, T) written as zeros (the conv's zero padding).  dst rows [o0, o0 + n).
-template <typename E, int SS, int S>
+template <typename E, int SS, int S, bool PAIR = true>
 __device__ __forceinline__ void snake_edge(const char* src, char* dst, int tsrc0, int tdst0, int o0, int n, int Tlen, int c2,
                                            const float (&fup2)[12], const float (&fdn)[12], float w0, float w1, float inv0,
                                            float inv1) {
   auto ldx = [&](int t, float& a, float& b) {
     const int row = min(max(t, 0), Tlen - 1) - tsrc0;
-    E::unpack(*reinterpret_cast<const uint32_t*>(src + (int64_t)row * SS + c2), a, b);
+    if constexpr (PAIR) E::unpack(AF_LD(src + (int64_t)row * SS + c2), a, b);
+    else { a = E::unpack1(AF_LD(src + (int64_t)row * SS + c2)); b = 0.f; }
   };
-  auto st = [&](int i, float a, float b) { *reinterpret_cast<uint32_t*>(dst + i * S + c2) = E::pack(a, b); };
+  auto st = [&](int i, float a, float b) { AF_ST(dst + i * S + c2, a, b) };
   const int ta = tdst0 + o0, tb = ta + n;
   const int tv0 = max(ta, 0), tv1 = min(tb, Tlen);
   for (int t = ta; t < min(tb, tv0); ++t) st(t - tdst0, 0.f, 0.f);
   for (int t = max(ta, tv1); t < tb; ++t) st(t - tdst0, 0.f, 0.f);
   if (tv1 <= tv0) return;
   float xa[6], xb[6], sa[12], sb[12];
-  float soa, sea, sob, seb;
+  float soa, sea, sob = 0.f, seb = 0.f;
   const int tp0 = max(tv0 - 6, -3);
   float pa = 0.f, pb = 0.f;
   if (tv0 < 3) {  // s[0] = snake(u[0]), u[0] = sum_a x[clamp(a-3)] * 2 f[11-2a]
@@ -227,7 +248,7 @@ __device__ __forceinline__ void snake_edge(const char* src, char* dst, int tsrc0
   {                                                                                         \
     const int tp = tg + (K);                                                                \
     const int rowc = min(max(tp + 6, 0), Tlen - 1) - tsrc0;                                 \
-    const uint32_t raw = *reinterpret_cast<const uint32_t*>(src + (int64_t)rowc * SS + c2);  \
+    const uint32_t raw = AF_LD(src + (int64_t)rowc * SS + c2);                              \
     AF_STEP_CORE(K, raw)                                                                    \
     const int m1 = 2 * tp + 7;                                                              \
     if (m1 > mlast) { soa = sa[(2 * (K) + 11) % 12]; sob = sb[(2 * (K) + 11) % 12]; }       \
@@ -318,11 +339,13 @@ __global__ __launch_bounds__(256) void amp_wstream_kernel(const uint16_t* __rest
   out[q] = *reinterpret_cast<const uint4*>(wp + ((int64_t)co * ks + j) * C + kc * 32 + lg * 8);
 }
 
-template <typename E, int C, int BT, int S, int MG1, int MG2>
+template <typename E, int C, int BT, int S, int MG1, int MG2, bool PAIR>
 __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
   constexpr int NT = 512;
   constexpr int NCH = C / 8;          // 16-byte chunks per row
-  constexpr int CP = C / 2;           // channel pairs
+  constexpr int CP = PAIR ? C / 2 : C;  // Snake work items per row: channel pairs, or single channels (twice the run length:
+                                        // the 5 warm-up steps of a run weigh half as much)
+  constexpr int CB = PAIR ? 4 : 2;    // bytes of a work item in a row
   constexpr int NRUN = NT / CP;       // row runs per Snake phase
   constexpr int WN = C / 32;          // waves along the output channels (a wave owns 32 of them)
   constexpr int WM = 8 / WN;          // waves along the rows
@@ -368,7 +391,7 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
   constexpr float WSC = 0.15915494309189535f;  // v_sin_f32 takes revolutions
   float ea0, ea1, inv0, inv1;
   {
-    const float a0 = __expf(p.la1[2 * cpair]), a1 = __expf(p.la1[2 * cpair + 1]);
+    const float a0 = __expf(p.la1[PAIR ? 2 * cpair : cpair]), a1 = __expf(p.la1[PAIR ? 2 * cpair + 1 : cpair]);
     ea0 = a0 * WSC; ea1 = a1 * WSC; inv0 = 1.0f / (a0 + 1e-9f); inv1 = 1.0f / (a1 + 1e-9f);
   }
   __syncthreads();
@@ -380,10 +403,10 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
     for (int i = 0; i < 12; ++i) { fu[i] = in_vgpr(2.0f * p.up1[i]); fd[i] = in_vgpr(p.dn1[i]); }
     const int o0 = run * p.R1;
     if (interior) {
-      snake_fast<E, S, S>(Xs, As, o0, p.R1, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+      snake_fast<E, S, S, PAIR>(Xs, As, o0, p.R1, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
     } else {
       const int n = min(p.R1, n_a1 - o0);
-      if (n > 0) snake_edge<E, S, S>(Xs, As, tx0, ta0, o0, n, Tlen, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+      if (n > 0) snake_edge<E, S, S, PAIR>(Xs, As, tx0, ta0, o0, n, Tlen, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
     }
   }
   __syncthreads();
@@ -414,7 +437,7 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
     }
   }
   {
-    const float a0 = __expf(p.la2[2 * cpair]), a1 = __expf(p.la2[2 * cpair + 1]);
+    const float a0 = __expf(p.la2[PAIR ? 2 * cpair : cpair]), a1 = __expf(p.la2[PAIR ? 2 * cpair + 1 : cpair]);
     ea0 = a0 * WSC; ea1 = a1 * WSC; inv0 = 1.0f / (a0 + 1e-9f); inv1 = 1.0f / (a1 + 1e-9f);
   }
   __syncthreads();
@@ -427,10 +450,10 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
     for (int i = 0; i < 12; ++i) { fu[i] = in_vgpr(2.0f * p.up2[i]); fd[i] = in_vgpr(p.dn2[i]); }
     const int o0 = run * p.R2;
     if (interior) {
-      snake_fast<E, S, S>(Xs, As, o0, p.R2, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+      snake_fast<E, S, S, PAIR>(Xs, As, o0, p.R2, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
     } else {
       const int n = min(p.R2, n_a2 - o0);
-      if (n > 0) snake_edge<E, S, S>(Xs, As, tc0, t0 - pad2, o0, n, Tlen, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+      if (n > 0) snake_edge<E, S, S, PAIR>(Xs, As, tc0, t0 - pad2, o0, n, Tlen, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
     }
   }
   __syncthreads();
@@ -539,12 +562,13 @@ struct SnkP {
   int skip;
 };
 
-template <typename E, int C, int BT, int S, int MG>
+template <typename E, int C, int BT, int S, int MG, bool PAIR>
 __global__ __launch_bounds__(512, 4) void snake_conv_kernel(const SnkP p) {
   constexpr int NT = 512;
   constexpr int NCH = C / 8;
-  constexpr int CP = C / 2;
-  constexpr int NRUN = NT / CP;       // row runs of the Snake (C = 128: 8, C = 256: 4)
+  constexpr int CP = PAIR ? C / 2 : C;  // Snake work items per row (channel pairs / single channels)
+  constexpr int CB = PAIR ? 4 : 2;
+  constexpr int NRUN = NT / CP;       // row runs of the Snake
   constexpr int WN = C / 32 > 8 ? 8 : C / 32;   // waves along the output channels
   constexpr int WM = 8 / WN;          // waves along the rows
   constexpr int NPW = C / 32 / WN;    // channel-fragment pairs per wave (1)
@@ -567,7 +591,7 @@ __global__ __launch_bounds__(512, 4) void snake_conv_kernel(const SnkP p) {
   constexpr float WSC = 0.15915494309189535f;
   float ea0, ea1, inv0, inv1;
   {
-    const float a0 = __expf(p.la[2 * cpair]), a1 = __expf(p.la[2 * cpair + 1]);
+    const float a0 = __expf(p.la[PAIR ? 2 * cpair : cpair]), a1 = __expf(p.la[PAIR ? 2 * cpair + 1 : cpair]);
     ea0 = a0 * WSC; ea1 = a1 * WSC; inv0 = 1.0f / (a0 + 1e-9f); inv1 = 1.0f / (a1 + 1e-9f);
   }
   // ---- P1: Snake: global x -> A rows [0, n_a) ----
@@ -578,10 +602,10 @@ __global__ __launch_bounds__(512, 4) void snake_conv_kernel(const SnkP p) {
     const int o0 = run * p.R;
     const char* src = reinterpret_cast<const char*>(xb) + (int64_t)tx0 * (C * 2);
     if (interior) {
-      snake_fast<E, C * 2, S>(src, As, o0, p.R, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+      snake_fast<E, C * 2, S, PAIR>(src, As, o0, p.R, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
     } else {
       const int n = min(p.R, n_a - o0);
-      if (n > 0) snake_edge<E, C * 2, S>(src, As, tx0, ta0, o0, n, Tlen, cpair * 4, fu, fd, ea0, ea1, inv0, inv1);
+      if (n > 0) snake_edge<E, C * 2, S, PAIR>(src, As, tx0, ta0, o0, n, Tlen, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
     }
   }
   // the residual rows of the tile, row-contiguous, requested before the MFMAs and parked in the output image after them
@@ -672,9 +696,9 @@ __global__ __launch_bounds__(512, 4) void snake_conv_kernel(const SnkP p) {
   }
 }
 
-template <typename E, int C, int BT, int S, int MG>
+template <typename E, int C, int BT, int S, int MG, bool PAIR>
 int launch_snake_conv(SnkP& p, hipStream_t st) {
-  constexpr int NRUN = 512 / (C / 2);
+  constexpr int NRUN = 512 / (PAIR ? C / 2 : C);
   const int pad = p.dil * (p.ks - 1) / 2;
   const int n_a = BT + 2 * pad;
   p.R = (n_a + NRUN - 1) / NRUN;
@@ -686,7 +710,7 @@ int launch_snake_conv(SnkP& p, hipStream_t st) {
     ptpp_set_error("snake_conv: LDS tile too large (%zu B)", smem);
     return PTPP_ENOTSUP;
   }
-  auto kern = snake_conv_kernel<E, C, BT, S, MG>;
+  auto kern = snake_conv_kernel<E, C, BT, S, MG, PAIR>;
   if (smem > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) {
@@ -701,9 +725,9 @@ int launch_snake_conv(SnkP& p, hipStream_t st) {
 }
 
 // LDS geometry of one block (shared by the size query and the launch)
-template <int C, int BT, int S>
+template <int C, int BT, int S, bool PAIR>
 size_t amp_fused_geometry(AmpF& p) {
-  constexpr int NRUN = 512 / (C / 2);
+  constexpr int NRUN = 512 / (PAIR ? C / 2 : C);
   const int pad1 = p.dil * (p.ks - 1) / 2, pad2 = (p.ks - 1) / 2;
   const int n_c1 = BT + 2 * pad2 + 12, M1 = (n_c1 + 15) & ~15;
   const int n_a1 = n_c1 + 2 * pad1, n_x = n_a1 + 12, n_a2 = BT + 2 * pad2;
@@ -723,7 +747,7 @@ size_t amp_fused_geometry(AmpF& p) {
   return (size_t)(rowsX + rowsA) * S;
 }
 
-template <typename E, int C, int BT, int S, int MG1, int MG2>
+template <typename E, int C, int BT, int S, int MG1, int MG2, bool PAIR>
 int launch_amp_fused(AmpF& p, hipStream_t st) {
   constexpr int WM = 8 / (C / 32);
   const int pad2 = (p.ks - 1) / 2;
@@ -732,13 +756,13 @@ int launch_amp_fused(AmpF& p, hipStream_t st) {
     ptpp_set_error("amp_fused: ks=%d needs %d conv1 row fragments per wave (built for %d)", p.ks, (M1 / 16 + WM - 1) / WM, MG1);
     return PTPP_ENOTSUP;
   }
-  size_t smem = amp_fused_geometry<C, BT, S>(p);
+  size_t smem = amp_fused_geometry<C, BT, S, PAIR>(p);
   if (getenv("PTPP_AMP_ONE_BLOCK")) smem = 100 * 1024;  // experiment: one workgroup per CU
   if (smem > 160 * 1024) {
     ptpp_set_error("amp_fused: LDS tile too large (%zu B)", smem);
     return PTPP_ENOTSUP;
   }
-  auto kern = amp_fused_kernel<E, C, BT, S, MG1, MG2>;
+  auto kern = amp_fused_kernel<E, C, BT, S, MG1, MG2, PAIR>;
   if (smem > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) {
@@ -753,14 +777,14 @@ int launch_amp_fused(AmpF& p, hipStream_t st) {
 }
 
 // the tallest tile whose LDS image leaves room for a second workgroup on the CU (2 x 80 KiB)
-template <typename E, int C, int S, int BT0, int BT1, int BT2, int MGA0, int MGB0, int MGA1, int MGB1, int MGA2, int MGB2>
+template <typename E, int C, int S, bool PAIR, int BT0, int BT1, int BT2, int MGA0, int MGB0, int MGA1, int MGB1, int MGA2, int MGB2>
 int launch_amp_fused_pick(AmpF& p, hipStream_t st, int variant) {
   constexpr size_t HALF = 80 * 1024;
   if (variant == 0 || variant == 1)
-    if (variant == 1 || amp_fused_geometry<C, BT0, S>(p) <= HALF) return launch_amp_fused<E, C, BT0, S, MGA0, MGB0>(p, st);
+    if (variant == 1 || amp_fused_geometry<C, BT0, S, PAIR>(p) <= HALF) return launch_amp_fused<E, C, BT0, S, MGA0, MGB0, PAIR>(p, st);
   if (variant == 0 || variant == 2)
-    if (variant == 2 || amp_fused_geometry<C, BT1, S>(p) <= HALF) return launch_amp_fused<E, C, BT1, S, MGA1, MGB1>(p, st);
-  return launch_amp_fused<E, C, BT2, S, MGA2, MGB2>(p, st);
+    if (variant == 2 || amp_fused_geometry<C, BT1, S, PAIR>(p) <= HALF) return launch_amp_fused<E, C, BT1, S, MGA1, MGB1, PAIR>(p, st);
+  return launch_amp_fused<E, C, BT2, S, MGA2, MGB2, PAIR>(p, st);
 }
 
 }  // namespace
@@ -783,12 +807,12 @@ int amp_fused_launch_16bit(const ptpp_amp_layer_args* a, void* stream) {
   p.stagger = getenv("PTPP_AMP_STAGGER") ? atoi(getenv("PTPP_AMP_STAGGER")) : 0;
   // variant 0: tallest tile that keeps two workgroups per CU; 1 / 2 / 3: force the first / second / third height
   if (a->dtype == PTPP_BF16) {
-    if (variant >= 4) {  // conflict-free row strides (16 (4 n + 2) bytes): more LDS per row, shorter tiles
-      if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 160, 176, 160, 128, 4, 3, 3, 3, 3, 2>(p, st, variant - 4);
-      if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 96, 320, 288, 256, 3, 3, 3, 3, 3, 2>(p, st, variant - 4);
+    if (variant >= 4) {  // (experiment) the Snake on channel PAIRS per thread: half the run length
+      if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 144, true, 192, 160, 128, 4, 3, 3, 3, 3, 2>(p, st, variant - 4);
+      if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 80, true, 384, 320, 256, 4, 3, 3, 3, 3, 2>(p, st, variant - 4);
     }
-    if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 144, 192, 160, 128, 4, 3, 3, 3, 3, 2>(p, st, variant);
-    if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 80, 384, 320, 256, 4, 3, 3, 3, 3, 2>(p, st, variant);
+    if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 144, false, 192, 160, 128, 4, 3, 3, 3, 3, 2>(p, st, variant);
+    if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 80, false, 384, 320, 256, 4, 3, 3, 3, 3, 2>(p, st, variant);
   }
   ptpp_set_error("amp_fused: C=%d dtype=%d not built", a->C, a->dtype);
   return PTPP_ENOTSUP;
@@ -815,8 +839,13 @@ extern "C" int ptpp_snake_conv1d_fwd(const ptpp_snake_conv_args* a, void* stream
   p.nMT = 0; p.R = 0; p.rowsA = 0;
   p.skip = getenv("PTPP_AMP_SKIP") ? atoi(getenv("PTPP_AMP_SKIP")) : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->C == 128) return launch_snake_conv<EB16, 128, 128, 272, 4>(p, st);
-  return launch_snake_conv<EB16, 256, 64, 528, 4>(p, st);
+  const int variant = getenv("PTPP_AMP_VARIANT") ? atoi(getenv("PTPP_AMP_VARIANT")) : 0;
+  if (variant >= 4) {  // (experiment) the Snake on channel pairs
+    if (a->C == 128) return launch_snake_conv<EB16, 128, 128, 272, 4, true>(p, st);
+    return launch_snake_conv<EB16, 256, 64, 528, 4, true>(p, st);
+  }
+  if (a->C == 128) return launch_snake_conv<EB16, 128, 128, 272, 4, false>(p, st);
+  return launch_snake_conv<EB16, 256, 64, 528, 4, false>(p, st);
 }
 
 extern "C" int ptpp_amp_pack_wstream(const void* wp, void* out, int C, int ks, int dtype, void* stream) {
