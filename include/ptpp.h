@@ -634,6 +634,14 @@ int ptpp_add3_scale(const void* a, const void* b, const void* c, void* y,
 int ptpp_conv_post_tanh(const void* x, const float* w, float bias, float* y,
                         int B, int T, int C, int ks, int dtype, void* stream);
 
+/* act_post + conv_post + tanh in ONE launch (vocoders/bigvgan.py:129-131; layers/activations.py:22-44, 74-138):
+ *   y[b, t] = tanh(bias + sum_{j, c} w[j, c] * aa_snake(x)[b, t + j - ks/2, c])
+ * x: (B, T, C) 16-bit; log_alpha (C) f32; filt_up / filt_down: HOST pointers to the 12 taps; w: (ks, C) f32; y: (B, T) f32.
+ * Built for C = 32 (the generator's last stage): ptpp_snake_conv_post_supported(C, ks, dtype) != 0. */
+int ptpp_snake_conv_post_supported(int C, int ks, int dtype);
+int ptpp_snake_conv_post_tanh(const void* x, const float* log_alpha, const float* filt_up, const float* filt_down,
+                              const float* w, float bias, float* y, int B, int T, int C, int ks, int dtype, void* stream);
+
 /* Dimension-wise mixture-density NLL (modules/mdn.py:81-175, `dim_wise`): log_pi / log_sigma / mu (rows, G, D) f32,
  * target (rows, D), mask (rows) bytes or NULL (0 = masked: loss +inf, zero gradients) -> loss (rows, D) = -logsumexp_g.
  * _bwd recomputes the component log-likelihoods from the inputs and the saved loss. */

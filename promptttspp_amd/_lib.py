@@ -278,6 +278,8 @@ SIGNATURES = {
     "ptpp_amp_layer_supported": (I, [I, I]),
     "ptpp_amp_layer_fwd": (I, [POINTER(AmpLayerArgs), P]),
     "ptpp_amp_pack_wstream": (I, [P, P, I, I, I, P]),
+    "ptpp_snake_conv_post_supported": (I, [I, I, I]),
+    "ptpp_snake_conv_post_tanh": (I, [P, P, POINTER(c_float), POINTER(c_float), P, F, P, I, I, I, I, I, P]),
     "ptpp_snake_conv1d_supported": (I, [I, I]),
     "ptpp_snake_conv1d_fwd": (I, [POINTER(SnakeConvArgs), P]),
     "ptpp_add3_scale": (I, [P, P, P, P, F, I64, I, P]),

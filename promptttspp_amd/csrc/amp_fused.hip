@@ -293,23 +293,21 @@ __device__ __forceinline__ void conv_pair(const char* act, const uint4* __restri
 #pragma unroll
   for (int mi = 0; mi < MG; ++mi) abase[mi] = act + ((mf0 + (mi < nmf ? mi : 0)) * 16 + lr) * S + lg * 16;
   const int dS = dil * S;
-  // three weight register sets in rotation, no moves: step s reads set s % 3 and requests step s + 2 into set (s + 2) % 3
+  // three weight register sets in rotation, no moves: step s reads set s % 3 and requests step s + 2 into set (s + 2) % 3.
+  // The loads are UNCONDITIONAL (past the end the last step's fragments are requested again): with a branch around them the
+  // compiler's vmcnt bookkeeping gives up at the merge and drains the queue (s_waitcnt vmcnt(0)) every step.
   uint4 w[3][2];
+  const int last = steps - 1;
   w[0][0] = wr[0];
   w[0][1] = wr[64];
-  w[1][0] = w[0][0]; w[1][1] = w[0][1];
-  if (steps > 1) {
-    w[1][0] = wr[NF * 64];
-    w[1][1] = wr[NF * 64 + 64];
-  }
-  w[2][0] = w[0][0]; w[2][1] = w[0][1];
+  w[1][0] = wr[min(1, last) * NF * 64];
+  w[1][1] = wr[min(1, last) * NF * 64 + 64];
 #define AF_CONV_STEP(CUR, NXT, SI)                                                                  \
   {                                                                                                 \
     const int s_ = (SI);                                                                            \
-    if (s_ + 2 < steps && !(dbg & 16)) {                                                            \
-      w[NXT][0] = wr[(s_ + 2) * NF * 64];                                                           \
-      w[NXT][1] = wr[(s_ + 2) * NF * 64 + 64];                                                      \
-    }                                                                                               \
+    const int sn_ = (dbg & 16) ? 0 : min(s_ + 2, last);                                             \
+    w[NXT][0] = wr[sn_ * NF * 64];                                                                  \
+    w[NXT][1] = wr[sn_ * NF * 64 + 64];                                                             \
     const int off = (dbg & 32) ? 0 : (s_ / NKC) * dS + (s_ % NKC) * 64;                             \
     uint4 xf[MG];                                                                                   \
     _Pragma("unroll") for (int mi = 0; mi < MG; ++mi) xf[mi] = *reinterpret_cast<const uint4*>(abase[mi] + off); \
@@ -318,10 +316,15 @@ __device__ __forceinline__ void conv_pair(const char* act, const uint4* __restri
       E::mma(acc[mi][1], w[CUR][1], xf[mi]);                                                        \
     }                                                                                               \
   }
-  for (int s = 0; s < steps; s += 3) {
+  int s = 0;
+  for (; s + 3 <= steps; s += 3) {
+    AF_CONV_STEP(0, 2, s)
+    AF_CONV_STEP(1, 0, s + 1)
+    AF_CONV_STEP(2, 1, s + 2)
+  }
+  if (s < steps) {
     AF_CONV_STEP(0, 2, s)
     if (s + 1 < steps) AF_CONV_STEP(1, 0, s + 1)
-    if (s + 2 < steps) AF_CONV_STEP(2, 1, s + 2)
   }
 #undef AF_CONV_STEP
   if (dbg & 128) __builtin_amdgcn_s_setprio(0);
@@ -608,11 +611,13 @@ __global__ __launch_bounds__(512, 4) void snake_conv_kernel(const SnkP p) {
       if (n > 0) snake_edge<E, C * 2, S, PAIR>(src, As, tx0, ta0, o0, n, Tlen, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
     }
   }
-  // the residual rows of the tile, row-contiguous, requested before the MFMAs and parked in the output image after them
+  // the residual rows of the tile, row-contiguous, parked in the output image after the MFMAs; requested before them where
+  // the registers allow (4 row fragments per wave), after them with 6 (the other resident workgroup covers the round trip)
   constexpr int NRV = BT * NCH / NT;
   static_assert(NRV * NT == BT * NCH, "tile vectors must divide over the threads");
+  constexpr bool LATE = MG > 4;
   uint4 rx[NRV];
-  if (p.res) {
+  auto load_res = [&]() {
     const uint16_t* rb = reinterpret_cast<const uint16_t*>(p.res) + (int64_t)b * Tlen * C;
 #pragma unroll
     for (int i = 0; i < NRV; ++i) {
@@ -621,7 +626,8 @@ __global__ __launch_bounds__(512, 4) void snake_conv_kernel(const SnkP p) {
       const int t = t0 + r;
       rx[i] = t < Tlen ? *reinterpret_cast<const uint4*>(rb + (int64_t)t * C + ch * 8) : make_uint4(0, 0, 0, 0);
     }
-  }
+  };
+  if (!LATE && p.res) load_res();
   __syncthreads();
 
   // ---- P2: conv on the matrix cores ----
@@ -631,19 +637,22 @@ __global__ __launch_bounds__(512, 4) void snake_conv_kernel(const SnkP p) {
   const int co = wn * 32 + lg * 8;
   const uint16_t* r2b = p.res2 ? reinterpret_cast<const uint16_t*>(p.res2) + (int64_t)b * Tlen * C : nullptr;
   uint4 q2[MG];
-  if (r2b) {
+  auto load_res2 = [&]() {
 #pragma unroll
     for (int mi = 0; mi < MG; ++mi) {
       const int t = t0 + (mf0 + mi) * 16 + lr;
       q2[mi] = t < Tlen ? *reinterpret_cast<const uint4*>(r2b + (int64_t)t * C + co) : make_uint4(0, 0, 0, 0);
     }
-  }
+  };
+  if (!LATE && r2b) load_res2();
   f32x4 acc[MG][2];
   if (!(p.skip & 2)) conv_pair<E, C, S, MG>(As, reinterpret_cast<const uint4*>(p.ws), ks, dil, mf0, MG, wn, lane, acc, p.skip);
   else {
 #pragma unroll
     for (int mi = 0; mi < MG; ++mi) { acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mi][1] = acc[mi][0]; }
   }
+  if (LATE && p.res) load_res();
+  if (LATE && r2b) load_res2();
   __syncthreads();  // every wave is done with the A image: it becomes the output tile
 
   // ---- P3: epilogue through the LDS image of the output tile ----
@@ -696,8 +705,8 @@ __global__ __launch_bounds__(512, 4) void snake_conv_kernel(const SnkP p) {
   }
 }
 
-template <typename E, int C, int BT, int S, int MG, bool PAIR>
-int launch_snake_conv(SnkP& p, hipStream_t st) {
+template <int C, int BT, int S, bool PAIR>
+size_t snake_conv_geometry(SnkP& p) {
   constexpr int NRUN = 512 / (PAIR ? C / 2 : C);
   const int pad = p.dil * (p.ks - 1) / 2;
   const int n_a = BT + 2 * pad;
@@ -705,7 +714,12 @@ int launch_snake_conv(SnkP& p, hipStream_t st) {
   int rowsA = n_a > NRUN * p.R ? n_a : NRUN * p.R;
   if (rowsA < BT) rowsA = BT;
   p.rowsA = rowsA;
-  const size_t smem = (size_t)rowsA * S;
+  return (size_t)rowsA * S;
+}
+
+template <typename E, int C, int BT, int S, int MG, bool PAIR>
+int launch_snake_conv(SnkP& p, hipStream_t st) {
+  const size_t smem = snake_conv_geometry<C, BT, S, PAIR>(p);
   if (smem > 160 * 1024) {
     ptpp_set_error("snake_conv: LDS tile too large (%zu B)", smem);
     return PTPP_ENOTSUP;
@@ -722,6 +736,75 @@ int launch_snake_conv(SnkP& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, st, p);
   PTPP_CHECK_LAUNCH("snake_conv1d_fwd");
   return PTPP_OK;
+}
+
+// ---- act_post + conv_post + tanh (vocoders/bigvgan.py:129-131): the last anti-aliased Snake while conv_post's input is staged --
+//   y[b, t] = tanh(bias + sum_{j < ks, c < C} w[j, c] * snake(x)[b, t + j - ks/2, c])        (zero padding), y f32
+struct SnkPostP {
+  const void* x;
+  float* y;
+  const float* w;      // (ks, C) f32
+  const float* la;
+  float up[12], dn[12];
+  float bias;
+  int B, T, ks;
+  int nMT, R, rowsA;
+};
+
+template <typename E, int C, int BT, int S>
+__global__ __launch_bounds__(512, 4) void snake_post_kernel(const SnkPostP p) {
+  constexpr int NT = 512;
+  constexpr int NRUN = NT / C;  // one channel per thread
+  static_assert(BT == NT && C % 8 == 0 && S % 16 == 0 && S >= C * 2, "one output sample per thread");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;
+  float* wsm = reinterpret_cast<float*>(smem + p.rowsA * S);
+  const int ks = p.ks, Tlen = p.T;
+  const int pad = ks / 2;
+  const int n_a = BT + 2 * pad;
+  const int tid = threadIdx.x;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid % p.nMT, b = lid / p.nMT;
+  const int t0 = mt * BT;
+  const int ta0 = t0 - pad, tx0 = ta0 - 6;
+  const bool interior = tx0 >= 0 && tx0 + NRUN * p.R + 17 <= Tlen;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)b * Tlen * C;
+  const int cidx = tid % C, run = tid / C;
+  constexpr float WSC = 0.15915494309189535f;
+  const float a0 = __expf(p.la[cidx]);
+  const float ea = a0 * WSC, iv = 1.0f / (a0 + 1e-9f);
+  for (int i = tid; i < ks * C; i += NT) wsm[i] = p.w[i];
+  {
+    float fu[12], fd[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { fu[i] = in_vgpr(2.0f * p.up[i]); fd[i] = in_vgpr(p.dn[i]); }
+    const int o0 = run * p.R;
+    const char* src = reinterpret_cast<const char*>(xb) + (int64_t)tx0 * (C * 2);
+    if (interior) {
+      snake_fast<E, C * 2, S, false>(src, As, o0, p.R, cidx * 2, fu, fd, ea, ea, iv, iv);
+    } else {
+      const int n = min(p.R, n_a - o0);
+      if (n > 0) snake_edge<E, C * 2, S, false>(src, As, tx0, ta0, o0, n, Tlen, cidx * 2, fu, fd, ea, ea, iv, iv);
+    }
+  }
+  __syncthreads();
+  const int t = t0 + tid;
+  float acc = p.bias;
+  for (int j = 0; j < ks; ++j) {
+    const char* row = As + (tid + j) * S;
+    const float* wr = wsm + j * C;
+#pragma unroll
+    for (int q = 0; q < C / 8; ++q) {
+      const uint4 v = *reinterpret_cast<const uint4*>(row + q * 16);
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(wr + q * 8), wb = *reinterpret_cast<const f32x4*>(wr + q * 8 + 4);
+      float e0, e1;
+      E::unpack(v.x, e0, e1); acc = fmaf(e0, wa[0], acc); acc = fmaf(e1, wa[1], acc);
+      E::unpack(v.y, e0, e1); acc = fmaf(e0, wa[2], acc); acc = fmaf(e1, wa[3], acc);
+      E::unpack(v.z, e0, e1); acc = fmaf(e0, wb[0], acc); acc = fmaf(e1, wb[1], acc);
+      E::unpack(v.w, e0, e1); acc = fmaf(e0, wb[2], acc); acc = fmaf(e1, wb[3], acc);
+    }
+  }
+  if (t < Tlen) p.y[(int64_t)b * Tlen + t] = tanhf(acc);
 }
 
 // LDS geometry of one block (shared by the size query and the launch)
@@ -844,8 +927,42 @@ extern "C" int ptpp_snake_conv1d_fwd(const ptpp_snake_conv_args* a, void* stream
     if (a->C == 128) return launch_snake_conv<EB16, 128, 128, 272, 4, true>(p, st);
     return launch_snake_conv<EB16, 256, 64, 528, 4, true>(p, st);
   }
-  if (a->C == 128) return launch_snake_conv<EB16, 128, 128, 272, 4, false>(p, st);
+  // the tallest tile that leaves room for a second workgroup on the CU (the halo of 2 pad rows and the 5 warm-up steps of a
+  // Snake run weigh less on a taller tile: Snake rows per output row 1.55 -> 1.36 at C = 128, k = 11, d = 5)
+  constexpr size_t HALF = 80 * 1024;
+  if (a->C == 128) {
+    if (variant != 1 && snake_conv_geometry<128, 192, 272, false>(p) <= HALF) return launch_snake_conv<EB16, 128, 192, 272, 6, false>(p, st);
+    return launch_snake_conv<EB16, 128, 128, 272, 4, false>(p, st);
+  }
+  if (variant != 1 && snake_conv_geometry<256, 96, 528, false>(p) <= HALF) return launch_snake_conv<EB16, 256, 96, 528, 6, false>(p, st);
   return launch_snake_conv<EB16, 256, 64, 528, 4, false>(p, st);
+}
+
+extern "C" int ptpp_snake_conv_post_supported(int C, int ks, int dtype) { return dtype == PTPP_BF16 && C == 32 && ks >= 1 && ks <= 15 && (ks & 1); }
+
+extern "C" int ptpp_snake_conv_post_tanh(const void* x, const float* log_alpha, const float* filt_up, const float* filt_down,
+                                         const float* w, float bias, float* y, int B, int T, int C, int ks, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && log_alpha && filt_up && filt_down && w && y, "snake_conv_post_tanh: null pointer");
+  PTPP_CHECK_ARG(B > 0 && T > 0, "snake_conv_post_tanh: bad shape B=%d T=%d", B, T);
+  PTPP_CHECK_ARG((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "snake_conv_post_tanh: pointers must be 16-byte aligned");
+  if (!ptpp_snake_conv_post_supported(C, ks, dtype)) {
+    ptpp_set_error("snake_conv_post_tanh: C=%d ks=%d dtype=%d not built (C = 32, odd ks, 16-bit)", C, ks, dtype);
+    return PTPP_ENOTSUP;
+  }
+  constexpr int BT = 512, S = 80, CC = 32, NRUN = 512 / CC;
+  SnkPostP p;
+  p.x = x; p.y = y; p.w = w; p.la = log_alpha; p.bias = bias;
+  for (int i = 0; i < 12; ++i) { p.up[i] = filt_up[i]; p.dn[i] = filt_down[i]; }
+  p.B = B; p.T = T; p.ks = ks;
+  const int n_a = BT + 2 * (ks / 2);
+  p.R = (n_a + NRUN - 1) / NRUN;
+  p.rowsA = n_a > NRUN * p.R ? n_a : NRUN * p.R;
+  p.nMT = (T + BT - 1) / BT;
+  const size_t smem = (size_t)p.rowsA * S + (size_t)ks * CC * sizeof(float);
+  hipLaunchKernelGGL((snake_post_kernel<EB16, CC, BT, S>), dim3((unsigned)((int64_t)B * p.nMT)), dim3(512), smem,
+                     reinterpret_cast<hipStream_t>(stream), p);
+  PTPP_CHECK_LAUNCH("snake_conv_post_tanh");
+  return PTPP_OK;
 }
 
 extern "C" int ptpp_amp_pack_wstream(const void* wp, void* out, int C, int ks, int dtype, void* stream) {

@@ -960,6 +960,22 @@ def conv_post_tanh(x, w, bias):
     return y
 
 
+def snake_conv_post_supported(C, ks, dtype):
+    return bool(_lib.load().ptpp_snake_conv_post_supported(int(C), int(ks), dtype_code(dtype)))
+
+
+def snake_conv_post_tanh(x, log_alpha, taps, w, bias):
+    """tanh(conv_post(aa_snake(x))) in one launch (ptpp_snake_conv_post_tanh): x (B,T,C) 16-bit; w (ks, C) f32 -> (B, T) f32."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dim() == 3
+    B, T, C = x.shape
+    y = torch.empty((B, T), device=x.device, dtype=torch.float32)
+    up, dn = taps
+    check(_lib.load().ptpp_snake_conv_post_tanh(_ptr(x), _ptr(log_alpha), up, dn, _ptr(w), float(bias), _ptr(y), B, T, C,
+                                                w.shape[0], dtype_code(x.dtype), _stream()), "ptpp_snake_conv_post_tanh")
+    return y
+
+
 def filtfilt(x, b, a, lengths=None):
     """Zero-phase IIR along the last axis of a contiguous f32 tensor (..., T) on the device (ptpp_filtfilt);
     b, a: coefficient sequences (host).  No host synchronisation."""

@@ -340,6 +340,12 @@ class BigVGAN(nn.Module):
     def forward(self, x):
         """x: (B, in_channel, T) float mel -> (B, 1, T*hop) float waveform in (-1, 1)."""
         h, pk = self._generate(x)
+        return self._post(h, pk).unsqueeze(1)
+
+    def _post(self, h, pk):
+        """act_post -> conv_post -> tanh (bigvgan.py:129-131): one launch where ptpp_snake_conv_post_tanh is built."""
+        if self.fuse_amp_layers and ops.snake_conv_post_supported(h.shape[-1], pk["post_w"].shape[0], h.dtype):
+            return ops.snake_conv_post_tanh(h.contiguous(), self.act_post.act.alpha.detach().reshape(-1).float().contiguous(),
+                                            self.act_post.taps(), pk["post_w"], pk["post_b"])
         h = self.act_post.forward_cl(h)
-        y = ops.conv_post_tanh(h, pk["post_w"], pk["post_b"])
-        return y.unsqueeze(1)
+        return ops.conv_post_tanh(h, pk["post_w"], pk["post_b"])

@@ -73,5 +73,4 @@ class F0AwareBigVGAN(BigVGAN):
             return h + self._source_term(s, h, src)
 
         h, pk = self._generate(x, source_hook=hook)
-        h = self.act_post.forward_cl(h)
-        return ops.conv_post_tanh(h, pk["post_w"], pk["post_b"]).unsqueeze(1)
+        return self._post(h, pk).unsqueeze(1)

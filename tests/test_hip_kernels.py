@@ -704,6 +704,34 @@ def test_snake_conv1d_wide_stage_kernel(C, dev):
         assert torch.equal(y[1:2], ops.snake_conv1d(x[1:2].contiguous(), ws, b, la, taps, ks, d))
 
 
+def test_snake_conv_post_tanh_kernel(dev):
+    """ptpp_snake_conv_post_tanh (act_post + conv_post + tanh in one launch, vocoders/bigvgan.py:129-131) against the oracle's
+    aa_snake + conv + tanh on bf16-rounded input and against the two launches it replaces; edge tiles, short and ragged
+    lengths; batch entries independent."""
+    import torch.nn.functional as F
+
+    from promptttspp_amd import ops
+
+    g = load_golden("aa_snake")
+    taps = (ops._taps(g["f_up"]), ops._taps(g["f_dn"]))
+    gen = torch.Generator(dev).manual_seed(7)
+    C, ks = 32, 7
+    for T in (5, 61, 512, 777, 2100):
+        B = 3
+        x = torch.randn(B, T, C, device=dev, generator=gen).bfloat16()
+        w = 0.2 * torch.randn(ks, C, device=dev, generator=gen)
+        la = 0.3 * torch.randn(C, device=dev, generator=gen)
+        y = ops.snake_conv_post_tanh(x, la, taps, w, 0.05)
+        a_ref = R.aa_snake(x.float().cpu().transpose(1, 2), la.cpu(), g["f_up"], g["f_dn"])
+        ref = torch.tanh(F.conv1d(a_ref, w.cpu().t().unsqueeze(0), torch.tensor([0.05]), padding=ks // 2))[:, 0]
+        assert float((y.cpu() - ref).abs().max()) < 2e-2, (T, float((y.cpu() - ref).abs().max()))
+        two = ops.conv_post_tanh(ops.aa_snake(x, la, *taps), w, 0.05)
+        # the two launches: aa_snake_kernel scales the sin argument as (u e^alpha) / 2 pi, the fused kernels as u (e^alpha / 2 pi):
+        # an activated value now and then rounds to the other bf16 neighbour
+        assert float((y - two).abs().max()) < 5e-3 and float((y - two).abs().mean()) < 2e-5, T
+        assert torch.equal(y[1:2], ops.snake_conv_post_tanh(x[1:2].contiguous(), la, taps, w, 0.05))
+
+
 def test_mel_front_end_and_lowpass_on_device(dev):
     """n1 / n2 on the GPU: the log-mel front-end on the exact-f32 GEMM (windowed DFT and filterbank as two products)
     and the zero-phase IIR kernel, against the oracle's numpy restatements."""

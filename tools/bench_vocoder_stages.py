@@ -52,7 +52,5 @@ with torch.no_grad():
         ms, h = timed(lambda: m._mrf(hh, blocks, inv))
         fl = sum(2 * 2 * Bh * Th * u * C * C * l[1].ks for blk in blocks for l in blk) / 1e12
         print(f"stage {s}: MRF (9 AMP layers): {ms:.3f} ms   {fl / ms * 1e3:.0f} TFLOP/s")
-    ms, h2 = timed(lambda: m.act_post.forward_cl(h))
-    print(f"act_post: {ms:.3f} ms")
-    ms, _ = timed(lambda: ops.conv_post_tanh(h2, pk["post_w"], pk["post_b"]))
-    print(f"conv_post + tanh: {ms:.3f} ms")
+    ms, _ = timed(lambda: m._post(h, pk))
+    print(f"act_post + conv_post + tanh: {ms:.3f} ms")
