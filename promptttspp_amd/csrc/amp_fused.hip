@@ -19,8 +19,7 @@
 //     fragment per wave per K step through the 64 B/clk texture path: 0.33 KB per MFMA then, 0.25-0.2 now), activation
 //     fragments from LDS (0.5 KB per MFMA = half the 256 B/clk the LDS delivers), the row fragments divide evenly.
 // Phases of a block (8 waves, __syncthreads between phases):
-//   P0  global -> LDS X: rows [t0 - H, t0 + BT + H) of x, time index clamped into [0, T)
-//   P1  Snake 1 (VALU): X -> A          P2  conv1 (MFMA): A -> c1 (+ bias) in X
+//   P1  Snake 1 (VALU): global x -> A   P2  conv1 (MFMA): A -> c1 (+ bias) in X
 //   P3  Snake 2: X -> A                 P4  conv2; epilogue through an LDS image of the output tile (bias, residual x, running
 //                                           AMP-block mean res2, 16-byte coalesced stores)
 #include <stdlib.h>
@@ -361,7 +360,6 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
   const int n_c1 = BT + 2 * pad2 + 12;          // conv1 output rows snake 2 reads
   const int M1 = (n_c1 + 15) & ~15;             // ... rounded up to whole MFMA fragments
   const int n_a1 = n_c1 + 2 * pad1;             // snake-1 rows conv1 reads (without the fragment overhang)
-  const int n_x = n_a1 + 12;
   char* Xs = smem;
   char* As = smem + p.rowsX * S;
 
@@ -380,16 +378,10 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
   const int tc0 = t0 - pad2 - 6;     // time of c1 row 0
   const int ta0 = tc0 - pad1;        // time of a1 row 0
   const int tx0 = ta0 - 6;           // time of X row 0
-  const bool interior = tx0 >= 0 && tx0 + n_x <= Tlen;
+  // interior: every row a Snake-1 run reads (its overhang and the prefetched group included) lies inside the utterance
+  const bool interior = tx0 >= 0 && tx0 + NRUN * p.R1 + 17 <= Tlen;
   const uint16_t* xb = reinterpret_cast<const uint16_t*>(p.x) + (int64_t)b * Tlen * C;
 
-  // ---- P0: x tile -> LDS (time index clamped: replicate padding of the first Snake) ----
-  for (int idx = tid; idx < n_x * NCH; idx += NT) {
-    const int r = idx / NCH, ch = idx - r * NCH;
-    const int t = min(max(tx0 + r, 0), Tlen - 1);
-    const uint4 v = *reinterpret_cast<const uint4*>(xb + (int64_t)t * C + ch * 8);
-    *reinterpret_cast<uint4*>(Xs + r * S + ch * 16) = v;
-  }
   const int cpair = tid % CP, run = tid / CP;
   constexpr float WSC = 0.15915494309189535f;  // v_sin_f32 takes revolutions
   float ea0, ea1, inv0, inv1;
@@ -397,19 +389,20 @@ __global__ __launch_bounds__(512, 4) void amp_fused_kernel(const AmpF p) {
     const float a0 = __expf(p.la1[PAIR ? 2 * cpair : cpair]), a1 = __expf(p.la1[PAIR ? 2 * cpair + 1 : cpair]);
     ea0 = a0 * WSC; ea1 = a1 * WSC; inv0 = 1.0f / (a0 + 1e-9f); inv1 = 1.0f / (a1 + 1e-9f);
   }
-  __syncthreads();
 
-  // ---- P1: snake 1: X -> A (a1 rows [0, n_a1); time ta0 + i) ----
+  // ---- P1: snake 1: global x -> A (a1 rows [0, n_a1); time ta0 + i).  No x image and no load phase: a thread's rows come
+  // straight from global memory, one 6-step group ahead of their use (a wave-load is two full 128-byte row pieces) ----
   if (!(skip & 1)) {
     float fu[12], fd[12];  // the taps in VECTOR registers (in_vgpr)
 #pragma unroll
     for (int i = 0; i < 12; ++i) { fu[i] = in_vgpr(2.0f * p.up1[i]); fd[i] = in_vgpr(p.dn1[i]); }
     const int o0 = run * p.R1;
+    const char* src = reinterpret_cast<const char*>(xb) + (int64_t)tx0 * (C * 2);
     if (interior) {
-      snake_fast<E, S, S, PAIR>(Xs, As, o0, p.R1, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
+      snake_fast<E, C * 2, S, PAIR>(src, As, o0, p.R1, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
     } else {
       const int n = min(p.R1, n_a1 - o0);
-      if (n > 0) snake_edge<E, S, S, PAIR>(Xs, As, tx0, ta0, o0, n, Tlen, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
+      if (n > 0) snake_edge<E, C * 2, S, PAIR>(src, As, tx0, ta0, o0, n, Tlen, cpair * CB, fu, fd, ea0, ea1, inv0, inv1);
     }
   }
   __syncthreads();
@@ -813,15 +806,15 @@ size_t amp_fused_geometry(AmpF& p) {
   constexpr int NRUN = 512 / (PAIR ? C / 2 : C);
   const int pad1 = p.dil * (p.ks - 1) / 2, pad2 = (p.ks - 1) / 2;
   const int n_c1 = BT + 2 * pad2 + 12, M1 = (n_c1 + 15) & ~15;
-  const int n_a1 = n_c1 + 2 * pad1, n_x = n_a1 + 12, n_a2 = BT + 2 * pad2;
+  const int n_a1 = n_c1 + 2 * pad1, n_a2 = BT + 2 * pad2;
   p.R1 = (n_a1 + NRUN - 1) / NRUN;
   p.R2 = (n_a2 + NRUN - 1) / NRUN;
-  // interior tiles walk NRUN equal runs: the last run may overhang the image (rows it reads: up to o0 + R + 16 with the
-  // prefetched group; rows it writes: up to NRUN * R)
-  int rowsX = n_x > M1 ? n_x : M1;
-  const int need1 = NRUN * p.R1 + 17, need2 = NRUN * p.R2 + 17;
-  if (rowsX < need1) rowsX = need1;
+  // the X image holds c1 (M1 rows), then the output tile.  Interior tiles walk NRUN equal runs: the last run of Snake 2 may
+  // overhang (rows it reads: up to o0 + R + 16 with the prefetched group; rows it writes: up to NRUN * R)
+  int rowsX = M1;
+  const int need2 = NRUN * p.R2 + 17;
   if (rowsX < need2) rowsX = need2;
+  if (rowsX < BT) rowsX = BT;
   int rowsA = M1 + 2 * pad1;
   if (rowsA < n_a2) rowsA = n_a2;
   if (rowsA < NRUN * p.R1) rowsA = NRUN * p.R1;
@@ -860,14 +853,19 @@ int launch_amp_fused(AmpF& p, hipStream_t st) {
 }
 
 // the tallest tile whose LDS image leaves room for a second workgroup on the CU (2 x 80 KiB)
-template <typename E, int C, int S, bool PAIR, int BT0, int BT1, int BT2, int MGA0, int MGB0, int MGA1, int MGB1, int MGA2, int MGB2>
+template <typename E, int C, int S, bool PAIR, int BT0, int BT1, int BT2, int BT3, int MGA0, int MGB0, int MGA1, int MGB1, int MGA2,
+          int MGB2, int MGA3, int MGB3>
 int launch_amp_fused_pick(AmpF& p, hipStream_t st, int variant) {
   constexpr size_t HALF = 80 * 1024;
-  if (variant == 0 || variant == 1)
-    if (variant == 1 || amp_fused_geometry<C, BT0, S, PAIR>(p) <= HALF) return launch_amp_fused<E, C, BT0, S, MGA0, MGB0, PAIR>(p, st);
-  if (variant == 0 || variant == 2)
-    if (variant == 2 || amp_fused_geometry<C, BT1, S, PAIR>(p) <= HALF) return launch_amp_fused<E, C, BT1, S, MGA1, MGB1, PAIR>(p, st);
-  return launch_amp_fused<E, C, BT2, S, MGA2, MGB2, PAIR>(p, st);
+  constexpr int WM = 8 / (C / 32);
+  auto fits = [&](int BT, int MGA, size_t smem) {  // LDS for two workgroups per CU, conv1 row fragments per wave as built
+    const int M1 = (BT + 2 * ((p.ks - 1) / 2) + 12 + 15) & ~15;
+    return smem <= HALF && (M1 / 16 + WM - 1) / WM <= MGA;
+  };
+  if (variant == 1 || (variant == 0 && fits(BT0, MGA0, amp_fused_geometry<C, BT0, S, PAIR>(p)))) return launch_amp_fused<E, C, BT0, S, MGA0, MGB0, PAIR>(p, st);
+  if (variant == 2 || (variant == 0 && fits(BT1, MGA1, amp_fused_geometry<C, BT1, S, PAIR>(p)))) return launch_amp_fused<E, C, BT1, S, MGA1, MGB1, PAIR>(p, st);
+  if (variant == 3 || (variant == 0 && fits(BT2, MGA2, amp_fused_geometry<C, BT2, S, PAIR>(p)))) return launch_amp_fused<E, C, BT2, S, MGA2, MGB2, PAIR>(p, st);
+  return launch_amp_fused<E, C, BT3, S, MGA3, MGB3, PAIR>(p, st);
 }
 
 }  // namespace
@@ -890,12 +888,12 @@ int amp_fused_launch_16bit(const ptpp_amp_layer_args* a, void* stream) {
   p.stagger = getenv("PTPP_AMP_STAGGER") ? atoi(getenv("PTPP_AMP_STAGGER")) : 0;
   // variant 0: tallest tile that keeps two workgroups per CU; 1 / 2 / 3: force the first / second / third height
   if (a->dtype == PTPP_BF16) {
-    if (variant >= 4) {  // (experiment) the Snake on channel PAIRS per thread: half the run length
-      if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 144, true, 192, 160, 128, 4, 3, 3, 3, 3, 2>(p, st, variant - 4);
-      if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 80, true, 384, 320, 256, 4, 3, 3, 3, 3, 2>(p, st, variant - 4);
+    if (variant >= 5) {  // (experiment) the Snake on channel PAIRS per thread: half the run length
+      if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 144, true, 256, 224, 192, 128, 5, 4, 4, 4, 4, 3, 3, 2>(p, st, variant - 5);
+      if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 80, true, 448, 384, 320, 256, 4, 4, 4, 3, 3, 3, 3, 2>(p, st, variant - 5);
     }
-    if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 144, false, 192, 160, 128, 4, 3, 3, 3, 3, 2>(p, st, variant);
-    if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 80, false, 384, 320, 256, 4, 3, 3, 3, 3, 2>(p, st, variant);
+    if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 144, false, 256, 224, 192, 128, 5, 4, 4, 4, 4, 3, 3, 2>(p, st, variant);
+    if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 80, false, 448, 384, 320, 256, 4, 4, 4, 3, 3, 3, 3, 2>(p, st, variant);
   }
   ptpp_set_error("amp_fused: C=%d dtype=%d not built", a->C, a->dtype);
   return PTPP_ENOTSUP;

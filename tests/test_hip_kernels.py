@@ -655,7 +655,7 @@ def test_fused_amp_layer_second_generation_is_bit_identical(dev, monkeypatch):
             monkeypatch.setenv("PTPP_AMP_OLD", "1")
             ref, ref2 = run(), run(res2=acc, out_scale=1 / 3, res_scale=1 / 3)
             monkeypatch.delenv("PTPP_AMP_OLD")
-            for variant in ("0", "1", "2", "3", "4", "5", "6"):
+            for variant in ("0", "1", "2", "3", "4", "5", "6", "7", "8"):
                 monkeypatch.setenv("PTPP_AMP_VARIANT", variant)
                 assert torch.equal(run(), ref), (C, ks, d, T, variant)
                 assert torch.equal(run(res2=acc, out_scale=1 / 3, res_scale=1 / 3), ref2), (C, ks, d, T, variant, "res2")
