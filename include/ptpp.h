@@ -41,6 +41,10 @@ extern "C" {
 
 #define PTPP_F32 0
 #define PTPP_BF16 1
+#define PTPP_F16 2 /* IEEE half, f32 accumulation: the vocoder's inference kernels (BigVGAN, BASELINE configs 4 / 5; the reference's AMP
+                      is fp16, trainers/tts.py:92,203-211) -- ptpp_pack_conv_weight (modes 0 / 1), ptpp_conv1d_fwd*, the layout bridges,
+                      ptpp_aa_snake_fwd, ptpp_amp_layer_fwd, ptpp_snake_conv1d_fwd, ptpp_snake_conv_post_tanh, ptpp_conv_post_tanh,
+                      ptpp_add3_scale, ptpp_cast_from_f32; every other entry point refuses it */
 
 #define PTPP_OK 0
 #define PTPP_EINVAL (-1)   /* bad argument (shape / alignment / dtype) */

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_longl
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libptpp_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SWISH, ACT_TANH, ACT_MISH = 0, 1, 2, 3, 4, 5
 ATTN_NEW, ATTN_LEGACY, ATTN_PLAIN = 0, 1, 2
 

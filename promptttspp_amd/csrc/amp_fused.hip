@@ -895,11 +895,15 @@ int amp_fused_launch_16bit(const ptpp_amp_layer_args* a, void* stream) {
     if (a->C == 64) return launch_amp_fused_pick<EB16, 64, 144, false, 256, 224, 192, 128, 5, 4, 4, 4, 4, 3, 3, 2>(p, st, variant);
     if (a->C == 32) return launch_amp_fused_pick<EB16, 32, 80, false, 448, 384, 320, 256, 4, 4, 4, 3, 3, 3, 3, 2>(p, st, variant);
   }
+  if (a->dtype == PTPP_F16) {
+    if (a->C == 64) return launch_amp_fused_pick<EF16, 64, 144, false, 256, 224, 192, 128, 5, 4, 4, 4, 4, 3, 3, 2>(p, st, variant);
+    if (a->C == 32) return launch_amp_fused_pick<EF16, 32, 80, false, 448, 384, 320, 256, 4, 4, 4, 3, 3, 3, 3, 2>(p, st, variant);
+  }
   ptpp_set_error("amp_fused: C=%d dtype=%d not built", a->C, a->dtype);
   return PTPP_ENOTSUP;
 }
 
-extern "C" int ptpp_snake_conv1d_supported(int C, int dtype) { return dtype == PTPP_BF16 && (C == 128 || C == 256); }
+extern "C" int ptpp_snake_conv1d_supported(int C, int dtype) { return (dtype == PTPP_BF16 || dtype == PTPP_F16) && (C == 128 || C == 256); }
 
 extern "C" int ptpp_snake_conv1d_fwd(const ptpp_snake_conv_args* a, void* stream) {
   PTPP_CHECK_ARG(a && a->x && a->y && a->ws && a->bias && a->log_alpha, "snake_conv: null pointer");
@@ -928,6 +932,14 @@ extern "C" int ptpp_snake_conv1d_fwd(const ptpp_snake_conv_args* a, void* stream
   // the tallest tile that leaves room for a second workgroup on the CU (the halo of 2 pad rows and the 5 warm-up steps of a
   // Snake run weigh less on a taller tile: Snake rows per output row 1.55 -> 1.36 at C = 128, k = 11, d = 5)
   constexpr size_t HALF = 80 * 1024;
+  if (a->dtype == PTPP_F16) {
+    if (a->C == 128) {
+      if (variant != 1 && snake_conv_geometry<128, 192, 272, false>(p) <= HALF) return launch_snake_conv<EF16, 128, 192, 272, 6, false>(p, st);
+      return launch_snake_conv<EF16, 128, 128, 272, 4, false>(p, st);
+    }
+    if (variant != 1 && snake_conv_geometry<256, 96, 528, false>(p) <= HALF) return launch_snake_conv<EF16, 256, 96, 528, 6, false>(p, st);
+    return launch_snake_conv<EF16, 256, 64, 528, 4, false>(p, st);
+  }
   if (a->C == 128) {
     if (variant != 1 && snake_conv_geometry<128, 192, 272, false>(p) <= HALF) return launch_snake_conv<EB16, 128, 192, 272, 6, false>(p, st);
     return launch_snake_conv<EB16, 128, 128, 272, 4, false>(p, st);
@@ -936,7 +948,9 @@ extern "C" int ptpp_snake_conv1d_fwd(const ptpp_snake_conv_args* a, void* stream
   return launch_snake_conv<EB16, 256, 64, 528, 4, false>(p, st);
 }
 
-extern "C" int ptpp_snake_conv_post_supported(int C, int ks, int dtype) { return dtype == PTPP_BF16 && C == 32 && ks >= 1 && ks <= 15 && (ks & 1); }
+extern "C" int ptpp_snake_conv_post_supported(int C, int ks, int dtype) {
+  return (dtype == PTPP_BF16 || dtype == PTPP_F16) && C == 32 && ks >= 1 && ks <= 15 && (ks & 1);
+}
 
 extern "C" int ptpp_snake_conv_post_tanh(const void* x, const float* log_alpha, const float* filt_up, const float* filt_down,
                                          const float* w, float bias, float* y, int B, int T, int C, int ks, int dtype, void* stream) {
@@ -957,15 +971,19 @@ extern "C" int ptpp_snake_conv_post_tanh(const void* x, const float* log_alpha, 
   p.rowsA = n_a > NRUN * p.R ? n_a : NRUN * p.R;
   p.nMT = (T + BT - 1) / BT;
   const size_t smem = (size_t)p.rowsA * S + (size_t)ks * CC * sizeof(float);
-  hipLaunchKernelGGL((snake_post_kernel<EB16, CC, BT, S>), dim3((unsigned)((int64_t)B * p.nMT)), dim3(512), smem,
-                     reinterpret_cast<hipStream_t>(stream), p);
+  if (dtype == PTPP_F16)
+    hipLaunchKernelGGL((snake_post_kernel<EF16, CC, BT, S>), dim3((unsigned)((int64_t)B * p.nMT)), dim3(512), smem,
+                       reinterpret_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL((snake_post_kernel<EB16, CC, BT, S>), dim3((unsigned)((int64_t)B * p.nMT)), dim3(512), smem,
+                       reinterpret_cast<hipStream_t>(stream), p);
   PTPP_CHECK_LAUNCH("snake_conv_post_tanh");
   return PTPP_OK;
 }
 
 extern "C" int ptpp_amp_pack_wstream(const void* wp, void* out, int C, int ks, int dtype, void* stream) {
   PTPP_CHECK_ARG(wp && out && wp != out, "amp_pack_wstream: null / aliased pointer");
-  PTPP_CHECK_ARG(dtype == PTPP_BF16 && (C == 32 || C == 64 || C == 128 || C == 256) && ks >= 1 && ks <= 15,
+  PTPP_CHECK_ARG((dtype == PTPP_BF16 || dtype == PTPP_F16) && (C == 32 || C == 64 || C == 128 || C == 256) && ks >= 1 && ks <= 15,
                  "amp_pack_wstream: C=%d ks=%d dtype=%d not built", C, ks, dtype);
   PTPP_CHECK_ARG((((uintptr_t)wp | (uintptr_t)out) & 15) == 0, "amp_pack_wstream: pointers must be 16-byte aligned");
   const int n = ks * (C / 32) * (C / 16) * 64;

@@ -518,7 +518,7 @@ int launch_amp(AmpP& p, hipStream_t st) {
 int amp_fused_launch_16bit(const ptpp_amp_layer_args* a, void* stream);  // amp_fused.hip
 
 extern "C" int ptpp_amp_layer_supported(int C, int dtype) {
-  if (dtype == PTPP_BF16) return C == 32 || C == 64;
+  if (dtype == PTPP_BF16 || dtype == PTPP_F16) return C == 32 || C == 64;
   if (dtype == PTPP_F32) return C == 32 || C == 64;
   return 0;
 }
@@ -526,7 +526,7 @@ extern "C" int ptpp_amp_layer_supported(int C, int dtype) {
 extern "C" int ptpp_amp_layer_fwd(const ptpp_amp_layer_args* a, void* stream) {
   PTPP_CHECK_ARG(a && a->x && a->y && a->b1 && a->b2 && a->log_alpha1 && a->log_alpha2, "amp_layer: null pointer");
   const bool old16 = getenv("PTPP_AMP_OLD") && atoi(getenv("PTPP_AMP_OLD"));  // A/B: the round-2 kernel for 16-bit tensors
-  const bool fused16 = a->dtype == PTPP_BF16 && !old16;
+  const bool fused16 = (a->dtype == PTPP_BF16 && !old16) || a->dtype == PTPP_F16;
   PTPP_CHECK_ARG(fused16 ? (a->w1s && a->w2s) : (a->w1p && a->w2p), "amp_layer: null weight operand (%s)",
                  fused16 ? "16-bit tensors take the fragment streams w1s / w2s" : "w1p / w2p");
   PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->ks >= 1 && (a->ks & 1) && a->ks <= 15 && a->dil >= 1 && a->dil <= 8,

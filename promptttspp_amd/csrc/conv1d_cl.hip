@@ -51,6 +51,14 @@ struct Mma<bf16_raw> {
   }
 };
 
+template <>
+struct Mma<f16_raw> {
+  static __device__ __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+  }
+};
+
 // SK: split-K variant -- block (b, mt, nt, split) walks only its share of the Cin chunks and stores raw
 // f32 partial sums; conv_splitk_finish_kernel adds the splits and applies the epilogue.  For layers with
 // few output tiles and a long K (Conformer FFN k = 9: 144 K steps, BERT FFN: 48) every K step costs a
@@ -359,7 +367,7 @@ int launch_tiles(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes) {
     if (launch_splitk<T, NCH, 2, 1, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
     return launch_cfg<T, NCH, 2, 1, 2, 8>(p, st);                      //  32 x 128, 8 waves of 16 x 32
   }
-  if constexpr (sizeof(T) == 2 && NCH == 8) {
+  if constexpr (IsBf16<T>::value && NCH == 8) {  // (the LDS-DMA kernels are bf16 only)
     // few output tiles and a long K (the Conformer feed-forward k = 9 convs at phone level: 1024 -> 256 over ~150 rows per
     // utterance = 114 tiles, 144 K steps): split-K on the LDS-DMA kernel -- a K step there costs ~0.5 us against ~3 us in
     // the register-staged 8-wave kernel below.  PTPP_CONV_GLDS_SPLITK=0 keeps the old route.
@@ -394,7 +402,7 @@ int launch_tiles(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes) {
     if (launch_splitk<T, NCH, 2, 2, 2, 8>(p, st, ws, ws_bytes, &sk_status)) return sk_status;
     return launch_cfg<T, NCH, 2, 2, 2, 8>(p, st);
   }
-  if constexpr (sizeof(T) == 2 && NCH == 8) {
+  if constexpr (IsBf16<T>::value && NCH == 8) {  // (the LDS-DMA kernels are bf16 only)
     // LDS-DMA pipeline (conv1d_glds.h), 4 waves per block.  Large grids (the vocoder: thousands of 128 x 128 tiles,
     // many rounds over the 256 CUs) take 128 x 128 tiles with 64 x 64 wave tiles -- the highest MFMA : L2-traffic
     // ratio; the frame-level shapes of the acoustic model (B x 576: about two rounds) take 64 x 128 tiles, three
@@ -416,7 +424,7 @@ int launch_tiles(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes) {
 }  // namespace
 
 extern "C" int ptpp_conv_cin_padded(int cin, int dtype) {
-  const int kc = dtype == PTPP_BF16 ? 8 : 4;
+  const int kc = dtype == PTPP_F32 ? 4 : 8;
   if (cin % (8 * kc) == 0) return cin;
   const int q = 4 * kc;
   return (cin + q - 1) / q * q;
@@ -427,9 +435,9 @@ extern "C" int ptpp_conv1d_fwd_ws(const ptpp_conv1d_args* a, const void* res2, i
                                   float drop_p, uint64_t drop_seed, void* workspace, size_t workspace_bytes,
                                   void* stream) {
   PTPP_CHECK_ARG(a && a->x && a->wp && a->y, "conv1d: null pointer");
-  PTPP_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "conv1d: bad dtype %d", a->dtype);
-  const int kc = a->dtype == PTPP_BF16 ? 8 : 4;
-  const int es = a->dtype == PTPP_BF16 ? 2 : 4;
+  PTPP_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16 || a->dtype == PTPP_F16, "conv1d: bad dtype %d", a->dtype);
+  const int kc = a->dtype == PTPP_F32 ? 4 : 8;
+  const int es = a->dtype == PTPP_F32 ? 4 : 2;
   PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->Cin > 0 && a->Cout > 0 && a->ks > 0 && a->dil > 0,
                  "conv1d: bad shape B=%d T=%d Cin=%d Cout=%d ks=%d dil=%d", a->B, a->T, a->Cin, a->Cout, a->ks, a->dil);
   PTPP_CHECK_ARG(a->Cin % kc == 0, "conv1d: Cin=%d must be a multiple of %d for this dtype", a->Cin, kc);
@@ -476,6 +484,9 @@ extern "C" int ptpp_conv1d_fwd_ws(const ptpp_conv1d_args* a, const void* res2, i
   if (a->dtype == PTPP_F32)
     return wide ? launch_tiles<float, 8>(p, st, workspace, workspace_bytes)
                 : launch_tiles<float, 4>(p, st, workspace, workspace_bytes);
+  if (a->dtype == PTPP_F16)
+    return wide ? launch_tiles<f16_raw, 8>(p, st, workspace, workspace_bytes)
+                : launch_tiles<f16_raw, 4>(p, st, workspace, workspace_bytes);
   return wide ? launch_tiles<bf16_raw, 8>(p, st, workspace, workspace_bytes)
               : launch_tiles<bf16_raw, 4>(p, st, workspace, workspace_bytes);
 }

@@ -131,17 +131,17 @@ __device__ __forceinline__ void conv_epilogue_act(const ConvP& p, f32x4 (&acc)[F
             f32x4 v0 = finish4(acc[fm][2 * h], t, co, keep), v1 = finish4(acc[fm][2 * h + 1], t, co + 4, keep);
             if (rb) {
               const uint4 r = *reinterpret_cast<const uint4*>(rb + (int64_t)t * e_ldr + co);
-              v0[0] += __uint_as_float(r.x << 16) * e_rscale; v0[1] += __uint_as_float(r.x & 0xffff0000u) * e_rscale;
-              v0[2] += __uint_as_float(r.y << 16) * e_rscale; v0[3] += __uint_as_float(r.y & 0xffff0000u) * e_rscale;
-              v1[0] += __uint_as_float(r.z << 16) * e_rscale; v1[1] += __uint_as_float(r.z & 0xffff0000u) * e_rscale;
-              v1[2] += __uint_as_float(r.w << 16) * e_rscale; v1[3] += __uint_as_float(r.w & 0xffff0000u) * e_rscale;
+              v0[0] += H2<T>::lo(r.x) * e_rscale; v0[1] += H2<T>::hi(r.x) * e_rscale;
+              v0[2] += H2<T>::lo(r.y) * e_rscale; v0[3] += H2<T>::hi(r.y) * e_rscale;
+              v1[0] += H2<T>::lo(r.z) * e_rscale; v1[1] += H2<T>::hi(r.z) * e_rscale;
+              v1[2] += H2<T>::lo(r.w) * e_rscale; v1[3] += H2<T>::hi(r.w) * e_rscale;
             }
             if (r2b) {
               const uint4 r = *reinterpret_cast<const uint4*>(r2b + (int64_t)t * e_ldr2 + co);
-              v0[0] += __uint_as_float(r.x << 16); v0[1] += __uint_as_float(r.x & 0xffff0000u);
-              v0[2] += __uint_as_float(r.y << 16); v0[3] += __uint_as_float(r.y & 0xffff0000u);
-              v1[0] += __uint_as_float(r.z << 16); v1[1] += __uint_as_float(r.z & 0xffff0000u);
-              v1[2] += __uint_as_float(r.w << 16); v1[3] += __uint_as_float(r.w & 0xffff0000u);
+              v0[0] += H2<T>::lo(r.x); v0[1] += H2<T>::hi(r.x);
+              v0[2] += H2<T>::lo(r.y); v0[3] += H2<T>::hi(r.y);
+              v1[0] += H2<T>::lo(r.z); v1[1] += H2<T>::hi(r.z);
+              v1[2] += H2<T>::lo(r.w); v1[3] += H2<T>::hi(r.w);
             }
             if constexpr (ACT == PTPP_ACT_GATE) {
               // fused DiffNet gate: the 8 channels are [4 "gate" | their 4 "filter" partners] (weights
@@ -150,16 +150,16 @@ __device__ __forceinline__ void conv_epilogue_act(const ConvP& p, f32x4 (&acc)[F
               float gte[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) gte[e] = keep ? gate_fast(v0[e], v1[e]) : 0.f;
-              o.x = (uint32_t)f32_to_bf16(gte[0]) | ((uint32_t)f32_to_bf16(gte[1]) << 16);
-              o.y = (uint32_t)f32_to_bf16(gte[2]) | ((uint32_t)f32_to_bf16(gte[3]) << 16);
+              o.x = H2<T>::pack(gte[0], gte[1]);
+              o.y = H2<T>::pack(gte[2], gte[3]);
               *reinterpret_cast<uint2*>(yb + (int64_t)t * e_ldy + (co >> 1)) = o;
               continue;
             }
             uint4 o;
-            o.x = (uint32_t)f32_to_bf16(v0[0]) | ((uint32_t)f32_to_bf16(v0[1]) << 16);
-            o.y = (uint32_t)f32_to_bf16(v0[2]) | ((uint32_t)f32_to_bf16(v0[3]) << 16);
-            o.z = (uint32_t)f32_to_bf16(v1[0]) | ((uint32_t)f32_to_bf16(v1[1]) << 16);
-            o.w = (uint32_t)f32_to_bf16(v1[2]) | ((uint32_t)f32_to_bf16(v1[3]) << 16);
+            o.x = H2<T>::pack(v0[0], v0[1]);
+            o.y = H2<T>::pack(v0[2], v0[3]);
+            o.z = H2<T>::pack(v1[0], v1[1]);
+            o.w = H2<T>::pack(v1[2], v1[3]);
             *reinterpret_cast<uint4*>(yb + (int64_t)t * e_ldy + co) = o;
           }
         }

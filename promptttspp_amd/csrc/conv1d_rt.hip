@@ -265,14 +265,14 @@ int rt_launch(const RtP& p, hipStream_t st) {
   const size_t smem = (size_t)NS * RT_STAGE_U4 * 16 + (size_t)2 * xrows * 128;
   auto kern = conv1d_rt_kernel<NS, FM, ACT>;
   {
-    static const void* done[8];
-    static int ndone = 0;
     const void* kp = reinterpret_cast<const void*>(kern);
-    bool seen = false;
-    for (int i = 0; i < ndone; ++i) seen = seen || done[i] == kp;
-    if (!seen) {
-      (void)hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (ndone < 8) done[ndone++] = kp;
+    if (!lds_limit_raised(kp)) {
+      const hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        ptpp_set_error("conv1d_rt_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        return PTPP_ELAUNCH;
+      }
+      lds_limit_mark(kp);
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, st, p);

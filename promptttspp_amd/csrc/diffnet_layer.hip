@@ -705,15 +705,15 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
       default: ptpp_set_error("diffnet_layer_fwd_dbg: mode %d is not built", dbg); return PTPP_EINVAL;
     }
   }
-  {  // once per kernel: the dynamic LDS size is above the 64 KiB default
-    static const void* done[24];
-    static int ndone = 0;
+  {  // once per (device, kernel): the dynamic LDS size is above the 64 KiB default
     const void* kp = reinterpret_cast<const void*>(kern);
-    bool seen = false;
-    for (int i = 0; i < ndone; ++i) seen = seen || done[i] == kp;
-    if (!seen) {
-      (void)hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (ndone < 24) done[ndone++] = kp;
+    if (!lds_limit_raised(kp)) {
+      const hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        ptpp_set_error("diffnet_layer_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        return PTPP_ELAUNCH;
+      }
+      lds_limit_mark(kp);
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, reinterpret_cast<hipStream_t>(stream), p);

@@ -63,6 +63,9 @@ extern "C" int ptpp_add3_scale(const void* a, const void* b, const void* c, void
   else if (dtype == PTPP_BF16)
     hipLaunchKernelGGL(add3_scale_kernel<bf16_raw>, dim3(grid), dim3(256), 0, st, (const bf16_raw*)a,
                        (const bf16_raw*)b, (const bf16_raw*)c, (bf16_raw*)y, scale, n4);
+  else if (dtype == PTPP_F16)
+    hipLaunchKernelGGL(add3_scale_kernel<f16_raw>, dim3(grid), dim3(256), 0, st, (const f16_raw*)a, (const f16_raw*)b,
+                       (const f16_raw*)c, (f16_raw*)y, scale, n4);
   else
     PTPP_CHECK_ARG(false, "add3_scale: bad dtype");
   PTPP_CHECK_LAUNCH("add3_scale");
@@ -76,6 +79,7 @@ extern "C" int ptpp_cast_from_f32(const float* x, void* y, int64_t n, int dtype,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PTPP_F32) hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)y, n4);
   else if (dtype == PTPP_BF16) hipLaunchKernelGGL(cast_from_f32_kernel<bf16_raw>, dim3(grid), dim3(256), 0, st, x, (bf16_raw*)y, n4);
+  else if (dtype == PTPP_F16) hipLaunchKernelGGL(cast_from_f32_kernel<f16_raw>, dim3(grid), dim3(256), 0, st, x, (f16_raw*)y, n4);
   else PTPP_CHECK_ARG(false, "cast_from_f32: bad dtype");
   PTPP_CHECK_LAUNCH("cast_from_f32");
   return PTPP_OK;
@@ -92,6 +96,8 @@ extern "C" int ptpp_conv_post_tanh(const void* x, const float* w, float bias, fl
     hipLaunchKernelGGL(conv_post_tanh_kernel<float>, grid, blk, smem, st, (const float*)x, w, bias, y, T, C, ks);
   else if (dtype == PTPP_BF16)
     hipLaunchKernelGGL(conv_post_tanh_kernel<bf16_raw>, grid, blk, smem, st, (const bf16_raw*)x, w, bias, y, T, C, ks);
+  else if (dtype == PTPP_F16)
+    hipLaunchKernelGGL(conv_post_tanh_kernel<f16_raw>, grid, blk, smem, st, (const f16_raw*)x, w, bias, y, T, C, ks);
   else
     PTPP_CHECK_ARG(false, "conv_post_tanh: bad dtype");
   PTPP_CHECK_LAUNCH("conv_post_tanh");

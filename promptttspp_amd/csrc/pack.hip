@@ -244,7 +244,7 @@ extern "C" int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin
   PTPP_CHECK_ARG(w && wp, "pack_conv_weight: null pointer");
   PTPP_CHECK_ARG(cout > 0 && cin > 0 && ks > 0 && (mode == 0 || mode == 1 || (mode == 2 && cout % 8 == 0) || mode == 3 || mode == 4),
                  "pack_conv_weight: bad args");
-  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "pack_conv_weight: bad dtype");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16 || (dtype == PTPP_F16 && mode <= 1), "pack_conv_weight: bad dtype (f16: modes 0 / 1)");
   const bool tr = mode == 1 || mode == 4;
   const int rows = !tr ? cout : cin;
   const int inner = !tr ? cin : cout;
@@ -258,6 +258,9 @@ extern "C" int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin
   if (dtype == PTPP_F32)
     hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)wp, cout, cin, ks, mode, rows,
                        inner, innerp);
+  else if (dtype == PTPP_F16)
+    hipLaunchKernelGGL(pack_conv_kernel<f16_raw>, dim3(grid), dim3(256), 0, st, w, (f16_raw*)wp, cout, cin, ks, mode,
+                       rows, inner, innerp);
   else
     hipLaunchKernelGGL(pack_conv_kernel<bf16_raw>, dim3(grid), dim3(256), 0, st, w, (bf16_raw*)wp, cout, cin, ks, mode,
                        rows, inner, innerp);
@@ -282,6 +285,8 @@ extern "C" int ptpp_bct_to_btc(const float* x, void* y, int B, int C, int T, int
     hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, st, x, (float*)y, C, T);
   else if (dtype == PTPP_BF16)
     hipLaunchKernelGGL((transpose_kernel<float, bf16_raw>), grid, blk, 0, st, x, (bf16_raw*)y, C, T);
+  else if (dtype == PTPP_F16)
+    hipLaunchKernelGGL((transpose_kernel<float, f16_raw>), grid, blk, 0, st, x, (f16_raw*)y, C, T);
   else
     PTPP_CHECK_ARG(false, "bct_to_btc: bad dtype");
   PTPP_CHECK_LAUNCH("bct_to_btc");
@@ -296,6 +301,8 @@ extern "C" int ptpp_btc_to_bct(const void* x, float* y, int B, int T, int C, int
     hipLaunchKernelGGL((transpose_kernel<float, float>), grid, blk, 0, st, (const float*)x, y, T, C);
   else if (dtype == PTPP_BF16)
     hipLaunchKernelGGL((transpose_kernel<bf16_raw, float>), grid, blk, 0, st, (const bf16_raw*)x, y, T, C);
+  else if (dtype == PTPP_F16)
+    hipLaunchKernelGGL((transpose_kernel<f16_raw, float>), grid, blk, 0, st, (const f16_raw*)x, y, T, C);
   else
     PTPP_CHECK_ARG(false, "btc_to_bct: bad dtype");
   PTPP_CHECK_LAUNCH("btc_to_bct");

@@ -9,6 +9,9 @@
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef unsigned short bf16_raw;  // storage type of a bf16 element
+struct f16_raw {                  // storage type of an IEEE half element (a distinct type: the kernels are templated on it)
+  unsigned short v;
+};
 
 // ---- error plumbing ---------------------------------------------------------
 void ptpp_set_error(const char* fmt, ...);
@@ -29,6 +32,35 @@ void ptpp_set_error(const char* fmt, ...);
       return PTPP_ELAUNCH;                                            \
     }                                                                 \
   } while (0)
+
+// ---- "the dynamic-LDS limit of this kernel was raised on this device" (hipFuncSetAttribute is per device; the launchers call it
+// once per (device, kernel) instead of before every launch).  Per translation unit, guarded by a mutex: launches may come from
+// the autograd thread and the main thread.
+#include <mutex>
+namespace {
+struct LdsLimitSeen {
+  std::mutex mu;
+  struct Key { int dev; const void* k; } seen[64];
+  int n = 0;
+};
+inline LdsLimitSeen& lds_limit_table() { static LdsLimitSeen t; return t; }
+inline bool lds_limit_raised(const void* kern) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  LdsLimitSeen& t = lds_limit_table();
+  std::lock_guard<std::mutex> g(t.mu);
+  for (int i = 0; i < t.n; ++i)
+    if (t.seen[i].dev == dev && t.seen[i].k == kern) return true;
+  return false;
+}
+inline void lds_limit_mark(const void* kern) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  LdsLimitSeen& t = lds_limit_table();
+  std::lock_guard<std::mutex> g(t.mu);
+  if (t.n < 64) t.seen[t.n++] = {dev, kern};
+}
+}  // namespace
 
 // ---- bf16 <-> f32 (round to nearest even, like torch) -------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_raw v) {
@@ -84,6 +116,49 @@ struct Elem<bf16_raw> {
     *reinterpret_cast<uint2*>(p) = r;
   }
 };
+
+template <>
+struct Elem<f16_raw> {
+  static constexpr int PER16 = 8;
+  static __device__ __forceinline__ float ld(const f16_raw* p) { return (float)__builtin_bit_cast(_Float16, p->v); }
+  static __device__ __forceinline__ void st(f16_raw* p, float v) { p->v = __builtin_bit_cast(unsigned short, (_Float16)v); }
+  static __device__ __forceinline__ f32x4 ld4(const f16_raw* p) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const h4 r = *reinterpret_cast<const h4*>(p);
+    return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+  }
+  static __device__ __forceinline__ void st4(f16_raw* p, f32x4 v) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    *reinterpret_cast<h4*>(p) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  }
+};
+
+// two 16-bit elements in a 32-bit word (element 0 in the low half)
+template <typename T>
+struct H2;
+template <>
+struct H2<bf16_raw> {
+  static __device__ __forceinline__ float lo(uint32_t r) { return __uint_as_float(r << 16); }
+  static __device__ __forceinline__ float hi(uint32_t r) { return __uint_as_float(r & 0xffff0000u); }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+};
+template <>
+struct H2<f16_raw> {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  static __device__ __forceinline__ float lo(uint32_t r) { return (float)__builtin_bit_cast(h2, r)[0]; }
+  static __device__ __forceinline__ float hi(uint32_t r) { return (float)__builtin_bit_cast(h2, r)[1]; }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) { return __builtin_bit_cast(uint32_t, h2{(_Float16)a, (_Float16)b}); }
+};
+template <>
+struct H2<float> {  // (never used: the paired-fragment epilogue is 16-bit only; keeps the template well-formed)
+  static __device__ __forceinline__ float lo(uint32_t r) { return __uint_as_float(r); }
+  static __device__ __forceinline__ float hi(uint32_t r) { return __uint_as_float(r); }
+  static __device__ __forceinline__ uint32_t pack(float a, float) { return __float_as_uint(a); }
+};
+template <typename T>
+struct IsBf16 { static constexpr bool value = false; };
+template <>
+struct IsBf16<bf16_raw> { static constexpr bool value = true; };
 
 // ---- activations ------------------------------------------------------------
 __device__ __forceinline__ float act_apply(float v, int act) {

@@ -145,6 +145,8 @@ extern "C" int ptpp_aa_snake_fwd(const void* x, void* y, const float* log_alpha,
   else if (dtype == PTPP_BF16)
     hipLaunchKernelGGL((aa_snake_kernel<bf16_raw, G>), grid, blk, 0, st, (const bf16_raw*)x, (bf16_raw*)y, log_alpha,
                        f, T, C, nrun);
+  else if (dtype == PTPP_F16)
+    hipLaunchKernelGGL((aa_snake_kernel<f16_raw, G>), grid, blk, 0, st, (const f16_raw*)x, (f16_raw*)y, log_alpha, f, T, C, nrun);
   else
     PTPP_CHECK_ARG(false, "aa_snake: bad dtype %d", dtype);
   PTPP_CHECK_LAUNCH("aa_snake_fwd");

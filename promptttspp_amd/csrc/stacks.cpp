@@ -49,9 +49,23 @@ ptpp_conv1d_args conv_args(const void* x, int ldx, const void* wp, const float* 
 // frame-level -- the SAME rule as promptttspp_amd/ops.py::conv1d_rt_ok, so that both paths take the same kernel -- else as before
 static bool rt_takes(const ptpp_conv1d_args& c, const void* wstream) {
   int64_t min_rows = 24576;
-  if (const char* e = getenv("PTPP_CONV_RT_MIN_ROWS")) min_rows = atoll(e);  // (tests run the row-tile paths at small shapes)
+  if (const char* e = getenv("PTPP_CONV_RT_MIN_ROWS")) min_rows = atoll(e);  // (the same variable ops.py reads; tests run the row-tile paths at small shapes)
   return wstream && (int64_t)c.B * c.T >= min_rows && ptpp_conv1d_rt_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype);
 }
+// 1: the row-tile kernel takes the launch; 0: no operand stream was handed over (the tile kernel reads wp); -1: a stream WAS
+// handed over but this side would not take the row-tile kernel.  The caller packs ONLY the stream form in that case (and may
+// alias wp to it), so falling back to wp would read a stream image as a [Cout][ks][Cin] operand: refuse instead.
+static int rt_decide(const ptpp_conv1d_args& c, const void* wstream, const char* who) {
+  if (!wstream) return 0;
+  if (rt_takes(c, wstream)) return 1;
+  ptpp_set_error("%s: an operand stream (pack mode 3 / 4) was passed for a launch the row-tile kernel does not take here (B*T=%lld, "
+                 "Cin=%d, Cout=%d, ks=%d, dil=%d; PTPP_CONV_RT_MIN_ROWS must read the same in both layers)",
+                 who, (long long)c.B * c.T, c.Cin, c.Cout, c.ks, c.dil);
+  return -1;
+}
+#define ST_RT(var, c, ws, who)                 \
+  const int var = rt_decide(c, ws, who);       \
+  if (var < 0) return PTPP_EINVAL
 
 extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void* stream) {
   ST_CHECK_ARG(a && a->h0 && (a->cond_all || a->condx) && a->dsteps && a->skip && a->dil_wp && a->dil_b && a->out_wp && a->out_b && a->yin_all &&
@@ -167,7 +181,8 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
     const int d = 1 << (l % a->cycle);
     ptpp_conv1d_args c = conv_args(a->dcond_all, ldc, a->dil_wpt[l], nullptr, a->gx_all, C, a->gx_all, C, a->lengths, B, T, 2 * C, C, 3, d, d,
                                    PTPP_ACT_NONE, bmask, 0, dt);
-    fold = rt_takes(c, a->dil_wst[l]);
+    ST_RT(rt, c, a->dil_wst[l], "diffnet_stack_bwd");
+    fold = rt == 1;
   }
   if (fold) ST_TRY(ptpp_diffnet_post_bwd_fill(a->gS, a->do_all, a->lengths, B, T, C, L, dt, stream));
   for (int l = L - 1; l >= 0; --l) {
@@ -203,8 +218,7 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
     ptpp_conv1d_args c = conv_args(da, ldc, a->dil_wpt[l], nullptr, gx, C, at(a->gx_all, (size_t)l * BTC, dt), C, a->lengths, B, T, 2 * C, C,
                                    3, d, d, PTPP_ACT_NONE, bmask, 0, dt);
     if (fold) ST_TRY(ptpp_conv1d_rt_fwd_aux(&c, a->dil_wst[l], r2, l > 0 ? at(a->do_all, (size_t)(l - 1) * 2 * BTC, dt) : nullptr, 2 * C, r2, stream));
-    else if (rt_takes(c, a->dil_wst ? a->dil_wst[l] : nullptr)) ST_TRY(ptpp_conv1d_rt_fwd(&c, a->dil_wst[l], r2, stream));
-    else ST_TRY(ptpp_conv1d_fwd_ex(&c, nullptr, 0, r2, 0.f, 0, stream));
+    else ST_TRY(ptpp_conv1d_fwd_ex(&c, nullptr, 0, r2, 0.f, 0, stream));  // (fold is false only without operand streams: checked above)
   }
   if (a->batched_wgrad) {
     // every layer's (g, do) and (yin, da) pair is still in its slab: all output-projection gradients in one launch, all
@@ -290,7 +304,8 @@ extern "C" int ptpp_conv_ln_stack_fwd(const ptpp_conv_ln_stack_fwd_args* a, void
     void* y = at(a->x_all, i * BTC, dt);
     ptpp_conv1d_args c = conv_args(x, C, a->wp[i], a->bias[i], nullptr, 0, z, C, a->conv_mask ? a->lengths : nullptr, B, T, C, C, a->ks, 1,
                                    a->ks / 2, a->conv_act, a->conv_mask ? 1 : 0, 0, dt);
-    if (rt_takes(c, a->wstream ? a->wstream[i] : nullptr)) ST_TRY(ptpp_conv1d_rt_fwd(&c, a->wstream[i], 1.0f, stream));
+    ST_RT(rt, c, a->wstream ? a->wstream[i] : nullptr, "conv_ln_stack_fwd");
+    if (rt) ST_TRY(ptpp_conv1d_rt_fwd(&c, a->wstream[i], 1.0f, stream));
     else ST_TRY(linear_like_ops(c, 0.f, 0, a->ws, a->ws_bytes, stream));
     const int om = a->out_mask == 1 || (a->out_mask == 2 && i == n - 1);
     ST_TRY(ptpp_layernorm_fwd(z, a->ln_res ? x : nullptr, a->gamma[i], a->beta[i], y, fused_in ? at(a->sum_all, i * BTC, dt) : nullptr,
@@ -352,7 +367,8 @@ extern "C" int ptpp_conv_ln_stack_bwd(const ptpp_conv_ln_stack_bwd_args* a, void
       void* dx = a->ln_res ? aux : gnext;
       ptpp_conv1d_args c = conv_args(gz, C, a->wpt[i], nullptr, nullptr, 0, dx, C, clen, B, T, C, C, ks, 1, (ks - 1) - pad, PTPP_ACT_NONE, 0,
                                      a->conv_mask ? 1 : 0, dt);
-      if (rt_takes(c, a->wstream_t ? a->wstream_t[i] : nullptr)) ST_TRY(ptpp_conv1d_rt_fwd(&c, a->wstream_t[i], 1.0f, stream));
+      ST_RT(rt, c, a->wstream_t ? a->wstream_t[i] : nullptr, "conv_ln_stack_bwd");
+      if (rt) ST_TRY(ptpp_conv1d_rt_fwd(&c, a->wstream_t[i], 1.0f, stream));
       else ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
       if (a->ln_res) ST_TRY(ptpp_add3_scale(dx, want_dz ? dsum : gz, nullptr, gnext, 1.0f, (int64_t)BTC, dt, stream));
       gout = gnext;

@@ -347,7 +347,9 @@ class GaussianDiffusion(nn.Module):
 
         fn = self.denoise_fn
         C = getattr(fn, "residual_channels", None) or fn.input_projection.weight.shape[0]
-        return PF.DIFFNET_LAYER_KERNEL and PF.STACK_DRIVERS and PF.diffnet_fused_gate(cond.dtype) and ops.diffnet_layer_supported(C, cond.dtype)
+        cycle = getattr(fn, "dilation_cycle_length", None) or getattr(fn, "cycle", 4)
+        return PF.DIFFNET_LAYER_KERNEL and PF.STACK_DRIVERS and PF.diffnet_fused_gate(cond.dtype) and cycle <= 4 and \
+            ops.diffnet_layer_supported(C, cond.dtype)
 
     split_min_rows = 8192
     split_ways = int(__import__("os").environ.get("PTPP_SAMPLER_WAYS", "2"))

@@ -14,7 +14,7 @@ import struct
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ConvArgs, check
+from ._lib import BF16, F16, F32, ConvArgs, check
 
 _ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "swish": 3, "tanh": 4, "mish": 5, "gate": 6}
 _VARIANT = {"new": 0, "legacy": 1, "plain": 2}
@@ -25,6 +25,8 @@ def dtype_code(dt):
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:  # the vocoder's inference kernels only (include/ptpp.h: PTPP_F16)
+        return F16
     raise TypeError(f"promptttspp_amd: unsupported compute dtype {dt}")
 
 
@@ -192,12 +194,20 @@ CONV_RT_MIN_ROWS = 24576  # (below ~200 row tiles of 128 the chip is not filled 
 _rt_ok = {}
 
 
+def conv_rt_min_rows():
+    """The row count from which a frame-level launch goes to the row-tile kernel.  ONE rule for both layers: the C drivers
+    (csrc/stacks.cpp::rt_takes) read PTPP_CONV_RT_MIN_ROWS, so this side reads it too (the module constant is the default and
+    what tests patch together with the variable); a driver that is handed an operand stream it would not use refuses the call."""
+    e = __import__("os").environ.get("PTPP_CONV_RT_MIN_ROWS")
+    return int(e) if e else CONV_RT_MIN_ROWS
+
+
 def conv1d_rt_ok(x, cout, ks, dil, act, res2=None, drop_p=0.0):
     """Whether ``conv1d`` would take the row-tile kernel (csrc/conv1d_rt.hip) for this launch when handed the operand stream
     (pack mode 3 / 4): bf16, 256 output channels, Cin % 64 == 0, ks >= 3, frame-level row counts, plain epilogue."""
     if not (CONV_RT and x.is_cuda and x.dtype == torch.bfloat16 and cout == 256 and res2 is None and drop_p == 0.0):
         return False
-    if x.shape[0] * x.shape[1] < CONV_RT_MIN_ROWS or x.stride(2) != 1:
+    if x.shape[0] * x.shape[1] < conv_rt_min_rows() or x.stride(2) != 1:
         return False
     key = (x.shape[2], ks, dil, act)
     ok = _rt_ok.get(key)

@@ -1000,10 +1000,15 @@ def test_sampler_loop_with_the_fused_head_matches_the_plain_loop(dev, B, T):
     assert rel_err(outs[True], outs[False]) < 1e-2, rel_err(outs[True], outs[False])
 
 
-def test_sampler_split_over_two_streams_is_bit_identical(dev):
+def test_sampler_split_over_two_streams_is_bit_identical(dev, monkeypatch):
     """Large batches: the two halves of the batch run their reverse loops on two streams (GaussianDiffusion._inference_split);
-    per utterance the arithmetic is that of the unsplit loop, so the mel is equal bit for bit (bf16 and f32, odd batch)."""
+    per utterance the arithmetic is that of the unsplit loop, so the mel is equal bit for bit (bf16 and f32, odd batch).
+    (Where the one-launch DiffNet layer serves, the product keeps the batch whole: the guard is lifted here so that the
+    split path itself is what runs in bf16 too.)"""
     from promptttspp_amd import config
+    from promptttspp_amd.modules.diffusion import GaussianDiffusion
+
+    monkeypatch.setattr(GaussianDiffusion, "_one_launch_layers", lambda self, cond: False)
 
     g = load_golden("diffusion")
     m, _ = load(node("decoder"), key_shapes(g["keys"]), 90, dev)

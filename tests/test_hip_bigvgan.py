@@ -66,9 +66,24 @@ def test_bigvgan_bf16_close(dev):
     m.set_compute_dtype(torch.bfloat16)
     y = m(g["x"].to(dev)).cpu()
     # bf16 storage through 72 convs: waveform-level agreement, not 1e-3
-    assert rel_err(y, g["y"]) < 0.08
+    assert rel_err(y, g["y"]) < 1.3e-2  # measured 8.2e-3 (round 5: x 1.5); the f16 mode holds 1.0e-3 (test_bigvgan_f16_close)
     mse = float(((y - g["y"]) ** 2).mean() / (g["y"] ** 2).mean())
     assert mse < 1e-3
+
+
+def test_bigvgan_f16_close(dev):
+    """PTPP_F16 (the reference's AMP dtype, BASELINE configs 4 / 5): half storage, f32 accumulation -- 3 more mantissa bits than
+    bf16 through the same 72 convs."""
+    m, sd, g = build(dev)
+    m.set_compute_dtype(torch.float16)
+    y = m(g["x"].to(dev)).cpu()
+    assert torch.isfinite(y).all()
+    e16 = rel_err(y, g["y"])
+    m.set_compute_dtype(torch.bfloat16)
+    eb = rel_err(m(g["x"].to(dev)).cpu(), g["y"])
+    print(f"BigVGAN waveform max-norm error vs the reference golden: f16 {e16:.2e}, bf16 {eb:.2e}")
+    assert e16 < 1.5e-2 and e16 < eb
+    assert float(((y - g["y"]) ** 2).mean() / (g["y"] ** 2).mean()) < 1e-5
 
 
 def test_weight_cache_follows_state_dict(dev):

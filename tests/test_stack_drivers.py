@@ -111,6 +111,32 @@ def test_diffnet_stack_backward_takes_dout_from_the_data_gradient_epilogue(dev, 
             assert float((a.double() - b.double()).abs().max() / a.double().abs().max()) < 2e-5, i
 
 
+def test_stack_driver_refuses_an_operand_stream_it_would_not_use(dev, monkeypatch):
+    """The row-tile decision is made on both sides of the C ABI (ops.conv1d_rt_ok / stacks.cpp::rt_takes) from the SAME
+    variable, PTPP_CONV_RT_MIN_ROWS.  Should the two ever disagree -- forced here by patching the Python side only -- the
+    driver must refuse the operand stream instead of reading it as a [Cout][ks][Cin] operand (silently wrong
+    activations and gradients)."""
+    from promptttspp_amd import _lib
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd import ops
+
+    B, T, C, L = 3, 333, 256, 5
+    h0, cond, dsteps, lengths, params = _stack_case(dev, B, T, C, L, torch.bfloat16, False, seed=5)
+    gout = rnd(9, B, T, C).to(dev).bfloat16()
+    monkeypatch.setattr(PF, "BATCHED_WGRAD", False)
+    monkeypatch.setattr(PF, "STACK_DRIVERS", True)
+    monkeypatch.setenv("PTPP_CONV_RT_MIN_ROWS", "1")
+    assert ops.conv_rt_min_rows() == 1                       # the Python side follows the variable
+    ok = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    monkeypatch.setattr(ops, "conv_rt_min_rows", lambda: 1)  # Python: row-tile; C (env): tile kernel
+    monkeypatch.setenv("PTPP_CONV_RT_MIN_ROWS", str(10 ** 9))
+    with pytest.raises(_lib.PtppError, match="operand stream"):
+        _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    monkeypatch.setenv("PTPP_CONV_RT_MIN_ROWS", "1")
+    again = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    assert all(torch.equal(a, b) for a, b in zip(ok, again))
+
+
 @pytest.mark.parametrize("B,T,C,L", [(6, 700, 256, 8), (19, 1500, 256, 20)])
 def test_diffnet_stack_batched_weight_gradients(dev, monkeypatch, B, T, C, L):
     """The driver's default: the 2 L weight gradients of the stack as two batched launches in which every dw element has ONE
