@@ -812,7 +812,25 @@ def main():
         ach = alg_bytes / vdt / 1e9
         traffic, tsrc = measured_traffic(TRAFFIC_VOC) if (a.dtype == "bf16" and a.voc_batch == 64 and a.voc_frames == 1000) \
             else (None, "PMC summary is for 64 x 1000 frames bf16 only")
-        voc = {"rtf": vdt / audio_s, "ms_per_batch": 1e3 * vdt, "batch": a.voc_batch, "frames": a.voc_frames,
+        # BASELINE config 4 is worded "fp16": the same generator with IEEE-half storage (PTPP_F16), timed beside the bf16 run
+        f16 = None
+        if a.dtype == "bf16" and world == 1:
+            voc_model.set_compute_dtype(torch.float16)
+            xx = torch.clamp(-5.5 + 2.1 * torch.randn(a.voc_batch, 80, a.voc_frames, device=dev), -11.5, 2.0)
+            for _ in range(2):
+                voc_model(xx)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                voc_model(xx)
+            torch.cuda.synchronize()
+            fdt = (time.perf_counter() - t0) / 3
+            voc_model.set_compute_dtype(torch.bfloat16)
+            f16 = {"ms_per_batch": round(1e3 * fdt, 3), "rtf": fdt / audio_s,
+                   "roofline_frac": round(alg_bytes / fdt / 1e9 / HBM_PEAK_GBS, 4), "dtype": "f16"}
+            del xx
+        voc = {"rtf": vdt / audio_s, "ms_per_batch": 1e3 * vdt, "batch": a.voc_batch, "frames": a.voc_frames, "dtype": a.dtype,
+               "f16": f16,
                "algorithmic_tflops": world * a.voc_batch * a.voc_frames * 444.5e6 / vdt / 1e12,
                "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg_bytes, "traffic": traffic,

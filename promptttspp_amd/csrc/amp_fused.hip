@@ -718,12 +718,13 @@ int launch_snake_conv(SnkP& p, hipStream_t st) {
     return PTPP_ENOTSUP;
   }
   auto kern = snake_conv_kernel<E, C, BT, S, MG, PAIR>;
-  if (smem > 64 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 64 * 1024 && !lds_limit_raised(reinterpret_cast<const void*>(kern))) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
-      ptpp_set_error("snake_conv: cannot raise the dynamic LDS limit to %zu B: %s", smem, hipGetErrorString(e));
+      ptpp_set_error("snake_conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
       return PTPP_ELAUNCH;
     }
+    lds_limit_mark(reinterpret_cast<const void*>(kern));
   }
   p.nMT = (p.T + BT - 1) / BT;
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, st, p);
@@ -839,12 +840,13 @@ int launch_amp_fused(AmpF& p, hipStream_t st) {
     return PTPP_ENOTSUP;
   }
   auto kern = amp_fused_kernel<E, C, BT, S, MG1, MG2, PAIR>;
-  if (smem > 64 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 64 * 1024 && !lds_limit_raised(reinterpret_cast<const void*>(kern))) {  // once per (device, kernel)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
-      ptpp_set_error("amp_fused: cannot raise the dynamic LDS limit to %zu B: %s", smem, hipGetErrorString(e));
+      ptpp_set_error("amp_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
       return PTPP_ELAUNCH;
     }
+    lds_limit_mark(reinterpret_cast<const void*>(kern));
   }
   p.nMT = (p.T + BT - 1) / BT;
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, st, p);

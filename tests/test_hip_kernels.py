@@ -1026,6 +1026,62 @@ def test_attention_backward_on_the_matrix_cores(dev, variant, B, T, H, dk, drop)
             assert float(got[0][bi, n:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,T,H,dk", [(3, 130, 2, 128), (4, 77, 4, 64)])
+def test_attention_backward_on_the_matrix_cores_against_the_oracle(dev, B, T, H, dk):
+    """ONE hop from the oracle: the bf16 attention forward + attn_bwd_{q,k,pos}_mfma_kernel against
+    oracle/ref_torch.relpos_attention (esp/transformer/attention.py:63-93, 237-305) under f32 autograd -- the same weights,
+    positional table and ragged lengths; q / k / v and the projected table enter the kernels rounded to bf16.  Compared: the
+    context, and the gradients of the layer input (dq Wq + dk Wk + dv Wv), of linear_pos.weight (dpos^T pos_emb) and of the
+    two biases."""
+    from promptttspp_amd import ops
+
+    C = H * dk
+    L = 2 * T - 1
+    sd = {}
+    for i, n in enumerate(("linear_q", "linear_k", "linear_v", "linear_out")):
+        sd[f"a.{n}.weight"] = rnd(10 + i, C, C) / C ** 0.5
+        sd[f"a.{n}.bias"] = 0.1 * rnd(20 + i, C)
+    sd["a.linear_out.weight"], sd["a.linear_out.bias"] = torch.eye(C), torch.zeros(C)   # the kernels end at the context
+    sd["a.linear_pos.weight"] = rnd(30, C, C) / C ** 0.5
+    sd["a.pos_bias_u"], sd["a.pos_bias_v"] = 0.1 * rnd(31, H, dk), 0.1 * rnd(32, H, dk)
+    x = 0.7 * rnd(1, B, T, C)
+    pos_emb = 0.7 * rnd(2, L, C)
+    g = 0.5 * rnd(3, B, T, C)
+    lens = torch.tensor([max(1, T - 19 * i) for i in range(B)], dtype=torch.int32)
+    key_mask = torch.arange(T)[None, :] < lens[:, None]
+    # oracle, f32 autograd
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in ("a.linear_pos.weight", "a.pos_bias_u", "a.pos_bias_v")}
+    xr = x.clone().requires_grad_(True)
+    ctx_ref = R.relpos_attention({**sd, **leaf}, "a", xr, pos_emb, key_mask, H, "new")
+    valid = key_mask[:, :, None].float()
+    (ctx_ref * g * valid).sum().backward()
+    # kernels, bf16
+    q = F.linear(x, sd["a.linear_q.weight"], sd["a.linear_q.bias"])
+    k = F.linear(x, sd["a.linear_k.weight"], sd["a.linear_k.bias"])
+    v = F.linear(x, sd["a.linear_v.weight"], sd["a.linear_v.bias"])
+    qkv = torch.cat([q, k, v], -1).to(dev).bfloat16()
+    pp = F.linear(pos_emb, sd["a.linear_pos.weight"]).to(dev).bfloat16()
+    u, vb = sd["a.pos_bias_u"].to(dev), sd["a.pos_bias_v"].to(dev)
+    ld = lens.to(dev)
+    qd, kd, vd = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+    ctx, probs = ops.attention_fwd(qd, kd, vd, pp, u, vb, ld, H, "new", save_probs=True)
+    d = torch.zeros((B, T, 3 * C), device=dev, dtype=torch.bfloat16)
+    dctx = (g * valid).to(dev).bfloat16()
+    dpos, du, dvb = ops.attention_bwd(qd, kd, vd, pp, u, vb, probs, dctx, ld, H, "new", d[:, :, :C], d[:, :, C:2 * C], d[:, :, 2 * C:])
+    torch.cuda.synchronize()
+
+    def nerr(a, r):
+        return float((a - r).abs().max() / r.abs().max())
+
+    assert nerr(ctx.float().cpu() * valid, ctx_ref.detach() * valid) < 2e-2
+    df = d.float().cpu()
+    dx = df[:, :, :C] @ sd["a.linear_q.weight"] + df[:, :, C:2 * C] @ sd["a.linear_k.weight"] + df[:, :, 2 * C:] @ sd["a.linear_v.weight"]
+    assert nerr(dx, xr.grad) < 3e-2, nerr(dx, xr.grad)
+    assert nerr(dpos.cpu().t() @ pos_emb, leaf["a.linear_pos.weight"].grad) < 3e-2
+    assert nerr(du.cpu().view(H, dk), leaf["a.pos_bias_u"].grad) < 3e-2
+    assert nerr(dvb.cpu().view(H, dk), leaf["a.pos_bias_v"].grad) < 3e-2
+
+
 @pytest.mark.parametrize("dtype,B,T,H,dk,w", [(torch.float32, 3, 77, 2, 128, 4), (torch.float32, 2, 130, 4, 64, 2),
                                               (torch.bfloat16, 5, 150, 2, 128, 4), (torch.float32, 1, 5, 2, 64, 4)])
 def test_windowed_relative_attention_kernel(dev, dtype, B, T, H, dk, w):
