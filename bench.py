@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0
 # HBM traffic comes from PMC passes (bench.py cannot run rocprofv3 on itself): the committed summaries of
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command / of tools/bench_vocoder.py, written by
 # tools/pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md; the JSON line names the file it read.
-TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r04_hbm_traffic_train.json")
-TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r04_hbm_traffic_bigvgan.json")
+TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r05_hbm_traffic_train.json")
+TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r05_hbm_traffic_bigvgan.json")
 
 
 def measured_traffic(path, kernel_substr=None):
@@ -370,6 +370,12 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
             "diffnet_layer": layer, "launch_by_launch_path": per_launch,
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src,
+            # `traffic` above is the 64 x 128-tile kernel's; the two other families the `kernel` string names, from the same passes
+            "traffic_by_family": {k: measured_traffic(TRAFFIC_TRAIN, sub)[0] for k, sub in
+                                  (("conv1d_glds_kernel<2,4,2,2,2,false,0>", "conv1d_glds_kernel<2, 4, 2, 2, 2, false, 0"),
+                                   ("conv1d_rt_kernel<5,4,0>", "conv1d_rt_kernel<5, 4, 0"),
+                                   ("diffnet_layer_kernel<5,true,0,4,true>", "diffnet_layer_kernel<5, true, 0, 4, true"))}
+            if dtype_name == "bf16" else None,
             "launches": n_launch, "avg_launch_us": round(1e3 * tot_ms / max(n_launch, 1), 2),
             "flop_per_step": tot_flop, "by_bound": by_bound,
             "note": "instrumented extra step on the timed batch with the longest utterances, issued launch by launch (the timed "

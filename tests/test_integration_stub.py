@@ -25,7 +25,7 @@ def _stub():
 
 def test_stub_binds_and_names_the_references_attributes():
     mod, src = _stub()
-    for fn in ("aa_snake_channels_last", "conv1d_channels_last", "amp_layer_channels_last"):
+    for fn in ("aa_snake_channels_last", "conv1d_channels_last", "amp_layer_channels_last", "amp_layer_fused_channels_last"):
         assert callable(getattr(mod, fn))
     # the reference's own names (activations.py:22-44, bigvgan.py:24-40), not another code base's
     for name in ("act.up.filter", "act.down.lowpass.filter", "act.act.alpha", "layer.act1", "layer.conv2", "weight_g"):
@@ -38,10 +38,11 @@ def test_stub_binds_and_names_the_references_attributes():
     from promptttspp_amd import _lib
 
     assert ctypes.sizeof(mod.ConvArgs) == ctypes.sizeof(_lib.ConvArgs) == 112
+    assert ctypes.sizeof(mod.AmpLayerArgs) == ctypes.sizeof(_lib.AmpLayerArgs)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 3e-2), (torch.float16, 4e-3)])
 def test_stub_amp_layer_matches_oracle(dtype, tol):
     from oracle import ref_torch as R
     from oracle.fill import fill_state_dict
@@ -58,3 +59,5 @@ def test_stub_amp_layer_matches_oracle(dtype, tol):
     y = mod.amp_layer_channels_last(x.transpose(1, 2).contiguous().to(dev).to(dtype), layer)
     torch.cuda.synchronize()
     assert rel_err(y.float().cpu().transpose(1, 2), ref) < tol
+    yf = mod.amp_layer_fused_channels_last(x.transpose(1, 2).contiguous().to(dev).to(dtype), layer)   # the one-launch form
+    assert rel_err(yf.float().cpu().transpose(1, 2), ref) < tol
