@@ -29,6 +29,7 @@
 
 #include "conv1d_common.h"
 #include "lds_dma.h"
+#include <type_traits>
 
 namespace {
 
@@ -75,11 +76,11 @@ __device__ __forceinline__ float hi_bf16(uint32_t v) { return __uint_as_float(v 
 __device__ __forceinline__ float round_bf16_(float v) { return lo_bf16(pack_bf16x2(v, 0.f)); }
 
 // 16 MFMAs of one step: weights as the A operand, acc[fm][fn] += W[fn] * X[fm]
-template <bool NOMFMA = false, int FM = 4>
-__device__ __forceinline__ void dn_mfma_step(f32x4 (&acc)[FM][4], const uint4 (&wf)[4], const uint4 (&xf)[FM]) {
+template <bool NOMFMA = false, int FM = 4, int FN = 4>
+__device__ __forceinline__ void dn_mfma_step(f32x4 (&acc)[FM][FN], const uint4 (&wf)[FN], const uint4 (&xf)[FM]) {
   if constexpr (NOMFMA) {  // keep the LDS reads alive without the matrix work
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FN; ++i) {
       asm volatile("" ::"v"(wf[i].x), "v"(wf[i].w), "v"(xf[i % FM].x), "v"(xf[i % FM].w));
     }
     return;
@@ -87,7 +88,7 @@ __device__ __forceinline__ void dn_mfma_step(f32x4 (&acc)[FM][4], const uint4 (&
 #pragma unroll
   for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-    for (int fn = 0; fn < 4; ++fn)
+    for (int fn = 0; fn < FN; ++fn)
       acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[fn]), __builtin_bit_cast(bf16x8_t, xf[fm]),
                                                             acc[fm][fn], 0, 0, 0);
 }
@@ -106,9 +107,22 @@ __device__ __forceinline__ void dn_wait_stage(int s) {
 
 // DBG (tools only, ptpp_diffnet_layer_fwd_dbg): bit 0 = clock stamps per block into p.stamps, bit 1 = no MFMAs, bit 2 = no
 // weight stream (the waits find nothing outstanding), bit 3 = no epilogue loads / stores
-template <int NS, bool SAVE, int DBG = 0, int FM = 4, bool COND = false>
+// GW (round 5): the weight fragments come STRAIGHT FROM GLOBAL MEMORY into registers, two steps ahead -- no LDS ring, no LDS-DMA
+// of weights, no barrier inside a 64-channel chunk.  A fragment of the stream's stage image is 1 KiB contiguous (16 rows of 64
+// bytes; the swizzle only permutes inside it), so the SAME stream serves both forms.  Why: the ring loop spends 700-900 cycles
+// per step against 256 of MFMA issue -- a barrier, a counted vmcnt wait and ~40 scalar / address instructions per step for the
+// DMA bookkeeping (profiles/r04_diffnet_layer_phases.txt; the same fragment reads ALONE run at 332 cycles per step with a
+// barrier per step and 192 without, tools/experiments/lds_read_mimic.hip).  Here a chunk is 12 straight-line steps with
+// compile-time tap / half / register-set indices; barriers stay at the chunk boundaries (x windows) and around the epilogues.
+// FN (round 5): MFMA tiles per wave along the output channels.  4 = the 2 x 4 wave grid (a wave owns FM row tiles x 64 channels
+// per half); 2 = a 1 x 8 grid (every wave owns ALL rows of the block x 32 channels): no two waves read the same weight fragment,
+// so the GW form's L1 traffic halves (16 KiB per step and CU) -- the x fragments are what every wave reads, from LDS.
+template <int NS, bool SAVE, int DBG = 0, int FM = 4, bool COND = false, bool GW = false, int FN = 4>
 __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p) {
-  constexpr int BM = 32 * FM;  // rows per block: 2 wave rows x FM MFMA tiles of 16
+  constexpr int NWN = 16 / FN, NWM = 8 / NWN;  // the wave grid
+  constexpr int HN = FN / 2;                   // 32-channel groups [16 gate | 16 filter] per wave and half
+  constexpr int BM = 16 * FM * NWM;            // rows per block: NWM wave rows x FM MFMA tiles of 16
+  static_assert(FN == 2 || FN == 4, "wave grid");
   // COND: the conditioner projection (1 x 1, 256 -> 2C) joins pass A as four more 64-channel chunks with one tap each
   // (8 more pairs of steps); the gate epilogue then has no conditioner slice to read
   constexpr int NA = COND ? 32 : 24;        // pairs of steps of pass A
@@ -117,13 +131,13 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
   constexpr int LASTC = COND ? 7 : 3;       // last x chunk
   static_assert(NS >= 3 && NS <= 6, "ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object
-  uint4* Ring = reinterpret_cast<uint4*>(smem);                // [NS][1024]
-  uint4* G = Ring + NS * DN_STAGE_U4;                          // g [BM][32 chunks of 16 bytes]; first the x windows [2][xrows][8]
+  uint4* Ring = reinterpret_cast<uint4*>(smem);                // [NS][1024]  (GW: no ring)
+  uint4* G = Ring + (GW ? 0 : NS) * DN_STAGE_U4;               // g [BM][32 chunks of 16 bytes]; first the x windows [2][xrows][8]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.x / p.nMT, mt = blockIdx.x - b * p.nMT;
   const int t0 = mt * BM;
@@ -157,16 +171,16 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
 
   unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (DBG & 1) stamp[0] = wall_clock64();
-  f32x4 acc[2][FM][4];
+  f32x4 acc[2][FM][FN];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < FN; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: the ring fills while the scalar load of lengths[b] is on its way
-  issue_w(0, 0);
+  if constexpr (!GW) issue_w(0, 0);
   const int len = min(len_raw, T);
   const bool masked = p.lengths != nullptr;
   // a tile past the utterance's end (token-bucket batches are padded): every output is masked, no MFMA work
@@ -177,21 +191,21 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
   // DMA of stage s + NS - 1 into the slot of stage s - 1, requests the fragments of step s + 1 from LDS and only then
   // runs the 16 MFMAs of step s on the fragments requested a step earlier: the LDS round trip (all 8 waves read at once
   // after a barrier: ~0.2 us, as long as the MFMAs themselves) hides under the matrix work instead of preceding it.
-  uint4 wf0[4] = {}, wf1[4] = {}, xa[FM] = {}, xb_[FM] = {};
-  auto ld_w = [&](uint4 (&wf)[4], int slot) {
+  uint4 wf0[FN] = {}, wf1[FN] = {}, xa[FM] = {}, xb_[FM] = {};
+  auto ld_w = [&](uint4 (&wf)[FN], int slot) {
     if constexpr ((DBG & 64) != 0) return;  // (timing experiment: no fragment reads)
     const uint4* Wst = Ring + slot * DN_STAGE_U4;
     if constexpr ((DBG & 128) != 0) {  // (timing experiment: the x window's 128-byte-row pattern on the ring memory)
 #pragma unroll
-      for (int fn = 0; fn < 4; ++fn) {
+      for (int fn = 0; fn < FN; ++fn) {
         const int q = (wn & 1) * 64 + fn * 16 + lr;
         wf[fn] = Wst[q * 8 + (lg ^ swz<8>(q))];
       }
       return;
     }
 #pragma unroll
-    for (int fn = 0; fn < 4; ++fn) {
-      const int q = wn * 64 + fn * 16 + lr;
+    for (int fn = 0; fn < FN; ++fn) {
+      const int q = wn * (16 * FN) + fn * 16 + lr;
       wf[fn] = Wst[q * 4 + (lg ^ swz<4>(q))];
     }
   };
@@ -240,6 +254,177 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
   };
   auto next_slot = [&](int slot) { return slot + 1 == NS ? 0 : slot + 1; };
   int slot = 0;  // slot of the CURRENT step's stage
+  // ---- GW: weight fragments from global memory.  Lane (lr, lg) of wave (wm, wn) reads, for fragment fn of stage s, the 16 bytes
+  // at stage + ((wn * 64 + fn * 16 + lr) * 4 + (lg ^ swz<4>(row))) * 16 -- swz<4> does not change with fn * 16 or wn * 64, so the
+  // four fragments are ONE per-lane offset plus 1 KiB each.
+  typedef __attribute__((ext_vector_type(4))) uint32_t dn_u32x4;
+  constexpr bool XPF = (FN == 2 && !(COND && FM == 8)) || FM < 4;  // a second x-fragment register set (prefetch one pair ahead) where it fits
+  dn_u32x4 W[3][FN];
+  const uint32_t gw_off = (uint32_t)(((wn * (16 * FN) + lr) * 4 + (lg ^ swz<4>(wn * (16 * FN) + lr))) * 16);
+  const char* gw_base = reinterpret_cast<const char*>(p.wstream);
+  auto ldg = [&](dn_u32x4 (&w)[FN], int s) __attribute__((always_inline)) {
+    const char* sb = gw_base + (size_t)s * (DN_STAGE_U4 * 16);
+    if constexpr (FN == 4) {
+      asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                   "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                   "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+                   "global_load_dwordx4 %3, %4, %5 offset:3072"
+                   : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                   : "v"(gw_off), "s"(sb)
+                   : "memory");
+    } else {
+      asm volatile("global_load_dwordx4 %0, %2, %3\n\t"
+                   "global_load_dwordx4 %1, %2, %3 offset:1024"
+                   : "=&v"(w[0]), "=&v"(w[1])
+                   : "v"(gw_off), "s"(sb)
+                   : "memory");
+    }
+  };
+  auto gw_mfma = [&](f32x4 (&a)[FM][FN], const dn_u32x4 (&w)[FN], const uint4 (&xf)[FM]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn)
+        a[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[fn]), __builtin_bit_cast(bf16x8_t, xf[fm]), a[fm][fn], 0, 0, 0);
+  };
+  // wait until the weights of step s have landed: everything issued after them may stay in flight -- the two younger weight
+  // groups (if they exist) and the NPW x-window pieces issued in between (loads retire in order).  EVERY wave issues exactly
+  // NPW pieces per window (a wave without a piece of its own repeats the window's last piece: same bytes to the same place),
+  // so the counts are compile-time constants.
+  constexpr int NPW = (BM + 2 * 8 + 7) / 8 > 16 ? 3 : 2;  // 8 waves x NPW >= the pieces of the widest window
+  auto gw_wait = [&](int younger_w, bool pieces) __attribute__((always_inline)) {
+    const int n = younger_w * FN + (pieces ? NPW : 0);
+    if (n >= 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // x-window pieces with one lane offset: piece q holds rows 8 q .. 8 q + 7 of the window; lane (l3 = lane / 8, l7 = lane % 8)
+  // moves the 16 bytes of row l3, chunk column l7 ^ swz<8>(8 q + l3) = l7 ^ (l3 / 2) ^ 4 (q & 1)
+  const uint32_t gx_voff = (uint32_t)((lane >> 3) * (DN_C * 2) + (((lane & 7) ^ (lane >> 4)) << 4));
+  auto gw_piece = [&](int ci, int k) __attribute__((always_inline)) {
+    const int q = min(wave + 8 * k, np - 1);
+    const int ts0 = t0 - dil + q * 8;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(xs_lds + (uint32_t)(((ci & 1) * xrows + q * 8) * 128));
+    const bf16_raw* base = (COND && ci >= 4) ? cxb + (int64_t)ts0 * p.ldcx + (ci - 4) * 64 : yb + (int64_t)ts0 * DN_C + ci * 64;
+    const uint32_t rowb = (COND && ci >= 4) ? (uint32_t)p.ldcx * 2u : (uint32_t)(DN_C * 2);
+    uint32_t voff = gx_voff ^ (uint32_t)((q & 1) << 6);
+    if (COND && ci >= 4) voff = (uint32_t)(lane >> 3) * rowb + (voff & 127u);
+    if (ts0 >= 0 && ts0 + 7 < T) {
+      glds16_s(base, voff, dst);
+    } else {  // a window edge: rows outside the utterance come from the zero page (still exactly one DMA)
+      const int ts = ts0 + (lane >> 3);
+      const char* src = (ts >= 0 && ts < T) ? reinterpret_cast<const char*>(base) + voff : zero;
+      glds16(src, dst);
+    }
+  };
+  // x fragments with three lane addresses (one per tap): kh flips bit 2 of the swizzled chunk column = 64 bytes
+  int gx_idx[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int r = xrow0 + k * dil;
+    gx_idx[k] = r * 8 + (lg ^ swz<8>(r));
+  }
+  auto gw_ld_x = [&](uint4 (&xf)[FM], int par, int tap, int kh) __attribute__((always_inline)) {
+    int idx = gx_idx[tap];
+    if (kh) asm volatile("v_xor_b32 %0, 4, %1" : "=v"(idx) : "v"(gx_idx[tap]));  // (volatile: not hoisted into six loop invariants)
+    const uint4* src = G + par * xrows * 8 + idx;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) xf[fm] = src[fm * 128];
+  };
+  const int gg_idx = xrow0 * 32 + (lg ^ (xrow0 & 15));
+  auto gw_ld_g = [&](uint4 (&gf)[FM], int kc) __attribute__((always_inline)) {
+    int idx = gg_idx;
+    if (kc) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(idx) : "s"(kc * 4), "v"(gg_idx));
+    const uint4* src = G + idx;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) gf[fm] = src[fm * 512];
+  };
+  if constexpr (GW) {
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < NPW; ++k) gw_piece(0, k);
+      ldg(W[0], 0);
+      ldg(W[1], 1);
+      gw_wait(2, false);  // the window pieces are older than the two weight groups
+      lds_barrier();
+      gw_ld_x(xa, 0, 0, 0);
+      // One trip = one 64-channel chunk: 12 straight-line steps i = ((tap * 2 + kh) * 2 + nh); the register set of step s is
+      // s % 3 (a trip starts at a multiple of 3).  The next chunk's window pieces go out at the trip's first step, between the
+      // weight groups of s0 + 1 and s0 + 2: they are younger than the weights steps s0 and s0 + 1 wait for, older afterwards.
+      auto chunk = [&](int ci, int s0, auto more_c) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_c)::value;  // another window follows this chunk
+        const int par = ci & 1;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int s = s0 + i;
+          const int tk = i >> 1;  // tap * 2 + kh
+          if (i == 0 && MORE) {
+#pragma unroll
+            for (int k = 0; k < NPW; ++k) gw_piece(ci + 1, k);
+          }
+          if (s + 2 < SB) ldg(W[(i + 2) % 3], s + 2);
+          if constexpr (XPF) {  // the next pair's x fragments, one pair ahead (a second register set)
+            if (!(i & 1) && i + 2 < 12) {
+              if (tk & 1) gw_ld_x(xa, par, (tk + 1) >> 1, (tk + 1) & 1);
+              else gw_ld_x(xb_, par, (tk + 1) >> 1, (tk + 1) & 1);
+            }
+          } else {              // 128-row tiles: no registers for a second set -- the pair's fragments right before its first step
+            if (!(i & 1) && i > 0) gw_ld_x(xa, par, tk >> 1, tk & 1);
+          }
+          const int yw = (s + 2 < SB ? 1 : 0) + (s + 1 < SB ? 1 : 0);
+          gw_wait(yw, i <= 1 && MORE);
+          __builtin_amdgcn_sched_barrier(0);
+          if (XPF && (tk & 1)) gw_mfma(acc[i & 1], W[i % 3], xb_);
+          else gw_mfma(acc[i & 1], W[i % 3], xa);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+#pragma unroll 1
+      for (int ci = 0; ci < (COND ? 4 : 3); ++ci) {
+        chunk(ci, ci * 12, std::true_type{});
+        // the next window: this wave's pieces landed steps ago (the in-order waits above), now everyone's
+        lds_barrier();
+        gw_ld_x(xa, (ci + 1) & 1, COND && ci == 3 ? 1 : 0, 0);
+      }
+      if constexpr (!COND) chunk(3, 36, std::false_type{});
+      if constexpr (COND) {
+        // the four conditioner chunks (centre tap only: 4 steps each) as ONE straight-line trip of 16 steps, s0 = 48 = 0 mod 3
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int par = cc & 1;  // chunk 4 + cc
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = cc * 4 + j;
+            const int s = 48 + i;
+            if (j == 0 && cc < 3) {
+#pragma unroll
+              for (int k = 0; k < NPW; ++k) gw_piece(4 + cc + 1, k);
+            }
+            if (s + 2 < SB) ldg(W[(i + 2) % 3], s + 2);
+            if (XPF && j == 0) gw_ld_x(xb_, par, 1, 1);
+            if (!XPF && j == 2) gw_ld_x(xa, par, 1, 1);
+            const int yw = (s + 2 < SB ? 1 : 0) + (s + 1 < SB ? 1 : 0);
+            gw_wait(yw, j <= 1 && cc < 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (XPF && (j >> 1)) gw_mfma(acc[j & 1], W[i % 3], xb_);
+            else gw_mfma(acc[j & 1], W[i % 3], xa);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (cc < 3) {
+            lds_barrier();
+            gw_ld_x(xa, (cc + 1) & 1, 1, 0);
+          }
+        }
+      }
+    } else {
+      glds_wait<0>();
+    }
+  } else
   if (active) {
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -272,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       ld_w(wf1, next_slot(slot));
       fine_stamp(s, 4);
       __builtin_amdgcn_sched_barrier(0);  // the LDS requests above are issued BEFORE the matrix work ...
-      dn_mfma_step<(DBG & 2) != 0, FM>(acc[0], wf0, xcur);
+      dn_mfma_step<(DBG & 2) != 0, FM, FN>(acc[0], wf0, xcur);
       __builtin_amdgcn_sched_barrier(0);  // ... which stays on this side of the next barrier (register-only code moves across asm)
       fine_stamp(s, 5);
       slot = next_slot(slot);
@@ -288,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       }
       fine_stamp(s + 1, 4);
       __builtin_amdgcn_sched_barrier(0);
-      dn_mfma_step<(DBG & 2) != 0, FM>(acc[1], wf1, xcur);
+      dn_mfma_step<(DBG & 2) != 0, FM, FN>(acc[1], wf1, xcur);
       __builtin_amdgcn_sched_barrier(0);
       fine_stamp(s + 1, 5);
       slot = next_slot(slot);
@@ -309,28 +494,33 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     const bf16_raw* cb = p.cond + (int64_t)b * T * p.ldc;
     bf16_raw* ab = SAVE ? p.a_out + (int64_t)b * T * (2 * DN_C) : nullptr;
     uint2* G2 = reinterpret_cast<uint2*>(G);
-    // every conditioner vector of the wave's tile is requested before the first is used: one memory round trip, not sixteen
-    uint4 cv[2][2][FM];
+    // (the lane coordinates pass through an opaque copy: the epilogue's addresses are then computed HERE, not hoisted above
+    // pass A where they would sit in registers the K loop needs)
+    int lr_e = lr, lg_e = lg;
+    asm volatile("" : "+v"(lr_e), "+v"(lg_e));
+    // the conditioner vectors are requested two phases (nh, h) ahead of their use: two memory round trips in flight at any time,
+    // not sixteen serial ones -- and not all four phases at once either (64 registers the K loops need at 128-row tiles)
+    uint4 cv[2][HN][FM];
+    auto cv_load = [&](int nh, int h) __attribute__((always_inline)) {
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
+      for (int fm = 0; fm < FM; ++fm) {
+        const int t = t0 + wm * (16 * FM) + fm * 16 + lr_e;
+        cv[nh][h][fm] = make_uint4(0, 0, 0, 0);
+        if (!COND && t < T && !(DBG & 8)) cv[nh][h][fm] = *reinterpret_cast<const uint4*>(cb + (int64_t)t * p.ldc + nh * 256 + wn * (16 * FN) + h * 32 + lg_e * 8);
+      }
+    };
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) {
-          const int t = t0 + wm * (16 * FM) + fm * 16 + lr;
-          cv[nh][h][fm] = make_uint4(0, 0, 0, 0);
-          if (!COND && t < T && !(DBG & 8)) cv[nh][h][fm] = *reinterpret_cast<const uint4*>(cb + (int64_t)t * p.ldc + nh * 256 + wn * 64 + h * 32 + lg * 8);
-        }
+    for (int h = 0; h < HN; ++h) cv_load(0, h);
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int pch = nh * 256 + wn * 64 + h * 32 + lg * 8;  // 8 packed channels: [4 gate | their 4 filter partners]
+      for (int h = 0; h < HN; ++h) {
+        const int pch = nh * 256 + wn * (16 * FN) + h * 32 + lg_e * 8;  // 8 packed channels: [4 gate | their 4 filter partners]
         const int gch = pch >> 1;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.dil_b + pch), b1 = *reinterpret_cast<const f32x4*>(p.dil_b + pch + 4);
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) {
-          const int row = wm * (16 * FM) + fm * 16 + lr;
+          const int row = wm * (16 * FM) + fm * 16 + lr_e;
           const int t = t0 + row;
           const bool valid = t < T;
           const bool keep = !(masked && t >= len);
@@ -366,6 +556,11 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
           }
           G2[(row * 32 + ((gch >> 3) ^ (row & 15))) * 2 + ((gch >> 2) & 1)] = o;
         }
+        if (nh == 0) {
+          if constexpr (!COND) __builtin_amdgcn_sched_barrier(0);
+          cv_load(1, h);
+          if constexpr (!COND) __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
@@ -378,7 +573,32 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < FN; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (GW) {
+    if (active) {  // 16 straight-line steps i = kc * 2 + nh; no barrier: g is read-only now
+      constexpr int PB = SB % 3;
+      ldg(W[PB], SB);
+      ldg(W[(PB + 1) % 3], SB + 1);
+      gw_ld_g(xa, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i + 2 < 16) ldg(W[(PB + i + 2) % 3], SB + i + 2);
+        if constexpr (XPF) {
+          if (!(i & 1) && i + 2 < 16) {
+            if ((i >> 1) & 1) gw_ld_g(xa, (i >> 1) + 1);
+            else gw_ld_g(xb_, (i >> 1) + 1);
+          }
+        } else {
+          if (!(i & 1) && i > 0) gw_ld_g(xa, i >> 1);
+        }
+        gw_wait((i + 2 < 16 ? 1 : 0) + (i + 1 < 16 ? 1 : 0), false);
+        __builtin_amdgcn_sched_barrier(0);
+        if (XPF && ((i >> 1) & 1)) gw_mfma(acc[i & 1], W[(PB + i) % 3], xb_);
+        else gw_mfma(acc[i & 1], W[(PB + i) % 3], xa);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else
   if (active) {
     // (stage 48 landed and became visible at the top of step 47; g became visible at the barrier above)
     ld_w(wf0, slot);
@@ -388,7 +608,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       step_top(s, slot);
       ld_w(wf1, next_slot(slot));
       __builtin_amdgcn_sched_barrier(0);
-      dn_mfma_step<(DBG & 2) != 0, FM>(acc[0], wf0, gcur);
+      dn_mfma_step<(DBG & 2) != 0, FM, FN>(acc[0], wf0, gcur);
       __builtin_amdgcn_sched_barrier(0);
       slot = next_slot(slot);
       step_top(s + 1, slot);
@@ -397,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
         ld_g(gnext, kc + 1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      dn_mfma_step<(DBG & 2) != 0, FM>(acc[1], wf1, gcur);
+      dn_mfma_step<(DBG & 2) != 0, FM, FN>(acc[1], wf1, gcur);
       __builtin_amdgcn_sched_barrier(0);
       slot = next_slot(slot);
     };
@@ -417,10 +637,10 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     bf16_raw* yib = p.yin_next ? p.yin_next + (int64_t)b * T * DN_C : nullptr;
     float* skb = p.skip + (int64_t)b * T * DN_C;
     // biases / next step projection of the wave's 2 x 8 channels per lane
-    f32x4 bo[2][2], bs[2][2], dn[2][2];
+    f32x4 bo[HN][2], bs[HN][2], dn[HN][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ch = wn * 64 + h * 32 + lg * 8;
+    for (int h = 0; h < HN; ++h) {
+      const int ch = wn * (16 * FN) + h * 32 + lg * 8;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         bo[h][u] = *reinterpret_cast<const f32x4*>(p.out_b + ch + 4 * u);
@@ -434,16 +654,16 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     // are in flight per round (all sixteen + the accumulators spilled).
 #pragma unroll
     for (int f0 = 0; f0 < FM; f0 += 2) {
-      uint4 xr[2][2];
-      f32x4 sk[2][2][2];
+      uint4 xr[2][HN];
+      f32x4 sk[2][HN][2];
 #pragma unroll
       for (int df = 0; df < 2; ++df) {
         if (f0 + df >= FM) continue;  // (FM = 3: the last round has one tile)
         const int t = t0 + wm * (16 * FM) + (f0 + df) * 16 + lr;
         const bool in = t < T && !((DBG & 8) && t > 0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int ch = wn * 64 + h * 32 + lg * 8;
+        for (int h = 0; h < HN; ++h) {
+          const int ch = wn * (16 * FN) + h * 32 + lg * 8;
           xr[df][h] = make_uint4(0, 0, 0, 0);
           sk[df][h][0] = sk[df][h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (in) {
@@ -462,8 +682,8 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
         if (f0 + df >= FM || t >= T || ((DBG & 8) && t > 0)) continue;
         const bool keep = !(masked && t >= len);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int ch = wn * 64 + h * 32 + lg * 8;
+        for (int h = 0; h < HN; ++h) {
+          const int ch = wn * (16 * FN) + h * 32 + lg * 8;
           const uint4 xv4 = xr[df][h];
           const float xv[8] = {lo_bf16(xv4.x), hi_bf16(xv4.x), lo_bf16(xv4.y), hi_bf16(xv4.y), lo_bf16(xv4.z), hi_bf16(xv4.z), lo_bf16(xv4.w), hi_bf16(xv4.w)};
           float xn[8], yi[8];
@@ -484,8 +704,8 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
                 make_uint4(pack_bf16x2(yi[0], yi[1]), pack_bf16x2(yi[2], yi[3]), pack_bf16x2(yi[4], yi[5]), pack_bf16x2(yi[6], yi[7]));
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float* sp = skb + (int64_t)t * DN_C + wn * 64 + h * 32 + lg * 8;
+        for (int h = 0; h < HN; ++h) {
+          float* sp = skb + (int64_t)t * DN_C + wn * (16 * FN) + h * 32 + lg * 8;
           uint32_t sb[4];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -501,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
             sb[2 * u + 1] = pack_bf16x2(sv[2] * p.skip_scale, sv[3] * p.skip_scale);
           }
           if (p.skip_scaled)
-            *reinterpret_cast<uint4*>(p.skip_scaled + ((int64_t)b * T + t) * DN_C + wn * 64 + h * 32 + lg * 8) = make_uint4(sb[0], sb[1], sb[2], sb[3]);
+            *reinterpret_cast<uint4*>(p.skip_scaled + ((int64_t)b * T + t) * DN_C + wn * (16 * FN) + h * 32 + lg * 8) = make_uint4(sb[0], sb[1], sb[2], sb[3]);
         }
       }
     }
@@ -670,7 +890,12 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
   const bool small = bm == 64;
   p.nMT = (a->T + bm - 1) / bm;
   constexpr int NS = 5;
-  const size_t smem = (size_t)(NS * DN_STAGE_U4 + bm * 32) * 16 + ((dbg & 16) ? 1024 : 0);
+  // PTPP_DIFFNET_GW: 0 = LDS ring (default); 1 = weights straight from global memory, 2 x 4 wave grid; 2 = the same on the
+  // 1 x 8 wave grid (FN = 2).  Diagnostics builds exist for the ring form only.
+  const char* gwe = getenv("PTPP_DIFFNET_GW");
+  const int gwm = dbg ? 0 : (gwe ? atoi(gwe) : 2);
+  const bool gw = gwm == 1 || gwm == 2;
+  const size_t smem = (size_t)((gw ? 0 : NS * DN_STAGE_U4) + bm * 32) * 16 + ((dbg & 16) ? 1024 : 0);
   p.stamps = stamps;
   const bool sv = a->a_out != nullptr;
   auto kern = sv ? diffnet_layer_kernel<NS, true> : diffnet_layer_kernel<NS, false>;
@@ -680,6 +905,28 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
     kern = sv ? diffnet_layer_kernel<NS, true, 0, 4, true> : diffnet_layer_kernel<NS, false, 0, 4, true>;
     if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 2, true> : diffnet_layer_kernel<NS, false, 0, 2, true>;
     if (bm == 96) kern = sv ? diffnet_layer_kernel<NS, true, 0, 3, true> : diffnet_layer_kernel<NS, false, 0, 3, true>;
+  }
+  if (gwm == 1) {
+    if (a->condx) {
+      kern = sv ? diffnet_layer_kernel<NS, true, 0, 4, true, true> : diffnet_layer_kernel<NS, false, 0, 4, true, true>;
+      if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 2, true, true> : diffnet_layer_kernel<NS, false, 0, 2, true, true>;
+      if (bm == 96) kern = sv ? diffnet_layer_kernel<NS, true, 0, 3, true, true> : diffnet_layer_kernel<NS, false, 0, 3, true, true>;
+    } else {
+      kern = sv ? diffnet_layer_kernel<NS, true, 0, 4, false, true> : diffnet_layer_kernel<NS, false, 0, 4, false, true>;
+      if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 2, false, true> : diffnet_layer_kernel<NS, false, 0, 2, false, true>;
+      if (bm == 96) kern = sv ? diffnet_layer_kernel<NS, true, 0, 3, false, true> : diffnet_layer_kernel<NS, false, 0, 3, false, true>;
+    }
+  }
+  if (gwm == 2) {
+    if (a->condx) {
+      kern = sv ? diffnet_layer_kernel<NS, true, 0, 8, true, true, 2> : diffnet_layer_kernel<NS, false, 0, 8, true, true, 2>;
+      if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 4, true, true, 2> : diffnet_layer_kernel<NS, false, 0, 4, true, true, 2>;
+      if (bm == 96) kern = sv ? diffnet_layer_kernel<NS, true, 0, 6, true, true, 2> : diffnet_layer_kernel<NS, false, 0, 6, true, true, 2>;
+    } else {
+      kern = sv ? diffnet_layer_kernel<NS, true, 0, 8, false, true, 2> : diffnet_layer_kernel<NS, false, 0, 8, false, true, 2>;
+      if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 4, false, true, 2> : diffnet_layer_kernel<NS, false, 0, 4, false, true, 2>;
+      if (bm == 96) kern = sv ? diffnet_layer_kernel<NS, true, 0, 6, false, true, 2> : diffnet_layer_kernel<NS, false, 0, 6, false, true, 2>;
+    }
   }
   if (bm == 96 && dbg) { ptpp_set_error("diffnet_layer_fwd_dbg: the 96-row instantiation has no diagnostics build"); return PTPP_EINVAL; }
   if (dbg) {

@@ -17,6 +17,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// the same with a wave-uniform base (SGPR pair) and a 32-bit byte offset per lane: no 64-bit lane pointers to keep
+__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
 template <int N>
 __device__ __forceinline__ void glds_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

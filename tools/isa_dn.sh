@@ -7,6 +7,6 @@ import re
 t=open('/tmp/isa/diffnet.s').read()
 for m in re.finditer(r"\.name:\s+(\S+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", t, re.S):
     n=m.group(1)
-    if 'diffnet_layer_kernel' in n and 'Li0E' in n and 'Lb1EEEv' in n:
-        print(n[32:75], m.group(2), m.group(3))
+    if 'diffnet_layer_kernel' in n and 'Li0E' in n and 'Lb1E' in n[60:]:
+        print(n[32:80], m.group(2), m.group(3))
 PY
