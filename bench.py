@@ -773,10 +773,11 @@ def main():
         b = batches[a.warmup + i]
         out = train_step(model, b, red, opt, sched)
         frames += frame_counts[a.warmup + i]
+    host_dt = time.perf_counter() - t0  # the host has ENQUEUED the K steps (no device sync inside a step): << dt = the GPU is the limit
     barrier()
     dt = time.perf_counter() - t0
     loss = float(out["loss"])
-    log(f"timed region done: {dt:.3f}s for {a.steps} steps, loss {loss:.4f}; device allocations inside it: "
+    log(f"timed region done: {dt:.3f}s for {a.steps} steps (host enqueue {host_dt:.3f}s), loss {loss:.4f}; device allocations inside it: "
         f"{torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - nalloc0}, reserved {torch.cuda.memory_reserved(dev) / 2**30:.1f} GiB")
 
     dp = None
@@ -873,7 +874,7 @@ def main():
             "config": {"workload": "train.py model=prompttts_mdn_v2_wo_erg_final, dataset.max_tokens=%d per GPU, synthetic "
                                    "LibriTTS-R-shaped utterances, fwd+bwd+clip+AdamW+Noam, train mode (dropout on)" % a.max_tokens,
                        "utts_per_gpu_batch": int(B), "parallelism": f"dp{world}", "final_loss": round(loss, 4),
-                       "preheat_steps": a.preheat},
+                       "preheat_steps": a.preheat, "host_enqueue_ms_per_step": round(1e3 * host_dt / a.steps, 3)},
             "roofline": roof, "cpu_baseline": cpu,
             "per_gpu_value": round(frames / dt / world, 1),
             "dp": dp,

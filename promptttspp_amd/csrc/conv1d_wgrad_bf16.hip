@@ -26,8 +26,10 @@
 // and adds into dw: deterministic, and ~10x cheaper than the atomics.  Without a
 // workspace the partials are combined with atomics (fewer splits).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "ptpp_common.h"
+#include "lds_dma.h"
 #include "../../include/ptpp.h"
 
 namespace {
@@ -63,6 +65,16 @@ __device__ __forceinline__ void lds_fence(Frag (&f)[N]) {
   else
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi));
 }
+// the same with N younger LDS requests allowed to stay outstanding
+template <int NW, int N>
+__device__ __forceinline__ void lds_fence_n(Frag (&f)[N]) {
+  if constexpr (N == 4)
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo), "+v"(f[3].hi)
+                 : "n"(NW));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi) : "n"(NW));
+}
 __device__ __forceinline__ bf16x8_t join(const Frag& f) {
   v8s v;
   v[0] = f.lo[0]; v[1] = f.lo[1]; v[2] = f.lo[2]; v[3] = f.lo[3];
@@ -93,6 +105,40 @@ __device__ __forceinline__ Frag frag(const bf16_raw* tile, int row0, int c0, int
   Frag f;
   f.lo = tr_read(p);
   f.hi = tr_read(q);
+  return f;
+}
+
+// byte offset (inside a [rows][TW] tile) of the first transpose read of the fragment frag<TW>() reads
+template <int TW>
+__device__ __forceinline__ uint32_t frag_off(int row0, int c0, int lane) {
+  constexpr int CPR = TW / 8;
+  const int g = lane >> 4, i = lane & 15;
+  const int row = row0 + 8 * g + (i >> 2);
+  const int col = c0 + 4 * (i & 3);
+  return (uint32_t)(row * TW + (((col >> 3) ^ sw<CPR>(row)) << 3) + (col & 7)) * 2u;
+}
+// ... and of its second read (row + 4: the swizzle moves with the row, so this is a second per-lane constant unless
+// row0 % 8 == 0, where it is the first offset + 4 TW elements)
+template <int TW>
+__device__ __forceinline__ uint32_t frag_off_hi(int row0, int c0, int lane) {
+  constexpr int CPR = TW / 8;
+  const int g = lane >> 4, i = lane & 15;
+  const int row = row0 + 8 * g + (i >> 2) + 4;
+  const int col = c0 + 4 * (i & 3);
+  return (uint32_t)(row * TW + (((col >> 3) ^ sw<CPR>(row)) << 3) + (col & 7)) * 2u;
+}
+// the fragment at LDS byte addresses; row0 % 8 == 0 form: one address, the second read at a compile-time offset
+template <int TW>
+__device__ __forceinline__ Frag frag_at(uint32_t addr) {
+  Frag f;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(4 * TW * 2));
+  return f;
+}
+__device__ __forceinline__ Frag frag_at2(uint32_t lo, uint32_t hi) {
+  Frag f;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(lo));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(hi));
   return f;
 }
 
@@ -200,7 +246,8 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__
   constexpr int STAGE = KR * TM + XR * TN;         // elements per ring stage
   extern __shared__ __attribute__((aligned(16))) char smem[];  // the ONLY LDS object (see header)
   bf16_raw* S = reinterpret_cast<bf16_raw*>(smem);  // [NS][dy: KR x TM | x: KR x TN]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
 
   int bid = OWNER ? bid_in : xcd_remap(blockIdx.x, gridDim.x);
@@ -253,81 +300,168 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__
     xcol[q] = ((lane % CX) ^ sw<CX>(xrow[q])) * 8;
   }
 
-  auto issue = [&](int i) {  // chunk number i of this block -> ring stage i % NS
-    const int ch = split + i * p.nsplit;
-    const int b = ch / p.tchunks, tb = (ch - b * p.tchunks) * KR;
-    const int Tin = lengths ? min(lengths[b], p.T) : p.T;
-    bf16_raw* st = S + (i % NS) * STAGE;
-    const bf16_raw* dyb = pdy + (int64_t)b * p.T * p.lddy + co0;
-    const bf16_raw* xb = px + (int64_t)b * p.T * p.ldx + ci0;
+  // The loop's bookkeeping is kept off the issue ports (round 4 spent ~105 scalar + ~70 vector instructions per chunk on it --
+  // a division, the lengths load, 64-bit lane addresses, the fragment swizzles -- against 24 MFMAs: two waves per SIMD then
+  // need ~2100 cycles per chunk for 768 cycles of matrix work, profiles/r05_wgrad.txt).  Chunks are ISSUED in order, so the
+  // issue side keeps (utterance, chunk in utterance, ring slot) incrementally; an interior chunk (all rows of both operands
+  // inside the utterance, all columns inside the tensors) is LPW loads from a wave-uniform base plus a per-lane offset that
+  // never changes; only chunks touching an utterance's edge compute lane addresses and pick the zero page.
+  int ib, itc;  // utterance and chunk-in-utterance of the NEXT chunk to issue
+  {
+    ib = split / p.tchunks;
+    itc = split - ib * p.tchunks;
+  }
+  int islot = 0;
+  int iTin = 0, iTin_b = -1;
+  // row pointers of the next chunk to issue (utterance ib, row itc * KR), advanced by additions only
+  const char* yptr = reinterpret_cast<const char*>(pdy + ((int64_t)ib * p.T + (int64_t)itc * KR) * p.lddy + co0);
+  const char* xptr = reinterpret_cast<const char*>(px + ((int64_t)ib * p.T + (int64_t)itc * KR + shift) * p.ldx + ci0);
+  const int64_t ystep = (int64_t)p.nsplit * KR * p.lddy * 2, xstep = (int64_t)p.nsplit * KR * p.ldx * 2;
+  const int wrap_rows = p.T - p.tchunks * KR;  // row correction when the chunk index wraps into the next utterance (<= 0)
+  const int64_t ywrap = (int64_t)wrap_rows * p.lddy * 2, xwrap = (int64_t)wrap_rows * p.ldx * 2;
+  uint32_t yoff[LY], xoff[LX];
 #pragma unroll
-    for (int q = 0; q < LY; ++q) {
-      const int t = tb + yrow[q];
-      const bool ok = t < p.T && co0 + ycol[q] < p.Cout;
-      const char* src = ok ? reinterpret_cast<const char*>(dyb + (int64_t)t * p.lddy + ycol[q]) : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + (wave * LY + q) * 512), 16, 0, 0);
+  for (int q = 0; q < LY; ++q) yoff[q] = (uint32_t)(yrow[q] * p.lddy + ycol[q]) * 2u;
+#pragma unroll
+  for (int q = 0; q < LX; ++q) xoff[q] = (uint32_t)(xrow[q] * p.ldx + xcol[q]) * 2u;
+  const bool cols_in = co0 + TM <= p.Cout && ci0 + TN <= p.Cin;  // block-uniform
+  const uint32_t s_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) bf16_raw*)S;
+  auto issue = [&]() {  // the next chunk of this block -> ring slot islot
+    const int b = ib, tb = itc * KR;
+    if (b != iTin_b) {  // (scalar load: once per utterance)
+      iTin = lengths ? min(lengths[b], p.T) : p.T;
+      iTin_b = b;
     }
+    const int Tin = iTin;
+    const uint32_t st_lds = s_lds + (uint32_t)islot * (uint32_t)(STAGE * 2);
+    const bool interior = cols_in && tb + KR <= p.T && tb + shift >= 0 && tb + shift + XR <= Tin;
+    if (interior) {
+      glds16_s_n<LY>(yptr, yoff, st_lds + (uint32_t)(wave * LY * 1024));
+      glds16_s_n<LX>(xptr, xoff, st_lds + (uint32_t)(KR * TM * 2 + wave * LX * 1024));
+    } else {
+      const bf16_raw* dyb = pdy + (int64_t)b * p.T * p.lddy + co0;
+      const bf16_raw* xb = px + (int64_t)b * p.T * p.ldx + ci0;
 #pragma unroll
-    for (int q = 0; q < LX; ++q) {
-      const int ts = tb + xrow[q] + shift;  // (rows paired only with dy rows past T meet zeros there)
-      const bool ok = ts >= 0 && ts < Tin && ci0 + xcol[q] < p.Cin;
-      const char* src = ok ? reinterpret_cast<const char*>(xb + (int64_t)ts * p.ldx + xcol[q]) : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + KR * TM + (wave * LX + q) * 512), 16, 0, 0);
+      for (int q = 0; q < LY; ++q) {
+        const int t = tb + yrow[q];
+        const bool ok = t < p.T && co0 + ycol[q] < p.Cout;
+        const char* src = ok ? reinterpret_cast<const char*>(dyb + (int64_t)t * p.lddy + ycol[q]) : zero;
+        glds16(src, __builtin_amdgcn_readfirstlane(st_lds + (uint32_t)((wave * LY + q) * 1024)));
+      }
+#pragma unroll
+      for (int q = 0; q < LX; ++q) {
+        const int ts = tb + xrow[q] + shift;  // (rows paired only with dy rows past T meet zeros there)
+        const bool ok = ts >= 0 && ts < Tin && ci0 + xcol[q] < p.Cin;
+        const char* src = ok ? reinterpret_cast<const char*>(xb + (int64_t)ts * p.ldx + xcol[q]) : zero;
+        glds16(src, __builtin_amdgcn_readfirstlane(st_lds + (uint32_t)(KR * TM * 2 + (wave * LX + q) * 1024)));
+      }
+    }
+    islot = islot + 1 == NS ? 0 : islot + 1;
+    itc += p.nsplit;
+    yptr += ystep;
+    xptr += xstep;
+    while (itc >= p.tchunks) {
+      itc -= p.tchunks;
+      ++ib;
+      yptr += ywrap;
+      xptr += xwrap;
     }
   };
+
+  // fragment addresses: one LDS byte offset per lane and fragment, relative to the stage (they never change); the second
+  // transpose read of a fragment is 4 rows further = a compile-time offset
+  uint32_t offA[FM], offB[TG][FN], offBh[TG][FN];
+#pragma unroll
+  for (int a = 0; a < FM; ++a) offA[a] = frag_off<TM>(0, (wr * FM + a) * 16, lane);
+#pragma unroll
+  for (int g = 0; g < TG; ++g)
+#pragma unroll
+    for (int c = 0; c < FN; ++c) {
+      offB[g][c] = (uint32_t)(KR * TM * 2) + frag_off<TN>(g * pdil, (wc * FN + c) * 16, lane);
+      offBh[g][c] = (uint32_t)(KR * TM * 2) + frag_off_hi<TN>(g * pdil, (wc * FN + c) * 16, lane);
+    }
 
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, v8s{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i)
-    if (i < n) issue(i);
-  for (int i = 0; i < n; ++i) {
+    if (i < n) issue();
+  uint32_t cslot_lds = s_lds;  // ring slot of the chunk being multiplied
+  // the whole row loop exists twice: FULL = all TG taps of the group exist (the common case: no tap tests, the accumulators
+  // never move between the two forms' register assignments)
+  auto kloop = [&](auto full_c) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
+  auto chunk = [&](int i, auto steady_c) __attribute__((always_inline)) {
+    constexpr bool STEADY = decltype(steady_c)::value;  // NS - 2 younger chunks in flight and one more to issue: no tests
     // chunk i has landed once at most the loads of the (up to NS - 2) younger chunks are outstanding
-    const int younger = min(n - 1 - i, NS - 2);
     static_assert((NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
-    if (younger == NS - 2) wait_vm<(NS - 2) * LPW>();  // steady state
-    else if constexpr (NS > 3) {                        // drain at the end of the block's rows
-      if (younger >= 2) wait_vm<2 * LPW>();             // (waits for more than necessary for 2 < younger < NS - 2: tail only)
-      else if (younger == 1) wait_vm<LPW>();
-      else wait_vm<0>();
-    } else {
-      if (younger == 1) wait_vm<LPW>();
-      else wait_vm<0>();
+    if constexpr (STEADY) {
+      wait_vm<(NS - 2) * LPW>();
+    } else {  // drain at the end of the block's rows
+      const int younger = min(n - 1 - i, NS - 2);
+      if (younger == NS - 2) wait_vm<(NS - 2) * LPW>();
+      else if constexpr (NS > 3) {
+        if (younger >= 2) wait_vm<2 * LPW>();  // (waits for more than necessary for 2 < younger < NS - 2: tail only)
+        else if (younger == 1) wait_vm<LPW>();
+        else wait_vm<0>();
+      } else {
+        if (younger == 1) wait_vm<LPW>();
+        else wait_vm<0>();
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's pieces of chunk i visible; everyone done reading chunk i - 1
-    if (i + NS - 1 < n) issue(i + NS - 1);  // into the stage chunk i - 1 just vacated
-    const bf16_raw* Yb = S + (i % NS) * STAGE;
-    const bf16_raw* Xb = Yb + KR * TM;
-    Frag fa[FM];
+    if (STEADY || i + NS - 1 < n) issue();  // into the stage chunk i - 1 just vacated
+    // One exposed LDS round trip per chunk: the dy fragments and the first tap's x fragments are requested together; every
+    // further tap's fragments are requested BEFORE the previous tap's MFMAs and waited for with a counted lgkmcnt (the
+    // requests retire in order: 2 FN transpose reads of the younger tap may stay outstanding).  Round 4 fenced each tap's
+    // reads right after issuing them: 1 + TG round trips per chunk at 24 MFMAs per wave (profiles/r05_wgrad.txt).
+    Frag fa[FM], fb[2][FN];
 #pragma unroll
-    for (int a = 0; a < FM; ++a) fa[a] = frag<TM>(Yb, 0, (wr * FM + a) * 16, lane);
+    for (int a = 0; a < FM; ++a) fa[a] = frag_at<TM>(cslot_lds + offA[a]);
+#pragma unroll
+    for (int c = 0; c < FN; ++c) fb[0][c] = frag_at2(cslot_lds + offB[0][c], cslot_lds + offBh[0][c]);
     lds_fence(fa);
     bf16x8_t af[FM];
 #pragma unroll
     for (int a = 0; a < FM; ++a) af[a] = join(fa[a]);
+    {
 #pragma unroll
-    for (int g = 0; g < TG; ++g) {
-      if (g < ntap) {
-        Frag fb[FN];
+      for (int g = 0; g < TG; ++g) {
+        if (FULL || g < ntap) {
+          const bool more = g + 1 < TG && (FULL || g + 1 < ntap);
+          if (g + 1 < TG) {
+            if (more) {
 #pragma unroll
-        for (int c = 0; c < FN; ++c) fb[c] = frag<TN>(Xb, g * pdil, (wc * FN + c) * 16, lane);
-        lds_fence(fb);
-        bf16x8_t bfr[FN];
+              for (int c = 0; c < FN; ++c) fb[(g + 1) & 1][c] = frag_at2(cslot_lds + offB[g + 1 < TG ? g + 1 : 0][c], cslot_lds + offBh[g + 1 < TG ? g + 1 : 0][c]);
+            }
+          }
+          if (more) lds_fence_n<2 * FN>(fb[g & 1]);
+          else lds_fence(fb[g & 1]);
+          bf16x8_t bfr[FN];
 #pragma unroll
-        for (int c = 0; c < FN; ++c) bfr[c] = join(fb[c]);
+          for (int c = 0; c < FN; ++c) bfr[c] = join(fb[g & 1][c]);
 #pragma unroll
-        for (int a = 0; a < FM; ++a)
+          for (int a = 0; a < FM; ++a)
 #pragma unroll
-          for (int c = 0; c < FN; ++c)
-            acc[g][a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[c], acc[g][a][c], 0, 0, 0);
+            for (int c = 0; c < FN; ++c)
+              acc[g][a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[c], acc[g][a][c], 0, 0, 0);
+        }
       }
     }
     if (do_bias) {
 #pragma unroll
       for (int a = 0; a < FM; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
     }
-  }
+    cslot_lds = cslot_lds + (uint32_t)(STAGE * 2) == s_lds + (uint32_t)(NS * STAGE * 2) ? s_lds : cslot_lds + (uint32_t)(STAGE * 2);
+  };
+    const int nsteady = n - (NS - 1);  // chunks i with i + NS - 1 < n
+    int i = 0;
+    for (; i < nsteady; ++i) chunk(i, std::true_type{});
+    for (; i < n; ++i) chunk(i, std::false_type{});
+  };
+  if (ntap == TG) kloop(std::true_type{});
+  else kloop(std::false_type{});
 
   // D[i = co (rows 4*(lane>>4) + r)][j = ci (col lane&15)]
   const int lr = lane & 15, lg = lane >> 4;

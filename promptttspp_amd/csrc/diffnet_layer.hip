@@ -281,6 +281,11 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     }
   };
   auto gw_mfma = [&](f32x4 (&a)[FM][FN], const dn_u32x4 (&w)[FN], const uint4 (&xf)[FM]) __attribute__((always_inline)) {
+    if constexpr ((DBG & 2) != 0) {  // (timing experiment: the loads stay, the matrix work goes)
+#pragma unroll
+      for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(w[i]), "v"(xf[i % FM].x), "v"(xf[i % FM].w));
+      return;
+    }
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
@@ -352,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       ldg(W[1], 1);
       gw_wait(2, false);  // the window pieces are older than the two weight groups
       lds_barrier();
+      if constexpr (DBG & 1) stamp[1] = wall_clock64();
       gw_ld_x(xa, 0, 0, 0);
       // One trip = one 64-channel chunk: 12 straight-line steps i = ((tap * 2 + kh) * 2 + nh); the register set of step s is
       // s % 3 (a trip starts at a multiple of 3).  The next chunk's window pieces go out at the trip's first step, between the
@@ -883,7 +889,7 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
       const float cost = (float)((nb + 255) / 256) * tblk[i];
       if (cost < best - 0.5f) { best = cost; bm = cand[i]; }
     }
-    if (dbg & 16) bm = 128;
+    if ((dbg & 16) || dbg >= 200) bm = 128;
     const char* force = getenv("PTPP_DIFFNET_BM");  // (experiments)
     if (force && (atoi(force) == 64 || atoi(force) == 96 || atoi(force) == 128)) bm = atoi(force);
   }
@@ -893,9 +899,9 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
   // PTPP_DIFFNET_GW: 0 = LDS ring (default); 1 = weights straight from global memory, 2 x 4 wave grid; 2 = the same on the
   // 1 x 8 wave grid (FN = 2).  Diagnostics builds exist for the ring form only.
   const char* gwe = getenv("PTPP_DIFFNET_GW");
-  const int gwm = dbg ? 0 : (gwe ? atoi(gwe) : 2);
+  const int gwm = dbg >= 200 ? 2 : dbg ? 0 : (gwe ? atoi(gwe) : 2);  // (dbg 200 + m: mode m of the 1 x 8 GW form, 128 rows)
   const bool gw = gwm == 1 || gwm == 2;
-  const size_t smem = (size_t)((gw ? 0 : NS * DN_STAGE_U4) + bm * 32) * 16 + ((dbg & 16) ? 1024 : 0);
+  const size_t smem = (size_t)((gw ? 0 : NS * DN_STAGE_U4) + bm * 32) * 16 + ((dbg < 200 && (dbg & 16)) ? 1024 : 0);
   p.stamps = stamps;
   const bool sv = a->a_out != nullptr;
   auto kern = sv ? diffnet_layer_kernel<NS, true> : diffnet_layer_kernel<NS, false>;
@@ -946,6 +952,10 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
       case 143: kern = sv ? diffnet_layer_kernel<NS, true, 143> : diffnet_layer_kernel<NS, false, 143>; break;
       case 129: kern = sv ? diffnet_layer_kernel<NS, true, 129> : diffnet_layer_kernel<NS, false, 129>; break;
       case 111: kern = sv ? diffnet_layer_kernel<NS, true, 111> : diffnet_layer_kernel<NS, false, 111>; break;
+      case 201: kern = sv ? diffnet_layer_kernel<NS, true, 1, 8, false, true, 2> : diffnet_layer_kernel<NS, false, 1, 8, false, true, 2>; break;
+      case 203: kern = sv ? diffnet_layer_kernel<NS, true, 3, 8, false, true, 2> : diffnet_layer_kernel<NS, false, 3, 8, false, true, 2>; break;
+      case 209: kern = sv ? diffnet_layer_kernel<NS, true, 9, 8, false, true, 2> : diffnet_layer_kernel<NS, false, 9, 8, false, true, 2>; break;
+      case 211: kern = sv ? diffnet_layer_kernel<NS, true, 11, 8, false, true, 2> : diffnet_layer_kernel<NS, false, 11, 8, false, true, 2>; break;
       case 101: kern = sv ? diffnet_layer_kernel<NS, true, 1, 2> : diffnet_layer_kernel<NS, false, 1, 2>; break;
       case 109: kern = sv ? diffnet_layer_kernel<NS, true, 9, 2> : diffnet_layer_kernel<NS, false, 9, 2>; break;
       case 115: kern = sv ? diffnet_layer_kernel<NS, true, 15, 2> : diffnet_layer_kernel<NS, false, 15, 2>; break;

@@ -26,6 +26,31 @@ __device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, uint3
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
 }
+// N pieces of 1 KiB at consecutive LDS addresses lds_dst + 1024 q from one wave-uniform base and N lane offsets: M0 is saved
+// and restored once
+template <int N>
+__device__ __forceinline__ void glds16_s_n(const void* sbase, const uint32_t (&voff)[N], uint32_t lds_dst) {
+  static_assert(N >= 1 && N <= 4, "pieces per call");
+  unsigned keep;
+  if constexpr (N == 1)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "s"(sbase), "s"(lds_dst) : "memory");
+  else if constexpr (N == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(sbase), "s"(lds_dst) : "memory", "scc");
+  else if constexpr (N == 3)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(sbase), "s"(lds_dst) : "memory", "scc");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase), "s"(lds_dst) : "memory", "scc");
+}
 template <int N>
 __device__ __forceinline__ void glds_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

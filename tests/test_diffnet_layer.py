@@ -185,6 +185,45 @@ def test_layer_with_the_conditioner_projection_inside(dev, monkeypatch, B, T, di
     assert float(a_got_err.mean()) < float(a_ref_err.mean())
 
 
+@pytest.mark.parametrize("B,T,dil,masked,bm,cond_inside,save", [
+    (3, 333, 4, False, 128, False, True), (4, 517, 8, True, 96, False, False), (2, 100, 1, True, 64, False, True),
+    (3, 333, 2, True, 128, True, True), (4, 517, 8, False, 96, True, False), (2, 100, 1, True, 64, True, True)])
+def test_the_three_weight_paths_are_bit_identical(dev, monkeypatch, B, T, dil, masked, bm, cond_inside, save):
+    """PTPP_DIFFNET_GW = 0 (weight stages through the LDS ring, 2 x 4 wave grid), 1 (weight fragments straight from global
+    memory, 2 x 4) and 2 (the default: straight from global memory on the 1 x 8 wave grid) read the SAME operand stream and
+    issue the same MFMAs in the same K order: every output must be equal bit for bit, with and without the conditioner
+    projection inside the launch."""
+    from promptttspp_amd import functional as PF
+    from promptttspp_amd import ops
+
+    monkeypatch.setenv("PTPP_DIFFNET_BM", str(bm))
+    x, yin, cond_all, cond, dil_w, dil_b, out_w, out_b, dnext, skip0 = _case(dev, B, T, seed=90 + dil)
+    g = torch.Generator().manual_seed(78)
+    lengths = torch.tensor([max(1, T - 70 * i) for i in range(B)], device=dev, dtype=torch.int32) if masked else None
+    perm = PF._gate_perm(2 * C, x.device)
+    dwp, owp = ops.pack_conv_weight(dil_w, torch.bfloat16, 2), ops.pack_conv_weight(out_w, torch.bfloat16)
+    if cond_inside:
+        condx = torch.randn(B, T, 256, generator=g).to(dev).bfloat16()
+        cwp = ops.pack_conv_weight((torch.randn(2 * C, 256, 1, generator=g) * 0.05).to(dev), torch.bfloat16, 2)
+        ws = ops.diffnet_pack_wstream([dwp], [owp], C, cond_wps=[cwp])
+        kw = dict(condx=condx)
+        cnd = None
+    else:
+        ws = ops.diffnet_pack_wstream([dwp], [owp], C)
+        kw = {}
+        cnd = cond
+    outs = []
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("PTPP_DIFFNET_GW", mode)
+        sk = skip0.clone()
+        o = ops.diffnet_layer_fwd(yin, x, cnd, ws[0], dil_b[perm].contiguous(), out_b, dnext, sk, dil, False, lengths=lengths, save=save, **kw)
+        torch.cuda.synchronize()
+        outs.append([t for t in o if t is not None] + [sk])
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 def test_stack_with_folded_conditioner_matches_the_slice_form(dev, monkeypatch):
     """DiffNetStackFn in training, conditioner projected inside the layer launches (the default) against the (B, T, L * 2C)
     slice form: output and every gradient within the bf16 tolerance of one another."""

@@ -45,6 +45,16 @@ def case(B, T, dil, save, masked):
     def one():
         ops.diffnet_layer_fwd(yin, x, cond, ws[0], bp, out_b, dnext, skip, dil, False, lengths=lengths, save=save)
 
+    # the form the training step and the sampler launch: conditioner projection inside (80-stage stream)
+    condx = r(B, T, 256).bfloat16()
+    cwp = ops.pack_conv_weight(r(2 * C, 256, 1, sc=0.05), torch.bfloat16, 2)
+    wsc = ops.diffnet_pack_wstream([wp2], [wo], C, cond_wps=[cwp])
+
+    def one_cond():
+        ops.diffnet_layer_fwd(yin, x, None, wsc[0], bp, out_b, dnext, skip, dil, False, lengths=lengths, save=save, condx=condx)
+
+    one.cond = one_cond
+
     def dbg(mode, stamps):
         import ctypes
 
@@ -73,9 +83,12 @@ def phases(B, T, dil, save, masked):
         nblk = B * ((T + 63) // 64)
     names = {1: "full", 3: "no MFMA", 5: "no weight stream", 7: "no MFMA, no weights", 9: "no epilogue traffic", 15: "nothing but barriers + x windows", 33: "no s_barrier", 65: "no fragment LDS reads", 47: "nothing, no s_barrier",
              79: "nothing, no LDS reads", 111: "nothing, no barrier, no LDS reads", 143: "nothing, W reads in 128-B-row pattern",
-             129: "full, W reads in 128-B-row pattern"}
+             129: "full, W reads in 128-B-row pattern",
+             201: "1x8 global-weights form: full", 203: "1x8 GW: no MFMA", 209: "1x8 GW: no epilogue traffic", 211: "1x8 GW: no MFMA, no epilogue traffic"}
     print(f"-- phases, B {B} T {T} dil {dil} {'train' if save else 'infer'} ({nblk} blocks): us  prologue | dilated conv | gate epilogue | projection | tail || block, launch")
     for mode, name in names.items():
+        if mode >= 200 and nblk != B * ((T + 127) // 128):
+            continue
         st = torch.zeros((nblk, 6), device=dev, dtype=torch.int64)
         try:
             for _ in range(3):
@@ -186,13 +199,15 @@ def main():
         for save, masked in ((True, True), (False, False)):
             for dil in (1, 8):
                 two, one = case(B, T, dil, save, masked)
-                res = {"two": [], "one": []}
+                res = {"two": [], "one": [], "cond": []}
                 for _ in range(5):
                     res["two"].append(timeit(two))
                     res["one"].append(timeit(one))
+                    res["cond"].append(timeit(one.cond))
                 t2, t1 = min(res["two"]), min(res["one"])
                 print(f"B {B:3d} T {T:5d} dil {dil} {'train' if save else 'infer'}: two launches {t2:7.1f} us ({flop / t2 * 1e-6:6.1f} TF/s)"
-                      f"   one launch {t1:7.1f} us ({flop / t1 * 1e-6:6.1f} TF/s)   x{t2 / t1:.2f}", flush=True)
+                      f"   one launch {t1:7.1f} us ({flop / t1 * 1e-6:6.1f} TF/s)   x{t2 / t1:.2f}"
+                      f"   with the conditioner inside {min(res['cond']):7.1f} us", flush=True)
 
 
 if __name__ == "__main__":

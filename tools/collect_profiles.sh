@@ -7,8 +7,8 @@
 tag=${1:-r05}; out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TRAIN="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vocoder --no-app"
-TRAIN2="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-app"
+TRAIN="python $R/bench.py --steps 20 --warmup 5 --preheat 0 --no-cpu-baseline --no-vocoder --no-app"
+TRAIN2="python $R/bench.py --steps 2 --warmup 1 --preheat 0 --no-cpu-baseline --no-vocoder --no-app"
 VOC="python $R/tools/bench_vocoder.py --iters 2"
 rm -rf /tmp/p_*
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_train -o t -- $TRAIN > $out/train.log 2>&1
