@@ -467,12 +467,19 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
   const uint32_t xs_lds = lds_addr(Xs);
   const char* zero = reinterpret_cast<const char*>(g_conv_zero_page) + lane * 16;
 
-  auto issue_w = [&](int s, int stage) {
-    const int ci = s / p.ks, j = s - ci * p.ks;
-    const int off = (j * p.cinp + ci * 64) * 2;
+  // Weight stages are issued strictly in step order, so the issue side keeps its own (chunk, tap) pair incrementally: the
+  // loop used to divide by ks twice per step (once here, once for the step it multiplies) -- ~60 of the ~120 scalar
+  // instructions a step spent beside its 16 MFMAs (profiles/r05_kloop_instruction_mix.txt)
+  int wci = sbeg / p.ks, wj = 0;  // (sbeg is a multiple of ks)
+  auto issue_w = [&](int stage) {
+    const int off = (wj * p.cinp + wci * 64) * 2;
 #pragma unroll
     for (int q = 0; q < LW; ++q)
       glds16(wsrc[q] + off, __builtin_amdgcn_readfirstlane(ws_lds + (uint32_t)(stage * WSTAGE * 16 + q * 1024)));
+    if (++wj == p.ks) {
+      wj = 0;
+      ++wci;
+    }
   };
   auto issue_x = [&](int ci, int buf) {
     const int np = xrows >> 3;
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
   // The first weight stage does not depend on the utterance length: it leaves before the scalar load of lengths[b] is waited
   // for (that wait used to sit in front of every load of the block).
   const bool any = steps > sbeg;
-  if (any) issue_w(sbeg, 0);
+  if (any) issue_w(0);
   len = min(len_raw, p.T);
   Tin = p.in_mask ? len : p.T;
   // No K loop for a tile whose output rows are all masked out, or whose whole input window lies past the utterance's end
@@ -541,13 +548,13 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
   if (!SK && ((p.out_mask && t0 >= len) || (p.in_mask && t0 - p.pad >= len))) steps = sbeg;
   if (steps > sbeg) {
     issue_x(sbeg / p.ks, (sbeg / p.ks) & 1);
-    if (D > 2 && steps > sbeg + 1) issue_w(sbeg + 1, 1);
+    if (D > 2 && steps > sbeg + 1) issue_w(1);
   } else if (any) {
     glds_wait<0>();
   }
   int stage = 0;
+  int ci = sbeg / p.ks, j = 0;  // chunk and tap of the step being multiplied
   for (int s = sbeg; s < steps; ++s) {
-    const int ci = s / p.ks, j = s - ci * p.ks;
     if (D > 2 && s + 1 < steps) glds_wait<LW>();
     else glds_wait<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -556,7 +563,7 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
       if (s == 0) stamp1 = wall_clock64();
     }
     if (j == 0 && (ci + 1) * p.ks < steps) issue_x(ci + 1, (ci + 1) & 1);
-    if (s + D - 1 < steps) issue_w(s + D - 1, stage == 0 ? D - 1 : stage - 1);
+    if (s + D - 1 < steps) issue_w(stage == 0 ? D - 1 : stage - 1);
 
     const uint4* Wb = Ws + stage * WSTAGE;
     const uint4* Xb = Xs + (ci & 1) * xrows * 8;
@@ -583,6 +590,10 @@ __global__ __launch_bounds__(WR* WC * 64) void conv1d_glds_kernel(const ConvP p)
                                                                 __builtin_bit_cast(bf16x8_t, xf[fm]), acc[fm][fn], 0, 0, 0);
     }
     stage = stage + 1 == D ? 0 : stage + 1;
+    if (++j == p.ks) {
+      j = 0;
+      ++ci;
+    }
   }
   if constexpr (DBG) stamp2 = wall_clock64();
   if constexpr (SK) {

@@ -19,6 +19,8 @@
 //     these grid sizes) 33 % of peak, 64 x 64 50 %; fragments are requested one step ahead so the round trip hides under the
 //     previous step's MFMAs.
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 #include "conv1d_common.h"
 #include "lds_dma.h"
@@ -257,6 +259,265 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_kernel(const RtP p) {
   }
 }
 
+
+// ---- the same convolution with the weight fragments STRAIGHT FROM GLOBAL MEMORY on a 1 x 8 wave grid (round 5) -----------------
+// The ring loop above spends ~100 scalar instructions per step (two LDS-DMA issues with their M0 traffic, a counted wait picked
+// by comparisons, slot / chunk / tap counters, a barrier) beside 16 MFMAs -- two waves per SIMD then need ~2x the matrix time
+// (profiles/r05_kloop_instruction_mix.txt).  Here a wave owns ALL rows of the block x 32 output channels, so no two waves read
+// the same weight fragment: the fragments (1 KiB contiguous each in the stream's stage image, two per step) come with plain
+// global loads three steps ahead into four rotating register sets, the x window stays in LDS (double-buffered per 64-channel
+// chunk, LDS-DMA), and the only barriers are the window swaps.  KS is a template parameter and a trip covers two chunks
+// (4 KS straight-line steps): taps, k-halves, register sets, wait counts and the window pieces' position are compile-time.
+// Same stream, same K order, same epilogue arithmetic as the ring kernel: bit-identical outputs.
+template <typename F, int... I>
+__device__ __forceinline__ void rt_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void rt_static_for(F&& f) {
+  rt_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int FM, int KS, int ACT>
+__global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
+  constexpr int BM = 16 * FM;
+  constexpr int CS = 2 * KS;       // steps per chunk
+  constexpr int NSTEP = 2 * CS;    // steps per trip (two chunks)
+  constexpr int NPW = (BM + 7) / 8 + 6 > 16 ? 3 : 2;  // window pieces per wave (runtime np <= 8 NPW is checked by the launcher)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* Xw = reinterpret_cast<uint4*>(smem);  // x windows [2][xrows][8]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / p.nMT, mt = blockIdx.x - b * p.nMT;
+  const int t0 = mt * BM;
+  const int T = p.T, dil = p.dil;
+  const int xrows = (BM + (KS - 1) * dil + 7) & ~7;
+  const int np = xrows >> 3;
+  const int ntrips = p.Cin >> 7;  // two 64-channel chunks per trip
+  const int len_raw = p.lengths ? p.lengths[b] : T;
+
+  const bf16_raw* xb = p.x + (int64_t)b * T * p.ldx;
+  const uint32_t xs_lds = lds_addr(Xw);
+  const char* zero = reinterpret_cast<const char*>(g_conv_zero_page) + lane * 16;
+
+  f32x4 acc[FM][2];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 W[4][2];
+  const uint32_t gw_off = (uint32_t)(((wave * 32 + lr) * 4 + (lg ^ swz<4>(wave * 32 + lr))) * 16);
+  const char* wptr = reinterpret_cast<const char*>(p.wstream);  // stage of the next group to request
+  auto ldg = [&](u32x4 (&w)[2]) __attribute__((always_inline)) {
+    asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                 : "=&v"(w[0]), "=&v"(w[1]) : "v"(gw_off), "s"(wptr) : "memory");
+    wptr += RT_STAGE_U4 * 16;
+  };
+  ldg(W[0]);  // (independent of the utterance length)
+  const int len = min(len_raw, T);
+  const int Tin = p.in_mask ? len : T;
+  const bool active = !((p.out_mask && t0 >= len) || (p.in_mask && t0 - p.pad >= len));
+
+  // window pieces: piece q = rows 8 q .. 8 q + 7; lane (l3 = lane / 8, l7 = lane % 8) moves 16 bytes of row l3, chunk column
+  // l7 ^ swz<8>(8 q + l3) = l7 ^ (l3 / 2) ^ 4 (q & 1).  Every wave issues exactly NPW pieces per window (a wave without a
+  // piece of its own repeats the last one: same bytes, same place) so the waits below count compile-time constants.
+  const uint32_t gx_voff = (uint32_t)((lane >> 3) * (p.ldx * 2) + (((lane & 7) ^ (lane >> 4)) << 4));
+  auto piece = [&](int ci, int par, int k) __attribute__((always_inline)) {
+    const int q = min(wave + 8 * k, np - 1);
+    const int ts0 = t0 - p.pad + q * 8;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(xs_lds + (uint32_t)((par * xrows + q * 8) * 128));
+    const bf16_raw* base = xb + (int64_t)ts0 * p.ldx + ci * 64;
+    const uint32_t voff = gx_voff ^ (uint32_t)((q & 1) << 6);
+    if (ts0 >= 0 && ts0 + 7 < Tin) {
+      glds16_s(base, voff, dst);
+    } else {
+      const int ts = ts0 + (lane >> 3);
+      const char* src = (ts >= 0 && ts < Tin) ? reinterpret_cast<const char*>(base) + voff : zero;
+      glds16(src, dst);
+    }
+  };
+  // x fragments of a step: tile fm is 16 rows = 2 KiB further (both swizzles unchanged)
+  auto ld_x = [&](uint4 (&xf)[FM], int par, int tap, int kh) __attribute__((always_inline)) {
+    int lr_o = lr;
+    asm volatile("" : "+v"(lr_o));  // (opaque: the 2 KS addresses of a chunk are computed where they are used -- five VALU
+                                    //  instructions per step -- instead of living in 2 KS registers across the trip loop)
+    const int r = lr_o + tap * dil;
+    const uint4* src = Xw + par * xrows * 8 + r * 8 + ((kh * 4 + lg) ^ swz<8>(r));
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) xf[fm] = src[fm * 128];
+  };
+  auto wait_n = [&](int n) __attribute__((always_inline)) {  // (n is a compile-time constant at every call)
+    if (n >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto mfma = [&](const u32x4 (&w)[2], const uint4 (&xf)[FM]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < 2; ++fn)
+        acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[fn]), __builtin_bit_cast(bf16x8_t, xf[fm]),
+                                                              acc[fm][fn], 0, 0, 0);
+  };
+
+  if (active) {
+    uint4 xa[FM], xb_[FM];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) piece(0, 0, k);
+    ldg(W[1]);
+    ldg(W[2]);
+    wait_n(4);  // the pieces are older than the groups of steps 1 and 2 (group 0 is older still)
+    rt_barrier();
+    ld_x(xa, 0, 0, 0);
+#pragma unroll 1
+    for (int t = 0; t < ntrips; ++t) {
+      const bool more = t + 1 < ntrips;  // another trip follows: its first window and weight groups are requested in this one
+      // (the step index MUST be a compile-time constant: with a run-time index the register-set selection becomes copies of
+      //  the asm loads' destination registers, made before the data has arrived -- a 68-step `#pragma unroll` loop was only
+      //  unrolled by half)
+      rt_static_for<NSTEP>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int cc = i / CS, j = i - cc * CS;  // chunk of the trip (= LDS window), step in the chunk
+        constexpr int tap = j >> 1, kh = j & 1;
+        (void)tap; (void)kh;
+        constexpr bool pieces_here = j == 0;                       // the next chunk's window goes out at a chunk's first step
+        constexpr bool pieces_exist = cc == 0;                      // ... unconditionally inside a trip, else only if (more)
+        if (pieces_here && (pieces_exist || more)) {
+#pragma unroll
+          for (int k = 0; k < NPW; ++k) piece(2 * t + cc + 1, cc ^ 1, k);
+        }
+        if (i + 3 < NSTEP || more) ldg(W[(i + 3) & 3]);
+        // the next step's x fragments, unless it opens a chunk (those follow the window barrier below)
+        if (j + 1 < CS) {
+          if (i & 1) ld_x(xa, cc, (j + 1) >> 1, (j + 1) & 1);
+          else ld_x(xb_, cc, (j + 1) >> 1, (j + 1) & 1);
+        }
+        // younger than this step's weights: the groups of the next three steps (two loads each) and, during a chunk's first
+        // three steps, the window pieces issued at its first step (between the groups of +2 and +3)
+        {
+          const int yg_static = NSTEP - 1 - i < 3 ? NSTEP - 1 - i : 3;  // groups that exist without another trip
+          const bool pz = j < 3;
+          if (i + 3 < NSTEP) {
+            if (pz && !pieces_exist) {
+              if (more) wait_n(6 + NPW);
+              else wait_n(6);
+            } else {
+              wait_n(6 + (pz ? NPW : 0));
+            }
+          } else {  // (the trip's last three steps: j >= 3 for every KS >= 3, no pieces in flight)
+            if (more) wait_n(6);
+            else wait_n(2 * yg_static);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i & 1) mfma(W[i & 3], xb_);
+        else mfma(W[i & 3], xa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 == CS && (cc == 0 || more)) {  // window swap: everyone's pieces of the next chunk have landed (in-order waits above)
+          rt_barrier();
+          if (i & 1) ld_x(xa, cc ^ 1, 0, 0);
+          else ld_x(xb_, cc ^ 1, 0, 0);
+        }
+      });
+    }
+  } else {
+    glds_wait<0>();
+  }
+
+  // ---- epilogue: a lane holds 8 consecutive channels (wave * 32 + lg * 8 ..) of row fm * 16 + lr; conv_epilogue_act arithmetic
+  {
+    bf16_raw* yb = p.y + (int64_t)b * T * p.ldy;
+    const bf16_raw* rb = p.res ? p.res + (int64_t)b * T * p.ldr : nullptr;
+    const float e_scale = p.out_scale, e_rscale = p.res_scale;
+    const int ch = wave * 32 + lg * 8;
+    f32x4 bia[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) bia[u] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ch + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f0 = 0; f0 < FM; f0 += 4) {
+      uint4 rr[4];
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        rr[df] = make_uint4(0, 0, 0, 0);
+        const int t = t0 + (f0 + df) * 16 + lr;
+        if (rb && f0 + df < FM && t < T) rr[df] = *reinterpret_cast<const uint4*>(rb + (int64_t)t * p.ldr + ch);
+      }
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const int fm = f0 + df < FM ? f0 + df : FM - 1;
+        const int t = t0 + fm * 16 + lr;
+        if (f0 + df >= FM || t >= T) continue;
+        const bool keep = !(p.out_mask && t >= len);
+        f32x4 v[2] = {acc[fm][0], acc[fm][1]};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (p.bias) v[u] += bia[u];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[u][e] = keep ? act_apply_c<ACT>(v[u][e]) * e_scale : 0.f;
+        }
+        if (rb) {
+          const uint4 r = rr[df];
+          v[0][0] += __uint_as_float(r.x << 16) * e_rscale; v[0][1] += __uint_as_float(r.x & 0xffff0000u) * e_rscale;
+          v[0][2] += __uint_as_float(r.y << 16) * e_rscale; v[0][3] += __uint_as_float(r.y & 0xffff0000u) * e_rscale;
+          v[1][0] += __uint_as_float(r.z << 16) * e_rscale; v[1][1] += __uint_as_float(r.z & 0xffff0000u) * e_rscale;
+          v[1][2] += __uint_as_float(r.w << 16) * e_rscale; v[1][3] += __uint_as_float(r.w & 0xffff0000u) * e_rscale;
+        }
+        uint4 o;
+        o.x = (uint32_t)f32_to_bf16(v[0][0]) | ((uint32_t)f32_to_bf16(v[0][1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(v[0][2]) | ((uint32_t)f32_to_bf16(v[0][3]) << 16);
+        o.z = (uint32_t)f32_to_bf16(v[1][0]) | ((uint32_t)f32_to_bf16(v[1][1]) << 16);
+        o.w = (uint32_t)f32_to_bf16(v[1][2]) | ((uint32_t)f32_to_bf16(v[1][3]) << 16);
+        *reinterpret_cast<uint4*>(yb + (int64_t)t * p.ldy + ch) = o;
+        if (p.aux) {  // from the ROUNDED output, like a separate pass over y would compute it
+          const float sc = t < len ? p.aux_scale : 0.f;
+          uint4 q;
+          q.x = (uint32_t)f32_to_bf16(__uint_as_float(o.x << 16) * sc) | ((uint32_t)f32_to_bf16(__uint_as_float(o.x & 0xffff0000u) * sc) << 16);
+          q.y = (uint32_t)f32_to_bf16(__uint_as_float(o.y << 16) * sc) | ((uint32_t)f32_to_bf16(__uint_as_float(o.y & 0xffff0000u) * sc) << 16);
+          q.z = (uint32_t)f32_to_bf16(__uint_as_float(o.z << 16) * sc) | ((uint32_t)f32_to_bf16(__uint_as_float(o.z & 0xffff0000u) * sc) << 16);
+          q.w = (uint32_t)f32_to_bf16(__uint_as_float(o.w << 16) * sc) | ((uint32_t)f32_to_bf16(__uint_as_float(o.w & 0xffff0000u) * sc) << 16);
+          *reinterpret_cast<uint4*>(p.aux + ((int64_t)b * T + t) * p.ldaux + ch) = q;
+        }
+      }
+    }
+  }
+}
+
+template <int FM, int KS, int ACT>
+int rt_gw_launch(const RtP& p, hipStream_t st) {
+  constexpr int BM = 16 * FM;
+  const int xrows = (BM + (KS - 1) * p.dil + 7) & ~7;
+  const size_t smem = (size_t)2 * xrows * 128;
+  auto kern = conv1d_rt_gw_kernel<FM, KS, ACT>;
+  if (smem > 64 * 1024) {
+    const void* kp = reinterpret_cast<const void*>(kern);
+    if (!lds_limit_raised(kp)) {
+      const hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        ptpp_set_error("conv1d_rt_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        return PTPP_ELAUNCH;
+      }
+      lds_limit_mark(kp);
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, st, p);
+  PTPP_CHECK_LAUNCH("conv1d_rt_fwd");
+  return PTPP_OK;
+}
+template <int KS>
+int rt_gw_dispatch(const RtP& p, int bm, bool relu, hipStream_t st) {
+  if (bm == 128) return relu ? rt_gw_launch<8, KS, PTPP_ACT_RELU>(p, st) : rt_gw_launch<8, KS, PTPP_ACT_NONE>(p, st);
+  if (bm == 96) return relu ? rt_gw_launch<6, KS, PTPP_ACT_RELU>(p, st) : rt_gw_launch<6, KS, PTPP_ACT_NONE>(p, st);
+  return relu ? rt_gw_launch<4, KS, PTPP_ACT_RELU>(p, st) : rt_gw_launch<4, KS, PTPP_ACT_NONE>(p, st);
+}
+
 template <int FM, int ACT>
 int rt_launch(const RtP& p, hipStream_t st) {
   constexpr int NS = 5;
@@ -335,6 +596,17 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
   p.nMT = (a->T + bm - 1) / bm;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool relu = a->act == PTPP_ACT_RELU;
+  {  // the global-weights form (1 x 8 wave grid) for the tap counts of the model's layers; PTPP_CONV_RT_GW=0: the ring form
+    const char* gwe = getenv("PTPP_CONV_RT_GW");
+    const bool gw = !(gwe && gwe[0] == '0') && (a->Cin & 127) == 0;
+    const int xr = (bm + (a->ks - 1) * a->dil + 7) & ~7;
+    const int npw = (bm + 7) / 8 + 6 > 16 ? 3 : 2;
+    if (gw && (xr >> 3) <= 8 * npw) {
+      if (a->ks == 3) return rt_gw_dispatch<3>(p, bm, relu, st);
+      if (a->ks == 5) return rt_gw_dispatch<5>(p, bm, relu, st);
+      if (a->ks == 17) return rt_gw_dispatch<17>(p, bm, relu, st);
+    }
+  }
   if (bm == 128) return relu ? rt_launch<4, PTPP_ACT_RELU>(p, st) : rt_launch<4, PTPP_ACT_NONE>(p, st);
   if (bm == 96) return relu ? rt_launch<3, PTPP_ACT_RELU>(p, st) : rt_launch<3, PTPP_ACT_NONE>(p, st);
   return relu ? rt_launch<2, PTPP_ACT_RELU>(p, st) : rt_launch<2, PTPP_ACT_NONE>(p, st);

@@ -34,6 +34,15 @@ from ...utils.model import sequence_mask
 # test_direct_gradient_accumulation_equals_autograd produced a wrong duration-predictor weight gradient (an unordered
 # dependency that is not found yet; modes 0 / 1 / 2: 6 of 6 clean), so it is never the default
 BRANCH_STREAMS = os.environ.get("PTPP_BRANCH_STREAMS", "2")
+JOIN_PROBE = None  # tools/diag_joins.py sets a list: (name, event on the waiting stream before the wait, event at the branch's end)
+
+
+def _probe(name, waiting, branch):
+    if JOIN_PROBE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(waiting)
+        e1.record(branch)
+        JOIN_PROBE.append((name, e0, e1))
 if BRANCH_STREAMS in ("0", "off", "no"):
     BRANCH_STREAMS = ""
 _branch = {}
@@ -136,6 +145,7 @@ class PromptTTSMDNDurCFG(nn.Module):
         n_frames = fm1.sum()
 
         if sa is not None:
+            _probe("reference encoder -> x + style_emb", torch.cuda.current_stream(), sa)
             torch.cuda.current_stream().wait_stream(sa)
             style_emb.record_stream(torch.cuda.current_stream())
         else:
@@ -173,6 +183,7 @@ class PromptTTSMDNDurCFG(nn.Module):
 
         if bs is not None:  # join: the losses read the branches' outputs
             main = torch.cuda.current_stream()
+            _probe("prompt branch -> losses", main, bs)
             main.wait_stream(bs)
             for t in ((prompt_emb,) if style_mdn_out is None else tuple(style_mdn_out)):
                 t.record_stream(main)

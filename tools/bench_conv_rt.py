@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from promptttspp_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
+ops.CONV_RT_MIN_ROWS = 1  # (the sampler-size case is below the product's threshold)
 SHAPES = [("frame prior 256->256 k17", 19, 1550, 256, 17, 1, None, False), ("pitch predictor 256->256 k5 relu", 19, 1550, 256, 5, 1, "relu", False),
           ("DiffNet dgrad 512->256 k3 d8 +res", 19, 1550, 512, 3, 8, None, True), ("DiffNet dgrad 512->256 k3 d1 +res", 19, 1550, 512, 3, 1, None, True),
           ("frame prior, sampler-size batch", 32, 540, 256, 17, 1, None, False)]
