@@ -407,6 +407,11 @@ int ptpp_sampler_head(const ptpp_sampler_head_args* a, void* stream);
 int ptpp_conv1d_gate_bwd_supported(int C, int cin, int dtype);
 int ptpp_conv1d_gate_bwd(const ptpp_conv1d_args* a, const void* act, void* da, int ldda,
                          void* stream);
+/* ... on the row-tile engine (csrc/conv1d_rt.hip, the global-weights form): the projection weight as an operand stream
+ * (`wstream`: the (2C, C, 1) weight in pack mode 4; a->wp is ignored), a->ks = 1, a->Cout = C = 256, a->Cin % 128 == 0, bf16.
+ * Same arithmetic in the same order as ptpp_conv1d_gate_bwd: bit-identical da. */
+int ptpp_conv1d_rt_gate_bwd_supported(int C, int cin, int dtype);
+int ptpp_conv1d_rt_gate_bwd(const ptpp_conv1d_args* a, const void* wstream, const void* act, void* da, int ldda, void* stream);
 
 /* The DiffNet dilated conv (+ conditioner slice as `res`) of the TRAINING forward with the gate in the epilogue and the
  * pre-activation kept for the backward (modules/denoiser.py:76-79): weights, bias and `res` in the gate-interleaved row order
@@ -774,6 +779,8 @@ typedef struct {
                              * operands are slabs that outlive it): no split-K partials, bit-reproducible; 0: one
                              * ptpp_conv1d_wgrad per layer inside the loop, exactly as the per-launch path */
   const void* const* dil_wst;  /* [L] pack mode 4 operands of the dilated convs or NULL: their data gradients on the row-tile kernel */
+  const void* const* out_wst;  /* [L] pack mode 4 operands of the output projections or NULL: the fused gate backward on the row-tile
+                                * engine (ptpp_conv1d_rt_gate_bwd) where it is supported, bit-identically */
 } ptpp_diffnet_stack_bwd_args;
 int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void* stream);
 

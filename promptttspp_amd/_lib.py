@@ -107,7 +107,7 @@ class DiffNetBwdArgs(Structure):
                                         "dw_out", "db_out", "gx_all", "do_all", "dg_buf", "dcond_all", "S", "ws_main")] + \
                [("ws_main_bytes", ctypes.c_size_t), ("ws_side", c_void_p), ("ws_side_bytes", ctypes.c_size_t),
                 ("side_stream", c_void_p)] + \
-               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "dtype", "batched_wgrad")] + [("dil_wst", c_void_p)]
+               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "dtype", "batched_wgrad")] + [("dil_wst", c_void_p), ("out_wst", c_void_p)]
 
 
 class EncoderLayersFwdArgs(Structure):
@@ -253,6 +253,8 @@ SIGNATURES = {
     "ptpp_mdn_nll_bwd": (I, [P] * 10 + [I64, I, I, F, F, P]),
     "ptpp_conv1d_gate_bwd_supported": (I, [I, I, I]),
     "ptpp_conv1d_gate_bwd": (I, [POINTER(ConvArgs), P, P, I, P]),
+    "ptpp_conv1d_rt_gate_bwd_supported": (I, [I, I, I]),
+    "ptpp_conv1d_rt_gate_bwd": (I, [POINTER(ConvArgs), P, P, P, I, P]),
     "ptpp_conv1d_gate_fwd_save_supported": (I, [I, I, I]),
     "ptpp_conv1d_gate_fwd_save": (I, [POINTER(ConvArgs), P, I, P]),
     "ptpp_diffnet_post_bwd": (I, [P, P, P, P, I, I, I, I, P]),

@@ -44,6 +44,10 @@ struct RtP {
   bf16_raw* aux;  // optional second output: bf16(y * aux_scale), row stride ldaux, rows past an utterance's end zero
   int ldaux;
   float aux_scale;
+  // gate-backward epilogue (conv1d_rt_gw_kernel<.., EPI = 1>): saved pre-activation (B, T, 2 N) and the gradient it yields
+  const bf16_raw* gate_a;
+  bf16_raw* gate_da;
+  int ldda;
 };
 
 __device__ __forceinline__ void rt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -278,7 +282,10 @@ __device__ __forceinline__ void rt_static_for(F&& f) {
   rt_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int FM, int KS, int ACT>
+// EPI = 1: the DiffNet gate backward as the epilogue (tile_epilogue_gate_bwd of conv1d_glds.h; reference modules/denoiser.py:76-77
+// differentiated): the accumulator is dg, never stored; with s = a[:, c], f = a[:, N + c]: da[:, c] = dg th sg (1 - sg),
+// da[:, N + c] = dg sg (1 - th^2), dg rounded to bf16 first as the two-kernel path stores it.
+template <int FM, int KS, int ACT, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
   constexpr int BM = 16 * FM;
   constexpr int CS = 2 * KS;       // steps per chunk
@@ -422,6 +429,11 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
         else mfma(W[i & 3], xa);
         __builtin_amdgcn_sched_barrier(0);
         if (j + 1 == CS && (cc == 0 || more)) {  // window swap: everyone's pieces of the next chunk have landed (in-order waits above)
+          if constexpr (CS < 4) {  // (a chunk of two steps: the waits above have not reached the pieces yet -- younger than them are
+                                   //  the weight groups requested at this chunk's steps)
+            if (cc == 0 && !more) wait_n(2);
+            else wait_n(4);
+          }
           rt_barrier();
           if (i & 1) ld_x(xa, cc ^ 1, 0, 0);
           else ld_x(xb_, cc ^ 1, 0, 0);
@@ -432,6 +444,58 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
     glds_wait<0>();
   }
 
+  if constexpr (EPI == 1) {
+    const bf16_raw* ab = p.gate_a + (int64_t)b * T * (2 * RT_N);
+    bf16_raw* dab = p.gate_da + (int64_t)b * T * p.ldda;
+    const int ch = wave * 32 + lg * 8;
+#pragma unroll
+    for (int f0 = 0; f0 < FM; f0 += 2) {
+      uint4 rs[2], rf[2];
+#pragma unroll
+      for (int df = 0; df < 2; ++df) {
+        rs[df] = rf[df] = make_uint4(0, 0, 0, 0);
+        const int t = t0 + (f0 + df) * 16 + lr;
+        if (f0 + df < FM && t < T) {
+          rs[df] = *reinterpret_cast<const uint4*>(ab + (int64_t)t * (2 * RT_N) + ch);
+          rf[df] = *reinterpret_cast<const uint4*>(ab + (int64_t)t * (2 * RT_N) + RT_N + ch);
+        }
+      }
+#pragma unroll
+      for (int df = 0; df < 2; ++df) {
+        const int fm = f0 + df < FM ? f0 + df : FM - 1;
+        const int t = t0 + fm * 16 + lr;
+        if (f0 + df >= FM || t >= T) continue;
+        const uint4 s4 = rs[df], f4 = rf[df];
+        const float sv[8] = {__uint_as_float(s4.x << 16), __uint_as_float(s4.x & 0xffff0000u), __uint_as_float(s4.y << 16),
+                             __uint_as_float(s4.y & 0xffff0000u), __uint_as_float(s4.z << 16), __uint_as_float(s4.z & 0xffff0000u),
+                             __uint_as_float(s4.w << 16), __uint_as_float(s4.w & 0xffff0000u)};
+        const float fv[8] = {__uint_as_float(f4.x << 16), __uint_as_float(f4.x & 0xffff0000u), __uint_as_float(f4.y << 16),
+                             __uint_as_float(f4.y & 0xffff0000u), __uint_as_float(f4.z << 16), __uint_as_float(f4.z & 0xffff0000u),
+                             __uint_as_float(f4.w << 16), __uint_as_float(f4.w & 0xffff0000u)};
+        float ds[8], dfv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = bf16_to_f32(f32_to_bf16(acc[fm][e >> 2][e & 3] * p.out_scale));
+          float sg, th;
+          gate_fast_parts(sv[e], fv[e], sg, th);
+          ds[e] = d * th * sg * (1.f - sg);
+          dfv[e] = d * sg * (1.f - th * th);
+        }
+        uint4 o1, o2;
+        o1.x = (uint32_t)f32_to_bf16(ds[0]) | ((uint32_t)f32_to_bf16(ds[1]) << 16);
+        o1.y = (uint32_t)f32_to_bf16(ds[2]) | ((uint32_t)f32_to_bf16(ds[3]) << 16);
+        o1.z = (uint32_t)f32_to_bf16(ds[4]) | ((uint32_t)f32_to_bf16(ds[5]) << 16);
+        o1.w = (uint32_t)f32_to_bf16(ds[6]) | ((uint32_t)f32_to_bf16(ds[7]) << 16);
+        o2.x = (uint32_t)f32_to_bf16(dfv[0]) | ((uint32_t)f32_to_bf16(dfv[1]) << 16);
+        o2.y = (uint32_t)f32_to_bf16(dfv[2]) | ((uint32_t)f32_to_bf16(dfv[3]) << 16);
+        o2.z = (uint32_t)f32_to_bf16(dfv[4]) | ((uint32_t)f32_to_bf16(dfv[5]) << 16);
+        o2.w = (uint32_t)f32_to_bf16(dfv[6]) | ((uint32_t)f32_to_bf16(dfv[7]) << 16);
+        *reinterpret_cast<uint4*>(dab + (int64_t)t * p.ldda + ch) = o1;
+        *reinterpret_cast<uint4*>(dab + (int64_t)t * p.ldda + RT_N + ch) = o2;
+      }
+    }
+    return;
+  }
   // ---- epilogue: a lane holds 8 consecutive channels (wave * 32 + lg * 8 ..) of row fm * 16 + lr; conv_epilogue_act arithmetic
   {
     bf16_raw* yb = p.y + (int64_t)b * T * p.ldy;
@@ -490,12 +554,12 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
   }
 }
 
-template <int FM, int KS, int ACT>
+template <int FM, int KS, int ACT, int EPI = 0>
 int rt_gw_launch(const RtP& p, hipStream_t st) {
   constexpr int BM = 16 * FM;
   const int xrows = (BM + (KS - 1) * p.dil + 7) & ~7;
   const size_t smem = (size_t)2 * xrows * 128;
-  auto kern = conv1d_rt_gw_kernel<FM, KS, ACT>;
+  auto kern = conv1d_rt_gw_kernel<FM, KS, ACT, EPI>;
   if (smem > 64 * 1024) {
     const void* kp = reinterpret_cast<const void*>(kern);
     if (!lds_limit_raised(kp)) {
@@ -579,6 +643,7 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
   p.act = a->act; p.in_mask = a->in_mask; p.out_mask = a->out_mask;
   p.out_scale = a->out_scale; p.res_scale = res_scale;
   p.aux = reinterpret_cast<bf16_raw*>(aux); p.ldaux = ldaux; p.aux_scale = aux_scale;
+  p.gate_a = nullptr; p.gate_da = nullptr; p.ldda = 0;
   // rows per block: least (rounds of 256 one-per-CU blocks) x (time of a block)
   int bm = 128;
   {
@@ -610,4 +675,55 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
   if (bm == 128) return relu ? rt_launch<4, PTPP_ACT_RELU>(p, st) : rt_launch<4, PTPP_ACT_NONE>(p, st);
   if (bm == 96) return relu ? rt_launch<3, PTPP_ACT_RELU>(p, st) : rt_launch<3, PTPP_ACT_NONE>(p, st);
   return relu ? rt_launch<2, PTPP_ACT_RELU>(p, st) : rt_launch<2, PTPP_ACT_NONE>(p, st);
+}
+
+// ---- the DiffNet output projection's data gradient with the gate backward in its epilogue, on the row-tile engine ---------------
+// Same contract as ptpp_conv1d_gate_bwd (conv1d_cl.hip) with the weight as an operand STREAM (pack mode 4 of the (2C, C, 1)
+// projection weight): dg = conv1x1(do, W^T) is never stored, da (B, T, 2C view, row stride ldda) is written in place.
+extern "C" int ptpp_conv1d_rt_gate_bwd_supported(int C, int cin, int dtype) {
+  return dtype == PTPP_BF16 && C == RT_N && cin > 0 && (cin & 127) == 0;
+}
+
+static int rt_bm_for(int B, int T) {
+  int bm = 128;
+  const int cand[3] = {128, 96, 64};
+  const float tblk[3] = {1.f, 0.8f, 0.6f};
+  float best = 1e30f;
+  for (int i = 0; i < 3; ++i) {
+    const int64_t nb = (int64_t)B * ((T + cand[i] - 1) / cand[i]);
+    const float cost = (float)((nb + 255) / 256) * tblk[i];
+    if (cost < best - 1e-3f) { best = cost; bm = cand[i]; }
+  }
+  const char* force = getenv("PTPP_CONV_RT_BM");  // (experiments / tests)
+  if (force && (atoi(force) == 64 || atoi(force) == 96 || atoi(force) == 128)) bm = atoi(force);
+  return bm;
+}
+
+extern "C" int ptpp_conv1d_rt_gate_bwd(const ptpp_conv1d_args* a, const void* wstream, const void* act, void* da, int ldda, void* stream) {
+  PTPP_CHECK_ARG(a && a->x && wstream && act && da, "conv1d_rt_gate_bwd: null pointer");
+  PTPP_CHECK_ARG(a->ks == 1 && a->dil == 1 && a->pad == 0 && a->act == PTPP_ACT_NONE && !a->res && !a->bias &&
+                     ptpp_conv1d_rt_gate_bwd_supported(a->Cout, a->Cin, a->dtype),
+                 "conv1d_rt_gate_bwd: unsupported shape (bf16, 1 x 1, C = 256, Cin %% 128 == 0; C %d Cin %d ks %d)", a->Cout, a->Cin, a->ks);
+  PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && (a->ldx & 7) == 0 && ldda >= 2 * a->Cout && (ldda & 7) == 0, "conv1d_rt_gate_bwd: bad geometry");
+  PTPP_CHECK_ARG((((uintptr_t)a->x | (uintptr_t)wstream | (uintptr_t)act | (uintptr_t)da) & 15) == 0, "conv1d_rt_gate_bwd: operands must be 16-byte aligned");
+  PTPP_CHECK_ARG(!(a->in_mask || a->out_mask) || a->lengths, "conv1d_rt_gate_bwd: masks need lengths");
+  RtP p;
+  p.x = reinterpret_cast<const bf16_raw*>(a->x);
+  p.wstream = reinterpret_cast<const uint4*>(wstream);
+  p.bias = nullptr; p.res = nullptr; p.y = nullptr;
+  p.lengths = a->lengths;
+  p.B = a->B; p.T = a->T; p.Cin = a->Cin; p.ks = 1; p.dil = 1; p.pad = 0;
+  p.ldx = a->ldx; p.ldy = 0; p.ldr = 0;
+  p.act = PTPP_ACT_NONE; p.in_mask = a->in_mask; p.out_mask = 0;  // (as the tile kernel: rows past the end follow from the masked input)
+  p.out_scale = a->out_scale; p.res_scale = 1.f;
+  p.aux = nullptr; p.ldaux = 0; p.aux_scale = 0.f;
+  p.gate_a = reinterpret_cast<const bf16_raw*>(act);
+  p.gate_da = reinterpret_cast<bf16_raw*>(da);
+  p.ldda = ldda;
+  const int bm = rt_bm_for(a->B, a->T);
+  p.nMT = (a->T + bm - 1) / bm;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (bm == 128) return rt_gw_launch<8, 1, PTPP_ACT_NONE, 1>(p, st);
+  if (bm == 96) return rt_gw_launch<6, 1, PTPP_ACT_NONE, 1>(p, st);
+  return rt_gw_launch<4, 1, PTPP_ACT_NONE, 1>(p, st);
 }

@@ -318,12 +318,19 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     const bf16_raw* base = (COND && ci >= 4) ? cxb + (int64_t)ts0 * p.ldcx + (ci - 4) * 64 : yb + (int64_t)ts0 * DN_C + ci * 64;
     const uint32_t rowb = (COND && ci >= 4) ? (uint32_t)p.ldcx * 2u : (uint32_t)(DN_C * 2);
     uint32_t voff = gx_voff ^ (uint32_t)((q & 1) << 6);
-    if (COND && ci >= 4) voff = (uint32_t)(lane >> 3) * rowb + (voff & 127u);
+    if (COND && ci >= 4) {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));  // (opaque: the conditioner windows' lane offsets are not kept across the trip)
+      voff = (uint32_t)(lane_o >> 3) * rowb + (uint32_t)((((lane_o & 7) ^ (lane_o >> 4)) << 4) ^ ((q & 1) << 6));
+    }
     if (ts0 >= 0 && ts0 + 7 < T) {
       glds16_s(base, voff, dst);
     } else {  // a window edge: rows outside the utterance come from the zero page (still exactly one DMA)
-      const int ts = ts0 + (lane >> 3);
-      const char* src = (ts >= 0 && ts < T) ? reinterpret_cast<const char*>(base) + voff : zero;
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int ts = ts0 + (lane_o >> 3);
+      const char* zero_o = reinterpret_cast<const char*>(g_conv_zero_page) + lane_o * 16;
+      const char* src = (ts >= 0 && ts < T) ? reinterpret_cast<const char*>(base) + voff : zero_o;
       glds16(src, dst);
     }
   };
@@ -336,7 +343,13 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
   }
   auto gw_ld_x = [&](uint4 (&xf)[FM], int par, int tap, int kh) __attribute__((always_inline)) {
     int idx = gx_idx[tap];
-    if (kh) asm volatile("v_xor_b32 %0, 4, %1" : "=v"(idx) : "v"(gx_idx[tap]));  // (volatile: not hoisted into six loop invariants)
+    if constexpr (COND && FM == 8) {  // (no register to spare for the three tap addresses: recomputed where they are used)
+      int lr_o = xrow0;
+      asm volatile("" : "+v"(lr_o));
+      const int r = lr_o + tap * dil;
+      idx = r * 8 + (lg ^ swz<8>(r));
+    }
+    if (kh) asm volatile("v_xor_b32 %0, 4, %1" : "=v"(idx) : "v"(idx));  // (volatile: not hoisted into six loop invariants)
     const uint4* src = G + par * xrows * 8 + idx;
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) xf[fm] = src[fm * 128];
@@ -638,6 +651,10 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
   // ---- tail: residual half -> xn, yin'; skip half -> skip (f32); o is rounded to bf16 first, as the two-kernel path stores it
   {
     const float r2 = 0.70710678118654752f;
+    // (opaque lane coordinates, as in the gate epilogue: the bias / next-step vectors and the row addresses are computed and
+    //  loaded HERE, not hoisted above the K loops where they would hold ~30 registers)
+    int lr_t = lr, lg_t = lg;
+    asm volatile("" : "+v"(lr_t), "+v"(lg_t));
     const bf16_raw* xb = p.x + (int64_t)b * T * DN_C;
     bf16_raw* xnb = p.xn + (int64_t)b * T * DN_C;
     bf16_raw* yib = p.yin_next ? p.yin_next + (int64_t)b * T * DN_C : nullptr;
@@ -646,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     f32x4 bo[HN][2], bs[HN][2], dn[HN][2];
 #pragma unroll
     for (int h = 0; h < HN; ++h) {
-      const int ch = wn * (16 * FN) + h * 32 + lg * 8;
+      const int ch = wn * (16 * FN) + h * 32 + lg_t * 8;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         bo[h][u] = *reinterpret_cast<const f32x4*>(p.out_b + ch + 4 * u);
@@ -665,11 +682,11 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
 #pragma unroll
       for (int df = 0; df < 2; ++df) {
         if (f0 + df >= FM) continue;  // (FM = 3: the last round has one tile)
-        const int t = t0 + wm * (16 * FM) + (f0 + df) * 16 + lr;
+        const int t = t0 + wm * (16 * FM) + (f0 + df) * 16 + lr_t;
         const bool in = t < T && !((DBG & 8) && t > 0);
 #pragma unroll
         for (int h = 0; h < HN; ++h) {
-          const int ch = wn * (16 * FN) + h * 32 + lg * 8;
+          const int ch = wn * (16 * FN) + h * 32 + lg_t * 8;
           xr[df][h] = make_uint4(0, 0, 0, 0);
           sk[df][h][0] = sk[df][h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (in) {
@@ -684,12 +701,12 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
 #pragma unroll
       for (int df = 0; df < 2; ++df) {
         const int fm = f0 + df < FM ? f0 + df : FM - 1;
-        const int t = t0 + wm * (16 * FM) + fm * 16 + lr;
+        const int t = t0 + wm * (16 * FM) + fm * 16 + lr_t;
         if (f0 + df >= FM || t >= T || ((DBG & 8) && t > 0)) continue;
         const bool keep = !(masked && t >= len);
 #pragma unroll
         for (int h = 0; h < HN; ++h) {
-          const int ch = wn * (16 * FN) + h * 32 + lg * 8;
+          const int ch = wn * (16 * FN) + h * 32 + lg_t * 8;
           const uint4 xv4 = xr[df][h];
           const float xv[8] = {lo_bf16(xv4.x), hi_bf16(xv4.x), lo_bf16(xv4.y), hi_bf16(xv4.y), lo_bf16(xv4.z), hi_bf16(xv4.z), lo_bf16(xv4.w), hi_bf16(xv4.w)};
           float xn[8], yi[8];
@@ -711,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
         }
 #pragma unroll
         for (int h = 0; h < HN; ++h) {
-          float* sp = skb + (int64_t)t * DN_C + wn * (16 * FN) + h * 32 + lg * 8;
+          float* sp = skb + (int64_t)t * DN_C + wn * (16 * FN) + h * 32 + lg_t * 8;
           uint32_t sb[4];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -727,7 +744,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
             sb[2 * u + 1] = pack_bf16x2(sv[2] * p.skip_scale, sv[3] * p.skip_scale);
           }
           if (p.skip_scaled)
-            *reinterpret_cast<uint4*>(p.skip_scaled + ((int64_t)b * T + t) * DN_C + wn * (16 * FN) + h * 32 + lg * 8) = make_uint4(sb[0], sb[1], sb[2], sb[3]);
+            *reinterpret_cast<uint4*>(p.skip_scaled + ((int64_t)b * T + t) * DN_C + wn * (16 * FN) + h * 32 + lg_t * 8) = make_uint4(sb[0], sb[1], sb[2], sb[3]);
         }
       }
     }

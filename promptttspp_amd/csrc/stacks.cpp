@@ -47,10 +47,13 @@ ptpp_conv1d_args conv_args(const void* x, int ldx, const void* wp, const float* 
 
 // A conv launch of a driver: on the row-tile kernel (conv1d_rt.hip) when its operand stream was handed over and the launch is
 // frame-level -- the SAME rule as promptttspp_amd/ops.py::conv1d_rt_ok, so that both paths take the same kernel -- else as before
-static bool rt_takes(const ptpp_conv1d_args& c, const void* wstream) {
+static int64_t rt_min_rows() {
   int64_t min_rows = 24576;
   if (const char* e = getenv("PTPP_CONV_RT_MIN_ROWS")) min_rows = atoll(e);  // (the same variable ops.py reads; tests run the row-tile paths at small shapes)
-  return wstream && (int64_t)c.B * c.T >= min_rows && ptpp_conv1d_rt_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype);
+  return min_rows;
+}
+static bool rt_takes(const ptpp_conv1d_args& c, const void* wstream) {
+  return wstream && (int64_t)c.B * c.T >= rt_min_rows() && ptpp_conv1d_rt_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype);
 }
 // 1: the row-tile kernel takes the launch; 0: no operand stream was handed over (the tile kernel reads wp); -1: a stream WAS
 // handed over but this side would not take the row-tile kernel.  The caller packs ONLY the stream form in that case (and may
@@ -176,6 +179,9 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
   }
   // Where the row-tile kernel runs every dilated data gradient, its epilogue also writes the NEXT iteration's residual half of
   // dout (gx / sqrt2, masked) and one launch fills the skip halves of all layers: no per-layer pass over gx and gS.
+  // the output projections' operand streams: the fused gate backward on the row-tile engine, at frame-level row counts
+  const bool gbwd_rt = fuse_gbwd && a->out_wst != nullptr && ptpp_conv1d_rt_gate_bwd_supported(C, 2 * C, dt) != 0 &&
+                       (int64_t)B * T >= rt_min_rows();
   bool fold = a->dil_wst != nullptr;
   for (int l = 0; l < L && fold; ++l) {
     const int d = 1 << (l % a->cycle);
@@ -203,7 +209,8 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
       // (do / da are zero past an utterance's end: the input mask changes nothing but lets those row tiles skip their K loops)
       ptpp_conv1d_args c = conv_args(dout, 2 * C, a->out_wpt[l], nullptr, nullptr, 0, nullptr, 0, a->lengths, B, T, 2 * C, C, 1, 1, 0,
                                      PTPP_ACT_NONE, bmask, 0, dt);
-      ST_TRY(ptpp_conv1d_gate_bwd(&c, act, da, ldc, stream));
+      if (gbwd_rt) ST_TRY(ptpp_conv1d_rt_gate_bwd(&c, a->out_wst[l], act, da, ldc, stream));
+      else ST_TRY(ptpp_conv1d_gate_bwd(&c, act, da, ldc, stream));
     } else {
       ptpp_conv1d_args c = conv_args(dout, 2 * C, a->out_wpt[l], nullptr, nullptr, 0, a->dg_buf, C, a->lengths, B, T, 2 * C, C, 1, 1, 0,
                                      PTPP_ACT_NONE, bmask, 0, dt);

@@ -1238,6 +1238,11 @@ def _diffnet_backward_driver(ctx, gS, gx_all):
     a.dil_wpt, a.out_wpt, a.dw_dil, a.db_dil, a.dw_out, a.db_out = [ctypes.cast(t, ctypes.c_void_p) for t in tabs]
     if rt:
         a.dil_wst = a.dil_wpt
+    if ops.conv1d_rt_gate_bwd_ok(do_all[0], C) and all(isinstance(w[4], torch.nn.Parameter) for w in ws):
+        # the output projections as operand streams too: the fused gate backward on the row-tile engine
+        owst = _ptr_table([packed(w[4], dt, mode=4) for w in ws])
+        tabs.append(owst)  # (kept alive with the other tables until the call returns)
+        a.out_wst = ctypes.cast(owst, ctypes.c_void_p)
     a.gx_all, a.do_all, a.dcond_all, a.S = gx_all.data_ptr(), do_all.data_ptr(), dcond_all.data_ptr(), S.data_ptr()
     a.dg_buf = dg_buf.data_ptr() if dg_buf is not None else None
     a.ws_main, a.ws_main_bytes = ws_main.data_ptr(), ws_main.numel()

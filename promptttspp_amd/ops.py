@@ -761,6 +761,38 @@ def conv1d_gate_bwd(do, wpt, a, da, lengths=None):
     return da
 
 
+_rt_gbwd_ok = {}
+
+
+def conv1d_rt_gate_bwd_ok(do, C):
+    """Whether the fused gate backward may run on the row-tile engine (ptpp_conv1d_rt_gate_bwd) for this launch: bf16, C = 256,
+    Cin % 128 == 0, frame-level row counts (the threshold of ``conv1d_rt_ok``)."""
+    if not (CONV_RT and do.is_cuda and do.dtype == torch.bfloat16 and do.stride(2) == 1):
+        return False
+    if do.shape[0] * do.shape[1] < conv_rt_min_rows():
+        return False
+    key = (C, do.shape[2])
+    ok = _rt_gbwd_ok.get(key)
+    if ok is None:
+        ok = _rt_gbwd_ok[key] = bool(_lib.load().ptpp_conv1d_rt_gate_bwd_supported(int(C), int(do.shape[2]), BF16))
+    return ok
+
+
+def conv1d_rt_gate_bwd(do, wstream, a, da, lengths=None):
+    """``conv1d_gate_bwd`` with the projection weight as the row-tile engine's operand stream (pack mode 4): same result bit
+    for bit (ptpp_conv1d_rt_gate_bwd)."""
+    B, T, cin = do.shape
+    C = a.shape[2] // 2
+    assert a.is_contiguous() and a.dtype == do.dtype == torch.bfloat16
+    if lengths is not None:
+        lengths = i32(lengths, do.device)
+    _CONV_FMT.pack_into(_conv_buf, 0, do.data_ptr(), 0, 0, 0, 0, lengths.data_ptr() if lengths is not None else 0,
+                        B, T, cin, C, 1, 1, 0, _ld_fast(do), 0, 0, _ACT[None], 1 if lengths is not None else 0, 0, 1.0, BF16)
+    check(_lib.load().ptpp_conv1d_rt_gate_bwd(_conv_args_ref, wstream.data_ptr(), a.data_ptr(), da.data_ptr(), _ld(da), _stream()),
+          "ptpp_conv1d_rt_gate_bwd")
+    return da
+
+
 def mdn_nll_fwd(log_pi, log_sigma, mu, target, mask, lp_min, ls_min):
     """(rows.., G, D) f32 x3, target (rows.., D), mask (rows..) bool or None -> loss (rows.., D)."""
     G, D = mu.shape[-2], mu.shape[-1]

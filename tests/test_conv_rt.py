@@ -61,3 +61,40 @@ def test_row_tile_data_gradient_operand_and_oracle(dev, monkeypatch):
     orc = F.conv_transpose1d(dy.float().cpu().transpose(1, 2), w.bfloat16().float().cpu(), padding=pad, dilation=dil).transpose(1, 2)
     err = float((got.float().cpu() - orc).abs().max() / orc.abs().max())
     assert err < 1e-2, err
+
+
+@pytest.mark.parametrize("B,T,masked,bm", [(9, 700, True, 128), (12, 450, False, 96), (40, 130, True, 64), (5, 1000, False, 0)])
+def test_gate_backward_on_the_row_tile_engine_is_bit_identical(dev, monkeypatch, B, T, masked, bm):
+    """ptpp_conv1d_rt_gate_bwd (the DiffNet output projection's data gradient, 512 -> 256, 1 x 1, with the gate backward as its
+    epilogue; reference modules/denoiser.py:76-83 differentiated) against ptpp_conv1d_gate_bwd on the tile kernel: the same MFMA
+    order and epilogue arithmetic, so da must be equal bit for bit -- and against the f32 oracle of the two steps."""
+    from promptttspp_amd import ops
+
+    monkeypatch.setattr(ops, "CONV_RT_MIN_ROWS", 1)
+    if bm:
+        monkeypatch.setenv("PTPP_CONV_RT_BM", str(bm))
+    C = 256
+    g = torch.Generator().manual_seed(900 + B)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    do = r(B, T, 2 * C).bfloat16()
+    a = r(B, T, 2 * C, sc=1.5).bfloat16()
+    w = r(2 * C, C, 1, sc=(2 * C) ** -0.5)
+    lengths = torch.tensor([max(1, T - 53 * i) for i in range(B)], device=dev, dtype=torch.int32) if masked else None
+    if masked:  # as the backward has it: do is zero past an utterance's end
+        do = do * (torch.arange(T, device=dev)[None, :, None] < lengths[:, None, None])
+    ldc = 3 * 2 * C  # da is a slice of the all-layer tensor
+    da_ref = torch.zeros(B, T, ldc, device=dev, dtype=torch.bfloat16)
+    da_got = torch.zeros_like(da_ref)
+    assert ops.conv1d_gate_bwd_supported(C, 2 * C, torch.bfloat16) and ops.conv1d_rt_gate_bwd_ok(do, C)
+    ops.conv1d_gate_bwd(do, ops.pack_conv_weight(w, torch.bfloat16, 1), a, da_ref[:, :, 2 * C:4 * C], lengths=lengths)
+    ops.conv1d_rt_gate_bwd(do, ops.pack_conv_weight(w, torch.bfloat16, 4), a, da_got[:, :, 2 * C:4 * C], lengths=lengths)
+    torch.cuda.synchronize()
+    assert torch.equal(da_ref, da_got), int((da_ref != da_got).sum())
+    # oracle: dg = do @ W (bf16 operands, f32 accumulation), then the gate's derivative
+    dg = torch.einsum("btk,kc->btc", do.float().cpu(), w[:, :, 0].bfloat16().float().cpu()).bfloat16().float()
+    s_, f_ = a[:, :, :C].float().cpu(), a[:, :, C:].float().cpu()
+    sg, th = torch.sigmoid(s_), torch.tanh(f_)
+    ora = torch.cat([dg * th * sg * (1 - sg), dg * sg * (1 - th * th)], dim=2)
+    got = da_got[:, :, 2 * C:4 * C].float().cpu()
+    assert float((got - ora).abs().max()) < 2e-2 * float(ora.abs().max())
+    assert float(got.abs().max()) > 0

@@ -48,4 +48,4 @@ print(f"per step: wall {tw / n / 1e6:.2f} ms, some kernel running {tu / n / 1e6:
       f">= 2 kernels at once {t2 / n / 1e6:.2f} ms; sum of kernel durations {sum(v[0] for v in acc.values()) / n / 1e6:.2f} ms")
 for s, (busy, cnt, top) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
     print(f"  stream {s}: busy {busy / n / 1e6:6.2f} ms, {cnt / n:6.1f} launches per step; " +
-          ", ".join(f"{k} {v / n / 1e3:.0f} us" for k, v in top.most_common(4)))
+          ", ".join(f"{k} {v / n / 1e3:.0f} us" for k, v in top.most_common(14 if s == main else 5)))
