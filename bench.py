@@ -310,8 +310,9 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
     peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else 157.3
     traffic, traffic_src = measured_traffic(TRAFFIC_TRAIN, "conv1d_glds_kernel<2, 4, 2, 2, 2") \
         if dtype_name == "bf16" else (None, "no PMC pass for the f32 mode")
-    kname = "conv1d_glds_kernel / conv1d_rt_kernel / diffnet_layer_kernel <bf16> (LDS-DMA implicit-GEMM conv family: 64x128 / 128x128 " \
-            "tiles, row tiles for the 256-channel layers, one launch per DiffNet layer)" if dtype_name == "bf16" else "conv1d_cl_kernel<f32>, 128x128 tiles"
+    kname = "conv1d_glds_kernel / conv1d_rt_gw_kernel / diffnet_layer_kernel <bf16> (implicit-GEMM conv family: LDS-DMA 64x128 / 128x128 " \
+            "tiles; row tiles with the weight fragments straight from global memory on a 1 x 8 wave grid for the 256-channel layers " \
+            "and the one-launch DiffNet layer)" if dtype_name == "bf16" else "conv1d_cl_kernel<f32>, 128x128 tiles"
     # The timed steps run the DiffNet forward as ONE launch per layer (csrc/diffnet_layer.hip, issued by the C-side stack
     # driver: the launch-by-launch step above takes the two launches it replaces).  One more step through the drivers with an
     # event pair around the driver call: 20 launches of that kernel (+ one elementwise launch), priced per launch.
@@ -373,8 +374,10 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
             # `traffic` above is the 64 x 128-tile kernel's; the two other families the `kernel` string names, from the same passes
             "traffic_by_family": {k: measured_traffic(TRAFFIC_TRAIN, sub)[0] for k, sub in
                                   (("conv1d_glds_kernel<2,4,2,2,2,false,0>", "conv1d_glds_kernel<2, 4, 2, 2, 2, false, 0"),
-                                   ("conv1d_rt_kernel<5,4,0>", "conv1d_rt_kernel<5, 4, 0"),
-                                   ("diffnet_layer_kernel<5,true,0,4,true>", "diffnet_layer_kernel<5, true, 0, 4, true"))}
+                                   ("conv1d_rt_gw_kernel<8,3,0,0>", "conv1d_rt_gw_kernel<8, 3, 0, 0"),
+                                   ("conv1d_rt_gw_kernel<8,17,0,0>", "conv1d_rt_gw_kernel<8, 17, 0, 0"),
+                                   ("conv1d_rt_gw_kernel<8,1,0,1> (gate backward)", "conv1d_rt_gw_kernel<8, 1, 0, 1"),
+                                   ("diffnet_layer_kernel<5,true,0,8,true,true,2>", "diffnet_layer_kernel<5, true, 0, 8, true, true, 2"))}
             if dtype_name == "bf16" else None,
             "launches": n_launch, "avg_launch_us": round(1e3 * tot_ms / max(n_launch, 1), 2),
             "flop_per_step": tot_flop, "by_bound": by_bound,
