@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))  # (run from anywhere)
 from promptttspp_amd import ops
 dev = torch.device("cuda:0")
 ops.CONV_RT_MIN_ROWS = 1

@@ -25,6 +25,7 @@ VIEWS = ("view", "reshape", "transpose", "permute", "slice", "select", "expand",
          "t.default", "split", "unbind", "_unsafe_view", "empty", "narrow", "chunk", "size", "stride", "is_", "sym_", "lift", "unfold",
          "_local_scalar", "set_", "record_stream", "new_empty", "empty_like", "empty_strided")
 sites = collections.defaultdict(collections.Counter)
+bwd_seq = []
 
 
 class Spy(TorchDispatchMode):
@@ -36,6 +37,8 @@ class Spy(TorchDispatchMode):
                 fr = [f for f in traceback.extract_stack()[:-1] if "/root/repo/promptttspp_amd" in f.filename or f.filename.endswith("bench.py")]
                 site = f"{fr[-1].filename.split('/root/repo/')[-1]}:{fr[-1].lineno} {fr[-1].name}" if fr else "(no package frame)"
                 sites[site][name.replace("aten.", "")] += 1
+                if not fr or fr[-1].name == "train_step":  # backward of torch-native nodes: the sequence, with shapes
+                    bwd_seq.append((name.replace("aten.", ""), [tuple(t.shape) for t in flat][:3]))
         return func(*args, **(kwargs or {}))
 
 
@@ -46,3 +49,7 @@ tot = sum(sum(c.values()) for c in sites.values())
 print(f"{tot} non-view aten ops on device tensors in the step")
 for s, c in sorted(sites.items(), key=lambda kv: -sum(kv[1].values()))[:60]:
     print(f"{sum(c.values()):4d}  {s[:95]:95s} {dict(c.most_common(4))}")
+
+print("-- the torch-native launches of the backward, in issue order (op, shapes of the first tensor arguments):")
+for i, (n, sh) in enumerate(bwd_seq):
+    print(f"  {i:3d} {n:28s} {sh}")

@@ -24,6 +24,7 @@ for k in range(max(1, len(ends) - 8), len(ends) - 1):
     steps.append((lo, hi, seg))
 print(f"{len(steps)} steps; main stream {main}; streams in use: {len(by)}")
 acc = collections.defaultdict(lambda: [0.0, 0, collections.Counter()])
+cnt_main = collections.Counter()
 tw = tu = t2 = 0.0
 for lo, hi, seg in steps:
     ev = []
@@ -33,6 +34,8 @@ for lo, hi, seg in steps:
         acc[s][0] += b - a
         acc[s][1] += 1
         acc[s][2][short(n)] += b - a
+        if s == main:
+            cnt_main[short(n)] += 1
     ev.sort()
     depth, last = 0, lo
     for t, d in ev:
@@ -49,3 +52,6 @@ print(f"per step: wall {tw / n / 1e6:.2f} ms, some kernel running {tu / n / 1e6:
 for s, (busy, cnt, top) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
     print(f"  stream {s}: busy {busy / n / 1e6:6.2f} ms, {cnt / n:6.1f} launches per step; " +
           ", ".join(f"{k} {v / n / 1e3:.0f} us" for k, v in top.most_common(14 if s == main else 5)))
+print("main stream, launches per step by kernel (count, total us):")
+for k, c in cnt_main.most_common(45):
+    print(f"  {c / n:6.1f} x  {acc[main][2][k] / n / 1e3:8.1f} us  {k}")
