@@ -651,6 +651,18 @@ int ptpp_snake_conv_post_supported(int C, int ks, int dtype);
 int ptpp_snake_conv_post_tanh(const void* x, const float* log_alpha, const float* filt_up, const float* filt_down,
                               const float* w, float bias, float* y, int B, int T, int C, int ks, int dtype, void* stream);
 
+/* Masked L1 mean: out[0] = sum_i |pred_i - target_i| * mask[i / cols] / denom[0] / scale -- the L1 losses of the training step
+ * (models/prompttts_mdn_v2_final/model.py:126, 138-170: F.l1_loss on masked tensors; mel / noise, log-F0, V/UV, energy).  pred
+ * (rows * cols, contiguous) f32 or bf16, target f32, mask (rows) f32 or NULL, denom / out / gout device scalars (no host sync).
+ * One launch each way; the forward adds its partial sums in a fixed order (bit-reproducible).  scratch: ptpp_l1_scratch_bytes()
+ * of device memory, zero before the FIRST call (the kernel leaves it zero).  _bwd: dpred (pred's dtype) =
+ * sgn(pred - target) * mask * ((gout / scale) / denom), the value autograd's nodes produce for the tensor-op form. */
+int64_t ptpp_l1_scratch_bytes(void);
+int ptpp_l1_masked_mean_fwd(const void* pred, const float* target, const float* mask, const float* denom, float scale,
+                            int64_t rows, int cols, int dtype, float* out, void* scratch, void* stream);
+int ptpp_l1_masked_mean_bwd(const void* pred, const float* target, const float* mask, const float* denom, const float* gout,
+                            float scale, int64_t rows, int cols, int dtype, void* dpred, void* stream);
+
 /* Dimension-wise mixture-density NLL (modules/mdn.py:81-175, `dim_wise`): log_pi / log_sigma / mu (rows, G, D) f32,
  * target (rows, D), mask (rows) bytes or NULL (0 = masked: loss +inf, zero gradients) -> loss (rows, D) = -logsumexp_g.
  * _bwd recomputes the component log-likelihoods from the inputs and the saved loss. */

@@ -253,6 +253,9 @@ SIGNATURES = {
     "ptpp_mdn_nll_bwd": (I, [P] * 10 + [I64, I, I, F, F, P]),
     "ptpp_conv1d_gate_bwd_supported": (I, [I, I, I]),
     "ptpp_conv1d_gate_bwd": (I, [POINTER(ConvArgs), P, P, I, P]),
+    "ptpp_l1_scratch_bytes": (I64, []),
+    "ptpp_l1_masked_mean_fwd": (I, [P, P, P, P, c_float, I64, I, I, P, P, P]),
+    "ptpp_l1_masked_mean_bwd": (I, [P, P, P, P, P, c_float, I64, I, I, P, P]),
     "ptpp_conv1d_rt_gate_bwd_supported": (I, [I, I, I]),
     "ptpp_conv1d_rt_gate_bwd": (I, [POINTER(ConvArgs), P, P, P, I, P]),
     "ptpp_conv1d_gate_fwd_save_supported": (I, [I, I, I]),

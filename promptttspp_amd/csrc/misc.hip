@@ -288,3 +288,95 @@ extern "C" int ptpp_filtfilt(const float* x, float* y, double* tmp, const int32_
   PTPP_CHECK_LAUNCH("filtfilt");
   return PTPP_OK;
 }
+
+// ---- masked L1 mean: the scalar losses of the training step as one launch each way ------------------------------------------------
+// loss = sum_i |pred_i - target_i| * mask[i / cols] / denom[0] / scale   (reference models/prompttts_mdn_v2_final/model.py:126,138-170:
+// F.l1_loss over masked tensors written as .abs().sum() / n_frames).  The tensor-op form is 6 launches forward and ~8 native
+// autograd nodes backward per loss; on the main stream every launch costs ~8 us beyond its kernel time.
+// Forward: L1_BLOCKS partial sums, the LAST block to arrive (ticket counter in `scratch`, reset for the next call) adds them in a
+// fixed order -- one launch, bit-reproducible.  Backward: d pred = sgn(pred - target) * mask * ((gout * (1 / scale)) / denom), the
+// arithmetic of autograd's two DivBackward nodes (a division by a host scalar is a multiplication by its reciprocal there),
+// rounded once into pred's dtype.
+constexpr int L1_BLOCKS = 128;
+template <typename T>
+static __global__ __launch_bounds__(256) void l1_masked_mean_fwd_kernel(const T* __restrict__ pred, const float* __restrict__ target,
+                                                                      const float* __restrict__ mask, const float* __restrict__ denom,
+                                                                      float scale, int64_t n, int cols, float* __restrict__ out,
+                                                                      float* __restrict__ scratch) {
+  __shared__ float red[4];
+  __shared__ int last;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)L1_BLOCKS * 256) {
+    const float d = fabsf(Elem<T>::ld(pred + i) - target[i]);
+    s += mask ? d * mask[i / cols] : d;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    scratch[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __threadfence();
+    const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(scratch), 1u);
+    last = t == (unsigned)L1_BLOCKS - 1u;
+  }
+  __syncthreads();
+  if (last && threadIdx.x < 64) {
+    __threadfence();
+    const volatile float* part = scratch + 1;
+    float v = part[threadIdx.x] + part[threadIdx.x + 64];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) {
+      out[0] = (v / denom[0]) * (1.f / scale);  // (torch divides by a host scalar as a multiplication by its f32 reciprocal)
+      *reinterpret_cast<unsigned*>(scratch) = 0u;
+    }
+  }
+}
+template <typename T>
+static __global__ __launch_bounds__(256) void l1_masked_mean_bwd_kernel(const T* __restrict__ pred, const float* __restrict__ target,
+                                                                      const float* __restrict__ mask, const float* __restrict__ denom,
+                                                                      const float* __restrict__ gout, float scale, int64_t n, int cols,
+                                                                      T* __restrict__ dpred) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float coef = (gout[0] * (1.f / scale)) / denom[0];  // DivBackward by the host scalar (x reciprocal), then by the tensor
+  const float d = Elem<T>::ld(pred + i) - target[i];
+  float g = d > 0.f ? coef : (d < 0.f ? -coef : 0.f);
+  if (mask) g *= mask[i / cols];
+  Elem<T>::st(dpred + i, g);
+}
+
+extern "C" int64_t ptpp_l1_scratch_bytes(void) { return (int64_t)(1 + L1_BLOCKS) * 4; }
+
+extern "C" int ptpp_l1_masked_mean_fwd(const void* pred, const float* target, const float* mask, const float* denom, float scale,
+                                       int64_t rows, int cols, int dtype, float* out, void* scratch, void* stream) {
+  PTPP_CHECK_ARG(pred && target && denom && out && scratch && rows > 0 && cols > 0 && scale != 0.f, "l1_masked_mean_fwd: bad args");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "l1_masked_mean_fwd: dtype %d (f32 / bf16)", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = rows * cols;
+  if (dtype == PTPP_F32)
+    hipLaunchKernelGGL(l1_masked_mean_fwd_kernel<float>, dim3(L1_BLOCKS), dim3(256), 0, st, reinterpret_cast<const float*>(pred), target,
+                       mask, denom, scale, n, cols, out, reinterpret_cast<float*>(scratch));
+  else
+    hipLaunchKernelGGL(l1_masked_mean_fwd_kernel<bf16_raw>, dim3(L1_BLOCKS), dim3(256), 0, st, reinterpret_cast<const bf16_raw*>(pred),
+                       target, mask, denom, scale, n, cols, out, reinterpret_cast<float*>(scratch));
+  PTPP_CHECK_LAUNCH("l1_masked_mean_fwd");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_l1_masked_mean_bwd(const void* pred, const float* target, const float* mask, const float* denom, const float* gout,
+                                       float scale, int64_t rows, int cols, int dtype, void* dpred, void* stream) {
+  PTPP_CHECK_ARG(pred && target && denom && gout && dpred && rows > 0 && cols > 0 && scale != 0.f, "l1_masked_mean_bwd: bad args");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "l1_masked_mean_bwd: dtype %d (f32 / bf16)", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = rows * cols;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  if (dtype == PTPP_F32)
+    hipLaunchKernelGGL(l1_masked_mean_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, reinterpret_cast<const float*>(pred), target, mask,
+                       denom, gout, scale, n, cols, reinterpret_cast<float*>(dpred));
+  else
+    hipLaunchKernelGGL(l1_masked_mean_bwd_kernel<bf16_raw>, dim3(nb), dim3(256), 0, st, reinterpret_cast<const bf16_raw*>(pred), target,
+                       mask, denom, gout, scale, n, cols, reinterpret_cast<bf16_raw*>(dpred));
+  PTPP_CHECK_LAUNCH("l1_masked_mean_bwd");
+  return PTPP_OK;
+}
+

@@ -815,6 +815,40 @@ def attention(qkv, pos, bias_u, bias_v, lengths, heads, variant, drop_p=0.0):
 
 
 # ----------------------------------------------------------------------------
+FUSED_L1 = not os.environ.get("PTPP_NO_FUSED_L1")  # (A/B knob: the tensor-op form of the L1 losses)
+
+
+class MaskedL1MeanFn(Function):
+    """sum |pred - target| * mask[row] / denom / scale: an L1 loss of the training step (reference
+    models/prompttts_mdn_v2_final/model.py:126, 138-170) as ONE launch forward and one backward instead of six tensor ops and
+    ~eight native autograd nodes.  Gradient for ``pred`` only (the targets are data)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask, denom, scale):
+        pred = pred.contiguous()
+        target = target.contiguous()
+        ctx.save_for_backward(pred, target, mask, denom)
+        ctx.scale = float(scale)
+        return ops.l1_masked_mean_fwd(pred, target, mask, denom, scale)
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, mask, denom = ctx.saved_tensors
+        return ops.l1_masked_mean_bwd(pred, target, mask, denom, gout.float(), ctx.scale), None, None, None, None
+
+
+def masked_l1_mean(pred, target, mask, denom, scale=1.0):
+    """|pred - target| summed over everything (rows weighted by ``mask`` (rows,) f32 if given), divided by ``denom`` (a 0-dim
+    tensor) and ``scale``.  Device tensors: one fused launch each way (MaskedL1MeanFn); CPU tensors: the tensor expression."""
+    if FUSED_L1 and pred.is_cuda and pred.dtype in (torch.float32, torch.bfloat16) and denom.dtype == torch.float32:
+        return MaskedL1MeanFn.apply(pred, target.float(), None if mask is None else mask.reshape(-1).float().contiguous(),
+                                    denom.reshape(()), scale)
+    d = (pred.float() - target.float()).abs()
+    if mask is not None:
+        d = d * mask.reshape(d.shape[:-1] + (1,))
+    return d.sum() / denom / scale
+
+
 class LengthRegulateFn(Function):
     @staticmethod
     def forward(ctx, x, cum, Tf):

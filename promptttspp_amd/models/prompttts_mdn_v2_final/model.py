@@ -178,8 +178,13 @@ class PromptTTSMDNDurCFG(nn.Module):
             pred = self._decode_conformer(h, flen, fm1)
             loss_dec = (pred.float() - mel_cl).abs().sum() / n_frames / self.loss_dec_scale
         else:
-            noise, pred = self.decoder.forward_cl(h, mel_cl, flen)
-            loss_dec = ((noise - pred) * fm1).abs().sum() / n_frames / self.loss_dec_scale
+            if dev.type == "cuda":
+                # (the prediction stays in the compute dtype: the fused loss reads it as it is, one launch each way)
+                noise, pred = self.decoder.forward_cl(h, mel_cl, flen, pred_f32=False)
+                loss_dec = PF.masked_l1_mean(pred, noise, fm1, n_frames, self.loss_dec_scale)
+            else:
+                noise, pred = self.decoder.forward_cl(h, mel_cl, flen)
+                loss_dec = ((noise - pred) * fm1).abs().sum() / n_frames / self.loss_dec_scale
 
         if bs is not None:  # join: the losses read the branches' outputs
             main = torch.cuda.current_stream()
@@ -199,8 +204,12 @@ class PromptTTSMDNDurCFG(nn.Module):
         nll = mdn_loss(*dur_out, log_dur.unsqueeze(-1), reduce=False, mask=pmb)
         loss_dur = torch.where(pmb, nll, torch.zeros_like(nll)).sum() / pmb.sum()
 
-        loss_cf0 = (cf0_pred - log_cf0.squeeze(1)).abs().sum() / n_frames
-        loss_vuv = (vuv_pred - vuv.squeeze(1)).abs().sum() / n_frames
+        if dev.type == "cuda":
+            loss_cf0 = PF.masked_l1_mean(cf0_pred, log_cf0.squeeze(1), None, n_frames)
+            loss_vuv = PF.masked_l1_mean(vuv_pred, vuv.squeeze(1), None, n_frames)
+        else:
+            loss_cf0 = (cf0_pred - log_cf0.squeeze(1)).abs().sum() / n_frames
+            loss_vuv = (vuv_pred - vuv.squeeze(1)).abs().sum() / n_frames
         if self.style_mdn is not None:
             loss_style = mdn_loss(*style_mdn_out, style_emb.detach().transpose(-1, -2)).mean()
         else:
@@ -209,7 +218,8 @@ class PromptTTSMDNDurCFG(nn.Module):
         loss = loss_dec + loss_dur + loss_cf0 + loss_vuv + loss_style
         out = dict(loss=loss, dec=loss_dec, dur=loss_dur, cf0=loss_cf0, vuv=loss_vuv, style=loss_style)
         if energy_pred is not None:
-            loss_energy = (energy_pred - energy.squeeze(1)).abs().sum() / n_frames
+            loss_energy = PF.masked_l1_mean(energy_pred, energy.squeeze(1), None, n_frames) if dev.type == "cuda" else \
+                (energy_pred - energy.squeeze(1)).abs().sum() / n_frames
             out["loss"] = loss + loss_energy
             out["energy"] = loss_energy
         return out

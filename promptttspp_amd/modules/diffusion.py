@@ -110,8 +110,9 @@ class GaussianDiffusion(nn.Module):
         return mean, extract(self.posterior_variance, t, x_t.shape), extract(self.posterior_log_variance_clipped, t, x_t.shape)
 
     # -- training ----------------------------------------------------------------------
-    def forward_cl(self, cond, mel_cl, lengths):
-        """cond (B,T,Cc) channels-last compute dtype; mel_cl (B,T,M) f32 -> (noise, prediction) (B,T,M) f32."""
+    def forward_cl(self, cond, mel_cl, lengths, pred_f32=True):
+        """cond (B,T,Cc) channels-last compute dtype; mel_cl (B,T,M) f32 -> (noise, prediction) (B,T,M) f32
+        (``pred_f32=False``: the prediction in the compute dtype, for the fused loss)."""
         B = cond.shape[0]
         inj = self.injected
         self.injected = None
@@ -122,7 +123,7 @@ class GaussianDiffusion(nn.Module):
             noise = torch.randn_like(mel_cl)
         x_noisy = self.q_sample(self._norm(mel_cl), t, noise)
         pred = self.denoise_fn.forward_cl(x_noisy.to(cond.dtype), t, cond, lengths)
-        return noise, pred.float()
+        return noise, (pred.float() if pred_f32 else pred)
 
     def forward(self, cond, lengths=None, y=None, g=None, mask=None):
         """Reference signature: cond (B,T,Cc), y (B,T,M), mask (B,1,T) -> (noise, x_recon) (B,T,M)."""

@@ -793,6 +793,44 @@ def conv1d_rt_gate_bwd(do, wstream, a, da, lengths=None):
     return da
 
 
+_l1_scratch = {}
+
+
+def _l1_scratch_of(device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
+    w = _l1_scratch.get(key)
+    if w is None:  # zero before the first call; every call leaves it zero (one per stream: calls on a stream are ordered)
+        w = _l1_scratch[key] = torch.zeros(int(_lib.load().ptpp_l1_scratch_bytes()), device=device, dtype=torch.uint8)
+    return w
+
+
+def l1_masked_mean_fwd(pred, target, mask, denom, scale):
+    """sum |pred - target| * mask[row] / denom / scale as a 0-dim f32 tensor (ptpp_l1_masked_mean_fwd): pred (..., cols) f32 or
+    bf16 contiguous, target f32 of the same shape, mask (rows) f32 or None, denom a device scalar."""
+    _need_gpu(pred)
+    assert pred.is_contiguous() and target.is_contiguous() and target.dtype == torch.float32 and target.shape == pred.shape
+    assert denom.dtype == torch.float32 and denom.numel() == 1 and (mask is None or (mask.dtype == torch.float32 and mask.is_contiguous()))
+    cols = pred.shape[-1] if mask is not None else 1
+    rows = pred.numel() // cols
+    assert mask is None or mask.numel() == rows
+    out = torch.empty((), device=pred.device, dtype=torch.float32)
+    check(_lib.load().ptpp_l1_masked_mean_fwd(pred.data_ptr(), target.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                              denom.data_ptr(), float(scale), rows, cols, dtype_code(pred.dtype), out.data_ptr(),
+                                              _l1_scratch_of(pred.device).data_ptr(), _stream()), "ptpp_l1_masked_mean_fwd")
+    return out
+
+
+def l1_masked_mean_bwd(pred, target, mask, denom, gout, scale):
+    cols = pred.shape[-1] if mask is not None else 1
+    rows = pred.numel() // cols
+    dpred = torch.empty_like(pred)
+    gout = gout.contiguous()
+    check(_lib.load().ptpp_l1_masked_mean_bwd(pred.data_ptr(), target.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                              denom.data_ptr(), gout.data_ptr(), float(scale), rows, cols, dtype_code(pred.dtype),
+                                              dpred.data_ptr(), _stream()), "ptpp_l1_masked_mean_bwd")
+    return dpred
+
+
 def mdn_nll_fwd(log_pi, log_sigma, mu, target, mask, lp_min, ls_min):
     """(rows.., G, D) f32 x3, target (rows.., D), mask (rows..) bool or None -> loss (rows.., D)."""
     G, D = mu.shape[-2], mu.shape[-1]

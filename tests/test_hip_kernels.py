@@ -1171,3 +1171,35 @@ def test_sampler_head_kernel(dev, B, T, last):
         for a, b in ((gh0, h0), (gy, yin0)):
             d = (a.float() - b.float()).abs()
             assert float((d > 0).float().mean()) < 1e-3 and float(d.max()) <= 2.0 ** -6 * float(b.float().abs().max())
+
+
+@pytest.mark.parametrize("shape,masked,dt", [((7, 333, 80), True, torch.bfloat16), ((7, 333, 80), True, torch.float32),
+                                             ((5, 1201), False, torch.float32), ((3, 17, 80), True, torch.bfloat16)])
+def test_masked_l1_mean_matches_the_tensor_expression_and_its_autograd(dev, shape, masked, dt):
+    """ptpp_l1_masked_mean_fwd / _bwd (the L1 losses of reference models/prompttts_mdn_v2_final/model.py:126,138-170) against
+    ((target - pred) * mask).abs().sum() / n / scale and torch autograd: the value to f32 summation-order accuracy, the gradient
+    BIT FOR BIT (sign * mask * ((g / scale) / n) rounded once into pred's dtype); two calls give identical bits (fixed order)."""
+    from promptttspp_amd import functional as PF
+
+    g = torch.Generator().manual_seed(123)
+    pred = torch.randn(*shape, generator=g).to(dev).to(dt).requires_grad_(True)
+    target = torch.randn(*shape, generator=g).to(dev)
+    target.view(-1)[::7] = pred.detach().float().view(-1)[::7]  # exact ties: sgn(0) = 0
+    rows = pred.numel() // shape[-1]
+    mask = (torch.rand(rows, generator=g) > 0.3).float().to(dev) if masked else None
+    n = torch.tensor(float(rows) * 0.7, device=dev)
+    scale = 6.0
+    loss = PF.masked_l1_mean(pred, target, None if mask is None else mask.view(shape[:-1] + (1,)), n, scale)
+    loss2 = PF.masked_l1_mean(pred, target, None if mask is None else mask.view(shape[:-1] + (1,)), n, scale)
+    assert torch.equal(loss, loss2)
+    (loss * 1.7).backward()
+    got = pred.grad.clone()
+    pred.grad = None
+    p32 = pred.float()
+    d = (target - p32)
+    if mask is not None:
+        d = d * mask.view(shape[:-1] + (1,))
+    ref = d.abs().sum() / n / scale
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert torch.equal(got, pred.grad)
