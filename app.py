@@ -5,6 +5,8 @@ The reference wraps this in a Gradio UI fed by g2p_en / nltk; that text front-en
 build, so ``synthesize`` starts from phoneme ids.  With gradio and the
 reference's text package importable, ``build_ui`` offers the same two-tab demo."""
 import os
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (promptttspp_amd/__init__.py); before the HIP runtime starts
 import sys
 
 import torch

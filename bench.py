@@ -16,6 +16,8 @@ import argparse
 import json
 import math
 import os
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (promptttspp_amd/__init__.py); before the HIP runtime starts
 import random
 import sys
 import time
@@ -877,7 +879,8 @@ def main():
             "config": {"workload": "train.py model=prompttts_mdn_v2_wo_erg_final, dataset.max_tokens=%d per GPU, synthetic "
                                    "LibriTTS-R-shaped utterances, fwd+bwd+clip+AdamW+Noam, train mode (dropout on)" % a.max_tokens,
                        "utts_per_gpu_batch": int(B), "parallelism": f"dp{world}", "final_loss": round(loss, 4),
-                       "preheat_steps": a.preheat, "host_enqueue_ms_per_step": round(1e3 * host_dt / a.steps, 3)},
+                       "preheat_steps": a.preheat, "host_enqueue_ms_per_step": round(1e3 * host_dt / a.steps, 3),
+                       "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")}},
             "roofline": roof, "cpu_baseline": cpu,
             "per_gpu_value": round(frames / dt / world, 1),
             "dp": dp,

@@ -14,6 +14,8 @@ not in this image): 32-bit float PCM, what ``torchaudio.save`` writes for a floa
 """
 import csv
 import os
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (promptttspp_amd/__init__.py); before the HIP runtime starts
 import sys
 from pathlib import Path
 

@@ -7,6 +7,8 @@ Hydra-style ``key=value`` overrides and runs ``promptttspp.trainers.tts.TTSTrain
 With hydra-core installed this is the reference's ``@hydra.main`` program; without it (this
 image) the in-tree composer ``promptttspp_amd.hydra_lite`` reads the same YAML tree."""
 import os
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (promptttspp_amd/__init__.py); before the HIP runtime starts
 import sys
 
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", "..")))
