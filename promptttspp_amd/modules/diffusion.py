@@ -206,12 +206,19 @@ class GaussianDiffusion(nn.Module):
         return self._denorm(x)
 
     @staticmethod
-    def _chunked_noise(device, shape, chunk=16):
-        """The default noise source of the reverse loop: standard normal draws, ``chunk`` steps per generator launch (one
-        launch per step was ~5 us of a ~1 ms step; the draws stay i.i.d. N(0, 1), only their position in the generator's stream
-        differs from a per-step ``randn``)."""
+    def _chunked_noise(device, shape, chunk=16, max_bytes=32 << 20):
+        """The default noise source of the reverse loop: standard normal draws, up to ``chunk`` steps per generator launch (one
+        launch per step was ~5 us of a ~1 ms step).  The draws stay i.i.d. N(0, 1), but their POSITION in the generator's
+        stream differs from a per-step ``randn``: since round 4 the same seed gives a different (equally distributed) mel than
+        rounds 1-3 and than the reference's loop; pass ``noise_fn`` to reproduce a given stream (the golden tests do).  The
+        chunk is sized by bytes (<= ``max_bytes`` of f32 noise alive at a time: 16 steps of a 32 x 1000 x 80 batch would hold
+        164 MB for the whole loop)."""
         if device.type != "cuda":
             return lambda i, s: torch.randn(s, device=device)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        chunk = max(1, min(int(chunk), int(max_bytes // max(1, 4 * n))))
         state = {"buf": None, "k": 0}
 
         def draw(i, s):
