@@ -607,6 +607,8 @@ int rt_launch(const RtP& p, hipStream_t st) {
 
 }  // namespace
 
+static int rt_bm_for(int B, int T);
+
 extern "C" int ptpp_conv1d_rt_supported(int cin, int cout, int ks, int dil, int act, int dtype) {
   if (dtype != PTPP_BF16 || cout != RT_N || cin <= 0 || (cin & 63) || ks < 3 || dil < 1) return 0;
   if (act != PTPP_ACT_NONE && act != PTPP_ACT_RELU) return 0;
@@ -644,20 +646,7 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
   p.out_scale = a->out_scale; p.res_scale = res_scale;
   p.aux = reinterpret_cast<bf16_raw*>(aux); p.ldaux = ldaux; p.aux_scale = aux_scale;
   p.gate_a = nullptr; p.gate_da = nullptr; p.ldda = 0;
-  // rows per block: least (rounds of 256 one-per-CU blocks) x (time of a block)
-  int bm = 128;
-  {
-    const int cand[3] = {128, 96, 64};
-    const float tblk[3] = {1.f, 0.8f, 0.6f};
-    float best = 1e30f;
-    for (int i = 0; i < 3; ++i) {
-      const int64_t nb = (int64_t)a->B * ((a->T + cand[i] - 1) / cand[i]);
-      const float cost = (float)((nb + 255) / 256) * tblk[i];
-      if (cost < best - 1e-3f) { best = cost; bm = cand[i]; }
-    }
-    const char* force = getenv("PTPP_CONV_RT_BM");  // (experiments / tests)
-    if (force && (atoi(force) == 64 || atoi(force) == 96 || atoi(force) == 128)) bm = atoi(force);
-  }
+  const int bm = rt_bm_for(a->B, a->T);  // rows per block: least (rounds of 256 one-per-CU blocks) x (time of a block)
   p.nMT = (a->T + bm - 1) / bm;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool relu = a->act == PTPP_ACT_RELU;

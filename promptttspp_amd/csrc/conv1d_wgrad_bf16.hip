@@ -42,15 +42,9 @@ constexpr int NS_DEFAULT = 4;  // LDS ring stages of the split-K kernels (NS - 1
 
 __device__ uint4 g_zero_page[64];  // source of out-of-range rows
 
-// The transpose reads are issued as inline asm: for a compiler-visible LDS read hipcc drains
+// The transpose reads are issued as inline asm (frag_at / frag_at2 below): for a compiler-visible LDS read hipcc drains
 // ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)) first, which would serialise the ring.  The
 // kernel counts vmcnt / lgkmcnt itself (wait_vm, lds_fence).
-__device__ __forceinline__ v4s tr_read(const bf16_raw* p) {
-  v4s r;
-  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) bf16_raw*)p;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a));
-  return r;
-}
 struct Frag {
   v4s lo, hi;
 };
@@ -93,22 +87,8 @@ __device__ __forceinline__ int sw<16>(int row) { return ((row & 3) | ((row >> 1)
 template <>
 __device__ __forceinline__ int sw<8>(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
 
-// 8 consecutive rows (k = 8g .. 8g+7) of column (c0 + i) for lane l = 16 g + i
-template <int TW>
-__device__ __forceinline__ Frag frag(const bf16_raw* tile, int row0, int c0, int lane) {
-  constexpr int CPR = TW / 8;
-  const int g = lane >> 4, i = lane & 15;
-  const int row = row0 + 8 * g + (i >> 2);
-  const int col = c0 + 4 * (i & 3);
-  const bf16_raw* p = tile + row * TW + (((col >> 3) ^ sw<CPR>(row)) << 3) + (col & 7);
-  const bf16_raw* q = tile + (row + 4) * TW + (((col >> 3) ^ sw<CPR>(row + 4)) << 3) + (col & 7);  // (== p + 4 TW for row0 % 8 == 0)
-  Frag f;
-  f.lo = tr_read(p);
-  f.hi = tr_read(q);
-  return f;
-}
-
-// byte offset (inside a [rows][TW] tile) of the first transpose read of the fragment frag<TW>() reads
+// A fragment = 8 consecutive rows (k = 8g .. 8g+7) of column (c0 + i) for lane l = 16 g + i, as two transpose reads (rows r and r + 4).
+// byte offset (inside a [rows][TW] tile) of the fragment's first transpose read
 template <int TW>
 __device__ __forceinline__ uint32_t frag_off(int row0, int c0, int lane) {
   constexpr int CPR = TW / 8;
