@@ -14,10 +14,11 @@
 //     per 128-channel tile) by LDS-DMA, double-buffered;
 //   * the weights arrive as ONE contiguous stream of 16 KiB stages ([256 channels][32 k], already the LDS image: pack modes
 //     3 / 4) through a ring of NS stages, NS - 3 stages in flight under the MFMAs;
-//   * wave tile 64 x 64 (BM = 128): 8 fragment reads per 16 MFMAs -- the LDS -> register return path (~64 B/clk/CU measured,
-//     DESIGN.md section 5e) caps an MFMA kernel at tile-shape-dependent rates: 32 x 64 wave tiles (the tile kernel's choice at
-//     these grid sizes) 33 % of peak, 64 x 64 50 %; fragments are requested one step ahead so the round trip hides under the
-//     previous step's MFMAs.
+//   * wave tile 64 x 64 (BM = 128): 8 fragment reads per 16 MFMAs, requested one step ahead so the round trip hides under the
+//     previous step's MFMAs.  (Round 4 blamed an "LDS -> register return path of ~64 B/clk/CU" for this loop's 33-50 % of peak;
+//     round 5's micro-benchmark measures 256 B/clk -- the loop is bound by the ~100 scalar instructions per step of its ring
+//     bookkeeping, DESIGN.md section 5f.  conv1d_rt_gw_kernel below is the form built on that finding; this one stays for the
+//     tap counts and channel counts it does not cover and as the bit-identity reference.)
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
