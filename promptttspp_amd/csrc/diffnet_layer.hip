@@ -896,27 +896,36 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
   // the choice with the least (rounds x time of one block) -- block times measured on the inference form, 57 / 46 / 35 us
   // (tools/bench_diffnet_layer.py); a 30 000-frame training bucket takes 128 (235 blocks), the sampler's 32 x 540 frames 96
   // (192 blocks: 64-row tiles would need two rounds, 128-row tiles leave 96 CUs idle).
+  // PTPP_DIFFNET_GW: 0 = LDS ring; 1 = weights straight from global memory, 2 x 4 wave grid; 2 (default) = the same on the
+  // 1 x 8 wave grid (FN = 2).  Diagnostics builds exist for the ring form and for dbg 200 + m (the 1 x 8 form, 128 rows).
+  const char* gwe = getenv("PTPP_DIFFNET_GW");
+  const int gwm = dbg >= 200 ? 2 : dbg ? 0 : (gwe ? atoi(gwe) : 2);
   int bm = 128;
   {
-    const int cand[3] = {128, 96, 64};
-    const float tblk[3] = {57.f, 46.f, 35.f};
+    // the 1 x 8 form also has 80- and 112-row blocks for the inference forms (a wave owns bm / 16 row tiles): block times of the
+    // inference form 41.7 / 36.2 / 34.3 us at 128 / 96 / 80 rows and 27.2 us per round at 64 (tools/bench_diffnet_layer.py 32 546), 112
+    // rows interpolated -- the sampler's 32 x 546 frames take 80 rows (224 blocks, one round) instead of 96
+    const int cand[5] = {128, 112, 96, 80, 64};
+    const float tblk_ring[5] = {57.f, 1e9f, 46.f, 1e9f, 35.f};
+    const float tblk_gw[5] = {41.7f, 39.5f, 36.2f, 34.3f, 27.2f};
+    const bool fine = gwm == 2 && !a->a_out && !dbg;  // (80 / 112 rows: inference instantiations of the 1 x 8 form only)
     float best = 1e30f;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 5; ++i) {
+      if ((i & 1) && !fine) continue;
       const int64_t nb = (int64_t)a->B * ((a->T + cand[i] - 1) / cand[i]);
-      const float cost = (float)((nb + 255) / 256) * tblk[i];
+      const float cost = (float)((nb + 255) / 256) * (gwm == 2 ? tblk_gw[i] : tblk_ring[i]);
       if (cost < best - 0.5f) { best = cost; bm = cand[i]; }
     }
     if ((dbg & 16) || dbg >= 200) bm = 128;
-    const char* force = getenv("PTPP_DIFFNET_BM");  // (experiments)
-    if (force && (atoi(force) == 64 || atoi(force) == 96 || atoi(force) == 128)) bm = atoi(force);
+    const char* force = getenv("PTPP_DIFFNET_BM");  // (experiments / tests)
+    if (force) {
+      const int f = atoi(force);
+      if (f == 64 || f == 96 || f == 128 || (fine && (f == 80 || f == 112))) bm = f;
+    }
   }
   const bool small = bm == 64;
   p.nMT = (a->T + bm - 1) / bm;
   constexpr int NS = 5;
-  // PTPP_DIFFNET_GW: 0 = LDS ring (default); 1 = weights straight from global memory, 2 x 4 wave grid; 2 = the same on the
-  // 1 x 8 wave grid (FN = 2).  Diagnostics builds exist for the ring form only.
-  const char* gwe = getenv("PTPP_DIFFNET_GW");
-  const int gwm = dbg >= 200 ? 2 : dbg ? 0 : (gwe ? atoi(gwe) : 2);  // (dbg 200 + m: mode m of the 1 x 8 GW form, 128 rows)
   const bool gw = gwm == 1 || gwm == 2;
   const size_t smem = (size_t)((gw ? 0 : NS * DN_STAGE_U4) + bm * 32) * 16 + ((dbg < 200 && (dbg & 16)) ? 1024 : 0);
   p.stamps = stamps;
@@ -945,10 +954,14 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
       kern = sv ? diffnet_layer_kernel<NS, true, 0, 8, true, true, 2> : diffnet_layer_kernel<NS, false, 0, 8, true, true, 2>;
       if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 4, true, true, 2> : diffnet_layer_kernel<NS, false, 0, 4, true, true, 2>;
       if (bm == 96) kern = sv ? diffnet_layer_kernel<NS, true, 0, 6, true, true, 2> : diffnet_layer_kernel<NS, false, 0, 6, true, true, 2>;
+      if (bm == 80) kern = diffnet_layer_kernel<NS, false, 0, 5, true, true, 2>;
+      if (bm == 112) kern = diffnet_layer_kernel<NS, false, 0, 7, true, true, 2>;
     } else {
       kern = sv ? diffnet_layer_kernel<NS, true, 0, 8, false, true, 2> : diffnet_layer_kernel<NS, false, 0, 8, false, true, 2>;
       if (small) kern = sv ? diffnet_layer_kernel<NS, true, 0, 4, false, true, 2> : diffnet_layer_kernel<NS, false, 0, 4, false, true, 2>;
       if (bm == 96) kern = sv ? diffnet_layer_kernel<NS, true, 0, 6, false, true, 2> : diffnet_layer_kernel<NS, false, 0, 6, false, true, 2>;
+      if (bm == 80) kern = diffnet_layer_kernel<NS, false, 0, 5, false, true, 2>;
+      if (bm == 112) kern = diffnet_layer_kernel<NS, false, 0, 7, false, true, 2>;
     }
   }
   if (bm == 96 && dbg) { ptpp_set_error("diffnet_layer_fwd_dbg: the 96-row instantiation has no diagnostics build"); return PTPP_EINVAL; }

@@ -59,10 +59,11 @@ def _one_launch(PF, ops, x, yin, cond, dil_w, dil_b, out_w, out_b, dnext, skip, 
     (1, 37, 8, False, False, True),      # shorter than the dilated window
     (7, 260, 8, True, True, True),
 ])
-@pytest.mark.parametrize("bm", [64, 96, 128])
+@pytest.mark.parametrize("bm", [64, 80, 96, 112, 128])
 def test_one_launch_layer_is_bit_identical_to_the_two_launches(dev, monkeypatch, B, T, dil, masked, save, init, bm):
-    """``bm``: rows per block (PTPP_DIFFNET_BM pins what the launcher otherwise picks from the block count: all three
-    instantiations must agree with the two-launch path on every shape)."""
+    """``bm``: rows per block (PTPP_DIFFNET_BM pins what the launcher otherwise picks from the block count: every
+    instantiation must agree with the two-launch path on every shape; 80 and 112 rows exist for the inference forms of the
+    default 1 x 8 kernel only -- with ``save`` the launcher ignores the request and the case repeats another height)."""
     from promptttspp_amd import functional as PF
     from promptttspp_amd import ops
 
