@@ -356,7 +356,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
                      "frac": round(lay_tf / MFMA_BF16_PEAK_TFLOPS, 4),
                      "algorithmic_gbs": round(nbytes / (us * 1e-6) / 1e9, 1), "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                      "note": "event pair around ptpp_diffnet_stack_fwd of a driver-path step / layers; both roofs are quoted: the "
-                             "launch alternates matrix passes with HBM-bound epilogues (DESIGN.md section 5e)"}
+                             "launch alternates matrix passes with HBM-bound epilogues (DESIGN.md sections 5e, 5f.2)"}
     per_launch = {"achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches": len(recs), "by_bound": by_bound,
                   "note": "every launch of the instrumented step as issued there: the DiffNet forward as two launches per layer + one "
                           "(B, T, L * 2C) conditioner GEMM (the form of rounds 1-3, kept for continuity)"}
