@@ -944,6 +944,47 @@ def test_transformer_encoder_plugin(rel, dev):
         assert float(enc.float()[1, 9:].abs().max()) == 0.0  # padded phones are zero, as in the reference (x * mask)
 
 
+BF16_TRANSFORMER_BOUNDS = {"y": 0.01, "dx": 0.07, "grad": 0.10}  # ~1.6-2 x the measured relative L2 errors (see the test)
+
+
+def test_transformer_plugin_bf16_one_hop_from_the_oracle(dev):
+    """the windowed relative-position attention (ptpp_attention_win_fwd / _bwd inside
+    modules/transformer.py::Transformer, reference modules/transformer.py:59-137) in the BENCHMARKED dtype, bf16, directly against
+    the fixture generated from the reference (outputs) and the f32 oracle's autograd (gradients) -- not against this package's own
+    f32 path.  Relative L2 error per tensor; measured on MI355X: y 0.5 %, dx 4.2 %, parameter gradients 0.5-6.2 % (the
+    relative-position tables emb_rel_k / emb_rel_v 3.1-3.3 %, the first feed-forward conv 6.2 %), bounds ~1.6-2 x that."""
+    from promptttspp.modules.transformer import Transformer
+    from promptttspp_amd import config, ops
+
+    g = load_golden("transformer")
+    tag = "rel"
+    m = Transformer(channels=256, num_head=2, num_layers=2, kernel_size=3, dropout=0.1, scale=4, window_size=4, use_rel=True)
+    m, sd = load(m, key_shapes(g[f"{tag}_keys"]), 511, dev, {"emb_rel_k": 0.5, "emb_rel_v": 0.5})
+    T = g["x"].shape[-1]
+    log = []
+    with config.use_dtype(torch.bfloat16):
+        m.eval()
+        mask = R.sequence_mask(g["lens"], T).unsqueeze(1).float().to(dev)
+        with torch.no_grad():
+            log.append(("y", "y", l2_err(m(g["x"].to(dev), mask).float().cpu(), g[f"{tag}_y"])))
+        _zero_dropout(m)
+        m.train()
+        xc = ops.bct_to_btc(g["x"].to(dev), torch.bfloat16).requires_grad_()
+        y = m.forward_cl(xc, g["lens"].to(dev).int())
+        y.backward(g["dy"].transpose(1, 2).contiguous().to(dev).to(y.dtype))
+    log.append(("dx", "dx", l2_err(xc.grad.float().cpu().transpose(1, 2), g[f"{tag}_dx"])))
+    P = dict(m.named_parameters())
+    for key in [k for k in g if k.startswith(f"{tag}_g:")]:
+        n = key[len(tag) + 3:]
+        gr = P[n].grad.float().cpu()
+        if gr.numel() > 70000:
+            gr = gr.flatten()[:: max(1, gr.numel() // 4096)][:4096]
+        log.append(("grad", n, l2_err(gr, g[key].reshape(gr.shape))))
+    print("bf16 transformer errors:", [(n, round(e, 4)) for _, n, e in log])
+    bad = [(n, e) for kind, n, e in log if not e < BF16_TRANSFORMER_BOUNDS[kind]]
+    assert not bad, (bad, log)
+
+
 def test_sampler_fused_gate_and_graph_consistency(dev):
     """bf16 sampler: the fused gate epilogue (PTPP_ACT_GATE, interleaved weight rows) and the HIP-graph replay
     against the unfused / eager path on the same injected noise: same mel within bf16 rounding."""
