@@ -578,6 +578,7 @@ int rt_gw_launch(const RtP& p, hipStream_t st) {
 }
 template <int KS>
 int rt_gw_dispatch(const RtP& p, int bm, bool relu, hipStream_t st) {
+  if (bm == 160) return relu ? rt_gw_launch<10, KS, PTPP_ACT_RELU>(p, st) : rt_gw_launch<10, KS, PTPP_ACT_NONE>(p, st);
   if (bm == 128) return relu ? rt_gw_launch<8, KS, PTPP_ACT_RELU>(p, st) : rt_gw_launch<8, KS, PTPP_ACT_NONE>(p, st);
   if (bm == 96) return relu ? rt_gw_launch<6, KS, PTPP_ACT_RELU>(p, st) : rt_gw_launch<6, KS, PTPP_ACT_NONE>(p, st);
   return relu ? rt_gw_launch<4, KS, PTPP_ACT_RELU>(p, st) : rt_gw_launch<4, KS, PTPP_ACT_NONE>(p, st);
@@ -608,7 +609,7 @@ int rt_launch(const RtP& p, hipStream_t st) {
 
 }  // namespace
 
-static int rt_bm_for(int B, int T);
+static int rt_bm_for(int B, int T, bool tall);
 
 extern "C" int ptpp_conv1d_rt_supported(int cin, int cout, int ks, int dil, int act, int dtype) {
   if (dtype != PTPP_BF16 || cout != RT_N || cin <= 0 || (cin & 63) || ks < 3 || dil < 1) return 0;
@@ -647,13 +648,16 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
   p.out_scale = a->out_scale; p.res_scale = res_scale;
   p.aux = reinterpret_cast<bf16_raw*>(aux); p.ldaux = ldaux; p.aux_scale = aux_scale;
   p.gate_a = nullptr; p.gate_da = nullptr; p.ldda = 0;
-  const int bm = rt_bm_for(a->B, a->T);  // rows per block: least (rounds of 256 one-per-CU blocks) x (time of a block)
+  // the global-weights form (1 x 8 wave grid) for the tap counts of the model's layers; PTPP_CONV_RT_GW=0: the ring form
+  const char* gwe = getenv("PTPP_CONV_RT_GW");
+  const bool gw_ok = !(gwe && gwe[0] == '0') && (a->Cin & 127) == 0 && (a->ks == 3 || a->ks == 5 || a->ks == 17);
+  int bm = rt_bm_for(a->B, a->T, gw_ok);
+  if (bm == 160 && ((160 + (a->ks - 1) * a->dil + 7) >> 3) > 24) bm = rt_bm_for(a->B, a->T, false);  // (window pieces: 8 waves x 3)
   p.nMT = (a->T + bm - 1) / bm;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool relu = a->act == PTPP_ACT_RELU;
-  {  // the global-weights form (1 x 8 wave grid) for the tap counts of the model's layers; PTPP_CONV_RT_GW=0: the ring form
-    const char* gwe = getenv("PTPP_CONV_RT_GW");
-    const bool gw = !(gwe && gwe[0] == '0') && (a->Cin & 127) == 0;
+  {
+    const bool gw = gw_ok;
     const int xr = (bm + (a->ks - 1) * a->dil + 7) & ~7;
     const int npw = (bm + 7) / 8 + 6 > 16 ? 3 : 2;
     if (gw && (xr >> 3) <= 8 * npw) {
@@ -674,18 +678,29 @@ extern "C" int ptpp_conv1d_rt_gate_bwd_supported(int C, int cin, int dtype) {
   return dtype == PTPP_BF16 && C == RT_N && cin > 0 && (cin & 127) == 0;
 }
 
-static int rt_bm_for(int B, int T) {
+// rows per block: least (rounds of 256 one-per-CU blocks) x (relative time of a block).  ``tall``: the global-weights form also has
+// 160-row blocks (a wave owns ten row tiles: 80 accumulator registers) -- a token-bucket batch whose 128-row tiling needs 257-300
+// blocks (a quarter of the bench's batches: 65 x 459, 33 x 904, ...) otherwise runs a second, nearly empty round.
+static int rt_bm_for(int B, int T, bool tall) {
   int bm = 128;
-  const int cand[3] = {128, 96, 64};
-  const float tblk[3] = {1.f, 0.8f, 0.6f};
+  const int cand[4] = {160, 128, 96, 64};
+  const float tblk[4] = {1.22f, 1.f, 0.8f, 0.6f};
   float best = 1e30f;
-  for (int i = 0; i < 3; ++i) {
+  static const bool tall_on = [] {
+    const char* e = getenv("PTPP_CONV_RT_TALL");  // (A/B knob: 0 = no 160-row blocks)
+    return !(e && e[0] == '0');
+  }();
+  tall = tall && tall_on;
+  for (int i = tall ? 0 : 1; i < 4; ++i) {
     const int64_t nb = (int64_t)B * ((T + cand[i] - 1) / cand[i]);
     const float cost = (float)((nb + 255) / 256) * tblk[i];
     if (cost < best - 1e-3f) { best = cost; bm = cand[i]; }
   }
   const char* force = getenv("PTPP_CONV_RT_BM");  // (experiments / tests)
-  if (force && (atoi(force) == 64 || atoi(force) == 96 || atoi(force) == 128)) bm = atoi(force);
+  if (force) {
+    const int f = atoi(force);
+    if (f == 64 || f == 96 || f == 128 || (tall && f == 160)) bm = f;
+  }
   return bm;
 }
 
@@ -710,9 +725,10 @@ extern "C" int ptpp_conv1d_rt_gate_bwd(const ptpp_conv1d_args* a, const void* ws
   p.gate_a = reinterpret_cast<const bf16_raw*>(act);
   p.gate_da = reinterpret_cast<bf16_raw*>(da);
   p.ldda = ldda;
-  const int bm = rt_bm_for(a->B, a->T);
+  const int bm = rt_bm_for(a->B, a->T, true);
   p.nMT = (a->T + bm - 1) / bm;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (bm == 160) return rt_gw_launch<10, 1, PTPP_ACT_NONE, 1>(p, st);
   if (bm == 128) return rt_gw_launch<8, 1, PTPP_ACT_NONE, 1>(p, st);
   if (bm == 96) return rt_gw_launch<6, 1, PTPP_ACT_NONE, 1>(p, st);
   return rt_gw_launch<4, 1, PTPP_ACT_NONE, 1>(p, st);

@@ -21,6 +21,9 @@ def _mk(dev, B, T, cin, ks, seed):
     (9, 1000, 512, 3, 8, None, True, True, 128),      # dilated data gradient: residual with scale, masked input
     (70, 130, 256, 3, 1, "relu", True, True, 64),     # short utterances: ragged last tiles
     (16, 617, 320, 7, 2, None, False, True, 0),       # Cin not a power of two, launcher's own tile choice
+    (9, 650, 256, 17, 1, None, True, False, 160),     # 160-row blocks of the global-weights form (ten row tiles per wave; T > 512, see above)
+    (7, 700, 512, 3, 8, "relu", True, True, 160),
+    (65, 459, 256, 5, 1, "relu", False, False, 0),    # 260 blocks of 128 rows: the launcher takes 160 rows on its own
 ])
 def test_row_tile_conv_is_bit_identical_to_the_tile_kernel(dev, monkeypatch, B, T, cin, ks, dil, act, masked, use_res, bm):
     from promptttspp_amd import ops
@@ -63,7 +66,8 @@ def test_row_tile_data_gradient_operand_and_oracle(dev, monkeypatch):
     assert err < 1e-2, err
 
 
-@pytest.mark.parametrize("B,T,masked,bm", [(9, 700, True, 128), (12, 450, False, 96), (40, 130, True, 64), (5, 1000, False, 0)])
+@pytest.mark.parametrize("B,T,masked,bm", [(9, 700, True, 128), (12, 450, False, 96), (40, 130, True, 64), (5, 1000, False, 0),
+                                          (6, 459, True, 160)])
 def test_gate_backward_on_the_row_tile_engine_is_bit_identical(dev, monkeypatch, B, T, masked, bm):
     """ptpp_conv1d_rt_gate_bwd (the DiffNet output projection's data gradient, 512 -> 256, 1 x 1, with the gate backward as its
     epilogue; reference modules/denoiser.py:76-83 differentiated) against ptpp_conv1d_gate_bwd on the tile kernel: the same MFMA
