@@ -1008,6 +1008,105 @@ size_t ptpp_refenc_convs_bwd_scratch_bytes(int B, int H, int W, int nlayer, cons
 int ptpp_refenc_convs_bwd(const ptpp_refenc_convs_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------ *
+ * Deferred reduction (round 6).  The finishing launch of a PARAMETER-gradient column sum (ptpp_layernorm_bwd's dgamma / dbeta,
+ * ptpp_attention_bwd's du / dvb, ptpp_scalar_embed_bwd) has no reader before the optimiser or the gradient exchange.  After
+ * ptpp_red_defer(arena, bytes) -- `arena`: ZEROED device memory, >= 4 MiB, owned by the caller, one device per process -- such a
+ * call ignores its `scratch` argument, takes a private slice of the arena (one sub-arena per stream) and queues its finishing
+ * step; ptpp_red_flush(stream) finishes everything queued with one launch per producing stream (on that stream) and makes
+ * `stream` wait for them.  The destinations are complete only after the flush: call it before the optimiser step and before a
+ * gradient bucket is exchanged.  ptpp_red_defer_suspend(+1 / -1) brackets calls whose destination IS read right away (they
+ * finish immediately, as without deferral); a full arena falls back the same way.  ptpp_red_defer(NULL, 0) turns deferral off
+ * (nothing may be queued).  ptpp_red_pending(): queued sums (diagnostics).
+ * ------------------------------------------------------------------ */
+int ptpp_red_defer(void* arena, size_t bytes);
+int ptpp_red_defer_suspend(int delta);
+int ptpp_red_pending(void);
+int ptpp_red_flush(void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Training-step glue (round 6, csrc/glue.hip): chains of small tensor ops around the hot kernels as one launch each.
+ * ------------------------------------------------------------------ */
+/* Every loss of PromptTTSMDNDurCFG.forward (models/prompttts_mdn_v2_final/model.py:126-183) in ONE launch each way:
+ *   dec   = sum_{valid frames} |noise - pred| / n_frames / dec_scale          (:138-157, F.l1_loss of the masked tensors)
+ *   cf0   = sum |pv[..., 0] - cf0_tgt| / n_frames,  vuv = sum |pv[..., 1] - vuv_tgt| / n_frames        (:168-170; no mask)
+ *   dur   = mean over valid phones of the mixture NLL of to_log_scale(dur)    (:151-154; modules/mdn.py:81-175, D = 1)
+ *   style = mean over (B, D) of the dimension-wise mixture NLL of sty_tgt     (:159-163)
+ *   total = dec + dur + cf0 + vuv + style
+ * y_dur (B, Tp, 3 G) / y_sty (B, 3 G D) are the RAW outputs of the MDN heads, [pi logits | log_sigma | mu] with (G, D) order
+ * inside each part; the log-softmax over the G components (mdn.py:56-60) happens here.  pred (B, Tf, M) and pv (B, Tf, 2) in
+ * `dtype` (f32 / bf16), everything else f32; flen / plen int32 (B).  Outputs: total[0]; comps[0..4] = dec, dur, cf0, vuv, style,
+ * comps[5..6] = n_frames, n_phones; nll_dur (B, Tp) and nll_sty (B, D) are kept for the backward.  scratch:
+ * ptpp_tts_losses_scratch_bytes() bytes, zero before the first call (left zero).  Partial sums are added in a fixed order.
+ * _bwd: g_total / g_comps (5) device scalars (either may be NULL = 0) -> dpred, dpv (`dtype`), dy_dur, dy_sty (f32), every
+ * element written. */
+typedef struct {
+  const void* pred;
+  const float* noise;
+  const int32_t* flen;
+  const void* pv;
+  const float* cf0_tgt;
+  const float* vuv_tgt;
+  const float* y_dur;
+  const float* dur;
+  const int32_t* plen;
+  const float* y_sty;
+  const float* sty_tgt;
+  float* total;
+  float* comps;
+  float* nll_dur;
+  float* nll_sty;
+  void* scratch;
+  int32_t B, Tf, Tp, M, G_dur, G_sty, D_sty, dtype;
+  float dec_scale, lp_min, ls_min;
+} ptpp_tts_loss_args;
+int64_t ptpp_tts_losses_scratch_bytes(void);
+int ptpp_tts_losses_fwd(const ptpp_tts_loss_args* a, void* stream);
+int ptpp_tts_losses_bwd(const ptpp_tts_loss_args* a, const float* g_total, const float* g_comps, void* dpred, void* dpv,
+                        float* dy_dur, float* dy_sty, void* stream);
+
+/* DDPM q_sample on the dataset's mel layout (modules/diffusion.py:97-101,110-115,304-313):
+ *   out[b, t, m] = sqrt_ac[step_b] * norm(mel[b, m, t]) + sqrt_1mac[step_b] * noise[b, t, m]   (unfused f32 sequence, then `dtype`)
+ * norm(x) = x / norm_scale (use_scale) or (x - a_min) / (a_max - a_min) * 2 - 1.  mel (B, M, T) f32, noise (B, T, M) f32, M <= 128. */
+int ptpp_q_sample_bct(const float* mel, const float* noise, const int64_t* step, const float* sqrt_ac, const float* sqrt_1mac,
+                      int K, float norm_scale, float a_min, float a_max, int use_scale, void* out, int B, int M, int T,
+                      int dtype, void* stream);
+
+/* SinusoidalPosEmb (modules/denoiser.py:29-41): out[b] = [sin(e) | cos(e)], e = float(scale * step_b) * exp(k * neg_log_rate),
+ * k < half, neg_log_rate = -(ln 10000 / (half - 1)) as f32; out (B, 2 half) f32.  Mish (:23-26) forward / backward on f32. */
+int ptpp_step_sinusoid(const int64_t* step, int64_t scale, float neg_log_rate, int B, int half, float* out, void* stream);
+int ptpp_mish_fwd(const float* x, float* y, int64_t n, void* stream);
+int ptpp_mish_bwd(const float* x, const float* gy, float* gx, int64_t n, void* stream);
+
+/* PhonemeEmbedding (layers/embedding.py:21-36), channels-last: out[b, t] = table[ids[b, t]] (* scale) for t < lengths[b], else 0.
+ * _bwd ADDS scale * (sum over the valid rows of an id of dout) into dtable, one block per vocabulary entry walking the rows in
+ * order (bit-reproducible); row `padding_idx` gets nothing.  ids int64, table / dtable (V, C) f32, out / dout `dtype`. */
+int ptpp_embed_cl_fwd(const int64_t* ids, const float* table, const int32_t* lengths, float scale, int do_scale, void* out,
+                      int B, int T, int C, int V, int dtype, void* stream);
+int ptpp_embed_cl_bwd(const int64_t* ids, const void* dout, const int32_t* lengths, float scale, int do_scale, float* dtable,
+                      int B, int T, int C, int V, int padding_idx, int dtype, void* stream);
+
+/* x + Conv1d(1 -> C, k = 1)(track) * mask (modules/variance_adaptor.py:139-146, pitch / energy embedding):
+ *   out[b, t, :] = x[b, t, :] + T(track[b, t] * w + bias)  for t < lengths[b], else x[b, t, :].
+ * _bwd: dw += sum_valid track * dout, db += sum_valid dout (C in {256 .. 1024}, through the reduction scratch; deferrable). */
+int ptpp_scalar_embed_add(const void* x, const float* track, const float* w, const float* bias, const int32_t* lengths,
+                          void* out, int B, int T, int C, int dtype, void* stream);
+int ptpp_scalar_embed_bwd(const void* dout, const float* track, const int32_t* lengths, float* dw, float* db, int B, int T,
+                          int C, int dtype, void* scratch, size_t scratch_bytes, void* stream);
+
+/* F.normalize over the channels of (rows, C) f32 (model.py:108: style embeddings): y = x / max(||x||, eps); nrm (rows) kept. */
+int ptpp_l2norm_fwd(const float* x, float* y, float* nrm, int rows, int C, float eps, void* stream);
+int ptpp_l2norm_bwd(const float* y, const float* nrm, const float* gy, float* gx, int rows, int C, float eps, void* stream);
+
+/* Running frame count per phone for ptpp_length_regulate_* (utils/model.py:37-47): cum[b, p] = min(sum_{q <= p} dur[b, q],
+ * 2^31 - 1); dur (B, Tp) f32 (integer valued; is_float) or int64. */
+int ptpp_durations_cumsum(const void* dur, int is_float, int32_t* cum, int B, int Tp, void* stream);
+
+/* y[b, t, :] = x[b, t, :] + T(e[b, :]) for EVERY row (model.py:111: the style embedding is added to padded phones too);
+ * ptpp_rows_sum: de[b, :] = sum_t dy[b, t, :] (f32, fixed order). */
+int ptpp_bcast_add_rows(const void* x, const float* e, void* y, int B, int T, int C, int dtype, void* stream);
+int ptpp_rows_sum(const void* dy, float* de, int B, int T, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ *
  * Data-parallel gradient exchange over RCCL / xGMI (reference: DistributedDataParallel set up in
  * trainers/tts.py:52-55 (init_process_group("nccl")) and :117 (DDP(model, device_ids=[rank])), whose
  * bucketed all-reduce averages the gradients over the ranks during backward).

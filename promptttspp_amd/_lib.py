@@ -49,6 +49,15 @@ class ConvArgs(Structure):
     ]
 
 
+class TtsLossArgs(Structure):
+    """Mirror of ``ptpp_tts_loss_args`` (include/ptpp.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("pred", "noise", "flen", "pv", "cf0_tgt", "vuv_tgt", "y_dur", "dur", "plen", "y_sty", "sty_tgt",
+                                        "total", "comps", "nll_dur", "nll_sty", "scratch")] + \
+               [(n, c_int32) for n in ("B", "Tf", "Tp", "M", "G_dur", "G_sty", "D_sty", "dtype")] + \
+               [(n, c_float) for n in ("dec_scale", "lp_min", "ls_min")]
+
+
 class AmpLayerArgs(Structure):
     """Mirror of ``ptpp_amp_layer_args`` (include/ptpp.h)."""
 
@@ -319,6 +328,26 @@ SIGNATURES = {
     "ptpp_refenc_convs_fwd": (I, [POINTER(RefEncConvsFwdArgs), P]),
     "ptpp_refenc_convs_bwd": (I, [POINTER(RefEncConvsBwdArgs), P]),
     "ptpp_encoder_layers_fwd": (I, [POINTER(EncoderLayersFwdArgs), P]),
+    "ptpp_red_defer": (I, [P, SZ]),
+    "ptpp_red_defer_suspend": (I, [I]),
+    "ptpp_red_pending": (I, []),
+    "ptpp_red_flush": (I, [P]),
+    "ptpp_tts_losses_scratch_bytes": (I64, []),
+    "ptpp_tts_losses_fwd": (I, [POINTER(TtsLossArgs), P]),
+    "ptpp_tts_losses_bwd": (I, [POINTER(TtsLossArgs), P, P, P, P, P, P, P]),
+    "ptpp_q_sample_bct": (I, [P, P, P, P, P, I, F, F, F, I, P, I, I, I, I, P]),
+    "ptpp_step_sinusoid": (I, [P, I64, F, I, I, P, P]),
+    "ptpp_mish_fwd": (I, [P, P, I64, P]),
+    "ptpp_mish_bwd": (I, [P, P, P, I64, P]),
+    "ptpp_embed_cl_fwd": (I, [P, P, P, F, I, P, I, I, I, I, I, P]),
+    "ptpp_embed_cl_bwd": (I, [P, P, P, F, I, P, I, I, I, I, I, I, P]),
+    "ptpp_scalar_embed_add": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "ptpp_scalar_embed_bwd": (I, [P, P, P, P, P, I, I, I, I, P, SZ, P]),
+    "ptpp_l2norm_fwd": (I, [P, P, P, I, I, F, P]),
+    "ptpp_l2norm_bwd": (I, [P, P, P, P, I, I, F, P]),
+    "ptpp_durations_cumsum": (I, [P, I, P, I, I, P]),
+    "ptpp_bcast_add_rows": (I, [P, P, P, I, I, I, I, P]),
+    "ptpp_rows_sum": (I, [P, P, I, I, I, I, P]),
     "ptpp_comm_unique_id": (I, [P]),
     "ptpp_comm_init": (I, [I, I, P, POINTER(c_void_p)]),
     "ptpp_comm_destroy": (I, [P]),

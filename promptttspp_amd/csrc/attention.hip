@@ -1242,6 +1242,11 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
   p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - p.drop_thresh16 / 65536.f) : 1.f;
   p.drop_seed = drop_seed;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  RedSlot slot{nullptr, 0};
+  if (variant != VAR_PLAIN) {
+    slot = red_take(scratch, scratch_bytes, 2 * H * dk, st);  // (a private arena slice when the finishing launch is deferred)
+    p.scratch = reinterpret_cast<float*>(slot.ptr);
+  }
   dim3 grid((T_ + 3) / 4, H, B);
   dim3 grid_row((T_ + 4 * ROWS_PER_WAVE - 1) / (4 * ROWS_PER_WAVE), H, B);
   const int Tpad = (T_ + 3) & ~3;
@@ -1280,7 +1285,7 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
   }
       if (dk == 128) ATTN_BWD_MF(128) else ATTN_BWD_MF(64)
 #undef ATTN_BWD_MF
-      if (variant != VAR_PLAIN) red_sum_launch(scratch, 2 * H * dk, du, H * dk, dvb, 1, st);
+      if (variant != VAR_PLAIN) red_finish(slot, 2 * H * dk, du, H * dk, dvb, 1, st);
       PTPP_CHECK_LAUNCH("attention_bwd (mfma)");
       return PTPP_OK;
     }
@@ -1309,7 +1314,7 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
   else if (dtype == PTPP_BF16) { ATTN_BWD(bf16_raw) }
   else PTPP_CHECK_ARG(false, "attention_bwd: bad dtype");
 #undef ATTN_BWD
-  if (variant != VAR_PLAIN) red_sum_launch(scratch, 2 * H * dk, du, H * dk, dvb, 1, st);
+  if (variant != VAR_PLAIN) red_finish(slot, 2 * H * dk, du, H * dk, dvb, 1, st);
   PTPP_CHECK_LAUNCH("attention_bwd");
   return PTPP_OK;
 }

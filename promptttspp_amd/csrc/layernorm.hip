@@ -254,11 +254,15 @@ int ln_bwd_dispatch(const void* dy, const void* xs, const void* z, const float* 
   int64_t nb = (rows + 3) / 4;
   if (nb > 2048) nb = 2048;
   const bool sums = dgamma || dbeta;
-  if (sums && !red_scratch_ok(scratch, scratch_bytes, 2 * C)) {
-    ptpp_set_error("layernorm_bwd: reduction scratch missing or too small");
-    return PTPP_EINVAL;
+  RedSlot slot{nullptr, 0};
+  if (sums) {
+    slot = red_take(scratch, scratch_bytes, 2 * C, st);  // (a private arena slice when the finishing launch is deferred)
+    if (!slot.ptr) {
+      ptpp_set_error("layernorm_bwd: reduction scratch missing or too small");
+      return PTPP_EINVAL;
+    }
   }
-  if (!sums) scratch = nullptr;
+  scratch = slot.ptr;
   const dim3 grid((unsigned)nb), blk(256);
 #define LN_BWD(NV)                                                                                              \
   hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, blk, 0, st, (const T*)dy, (const T*)xs, (const T*)z, gamma, mean, \
@@ -271,7 +275,7 @@ int ln_bwd_dispatch(const void* dy, const void* xs, const void* z, const float* 
     default: ptpp_set_error("layernorm: C=%d > 1024 unsupported", C); return PTPP_ENOTSUP;
   }
 #undef LN_BWD
-  if (sums) red_sum_launch(scratch, 2 * C, dgamma, C, dbeta, 1, st);
+  if (sums) red_finish(slot, 2 * C, dgamma, C, dbeta, 1, st);
   PTPP_CHECK_LAUNCH("layernorm_bwd");
   return PTPP_OK;
 }

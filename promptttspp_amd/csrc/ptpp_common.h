@@ -289,6 +289,29 @@ inline bool red_scratch_ok(const void* scratch, size_t bytes, int KC) {
   return scratch && bytes >= (size_t)PTPP_RED_NREP * KC * sizeof(float);
 }
 
+// ---- deferred finishing of PARAMETER-GRADIENT sums (red.hip; include/ptpp.h "Deferred reduction") ---------------------------
+// A parameter gradient (LayerNorm dgamma / dbeta, the attention position biases, the pitch embedding) is read by nobody before the
+// optimiser / the gradient exchange, so its finishing launch need not follow its producer: with deferral on (ptpp_red_defer) the
+// producer gets a private slice of a per-stream arena instead of the shared scratch, the (slice, destination) pair is queued, and
+// ptpp_red_flush finishes every queued sum of a stream in ONE launch on that stream.  43 finishing launches per training step
+// became 1-2 (profiles/r06_main_order_before.txt).  Sums whose result the next launch reads (BatchNorm statistics) keep
+// red_sum_launch.
+void* ptpp_red_arena_take(size_t bytes, hipStream_t st);  // NULL: deferral off / suspended / arena full -> finish immediately
+void ptpp_red_arena_push(void* slice, int KC, float* dst0, int n0, float* dst1, int accumulate, hipStream_t st);
+struct RedSlot {
+  void* ptr;
+  int deferred;
+};
+inline RedSlot red_take(void* scratch, size_t scratch_bytes, int KC, hipStream_t st) {
+  void* p = ptpp_red_arena_take((size_t)PTPP_RED_NREP * KC * sizeof(float), st);
+  if (p) return RedSlot{p, 1};
+  return RedSlot{red_scratch_ok(scratch, scratch_bytes, KC) ? scratch : nullptr, 0};
+}
+inline void red_finish(const RedSlot& s, int KC, float* dst0, int n0, float* dst1, int accumulate, hipStream_t st) {
+  if (s.deferred) ptpp_red_arena_push(s.ptr, KC, dst0, n0, dst1, accumulate, st);
+  else red_sum_launch(s.ptr, KC, dst0, n0, dst1, accumulate, st);
+}
+
 // One element of the reverse-diffusion update (modules/diffusion.py:283-302: predict_start_from_noise, clamp, q_posterior mean,
 // + sigma * noise) as the reference's UNFUSED f32 operation sequence -- shared by ptpp_ddpm_step and ptpp_sampler_head so that
 // both give the same bits (left to the optimiser, the two kernels contracted different multiply-add pairs).

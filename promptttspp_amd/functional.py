@@ -227,6 +227,13 @@ def enable_direct_grads(on=True, notify=None, async_wgrad=True):
     _direct["async"] = bool(on) and bool(async_wgrad) and not os.environ.get("PTPP_NO_ASYNC_WGRAD")
     _direct["uses"].clear()
     sync_wgrad_stream()  # also releases the tensors held for the side stream
+    # the finishing launches of the parameter-gradient column sums wait for ops.red_flush() (FlatGradReducer.finish, before a
+    # bucket's collective, FusedAdamW.step): include/ptpp.h "Deferred reduction"; PTPP_NO_DEFERRED_SUMS=1 finishes each at once
+    if torch.cuda.is_available():
+        if on and not os.environ.get("PTPP_NO_DEFERRED_SUMS"):
+            ops.red_defer_enable(torch.device("cuda", torch.cuda.current_device()))
+        else:
+            ops.red_defer_disable()
     if _direct["async"]:
         create_side_stream()
 
@@ -699,7 +706,8 @@ class ConvLnStackFn(Function):
         a.conv_act, a.conv_mask, a.ln_res = ops._ACT[cfg.conv_act], int(cfg.conv_mask), int(cfg.ln_res)
         a.act_in, a.out_mask, a.dtype = ops._ACT[cfg.act_in], cfg.out_mask, ops.dtype_code(dt)
         a.batched_wgrad = int(BATCHED_WGRAD)
-        _lib.check(_lib.load().ptpp_conv_ln_stack_bwd(ctypes.byref(a), main_h), "ptpp_conv_ln_stack_bwd")
+        with ops.red_immediate(not ctx.direct):
+            _lib.check(_lib.load().ptpp_conv_ln_stack_bwd(ctypes.byref(a), main_h), "ptpp_conv_ln_stack_bwd")
         if side_h is not None:
             d["keep"].extend((x, x_all, gz_all))
         ctx.slabs = None
@@ -864,7 +872,10 @@ class LengthRegulateFn(Function):
 def length_regulate(x, durations, Tf):
     """x: (B, Tp, C); durations: (B, Tp) integer-valued (float or int) frames per
     phone -> (B, Tf, C), frame f copying its phone (rows past the total are 0)."""
-    cum = torch.cumsum(durations.to(torch.int64), dim=1).clamp_(max=2**31 - 1).to(torch.int32).contiguous()
+    if durations.is_cuda:
+        cum = ops.durations_cumsum(durations)
+    else:
+        cum = torch.cumsum(durations.to(torch.int64), dim=1).clamp_(max=2**31 - 1).to(torch.int32).contiguous()
     return LengthRegulateFn.apply(x, cum, int(Tf))
 
 
@@ -883,6 +894,166 @@ class PosEncFn(Function):
 
 def posenc(x, pe, scale, drop_p=0.0):
     return PosEncFn.apply(x, pe, scale, drop_p)
+
+
+# ----------------------------------------------------------------------------
+# Training-step glue as single launches (csrc/glue.hip)
+# ----------------------------------------------------------------------------
+class TtsLossesFn(Function):
+    """Every loss of the training step (reference models/prompttts_mdn_v2_final/model.py:126-183) as ONE launch forward and ONE
+    backward: masked L1 of the decoder, L1 of the log-F0 / V-UV tracks, the two mixture NLLs (log-softmax of the raw MDN head
+    outputs included) and their weighted sum.  Returns (total (), comps (7,): dec, dur, cf0, vuv, style, n_frames, n_phones)."""
+
+    @staticmethod
+    def forward(ctx, pred, pv, y_dur, y_sty, noise, flen, cf0_t, vuv_t, dur, plen, sty_t, cfg):
+        pred, pv, y_dur, y_sty = pred.contiguous(), pv.contiguous(), y_dur.contiguous(), y_sty.contiguous()
+        total, comps, nll_dur, nll_sty = ops.tts_losses_fwd(pred, noise, flen, pv, cf0_t, vuv_t, y_dur, dur, plen, y_sty, sty_t,
+                                                            cfg.G_dur, cfg.G_sty, cfg.dec_scale)
+        ctx.cfg = cfg
+        ctx.save_for_backward(pred, noise, flen, pv, cf0_t, vuv_t, y_dur, dur, plen, y_sty, sty_t, comps, nll_dur, nll_sty)
+        return total, comps
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_total, g_comps):
+        cfg = ctx.cfg
+        gt = g_total.contiguous().float() if g_total is not None else None
+        gc = g_comps.contiguous().float() if g_comps is not None else None
+        dpred, dpv, dy_dur, dy_sty = ops.tts_losses_bwd(ctx.saved_tensors, gt, gc, cfg.G_dur, cfg.G_sty, cfg.dec_scale)
+        return dpred, dpv, dy_dur, dy_sty, None, None, None, None, None, None, None, None
+
+
+def tts_losses(pred, pv, y_dur, y_sty, noise, flen, cf0_t, vuv_t, dur, plen, sty_t, G_dur, G_sty, dec_scale):
+    cfg = SimpleNamespace(G_dur=G_dur, G_sty=G_sty, dec_scale=float(dec_scale))
+    return TtsLossesFn.apply(pred, pv, y_dur, y_sty, noise, flen, cf0_t, vuv_t, dur, plen, sty_t, cfg)
+
+
+class MishFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.mish_fwd(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        return ops.mish_bwd(ctx.saved_tensors[0], gy)
+
+
+def mish(x):
+    """x * tanh(softplus(x)) (modules/denoiser.py:23-26): one launch each way for f32 device tensors."""
+    if x.is_cuda and x.dtype == torch.float32:
+        return MishFn.apply(x)
+    return x * torch.tanh(torch.nn.functional.softplus(x))
+
+
+class EmbedClFn(Function):
+    """PhonemeEmbedding (layers/embedding.py:21-36): lookup, optional sqrt(C) scale, phone mask, cast -- one launch; the table
+    gradient by one block per vocabulary entry in row order (bit-reproducible), straight into ``weight.grad`` when the trainer
+    laid the gradients out flat."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, lengths, scale, dtype, padding_idx):
+        ids = ids.contiguous()
+        ctx.ids, ctx.lengths, ctx.scale, ctx.padding_idx = ids, lengths, scale, padding_idx
+        ctx.weight = weight
+        ctx.direct = ctx.needs_input_grad[1] and _sink(weight) is not None
+        if ctx.direct:
+            _use(weight)
+        return ops.embed_cl_fwd(ids, _f32c(weight), lengths, scale, dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        w = ctx.weight
+        if ctx.direct:
+            ops.embed_cl_bwd(ctx.ids, dout, ctx.lengths, ctx.scale, w.grad, ctx.padding_idx)
+            _done(w)
+            return None, None, None, None, None, None
+        dt = torch.zeros(w.shape, device=dout.device, dtype=torch.float32)
+        ops.embed_cl_bwd(ctx.ids, dout, ctx.lengths, ctx.scale, dt, ctx.padding_idx)
+        return None, dt, None, None, None, None
+
+
+def embed_cl(ids, weight, lengths, scale, dtype, padding_idx):
+    return EmbedClFn.apply(ids, weight, lengths, scale, dtype, padding_idx)
+
+
+class ScalarEmbedAddFn(Function):
+    """x + Conv1d(1 -> C, k = 1)(track) * mask (modules/variance_adaptor.py:139-146): one launch forward; backward = the
+    identity for x plus one column-sum launch for (dw, db) whose finishing step is deferrable."""
+
+    @staticmethod
+    def forward(ctx, x, track, weight, bias, lengths):
+        x, track = x.contiguous(), track.contiguous().float()
+        ctx.track, ctx.lengths, ctx.params = track, lengths, (weight, bias)
+        ctx.direct = _sink(weight) is not None and _sink(bias) is not None
+        if ctx.direct:
+            _use(weight)
+            _use(bias)
+        return ops.scalar_embed_add(x, track, _f32c(weight).reshape(-1), _f32c(bias), lengths)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        w, b = ctx.params
+        dout = dout.contiguous()
+        if ctx.direct:
+            ops.scalar_embed_bwd(dout, ctx.track, ctx.lengths, w.grad.view(-1), b.grad)
+            _done(w)
+            _done(b)
+            return dout, None, None, None, None
+        dw = torch.zeros(w.numel(), device=dout.device, dtype=torch.float32)
+        db = torch.zeros_like(dw)
+        with ops.red_immediate():
+            ops.scalar_embed_bwd(dout, ctx.track, ctx.lengths, dw, db)
+        return dout, None, dw.view_as(w), db, None
+
+
+def scalar_embed_add(x, track, emb, lengths):
+    """``emb``: nn.Conv1d(1, C, 1).  The track is data (teacher forcing) or a detached prediction: no gradient flows into it
+    here -- callers whose track needs one use the tensor expression."""
+    return ScalarEmbedAddFn.apply(x, track, emb.weight, emb.bias, lengths)
+
+
+class L2NormFn(Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        y, n = ops.l2norm_fwd(x.contiguous(), eps)
+        ctx.eps = eps
+        ctx.save_for_backward(y, n)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        y, n = ctx.saved_tensors
+        return ops.l2norm_bwd(y, n, gy, ctx.eps), None
+
+
+def l2_normalize_channels(e, eps=1e-12):
+    """F.normalize(e, dim=1) of a (B, C, 1) f32 device tensor as one launch each way."""
+    if e.is_cuda and e.dtype == torch.float32 and e.dim() == 3 and e.shape[2] == 1:
+        return L2NormFn.apply(e.reshape(e.shape[0], e.shape[1]), eps).unsqueeze(-1)
+    return torch.nn.functional.normalize(e, dim=1, eps=eps)
+
+
+class BcastAddRowsFn(Function):
+    @staticmethod
+    def forward(ctx, x, e):
+        ctx.need_e = ctx.needs_input_grad[1]
+        return ops.bcast_add_rows(x.contiguous(), e.contiguous())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return dy, (ops.rows_sum(dy) if ctx.need_e else None)
+
+
+def bcast_add_rows(x, e):
+    """x (B, T, C) + e (B, C) f32 on every row (model.py:111), e rounded to x's dtype first like ``e.to(x.dtype)``."""
+    return BcastAddRowsFn.apply(x, e)
 
 
 # ----------------------------------------------------------------------------

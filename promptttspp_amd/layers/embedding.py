@@ -1,6 +1,7 @@
 """Phoneme embedding (reference: promptttspp/layers/embedding.py:21-36)."""
 import math
 
+import torch
 import torch.nn as nn
 
 
@@ -13,9 +14,15 @@ class PhonemeEmbedding(nn.Module):
         self.scale = math.sqrt(channels)
         self.do_scale = do_scale
 
-    def forward_cl(self, ids, mask_bt1, dtype):
-        """ids (B,T) int64, mask (B,T,1) -> (B,T,C) channels-last in `dtype`.
-        A 90-row table lookup: left to torch's gather (not on the roofline)."""
+    def forward_cl(self, ids, mask_bt1, dtype, lengths=None):
+        """ids (B,T) int64, mask (B,T,1) (or, on the GPU, int32 ``lengths`` (B,)) -> (B,T,C) channels-last in `dtype`:
+        one launch each way on the GPU (ptpp_embed_cl_fwd / _bwd), torch's gather on the CPU."""
+        if lengths is not None and ids.is_cuda and ids.dtype == torch.int64 and self.emb.weight.shape[1] % 4 == 0:
+            from .. import functional as PF
+
+            return PF.embed_cl(ids, self.emb.weight, lengths, self.scale if self.do_scale else None, dtype, self.emb.padding_idx)
+        if mask_bt1 is None:
+            mask_bt1 = (torch.arange(ids.shape[1], device=ids.device)[None, :] < lengths[:, None]).unsqueeze(-1).float()
         x = self.emb(ids)
         if self.do_scale:
             x = x * self.scale

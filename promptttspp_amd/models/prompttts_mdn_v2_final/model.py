@@ -25,7 +25,7 @@ from ...config import compute_dtype
 from ...modules.diffusion import GaussianDiffusion
 from ...modules.esp import ConformerEncoder
 from ...modules.transformer import Transformer
-from ...modules.mdn import mdn_get_most_probable_sigma_and_mu, mdn_loss, mdn_sample_sigma_and_mu
+from ...modules.mdn import MDNLayer, mdn_get_most_probable_sigma_and_mu, mdn_loss, mdn_sample_sigma_and_mu
 from ...utils.model import sequence_mask
 
 
@@ -34,6 +34,7 @@ from ...utils.model import sequence_mask
 # test_direct_gradient_accumulation_equals_autograd produced a wrong duration-predictor weight gradient (an unordered
 # dependency that is not found yet; modes 0 / 1 / 2: 6 of 6 clean), so it is never the default
 BRANCH_STREAMS = os.environ.get("PTPP_BRANCH_STREAMS", "2")
+FUSED_GLUE = not os.environ.get("PTPP_NO_FUSED_GLUE")  # (tests compare the fused training forward with the general one)
 JOIN_PROBE = None  # tools/diag_joins.py sets a list: (name, event on the waiting stream before the wait, event at the branch's end)
 
 
@@ -117,11 +118,87 @@ class PromptTTSMDNDurCFG(nn.Module):
                          lengths=flen, out_mask=True)
 
     def _norm_style(self, e):
-        return F.normalize(e, dim=1) if self.norm_style_emb else e
+        if not self.norm_style_emb:
+            return e
+        return PF.l2_normalize_channels(e) if e.is_cuda else F.normalize(e, dim=1)
+
+    def _fused_glue_ok(self, dev):
+        """The reference's training configuration (prompttts_mdn_v2_wo_erg_final*.yaml) on the GPU: diffusion decoder, both MDN
+        heads dimension-wise, no energy branch -- its masks, losses and small tensor chains run as single launches
+        (``_forward_fused``).  Anything else takes the general path below."""
+        va = self.variance_adaptor
+        dp = va.duration_predictor
+        return (FUSED_GLUE and dev.type == "cuda" and not self.conformer_decoder and self.style_mdn is not None
+                and self.style_mdn.dim_wise and va.energy_predictor is None and va.energy_emb is None
+                and isinstance(getattr(dp, "out_layer", None), MDNLayer) and dp.out_layer.dim_wise and dp.out_layer.out_dim == 1
+                and getattr(va.pitch_predictor.out_layer, "out_channels", 0) == 2
+                and compute_dtype() in (torch.float32, torch.bfloat16) and isinstance(self.encoder, ConformerEncoder))
+
+    def _forward_fused(self, batch):
+        """``forward`` for the configuration of ``_fused_glue_ok``: the same graph with the glue as single launches -- phoneme
+        embedding + mask (1), style broadcast add (1), pitch embedding (1), q_sample on the (B, M, T) mel (1), step embedding
+        (sinusoid 1 + Mish 1), and ALL losses with both MDN log-softmaxes as one launch forward and one backward
+        (functional.TtsLossesFn; reference model.py:126-183).  No mask tensors are built."""
+        (phoneme, duration, phone_lengths, mel, log_cf0, vuv, energy, frame_lengths, prompt) = batch
+        dev = phoneme.device
+        dt = compute_dtype()
+        branches = BRANCH_STREAMS and self.training
+        if branches:
+            import ctypes
+
+            PF._direct["main"] = torch.cuda.current_stream()
+            PF._direct["main_h"] = ctypes.c_void_p(PF._direct["main"].cuda_stream)
+        sa = _branch_stream(dev, 1) if (branches and BRANCH_STREAMS in ("2", "3")) else None
+        if sa is not None:
+            sa.wait_stream(torch.cuda.current_stream())
+            with ops.unpinned(), torch.cuda.stream(sa):
+                style_emb = self._norm_style(self.reference_encoder(mel, frame_lengths))  # (B,C,1) f32
+        plen = phone_lengths.to(device=dev, dtype=torch.int32)
+        flen = frame_lengths.to(device=dev, dtype=torch.int32)
+        x = self.phoneme_emb.forward_cl(phoneme, None, dt, lengths=plen)
+        x = self.encoder.forward_cl(x, plen, None)
+        Tf = mel.shape[-1]
+        if sa is not None:
+            _probe("reference encoder -> x + style_emb", torch.cuda.current_stream(), sa)
+            torch.cuda.current_stream().wait_stream(sa)
+            style_emb.record_stream(torch.cuda.current_stream())
+        else:
+            style_emb = self._norm_style(self.reference_encoder(mel, frame_lengths))
+        bs = _branch_stream(dev, 0) if branches else None
+        if bs is not None:
+            bs.wait_stream(torch.cuda.current_stream())
+            with ops.unpinned(), torch.cuda.stream(bs):
+                prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
+                y_sty = self.style_mdn.raw(prompt_emb.transpose(-1, -2))
+        else:
+            prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
+            y_sty = self.style_mdn.raw(prompt_emb.transpose(-1, -2))
+        x = PF.bcast_add_rows(x, style_emb.float().reshape(style_emb.shape[0], -1))  # every phone, padded ones too (model.py:111)
+        vb = (bs, sa) if (branches and BRANCH_STREAMS == "3") else None
+        h, y_dur, pv, _, _ = self.variance_adaptor.forward_cl(x, plen, flen, None, duration.squeeze(1), log_cf0.squeeze(1), None,
+                                                              branch_streams=vb, raw=True, Tf=Tf)
+        noise, pred = self.decoder.forward_bct(h, mel, flen)
+        if bs is not None:  # join: the losses read the branches' outputs
+            main = torch.cuda.current_stream()
+            _probe("prompt branch -> losses", main, bs)
+            main.wait_stream(bs)
+            y_sty.record_stream(main)
+            if vb is not None:
+                main.wait_stream(sa)
+                y_dur.record_stream(main)
+                pv.record_stream(main)
+        sm, dl = self.style_mdn, self.variance_adaptor.duration_predictor.out_layer
+        total, comps = PF.tts_losses(pred, pv, y_dur, y_sty, noise, flen, log_cf0.squeeze(1).float().contiguous(),
+                                     vuv.squeeze(1).float().contiguous(), duration.squeeze(1).float().contiguous(), plen,
+                                     style_emb.detach().float().reshape(style_emb.shape[0], -1), dl.num_gaussians, sm.num_gaussians,
+                                     self.loss_dec_scale)
+        return dict(loss=total, dec=comps[0], dur=comps[1], cf0=comps[2], vuv=comps[3], style=comps[4])
 
     def forward(self, batch):
         (phoneme, duration, phone_lengths, mel, log_cf0, vuv, energy, frame_lengths, prompt) = batch
         dev = phoneme.device
+        if self._fused_glue_ok(dev):
+            return self._forward_fused(batch)
         dt = compute_dtype()
         branches = BRANCH_STREAMS and self.training and dev.type == "cuda"
         if branches:

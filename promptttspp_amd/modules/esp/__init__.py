@@ -335,7 +335,8 @@ class ConformerBlockFn(torch.autograd.Function):
         a.B, a.T, a.C, a.F, a.H, a.L = B, T, C, F_, H, L
         a.ks_ffn, a.ks_dw, a.variant = P[10].shape[2], P[33].shape[-1], _VARIANT[cfg.variant]
         a.bn_train, a.dtype = int(cfg.training), dcode
-        _lib.check(lib.ptpp_conformer_block_bwd(ctypes.byref(a), main_h), "ptpp_conformer_block_bwd")
+        with ops.red_immediate(not all(ctx.direct[i] for i in (*range(10), 27, 28))):  # LayerNorm / position-bias targets
+            _lib.check(lib.ptpp_conformer_block_bwd(ctypes.byref(a), main_h), "ptpp_conformer_block_bwd")
         if side_h is not None:  # the side stream still reads these: held until the streams are joined
             d["keep"].extend((x, pos, slab, scratch))
         ctx.tensors = None

@@ -25,14 +25,19 @@ class MDNLayer(nn.Module):
         self.log_sigma = nn.Linear(in_dim, out_dim * num_gaussians)
         self.mu = nn.Linear(in_dim, out_dim * num_gaussians)
 
-    def forward(self, minibatch):
-        """(B, T, D_in) -> log_pi (B,T,G[,D]), log_sigma (B,T,G,D), mu (B,T,G,D); f32."""
+    def raw(self, minibatch):
+        """(B, T, D_in) -> the three heads' outputs side by side, (B, T, n_pi + 2 G D) f32: [pi logits | log_sigma | mu].
+        The fused training loss (functional.tts_losses) applies the log-softmax itself."""
         x = minibatch.float().contiguous()
-        B, T, _ = x.shape
-        G, D = self.num_gaussians, self.out_dim
         # the three heads read the same input: ONE GEMM over their concatenated rows (the packed operand is
         # cached on the three Parameters, their gradients go straight into each layer's own buffer)
-        y = PF.linear_fused(x, [self.log_pi, self.log_sigma, self.mu])
+        return PF.linear_fused(x, [self.log_pi, self.log_sigma, self.mu])
+
+    def forward(self, minibatch):
+        """(B, T, D_in) -> log_pi (B,T,G[,D]), log_sigma (B,T,G,D), mu (B,T,G,D); f32."""
+        B, T, _ = minibatch.shape
+        G, D = self.num_gaussians, self.out_dim
+        y = self.raw(minibatch)
         n_pi = self.log_pi.weight.shape[0]
         log_pi, log_sigma, mu = y[..., :n_pi], y[..., n_pi : n_pi + G * D], y[..., n_pi + G * D :]
         if self.dim_wise:

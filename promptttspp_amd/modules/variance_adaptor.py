@@ -60,12 +60,13 @@ class Predictor(nn.Module):
         self.out_layer = nn.Conv1d(channels, out_channels, 1)
         self.detach = detach
 
-    def cl(self, x, lengths):
-        """(B,T,C) -> (B,T,out_channels) f32, masked."""
+    def cl(self, x, lengths, as_float=True):
+        """(B,T,C) -> (B,T,out_channels) f32 (``as_float=False``: in the compute dtype, for the fused loss), masked."""
         if self.detach:
             x = x.detach()
         x = _predictor_layers(self.layers, x, lengths, self.training)
-        return PF.conv1d(x, self.out_layer.weight, self.out_layer.bias, lengths=lengths, out_mask=True).float()
+        y = PF.conv1d(x, self.out_layer.weight, self.out_layer.bias, lengths=lengths, out_mask=True)
+        return y.float() if as_float else y
 
     def forward(self, x, mask):
         """Reference signature: x (B,C,T), mask (B,1,T) -> (B,out,T)."""
@@ -84,11 +85,12 @@ class MDNPredictor(nn.Module):
         self.out_layer = MDNLayer(channels, out_channels, num_gaussians, dim_wise)
         self.detach, self.disable_amp = detach, disable_amp
 
-    def cl(self, x, lengths):
+    def cl(self, x, lengths, raw=False):
         if self.detach:
             x = x.detach()
         x = _predictor_layers(self.layers, x, lengths, self.training)
-        return self.out_layer(x)  # MDN island: float32 regardless of the compute dtype
+        # MDN island: float32 regardless of the compute dtype (``raw``: the heads' outputs before the log-softmax / reshape)
+        return self.out_layer.raw(x) if raw else self.out_layer(x)
 
     def infer_cl(self, x, lengths):
         """log-normal mean of the most probable component -> (B, T) log-duration."""
@@ -120,7 +122,16 @@ class VarianceAdaptor(nn.Module):
         w = emb.weight.reshape(1, 1, -1)
         return ((v.unsqueeze(-1) * w + emb.bias.reshape(1, 1, -1)) * fmask_bt1).to(dtype)
 
-    def _frames(self, x, durations, flen, Tf, fmask_bt1, log_cf0_in=None, energy_in=None, pitch_stream=None):
+    def _add_embedding(self, h, emb, track, flen, fmask_bt1):
+        """h + emb(track) * mask: one launch on the GPU when the track needs no gradient (teacher forcing / inference)."""
+        if (h.is_cuda and not (track.requires_grad and torch.is_grad_enabled()) and h.shape[-1] % 256 == 0 and h.shape[-1] <= 1024
+                and emb.bias is not None):
+            return PF.scalar_embed_add(h, track, emb, flen)
+        if fmask_bt1 is None:
+            fmask_bt1 = (torch.arange(h.shape[1], device=h.device)[None, :] < flen[:, None]).unsqueeze(-1).float()
+        return h + self._embed_scalar(emb, track, fmask_bt1, h.dtype)
+
+    def _frames(self, x, durations, flen, Tf, fmask_bt1, log_cf0_in=None, energy_in=None, pitch_stream=None, raw_pitch=False):
         h = PF.length_regulate(x, durations, Tf)
         if self.frame_prior_network is not None:
             h = self.frame_prior_network.forward_cl(h, flen)
@@ -129,34 +140,39 @@ class VarianceAdaptor(nn.Module):
             # issued (and by autograd differentiated) on its own stream beside the decoder (model.py, PTPP_BRANCH_STREAMS)
             pitch_stream.wait_stream(torch.cuda.current_stream())
             with ops.unpinned(), torch.cuda.stream(pitch_stream):
-                pv = self.pitch_predictor.cl(h, flen)
+                pv = self.pitch_predictor.cl(h, flen, as_float=not raw_pitch)
         else:
-            pv = self.pitch_predictor.cl(h, flen)  # (B,Tf,2) f32
+            pv = self.pitch_predictor.cl(h, flen, as_float=not raw_pitch)  # (B,Tf,2) f32 (raw_pitch: compute dtype)
+        if raw_pitch:  # (training with the fused loss: the caller reads the (B,Tf,2) tensor as it is; the embedding is teacher forced)
+            assert log_cf0_in is not None and self.energy_predictor is None
+            return self._add_embedding(h, self.pitch_emb, log_cf0_in, flen, fmask_bt1), pv, None, None
         log_cf0, vuv = pv[..., 0], pv[..., 1]
         # both predictors read the frame-prior output; the embeddings are added together afterwards
         # (variance_adaptor.py:139-146: energy_predictor(x) runs BEFORE x = x + pitch_emb + energy_emb)
         energy = None
         if self.energy_predictor is not None:
             energy = self.energy_predictor.cl(h, flen)[..., 0]
-        h = h + self._embed_scalar(self.pitch_emb, log_cf0 if log_cf0_in is None else log_cf0_in, fmask_bt1, h.dtype)
+        h = self._add_embedding(h, self.pitch_emb, log_cf0 if log_cf0_in is None else log_cf0_in, flen, fmask_bt1)
         if self.energy_predictor is not None:
-            h = h + self._embed_scalar(self.energy_emb, energy if energy_in is None else energy_in, fmask_bt1, h.dtype)
+            h = self._add_embedding(h, self.energy_emb, energy if energy_in is None else energy_in, flen, fmask_bt1)
         return h, log_cf0, vuv, energy
 
-    def forward_cl(self, x, plen, flen, fmask_bt1, duration, log_cf0, energy=None, branch_streams=None):
+    def forward_cl(self, x, plen, flen, fmask_bt1, duration, log_cf0, energy=None, branch_streams=None, raw=False, Tf=None):
         """Training forward.  x (B,Tp,C); duration (B,Tp) frames (integer valued);
-        log_cf0 (B,Tf).  Returns (h (B,Tf,C), mdn_out, log_cf0_pred, vuv_pred, energy_pred)."""
+        log_cf0 (B,Tf).  Returns (h (B,Tf,C), mdn_out, log_cf0_pred, vuv_pred, energy_pred).
+        ``raw`` (the fused-loss path of the model): mdn_out is the duration head's raw output (B,Tp,3G), the second pitch
+        slot holds the (B,Tf,2) pitch / V-UV prediction in the compute dtype, and ``fmask_bt1`` may be None (``Tf`` given)."""
         sd, sp = branch_streams if branch_streams is not None else (None, None)
         if sd is not None and self.duration_predictor.detach:
             # the duration predictor reads a DETACHED copy of x and feeds only loss_dur: another independent branch
             sd.wait_stream(torch.cuda.current_stream())
             with ops.unpinned(), torch.cuda.stream(sd):
-                dur_out = self.duration_predictor.cl(x, plen)
+                dur_out = self.duration_predictor.cl(x, plen, raw=raw)
         else:
-            dur_out = self.duration_predictor.cl(x, plen)
+            dur_out = self.duration_predictor.cl(x, plen, raw=raw)
         teacher_forced = log_cf0 is not None and self.energy_predictor is None
-        h, cf0_p, vuv_p, en_p = self._frames(x, duration, flen, fmask_bt1.shape[1], fmask_bt1, log_cf0, energy,
-                                             pitch_stream=sp if teacher_forced else None)
+        h, cf0_p, vuv_p, en_p = self._frames(x, duration, flen, fmask_bt1.shape[1] if Tf is None else Tf, fmask_bt1, log_cf0, energy,
+                                             pitch_stream=sp if teacher_forced else None, raw_pitch=raw)
         return h, dur_out, cf0_p, vuv_p, en_p
 
     def durations_cl(self, x, plen, pmask_bt):

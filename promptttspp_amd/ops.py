@@ -457,13 +457,14 @@ def layernorm_bwd(dy, xsum, gamma, mean, rstd, lengths=None, out_mask=False, z=N
     dbeta = _acc_target(dbeta_out, C) if dbeta_out is not None else \
         torch.zeros((C,), device=dy.device, dtype=torch.float32)
     lengths = i32(lengths, dy.device)
-    check(
-        _lib.load().ptpp_layernorm_bwd(_ptr(dy), _ptr(xsum), _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dsum),
-                                       _ptr(dz), _ptr(dgamma), _ptr(dbeta), _ptr(lengths), B, T, C, int(bool(out_mask)),
-                                       _ACT[act_in], float(drop_in[0]), int(drop_in[1]), float(drop_out[0]),
-                                       int(drop_out[1]), dtype_code(dy.dtype), *reduction_scratch(dy.device), _stream()),
-        "ptpp_layernorm_bwd",
-    )
+    with red_immediate(dgamma_out is None or dbeta_out is None):  # (fresh buffers are read by autograd right away)
+        check(
+            _lib.load().ptpp_layernorm_bwd(_ptr(dy), _ptr(xsum), _ptr(z), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dsum),
+                                           _ptr(dz), _ptr(dgamma), _ptr(dbeta), _ptr(lengths), B, T, C, int(bool(out_mask)),
+                                           _ACT[act_in], float(drop_in[0]), int(drop_in[1]), float(drop_out[0]),
+                                           int(drop_out[1]), dtype_code(dy.dtype), *reduction_scratch(dy.device), _stream()),
+            "ptpp_layernorm_bwd",
+        )
     return dsum, dz, dgamma, dbeta
 
 
@@ -506,15 +507,16 @@ def attention_bwd(q, k, v, pos, bias_u, bias_v, probs, dctx, lengths, heads, var
         dvb = _acc_target(dvb_out, C) if dvb_out is not None else \
             torch.zeros((C,), device=q.device, dtype=torch.float32)
     lengths = i32(lengths, q.device)
-    check(
-        _lib.load().ptpp_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(pos), _ptr(bias_u), _ptr(bias_v), _ptr(probs),
-                                       _ptr(dctx), _ptr(dS), _ptr(dq), _ptr(dk_), _ptr(dv), _ptr(dpos), _ptr(du),
-                                       _ptr(dvb), _ptr(lengths), B, T, heads, dkh, _ld(q),
-                                       pos.stride(0) if pos is not None else 0, C, _ld(dq), _VARIANT[variant],
-                                       float(drop_p), int(drop_seed), dtype_code(q.dtype),
-                                       *reduction_scratch(q.device), _stream()),
-        "ptpp_attention_bwd",
-    )
+    with red_immediate(du_out is None or dvb_out is None):
+        check(
+            _lib.load().ptpp_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(pos), _ptr(bias_u), _ptr(bias_v), _ptr(probs),
+                                           _ptr(dctx), _ptr(dS), _ptr(dq), _ptr(dk_), _ptr(dv), _ptr(dpos), _ptr(du),
+                                           _ptr(dvb), _ptr(lengths), B, T, heads, dkh, _ld(q),
+                                           pos.stride(0) if pos is not None else 0, C, _ld(dq), _VARIANT[variant],
+                                           float(drop_p), int(drop_seed), dtype_code(q.dtype),
+                                           *reduction_scratch(q.device), _stream()),
+            "ptpp_attention_bwd",
+        )
     return dpos, du, dvb
 
 
@@ -1091,3 +1093,258 @@ def btc_to_bct(x):
     y = torch.empty((B, C, T), device=x.device, dtype=torch.float32)
     check(_lib.load().ptpp_btc_to_bct(_ptr(x), _ptr(y), B, T, C, dtype_code(x.dtype), _stream()), "ptpp_btc_to_bct")
     return y
+
+
+# ----------------------------------------------------------------------------
+# Deferred finishing of parameter-gradient sums (include/ptpp.h "Deferred reduction")
+# ----------------------------------------------------------------------------
+_red_arena = {"t": None}
+
+
+def red_defer_enable(device, mbytes=32):
+    """Queue the finishing launches of the parameter-gradient column sums (LayerNorm dgamma / dbeta, attention position
+    biases, scalar embeddings) until ``red_flush()``.  Only for callers whose destinations stay valid and unread until
+    then (the trainer's flat gradient buffer: functional.enable_direct_grads)."""
+    if _red_arena["t"] is None:
+        t = torch.zeros(int(mbytes) << 20, device=device, dtype=torch.uint8)
+        check(_lib.load().ptpp_red_defer(t.data_ptr(), t.numel()), "ptpp_red_defer")
+        _red_arena["t"] = t
+
+
+def red_defer_disable():
+    if _red_arena["t"] is not None:
+        red_flush()
+        check(_lib.load().ptpp_red_defer(None, 0), "ptpp_red_defer")
+        _red_arena["t"] = None
+
+
+def red_deferred():
+    return _red_arena["t"] is not None
+
+
+def red_flush():
+    """Finish every queued sum (one launch per producing stream) and order the current stream behind them."""
+    if _red_arena["t"] is not None:
+        check(_lib.load().ptpp_red_flush(_stream()), "ptpp_red_flush")
+
+
+class red_immediate:
+    """Calls inside finish their column sums at once (their destinations are read right away, e.g. tensors handed back to
+    autograd)."""
+
+    def __init__(self, on=True):
+        self.on = on and _red_arena["t"] is not None
+
+    def __enter__(self):
+        if self.on:
+            _lib.load().ptpp_red_defer_suspend(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lib.load().ptpp_red_defer_suspend(-1)
+        return False
+
+
+# ----------------------------------------------------------------------------
+# Training-step glue (csrc/glue.hip)
+# ----------------------------------------------------------------------------
+_loss_scratch = {}
+
+
+def _loss_scratch_of(device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
+    w = _loss_scratch.get(key)
+    if w is None:
+        w = _loss_scratch[key] = torch.zeros(int(_lib.load().ptpp_tts_losses_scratch_bytes()), device=device, dtype=torch.uint8)
+    return w
+
+
+def _tts_loss_args(pred, noise, flen, pv, cf0_t, vuv_t, y_dur, dur, plen, y_sty, sty_t, G_dur, G_sty, dec_scale, lp_min, ls_min,
+                   total, comps, nll_dur, nll_sty):
+    a = _lib.TtsLossArgs()
+    B, Tf, M = pred.shape
+    Tp = y_dur.shape[1]
+    D = sty_t.shape[-1]
+    for t in (pred, noise, pv, cf0_t, vuv_t, y_dur, dur, y_sty, sty_t):
+        if not t.is_contiguous():
+            raise ValueError("tts_losses: contiguous tensors expected")
+    if not (noise.dtype == cf0_t.dtype == vuv_t.dtype == y_dur.dtype == dur.dtype == y_sty.dtype == sty_t.dtype == torch.float32):
+        raise TypeError("tts_losses: float32 targets / head outputs expected")
+    if pv.dtype != pred.dtype or pv.shape != (B, Tf, 2) or noise.shape != pred.shape or cf0_t.shape != (B, Tf) or vuv_t.shape != (B, Tf):
+        raise ValueError("tts_losses: frame-level shapes do not match")
+    if y_dur.shape != (B, Tp, 3 * G_dur) or dur.shape != (B, Tp) or y_sty.numel() != B * 3 * G_sty * D or sty_t.numel() != B * D:
+        raise ValueError("tts_losses: phone-level / style shapes do not match")
+    if flen.dtype != torch.int32 or plen.dtype != torch.int32 or flen.numel() != B or plen.numel() != B:
+        raise ValueError("tts_losses: int32 lengths (B) expected")
+    a.pred, a.noise, a.flen, a.pv = pred.data_ptr(), noise.data_ptr(), flen.data_ptr(), pv.data_ptr()
+    a.cf0_tgt, a.vuv_tgt, a.y_dur, a.dur, a.plen = cf0_t.data_ptr(), vuv_t.data_ptr(), y_dur.data_ptr(), dur.data_ptr(), plen.data_ptr()
+    a.y_sty, a.sty_tgt = y_sty.data_ptr(), sty_t.data_ptr()
+    a.total, a.comps, a.nll_dur, a.nll_sty = total.data_ptr(), comps.data_ptr(), nll_dur.data_ptr(), nll_sty.data_ptr()
+    a.scratch = _loss_scratch_of(pred.device).data_ptr()
+    a.B, a.Tf, a.Tp, a.M, a.G_dur, a.G_sty, a.D_sty, a.dtype = B, Tf, Tp, M, G_dur, G_sty, D, dtype_code(pred.dtype)
+    a.dec_scale, a.lp_min, a.ls_min = float(dec_scale), float(lp_min), float(ls_min)
+    return a
+
+
+def tts_losses_fwd(pred, noise, flen, pv, cf0_t, vuv_t, y_dur, dur, plen, y_sty, sty_t, G_dur, G_sty, dec_scale, lp_min=-7.0,
+                   ls_min=-7.0):
+    """All losses of the training step in one launch (ptpp_tts_losses_fwd).  Returns (total (), comps (7,), nll_dur, nll_sty)."""
+    _need_gpu(pred)
+    dev = pred.device
+    total = torch.empty((), device=dev, dtype=torch.float32)
+    comps = torch.empty((7,), device=dev, dtype=torch.float32)
+    nll_dur = torch.empty(dur.shape, device=dev, dtype=torch.float32)
+    nll_sty = torch.empty((sty_t.numel(),), device=dev, dtype=torch.float32)
+    a = _tts_loss_args(pred, noise, flen, pv, cf0_t, vuv_t, y_dur, dur, plen, y_sty, sty_t, G_dur, G_sty, dec_scale, lp_min, ls_min,
+                       total, comps, nll_dur, nll_sty)
+    check(_lib.load().ptpp_tts_losses_fwd(ctypes.byref(a), _stream()), "ptpp_tts_losses_fwd")
+    return total, comps, nll_dur, nll_sty
+
+
+def tts_losses_bwd(saved, g_total, g_comps, G_dur, G_sty, dec_scale, lp_min=-7.0, ls_min=-7.0):
+    (pred, noise, flen, pv, cf0_t, vuv_t, y_dur, dur, plen, y_sty, sty_t, comps, nll_dur, nll_sty) = saved
+    dev = pred.device
+    dpred, dpv = torch.empty_like(pred), torch.empty_like(pv)
+    dy_dur, dy_sty = torch.empty_like(y_dur), torch.empty_like(y_sty)
+    total = comps  # (unused by the backward)
+    a = _tts_loss_args(pred, noise, flen, pv, cf0_t, vuv_t, y_dur, dur, plen, y_sty, sty_t, G_dur, G_sty, dec_scale, lp_min, ls_min,
+                       total, comps, nll_dur, nll_sty)
+    check(_lib.load().ptpp_tts_losses_bwd(ctypes.byref(a), _ptr(g_total), _ptr(g_comps), dpred.data_ptr(), dpv.data_ptr(),
+                                          dy_dur.data_ptr(), dy_sty.data_ptr(), _stream()), "ptpp_tts_losses_bwd")
+    return dpred, dpv, dy_dur, dy_sty
+
+
+def q_sample_bct(mel, noise, step, sqrt_ac, sqrt_1mac, norm_scale, a_min, a_max, dtype):
+    """mel (B, M, T) f32, noise (B, T, M) f32, step (B,) int64 -> noised normalised mel (B, T, M) in ``dtype``."""
+    _need_gpu(mel)
+    B, M, T = mel.shape
+    assert mel.dtype == noise.dtype == torch.float32 and mel.is_contiguous() and noise.is_contiguous() and noise.shape == (B, T, M)
+    assert step.dtype == torch.int64 and step.numel() == B and sqrt_ac.dtype == sqrt_1mac.dtype == torch.float32
+    out = torch.empty((B, T, M), device=mel.device, dtype=dtype)
+    use_scale = norm_scale is not None
+    check(_lib.load().ptpp_q_sample_bct(mel.data_ptr(), noise.data_ptr(), step.data_ptr(), sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(),
+                                        sqrt_ac.numel(), float(norm_scale) if use_scale else 1.0, float(a_min), float(a_max),
+                                        int(use_scale), out.data_ptr(), B, M, T, dtype_code(dtype), _stream()), "ptpp_q_sample_bct")
+    return out
+
+
+def step_sinusoid(step, dim, scale=1):
+    """SinusoidalPosEmb: step (B,) int64 -> (B, dim) f32."""
+    import math
+
+    _need_gpu(step)
+    assert step.dtype == torch.int64 and step.is_contiguous() and float(scale) == int(scale)
+    half = dim // 2
+    out = torch.empty((step.numel(), 2 * half), device=step.device, dtype=torch.float32)
+    check(_lib.load().ptpp_step_sinusoid(step.data_ptr(), int(scale), -(math.log(10000) / (half - 1)), step.numel(), half,
+                                         out.data_ptr(), _stream()), "ptpp_step_sinusoid")
+    return out
+
+
+def mish_fwd(x):
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    _need_gpu(x)
+    y = torch.empty_like(x)
+    check(_lib.load().ptpp_mish_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "ptpp_mish_fwd")
+    return y
+
+
+def mish_bwd(x, gy):
+    gy = gy.contiguous()
+    gx = torch.empty_like(x)
+    check(_lib.load().ptpp_mish_bwd(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), x.numel(), _stream()), "ptpp_mish_bwd")
+    return gx
+
+
+def embed_cl_fwd(ids, table, lengths, scale, dtype):
+    _need_gpu(ids)
+    B, T = ids.shape
+    V, C = table.shape
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and table.dtype == torch.float32 and table.is_contiguous()
+    out = torch.empty((B, T, C), device=ids.device, dtype=dtype)
+    check(_lib.load().ptpp_embed_cl_fwd(ids.data_ptr(), table.data_ptr(), _ptr(lengths), float(scale or 1.0), int(scale is not None),
+                                        out.data_ptr(), B, T, C, V, dtype_code(dtype), _stream()), "ptpp_embed_cl_fwd")
+    return out
+
+
+def embed_cl_bwd(ids, dout, lengths, scale, dtable, padding_idx):
+    B, T = ids.shape
+    V, C = dtable.shape
+    dout = dout.contiguous()
+    assert dtable.dtype == torch.float32 and dtable.is_contiguous()
+    check(_lib.load().ptpp_embed_cl_bwd(ids.data_ptr(), dout.data_ptr(), _ptr(lengths), float(scale or 1.0), int(scale is not None),
+                                        dtable.data_ptr(), B, T, C, V, -1 if padding_idx is None else int(padding_idx),
+                                        dtype_code(dout.dtype), _stream()), "ptpp_embed_cl_bwd")
+    return dtable
+
+
+def scalar_embed_add(x, track, w, bias, lengths):
+    _need_gpu(x)
+    B, T, C = x.shape
+    assert x.is_contiguous() and track.is_contiguous() and track.dtype == torch.float32 and track.shape == (B, T)
+    assert w.dtype == bias.dtype == torch.float32 and w.numel() == bias.numel() == C and w.is_contiguous() and bias.is_contiguous()
+    out = torch.empty_like(x)
+    check(_lib.load().ptpp_scalar_embed_add(x.data_ptr(), track.data_ptr(), w.data_ptr(), bias.data_ptr(), _ptr(lengths), out.data_ptr(),
+                                            B, T, C, dtype_code(x.dtype), _stream()), "ptpp_scalar_embed_add")
+    return out
+
+
+def scalar_embed_bwd(dout, track, lengths, dw, db):
+    """dw / db: f32 (C) buffers the sums are ADDED to."""
+    B, T, C = dout.shape
+    dout = dout.contiguous()
+    assert dw.dtype == db.dtype == torch.float32 and dw.numel() == db.numel() == C and dw.is_contiguous() and db.is_contiguous()
+    check(_lib.load().ptpp_scalar_embed_bwd(dout.data_ptr(), track.data_ptr(), _ptr(lengths), dw.data_ptr(), db.data_ptr(), B, T, C,
+                                            dtype_code(dout.dtype), *reduction_scratch(dout.device), _stream()), "ptpp_scalar_embed_bwd")
+
+
+def l2norm_fwd(x, eps=1e-12):
+    """x (rows, C) f32 contiguous -> (x / max(||x||, eps), norms)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    y = torch.empty_like(x)
+    n = torch.empty((x.shape[0],), device=x.device, dtype=torch.float32)
+    check(_lib.load().ptpp_l2norm_fwd(x.data_ptr(), y.data_ptr(), n.data_ptr(), x.shape[0], x.shape[1], float(eps), _stream()),
+          "ptpp_l2norm_fwd")
+    return y, n
+
+
+def l2norm_bwd(y, n, gy, eps=1e-12):
+    gy = gy.contiguous()
+    gx = torch.empty_like(y)
+    check(_lib.load().ptpp_l2norm_bwd(y.data_ptr(), n.data_ptr(), gy.data_ptr(), gx.data_ptr(), y.shape[0], y.shape[1], float(eps),
+                                      _stream()), "ptpp_l2norm_bwd")
+    return gx
+
+
+def durations_cumsum(dur):
+    """(B, Tp) float32 (integer valued) or int64 durations -> int32 running sums."""
+    _need_gpu(dur)
+    if dur.dtype not in (torch.float32, torch.int64):
+        dur = dur.to(torch.int64)
+    dur = dur.contiguous()
+    cum = torch.empty(dur.shape, device=dur.device, dtype=torch.int32)
+    check(_lib.load().ptpp_durations_cumsum(dur.data_ptr(), int(dur.dtype == torch.float32), cum.data_ptr(), dur.shape[0], dur.shape[1],
+                                            _stream()), "ptpp_durations_cumsum")
+    return cum
+
+
+def bcast_add_rows(x, e):
+    """x (B, T, C) + e (B, C) f32 (rounded to x's dtype first) on every row."""
+    _need_gpu(x)
+    B, T, C = x.shape
+    assert x.is_contiguous() and e.dtype == torch.float32 and e.is_contiguous() and e.shape == (B, C)
+    y = torch.empty_like(x)
+    check(_lib.load().ptpp_bcast_add_rows(x.data_ptr(), e.data_ptr(), y.data_ptr(), B, T, C, dtype_code(x.dtype), _stream()),
+          "ptpp_bcast_add_rows")
+    return y
+
+
+def rows_sum(dy):
+    """(B, T, C) -> (B, C) f32 sum over T."""
+    dy = dy.contiguous()
+    B, T, C = dy.shape
+    de = torch.empty((B, C), device=dy.device, dtype=torch.float32)
+    check(_lib.load().ptpp_rows_sum(dy.data_ptr(), de.data_ptr(), B, T, C, dtype_code(dy.dtype), _stream()), "ptpp_rows_sum")
+    return de

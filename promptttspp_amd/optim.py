@@ -82,6 +82,10 @@ class FusedAdamW(torch.optim.Optimizer):
         if not live:
             return loss
         dev = next(p for p in live[0][1]["params"] if p.grad is not None).device
+        if dev.type == "cuda":
+            from . import ops
+
+            ops.red_flush()  # parameter-gradient sums still queued (no-op after FlatGradReducer.finish())
         if self._sumsq is None:
             self._sumsq = torch.zeros(_SLOTS, device=dev, dtype=torch.float32)
         if self.max_grad_norm > 0:

@@ -196,7 +196,9 @@ class FlatGradReducer:
         side = None
         if self.flat.is_cuda:
             from . import functional as PF
+            from . import ops
 
+            ops.red_flush()  # the queued parameter-gradient sums of every stream, each on its producer's stream
             side = PF.side_stream_for_collective()
             if side is None:
                 PF.sync_wgrad_stream()  # the collective orders itself after the CURRENT stream only
@@ -271,7 +273,9 @@ class FlatGradReducer:
             e0.record()
         if self.flat.is_cuda:
             from . import functional as PF
+            from . import ops
 
+            ops.red_flush()
             PF.sync_wgrad_stream()
         if tm is not None:
             e1.record()
