@@ -328,7 +328,9 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
             e0.record()
             r = orig_drv(h0, cond_all, dsteps, weights, lengths, *rest, **kw)
             e1.record()
-            rows = float(lengths.sum()) if lengths is not None else h0.shape[0] * h0.shape[1]
+            # (no host read here: the step stays fully enqueued behind the spin kernel -- tools/prof_step_tail.py reads this step as
+            #  the device's own timeline; the valid-row count is taken after the synchronize below)
+            rows = lengths if lengths is not None else h0.shape[0] * h0.shape[1]
             cx = kw.get("condx")
             lrec.append((e0, e1, len(weights), rows, h0.shape[0] * h0.shape[1], h0.shape[2], 0 if cx is None else cx.shape[2]))
             return r
@@ -342,6 +344,7 @@ def conv_roofline(model, batch, red, opt, sched, dtype_name):
             PF._diffnet_stack_forward_driver = orig_drv
         if lrec:
             e0, e1, L, rows, padded, C, Cc = lrec[0]
+            rows = float(rows.sum()) if torch.is_tensor(rows) else rows
             us = 1e3 * e0.elapsed_time(e1) / L
             # dilated conv k3 C -> 2C + output projection C -> 2C (+ the conditioner projection Cc -> 2C where the layer does it)
             flop = 2.0 * rows * C * (3 * 2 * C + 2 * C) + 2.0 * rows * Cc * 2 * C

@@ -1093,6 +1093,15 @@ int ptpp_scalar_embed_add(const void* x, const float* track, const float* w, con
 int ptpp_scalar_embed_bwd(const void* dout, const float* track, const int32_t* lengths, float* dw, float* db, int B, int T,
                           int C, int dtype, void* scratch, size_t scratch_bytes, void* stream);
 
+/* Linear / 1x1 Conv1d with Cout in 1..4 (the pitch / V-UV head, modules/variance_adaptor.py:52-62): y[b, t, o] = x[b, t] . w[o] + bias[o]
+ * for t < lengths[b] (lengths NULL: every row), else 0; x (B, T, Cin) `dtype`, Cin in {256, 512, 768, 1024}, w (Cout, Cin) / bias
+ * f32, f32 accumulation.  _bwd: dx (nullable) = dy . w on valid rows (0 elsewhere); dw += sum_valid dy^T x, db += sum_valid dy
+ * (through the reduction scratch: PTPP_RED_SCRATCH_BYTES(Cout * Cin + Cout) / 2 bytes; deferrable). */
+int ptpp_linear_small_fwd(const void* x, const float* w, const float* bias, const int32_t* lengths, void* y, int B, int T,
+                          int Cin, int Cout, int dtype, void* stream);
+int ptpp_linear_small_bwd(const void* x, const void* dy, const float* w, const int32_t* lengths, void* dx, float* dw, float* db,
+                          int B, int T, int Cin, int Cout, int dtype, void* scratch, size_t scratch_bytes, void* stream);
+
 /* F.normalize over the channels of (rows, C) f32 (model.py:108: style embeddings): y = x / max(||x||, eps); nrm (rows) kept. */
 int ptpp_l2norm_fwd(const float* x, float* y, float* nrm, int rows, int C, float eps, void* stream);
 int ptpp_l2norm_bwd(const float* y, const float* nrm, const float* gy, float* gx, int rows, int C, float eps, void* stream);

@@ -343,6 +343,8 @@ SIGNATURES = {
     "ptpp_embed_cl_bwd": (I, [P, P, P, F, I, P, I, I, I, I, I, I, P]),
     "ptpp_scalar_embed_add": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "ptpp_scalar_embed_bwd": (I, [P, P, P, P, P, I, I, I, I, P, SZ, P]),
+    "ptpp_linear_small_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "ptpp_linear_small_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "ptpp_l2norm_fwd": (I, [P, P, P, I, I, F, P]),
     "ptpp_l2norm_bwd": (I, [P, P, P, P, I, I, F, P]),
     "ptpp_durations_cumsum": (I, [P, I, P, I, I, P]),

@@ -541,6 +541,106 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const T* __restrict__ dy,
   if (wv == 0 && c < C) de[(int64_t)b * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Linear / 1x1 Conv1d with 1-4 output channels (the pitch / V-UV head, modules/variance_adaptor.py:52-62: 256 -> 2): a row is one
+// wave's dot products, HBM-bound; the GEMM path needed a padded operand and, in the backward, ~15 tensor ops for Cout % 4 != 0.
+// f32 weights and accumulation.  Backward: dx, and (dw, db) as block column sums through the replicated reduction scratch.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, const int* __restrict__ lengths,
+                                                              T* __restrict__ y, int64_t rows, int Tn, int Cin) {
+  const int lane = threadIdx.x & 63;
+  const int nv = Cin / 256;
+  f32x4 wr[CO][4];
+#pragma unroll
+  for (int o = 0; o < CO; ++o)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wr[o][i] = i < nv ? *reinterpret_cast<const f32x4*>(w + (int64_t)o * Cin + i * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    const int b = (int)(row / Tn), t = (int)(row - (int64_t)b * Tn);
+    const bool valid = !lengths || t < lengths[b];
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nv) {
+          const f32x4 xv = Elem<T>::ld4(x + row * Cin + i * 256 + lane * 4);
+#pragma unroll
+          for (int o = 0; o < CO; ++o) acc[o] += (xv[0] * wr[o][i][0] + xv[1] * wr[o][i][1]) + (xv[2] * wr[o][i][2] + xv[3] * wr[o][i][3]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = wave_sum(acc[o]);
+    if (lane == 0)
+#pragma unroll
+      for (int o = 0; o < CO; ++o) Elem<T>::st(y + row * CO + o, valid ? acc[o] + (bias ? bias[o] : 0.f) : 0.f);
+  }
+}
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void linear_small_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ w,
+                                                              const int* __restrict__ lengths, T* __restrict__ dx, void* scratch,
+                                                              int64_t rows, int Tn, int Cin) {
+  __shared__ float tot[CO * 1024 + 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nv = Cin / 256;
+  f32x4 wr[CO][4], aw[CO][4];
+  float ab[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    ab[o] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wr[o][i] = i < nv ? *reinterpret_cast<const f32x4*>(w + (int64_t)o * Cin + i * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      aw[o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int b = (int)(row / Tn), t = (int)(row - (int64_t)b * Tn);
+    const bool valid = !lengths || t < lengths[b];
+    float g[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      g[o] = valid ? Elem<T>::ld(dy + row * CO + o) : 0.f;
+      ab[o] += g[o];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nv) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+          const f32x4 xv = Elem<T>::ld4(x + row * Cin + i * 256 + lane * 4);
+#pragma unroll
+          for (int o = 0; o < CO; ++o) {
+            d += wr[o][i] * g[o];
+            aw[o][i] += xv * g[o];
+          }
+        }
+        if (dx) Elem<T>::st4(dx + row * Cin + i * 256 + lane * 4, d);
+      }
+  }
+  const int KC = CO * Cin + CO;
+  for (int i = threadIdx.x; i < KC; i += 256) tot[i] = 0.f;
+  __syncthreads();
+  for (int k = 0; k < 4; ++k) {  // waves in order: a fixed summation order inside the block
+    if (wv == k) {
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nv)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tot[o * Cin + i * 256 + lane * 4 + e] += aw[o][i][e];
+        if (lane == 0) tot[CO * Cin + o] += ab[o];
+      }
+    }
+    __syncthreads();
+  }
+  red_block_add(scratch, tot, KC);
+}
 }  // namespace
 
 // ================================================================================================================================
@@ -754,5 +854,50 @@ extern "C" int ptpp_rows_sum(const void* dy, float* de, int B, int T, int C, int
   else
     PTPP_CHECK_ARG(false, "rows_sum: dtype %d (f32 / bf16)", dtype);
   PTPP_CHECK_LAUNCH("rows_sum");
+  return PTPP_OK;
+}
+
+extern "C" int ptpp_linear_small_fwd(const void* x, const float* w, const float* bias, const int32_t* lengths, void* y, int B, int T,
+                                     int Cin, int Cout, int dtype, void* stream) {
+  PTPP_CHECK_ARG(x && w && y && B > 0 && T > 0 && Cin > 0 && Cin % 256 == 0 && Cin <= 1024 && Cout >= 1 && Cout <= 4,
+                 "linear_small_fwd: bad args (Cin in {256 .. 1024}, Cout 1-4)");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "linear_small_fwd: dtype %d (f32 / bf16)", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t rows = (int64_t)B * T;
+  int64_t nb = (rows + 3) / 4;
+  if (nb > 4096) nb = 4096;
+#define LS_FWD(TT, CO_)                                                                                                            \
+  hipLaunchKernelGGL((linear_small_fwd_kernel<TT, CO_>), dim3((unsigned)nb), dim3(256), 0, st, reinterpret_cast<const TT*>(x), w, bias, \
+                     lengths, reinterpret_cast<TT*>(y), rows, T, Cin)
+#define LS_FWD_T(TT)                                                                                   \
+  switch (Cout) { case 1: LS_FWD(TT, 1); break; case 2: LS_FWD(TT, 2); break; case 3: LS_FWD(TT, 3); break; default: LS_FWD(TT, 4); }
+  if (dtype == PTPP_F32) { LS_FWD_T(float) } else { LS_FWD_T(bf16_raw) }
+#undef LS_FWD_T
+#undef LS_FWD
+  PTPP_CHECK_LAUNCH("linear_small_fwd");
+  return PTPP_OK;
+}
+extern "C" int ptpp_linear_small_bwd(const void* x, const void* dy, const float* w, const int32_t* lengths, void* dx, float* dw, float* db,
+                                     int B, int T, int Cin, int Cout, int dtype, void* scratch, size_t scratch_bytes, void* stream) {
+  PTPP_CHECK_ARG(x && dy && w && dw && db && B > 0 && T > 0 && Cin > 0 && Cin % 256 == 0 && Cin <= 1024 && Cout >= 1 && Cout <= 4,
+                 "linear_small_bwd: bad args (Cin in {256 .. 1024}, Cout 1-4)");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "linear_small_bwd: dtype %d (f32 / bf16)", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t rows = (int64_t)B * T;
+  const int KC = Cout * Cin + Cout;
+  RedSlot slot = red_take(scratch, scratch_bytes, KC, st);
+  PTPP_CHECK_ARG(slot.ptr, "linear_small_bwd: reduction scratch missing or too small");
+  int64_t nb = (rows + 3) / 4;
+  if (nb > 1024) nb = 1024;
+#define LS_BWD(TT, CO_)                                                                                                          \
+  hipLaunchKernelGGL((linear_small_bwd_kernel<TT, CO_>), dim3((unsigned)nb), dim3(256), 0, st, reinterpret_cast<const TT*>(x),       \
+                     reinterpret_cast<const TT*>(dy), w, lengths, reinterpret_cast<TT*>(dx), slot.ptr, rows, T, Cin)
+#define LS_BWD_T(TT)                                                                                   \
+  switch (Cout) { case 1: LS_BWD(TT, 1); break; case 2: LS_BWD(TT, 2); break; case 3: LS_BWD(TT, 3); break; default: LS_BWD(TT, 4); }
+  if (dtype == PTPP_F32) { LS_BWD_T(float) } else { LS_BWD_T(bf16_raw) }
+#undef LS_BWD_T
+#undef LS_BWD
+  red_finish(slot, KC, dw, Cout * Cin, db, 1, st);
+  PTPP_CHECK_LAUNCH("linear_small_bwd");
   return PTPP_OK;
 }

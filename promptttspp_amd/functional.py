@@ -123,6 +123,7 @@ def repack_all(bumped=None):
     (weakref + version + pointer reads, ~1 ms of host time per step) is skipped: the cached launch table is
     reused and the stamps of the entries it covers are advanced arithmetically.  An entry whose parameter
     changed in any other way simply fails its stamp check at the next use and is re-packed on its own."""
+    refresh_bias_cats()
     if bumped is not None and _repack["key"] is not None and _repack["gen"] == (_pack_gen[0], id(bumped), len(bumped)):
         ops.pack_conv_weights_batched(_repack["table"], _repack["n"], _repack["map"], _repack["blocks"])
         for ent in _repack["ents"]:
@@ -190,13 +191,68 @@ def _cat_cached(ts, kind, make):
     return val
 
 
+# Concatenated biases of layers that share a GEMM (q | k | v, the MDN heads, the DiffNet projections): a PERSISTENT f32 buffer per
+# parameter list.  After an optimiser step ``repack_all`` refreshes every stale buffer with ONE multi-tensor copy
+# (``refresh_bias_cats``) instead of one torch.cat per list at its next use (~10 launches per training step); a buffer that is
+# still stale when it is used is rebuilt on its own.
+_bias_cats = {}
+_bias_gen = [0]
+_bias_plan = {"gen": -1, "dst": [], "src": [], "ents": []}
+
+
+class _BiasCat:
+    __slots__ = ("refs", "vers", "buf", "views")
+
+
 def bias_cat(bs):
-    return _cat_cached(bs, "b", lambda: torch.cat([b.detach().float() for b in bs], dim=0))
+    bs = tuple(bs)
+    if not all(isinstance(b, torch.nn.Parameter) for b in bs):
+        return torch.cat([b.detach().float() for b in bs], dim=0)
+    key = tuple(id(b) for b in bs)
+    ent = _bias_cats.get(key)
+    stamp = tuple((b._version, b.data_ptr()) for b in bs)
+    if ent is not None and all(r() is b for r, b in zip(ent.refs, bs)):
+        if ent.vers != stamp:
+            torch.cat([b.detach().float() for b in bs], dim=0, out=ent.buf)
+            ent.vers = stamp
+        return ent.buf
+    ent = _BiasCat()
+    ent.refs = [weakref.ref(b, lambda _r, k=key: (_bias_cats.pop(k, None), _bias_gen.__setitem__(0, _bias_gen[0] + 1))) for b in bs]
+    ent.buf = torch.cat([b.detach().float() for b in bs], dim=0)
+    ent.vers = stamp
+    off, ent.views = 0, []
+    for b in bs:
+        ent.views.append(ent.buf[off:off + b.numel()].view(b.shape))
+        off += b.numel()
+    _bias_cats[key] = ent
+    _bias_gen[0] += 1
+    return ent.buf
+
+
+def refresh_bias_cats():
+    """One multi-tensor copy of every f32 device source into its slice of its concatenated buffer (after a parameter update)."""
+    pl = _bias_plan
+    if pl["gen"] != _bias_gen[0]:
+        pl["dst"], pl["src"], pl["ents"] = [], [], []
+        for ent in _bias_cats.values():
+            srcs = [r() for r in ent.refs]
+            if any(b is None or not b.is_cuda or b.dtype != torch.float32 for b in srcs):
+                continue
+            pl["ents"].append((ent, srcs))
+            pl["dst"].extend(ent.views)
+            pl["src"].extend(b.detach() for b in srcs)
+        pl["gen"] = _bias_gen[0]
+    if pl["dst"]:
+        torch._foreach_copy_(pl["dst"], pl["src"])
+        for ent, srcs in pl["ents"]:
+            ent.vers = tuple((b._version, b.data_ptr()) for b in srcs)
 
 
 def clear_caches():
     _pack_cache.clear()
     _cat_cache.clear()
+    _bias_cats.clear()
+    _bias_gen[0] += 1
     _pack_gen[0] += 1
     _repack["key"] = None
     _repack["gen"] = None
@@ -910,6 +966,7 @@ class TtsLossesFn(Function):
         total, comps, nll_dur, nll_sty = ops.tts_losses_fwd(pred, noise, flen, pv, cf0_t, vuv_t, y_dur, dur, plen, y_sty, sty_t,
                                                             cfg.G_dur, cfg.G_sty, cfg.dec_scale)
         ctx.cfg = cfg
+        ctx.set_materialize_grads(False)  # (the components are logged, not differentiated: no zero-filled gradient for them)
         ctx.save_for_backward(pred, noise, flen, pv, cf0_t, vuv_t, y_dur, dur, plen, y_sty, sty_t, comps, nll_dur, nll_sty)
         return total, comps
 
@@ -1017,6 +1074,91 @@ def scalar_embed_add(x, track, emb, lengths):
     return ScalarEmbedAddFn.apply(x, track, emb.weight, emb.bias, lengths)
 
 
+class LinearSmallFn(Function):
+    """A 1x1 Conv1d / Linear with 1-4 output channels and an output mask (the pitch / V-UV head, reference
+    modules/variance_adaptor.py:52-62) as one launch forward and one backward (f32 weights and accumulation)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, lengths):
+        x = x.contiguous()
+        w = _f32c(weight).reshape(weight.shape[0], -1)
+        ctx.lengths, ctx.params = lengths, (weight, bias)
+        ctx.direct = any(ctx.needs_input_grad) and _sink(weight) is not None and bias is not None and _sink(bias) is not None
+        if ctx.direct:
+            _use(weight)
+            _use(bias)
+        ctx.save_for_backward(x, w)
+        return ops.linear_small_fwd(x, w, _f32c(bias), lengths)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        weight, bias = ctx.params
+        if ctx.direct:
+            dx = ops.linear_small_bwd(x, dy, w, ctx.lengths, weight.grad.view(-1), bias.grad, want_dx=ctx.needs_input_grad[0])
+            _done(weight)
+            _done(bias)
+            return dx, None, None, None
+        dw = torch.zeros(weight.numel(), device=x.device, dtype=torch.float32)
+        db = torch.zeros(weight.shape[0], device=x.device, dtype=torch.float32)
+        with ops.red_immediate():
+            dx = ops.linear_small_bwd(x, dy, w, ctx.lengths, dw, db, want_dx=ctx.needs_input_grad[0])
+        return dx, dw.view_as(weight), (db if bias is not None else None), None
+
+
+def linear_small_ok(x, weight):
+    return (x.is_cuda and x.dim() == 3 and weight.shape[0] <= 4 and x.shape[-1] % 256 == 0 and x.shape[-1] <= 1024
+            and x.dtype in (torch.float32, torch.bfloat16) and weight.numel() == weight.shape[0] * x.shape[-1])
+
+
+def linear_small(x, weight, bias, lengths):
+    return LinearSmallFn.apply(x, weight, bias, lengths)
+
+
+class RejoinBranchFn(Function):
+    """The JOIN of a forward branch that was issued early on its own stream (the reference encoder: mel -> style embedding).
+    autograd runs ready nodes newest-first, so a branch whose nodes were created BEFORE the trunk's is differentiated LAST -- after
+    the whole phoneme-encoder backward, with the main stream idle for its ~1.7 ms of launches at the end of every step
+    (profiles/r06_step_tail_before.txt).  This node is created at the join instead; its backward runs the branch's own graph by a
+    re-entrant backward on the branch's stream as soon as the joined value's gradient exists, beside the trunk's backward."""
+
+    @staticmethod
+    def forward(ctx, _anchor, holder, stream):
+        # (the branch output travels in a holder: as a tensor ARGUMENT it would become an input edge of this node, and the outer
+        #  pass would run the branch's graph a second time with an undefined gradient)
+        ctx.inner, ctx.stream = holder[0], stream
+        return holder[0].detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        inner, st = ctx.inner, ctx.stream
+        ctx.inner = None
+        if st is None:
+            torch.autograd.backward(inner, g)
+            return None, None, None
+        st.wait_stream(torch.cuda.current_stream())
+        g.record_stream(st)
+        with ops.unpinned(), torch.cuda.stream(st):  # (the caller stream of the re-entrant pass: its end-of-pass join stays here)
+            torch.autograd.backward(inner, g)
+        return None, None, None
+
+
+_rejoin_anchor = {}
+
+
+def rejoin_branch(inner, stream=None):
+    """``inner``: a branch's output (its autograd graph hangs off it).  Returns a tensor with the same values whose gradient
+    is propagated into the branch when it arrives (see RejoinBranchFn)."""
+    if not (inner.requires_grad and torch.is_grad_enabled()):
+        return inner
+    key = str(inner.device)
+    a = _rejoin_anchor.get(key)
+    if a is None:  # an empty leaf that requires grad: makes autograd record the node (its own gradient is None)
+        a = _rejoin_anchor[key] = torch.empty(0, device=inner.device, requires_grad=True)
+    return RejoinBranchFn.apply(a, (inner,), stream)
+
+
 class L2NormFn(Function):
     @staticmethod
     def forward(ctx, x, eps):
@@ -1098,7 +1240,7 @@ def gate_biases(dil_bs, cond_bs):
     if idx is None:
         perm = _gate_perm(c2, dev)
         idx = _gate_perm_cache[key] = (torch.arange(2 * L, device=dev)[:, None] * c2 + perm[None, :]).reshape(-1)
-    allb = torch.cat([b.detach().float() for b in list(dil_bs) + list(cond_bs)], dim=0)[idx]
+    allb = bias_cat(list(dil_bs) + list(cond_bs))[idx]
     return [allb[l * c2:(l + 1) * c2] for l in range(L)], allb[L * c2:]
 
 
@@ -1331,7 +1473,10 @@ class DiffNetStackFn(Function):
         L, ws = ctx.L, ctx.ws
         B, T, C = gout.shape
         dt = gout.dtype
-        gS = (gout.float() * (1.0 / math.sqrt(L))).to(dt).contiguous()
+        if gout.is_cuda and dt != torch.float32:  # (one launch: float(gout) * s rounded to dt, the arithmetic of the tensor-op chain)
+            gS = ops.epilogue_bwd(gout.contiguous(), None, None, 1.0 / math.sqrt(L), False, False, 0.0, 0)
+        else:
+            gS = (gout.float() * (1.0 / math.sqrt(L))).to(dt).contiguous()
         # every layer's gx is kept ((L + 1, B, T, C): 0.3 GB at the bench shape) so that the per-utterance column sums
         # of all layers are ONE launch after the loop instead of one (plus its memset) per layer
         gx_all = torch.empty((L + 1, B, T, C), device=gout.device, dtype=dt)

@@ -34,6 +34,8 @@ from ...utils.model import sequence_mask
 # test_direct_gradient_accumulation_equals_autograd produced a wrong duration-predictor weight gradient (an unordered
 # dependency that is not found yet; modes 0 / 1 / 2: 6 of 6 clean), so it is never the default
 BRANCH_STREAMS = os.environ.get("PTPP_BRANCH_STREAMS", "2")
+REJOIN = not os.environ.get("PTPP_NO_REJOIN")  # the reference-encoder branch is differentiated from its join (functional.RejoinBranchFn)
+PROMPT_FIRST = not os.environ.get("PTPP_PROMPT_LATE")  # the prompt branch is issued at the start of the forward
 FUSED_GLUE = not os.environ.get("PTPP_NO_FUSED_GLUE")  # (tests compare the fused training forward with the general one)
 JOIN_PROBE = None  # tools/diag_joins.py sets a list: (name, event on the waiting stream before the wait, event at the branch's end)
 
@@ -153,6 +155,14 @@ class PromptTTSMDNDurCFG(nn.Module):
             sa.wait_stream(torch.cuda.current_stream())
             with ops.unpinned(), torch.cuda.stream(sa):
                 style_emb = self._norm_style(self.reference_encoder(mel, frame_lengths))  # (B,C,1) f32
+        # the prompt branch (BERT -> adaptor -> style MDN head) depends on the prompt only and feeds only the style loss: issued
+        # now (round 5 issued it after the phoneme encoder: the main stream then waited ~0.7 ms for it at the losses)
+        bs = _branch_stream(dev, 0) if branches else None
+        if bs is not None and PROMPT_FIRST:
+            bs.wait_stream(torch.cuda.current_stream())
+            with ops.unpinned(), torch.cuda.stream(bs):
+                prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
+                y_sty = self.style_mdn.raw(prompt_emb.transpose(-1, -2))
         plen = phone_lengths.to(device=dev, dtype=torch.int32)
         flen = frame_lengths.to(device=dev, dtype=torch.int32)
         x = self.phoneme_emb.forward_cl(phoneme, None, dt, lengths=plen)
@@ -162,18 +172,19 @@ class PromptTTSMDNDurCFG(nn.Module):
             _probe("reference encoder -> x + style_emb", torch.cuda.current_stream(), sa)
             torch.cuda.current_stream().wait_stream(sa)
             style_emb.record_stream(torch.cuda.current_stream())
+            if REJOIN:  # (the branch's backward is scheduled from HERE, not after the whole encoder backward: RejoinBranchFn)
+                style_emb = PF.rejoin_branch(style_emb, sa)
         else:
             style_emb = self._norm_style(self.reference_encoder(mel, frame_lengths))
-        bs = _branch_stream(dev, 0) if branches else None
-        if bs is not None:
+        x = PF.bcast_add_rows(x, style_emb.float().reshape(style_emb.shape[0], -1))  # every phone, padded ones too (model.py:111)
+        if bs is not None and not PROMPT_FIRST:
             bs.wait_stream(torch.cuda.current_stream())
             with ops.unpinned(), torch.cuda.stream(bs):
                 prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
                 y_sty = self.style_mdn.raw(prompt_emb.transpose(-1, -2))
-        else:
+        elif bs is None:
             prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
             y_sty = self.style_mdn.raw(prompt_emb.transpose(-1, -2))
-        x = PF.bcast_add_rows(x, style_emb.float().reshape(style_emb.shape[0], -1))  # every phone, padded ones too (model.py:111)
         vb = (bs, sa) if (branches and BRANCH_STREAMS == "3") else None
         h, y_dur, pv, _, _ = self.variance_adaptor.forward_cl(x, plen, flen, None, duration.squeeze(1), log_cf0.squeeze(1), None,
                                                               branch_streams=vb, raw=True, Tf=Tf)

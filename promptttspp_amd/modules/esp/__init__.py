@@ -153,13 +153,14 @@ class EncoderLayer(nn.Module):
         self.norm_final = _LN(size)
         self.dropout_rate = dropout_rate
 
-    def cl(self, x, pos_emb, lengths, mask_bt1):
+    def cl(self, x, pos_emb, lengths, mask_bt1, counted=False):
+        """``counted``: the caller has already advanced the BatchNorm step counter (one multi-tensor launch for all blocks)."""
         p = self.dropout_rate if self.training else 0.0
         if _block_driver_ok(self, x):
             from types import SimpleNamespace
 
             bn = self.conv_module.norm
-            if bn.training and bn.num_batches_tracked is not None:
+            if bn.training and bn.num_batches_tracked is not None and not counted:
                 bn.num_batches_tracked.add_(1)
             cfg = SimpleNamespace(lengths=lengths, heads=self.self_attn.h, variant=self.self_attn.variant, p=float(p),
                                   p_ffn=float(self.feed_forward.dropout_rate if self.training else 0.0), bn=bn, training=bn.training)
@@ -272,13 +273,14 @@ class ConformerBlockFn(torch.autograd.Function):
             ctx.tensors = (x, pos, lens, slab)
             ctx.w, ctx.w_keep = a.w, keep  # the forward operands: the backward reads the same ones (no second lookup)
             ctx.direct = [PF._sink(t) is not None for t in P]
-            # the BatchNorm parameter gradients come back through autograd (their kernel OVERWRITES a (2C) buffer);
-            # everything else accumulates in place when the trainer allows it (the depthwise kernel adds with atomics:
-            # straight into p.grad instead of into a zero-filled buffer that autograd then adds)
+            # everything accumulates in place when the trainer allows it (the depthwise kernel adds with atomics: straight into
+            # p.grad instead of into a zero-filled buffer that autograd then adds); the BatchNorm parameter gradients' kernel
+            # OVERWRITES a (2C) buffer, which the backward then adds to both p.grad with one multi-tensor launch
+            ctx.bn_direct = ctx.direct[35] and ctx.direct[36]
             for i in (35, 36):
                 ctx.direct[i] = False
             for i, t in enumerate(P):
-                if ctx.direct[i]:
+                if ctx.direct[i] or (ctx.bn_direct and i in (35, 36)):
                     PF._use(t)
         return y
 
@@ -298,7 +300,8 @@ class ConformerBlockFn(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(x)
         scratch = torch.empty(lib.ptpp_conformer_block_bwd_scratch_bytes(B, T, C, F_, H, L, dcode), device=dev, dtype=torch.uint8)
-        tg = [t.grad if d else torch.zeros(t.shape, device=dev, dtype=torch.float32) for t, d in zip(P, ctx.direct)]
+        tg = [t.grad if d else (None if i in (35, 36) else torch.zeros(t.shape, device=dev, dtype=torch.float32))
+              for i, (t, d) in enumerate(zip(P, ctx.direct))]
         bn_sums = torch.empty(2 * C, device=dev, dtype=torch.float32)
         a = _lib.ConformerBwdArgs()
         a.w = ctx.w
@@ -341,8 +344,10 @@ class ConformerBlockFn(torch.autograd.Function):
             d["keep"].extend((x, pos, slab, scratch))
         ctx.tensors = None
         grads = []
+        if ctx.bn_direct:
+            torch._foreach_add_([P[35].grad, P[36].grad], [bn_sums[C:].view_as(P[35]), bn_sums[:C].view_as(P[36])])
         for i, (t, dr) in enumerate(zip(P, ctx.direct)):
-            if dr:
+            if dr or (ctx.bn_direct and i in (35, 36)):
                 PF._done(t)
                 grads.append(None)
             elif i == 35:
@@ -398,8 +403,17 @@ class Encoder(nn.Module):
         pos = self.pos_table(x.shape[1], x.device, x.dtype)
         if p > 0:
             pos = PF.posenc(pos.unsqueeze(0), None, 1.0, p)[0]
+        # the BatchNorm step counters of all blocks in one multi-tensor launch (they feed nothing in the step)
+        drv = [l for l in self.encoders if _block_driver_ok(l, x)]
+        tracked = [l.conv_module.norm.num_batches_tracked for l in drv
+                   if l.conv_module.norm.training and l.conv_module.norm.num_batches_tracked is not None]
+        if len(tracked) > 1 and len(drv) == len(self.encoders):
+            torch._foreach_add_(tracked, 1)
+            counted = True
+        else:
+            counted = False
         for layer in self.encoders:
-            x = layer.cl(x, pos, lengths, mask_bt1)
+            x = layer.cl(x, pos, lengths, mask_bt1, counted=counted) if counted else layer.cl(x, pos, lengths, mask_bt1)
         return self.after_norm.cl(x, lengths=lengths, out_mask=True)
 
 

@@ -65,7 +65,11 @@ class Predictor(nn.Module):
         if self.detach:
             x = x.detach()
         x = _predictor_layers(self.layers, x, lengths, self.training)
-        y = PF.conv1d(x, self.out_layer.weight, self.out_layer.bias, lengths=lengths, out_mask=True)
+        ol = self.out_layer
+        if ol.bias is not None and PF.linear_small_ok(x, ol.weight):  # 1-4 output channels: one HBM-bound launch each way
+            y = PF.linear_small(x, ol.weight, ol.bias, ops.i32(lengths, x.device))
+        else:
+            y = PF.conv1d(x, ol.weight, ol.bias, lengths=lengths, out_mask=True)
         return y.float() if as_float else y
 
     def forward(self, x, mask):

@@ -309,7 +309,7 @@ def workspace_of(device, stream_handle):
     return w
 
 
-_RED_BYTES = 32 * 8 * 1024  # PTPP_RED_SCRATCH_BYTES(1024), the widest supported row
+_RED_BYTES = 32 * 4 * 4352  # 32 replicas of the widest sum: ptpp_linear_small_bwd's Cout * Cin + Cout = 4100 floats (LayerNorm: 2 * 1024)
 _red = {}
 
 
@@ -1348,3 +1348,29 @@ def rows_sum(dy):
     de = torch.empty((B, C), device=dy.device, dtype=torch.float32)
     check(_lib.load().ptpp_rows_sum(dy.data_ptr(), de.data_ptr(), B, T, C, dtype_code(dy.dtype), _stream()), "ptpp_rows_sum")
     return de
+
+
+def linear_small_fwd(x, w, bias, lengths):
+    """(B, T, Cin) x (Cout <= 4, Cin) f32 weights -> (B, T, Cout) in x's dtype, rows past ``lengths`` zero (ptpp_linear_small_fwd)."""
+    _need_gpu(x)
+    B, T, Cin = x.shape
+    Cout = w.shape[0]
+    assert x.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous() and w.numel() == Cout * Cin
+    y = torch.empty((B, T, Cout), device=x.device, dtype=x.dtype)
+    check(_lib.load().ptpp_linear_small_fwd(x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(lengths), y.data_ptr(), B, T, Cin, Cout,
+                                            dtype_code(x.dtype), _stream()), "ptpp_linear_small_fwd")
+    return y
+
+
+def linear_small_bwd(x, dy, w, lengths, dw, db, want_dx=True):
+    """dx (or None); dw (Cout * Cin) / db (Cout): f32 buffers the sums are ADDED to."""
+    B, T, Cin = x.shape
+    Cout = dy.shape[-1]
+    dy = dy.contiguous()
+    assert dy.dtype == x.dtype and dw.dtype == db.dtype == torch.float32 and dw.is_contiguous() and db.is_contiguous()
+    assert dw.numel() == Cout * Cin and db.numel() == Cout
+    dx = torch.empty_like(x) if want_dx else None
+    check(_lib.load().ptpp_linear_small_bwd(x.data_ptr(), dy.data_ptr(), w.data_ptr(), _ptr(lengths), _ptr(dx), dw.data_ptr(),
+                                            db.data_ptr(), B, T, Cin, Cout, dtype_code(x.dtype), *reduction_scratch(x.device),
+                                            _stream()), "ptpp_linear_small_bwd")
+    return dx

@@ -322,3 +322,31 @@ def test_fused_training_forward_equals_the_general_one(dev, dt, ltol, gtol):
     assert set(gf) == set(gg)
     worst = max((float((gf[n] - gg[n]).abs().max() / (gg[n].abs().max() + 1e-6)), n) for n in gg)
     assert worst[0] < gtol, worst
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("cout", [1, 2, 4])
+def test_small_output_linear_matches_conv1d_and_autograd(dev, dt, cout):
+    """ptpp_linear_small_fwd / _bwd (the pitch / V-UV head, reference modules/variance_adaptor.py:52-62: Conv1d(256 -> 2, k = 1)
+    followed by the frame mask) against F.conv1d * mask and its autograd on the same rounded operands."""
+    from promptttspp_amd import functional as PF
+
+    torch.manual_seed(4)
+    B, T, C = 3, 301, 256
+    lay = torch.nn.Conv1d(C, cout, 1).to(dev)
+    lens = torch.tensor([301, 17, 256], dtype=torch.int32, device=dev)
+    fm = (torch.arange(T, device=dev)[None] < lens[:, None]).unsqueeze(-1).float()
+    x = torch.randn(B, T, C, device=dev).to(dt).requires_grad_(True)
+    assert PF.linear_small_ok(x, lay.weight)
+    y = PF.linear_small(x, lay.weight, lay.bias, lens)
+    go = torch.randn(B, T, cout, device=dev).to(dt)
+    y.backward(go)
+    got = (x.grad.clone(), lay.weight.grad.clone(), lay.bias.grad.clone())
+    x.grad = lay.weight.grad = lay.bias.grad = None
+    ref = (F.conv1d(x.float().transpose(1, 2), lay.weight, lay.bias).transpose(1, 2) * fm)
+    ref.backward(go.float())
+    tol = 1e-2 if dt == torch.bfloat16 else 2e-5
+    assert float((y.float() - ref).abs().max() / ref.abs().max()) < tol
+    assert float(y[1, 17:].abs().max()) == 0.0 and float(got[0][1, 17:].abs().max()) == 0.0
+    for a, b in zip(got, (x.grad, lay.weight.grad, lay.bias.grad)):
+        assert float((a.float() - b.float()).abs().max() / b.float().abs().max()) < tol

@@ -343,8 +343,9 @@ def test_conv_ln_stack_driver_is_bit_identical(dev, monkeypatch, kind, dtype, B,
         assert a.shape == b.shape and a.dtype == b.dtype and float(a.float().abs().max()) > 0, n
         if dtype == torch.float32 and n not in ("y", "dx"):
             assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * float(a.abs().max())), n   # f32 weight-gradient kernel: atomics
-        elif "gamma" in n or "beta" in n:
-            # LayerNorm parameter gradients: per-block totals meet in the 32 replicas of the reduction scratch through f32
+        elif "gamma" in n or "beta" in n or n.startswith("out_layer"):
+            # LayerNorm parameter gradients -- and, since round 6, those of the pitch head's 256 -> 2 projection
+            # (ptpp_linear_small_bwd): per-block totals meet in the 32 replicas of the reduction scratch through f32
             # atomics (include/ptpp.h "Reduction scratch"), in both paths: last bits depend on the arrival order
             assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * float(a.abs().max())), n
         else:
