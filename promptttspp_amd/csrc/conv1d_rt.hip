@@ -612,8 +612,12 @@ int rt_launch(const RtP& p, hipStream_t st) {
 static int rt_bm_for(int B, int T, bool tall);
 
 extern "C" int ptpp_conv1d_rt_supported(int cin, int cout, int ks, int dil, int act, int dtype) {
-  if (dtype != PTPP_BF16 || cout != RT_N || cin <= 0 || (cin & 63) || ks < 3 || dil < 1) return 0;
+  if (dtype != PTPP_BF16 || cout != RT_N || cin <= 0 || (cin & 63) || ks < 1 || dil < 1) return 0;
   if (act != PTPP_ACT_NONE && act != PTPP_ACT_RELU) return 0;
+  if (ks < 3) {  // 1 x 1 (round 6: the DiffNet conditioner's data gradient, K = 20 x 512): the global-weights form only
+    const char* gwe = getenv("PTPP_CONV_RT_GW");
+    return ks == 1 && (cin & 127) == 0 && !(gwe && gwe[0] == '0');
+  }
   const int xrows = (128 + (ks - 1) * dil + 7) & ~7;
   return xrows <= 160;  // two windows of 20 KiB beside the 80 KiB ring
 }
@@ -627,7 +631,7 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
   PTPP_CHECK_ARG(a && a->x && a->y && wstream, "conv1d_rt_fwd: null pointer");
   PTPP_CHECK_ARG(!aux || ((ldaux & 7) == 0 && ldaux >= RT_N && ((uintptr_t)aux & 15) == 0), "conv1d_rt_fwd: bad aux output (ld %d)", ldaux);
   PTPP_CHECK_ARG(ptpp_conv1d_rt_supported(a->Cin, a->Cout, a->ks, a->dil, a->act, a->dtype),
-                 "conv1d_rt_fwd: unsupported shape (bf16, Cout = 256, Cin %% 64 == 0, ks >= 3, act none / relu; Cin %d Cout %d ks %d dil %d act %d)",
+                 "conv1d_rt_fwd: unsupported shape (bf16, Cout = 256, Cin %% 64 == 0, ks >= 3 or 1 x 1 with Cin %% 128 == 0, act none / relu; Cin %d Cout %d ks %d dil %d act %d)",
                  a->Cin, a->Cout, a->ks, a->dil, a->act);
   PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->pad >= 0 && a->pad <= (a->ks - 1) * a->dil && (a->ldx & 7) == 0 && (a->ldy & 7) == 0 &&
                      (!a->res || (a->ldr & 7) == 0),
@@ -650,7 +654,7 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
   p.gate_a = nullptr; p.gate_da = nullptr; p.ldda = 0;
   // the global-weights form (1 x 8 wave grid) for the tap counts of the model's layers; PTPP_CONV_RT_GW=0: the ring form
   const char* gwe = getenv("PTPP_CONV_RT_GW");
-  const bool gw_ok = !(gwe && gwe[0] == '0') && (a->Cin & 127) == 0 && (a->ks == 3 || a->ks == 5 || a->ks == 17);
+  const bool gw_ok = !(gwe && gwe[0] == '0') && (a->Cin & 127) == 0 && (a->ks == 1 || a->ks == 3 || a->ks == 5 || a->ks == 17);
   int bm = rt_bm_for(a->B, a->T, gw_ok);
   if (bm == 160 && ((160 + (a->ks - 1) * a->dil + 7) >> 3) > 24) bm = rt_bm_for(a->B, a->T, false);  // (window pieces: 8 waves x 3)
   p.nMT = (a->T + bm - 1) / bm;
@@ -661,6 +665,7 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
     const int xr = (bm + (a->ks - 1) * a->dil + 7) & ~7;
     const int npw = (bm + 7) / 8 + 6 > 16 ? 3 : 2;
     if (gw && (xr >> 3) <= 8 * npw) {
+      if (a->ks == 1) return rt_gw_dispatch<1>(p, bm, relu, st);
       if (a->ks == 3) return rt_gw_dispatch<3>(p, bm, relu, st);
       if (a->ks == 5) return rt_gw_dispatch<5>(p, bm, relu, st);
       if (a->ks == 17) return rt_gw_dispatch<17>(p, bm, relu, st);

@@ -86,11 +86,11 @@ __device__ __forceinline__ void pack_batched_tile(const int64_t* e, int lb, unsi
         if (mode != 1 && mode != 4) {
           const int co = co0 + r, ci = ci0 + tx;
           if (co < cout && ci < cin)
-            dst[mode == 3 ? stream_index(co, j, ci, ks) : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci] = buf[r * 33 + tx];
+            dst[mode == 3 ? stream_index(off + co, j, ci, ks) : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci] = buf[r * 33 + tx];
         } else {
           const int ci = ci0 + r, co = co0 + tx;
           if (co < cout && ci < cin)
-            dst[mode == 4 ? stream_index(ci, ks - 1 - j, co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co] = buf[tx * 33 + r];
+            dst[mode == 4 ? stream_index(ci, ks - 1 - j, off + co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co] = buf[tx * 33 + r];
         }
       }
       __syncthreads();
@@ -141,7 +141,7 @@ __device__ __forceinline__ void pack_batched_tile(const int64_t* e, int lb, unsi
           for (int r = 0; r < 32; r += 8) {
             const int co = co_w + r;
             if (co < cout) {
-              const int64_t d = mode == 3 ? stream_index(co, j, ci, ks)
+              const int64_t d = mode == 3 ? stream_index(off + co, j, ci, ks)
                                           : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
               dst[d] = buf[(ty + r) * pitch + tx * ks + j];
             }
@@ -154,7 +154,7 @@ __device__ __forceinline__ void pack_batched_tile(const int64_t* e, int lb, unsi
         for (int j = 0; j < ks; ++j) {
           for (int r = ty; r < cv; r += 8) {
             const int ci = ci0 + cs + r;
-            const int64_t d = mode == 4 ? stream_index(ci, ks - 1 - j, co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
+            const int64_t d = mode == 4 ? stream_index(ci, ks - 1 - j, off + co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
             dst[d] = buf[tx * pitch + r * ks + j];
           }
         }

@@ -158,9 +158,13 @@ class PromptTTSMDNDurCFG(nn.Module):
         # the prompt branch (BERT -> adaptor -> style MDN head) depends on the prompt only and feeds only the style loss: issued
         # now (round 5 issued it after the phoneme encoder: the main stream then waited ~0.7 ms for it at the losses)
         bs = _branch_stream(dev, 0) if branches else None
-        if bs is not None and PROMPT_FIRST:
-            bs.wait_stream(torch.cuda.current_stream())
-            with ops.unpinned(), torch.cuda.stream(bs):
+        if PROMPT_FIRST:  # (same program order -- dropout seeds -- with and without the branch stream)
+            if bs is not None:
+                bs.wait_stream(torch.cuda.current_stream())
+                with ops.unpinned(), torch.cuda.stream(bs):
+                    prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
+                    y_sty = self.style_mdn.raw(prompt_emb.transpose(-1, -2))
+            else:
                 prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
                 y_sty = self.style_mdn.raw(prompt_emb.transpose(-1, -2))
         plen = phone_lengths.to(device=dev, dtype=torch.int32)
@@ -177,14 +181,15 @@ class PromptTTSMDNDurCFG(nn.Module):
         else:
             style_emb = self._norm_style(self.reference_encoder(mel, frame_lengths))
         x = PF.bcast_add_rows(x, style_emb.float().reshape(style_emb.shape[0], -1))  # every phone, padded ones too (model.py:111)
-        if bs is not None and not PROMPT_FIRST:
-            bs.wait_stream(torch.cuda.current_stream())
-            with ops.unpinned(), torch.cuda.stream(bs):
+        if not PROMPT_FIRST:
+            if bs is not None:
+                bs.wait_stream(torch.cuda.current_stream())
+                with ops.unpinned(), torch.cuda.stream(bs):
+                    prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
+                    y_sty = self.style_mdn.raw(prompt_emb.transpose(-1, -2))
+            else:
                 prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
                 y_sty = self.style_mdn.raw(prompt_emb.transpose(-1, -2))
-        elif bs is None:
-            prompt_emb = self._norm_style(self.prompt_encoder(prompt, dev))
-            y_sty = self.style_mdn.raw(prompt_emb.transpose(-1, -2))
         vb = (bs, sa) if (branches and BRANCH_STREAMS == "3") else None
         h, y_dur, pv, _, _ = self.variance_adaptor.forward_cl(x, plen, flen, None, duration.squeeze(1), log_cf0.squeeze(1), None,
                                                               branch_streams=vb, raw=True, Tf=Tf)

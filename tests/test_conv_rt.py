@@ -24,6 +24,8 @@ def _mk(dev, B, T, cin, ks, seed):
     (9, 650, 256, 17, 1, None, True, False, 160),     # 160-row blocks of the global-weights form (ten row tiles per wave; T > 512, see above)
     (7, 700, 512, 3, 8, "relu", True, True, 160),
     (65, 459, 256, 5, 1, "relu", False, False, 0),    # 260 blocks of 128 rows: the launcher takes 160 rows on its own
+    (12, 650, 1024, 1, 1, None, False, False, 128),   # 1 x 1 with a long K (round 6: the DiffNet conditioner's data gradient, K = 10 240)
+    (9, 700, 2560, 1, 1, None, True, True, 0),
 ])
 def test_row_tile_conv_is_bit_identical_to_the_tile_kernel(dev, monkeypatch, B, T, cin, ks, dil, act, masked, use_res, bm):
     from promptttspp_amd import ops
