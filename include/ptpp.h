@@ -162,6 +162,17 @@ int ptpp_conv1d_rt_fwd(const ptpp_conv1d_args* a, const void* wstream, float res
 int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* aux, int ldaux, float aux_scale,
                            void* stream);
 
+/* Row-tile form for the phone-level feed-forward convs of the Conformer blocks (modules/esp/transformer/multi_layer_conv.py:52-67:
+ * Conv1d 256 -> 1024 -> 256, k = 9; round 6): bf16, Cout %% 256 == 0 (column groups of 256 over one x window), Cin %% 128 == 0, ks = 9,
+ * act none / ReLU, masks, residual, and dropout on the conv term (the epilogue of ptpp_conv1d_fwd_ex).  wstream: the weight in pack
+ * mode 3 (forward) / 4 (data gradient); more than 256 operand rows are laid out as one stream per group of 256, back to back.
+ * workspace (optional, as ptpp_conv1d_fwd_ws): with few blocks and a long Cin the input channels are split over blocks, f32
+ * partial sums go through it and a finishing launch applies the epilogue.  Within a split the accumulation order is the tile
+ * kernel's; across splits it is this kernel's own (results agree with ptpp_conv1d_fwd_ws to f32 summation order, not bit for bit). */
+int ptpp_conv1d_rt_ex_supported(int cin, int cout, int ks, int dil, int act, int dtype);
+int ptpp_conv1d_rt_fwd_ex(const ptpp_conv1d_args* a, const void* wstream, float res_scale, float drop_p, uint64_t drop_seed,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same with an optional scratch (16-byte aligned device memory, NULL = none): layers with few
  * output tiles and a long K (Conformer FFN k = 9, BERT FFN) are then split over K -- f32 partial sums
  * of B*T*Cout elements per split go through the scratch and a second launch adds them and applies the
@@ -920,6 +931,8 @@ typedef struct {
   const uint64_t* seeds;                        /* HOST [6]: ffm w1, ffm w2, attention out, pw2, ff w1, ff w2 */
   float p_ffn, p_drop, bn_momentum, bn_eps;
   int32_t B, T, C, F, H, L, ks_ffn, ks_dw, variant, bn_train, save, dtype;
+  const void* ffn_ws[4];                        /* round 6: ffm_w1, ffm_w2, ff_w1, ff_w2 as operand streams (pack mode 3) or NULL:
+                                                   those convs on ptpp_conv1d_rt_fwd_ex (all four or none) */
 } ptpp_conformer_block_fwd_args;
 size_t ptpp_conformer_block_slab_bytes(int B, int T, int C, int F, int H, int L, int dtype);
 int ptpp_conformer_block_fwd(const ptpp_conformer_block_fwd_args* a, void* stream);
@@ -949,6 +962,7 @@ typedef struct {
   const uint64_t* seeds;
   float p_ffn, p_drop;
   int32_t B, T, C, F, H, L, ks_ffn, ks_dw, variant, bn_train, dtype;
+  const void* ffn_wts[4];                       /* round 6: ffm_w1t, ffm_w2t, ff_w1t, ff_w2t as operand streams (pack mode 4) or NULL */
 } ptpp_conformer_block_bwd_args;
 size_t ptpp_conformer_block_bwd_scratch_bytes(int B, int T, int C, int F, int H, int L, int dtype);
 int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, void* stream);

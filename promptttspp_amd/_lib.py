@@ -180,7 +180,8 @@ class ConformerFwdArgs(Structure):
                 ("slab", c_void_p), ("slab_bytes", ctypes.c_size_t), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t),
                 ("red_scratch", c_void_p), ("red_bytes", ctypes.c_size_t), ("seeds", c_void_p),
                 ("p_ffn", c_float), ("p_drop", c_float), ("bn_momentum", c_float), ("bn_eps", c_float)] + \
-               [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "ks_ffn", "ks_dw", "variant", "bn_train", "save", "dtype")]
+               [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "ks_ffn", "ks_dw", "variant", "bn_train", "save", "dtype")] + \
+               [("ffn_ws", c_void_p * 4)]
 
 
 class ConformerBwdArgs(Structure):
@@ -193,7 +194,8 @@ class ConformerBwdArgs(Structure):
                 ("ws_main", c_void_p), ("ws_main_bytes", ctypes.c_size_t), ("ws_side", c_void_p), ("ws_side_bytes", ctypes.c_size_t),
                 ("red_scratch", c_void_p), ("red_bytes", ctypes.c_size_t), ("side_stream", c_void_p), ("seeds", c_void_p),
                 ("p_ffn", c_float), ("p_drop", c_float)] + \
-               [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "ks_ffn", "ks_dw", "variant", "bn_train", "dtype")]
+               [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "ks_ffn", "ks_dw", "variant", "bn_train", "dtype")] + \
+               [("ffn_wts", c_void_p * 4)]
 
 
 class WgradGProblem(Structure):
@@ -306,6 +308,8 @@ SIGNATURES = {
     "ptpp_adamw_step": (I, [P, I, P, c_longlong, P, P, F, F, F, F, I, F, P]),
     "ptpp_diffnet_stack_fwd": (I, [POINTER(DiffNetFwdArgs), P]),
     "ptpp_conv1d_rt_supported": (I, [I, I, I, I, I, I]),
+    "ptpp_conv1d_rt_ex_supported": (I, [I, I, I, I, I, I]),
+    "ptpp_conv1d_rt_fwd_ex": (I, [POINTER(ConvArgs), P, ctypes.c_float, ctypes.c_float, U64, P, SZ, P]),
     "ptpp_conv1d_rt_fwd": (I, [POINTER(ConvArgs), P, ctypes.c_float, P]),
     "ptpp_conv1d_rt_fwd_aux": (I, [POINTER(ConvArgs), P, ctypes.c_float, P, I, ctypes.c_float, P]),
     "ptpp_diffnet_layer_supported": (I, [I, I]),

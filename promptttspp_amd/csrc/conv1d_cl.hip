@@ -491,6 +491,34 @@ extern "C" int ptpp_conv1d_fwd_ws(const ptpp_conv1d_args* a, const void* res2, i
               : launch_tiles<bf16_raw, 4>(p, st, workspace, workspace_bytes);
 }
 
+// The epilogue pass over f32 partial sums [nsplit][B][T][Cout] that ANOTHER kernel produced (the row-tile conv's split over Cin,
+// conv1d_rt.hip): conv_splitk_finish_kernel with the epilogue of ptpp_conv1d_fwd_ex on these arguments (bf16).
+int ptpp_conv_splitk_finish_bf16(const ptpp_conv1d_args* a, float res_scale, float drop_p, uint64_t drop_seed, float* ws, int nsplit,
+                                 hipStream_t st) {
+  ConvP p;
+  p.x = a->x; p.wp = nullptr; p.bias = a->bias; p.res = a->res; p.res2 = nullptr; p.y = a->y;
+  p.lengths = a->lengths;
+  p.B = a->B; p.T = a->T; p.Cin = a->Cin; p.Cout = a->Cout; p.ks = a->ks; p.dil = a->dil; p.pad = a->pad;
+  p.ldx = a->ldx; p.ldy = a->ldy; p.ldr = a->ldr; p.ldr2 = 0;
+  p.cinp = a->Cin;
+  p.act = a->act; p.in_mask = a->in_mask; p.out_mask = a->out_mask;
+  p.out_scale = a->out_scale; p.res_scale = res_scale;
+  p.drop_thresh16 = drop_p > 0.f ? (unsigned)(drop_p * 65536.f + 0.5f) : 0u;
+  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - p.drop_thresh16 / 65536.f) : 1.f;
+  p.drop_seed = drop_seed;
+  p.ws = ws;
+  p.nsplit = nsplit;
+  p.nMT = p.nNT = 0;
+  p.post_skip = nullptr; p.post_dnext = nullptr; p.post_yin = nullptr; p.post_C = 0; p.post_init = 0;
+  p.gate_a = nullptr; p.gate_da = nullptr; p.gate_ldda = 0; p.gate_save = nullptr; p.gate_lds = 0;
+  const int64_t nvec = (int64_t)p.B * p.T * (p.Cout >> 2);
+  int64_t fb = (nvec + 255) / 256;
+  if (fb > 4096) fb = 4096;
+  hipLaunchKernelGGL(conv_splitk_finish_kernel<bf16_raw>, dim3((unsigned)fb), dim3(256), 0, st, p);
+  PTPP_CHECK_LAUNCH("conv1d (split finish)");
+  return PTPP_OK;
+}
+
 extern "C" int ptpp_conv1d_fwd_ex(const ptpp_conv1d_args* a, const void* res2, int ldr2, float res_scale,
                                   float drop_p, uint64_t drop_seed, void* stream) {
   return ptpp_conv1d_fwd_ws(a, res2, ldr2, res_scale, drop_p, drop_seed, nullptr, 0, stream);

@@ -49,7 +49,21 @@ struct RtP {
   const bf16_raw* gate_a;
   bf16_raw* gate_da;
   int ldda;
+  // round 6 (ptpp_conv1d_rt_fwd_ex, conv1d_rt_gw_kernel only): output channels in groups of 256 (blockIdx.y; the operand stream of
+  // group g starts grp_stride bytes further, bias / y / res / dropout indices move by 256 g), dropout on the conv term, and a
+  // split of the Cin trips over blockIdx.z whose raw f32 partial sums go to `ws` (EPI = 2) for conv_splitk_finish_kernel
+  int cout_total;
+  int64_t grp_stride;
+  unsigned drop_thresh16;
+  float drop_inv_keep;
+  unsigned long long drop_seed;
+  float* ws;
+  int split_trips;  // trips (two 64-channel chunks) per split; Cin / 128 when there is no split
 };
+inline void rtp_plain(RtP& p) {  // the fields of the forms that came before round 6
+  p.cout_total = RT_N; p.grp_stride = 0; p.drop_thresh16 = 0; p.drop_inv_keep = 1.f; p.drop_seed = 0; p.ws = nullptr;
+  p.split_trips = p.Cin >> 7;
+}
 
 __device__ __forceinline__ void rt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -303,7 +317,10 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
   const int T = p.T, dil = p.dil;
   const int xrows = (BM + (KS - 1) * dil + 7) & ~7;
   const int np = xrows >> 3;
-  const int ntrips = p.Cin >> 7;  // two 64-channel chunks per trip
+  const int grp = blockIdx.y, split = blockIdx.z;  // output-channel group of 256; share of the Cin trips (0 / 0 for the plain forms)
+  const int trip0 = split * p.split_trips;
+  const int ntrips = min(p.split_trips, (p.Cin >> 7) - trip0);  // two 64-channel chunks per trip
+  const int c0 = 2 * trip0;                                      // first 64-channel chunk of this block
   const int len_raw = p.lengths ? p.lengths[b] : T;
 
   const bf16_raw* xb = p.x + (int64_t)b * T * p.ldx;
@@ -317,7 +334,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
   u32x4 W[4][2];
   const uint32_t gw_off = (uint32_t)(((wave * 32 + lr) * 4 + (lg ^ swz<4>(wave * 32 + lr))) * 16);
-  const char* wptr = reinterpret_cast<const char*>(p.wstream);  // stage of the next group to request
+  // stage of the next group to request: a trip is 4 KS stages of 16 KiB
+  const char* wptr = reinterpret_cast<const char*>(p.wstream) + (int64_t)grp * p.grp_stride + (int64_t)trip0 * (4 * KS * RT_STAGE_U4 * 16);
   auto ldg = [&](u32x4 (&w)[2]) __attribute__((always_inline)) {
     asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
                  : "=&v"(w[0]), "=&v"(w[1]) : "v"(gw_off), "s"(wptr) : "memory");
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
     const int q = min(wave + 8 * k, np - 1);
     const int ts0 = t0 - p.pad + q * 8;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(xs_lds + (uint32_t)((par * xrows + q * 8) * 128));
-    const bf16_raw* base = xb + (int64_t)ts0 * p.ldx + ci * 64;
+    const bf16_raw* base = xb + (int64_t)ts0 * p.ldx + (c0 + ci) * 64;
     const uint32_t voff = gx_voff ^ (uint32_t)((q & 1) << 6);
     if (ts0 >= 0 && ts0 + 7 < Tin) {
       glds16_s(base, voff, dst);
@@ -497,12 +515,25 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
     }
     return;
   }
+  if constexpr (EPI == 2) {  // split over Cin: raw f32 partial sums [split][B][T][cout_total], epilogue in conv_splitk_finish_kernel
+    float* wsb = p.ws + ((int64_t)split * p.B + b) * T * p.cout_total + grp * RT_N + wave * 32 + lg * 8;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+      const int t = t0 + fm * 16 + lr;
+      if (t < T) {
+        *reinterpret_cast<f32x4*>(wsb + (int64_t)t * p.cout_total) = acc[fm][0];
+        *reinterpret_cast<f32x4*>(wsb + (int64_t)t * p.cout_total + 4) = acc[fm][1];
+      }
+    }
+    return;
+  }
   // ---- epilogue: a lane holds 8 consecutive channels (wave * 32 + lg * 8 ..) of row fm * 16 + lr; conv_epilogue_act arithmetic
   {
     bf16_raw* yb = p.y + (int64_t)b * T * p.ldy;
     const bf16_raw* rb = p.res ? p.res + (int64_t)b * T * p.ldr : nullptr;
     const float e_scale = p.out_scale, e_rscale = p.res_scale;
-    const int ch = wave * 32 + lg * 8;
+    const int ch = grp * RT_N + wave * 32 + lg * 8;
+    const unsigned e_dth = p.drop_thresh16;
     f32x4 bia[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) bia[u] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ch + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -527,6 +558,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
           if (p.bias) v[u] += bia[u];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[u][e] = keep ? act_apply_c<ACT>(v[u][e]) * e_scale : 0.f;
+          if (e_dth) v[u] *= drop_mask4(p.drop_seed, (uint64_t)(((int64_t)b * T + t) * p.cout_total + ch + 4 * u) >> 2, e_dth, p.drop_inv_keep);
         }
         if (rb) {
           const uint4 r = rr[df];
@@ -572,7 +604,9 @@ int rt_gw_launch(const RtP& p, hipStream_t st) {
       lds_limit_mark(kp);
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(512), smem, st, p);
+  const unsigned ngrp = (unsigned)(p.cout_total / RT_N);
+  const unsigned nsplit = (unsigned)(((p.Cin >> 7) + p.split_trips - 1) / p.split_trips);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT), ngrp, nsplit), dim3(512), smem, st, p);
   PTPP_CHECK_LAUNCH("conv1d_rt_fwd");
   return PTPP_OK;
 }
@@ -652,6 +686,7 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
   p.out_scale = a->out_scale; p.res_scale = res_scale;
   p.aux = reinterpret_cast<bf16_raw*>(aux); p.ldaux = ldaux; p.aux_scale = aux_scale;
   p.gate_a = nullptr; p.gate_da = nullptr; p.ldda = 0;
+  rtp_plain(p);
   // the global-weights form (1 x 8 wave grid) for the tap counts of the model's layers; PTPP_CONV_RT_GW=0: the ring form
   const char* gwe = getenv("PTPP_CONV_RT_GW");
   const bool gw_ok = !(gwe && gwe[0] == '0') && (a->Cin & 127) == 0 && (a->ks == 1 || a->ks == 3 || a->ks == 5 || a->ks == 17);
@@ -674,6 +709,101 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
   if (bm == 128) return relu ? rt_launch<4, PTPP_ACT_RELU>(p, st) : rt_launch<4, PTPP_ACT_NONE>(p, st);
   if (bm == 96) return relu ? rt_launch<3, PTPP_ACT_RELU>(p, st) : rt_launch<3, PTPP_ACT_NONE>(p, st);
   return relu ? rt_launch<2, PTPP_ACT_RELU>(p, st) : rt_launch<2, PTPP_ACT_NONE>(p, st);
+}
+
+// ---- round 6: the phone-level feed-forward convs of the Conformer blocks (reference modules/esp/transformer/multi_layer_conv.py:52-67:
+// 256 -> 1024 -> 256, k = 9; their data gradients are the same two shapes) on the global-weights form.  ~3 000 rows in ~20 utterances
+// are few tiles for 256 CUs: the 1024-channel output is four column groups (blockIdx.y) over the same x window, the 1024-channel
+// input is split over blockIdx.z (f32 partial sums, epilogue in conv_splitk_finish_kernel), 64-row blocks keep the padding of
+// utterances of ~160 phones at 17 % (128-row tiles: 34 %).  Epilogue with dropout on the conv term (ptpp_conv1d_fwd_ex's
+// arithmetic); the K order inside a split is the tile kernel's, the order ACROSS splits is this kernel's own.
+int ptpp_conv_splitk_finish_bf16(const ptpp_conv1d_args* a, float res_scale, float drop_p, uint64_t drop_seed, float* ws, int nsplit,
+                                 hipStream_t st);
+
+extern "C" int ptpp_conv1d_rt_ex_supported(int cin, int cout, int ks, int dil, int act, int dtype) {
+  const char* gwe = getenv("PTPP_CONV_RT_GW");
+  if (gwe && gwe[0] == '0') return 0;
+  const char* exe = getenv("PTPP_CONV_RT_EX");  // (A/B knob: 0 = the feed-forward convs stay on the tile kernels)
+  if (exe && exe[0] == '0') return 0;
+  if (dtype != PTPP_BF16 || cout <= 0 || cout % RT_N || cout > 4096 || cin <= 0 || (cin & 127) || ks != 9 || dil != 1) return 0;
+  return act == PTPP_ACT_NONE || act == PTPP_ACT_RELU;
+}
+
+extern "C" int ptpp_conv1d_rt_fwd_ex(const ptpp_conv1d_args* a, const void* wstream, float res_scale, float drop_p, uint64_t drop_seed,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  PTPP_CHECK_ARG(a && a->x && a->y && wstream, "conv1d_rt_fwd_ex: null pointer");
+  PTPP_CHECK_ARG(ptpp_conv1d_rt_ex_supported(a->Cin, a->Cout, a->ks, a->dil, a->act, a->dtype),
+                 "conv1d_rt_fwd_ex: unsupported shape (bf16, Cout %% 256 == 0, Cin %% 128 == 0, ks = 9, act none / relu; Cin %d Cout %d ks %d dil %d act %d)",
+                 a->Cin, a->Cout, a->ks, a->dil, a->act);
+  PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && a->pad >= 0 && a->pad <= (a->ks - 1) * a->dil && (a->ldx & 7) == 0 && (a->ldy & 7) == 0 &&
+                     (!a->res || (a->ldr & 7) == 0),
+                 "conv1d_rt_fwd_ex: bad geometry (B %d T %d pad %d ldx %d ldy %d ldr %d)", a->B, a->T, a->pad, a->ldx, a->ldy, a->ldr);
+  PTPP_CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->res | (uintptr_t)wstream | (uintptr_t)a->bias) & 15) == 0,
+                 "conv1d_rt_fwd_ex: operands must be 16-byte aligned");
+  PTPP_CHECK_ARG(!(a->in_mask || a->out_mask) || a->lengths, "conv1d_rt_fwd_ex: masks need lengths");
+  PTPP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "conv1d_rt_fwd_ex: bad dropout p");
+  RtP p;
+  p.x = reinterpret_cast<const bf16_raw*>(a->x);
+  p.wstream = reinterpret_cast<const uint4*>(wstream);
+  p.bias = a->bias;
+  p.res = reinterpret_cast<const bf16_raw*>(a->res);
+  p.y = reinterpret_cast<bf16_raw*>(a->y);
+  p.lengths = a->lengths;
+  p.B = a->B; p.T = a->T; p.Cin = a->Cin; p.ks = a->ks; p.dil = a->dil; p.pad = a->pad;
+  p.ldx = a->ldx; p.ldy = a->ldy; p.ldr = a->ldr;
+  p.act = a->act; p.in_mask = a->in_mask; p.out_mask = a->out_mask;
+  p.out_scale = a->out_scale; p.res_scale = res_scale;
+  p.aux = nullptr; p.ldaux = 0; p.aux_scale = 0.f;
+  p.gate_a = nullptr; p.gate_da = nullptr; p.ldda = 0;
+  rtp_plain(p);
+  p.cout_total = a->Cout;
+  const int ngrp = a->Cout / RT_N, ntr = a->Cin >> 7;
+  p.grp_stride = (int64_t)(a->Cin >> 6) * a->ks * 2 * RT_STAGE_U4 * 16;  // one group's stream: (Cin / 64) chunks x ks taps x 2 stages of 16 KiB
+  p.drop_thresh16 = drop_p > 0.f ? (unsigned)(drop_p * 65536.f + 0.5f) : 0u;
+  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - p.drop_thresh16 / 65536.f) : 1.f;
+  p.drop_seed = drop_seed;
+  // rows per block and the split of the Cin trips: least (rounds of one-block-per-CU) x (relative block time)
+  if (workspace && ((uintptr_t)workspace & 15)) workspace = nullptr;
+  const int64_t slab = (int64_t)a->B * a->T * a->Cout * (int64_t)sizeof(float);
+  const int cand[3] = {128, 96, 64};
+  const float tblk[3] = {1.f, 0.78f, 0.6f};
+  int bm = 64, nsplit = 1;
+  float best = 1e30f;
+  const char* fbm = getenv("PTPP_CONV_RT_BM");
+  const char* fns = getenv("PTPP_CONV_RT_NSPLIT");
+  for (int i = 0; i < 3; ++i) {
+    if (fbm && atoi(fbm) != cand[i] && (atoi(fbm) == 64 || atoi(fbm) == 96 || atoi(fbm) == 128)) continue;
+    const int64_t nb0 = (int64_t)a->B * ((a->T + cand[i] - 1) / cand[i]) * ngrp;
+    int ns = 1;
+    if (workspace && ntr >= 2 && nb0 < 160) {
+      ns = (int)((224 + nb0 - 1) / nb0);
+      if (ns > ntr) ns = ntr;
+      if ((int64_t)ns * slab > (int64_t)workspace_bytes) ns = (int)((int64_t)workspace_bytes / slab);
+      if (ns < 2) ns = 1;
+    }
+    if (fns && workspace && atoi(fns) >= 1 && atoi(fns) <= ntr && (int64_t)atoi(fns) * slab <= (int64_t)workspace_bytes) ns = atoi(fns);
+    const int st_ = (ntr + ns - 1) / ns;
+    ns = (ntr + st_ - 1) / st_;
+    const int64_t nb = nb0 * ns;
+    const float cost = (float)((nb + 255) / 256) * tblk[i] * (float)st_ + (ns > 1 ? 0.15f * (float)ntr : 0.f);
+    if (cost < best - 1e-3f) { best = cost; bm = cand[i]; nsplit = ns; }
+  }
+  p.split_trips = (ntr + nsplit - 1) / nsplit;
+  p.nMT = (a->T + bm - 1) / bm;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool relu = a->act == PTPP_ACT_RELU;
+  if (nsplit > 1) {
+    p.ws = reinterpret_cast<float*>(workspace);
+    int rc;
+    if (bm == 128) rc = rt_gw_launch<8, 9, PTPP_ACT_NONE, 2>(p, st);
+    else if (bm == 96) rc = rt_gw_launch<6, 9, PTPP_ACT_NONE, 2>(p, st);
+    else rc = rt_gw_launch<4, 9, PTPP_ACT_NONE, 2>(p, st);
+    if (rc != PTPP_OK) return rc;
+    return ptpp_conv_splitk_finish_bf16(a, res_scale, drop_p, drop_seed, p.ws, nsplit, st);
+  }
+  if (bm == 128) return relu ? rt_gw_launch<8, 9, PTPP_ACT_RELU>(p, st) : rt_gw_launch<8, 9, PTPP_ACT_NONE>(p, st);
+  if (bm == 96) return relu ? rt_gw_launch<6, 9, PTPP_ACT_RELU>(p, st) : rt_gw_launch<6, 9, PTPP_ACT_NONE>(p, st);
+  return relu ? rt_gw_launch<4, 9, PTPP_ACT_RELU>(p, st) : rt_gw_launch<4, 9, PTPP_ACT_NONE>(p, st);
 }
 
 // ---- the DiffNet output projection's data gradient with the gate backward in its epilogue, on the row-tile engine ---------------
@@ -730,6 +860,7 @@ extern "C" int ptpp_conv1d_rt_gate_bwd(const ptpp_conv1d_args* a, const void* ws
   p.gate_a = reinterpret_cast<const bf16_raw*>(act);
   p.gate_da = reinterpret_cast<bf16_raw*>(da);
   p.ldda = ldda;
+  rtp_plain(p);
   const int bm = rt_bm_for(a->B, a->T, true);
   p.nMT = (a->T + bm - 1) / bm;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -27,6 +27,12 @@ __device__ __forceinline__ int64_t stream_index(int n, int tap, int k, int ks) {
   return ((int64_t)(ci * ks + tap) * 2 + kh) * 8192 + (q * 4 + cp) * 8 + e;
 }
 
+// operand rows beyond 256 (round 6: the 1024-channel side of the Conformer feed-forward convs): one stream per group of 256 rows,
+// groups back to back; `inner` = the K length of a tap (all of it: the stream of a group has inner / 64 chunks)
+__device__ __forceinline__ int64_t stream_index_g(int n, int tap, int k, int ks, int inner) {
+  return (int64_t)(n >> 8) * ((int64_t)(inner >> 6) * ks * 2 * 8192) + stream_index(n & 255, tap, k, ks);
+}
+
 template <typename T>
 __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp, int cout, int cin, int ks,
                                  int mode, int rows, int inner, int innerp) {
@@ -44,7 +50,7 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ wp
       else
         v = w[((int64_t)c * cin + r) * ks + (ks - 1 - j)];
     }
-    Elem<T>::st(wp + (mode >= 3 ? stream_index(r, j, c, ks) : i), v);
+    Elem<T>::st(wp + (mode >= 3 ? stream_index_g(r, j, c, ks, innerp) : i), v);
   }
 }
 
@@ -86,11 +92,11 @@ __device__ __forceinline__ void pack_batched_tile(const int64_t* e, int lb, unsi
         if (mode != 1 && mode != 4) {
           const int co = co0 + r, ci = ci0 + tx;
           if (co < cout && ci < cin)
-            dst[mode == 3 ? stream_index(off + co, j, ci, ks) : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci] = buf[r * 33 + tx];
+            dst[mode == 3 ? stream_index_g(off + co, j, ci, ks, innerp) : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci] = buf[r * 33 + tx];
         } else {
           const int ci = ci0 + r, co = co0 + tx;
           if (co < cout && ci < cin)
-            dst[mode == 4 ? stream_index(ci, ks - 1 - j, off + co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co] = buf[tx * 33 + r];
+            dst[mode == 4 ? stream_index_g(ci, ks - 1 - j, off + co, ks, innerp) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co] = buf[tx * 33 + r];
         }
       }
       __syncthreads();
@@ -141,7 +147,7 @@ __device__ __forceinline__ void pack_batched_tile(const int64_t* e, int lb, unsi
           for (int r = 0; r < 32; r += 8) {
             const int co = co_w + r;
             if (co < cout) {
-              const int64_t d = mode == 3 ? stream_index(off + co, j, ci, ks)
+              const int64_t d = mode == 3 ? stream_index_g(off + co, j, ci, ks, innerp)
                                           : ((off + (mode == 2 ? gate_row_dst(co, cout) : co)) * ks + j) * innerp + ci;
               dst[d] = buf[(ty + r) * pitch + tx * ks + j];
             }
@@ -154,7 +160,7 @@ __device__ __forceinline__ void pack_batched_tile(const int64_t* e, int lb, unsi
         for (int j = 0; j < ks; ++j) {
           for (int r = ty; r < cv; r += 8) {
             const int ci = ci0 + cs + r;
-            const int64_t d = mode == 4 ? stream_index(ci, ks - 1 - j, off + co, ks) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
+            const int64_t d = mode == 4 ? stream_index_g(ci, ks - 1 - j, off + co, ks, innerp) : ((int64_t)ci * ks + (ks - 1 - j)) * innerp + off + co;
             dst[d] = buf[tx * pitch + r * ks + j];
           }
         }
@@ -248,8 +254,8 @@ extern "C" int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin
   const bool tr = mode == 1 || mode == 4;
   const int rows = !tr ? cout : cin;
   const int inner = !tr ? cin : cout;
-  PTPP_CHECK_ARG(mode < 3 || (dtype == PTPP_BF16 && rows == 256 && inner % 64 == 0),
-                 "pack_conv_weight: the operand stream (modes 3 / 4) needs bf16, 256 operand rows and inner %% 64 == 0 (rows %d, inner %d)",
+  PTPP_CHECK_ARG(mode < 3 || (dtype == PTPP_BF16 && rows % 256 == 0 && inner % 64 == 0),
+                 "pack_conv_weight: the operand stream (modes 3 / 4) needs bf16, operand rows %% 256 == 0 and inner %% 64 == 0 (rows %d, inner %d)",
                  rows, inner);
   const int innerp = ptpp_conv_cin_padded(inner, dtype);
   const int64_t n = (int64_t)rows * ks * innerp;

@@ -253,6 +253,14 @@ static int linear_like_ops(const ptpp_conv1d_args& c, float drop_p, uint64_t see
   return ptpp_conv1d_fwd_ex(&c, nullptr, 0, 1.0f, drop_p, seed, stream);
 }
 
+// A feed-forward conv of a Conformer block: on the row-tile engine (ptpp_conv1d_rt_fwd_ex) when its operand stream was handed
+// over and the shape qualifies -- the rule of promptttspp_amd/ops.py::conv1d (conv1d_rt_ex_ok) -- else as every other launch
+static int ffn_conv(const ptpp_conv1d_args& c, const void* wstream, float drop_p, uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
+  if (wstream && ptpp_conv1d_rt_ex_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype))
+    return ptpp_conv1d_rt_fwd_ex(&c, wstream, 1.0f, drop_p, seed, ws, ws_bytes, stream);
+  return linear_like_ops(c, drop_p, seed, ws, ws_bytes, stream);
+}
+
 extern "C" int ptpp_encoder_layers_fwd(const ptpp_encoder_layers_fwd_args* a, void* stream) {
   ST_CHECK_ARG(a && a->h_in && a->h_out && a->qkv_wp && a->qkv_b && a->ao_wp && a->ao_b && a->ln1_g && a->ln1_b && a->i_wp && a->i_b &&
                    a->o_wp && a->o_b && a->ln2_g && a->ln2_b && a->scratch && a->seeds,
@@ -486,10 +494,10 @@ extern "C" int ptpp_conformer_block_fwd(const ptpp_conformer_block_fwd_args* a, 
   ST_TRY(ln_fwd_plain(a->x, w.ln_g[0], w.ln_b[0], sl(S, lo.n1), stats, stats + R, nullptr, B, T, C, 0, dt, stream));
   ptpp_conv1d_args c = conv_args(sl(S, lo.n1), C, w.ffm_w1, w.ffm_b1, nullptr, 0, sl(S, lo.h1), F, len, B, T, C, F, kf, 1, pf, PTPP_ACT_RELU,
                                  1, 1, dt);
-  ST_TRY(linear_like_ops(c, a->p_ffn, seed(0, a->p_ffn), a->ws, a->ws_bytes, stream));
+  ST_TRY(ffn_conv(c, a->ffn_ws[0], a->p_ffn, seed(0, a->p_ffn), a->ws, a->ws_bytes, stream));
   c = conv_args(sl(S, lo.h1), F, w.ffm_w2, w.ffm_b2, a->x, C, sl(S, lo.x1), C, len, B, T, F, C, kf, 1, pf, PTPP_ACT_NONE, 0, 1, dt);
   c.out_scale = 0.5f;
-  ST_TRY(linear_like_ops(c, a->p_drop, seed(1, a->p_drop), a->ws, a->ws_bytes, stream));
+  ST_TRY(ffn_conv(c, a->ffn_ws[1], a->p_drop, seed(1, a->p_drop), a->ws, a->ws_bytes, stream));
   // ---- self-attention: x2 = x1 + drop(mask out(attn(...))) ----
   ST_TRY(ln_fwd_plain(sl(S, lo.x1), w.ln_g[1], w.ln_b[1], sl(S, lo.n2), stats + 2 * R, stats + 3 * R, nullptr, B, T, C, 0, dt, stream));
   c = conv_args(sl(S, lo.n2), C, w.qkv_w, w.qkv_b, nullptr, 0, sl(S, lo.qkv), 3 * C, nullptr, B, T, C, 3 * C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
@@ -523,10 +531,10 @@ extern "C" int ptpp_conformer_block_fwd(const ptpp_conformer_block_fwd_args* a, 
   // ---- feed-forward ----
   ST_TRY(ln_fwd_plain(sl(S, lo.x3), w.ln_g[3], w.ln_b[3], sl(S, lo.n4), stats + 6 * R, stats + 7 * R, nullptr, B, T, C, 0, dt, stream));
   c = conv_args(sl(S, lo.n4), C, w.ff_w1, w.ff_b1, nullptr, 0, sl(S, lo.h2), F, len, B, T, C, F, kf, 1, pf, PTPP_ACT_RELU, 1, 1, dt);
-  ST_TRY(linear_like_ops(c, a->p_ffn, seed(4, a->p_ffn), a->ws, a->ws_bytes, stream));
+  ST_TRY(ffn_conv(c, a->ffn_ws[2], a->p_ffn, seed(4, a->p_ffn), a->ws, a->ws_bytes, stream));
   c = conv_args(sl(S, lo.h2), F, w.ff_w2, w.ff_b2, sl(S, lo.x3), C, sl(S, lo.x4), C, len, B, T, F, C, kf, 1, pf, PTPP_ACT_NONE, 0, 1, dt);
   c.out_scale = 0.5f;
-  ST_TRY(linear_like_ops(c, a->p_drop, seed(5, a->p_drop), a->ws, a->ws_bytes, stream));
+  ST_TRY(ffn_conv(c, a->ffn_ws[3], a->p_drop, seed(5, a->p_drop), a->ws, a->ws_bytes, stream));
   return ln_fwd_plain(sl(S, lo.x4), w.ln_g[4], w.ln_b[4], a->y, stats + 8 * R, stats + 9 * R, len, B, T, C, 1, dt, stream);
 }
 
@@ -572,14 +580,14 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
 
   // backward of one feed-forward half: gres = gradient w.r.t. res + 0.5 drop(...) ; returns the gradient w.r.t. LN input in t1
   auto ffn_bwd = [&](const void* gres, const void* h, const void* n, const void* w1t, const void* w2t, float* dw1, float* db1, float* dw2,
-                     float* db2, int s1, int s2, void* dz2, void* dzF) -> int {
+                     float* db2, int s1, int s2, void* dz2, void* dzF, const void* w1ts, const void* w2ts) -> int {
     // (dz2 = gres * 0.5 * dropout mask s2, masked rows zero: written by the LayerNorm backward that produced gres)
     ptpp_conv1d_args c = conv_args(dz2, C, w2t, nullptr, nullptr, 0, gF, F, len, B, T, C, F, kf, 1, (kf - 1) - pf, PTPP_ACT_NONE, 0, 0, dt);
-    ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+    ST_TRY(ffn_conv(c, w2ts, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
     ST_TRY(wgrad(h, F, dz2, C, dw2, db2, len, B, T, F, C, kf, pf, 0));
     ST_TRY(ptpp_epilogue_bwd(gF, h, dzF, len, B, T, F, 1.0f, 1, 1, a->p_ffn, seed(s1, a->p_ffn), dt, stream));
     c = conv_args(dzF, F, w1t, nullptr, nullptr, 0, t1, C, len, B, T, F, C, kf, 1, (kf - 1) - pf, PTPP_ACT_NONE, 0, 1, dt);
-    ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+    ST_TRY(ffn_conv(c, w1ts, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
     return wgrad(n, C, dzF, F, dw1, db1, len, B, T, C, F, kf, pf, 1);
   };
 
@@ -588,7 +596,7 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
                       a->red_scratch, a->red_bytes, stream, nullptr, sl(X, sc.dz_c[0]), 0.5f, a->p_drop, seed(5, a->p_drop)));
   // ---- feed-forward ----
   ST_TRY(ffn_bwd(gA, sl(S, lo.h2), sl(S, lo.n4), a->ff_w1t, a->ff_w2t, g.ff_w1, g.ff_b1, g.ff_w2, g.ff_b2, 4, 5, sl(X, sc.dz_c[0]),
-                 sl(X, sc.dz_f[0])));
+                 sl(X, sc.dz_f[0]), a->ffn_wts[2], a->ffn_wts[3]));
   // gradient w.r.t. x3 = gA + LayerNorm input gradient, and the pointwise conv's dropout backward, one pass
   void* dz_pw2 = sl(X, sc.dz_c[1]);
   ST_TRY(ln_bwd_plain(t1, sl(S, lo.x3), w.ln_g[3], stats + 6 * R, stats + 7 * R, gB, g.ln_g[3], g.ln_b[3], len, B, T, C, 0, dt,
@@ -641,7 +649,7 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
                       a->red_scratch, a->red_bytes, stream, gC, sl(X, sc.dz_c[3]), 0.5f, a->p_drop, seed(1, a->p_drop)));  // gradient w.r.t. x1
   // ---- macaron feed-forward ----
   ST_TRY(ffn_bwd(gA, sl(S, lo.h1), sl(S, lo.n1), a->ffm_w1t, a->ffm_w2t, g.ffm_w1, g.ffm_b1, g.ffm_w2, g.ffm_b2, 0, 1, sl(X, sc.dz_c[3]),
-                 sl(X, sc.dz_f[1])));
+                 sl(X, sc.dz_f[1]), a->ffn_wts[0], a->ffn_wts[1]));
   ST_TRY(ln_bwd_plain(t1, a->x, w.ln_g[0], stats, stats + R, a->gx, g.ln_g[0], g.ln_b[0], nullptr, B, T, C, 0, dt, a->red_scratch,
                       a->red_bytes, stream, gA));
   if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));

@@ -100,10 +100,13 @@ def packed(w, dtype, mode=0):
     return _packed_entry((w,), dtype, mode).wp
 
 
-def rt_stream(w, x, cout, ks, dil, act, transposed=False):
+def rt_stream(w, x, cout, ks, dil, act, transposed=False, drop_p=0.0):
     """The weight as the operand stream of the row-tile conv kernel (pack mode 3, or 4 for the data gradient) when the launch
-    ``ops.conv1d(x, ..)`` qualifies for it (ops.conv1d_rt_ok: bf16, 256 output channels, frame-level row count ...), else None."""
-    if not isinstance(w, torch.nn.Parameter) or w.dim() != 3 or not ops.conv1d_rt_ok(x, cout, ks, dil, act):
+    ``ops.conv1d(x, ..)`` qualifies for it (ops.conv1d_rt_ok: bf16, 256 output channels, frame-level row count ...; or
+    ops.conv1d_rt_ex_ok: the Conformer feed-forward convs, dropout allowed), else None."""
+    if not isinstance(w, torch.nn.Parameter) or w.dim() != 3:
+        return None
+    if not ((drop_p == 0 and ops.conv1d_rt_ok(x, cout, ks, dil, act)) or ops.conv1d_rt_ex_ok(x, cout, ks, dil, act)):
         return None
     return packed(w, x.dtype, mode=4 if transposed else 3)
 
@@ -470,7 +473,7 @@ class Conv1dFn(Function):
         if cin % kc:  # tiny channel counts: zero-pad K to the 16-byte operand granule
             xk = torch.nn.functional.pad(x, (0, kc - cin % kc))
             wk = torch.nn.functional.pad(w3.detach(), (0, 0, 0, kc - cin % kc))
-        ws = rt_stream(w, x, cout, ks, cfg.dil, cfg.act) if cfg.drop_p == 0 else None
+        ws = rt_stream(w, x, cout, ks, cfg.dil, cfg.act, drop_p=cfg.drop_p) if cin % kc == 0 else None
         y = ops.conv1d(xk, packed(wk, x.dtype) if ws is None else None, _f32c(b), cout, ks=ks, dil=cfg.dil, pad=cfg.pad, act=cfg.act,
                        lengths=cfg.lengths, in_mask=cfg.in_mask, out_mask=cfg.out_mask, res=res,
                        out_scale=cfg.out_scale, drop_p=cfg.drop_p, drop_seed=seed, wstream=ws)

@@ -267,6 +267,14 @@ class ConformerBlockFn(torch.autograd.Function):
         a.B, a.T, a.C, a.F, a.H, a.L = B, T, C, F_, H, L
         a.ks_ffn, a.ks_dw, a.variant = P[10].shape[2], P[33].shape[-1], _VARIANT[cfg.variant]
         a.bn_train, a.save, a.dtype = int(cfg.training), int(need_bwd), dcode
+        # the feed-forward convs on the row-tile engine where they qualify (operand streams, pack mode 3): ops.conv1d's rule
+        hF = x.new_empty((1, 1, F_))
+        if ops.conv1d_rt_ex_ok(x, F_, P[10].shape[2], 1, "relu") and ops.conv1d_rt_ex_ok(hF, C, P[10].shape[2], 1, None) and \
+                all(isinstance(P[i], torch.nn.Parameter) for i in (10, 12, 14, 16)):
+            for k, i in enumerate((10, 12, 14, 16)):
+                t = PF.packed(P[i], dt, mode=3)
+                keep.append(t)
+                a.ffn_ws[k] = t.data_ptr()
         _lib.check(lib.ptpp_conformer_block_fwd(ctypes.byref(a), ops._stream()), "ptpp_conformer_block_fwd")
         if need_bwd:
             ctx.cfg, ctx.P, ctx.seeds, ctx.dims = cfg, P, seeds, (B, T, C, F_, H, L)
@@ -309,6 +317,13 @@ class ConformerBlockFn(torch.autograd.Function):
         tr = [PF.packed(P[i], dt, mode=1) for i in (10, 12, 14, 16)] + [PF.packed_cat((P[18], P[20], P[22]), dt, mode=1)] + \
              [PF.packed(P[i], dt, mode=1) for i in (25, 29, 31)]
         (a.ffm_w1t, a.ffm_w2t, a.ff_w1t, a.ff_w2t, a.qkv_wt, a.out_wt, a.pw1_wt, a.pw2_wt) = [t.data_ptr() for t in tr]
+        hF = gy.new_empty((1, 1, F_))
+        if ops.conv1d_rt_ex_ok(gy, F_, P[10].shape[2], 1, None) and ops.conv1d_rt_ex_ok(hF, C, P[10].shape[2], 1, None) and \
+                all(isinstance(P[i], torch.nn.Parameter) for i in (10, 12, 14, 16)):
+            for k, i in enumerate((10, 12, 14, 16)):  # the data gradients' operand streams (pack mode 4)
+                t = PF.packed(P[i], dt, mode=4)
+                tr.append(t)
+                a.ffn_wts[k] = t.data_ptr()
         g = a.g
         for i in range(5):
             setattr(g, f"ln_g{i}", tg[i].data_ptr())

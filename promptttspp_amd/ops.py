@@ -216,6 +216,21 @@ def conv1d_rt_ok(x, cout, ks, dil, act, res2=None, drop_p=0.0):
     return ok
 
 
+_rt_ex_ok = {}
+
+
+def conv1d_rt_ex_ok(x, cout, ks, dil, act, res2=None):
+    """Whether ``conv1d`` takes ptpp_conv1d_rt_fwd_ex for this launch when handed the operand stream: the Conformer blocks'
+    phone-level feed-forward convs (bf16, k = 9, Cout % 256 == 0, Cin % 128 == 0, ReLU / none, dropout allowed, any row count)."""
+    if not (CONV_RT and x.is_cuda and x.dtype == torch.bfloat16 and res2 is None and x.stride(2) == 1):
+        return False
+    key = (x.shape[2], cout, ks, dil, act)
+    ok = _rt_ex_ok.get(key)
+    if ok is None:
+        ok = _rt_ex_ok[key] = act in (None, "relu") and bool(_lib.load().ptpp_conv1d_rt_ex_supported(x.shape[2], cout, ks, dil, _ACT[act], BF16))
+    return ok
+
+
 def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mask=False, out_mask=False, res=None,
            out_scale=1.0, res2=None, res_scale=1.0, drop_p=0.0, drop_seed=0, out=None, wstream=None):
     """Channels-last conv / linear with the fused epilogue (see ptpp.h).
@@ -246,6 +261,12 @@ def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mas
     if wstream is not None and conv1d_rt_ok(x, cout, ks, dil, act, res2, drop_p):
         check(lib.ptpp_conv1d_rt_fwd(_conv_args_ref, wstream.data_ptr(), float(res_scale), _stream()), "ptpp_conv1d_rt_fwd")
         return y
+    if wstream is not None and conv1d_rt_ex_ok(x, cout, ks, dil, act, res2):
+        ws = None if torch.cuda.is_current_stream_capturing() else workspace(x.device)
+        check(lib.ptpp_conv1d_rt_fwd_ex(_conv_args_ref, wstream.data_ptr(), float(res_scale), float(drop_p), int(drop_seed),
+                                        _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "ptpp_conv1d_rt_fwd_ex")
+        return y
+    assert wp is not None, "conv1d: an operand stream was passed for a launch no row-tile kernel takes"
     if T <= 512 and ks * cin >= 2048 and not torch.cuda.is_current_stream_capturing():
         # few rows per utterance and a long K: hand the kernel the per-stream scratch so it may split K
         ws = workspace(x.device)

@@ -104,3 +104,68 @@ def test_gate_backward_on_the_row_tile_engine_is_bit_identical(dev, monkeypatch,
     got = da_got[:, :, 2 * C:4 * C].float().cpu()
     assert float((got - ora).abs().max()) < 2e-2 * float(ora.abs().max())
     assert float(got.abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,T,cin,cout,act,drop,res,bm,nsplit", [
+    (19, 169, 256, 1024, "relu", 0.2, False, 0, 0),    # feed-forward w_1 at the bench's phone-level shape: four column groups
+    (19, 169, 1024, 256, None, 0.2, True, 0, 0),       # w_2: the input channels split over blocks, residual + 0.5 scale + dropout
+    (7, 200, 256, 1024, None, 0.0, False, 96, 0),      # w_2's data gradient (256 -> 1024), 96-row blocks
+    (5, 300, 1024, 256, None, 0.0, False, 128, 2),     # w_1's data gradient (1024 -> 256), two splits of 128-row blocks
+    (40, 60, 1024, 256, "relu", 0.1, True, 64, 1),     # no split (one block walks all of Cin)
+    (3, 33, 256, 512, "relu", 0.0, False, 64, 0),      # a single ragged tile per utterance
+    (6, 150, 256, 1024, None, 0.3, False, 0, 0),       # dropout pattern: the same elements as the tile kernel drops
+    (6, 150, 1024, 256, None, 0.3, False, 0, 0),
+])
+def test_feed_forward_convs_on_the_row_tile_engine(dev, monkeypatch, B, T, cin, cout, act, drop, res, bm, nsplit):
+    """ptpp_conv1d_rt_fwd_ex (the Conformer blocks' k = 9 feed-forward convs, reference
+    modules/esp/transformer/multi_layer_conv.py:52-67, and their data gradients) against the tile kernel on the same operands and
+    dropout seed: the SAME elements are dropped, values agree to bf16 rounding of sums taken in another order, and both match the
+    f32 oracle (torch conv1d on the bf16-rounded operands)."""
+    import torch.nn.functional as F
+    from promptttspp_amd import ops
+
+    if bm:
+        monkeypatch.setenv("PTPP_CONV_RT_BM", str(bm))
+    if nsplit:
+        monkeypatch.setenv("PTPP_CONV_RT_NSPLIT", str(nsplit))
+    g = torch.Generator().manual_seed(900 + cin + B)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    ks, pad = 9, 4
+    x = r(B, T, cin).bfloat16()
+    w = r(cout, cin, ks, sc=(cin * ks) ** -0.5)
+    b = r(cout, sc=0.1)
+    rs = r(B, T, cout).bfloat16() if res else None
+    lengths = torch.tensor([max(1, T - 11 * i) for i in range(B)], device=dev, dtype=torch.int32)
+    kw = dict(ks=ks, pad=pad, act=act, lengths=lengths, in_mask=True, out_mask=True, res=rs, out_scale=0.5 if res else 1.0,
+              drop_p=drop, drop_seed=1234567)
+    assert ops.conv1d_rt_ex_ok(x, cout, ks, 1, act)
+    ref = ops.conv1d(x, ops.pack_conv_weight(w, torch.bfloat16), b, cout, **kw)
+    got = ops.conv1d(x, None, b, cout, wstream=ops.pack_conv_weight(w, torch.bfloat16, 3), **kw)
+    got2 = ops.conv1d(x, None, b, cout, wstream=ops.pack_conv_weight(w, torch.bfloat16, 3), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got, got2)  # deterministic
+    base = rs.float() if res else torch.zeros_like(ref, dtype=torch.float32)
+    if drop > 0.0 and not res and act is None:  # the same elements are dropped (no residual / ReLU zeros to confuse the pattern)
+        assert torch.equal(ref == 0, got == 0)
+    scale = float(ref.float().abs().max())
+    assert float((ref.float() - got.float()).abs().max()) <= 2e-2 * scale
+    m = (torch.arange(T, device=dev)[None, :] < lengths[:, None]).unsqueeze(-1).float()
+    orc = F.conv1d((x.float() * m).transpose(1, 2), w.bfloat16().float(), b, padding=pad).transpose(1, 2)
+    if act == "relu":
+        orc = torch.relu(orc)
+    orc = orc * m * (0.5 if res else 1.0)
+    if drop == 0.0:
+        orc = orc + base
+        assert float((got.float() - orc).abs().max()) <= 2e-2 * float(orc.abs().max())
+    else:  # kept elements: the oracle scaled by 1 / keep
+        keep = ((got.float() - base) != 0) & ((ref.float() - base) != 0)
+        thr = round(drop * 65536) / 65536
+        err = ((got.float() - base) - orc / (1 - thr))[keep].abs().max()
+        assert float(err) <= 2e-2 * float(orc.abs().max()) / (1 - thr)
+    # the data-gradient operand (pack mode 4) against mode 1 through the tile kernel
+    dy = r(B, T, cout).bfloat16()
+    kw2 = dict(ks=ks, pad=ks - 1 - pad, lengths=lengths, in_mask=False, out_mask=True)
+    if ops.conv1d_rt_ex_ok(dy, cin, ks, 1, None):
+        ref2 = ops.conv1d(dy, ops.pack_conv_weight(w, torch.bfloat16, 1), None, cin, **kw2)
+        got3 = ops.conv1d(dy, None, None, cin, wstream=ops.pack_conv_weight(w, torch.bfloat16, 4), **kw2)
+        assert float((ref2.float() - got3.float()).abs().max()) <= 2e-2 * float(ref2.float().abs().max())

@@ -15,7 +15,14 @@ by = {}
 for r in rows:
     by.setdefault(r[0], []).append(r[1:])
 main = max(by, key=lambda k: len(by[k]))
-m = by[main]
+if len(sys.argv) > 3:  # another stream, by rank of its launch count (1 = the busiest after the main stream)
+    main_ends = [r[1] for r in by[main] if "adamw_kernel" in r[2]]
+    other = sorted((k for k in by if k != main), key=lambda k: -len(by[k]))[int(sys.argv[3]) - 1]
+    # the steps' boundaries come from the main stream's optimiser launches
+    m = sorted(by[other] + [r for r in by[main] if "adamw_kernel" in r[2] or "spin_kernel" in r[2]], key=lambda r: r[0])
+    print(f"(stream {other}, between the main stream's optimiser launches)")
+else:
+    m = by[main]
 ends = [i for i, r in enumerate(m) if "adamw_kernel" in r[2]]
 want_spin = len(sys.argv) > 2 and sys.argv[2] == "spin"  # the instrumented step: the host enqueues everything behind a spin kernel
 seg = None

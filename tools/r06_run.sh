@@ -18,5 +18,6 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_train -o t -- python $R/b
 python $R/tools/prof_main_order.py /tmp/p_train > $out/main_order_$tag.txt 2>&1
 python $R/tools/prof_main_order.py /tmp/p_train spin > $out/main_order_spin_$tag.txt 2>&1
 python $R/tools/prof_streams.py /tmp/p_train > $out/streams_$tag.txt 2>&1
+for k in 1 2 3; do python $R/tools/prof_main_order.py /tmp/p_train spin $k > $out/order_s${k}_$tag.txt 2>&1; done
 python $R/tools/prof_step_tail.py /tmp/p_train > $out/step_tail_$tag.txt 2>&1
 head -3 $out/main_order_$tag.txt; head -8 $out/streams_$tag.txt | cut -c1-200
