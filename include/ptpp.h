@@ -170,6 +170,10 @@ int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wstream, float
  * partial sums go through it and a finishing launch applies the epilogue.  Within a split the accumulation order is the tile
  * kernel's; across splits it is this kernel's own (results agree with ptpp_conv1d_fwd_ws to f32 summation order, not bit for bit). */
 int ptpp_conv1d_rt_ex_supported(int cin, int cout, int ks, int dil, int act, int dtype);
+/* Row count from which the whole-unit drivers (ptpp_conv_ln_stack_*, ptpp_diffnet_stack_*) take the row-tile kernel for a launch
+ * whose operand stream was handed over; the Python layer pushes ITS threshold here so that both layers decide alike (default:
+ * PTPP_CONV_RT_MIN_ROWS or 24 576). */
+int ptpp_conv_rt_set_min_rows(long long rows);
 int ptpp_conv1d_rt_fwd_ex(const ptpp_conv1d_args* a, const void* wstream, float res_scale, float drop_p, uint64_t drop_seed,
                           void* workspace, size_t workspace_bytes, void* stream);
 

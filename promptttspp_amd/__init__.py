@@ -20,6 +20,17 @@ os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 # streams and each one's argument block is fetched when the dispatch starts -- 15.5 -> 14.7 ms per training step on the same
 # box.  Read by the HIP runtime when it initialises (first device call of the process); an
 # entry point that imports torch first sets it itself before that import (bench.py, __graft_entry__.py, train.py, app.py).
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# PTPP_NO_DEV_KERNARG=1 opts out (the variable is process-wide: it also affects other HIP users of the process).
+if not os.environ.get("PTPP_NO_DEV_KERNARG"):
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+    import sys as _sys
+
+    _t = _sys.modules.get("torch")
+    if _t is not None and getattr(_t, "cuda", None) is not None and _t.cuda.is_initialized() and os.environ.get("HIP_FORCE_DEV_KERNARG") == "1":
+        import warnings as _w
+
+        _w.warn("promptttspp_amd: the HIP runtime was initialised before this import, HIP_FORCE_DEV_KERNARG=1 cannot take effect any "
+                "more (~0.8 ms per training step); set it in the environment or import promptttspp_amd before touching the GPU",
+                stacklevel=2)
 
 __version__ = "0.1.0"

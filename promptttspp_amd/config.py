@@ -14,7 +14,9 @@ def compute_dtype():
 
 
 def set_compute_dtype(dtype):
-    assert dtype in (torch.float32, torch.bfloat16), "compute dtype must be float32 or bfloat16"
+    # float16 (round 6): INFERENCE of the acoustic model's decoder only -- the 100-step sampler (one-launch DiffNet layers,
+    # sampler head, conditioner GEMM) with the conditioning path in f32 (model.f32_conditioning); BASELINE config 5's wording
+    assert dtype in (torch.float32, torch.bfloat16, torch.float16), "compute dtype must be float32, bfloat16 or float16"
     _state["dtype"] = dtype
 
 

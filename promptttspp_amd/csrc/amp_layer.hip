@@ -505,8 +505,7 @@ int launch_amp(AmpP& p, hipStream_t st) {
     return PTPP_ENOTSUP;
   }
   auto kern = amp_layer_kernel<T, C, BT, MG>;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(kern), (int)smem, "amp_layer_fwd")) return PTPP_ELAUNCH;
   p.nMT = (p.T + BT - 1) / BT;
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)p.B * p.nMT)), dim3(256), smem, st, p);
   PTPP_CHECK_LAUNCH("amp_layer_fwd");

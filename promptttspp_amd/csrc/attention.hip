@@ -1205,10 +1205,10 @@ extern "C" int ptpp_attention_fwd(const void* q, const void* k, const void* v, c
     const size_t sm = (size_t)Tp * dk * 2 * 2 + 4 * 16 * 33 * sizeof(float);
     dim3 g((T_ + MF_QT - 1) / MF_QT, H, B);
     if (dk == 128) {
-      if (sm > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+      if (sm > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<128>), (int)sm, "attention_fwd")) return PTPP_ELAUNCH;
       hipLaunchKernelGGL(attn_fwd_mfma_kernel<128>, g, dim3(256), sm, st, p);
     } else {
-      if (sm > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+      if (sm > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<64>), (int)sm, "attention_fwd")) return PTPP_ELAUNCH;
       hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, g, dim3(256), sm, st, p);
     }
     PTPP_CHECK_LAUNCH("attention_fwd (mfma)");
@@ -1273,9 +1273,10 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
   {                                                                                                                                   \
     static bool attr_done = false;                                                                                                    \
     if (!attr_done) {                                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_mfma_kernel<DKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_k_mfma_kernel<DKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_pos_mfma_kernel<DKV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (!ptpp_lds_limit(reinterpret_cast<const void*>(attn_bwd_q_mfma_kernel<DKV>), 160 * 1024, "attention_bwd") ||                         \
+          !ptpp_lds_limit(reinterpret_cast<const void*>(attn_bwd_k_mfma_kernel<DKV>), 160 * 1024, "attention_bwd") ||                         \
+          !ptpp_lds_limit(reinterpret_cast<const void*>(attn_bwd_pos_mfma_kernel<DKV>), 160 * 1024, "attention_bwd"))                         \
+        return PTPP_ELAUNCH;                                                                                                            \
       attr_done = true;                                                                                                               \
     }                                                                                                                                 \
     hipLaunchKernelGGL(attn_bwd_q_mfma_kernel<DKV>, gq, dim3(256), sm_q, st, p);                                                      \
@@ -1301,9 +1302,8 @@ extern "C" int ptpp_attention_bwd(const void* q, const void* k, const void* v, c
   const size_t smem4 = (size_t)(4 * 4 * (dk + Tpad) + 8 * dk) * sizeof(float);
 #define ATTN_BWD(TT)                                                                                  \
   if (row4) {                                                                                         \
-    if (smem4 > 64 * 1024)                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_row4_kernel<TT>),              \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);              \
+    if (smem4 > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(attn_bwd_row4_kernel<TT>), (int)smem4, "attention_bwd")) \
+      return PTPP_ELAUNCH;                                                                            \
     hipLaunchKernelGGL(attn_bwd_row4_kernel<TT>, grid_row4, dim3(256), smem4, st, p);                 \
   } else                                                                                              \
     hipLaunchKernelGGL(attn_bwd_row_kernel<TT>, grid_row, dim3(256), smem, st, p);                    \

@@ -253,8 +253,10 @@ bool launch_splitk(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes, int* sta
   const size_t smem = (size_t)(2 * BN * NCH + 2 * BMW * NCH) * 16;
   if (smem > 160 * 1024) return false;
   auto kern = conv1d_cl_kernel<T, NCH, WM, FM, FN, NW, true>;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(kern), (int)smem, "conv1d_fwd (split-K)")) {
+    *status = PTPP_ELAUNCH;
+    return true;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * ns)), dim3(NW * 64), smem, st, p);
   const int64_t nvec = (int64_t)p.B * p.T * (p.Cout >> 2);
   int64_t fb = (nvec + 255) / 256;
@@ -278,8 +280,7 @@ int launch_cfg(ConvP& p, hipStream_t st) {
     return PTPP_EINVAL;
   }
   auto kern = conv1d_cl_kernel<T, NCH, WM, FM, FN, NW>;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(kern), (int)smem, "conv1d_fwd")) return PTPP_ELAUNCH;
   const int64_t nblk = (int64_t)p.B * p.nMT * p.nNT;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NW * 64), smem, st, p);
   PTPP_CHECK_LAUNCH("conv1d_fwd");

@@ -647,8 +647,7 @@ int launch_glds(ConvP& p, hipStream_t st) {
   auto kern = p.post_skip ? conv1d_glds_kernel<FM, FN, WR, WC, D, false, 1>
               : p.gate_a  ? conv1d_glds_kernel<FM, FN, WR, WC, D, false, 2>
                           : conv1d_glds_kernel<FM, FN, WR, WC, D, false, 0>;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(kern), (int)smem, "conv1d_fwd (lds-dma)")) return PTPP_ELAUNCH;
   const int64_t nblk = (int64_t)p.B * p.nMT * p.nNT;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WR * WC * 64), smem, st, p);
   PTPP_CHECK_LAUNCH("conv1d_fwd (lds-dma)");
@@ -682,8 +681,10 @@ bool launch_glds_splitk(ConvP& p, hipStream_t st, void* ws, size_t ws_bytes, int
   p.nMT = nMT;
   p.nNT = nNT;
   auto kern = conv1d_glds_kernel<FM, FN, WR, WC, D, false, 3>;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(kern), (int)smem, "conv1d_fwd (lds-dma, split-K)")) {
+    *status = PTPP_ELAUNCH;
+    return true;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * ns)), dim3(WR * WC * 64), smem, st, p);
   const int64_t nvec = (int64_t)p.B * p.T * (p.Cout >> 2);
   int64_t fb = (nvec + 255) / 256;

@@ -821,11 +821,8 @@ static int rt_bm_for(int B, int T, bool tall) {
   const int cand[4] = {160, 128, 96, 64};
   const float tblk[4] = {1.22f, 1.f, 0.8f, 0.6f};
   float best = 1e30f;
-  static const bool tall_on = [] {
-    const char* e = getenv("PTPP_CONV_RT_TALL");  // (A/B knob: 0 = no 160-row blocks)
-    return !(e && e[0] == '0');
-  }();
-  tall = tall && tall_on;
+  const char* te = getenv("PTPP_CONV_RT_TALL");  // (A/B knob: 0 = no 160-row blocks; read per call like PTPP_CONV_RT_BM)
+  tall = tall && !(te && te[0] == '0');
   for (int i = tall ? 0 : 1; i < 4; ++i) {
     const int64_t nb = (int64_t)B * ((T + cand[i] - 1) / cand[i]);
     const float cost = (float)((nb + 255) / 256) * tblk[i];

@@ -534,8 +534,7 @@ int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
   p.nsplit = nsplit;
   const size_t smem = (size_t)NS_DEFAULT * (KR * TM + XR * TN) * sizeof(bf16_raw);
   auto kern = conv1d_wgrad_bf16_kernel<FM, FN, WR, WC, TG, XH>;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(kern), (int)smem, "conv1d_wgrad(bf16)")) return PTPP_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)tiles * nsplit)), dim3(WR * WC * 64), smem, st, p,
                      p.in_mask ? p.lengths : nullptr);
   PTPP_CHECK_LAUNCH("conv1d_wgrad(bf16)");
@@ -561,8 +560,7 @@ int launch_batched(WgP& p, const WgBatch& batch, int nprob, hipStream_t st) {
   const size_t smem = (size_t)NS * (KR * TM + XR * TN) * sizeof(bf16_raw);
   static_assert((size_t)NS * (KR * TM + XR * TN) * sizeof(bf16_raw) <= 160 * 1024, "ring must fit LDS");
   auto kern = conv1d_wgrad_bf16_batched_kernel<FM, FN, WR, WC, TG, XH, NS>;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(kern), (int)smem, "conv1d_wgrad(bf16)")) return PTPP_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)tiles * nprob)), dim3(WR * WC * 64), smem, st, p,
                      p.in_mask ? p.lengths : nullptr, batch);
   PTPP_CHECK_LAUNCH("conv1d_wgrad_batched(bf16)");
@@ -627,8 +625,7 @@ static int launch_grouped(const ptpp_wgrad_gproblem* const* probs, int nprob, hi
   }
   const size_t smem = (size_t)NS_DEFAULT * (KR * TM + XR * TN) * sizeof(bf16_raw);
   auto kern = conv1d_wgrad_bf16_grouped_kernel<FM, FN, WR, WC, TG, XH>;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(kern), (int)smem, "conv1d_wgrad(bf16)")) return PTPP_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WR * WC * 64), smem, st, g);
   PTPP_CHECK_LAUNCH("conv1d_wgrad_grouped(bf16)");
   return PTPP_OK;

@@ -76,7 +76,33 @@ __device__ __forceinline__ float hi_bf16(uint32_t v) { return __uint_as_float(v 
 __device__ __forceinline__ float round_bf16_(float v) { return lo_bf16(pack_bf16x2(v, 0.f)); }
 
 // 16 MFMAs of one step: weights as the A operand, acc[fm][fn] += W[fn] * X[fm]
-template <bool NOMFMA = false, int FM = 4, int FN = 4>
+// element traits of the two 16-bit storage types the layer is built for (round 6: IEEE half for the sampler, BASELINE config 5
+// "fp16 mel decoder"): conversions and the matrix instruction; everything else in the kernel moves raw 16-byte vectors
+typedef __attribute__((ext_vector_type(8))) _Float16 dn_f16x8;
+template <bool F16>
+struct DnCv {
+  static __device__ __forceinline__ float lo(uint32_t v) { return lo_bf16(v); }
+  static __device__ __forceinline__ float hi(uint32_t v) { return hi_bf16(v); }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) { return pack_bf16x2(a, b); }
+  static __device__ __forceinline__ float round(float v) { return round_bf16_(v); }
+  template <typename A, typename B>
+  static __device__ __forceinline__ f32x4 mfma(const A& w, const B& x, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), c, 0, 0, 0);
+  }
+};
+template <>
+struct DnCv<true> {
+  static __device__ __forceinline__ float lo(uint32_t v) { return H2<f16_raw>::lo(v); }
+  static __device__ __forceinline__ float hi(uint32_t v) { return H2<f16_raw>::hi(v); }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) { return H2<f16_raw>::pack(a, b); }
+  static __device__ __forceinline__ float round(float v) { return (float)(_Float16)v; }
+  template <typename A, typename B>
+  static __device__ __forceinline__ f32x4 mfma(const A& w, const B& x, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dn_f16x8, w), __builtin_bit_cast(dn_f16x8, x), c, 0, 0, 0);
+  }
+};
+
+template <bool NOMFMA = false, int FM = 4, int FN = 4, bool F16 = false>
 __device__ __forceinline__ void dn_mfma_step(f32x4 (&acc)[FM][FN], const uint4 (&wf)[FN], const uint4 (&xf)[FM]) {
   if constexpr (NOMFMA) {  // keep the LDS reads alive without the matrix work
 #pragma unroll
@@ -89,8 +115,7 @@ __device__ __forceinline__ void dn_mfma_step(f32x4 (&acc)[FM][FN], const uint4 (
   for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn)
-      acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[fn]), __builtin_bit_cast(bf16x8_t, xf[fm]),
-                                                            acc[fm][fn], 0, 0, 0);
+      acc[fm][fn] = DnCv<F16>::mfma(wf[fn], xf[fm], acc[fm][fn]);
 }
 
 template <int NS, int NSTEPS = DN_STEPS>
@@ -117,7 +142,7 @@ __device__ __forceinline__ void dn_wait_stage(int s) {
 // FN (round 5): MFMA tiles per wave along the output channels.  4 = the 2 x 4 wave grid (a wave owns FM row tiles x 64 channels
 // per half); 2 = a 1 x 8 grid (every wave owns ALL rows of the block x 32 channels): no two waves read the same weight fragment,
 // so the GW form's L1 traffic halves (16 KiB per step and CU) -- the x fragments are what every wave reads, from LDS.
-template <int NS, bool SAVE, int DBG = 0, int FM = 4, bool COND = false, bool GW = false, int FN = 4>
+template <int NS, bool SAVE, int DBG = 0, int FM = 4, bool COND = false, bool GW = false, int FN = 4, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p) {
   constexpr int NWN = 16 / FN, NWM = 8 / NWN;  // the wave grid
   constexpr int HN = FN / 2;                   // 32-channel groups [16 gate | 16 filter] per wave and half
@@ -290,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
     for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn)
-        a[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[fn]), __builtin_bit_cast(bf16x8_t, xf[fm]), a[fm][fn], 0, 0, 0);
+        a[fm][fn] = DnCv<F16>::mfma(w[fn], xf[fm], a[fm][fn]);
   };
   // wait until the weights of step s have landed: everything issued after them may stay in flight -- the two younger weight
   // groups (if they exist) and the NPW x-window pieces issued in between (loads retire in order).  EVERY wave issues exactly
@@ -476,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       ld_w(wf1, next_slot(slot));
       fine_stamp(s, 4);
       __builtin_amdgcn_sched_barrier(0);  // the LDS requests above are issued BEFORE the matrix work ...
-      dn_mfma_step<(DBG & 2) != 0, FM, FN>(acc[0], wf0, xcur);
+      dn_mfma_step<(DBG & 2) != 0, FM, FN, F16>(acc[0], wf0, xcur);
       __builtin_amdgcn_sched_barrier(0);  // ... which stays on this side of the next barrier (register-only code moves across asm)
       fine_stamp(s, 5);
       slot = next_slot(slot);
@@ -492,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       }
       fine_stamp(s + 1, 4);
       __builtin_amdgcn_sched_barrier(0);
-      dn_mfma_step<(DBG & 2) != 0, FM, FN>(acc[1], wf1, xcur);
+      dn_mfma_step<(DBG & 2) != 0, FM, FN, F16>(acc[1], wf1, xcur);
       __builtin_amdgcn_sched_barrier(0);
       fine_stamp(s + 1, 5);
       slot = next_slot(slot);
@@ -551,27 +576,27 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
             v1 = v0;
           }
           const uint4 r = cv[nh][h][fm];
-          v0[0] += lo_bf16(r.x); v0[1] += hi_bf16(r.x); v0[2] += lo_bf16(r.y); v0[3] += hi_bf16(r.y);
-          v1[0] += lo_bf16(r.z); v1[1] += hi_bf16(r.z); v1[2] += lo_bf16(r.w); v1[3] += hi_bf16(r.w);
+          v0[0] += DnCv<F16>::lo(r.x); v0[1] += DnCv<F16>::hi(r.x); v0[2] += DnCv<F16>::lo(r.y); v0[3] += DnCv<F16>::hi(r.y);
+          v1[0] += DnCv<F16>::lo(r.z); v1[1] += DnCv<F16>::hi(r.z); v1[2] += DnCv<F16>::lo(r.w); v1[3] += DnCv<F16>::hi(r.w);
           uint2 o;
           if constexpr (SAVE) {
             // training: the pre-activation is kept (bf16) and the gate is computed FROM THE ROUNDED values, as gate_fwd does
-            const uint2 as = make_uint2(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]));
-            const uint2 af = make_uint2(pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3]));
+            const uint2 as = make_uint2(DnCv<F16>::pack(v0[0], v0[1]), DnCv<F16>::pack(v0[2], v0[3]));
+            const uint2 af = make_uint2(DnCv<F16>::pack(v1[0], v1[1]), DnCv<F16>::pack(v1[2], v1[3]));
             if (valid && !(DBG & 8)) {
               *reinterpret_cast<uint2*>(ab + (int64_t)t * (2 * DN_C) + gch) = as;
               *reinterpret_cast<uint2*>(ab + (int64_t)t * (2 * DN_C) + DN_C + gch) = af;
             }
-            const float sr[4] = {lo_bf16(as.x), hi_bf16(as.x), lo_bf16(as.y), hi_bf16(as.y)};
-            const float fr[4] = {lo_bf16(af.x), hi_bf16(af.x), lo_bf16(af.y), hi_bf16(af.y)};
-            o.x = pack_bf16x2(gate_fast(sr[0], fr[0]), gate_fast(sr[1], fr[1]));
-            o.y = pack_bf16x2(gate_fast(sr[2], fr[2]), gate_fast(sr[3], fr[3]));
+            const float sr[4] = {DnCv<F16>::lo(as.x), DnCv<F16>::hi(as.x), DnCv<F16>::lo(as.y), DnCv<F16>::hi(as.y)};
+            const float fr[4] = {DnCv<F16>::lo(af.x), DnCv<F16>::hi(af.x), DnCv<F16>::lo(af.y), DnCv<F16>::hi(af.y)};
+            o.x = DnCv<F16>::pack(gate_fast(sr[0], fr[0]), gate_fast(sr[1], fr[1]));
+            o.y = DnCv<F16>::pack(gate_fast(sr[2], fr[2]), gate_fast(sr[3], fr[3]));
           } else {
             float gte[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) gte[e] = keep ? gate_fast(v0[e], v1[e]) : 0.f;
-            o.x = pack_bf16x2(gte[0], gte[1]);
-            o.y = pack_bf16x2(gte[2], gte[3]);
+            o.x = DnCv<F16>::pack(gte[0], gte[1]);
+            o.y = DnCv<F16>::pack(gte[2], gte[3]);
           }
           G2[(row * 32 + ((gch >> 3) ^ (row & 15))) * 2 + ((gch >> 2) & 1)] = o;
         }
@@ -627,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
       step_top(s, slot);
       ld_w(wf1, next_slot(slot));
       __builtin_amdgcn_sched_barrier(0);
-      dn_mfma_step<(DBG & 2) != 0, FM, FN>(acc[0], wf0, gcur);
+      dn_mfma_step<(DBG & 2) != 0, FM, FN, F16>(acc[0], wf0, gcur);
       __builtin_amdgcn_sched_barrier(0);
       slot = next_slot(slot);
       step_top(s + 1, slot);
@@ -636,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
         ld_g(gnext, kc + 1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      dn_mfma_step<(DBG & 2) != 0, FM, FN>(acc[1], wf1, gcur);
+      dn_mfma_step<(DBG & 2) != 0, FM, FN, F16>(acc[1], wf1, gcur);
       __builtin_amdgcn_sched_barrier(0);
       slot = next_slot(slot);
     };
@@ -708,23 +733,23 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
         for (int h = 0; h < HN; ++h) {
           const int ch = wn * (16 * FN) + h * 32 + lg_t * 8;
           const uint4 xv4 = xr[df][h];
-          const float xv[8] = {lo_bf16(xv4.x), hi_bf16(xv4.x), lo_bf16(xv4.y), hi_bf16(xv4.y), lo_bf16(xv4.z), hi_bf16(xv4.z), lo_bf16(xv4.w), hi_bf16(xv4.w)};
+          const float xv[8] = {DnCv<F16>::lo(xv4.x), DnCv<F16>::hi(xv4.x), DnCv<F16>::lo(xv4.y), DnCv<F16>::hi(xv4.y), DnCv<F16>::lo(xv4.z), DnCv<F16>::hi(xv4.z), DnCv<F16>::lo(xv4.w), DnCv<F16>::hi(xv4.w)};
           float xn[8], yi[8];
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {  // (o rounded to bf16 in pairs: one conversion instruction per two values)
-            const uint32_t ob = pack_bf16x2(acc[0][fm][2 * h + (e >> 2)][e & 3] + bo[h][e >> 2][e & 3],
+            const uint32_t ob = DnCv<F16>::pack(acc[0][fm][2 * h + (e >> 2)][e & 3] + bo[h][e >> 2][e & 3],
                                             acc[0][fm][2 * h + (e >> 2)][(e & 3) + 1] + bo[h][e >> 2][(e & 3) + 1]);
-            const float o0 = keep ? lo_bf16(ob) : 0.f, o1 = keep ? hi_bf16(ob) : 0.f;
+            const float o0 = keep ? DnCv<F16>::lo(ob) : 0.f, o1 = keep ? DnCv<F16>::hi(ob) : 0.f;
             xn[e] = (xv[e] + o0) * r2;
             xn[e + 1] = (xv[e + 1] + o1) * r2;
             yi[e] = xn[e] + dn[h][e >> 2][e & 3];
             yi[e + 1] = xn[e + 1] + dn[h][e >> 2][(e & 3) + 1];
           }
           *reinterpret_cast<uint4*>(xnb + (int64_t)t * DN_C + ch) =
-              make_uint4(pack_bf16x2(xn[0], xn[1]), pack_bf16x2(xn[2], xn[3]), pack_bf16x2(xn[4], xn[5]), pack_bf16x2(xn[6], xn[7]));
+              make_uint4(DnCv<F16>::pack(xn[0], xn[1]), DnCv<F16>::pack(xn[2], xn[3]), DnCv<F16>::pack(xn[4], xn[5]), DnCv<F16>::pack(xn[6], xn[7]));
           if (yib)
             *reinterpret_cast<uint4*>(yib + (int64_t)t * DN_C + ch) =
-                make_uint4(pack_bf16x2(yi[0], yi[1]), pack_bf16x2(yi[2], yi[3]), pack_bf16x2(yi[4], yi[5]), pack_bf16x2(yi[6], yi[7]));
+                make_uint4(DnCv<F16>::pack(yi[0], yi[1]), DnCv<F16>::pack(yi[2], yi[3]), DnCv<F16>::pack(yi[4], yi[5]), DnCv<F16>::pack(yi[6], yi[7]));
         }
 #pragma unroll
         for (int h = 0; h < HN; ++h) {
@@ -735,13 +760,13 @@ __global__ __launch_bounds__(512, 2) void diffnet_layer_kernel(const DnLayerP p)
             f32x4 sv = sk[df][h][u];
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
-              const uint32_t ob = pack_bf16x2(acc[1][fm][2 * h + u][e] + bs[h][u][e], acc[1][fm][2 * h + u][e + 1] + bs[h][u][e + 1]);
-              sv[e] = (keep ? lo_bf16(ob) : 0.f) + sv[e];
-              sv[e + 1] = (keep ? hi_bf16(ob) : 0.f) + sv[e + 1];
+              const uint32_t ob = DnCv<F16>::pack(acc[1][fm][2 * h + u][e] + bs[h][u][e], acc[1][fm][2 * h + u][e + 1] + bs[h][u][e + 1]);
+              sv[e] = (keep ? DnCv<F16>::lo(ob) : 0.f) + sv[e];
+              sv[e + 1] = (keep ? DnCv<F16>::hi(ob) : 0.f) + sv[e + 1];
             }
             *reinterpret_cast<f32x4*>(sp + 4 * u) = sv;
-            sb[2 * u] = pack_bf16x2(sv[0] * p.skip_scale, sv[1] * p.skip_scale);
-            sb[2 * u + 1] = pack_bf16x2(sv[2] * p.skip_scale, sv[3] * p.skip_scale);
+            sb[2 * u] = DnCv<F16>::pack(sv[0] * p.skip_scale, sv[1] * p.skip_scale);
+            sb[2 * u + 1] = DnCv<F16>::pack(sv[2] * p.skip_scale, sv[3] * p.skip_scale);
           }
           if (p.skip_scaled)
             *reinterpret_cast<uint4*>(p.skip_scaled + ((int64_t)b * T + t) * DN_C + wn * (16 * FN) + h * 32 + lg_t * 8) = make_uint4(sb[0], sb[1], sb[2], sb[3]);
@@ -816,7 +841,9 @@ __global__ __launch_bounds__(256) void diffnet_pack_wstream_kernel(const DnPackT
 
 }  // namespace
 
-extern "C" int ptpp_diffnet_layer_supported(int C, int dtype) { return C == DN_C && dtype == PTPP_BF16; }
+// bf16: every form; IEEE half (PTPP_F16): the inference forms on the 1 x 8 wave grid (the sampler; no kept pre-activation, no
+// folded conditioner projection)
+extern "C" int ptpp_diffnet_layer_supported(int C, int dtype) { return C == DN_C && (dtype == PTPP_BF16 || dtype == PTPP_F16); }
 
 extern "C" int64_t ptpp_diffnet_wstream_bytes(int C) { return C == DN_C ? (int64_t)DN_STEPS * DN_STAGE_U4 * 16 : 0; }
 extern "C" int64_t ptpp_diffnet_wstream_bytes_cond(int C) { return C == DN_C ? (int64_t)(DN_STEPS + 16) * DN_STAGE_U4 * 16 : 0; }
@@ -864,7 +891,11 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
                  "diffnet_layer_fwd: null pointer");
   PTPP_CHECK_ARG(!a->condx || (a->ldcx >= DN_C && (a->ldcx & 7) == 0 && ((uintptr_t)a->condx & 15) == 0 && !dbg),
                  "diffnet_layer_fwd: bad conditioner input (ldcx %d; 256 channels, 16-byte aligned, no diagnostics build)", a->ldcx);
-  PTPP_CHECK_ARG(a->C == DN_C && a->dtype == PTPP_BF16, "diffnet_layer_fwd: C = 256 and bf16 only (C %d, dtype %d)", a->C, a->dtype);
+  PTPP_CHECK_ARG(a->C == DN_C && (a->dtype == PTPP_BF16 || a->dtype == PTPP_F16), "diffnet_layer_fwd: C = 256 and bf16 / f16 only (C %d, dtype %d)",
+                 a->C, a->dtype);
+  const bool f16 = a->dtype == PTPP_F16;
+  PTPP_CHECK_ARG(!f16 || (!a->a_out && !a->condx && !dbg), "diffnet_layer_fwd: f16 is built for the inference form (no kept pre-activation, "
+                 "no conditioner input, no diagnostics)");
   PTPP_CHECK_ARG(a->B > 0 && a->T > 0 && (a->dil == 1 || a->dil == 2 || a->dil == 4 || a->dil == 8) &&
                      (a->condx || (a->ldc >= 2 * DN_C && (a->ldc & 7) == 0)),
                  "diffnet_layer_fwd: bad shape (B %d T %d dil %d ldc %d)", a->B, a->T, a->dil, a->ldc);
@@ -899,7 +930,7 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
   // PTPP_DIFFNET_GW: 0 = LDS ring; 1 = weights straight from global memory, 2 x 4 wave grid; 2 (default) = the same on the
   // 1 x 8 wave grid (FN = 2).  Diagnostics builds exist for the ring form and for dbg 200 + m (the 1 x 8 form, 128 rows).
   const char* gwe = getenv("PTPP_DIFFNET_GW");
-  const int gwm = dbg >= 200 ? 2 : dbg ? 0 : (gwe ? atoi(gwe) : 2);
+  const int gwm = f16 ? 2 : dbg >= 200 ? 2 : dbg ? 0 : (gwe ? atoi(gwe) : 2);
   int bm = 128;
   {
     // the 1 x 8 form also has 80- and 112-row blocks for the inference forms (a wave owns bm / 16 row tiles): block times of the
@@ -963,6 +994,13 @@ static int diffnet_layer_launch(const ptpp_diffnet_layer_args* a, int dbg, unsig
       if (bm == 80) kern = diffnet_layer_kernel<NS, false, 0, 5, false, true, 2>;
       if (bm == 112) kern = diffnet_layer_kernel<NS, false, 0, 7, false, true, 2>;
     }
+  }
+  if (f16) {
+    kern = diffnet_layer_kernel<NS, false, 0, 8, false, true, 2, true>;
+    if (small) kern = diffnet_layer_kernel<NS, false, 0, 4, false, true, 2, true>;
+    if (bm == 96) kern = diffnet_layer_kernel<NS, false, 0, 6, false, true, 2, true>;
+    if (bm == 80) kern = diffnet_layer_kernel<NS, false, 0, 5, false, true, 2, true>;
+    if (bm == 112) kern = diffnet_layer_kernel<NS, false, 0, 7, false, true, 2, true>;
   }
   if (bm == 96 && dbg) { ptpp_set_error("diffnet_layer_fwd_dbg: the 96-row instantiation has no diagnostics build"); return PTPP_EINVAL; }
   if (dbg) {

@@ -270,6 +270,7 @@ inline float inv_keep_of(float p) { return p > 0.f ? 1.f / (1.f - thresh_of(p) /
 #define DISPATCH_T(dtype, name, ...)                         \
   if (dtype == PTPP_F32) { using T = float; __VA_ARGS__; }   \
   else if (dtype == PTPP_BF16) { using T = bf16_raw; __VA_ARGS__; } \
+  else if (dtype == PTPP_F16) { using T = f16_raw; __VA_ARGS__; } \
   else { ptpp_set_error("%s: bad dtype %d", name, dtype); return PTPP_EINVAL; }
 
 extern "C" int ptpp_epilogue_bwd(const void* dy, const void* y, void* dz, const int32_t* lengths, int B, int T_, int C,

@@ -250,7 +250,7 @@ extern "C" int ptpp_pack_conv_weight(const float* w, void* wp, int cout, int cin
   PTPP_CHECK_ARG(w && wp, "pack_conv_weight: null pointer");
   PTPP_CHECK_ARG(cout > 0 && cin > 0 && ks > 0 && (mode == 0 || mode == 1 || (mode == 2 && cout % 8 == 0) || mode == 3 || mode == 4),
                  "pack_conv_weight: bad args");
-  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16 || (dtype == PTPP_F16 && mode <= 1), "pack_conv_weight: bad dtype (f16: modes 0 / 1)");
+  PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16 || (dtype == PTPP_F16 && mode <= 2), "pack_conv_weight: bad dtype (f16: modes 0 / 1 / 2)");
   const bool tr = mode == 1 || mode == 4;
   const int rows = !tr ? cout : cin;
   const int inner = !tr ? cin : cout;

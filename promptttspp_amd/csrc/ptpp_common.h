@@ -62,6 +62,14 @@ inline void lds_limit_mark(const void* kern) {
 }
 }  // namespace
 
+// raise a kernel's dynamic-LDS limit; false -- with the error text set -- when the runtime refuses (every launcher checks it)
+inline bool ptpp_lds_limit(const void* kern, int bytes, const char* who) {
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) return true;
+  ptpp_set_error("%s: cannot raise the dynamic LDS limit to %d bytes: %s", who, bytes, hipGetErrorString(e));
+  return false;
+}
+
 // ---- bf16 <-> f32 (round to nearest even, like torch) -------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_raw v) {
   return __uint_as_float(((uint32_t)v) << 16);

@@ -38,13 +38,29 @@ struct ShP {
   int T, M, MP;  // MP = M padded to a multiple of 32 (the packed input-projection operand's row length)
 };
 
-__device__ __forceinline__ uint32_t sh_pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
-__device__ __forceinline__ f32x4 sh_mfma(uint4 a, uint4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+// F16 (round 6): IEEE-half storage and matrix instruction instead of bf16 (BASELINE config 5: "fp16 mel decoder"); the pointers of
+// ShP address 2-byte elements either way
+typedef __attribute__((ext_vector_type(8))) _Float16 sh_f16x8;
+template <bool F16>
+__device__ __forceinline__ uint32_t sh_pack2_(float a, float b) {
+  if constexpr (F16) return H2<f16_raw>::pack(a, b);
+  else return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+template <bool F16>
+__device__ __forceinline__ float sh_round_(float v) {
+  if constexpr (F16) return (float)(_Float16)v;
+  else return bf16_to_f32(f32_to_bf16(v));
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 sh_mfma_(uint4 a, uint4 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sh_f16x8, a), __builtin_bit_cast(sh_f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-template <int NT>  // n-tiles of 16 of the mel dimension (M = 16 NT)
+template <int NT, bool F16 = false>  // n-tiles of 16 of the mel dimension (M = 16 NT)
 __global__ __launch_bounds__(256, 2) void sampler_head_kernel(const ShP p) {
+  auto sh_pack2 = [](float a, float b) __attribute__((always_inline)) { return sh_pack2_<F16>(a, b); };
+  auto sh_mfma = [](uint4 a, uint4 b, f32x4 c) __attribute__((always_inline)) { return sh_mfma_<F16>(a, b, c); };
   constexpr int XCH = 2 * NT + ((2 * NT) % 4 ? 4 - (2 * NT) % 4 : 0);  // 16-byte chunks of a padded x row (MP / 8)
   constexpr int XST = XCH + 1;                                         // row stride of the x tile in chunks (odd multiple: no conflicts)
   __shared__ uint4 S[SH_BM * 32];   // s, then h: [row][chunk ^ (row & 15)]
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void sampler_head_kernel(const ShP p) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float ev = bf16_to_f32(f32_to_bf16(e2[nt][e] + bias[e]));  // eps as the output projection stores it
+          const float ev = sh_round_<F16>(e2[nt][e] + bias[e]);  // eps as the output projection stores it
           o[e] = ddpm_update(ca, cb, k1, k2, sg, xv[e], ev, nv[e]);
         }
         *reinterpret_cast<f32x4*>(p.x_out + grow * p.M + n) = o;
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void sampler_head_kernel(const ShP p) {
       f32x4 v = acc[fm][fn] + bias;
       float hr[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) hr[e] = bf16_to_f32(f32_to_bf16(fmaxf(v[e], 0.f)));
+      for (int e = 0; e < 4; ++e) hr[e] = sh_round_<F16>(fmaxf(v[e], 0.f));
       *reinterpret_cast<uint2*>(p.h0 + grow * SH_C + n) = make_uint2(sh_pack2(hr[0], hr[1]), sh_pack2(hr[2], hr[3]));
       *reinterpret_cast<uint2*>(p.yin0 + grow * SH_C + n) =
           make_uint2(sh_pack2(hr[0] + dsv[0], hr[1] + dsv[1]), sh_pack2(hr[2] + dsv[2], hr[3] + dsv[3]));
@@ -228,14 +244,14 @@ __global__ __launch_bounds__(256, 2) void sampler_head_kernel(const ShP p) {
 }  // namespace
 
 extern "C" int ptpp_sampler_head_supported(int C, int M, int dtype) {
-  return dtype == PTPP_BF16 && C == SH_C && M > 0 && M % 16 == 0 && M <= 96;  // (wider mels: the W_o prefetch spills)
+  return (dtype == PTPP_BF16 || dtype == PTPP_F16) && C == SH_C && M > 0 && M % 16 == 0 && M <= 96;  // (wider mels: the W_o prefetch spills)
 }
 
 extern "C" int ptpp_sampler_head(const ptpp_sampler_head_args* a, void* stream) {
   PTPP_CHECK_ARG(a && a->s && a->ws_p && a->ws_b && a->wo_p && a->wo_b && a->x && a->t && a->sra && a->srm1 && a->c1 && a->c2 &&
                      a->logvar && a->x_out,
                  "sampler_head: null pointer");
-  PTPP_CHECK_ARG(ptpp_sampler_head_supported(a->C, a->M, a->dtype), "sampler_head: bf16, C = 256, M %% 16 == 0, M <= 96 (C %d M %d dtype %d)",
+  PTPP_CHECK_ARG(ptpp_sampler_head_supported(a->C, a->M, a->dtype), "sampler_head: bf16 / f16, C = 256, M %% 16 == 0, M <= 96 (C %d M %d dtype %d)",
                  a->C, a->M, a->dtype);
   PTPP_CHECK_ARG(a->B > 0 && a->T > 0, "sampler_head: bad shape");
   PTPP_CHECK_ARG(!a->win_p || (a->win_b && a->ds0 && a->h0 && a->yin0), "sampler_head: the next step's outputs need win_b, ds0, h0, yin0");
@@ -255,6 +271,18 @@ extern "C" int ptpp_sampler_head(const ptpp_sampler_head_args* a, void* stream) 
   p.rows = (int64_t)a->B * a->T; p.T = a->T; p.M = a->M; p.MP = (a->M + 31) & ~31;
   const dim3 grid((unsigned)((p.rows + SH_BM - 1) / SH_BM)), blk(256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == PTPP_F16) {
+    switch (a->M / 16) {
+      case 1: hipLaunchKernelGGL((sampler_head_kernel<1, true>), grid, blk, 0, st, p); break;
+      case 2: hipLaunchKernelGGL((sampler_head_kernel<2, true>), grid, blk, 0, st, p); break;
+      case 3: hipLaunchKernelGGL((sampler_head_kernel<3, true>), grid, blk, 0, st, p); break;
+      case 4: hipLaunchKernelGGL((sampler_head_kernel<4, true>), grid, blk, 0, st, p); break;
+      case 5: hipLaunchKernelGGL((sampler_head_kernel<5, true>), grid, blk, 0, st, p); break;
+      default: hipLaunchKernelGGL((sampler_head_kernel<6, true>), grid, blk, 0, st, p); break;
+    }
+    PTPP_CHECK_LAUNCH("sampler_head");
+    return PTPP_OK;
+  }
   switch (a->M / 16) {
     case 1: hipLaunchKernelGGL(sampler_head_kernel<1>, grid, blk, 0, st, p); break;
     case 2: hipLaunchKernelGGL(sampler_head_kernel<2>, grid, blk, 0, st, p); break;

@@ -27,7 +27,7 @@ void ptpp_set_error(const char* fmt, ...);
 
 namespace {
 
-inline size_t esize(int dtype) { return dtype == PTPP_BF16 ? 2 : 4; }
+inline size_t esize(int dtype) { return dtype == PTPP_F32 ? 4 : 2; }
 inline char* at(void* base, size_t elems, int dtype) { return static_cast<char*>(base) + elems * esize(dtype); }
 inline const char* at(const void* base, size_t elems, int dtype) { return static_cast<const char*>(base) + elems * esize(dtype); }
 
@@ -47,9 +47,17 @@ ptpp_conv1d_args conv_args(const void* x, int ldx, const void* wp, const float* 
 
 // A conv launch of a driver: on the row-tile kernel (conv1d_rt.hip) when its operand stream was handed over and the launch is
 // frame-level -- the SAME rule as promptttspp_amd/ops.py::conv1d_rt_ok, so that both paths take the same kernel -- else as before
+// The threshold comes from the Python layer (ptpp_conv_rt_set_min_rows, pushed by ops.conv_rt_min_rows whenever its value
+// changes) so that both layers decide alike; a C-only caller gets the environment variable / the default.
+static long long g_rt_min_rows = -1;
+extern "C" int ptpp_conv_rt_set_min_rows(long long v) {
+  g_rt_min_rows = v;
+  return PTPP_OK;
+}
 static int64_t rt_min_rows() {
+  if (g_rt_min_rows >= 0) return g_rt_min_rows;
   int64_t min_rows = 24576;
-  if (const char* e = getenv("PTPP_CONV_RT_MIN_ROWS")) min_rows = atoll(e);  // (the same variable ops.py reads; tests run the row-tile paths at small shapes)
+  if (const char* e = getenv("PTPP_CONV_RT_MIN_ROWS")) min_rows = atoll(e);
   return min_rows;
 }
 static bool rt_takes(const ptpp_conv1d_args& c, const void* wstream) {
@@ -75,11 +83,14 @@ extern "C" int ptpp_diffnet_stack_fwd(const ptpp_diffnet_stack_fwd_args* a, void
                    a->g_all && a->x_buf[0] && a->x_buf[1],
                "diffnet_stack_fwd: null pointer");
   ST_CHECK_ARG(a->B > 0 && a->T > 0 && a->C > 0 && a->L > 0 && a->cycle > 0 && a->n_slabs >= 2, "diffnet_stack_fwd: bad shape");
-  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16, "diffnet_stack_fwd: bad dtype %d", a->dtype);
+  ST_CHECK_ARG(a->dtype == PTPP_F32 || a->dtype == PTPP_BF16 || a->dtype == PTPP_F16, "diffnet_stack_fwd: bad dtype %d", a->dtype);
+  ST_CHECK_ARG(a->dtype != PTPP_F16 || (a->fused_gate == 1 && a->wstream && !a->condx && !a->lengths),
+               "diffnet_stack_fwd: f16 is the sampler's form (fused gate without saving, operand stream, no masks)");
   // fused_gate: 0 = conv + gate_fwd, 1 = gate in the conv's epilogue, pre-activation not kept (inference), 2 = gate in the
   // epilogue AND the pre-activation kept in a_all (training: ptpp_conv1d_gate_fwd_save)
   ST_CHECK_ARG(a->fused_gate == 1 || a->a_all, "diffnet_stack_fwd: a_all is needed unless the gate is fused without saving");
-  ST_CHECK_ARG(a->fused_gate != 1 || (a->dtype == PTPP_BF16 && !a->lengths), "diffnet_stack_fwd: the fused gate is the bf16 inference path");
+  ST_CHECK_ARG(a->fused_gate != 1 || ((a->dtype == PTPP_BF16 || a->dtype == PTPP_F16) && !a->lengths),
+               "diffnet_stack_fwd: the fused gate is the 16-bit inference path");
   ST_CHECK_ARG(a->fused_gate != 2 || ptpp_conv1d_gate_fwd_save_supported(a->C, a->C, a->dtype),
                "diffnet_stack_fwd: the fused gate with the kept pre-activation needs bf16 and C %% 64 == 0");
   const int B = a->B, T = a->T, C = a->C, L = a->L, dt = a->dtype;

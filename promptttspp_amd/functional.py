@@ -450,7 +450,7 @@ def _done(p):
 
 def _kc(dtype):
     """elements per 16-byte MFMA operand chunk"""
-    return 8 if dtype == torch.bfloat16 else 4
+    return 4 if dtype == torch.float32 else 8
 
 
 def conv_cfg(ks=1, dil=1, pad=0, act=None, lengths=None, in_mask=False, out_mask=False, out_scale=1.0, drop_p=0.0):
@@ -907,7 +907,9 @@ class MaskedL1MeanFn(Function):
 def masked_l1_mean(pred, target, mask, denom, scale=1.0):
     """|pred - target| summed over everything (rows weighted by ``mask`` (rows,) f32 if given), divided by ``denom`` (a 0-dim
     tensor) and ``scale``.  Device tensors: one fused launch each way (MaskedL1MeanFn); CPU tensors: the tensor expression."""
-    if FUSED_L1 and pred.is_cuda and pred.dtype in (torch.float32, torch.bfloat16) and denom.dtype == torch.float32:
+    if (FUSED_L1 and pred.is_cuda and pred.dtype in (torch.float32, torch.bfloat16) and denom.dtype == torch.float32
+            and target.shape == pred.shape and not (target.requires_grad and torch.is_grad_enabled())):  # (the kernel pair
+        # differentiates pred only and reads target element for element: anything else takes the tensor expression)
         return MaskedL1MeanFn.apply(pred, target.float(), None if mask is None else mask.reshape(-1).float().contiguous(),
                                     denom.reshape(()), scale)
     d = (pred.float() - target.float()).abs()
@@ -1206,8 +1208,9 @@ def bcast_add_rows(x, e):
 # backward: per layer  conv(k3,dilated, +cond slice) -> gate -> 1x1 conv -> post.
 # ----------------------------------------------------------------------------
 def diffnet_fused_gate(dtype):
-    """Inference in bf16 fuses the DiffNet gate into the dilated conv's epilogue (ptpp.h, PTPP_ACT_GATE)."""
-    return dtype == torch.bfloat16
+    """Inference in bf16 / f16 fuses the DiffNet gate into the dilated conv's epilogue (ptpp.h, PTPP_ACT_GATE; f16: inside the
+    one-launch layer only, csrc/diffnet_layer.hip)."""
+    return dtype in (torch.bfloat16, torch.float16)
 
 
 _gate_perm_cache = {}

@@ -364,6 +364,9 @@ class PromptTTSMDNDurCFG(nn.Module):
         from ...config import use_dtype
 
         dt = compute_dtype()
+        if dt == torch.float16 and not (self.integer_island and self.f32_conditioning and not self.conformer_decoder):
+            raise NotImplementedError("compute dtype float16 serves the diffusion decoder's sampler only (csrc/diffnet_layer.hip, "
+                                      "sampler_head.hip): keep integer_island and f32_conditioning on (the text -> conditioning path in f32)")
         dur = None
         pm = lambda pmask: pmask if zero_padded_durations else None  # noqa: E731
         if self.integer_island and dt != torch.float32:

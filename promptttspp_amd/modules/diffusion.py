@@ -37,7 +37,39 @@ def extract(a, t, x_shape):
     return a.gather(-1, t).reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
 
 
+_STEP_TABLES = __import__("threading").local()  # per thread: {id(module): [step table, its (K, L, B, C) broadcast]}
+
+
+def _step_table_slot(mod, k):
+    d = getattr(_STEP_TABLES, "d", None)
+    if d is None:
+        d = _STEP_TABLES.d = {}
+    return d.setdefault(id(mod), [None, None]), k
+
+
 class GaussianDiffusion(nn.Module):
+    # The sampler's step-embedding tables (all K steps at once, ``inference_cl``) live for one call: kept per THREAD, not as
+    # module attributes, so two threads sampling with one module (a server) never see each other's tables.
+    @property
+    def _dstab(self):
+        s, k = _step_table_slot(self, 0)
+        return s[k]
+
+    @_dstab.setter
+    def _dstab(self, v):
+        s, k = _step_table_slot(self, 0)
+        s[k] = v
+
+    @property
+    def _dstab_lbc(self):
+        s, k = _step_table_slot(self, 1)
+        return s[k]
+
+    @_dstab_lbc.setter
+    def _dstab_lbc(self, v):
+        s, k = _step_table_slot(self, 1)
+        s[k] = v
+
     def __init__(self, in_dim, out_dim, denoise_fn, encoder=None, K_step=100, betas=None, schedule_type="linear",
                  scheduler_params=None, norm_scale=None, a_min=0, a_max=20, pndm_speedup=None):
         super().__init__()

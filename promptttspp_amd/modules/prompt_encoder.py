@@ -257,10 +257,14 @@ class BertWrapper(nn.Module):
         # the pointer tables of the frozen layers change only when their parameters do: cached on the parameters' versions
         # and storage (132 packed-operand lookups per step otherwise, ~0.8 ms of host time)
         srcs = getattr(self, "_frozen_srcs", None)
-        if srcs is None or srcs[0] != (len(layers), id(layers[0]), id(layers[-1])):
+        # identity of the layer list AND of a first / last parameter OBJECT: load_state_dict(assign=True), a parametrization or
+        # `module.weight = nn.Parameter(..)` replaces Parameters without touching the layer modules
+        ident = (len(layers), id(layers[0]), id(layers[-1]), id(layers[0].attention.self.query.weight), id(layers[-1].output.LayerNorm.bias))
+        if srcs is None or srcs[0] != ident:
             # (the parameter OBJECTS of the frozen layers do not change between steps: walking 11 layers x 16 parameters through
             #  named_parameters() every forward was ~0.2 ms of host time per step)
-            srcs = self._frozen_srcs = ((len(layers), id(layers[0]), id(layers[-1])), [t for layer in layers for t in layer.parameters()])
+            srcs = self._frozen_srcs = (ident, [t for layer in layers for t in layer.parameters()])
+            self._frozen_tables = None
         srcs = srcs[1]
         stamp = (dt, len(layers), PF._pack_gen[0], tuple(t._version for t in srcs), srcs[0].data_ptr())
         cached = getattr(self, "_frozen_tables", None)

@@ -194,12 +194,19 @@ CONV_RT_MIN_ROWS = 24576  # (below ~200 row tiles of 128 the chip is not filled 
 _rt_ok = {}
 
 
+_rt_min_pushed = [None]
+
+
 def conv_rt_min_rows():
     """The row count from which a frame-level launch goes to the row-tile kernel.  ONE rule for both layers: the C drivers
     (csrc/stacks.cpp::rt_takes) read PTPP_CONV_RT_MIN_ROWS, so this side reads it too (the module constant is the default and
     what tests patch together with the variable); a driver that is handed an operand stream it would not use refuses the call."""
     e = __import__("os").environ.get("PTPP_CONV_RT_MIN_ROWS")
-    return int(e) if e else CONV_RT_MIN_ROWS
+    v = int(e) if e else CONV_RT_MIN_ROWS
+    if v != _rt_min_pushed[0]:  # ONE source of truth: the C-side drivers take this side's threshold (ptpp_conv_rt_set_min_rows)
+        _lib.load().ptpp_conv_rt_set_min_rows(v)
+        _rt_min_pushed[0] = v
+    return v
 
 
 def conv1d_rt_ok(x, cout, ks, dil, act, res2=None, drop_p=0.0):
@@ -831,11 +838,14 @@ def l1_masked_mean_fwd(pred, target, mask, denom, scale):
     """sum |pred - target| * mask[row] / denom / scale as a 0-dim f32 tensor (ptpp_l1_masked_mean_fwd): pred (..., cols) f32 or
     bf16 contiguous, target f32 of the same shape, mask (rows) f32 or None, denom a device scalar."""
     _need_gpu(pred)
-    assert pred.is_contiguous() and target.is_contiguous() and target.dtype == torch.float32 and target.shape == pred.shape
-    assert denom.dtype == torch.float32 and denom.numel() == 1 and (mask is None or (mask.dtype == torch.float32 and mask.is_contiguous()))
+    if not (pred.is_contiguous() and target.is_contiguous() and target.dtype == torch.float32 and target.shape == pred.shape):
+        raise ValueError("l1_masked_mean: pred and an f32 target of the SAME shape, both contiguous (the kernel reads them element for element)")
+    if not (denom.dtype == torch.float32 and denom.numel() == 1 and (mask is None or (mask.dtype == torch.float32 and mask.is_contiguous()))):
+        raise ValueError("l1_masked_mean: denom must be an f32 device scalar, mask an f32 contiguous tensor")
     cols = pred.shape[-1] if mask is not None else 1
     rows = pred.numel() // cols
-    assert mask is None or mask.numel() == rows
+    if mask is not None and mask.numel() != rows:
+        raise ValueError("l1_masked_mean: one mask entry per row expected")
     out = torch.empty((), device=pred.device, dtype=torch.float32)
     check(_lib.load().ptpp_l1_masked_mean_fwd(pred.data_ptr(), target.data_ptr(), mask.data_ptr() if mask is not None else None,
                                               denom.data_ptr(), float(scale), rows, cols, dtype_code(pred.dtype), out.data_ptr(),
