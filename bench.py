@@ -451,22 +451,24 @@ def cpu_baseline(model, batch):
     # ascending thread counts; the sweep stops at the first count that is slower than the best so far (beyond a few dozen
     # threads this workload of many small ops only adds synchronisation: 0.35 / 0.59 / 1.30 s per step at 16 / 32 / 64
     # threads in round 2 -- and a 256-thread step did not finish within the bench's time budget)
-    # FULL sweep of the thread count ("N = all host cores" -- but this workload of many small ops gets SLOWER
-    # beyond a few dozen threads: 0.35 / 0.59 / 1.30 s per step at 16 / 32 / 64 threads in round 2), every power of two up to the
-    # host's logical cores on 2 utterances; a count whose warm-up step alone takes > 6 x the best step so far is recorded as such
-    # and not timed again (a 256-thread step did not finish within the bench's budget in round 2)
+    # sweep of the thread count ("N = all host cores" -- but this workload of many small ops gets SLOWER beyond
+    # a few dozen threads), ascending powers of two up to the host's logical cores on 2 utterances
     cands = [int(forced)] if forced else sorted({c for c in (4, 8, 16, 32, 64, 128, 256, ncores) if c <= ncores})
     sweep, skipped = {}, {}
     cb2, t2, n2, _ = sample(min(2, batch[0].shape[0]))
+    worse = 0
     for c in cands:
-        torch.set_num_threads(c)
-        w = step(cb2, t2, n2)
-        if sweep and w > 6.0 * min(sweep.values()):
-            skipped[c] = round(w, 2)
-            log(f"cpu baseline sweep: {c} threads: warm-up step {w:.2f}s, not timed")
+        if worse >= 2:
+            # two counts in a row slower than the best: past the optimum the step time only grows with the thread count (round 6's
+            # full sweep: 0.63 / 0.91 / 1.91 / 6.7 / 823 s per step at 16 / 32 / 64 / 128 / 256 threads -- the last one alone held
+            # the bench for 14 minutes), so the remaining counts are listed, not run
+            skipped[c] = "not run (past the optimum)"
             continue
+        torch.set_num_threads(c)
+        step(cb2, t2, n2)
         sweep[c] = step(cb2, t2, n2)
         log(f"cpu baseline sweep: {c} threads {sweep[c]:.2f}s")
+        worse = worse + 1 if sweep[c] > 1.05 * min(sweep.values()) else 0
     nthr = min(sweep, key=sweep.get)
     torch.set_num_threads(nthr)
     # the section 8(d) protocol at the best count: a quarter of the batch, 2 warm-ups, median of 5 timed steps
@@ -481,7 +483,7 @@ def cpu_baseline(model, batch):
             "sample": f"{n} utterances (a quarter of the bench batch of {batch[0].shape[0]}) / {frames} valid frames, fp32, dropout off, "
                       f"2 warm-ups + 5 timed steps, median {med:.2f} s/step (all {[round(x, 2) for x in times]}); thread count = best "
                       f"of a full sweep on 2 utterances: { {c: round(v, 2) for c, v in sweep.items()} } s/step"
-                      + (f", warm-up only (> 6 x the best, not timed): {skipped}" if skipped else "")
+                      + (f"; {skipped}" if skipped else "")
                       + f"; host has {ncores} logical cores"}
 
 
