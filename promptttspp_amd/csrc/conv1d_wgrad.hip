@@ -158,7 +158,7 @@ extern "C" int ptpp_conv1d_wgrad(const void* x, const void* dy, float* dw, float
 
 int ptpp_wgrad_bf16_batched_tiles(int Cin, int Cout, int ks, int max_dil);
 int ptpp_wgrad_bf16_launch_batched(const ptpp_wgrad_problem* probs, int nprob, const int32_t* lengths, int B, int T, int Cin,
-                                   int Cout, int ks, int ldx, int lddy, int in_mask, hipStream_t st);
+                                   int Cout, int ks, int ldx, int lddy, int in_mask, int nsplit, float* ws, hipStream_t st);
 
 extern "C" int ptpp_conv1d_wgrad_batched(const ptpp_wgrad_problem* probs, int nprob, const int32_t* lengths, int B, int T, int Cin,
                                          int Cout, int ks, int ldx, int lddy, int in_mask, int dtype, void* workspace,
@@ -181,10 +181,30 @@ extern "C" int ptpp_conv1d_wgrad_batched(const ptpp_wgrad_problem* probs, int np
     int Bf = B, Tf = T;
     if (ks == 1 && !in_mask && B > 1) { Tf = B * T; Bf = 1; }  // (as ptpp_conv1d_wgrad: one flat row sequence)
     constexpr int MAXP = 24;
-    for (int i0 = 0; i0 < nprob; i0 += MAXP) {
-      const int n = nprob - i0 < MAXP ? nprob - i0 : MAXP;
-      const int rc = ptpp_wgrad_bf16_launch_batched(probs + i0, n, lengths, Bf, Tf, Cin, Cout, ks, ldx, lddy, in_mask,
-                                                    reinterpret_cast<hipStream_t>(stream));
+    // Round 6 (opt-in, PTPP_WGRAD_BATCH_SPLIT=1): one owner block per tile leaves CUs idle when the batch has fewer tiles than the
+    // chip has CUs (the DiffNet stack: 20 layers x 8 tiles = 160 of 256).  With the workspace at hand the rows are split 3 ways
+    // (fixed chunk interleave, partials summed in split order by a second launch: still bit-reproducible) and the problems go out
+    // in groups that fill ONE round of 256 blocks: 2 x 240 blocks of a third of the rows instead of 1 x 160 blocks of all rows.
+    // Measured (profiles/r06_wgrad_split.md): the k = 3 batch 931 -> 611 us (773 TFLOP/s), the k = 1 batch 470 -> 321 us -- and the
+    // training step 13.60 -> 13.655 ms.  These launches run on the side stream next to the data-gradient chain; the CUs the split
+    // takes are CUs the main stream's kernels were using, and the main stream is the step's critical path.  Hence off by default:
+    // the right setting for a caller whose weight gradients are NOT overlapped (one stream), the wrong one for the training step.
+    const char* bse = getenv("PTPP_WGRAD_BATCH_SPLIT");
+    int nsplit = 1, group = MAXP;
+    const size_t per = ((size_t)ks * Cout * Cin + Cout) * sizeof(float);
+    if (bse && bse[0] == '1' && workspace && ((uintptr_t)workspace & 15) == 0 && Cout % 4 == 0 && (long long)tiles * nprob <= 192 &&
+        (long long)Bf * ((Tf + 31) / 32) >= 96) {
+      nsplit = 3;
+      group = 256 / (tiles * nsplit);
+      if (group < 1) group = 1;
+      if (group > MAXP) group = MAXP;
+      while (group > 1 && (size_t)group * nsplit * per > workspace_bytes) --group;
+      if ((size_t)group * nsplit * per > workspace_bytes) { nsplit = 1; group = MAXP; }
+    }
+    for (int i0 = 0; i0 < nprob; i0 += group) {
+      const int n = nprob - i0 < group ? nprob - i0 : group;
+      const int rc = ptpp_wgrad_bf16_launch_batched(probs + i0, n, lengths, Bf, Tf, Cin, Cout, ks, ldx, lddy, in_mask, nsplit,
+                                                    reinterpret_cast<float*>(workspace), reinterpret_cast<hipStream_t>(stream));
       if (rc != PTPP_OK) return rc;
     }
     return PTPP_OK;

@@ -240,12 +240,16 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__
   const bf16_raw* pdy = p.dy;
   float* pdw = p.dw;
   float* pdb = p.dbias;
+  float* wsb = p.ws;
   int pdil = p.dil, ppad = p.pad;
   if constexpr (BATCH) {  // block-uniform problem index: the operands come from the table (scalar loads)
     const int pi = __builtin_amdgcn_readfirstlane(bid / p.nsplit);
     split = bid - pi * p.nsplit;
     px = batch->pr[pi].x; pdy = batch->pr[pi].dy; pdw = batch->pr[pi].dw; pdb = batch->pr[pi].dbias;
     pdil = batch->pr[pi].dil; ppad = batch->pr[pi].pad;
+    // (round 6: a batched launch may split the rows too -- nsplit > 1, fixed chunk interleave -- its partials of problem pi live
+    //  at ws + pi * nsplit * (ks Cout Cin + Cout) and wgrad_reduce_batched_kernel adds them in split order)
+    if (p.ws) wsb = p.ws + (int64_t)pi * p.nsplit * ((int64_t)p.ks * p.Cout * p.Cin + p.Cout);
   }
   const int co0 = cot * TM, ci0 = cit * TN;
   const int shift = j * pdil - ppad;
@@ -458,7 +462,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__
           const int co = co0 + (wr * FM + a) * 16 + lg * 4 + r;
           if (co < p.Cout && ci < p.Cin) {
             if (OWNER || (BATCH && p.nsplit == 1)) pdw[((int64_t)co * p.Cin + ci) * p.ks + j + g] += acc[g][a][c][r];  // the only owner
-            else if (p.ws) p.ws[(((int64_t)split * p.ks + j + g) * p.Cout + co) * p.Cin + ci] = acc[g][a][c][r];
+            else if (wsb) wsb[(((int64_t)split * p.ks + j + g) * p.Cout + co) * p.Cin + ci] = acc[g][a][c][r];
             else atomicAdd(pdw + ((int64_t)co * p.Cin + ci) * p.ks + j + g, acc[g][a][c][r]);
           }
         }
@@ -472,7 +476,7 @@ __device__ __forceinline__ void wgrad_body(const WgP& p, const int* __restrict__
         const int co = co0 + (wr * FM + a) * 16 + lg * 4 + r;
         if (co < p.Cout) {
           if (OWNER || (BATCH && p.nsplit == 1)) pdb[co] += accb[a][r];  // one block per (problem, co tile) reaches here
-          else if (p.ws) p.ws[(int64_t)p.nsplit * p.ks * p.Cout * p.Cin + (int64_t)split * p.Cout + co] = accb[a][r];
+          else if (wsb) wsb[(int64_t)p.nsplit * p.ks * p.Cout * p.Cin + (int64_t)split * p.Cout + co] = accb[a][r];
           else atomicAdd(pdb + co, accb[a][r]);
         }
       }
@@ -501,6 +505,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)k * E + e);
   const int j = (int)(e / ((int64_t)Cout * Cin));
   const int64_t rem = e - (int64_t)j * Cout * Cin;  // co * Cin + ci  (Cin % 4 == 0: the 4 share co)
+  float* d = dw + rem * ks + j;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[(int64_t)k * ks] += s[k];
+}
+
+// the same for the problems of a batched launch whose rows were split (blockIdx.y = problem; targets from the table)
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const float* __restrict__ ws, const WgBatch batch, int nsplit, int Cout,
+                                                                   int Cin, int ks) {
+  const int64_t E = (int64_t)ks * Cout * Cin;
+  const int pi = blockIdx.y;
+  const float* wsp = ws + (int64_t)pi * nsplit * (E + Cout);
+  float* dw = batch.pr[pi].dw;
+  float* dbias = batch.pr[pi].dbias;
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= E) {
+    const int64_t co = e - E;
+    if (dbias && co < Cout) {
+      const float* b = wsp + (int64_t)nsplit * E + co;
+      f32x4 s = *reinterpret_cast<const f32x4*>(b);
+      for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(b + (int64_t)k * Cout);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dbias[co + k] += s[k];
+    }
+    return;
+  }
+  f32x4 s = *reinterpret_cast<const f32x4*>(wsp + e);
+  for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(wsp + (int64_t)k * E + e);
+  const int j = (int)(e / ((int64_t)Cout * Cin));
+  const int64_t rem = e - (int64_t)j * Cout * Cin;
   float* d = dw + rem * ks + j;
 #pragma unroll
   for (int k = 0; k < 4; ++k) d[(int64_t)k * ks] += s[k];
@@ -548,21 +581,26 @@ int launch(WgP& p, size_t ws_bytes, hipStream_t st) {
 }
 
 template <int FM, int FN, int WR = 2, int WC = 2, int TG = 1, int XH = 0, int NS = NS_DEFAULT>
-int launch_batched(WgP& p, const WgBatch& batch, int nprob, hipStream_t st) {
+int launch_batched(WgP& p, const WgBatch& batch, int nprob, int nsplit, float* ws, hipStream_t st) {
   constexpr int TM = WR * FM * 16, TN = WC * FN * 16;
   constexpr int XR = KR + XH;
   p.nCO = (p.Cout + TM - 1) / TM;
   p.nCI = (p.Cin + TN - 1) / TN;
   p.tchunks = (p.T + KR - 1) / KR;
-  p.nsplit = 1;
-  p.ws = nullptr;
+  p.nsplit = nsplit > 1 && ws ? nsplit : 1;
+  p.ws = p.nsplit > 1 ? ws : nullptr;
   const int tiles = p.nCO * p.nCI * ((p.ks + TG - 1) / TG);
   const size_t smem = (size_t)NS * (KR * TM + XR * TN) * sizeof(bf16_raw);
   static_assert((size_t)NS * (KR * TM + XR * TN) * sizeof(bf16_raw) <= 160 * 1024, "ring must fit LDS");
   auto kern = conv1d_wgrad_bf16_batched_kernel<FM, FN, WR, WC, TG, XH, NS>;
   if (smem > 64 * 1024 && !ptpp_lds_limit(reinterpret_cast<const void*>(kern), (int)smem, "conv1d_wgrad(bf16)")) return PTPP_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)tiles * nprob)), dim3(WR * WC * 64), smem, st, p,
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)tiles * nprob * p.nsplit)), dim3(WR * WC * 64), smem, st, p,
                      p.in_mask ? p.lengths : nullptr, batch);
+  if (p.nsplit > 1) {
+    const int64_t E4 = ((int64_t)p.ks * p.Cout * p.Cin + p.Cout + 3) / 4;
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)((E4 + 255) / 256), (unsigned)nprob), dim3(256), 0, st, ws, batch,
+                       p.nsplit, p.Cout, p.Cin, p.ks);
+  }
   PTPP_CHECK_LAUNCH("conv1d_wgrad_batched(bf16)");
   return PTPP_OK;
 }
@@ -579,7 +617,7 @@ int ptpp_wgrad_bf16_batched_tiles(int Cin, int Cout, int ks, int max_dil) {
 
 // called by ptpp_conv1d_wgrad_batched for bf16 tensors with 16-byte aligned rows; nprob <= WG_MAXP
 int ptpp_wgrad_bf16_launch_batched(const ptpp_wgrad_problem* probs, int nprob, const int32_t* lengths, int B, int T, int Cin,
-                                   int Cout, int ks, int ldx, int lddy, int in_mask, hipStream_t st) {
+                                   int Cout, int ks, int ldx, int lddy, int in_mask, int nsplit, float* ws, hipStream_t st) {
   WgP p;
   p.x = nullptr; p.dy = nullptr; p.dw = nullptr; p.dbias = nullptr; p.lengths = lengths;
   p.B = B; p.T = T; p.Cin = Cin; p.Cout = Cout; p.ks = ks; p.dil = 1; p.pad = 0; p.ldx = ldx; p.lddy = lddy;
@@ -596,11 +634,11 @@ int ptpp_wgrad_bf16_launch_batched(const ptpp_wgrad_problem* probs, int nprob, c
   //  959 vs 1008 us for the 20 k = 3 layers, 1025 vs 1027 us for k = 1, profiles/r03_wgrad_batched.txt; PTPP_WGRAD_DEEP=1)
   static const char* deep = getenv("PTPP_WGRAD_DEEP");
   if (deep && deep[0] == '1') {
-    if (ks > 1 && 2 * max_dil <= 32) return launch_batched<4, 2, 2, 4, 3, 32, 6>(p, batch, nprob, st);
-    return launch_batched<4, 4, 2, 2, 1, 0, 9>(p, batch, nprob, st);
+    if (ks > 1 && 2 * max_dil <= 32) return launch_batched<4, 2, 2, 4, 3, 32, 6>(p, batch, nprob, nsplit, ws, st);
+    return launch_batched<4, 4, 2, 2, 1, 0, 9>(p, batch, nprob, nsplit, ws, st);
   }
-  if (ks > 1 && 2 * max_dil <= 32) return launch_batched<4, 2, 2, 4, 3, 32>(p, batch, nprob, st);
-  return launch_batched<4, 4>(p, batch, nprob, st);
+  if (ks > 1 && 2 * max_dil <= 32) return launch_batched<4, 2, 2, 4, 3, 32>(p, batch, nprob, nsplit, ws, st);
+  return launch_batched<4, 4>(p, batch, nprob, nsplit, ws, st);
 }
 
 // called by ptpp_conv1d_wgrad_grouped for bf16 problems with 16-byte aligned rows; nprob <= 16.  Two launches at most: the

@@ -57,8 +57,10 @@ __device__ __forceinline__ f32x4 sh_mfma_(uint4 a, uint4 b, f32x4 c) {
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// (the f16 form holds ~60 more registers than the bf16 one -- the conversions do not fold into integer shifts -- and at M = 96 no
+// longer fits two blocks per CU without spilling: that one instantiation runs one block per CU; config 5's M = 80 is unaffected)
 template <int NT, bool F16 = false>  // n-tiles of 16 of the mel dimension (M = 16 NT)
-__global__ __launch_bounds__(256, 2) void sampler_head_kernel(const ShP p) {
+__global__ __launch_bounds__(256, (F16 && NT == 6) ? 1 : 2) void sampler_head_kernel(const ShP p) {
   auto sh_pack2 = [](float a, float b) __attribute__((always_inline)) { return sh_pack2_<F16>(a, b); };
   auto sh_mfma = [](uint4 a, uint4 b, f32x4 c) __attribute__((always_inline)) { return sh_mfma_<F16>(a, b, c); };
   constexpr int XCH = 2 * NT + ((2 * NT) % 4 ? 4 - (2 * NT) % 4 : 0);  // 16-byte chunks of a padded x row (MP / 8)

@@ -60,20 +60,24 @@ def test_two_ranks_on_one_device_selftest():
 
 
 @pytest.mark.gpu
-def test_one_rank_over_rccl_fills_the_dp_object():
+@pytest.mark.parametrize("backend,port", [("torch", "29653"), ("native", "29655")])
+def test_one_rank_over_rccl_fills_the_dp_object(backend, port):
     """What the first 8-GPU driver run will exercise, as far as one GPU can: the data-parallel
     machinery over RCCL itself -- process group "nccl", parameter broadcast, per-forward BatchNorm-buffer broadcast (the default,
     trainers/tts.py:117 `broadcast_buffers`), gradient hooks, bucket all-reduces on their stream, finish() -- with ONE rank
     (PTPP_DP_FORCE_COLLECTIVES), and the `dp` diagnostics of the bench line populated so that a scaling run is readable."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--preheat", "0",
                         "--no-vocoder", "--no-cpu-baseline", "--no-app"],
-                       env=_env(PTPP_DP_FORCE_COLLECTIVES="1", PTPP_RESERVE_GIB="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29653"),
+                       env=_env(PTPP_DP_FORCE_COLLECTIVES="1", PTPP_RESERVE_GIB="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                                PTPP_DP_BACKEND=backend),
                        capture_output=True, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     d = _one_json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0
     dp = d["dp"]
     assert dp is not None and dp["steps"] == 2 and dp["world"] == 1
-    assert dp["backend"] in ("nccl", "native-rccl") and dp["buckets"] >= 1 and len(dp["bucket_mb"]) == dp["buckets"]
+    # (round 6: the same machinery through the C ABI's own communicator -- ptpp_comm_init / ptpp_allreduce_mean / ptpp_broadcast --
+    #  the entry points a non-Python host would bind, include/ptpp.h)
+    assert dp["backend"] == ("native-rccl" if backend == "native" else "nccl") and dp["buckets"] >= 1 and len(dp["bucket_mb"]) == dp["buckets"]
     assert dp["join_gradient_streams_ms"] is not None and dp["exposed_allreduce_ms"] is not None and dp["exposed_allreduce_ms_max"] is not None
     assert sum(dp["bucket_mb"]) > 250  # ~298 MB of f32 gradients (SURVEY section 8e)

@@ -113,7 +113,8 @@ def test_diffnet_stack_backward_takes_dout_from_the_data_gradient_epilogue(dev, 
 
 def test_stack_driver_refuses_an_operand_stream_it_would_not_use(dev, monkeypatch):
     """The row-tile decision is made on both sides of the C ABI (ops.conv1d_rt_ok / stacks.cpp::rt_takes) from the SAME
-    variable, PTPP_CONV_RT_MIN_ROWS.  Should the two ever disagree -- forced here by patching the Python side only -- the
+    threshold (PTPP_CONV_RT_MIN_ROWS, pushed to the C side by ops.conv_rt_min_rows whenever it changes).  Should the two ever
+    disagree -- forced here by setting the C side's threshold behind Python's back -- the
     driver must refuse the operand stream instead of reading it as a [Cout][ks][Cin] operand (silently wrong
     activations and gradients)."""
     from promptttspp_amd import _lib
@@ -128,11 +129,15 @@ def test_stack_driver_refuses_an_operand_stream_it_would_not_use(dev, monkeypatc
     monkeypatch.setenv("PTPP_CONV_RT_MIN_ROWS", "1")
     assert ops.conv_rt_min_rows() == 1                       # the Python side follows the variable
     ok = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
-    monkeypatch.setattr(ops, "conv_rt_min_rows", lambda: 1)  # Python: row-tile; C (env): tile kernel
-    monkeypatch.setenv("PTPP_CONV_RT_MIN_ROWS", str(10 ** 9))
-    with pytest.raises(_lib.PtppError, match="operand stream"):
-        _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
-    monkeypatch.setenv("PTPP_CONV_RT_MIN_ROWS", "1")
+    real = ops.conv_rt_min_rows
+    monkeypatch.setattr(ops, "conv_rt_min_rows", lambda: 1)  # Python: row-tile ...
+    _lib.load().ptpp_conv_rt_set_min_rows(10 ** 9)           # ... C (threshold pushed behind Python's back): tile kernel
+    try:
+        with pytest.raises(_lib.PtppError, match="operand stream"):
+            _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
+    finally:
+        _lib.load().ptpp_conv_rt_set_min_rows(1)
+    monkeypatch.setattr(ops, "conv_rt_min_rows", real)
     again = _run(PF, h0, cond, dsteps, lengths, params, 4, gout)
     assert all(torch.equal(a, b) for a, b in zip(ok, again))
 
@@ -162,14 +167,18 @@ def test_diffnet_stack_batched_weight_gradients(dev, monkeypatch, B, T, C, L):
 
 
 @pytest.mark.parametrize("cin,cout,ks,dils,masked", [(256, 512, 3, (1, 2, 4, 8, 1, 2), False), (256, 512, 1, (1,) * 16, False),
-                                                     (128, 256, 5, (1, 1, 1, 1, 1, 1, 1, 1), True), (64, 64, 3, (1, 2), False)])
-def test_conv1d_wgrad_batched_against_the_single_problem_kernel(dev, cin, cout, ks, dils, masked):
+                                                     (128, 256, 5, (1, 1, 1, 1, 1, 1, 1, 1), True), (64, 64, 3, (1, 2), False),
+                                                     (256, 512, 3, (1, 2, 4, 8) * 5, False), (256, 512, 1, (1,) * 20, True)])
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_conv1d_wgrad_batched_against_the_single_problem_kernel(dev, monkeypatch, cin, cout, ks, dils, masked, split):
     """ptpp_conv1d_wgrad_batched (reference: autograd of nn.Conv1d, e.g. modules/denoiser.py:58-64) on problems of one shape:
     accumulates into pre-filled targets exactly what ptpp_conv1d_wgrad adds, within f32 summation noise; also against
     torch's f32 convolution backward of the same bf16-rounded operands.  (The last case is too small to batch: the entry
-    point falls back to the single-problem kernel.)"""
+    point falls back to the single-problem kernel.)  ``split`` = 1: the opt-in 3-way row split of a batch that does not fill the
+    chip (PTPP_WGRAD_BATCH_SPLIT; partials summed in split order by a second launch) -- same bounds, and bit-reproducible."""
     from promptttspp_amd import ops
 
+    monkeypatch.setenv("PTPP_WGRAD_BATCH_SPLIT", split)
     B, T = 7, 900
     n = len(dils)
     lengths = torch.tensor([T - 31 * i for i in range(B)], device=dev, dtype=torch.int32) if masked else None
@@ -183,6 +192,11 @@ def test_conv1d_wgrad_batched_against_the_single_problem_kernel(dev, cin, cout, 
         pad = (ks - 1) * d // 2
         probs.append((xs[i], dy_all[:, :, i * cout:(i + 1) * cout], got_w[i], got_b[i], d, pad))
     ops.conv1d_wgrad_batched(probs, cin, cout, ks, lengths=lengths, in_mask=masked)
+    if len(dils) >= 16:  # the batched forms have one owner per element (or a fixed-order sum of three): run twice, same bits
+        rep_w, rep_b = [t.clone() for t in init_w], [t.clone() for t in init_b]
+        ops.conv1d_wgrad_batched([(xs[i], dy_all[:, :, i * cout:(i + 1) * cout], rep_w[i], rep_b[i], d, (ks - 1) * d // 2)
+                                  for i, d in enumerate(dils)], cin, cout, ks, lengths=lengths, in_mask=masked)
+        assert all(torch.equal(a, b) for a, b in zip(rep_w + rep_b, got_w + got_b))
     for i, d in enumerate(dils):
         pad = (ks - 1) * d // 2
         dy = dy_all[:, :, i * cout:(i + 1) * cout]
