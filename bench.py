@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0
 # HBM traffic comes from PMC passes (bench.py cannot run rocprofv3 on itself): the committed summaries of
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command / of tools/bench_vocoder.py, written by
 # tools/pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md; the JSON line names the file it read.
-TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r05_hbm_traffic_train.json")
-TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r05_hbm_traffic_bigvgan.json")
+TRAFFIC_TRAIN = os.path.join(ROOT, "profiles", "r06_hbm_traffic_train.json")
+TRAFFIC_VOC = os.path.join(ROOT, "profiles", "r06_hbm_traffic_bigvgan.json")
 
 
 def measured_traffic(path, kernel_substr=None):

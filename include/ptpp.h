@@ -260,6 +260,11 @@ typedef struct {
 } ptpp_wgrad_gproblem;
 int ptpp_conv1d_wgrad_grouped(const ptpp_wgrad_gproblem* probs, int nprob, int dtype,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the 1 x 1 problems of the bf16 fast path on `stream2` when it is not NULL (the two launches of the grouped form
+ * are independent: on two streams they share the chip instead of queueing).  Both streams must already be ordered after the
+ * producers of the operands; the fallback (per-problem kernels, shared workspace) uses `stream` only. */
+int ptpp_conv1d_wgrad_grouped2(const ptpp_wgrad_gproblem* probs, int nprob, int dtype,
+                               void* workspace, size_t workspace_bytes, void* stream, void* stream2);
 
 /* Reduction scratch (ptpp_layernorm_bwd, ptpp_col_reduce, ptpp_bn_act_bwd): f32 atomics from
  * many blocks on one cache line serialise on MI355X (~50 ns per block visit), so per-column sums
@@ -967,6 +972,9 @@ typedef struct {
   float p_ffn, p_drop;
   int32_t B, T, C, F, H, L, ks_ffn, ks_dw, variant, bn_train, dtype;
   const void* ffn_wts[4];                       /* round 6: ffm_w1t, ffm_w2t, ff_w1t, ff_w2t as operand streams (pack mode 4) or NULL */
+  void* side_stream2;                           /* round 6: with side_stream, a SECOND stream that takes the depthwise and the 1 x 1
+                                                   weight gradients while side_stream runs the k = 9 ones; or NULL.  The caller
+                                                   joins both before it reads the gradients. */
 } ptpp_conformer_block_bwd_args;
 size_t ptpp_conformer_block_bwd_scratch_bytes(int B, int T, int C, int F, int H, int L, int dtype);
 int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, void* stream);

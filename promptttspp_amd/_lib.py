@@ -195,7 +195,7 @@ class ConformerBwdArgs(Structure):
                 ("red_scratch", c_void_p), ("red_bytes", ctypes.c_size_t), ("side_stream", c_void_p), ("seeds", c_void_p),
                 ("p_ffn", c_float), ("p_drop", c_float)] + \
                [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "ks_ffn", "ks_dw", "variant", "bn_train", "dtype")] + \
-               [("ffn_wts", c_void_p * 4)]
+               [("ffn_wts", c_void_p * 4), ("side_stream2", c_void_p)]
 
 
 class WgradGProblem(Structure):
@@ -240,6 +240,7 @@ SIGNATURES = {
     "ptpp_conv1d_wgrad": (I, [P, P, P, P, P] + [I] * 11 + [P, SZ, P]),
     "ptpp_conv1d_wgrad_batched": (I, [POINTER(WgradProblem), I, P, I, I, I, I, I, I, I, I, I, P, SZ, P]),
     "ptpp_conv1d_wgrad_grouped": (I, [POINTER(WgradGProblem), I, I, P, SZ, P]),
+    "ptpp_conv1d_wgrad_grouped2": (I, [POINTER(WgradGProblem), I, I, P, SZ, P, P]),
     "ptpp_epilogue_bwd": (I, [P, P, P, P, I, I, I, F, I, I, F, U64, I, P]),
     "ptpp_layernorm_fwd": (I, [P] * 9 + [I, I, I, F, I, I, F, U64, F, U64, I, P]),
     "ptpp_layernorm_bwd": (I, [P] * 11 + [I, I, I, I, I, F, U64, F, U64, I, P, SZ, P]),

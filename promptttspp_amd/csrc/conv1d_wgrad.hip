@@ -218,10 +218,15 @@ extern "C" int ptpp_conv1d_wgrad_batched(const ptpp_wgrad_problem* probs, int np
 }
 
 
-int ptpp_wgrad_bf16_launch_grouped(const ptpp_wgrad_gproblem* probs, int nprob, hipStream_t st);
+int ptpp_wgrad_bf16_launch_grouped(const ptpp_wgrad_gproblem* probs, int nprob, hipStream_t st, hipStream_t st2);
 
 extern "C" int ptpp_conv1d_wgrad_grouped(const ptpp_wgrad_gproblem* probs, int nprob, int dtype, void* workspace, size_t workspace_bytes,
                                          void* stream) {
+  return ptpp_conv1d_wgrad_grouped2(probs, nprob, dtype, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int ptpp_conv1d_wgrad_grouped2(const ptpp_wgrad_gproblem* probs, int nprob, int dtype, void* workspace, size_t workspace_bytes,
+                                          void* stream, void* stream2) {
   PTPP_CHECK_ARG(probs && nprob > 0, "conv1d_wgrad_grouped: no problems");
   PTPP_CHECK_ARG(dtype == PTPP_F32 || dtype == PTPP_BF16, "conv1d_wgrad_grouped: bad dtype %d", dtype);
   static const char* off = getenv("PTPP_WGRAD_NO_GROUP");
@@ -239,7 +244,8 @@ extern "C" int ptpp_conv1d_wgrad_grouped(const ptpp_wgrad_gproblem* probs, int n
   if (fast && blocks >= 64) {
     constexpr int GMAX = 16;
     for (int i0 = 0; i0 < nprob; i0 += GMAX) {
-      const int rc = ptpp_wgrad_bf16_launch_grouped(probs + i0, nprob - i0 < GMAX ? nprob - i0 : GMAX, reinterpret_cast<hipStream_t>(stream));
+      const int rc = ptpp_wgrad_bf16_launch_grouped(probs + i0, nprob - i0 < GMAX ? nprob - i0 : GMAX, reinterpret_cast<hipStream_t>(stream),
+                                                    reinterpret_cast<hipStream_t>(stream2));
       if (rc != PTPP_OK) return rc;
     }
     return PTPP_OK;

@@ -668,7 +668,7 @@ static int launch_grouped(const ptpp_wgrad_gproblem* const* probs, int nprob, hi
   PTPP_CHECK_LAUNCH("conv1d_wgrad_grouped(bf16)");
   return PTPP_OK;
 }
-int ptpp_wgrad_bf16_launch_grouped(const ptpp_wgrad_gproblem* probs, int nprob, hipStream_t st) {
+int ptpp_wgrad_bf16_launch_grouped(const ptpp_wgrad_gproblem* probs, int nprob, hipStream_t st, hipStream_t st2) {
   const ptpp_wgrad_gproblem* taps[WG_GMAX];
   const ptpp_wgrad_gproblem* flat[WG_GMAX];
   int nt = 0, nf = 0;
@@ -680,7 +680,7 @@ int ptpp_wgrad_bf16_launch_grouped(const ptpp_wgrad_gproblem* probs, int nprob, 
     const int rc = launch_grouped<4, 2, 2, 4, 3, 32>(taps, nt, st);
     if (rc != PTPP_OK) return rc;
   }
-  if (nf) return launch_grouped<4, 4, 2, 2, 1, 0>(flat, nf, st);
+  if (nf) return launch_grouped<4, 4, 2, 2, 1, 0>(flat, nf, st2 ? st2 : st);
   return PTPP_OK;
 }
 

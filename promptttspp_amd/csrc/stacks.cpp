@@ -664,8 +664,13 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
   ST_TRY(ln_bwd_plain(t1, a->x, w.ln_g[0], stats, stats + R, a->gx, g.ln_g[0], g.ln_b[0], nullptr, B, T, C, 0, dt, a->red_scratch,
                       a->red_bytes, stream, gA));
   if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
-  ST_TRY(ptpp_dwconv1d_wgrad(sl(S, lo.u), dz_dw, g.dw_w, g.dw_b, len, B, T, C, a->ks_dw, dt, wstream));
-  return ptpp_conv1d_wgrad_grouped(wg, nwg, dt, ws_w, ws_w_bytes, wstream);
+  // Round 6: the three launches (depthwise, k = 9 group, 1 x 1 group) are independent and none fills the chip (76 / 192 / 32
+  // workgroups): with a second side stream the k = 9 group runs beside the other two.  It matters at the END of the backward,
+  // where the main stream has nothing left and the step waits for the first encoder block's weight gradients.
+  void* wstream2 = a->side_stream && a->side_stream2 ? a->side_stream2 : nullptr;
+  if (wstream2) ST_TRY(ptpp_stream_wait(wstream2, stream));
+  ST_TRY(ptpp_dwconv1d_wgrad(sl(S, lo.u), dz_dw, g.dw_w, g.dw_b, len, B, T, C, a->ks_dw, dt, wstream2 ? wstream2 : wstream));
+  return ptpp_conv1d_wgrad_grouped2(wg, nwg, dt, ws_w, ws_w_bytes, wstream, wstream2);
 }
 
 

@@ -369,6 +369,28 @@ def register_gradient_stream(stream):
         _grad_streams.append(stream)
 
 
+SECOND_WGRAD_STREAM = __import__("os").environ.get("PTPP_WGRAD_STREAM2", "1") != "0"
+
+
+def second_wgrad_stream(device):
+    """Raw handle of a second stream for weight-gradient launches that are independent of the ones on the side stream (the
+    Conformer block's depthwise / 1 x 1 group beside its k = 9 group, ptpp_conformer_block_bwd), or None.  It is the model's
+    prompt-branch stream when that one is registered as a gradient stream: its own backward is long over when the phone encoder's
+    runs (profiles/r06_streams.txt), ``sync_wgrad_stream`` and ``side_stream_for_collective`` already join it, and no new stream
+    means no new hardware-queue assignment.  PTPP_WGRAD_STREAM2=0 turns it off."""
+    s = _direct.get("wgrad2")
+    if not SECOND_WGRAD_STREAM or s is None or _direct["side"] is None or s.device != device:
+        return None
+    if s == torch.cuda.current_stream() or all(g is not s for g in _grad_streams):
+        return None
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def offer_second_wgrad_stream(stream):
+    """The model names the registered gradient stream that is idle during the phone encoder's backward."""
+    _direct["wgrad2"] = stream
+
+
 def side_stream_for_collective():
     """The weight-gradient side stream, made to wait for everything enqueued so far on the current stream and on every
     registered gradient stream -- or None when it is not in use.  A collective issued under ``torch.cuda.stream(<it>)`` is
@@ -402,6 +424,9 @@ def sync_wgrad_stream():
             # called from a backward node that runs on a branch stream (the keep-flush of wgrad_stream): the held tensors
             # were allocated on the main stream, whose pool gets them back -- it has to wait for the side stream too
             main.wait_stream(_direct["side"])
+            for s in _grad_streams:  # (the second weight-gradient stream reads held tensors too)
+                if s != main:
+                    main.wait_stream(s)
         _direct["keep"].clear()
     # explicit join of the branch streams: their backward kernels write p.grad in place (LayerNorm / BatchNorm / GRU
     # parameters, the owner-block weight gradients); whatever the caller enqueues next (the optimizer, a collective) must

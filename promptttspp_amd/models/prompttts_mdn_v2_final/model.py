@@ -68,6 +68,8 @@ def _branch_stream(dev, idx=0):
         except RuntimeError:
             pass
         PF.register_gradient_stream(st)  # bucket collectives of the data-parallel reducer wait for its gradient kernels too
+        if idx == 0:  # the prompt branch's backward ends ~7 ms before the phone encoder's starts: its stream takes part of those
+            PF.offer_second_wgrad_stream(st)  # weight gradients (functional.second_wgrad_stream)
     return st
 
 
@@ -199,6 +201,11 @@ class PromptTTSMDNDurCFG(nn.Module):
             _probe("prompt branch -> losses", main, bs)
             main.wait_stream(bs)
             y_sty.record_stream(main)
+            if REJOIN:
+                # The prompt branch was issued FIRST, so autograd would differentiate it LAST: its ~30 launches and their weight
+                # gradients then sit at the very end of the side stream's queue although their inputs exist 8 ms earlier
+                # (profiles/r06_step_tail_ws2.txt).  Re-joined here, its backward is the first thing the pass enqueues.
+                y_sty = PF.rejoin_branch(y_sty, bs)
             if vb is not None:
                 main.wait_stream(sa)
                 y_dur.record_stream(main)

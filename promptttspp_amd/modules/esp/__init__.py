@@ -347,6 +347,7 @@ class ConformerBlockFn(torch.autograd.Function):
         a.ws_side, a.ws_side_bytes = ws_side.data_ptr(), ws_side.numel()
         a.red_scratch, a.red_bytes = ops.reduction_scratch(dev)
         a.side_stream = side_h
+        a.side_stream2 = PF.second_wgrad_stream(dev) if side_h is not None else None
         sd = (ctypes.c_uint64 * 6)(*ctx.seeds)
         a.seeds = ctypes.cast(sd, ctypes.c_void_p)
         a.p_ffn, a.p_drop = cfg.p_ffn, cfg.p
