@@ -220,7 +220,8 @@ def bias_cat(bs):
             ent.vers = stamp
         return ent.buf
     ent = _BiasCat()
-    ent.refs = [weakref.ref(b, lambda _r, k=key: (_bias_cats.pop(k, None), _bias_gen.__setitem__(0, _bias_gen[0] + 1))) for b in bs]
+    ent.refs = [weakref.ref(b, lambda _r, k=key, cats=_bias_cats, gen=_bias_gen: (cats.pop(k, None), gen.__setitem__(0, gen[0] + 1))) for b in bs]
+    # (the tables are bound as defaults: at interpreter shutdown the module globals are gone before the last parameters die)
     ent.buf = torch.cat([b.detach().float() for b in bs], dim=0)
     ent.vers = stamp
     off, ent.views = 0, []
@@ -594,20 +595,29 @@ class FusedLinearFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv1d(dy, packed_cat(ws, dy.dtype, mode=1), None, cin)
-        gw, gb, c0 = [], [], 0
-        for w, b, co in zip(ws, bs, ctx.couts):
-            with wgrad_stream(*((x, dy) if ctx.direct else ())):
+        gw, gb, c0 = [None] * n, [None] * n, 0
+        if ctx.direct and n > 4 and x.is_cuda:
+            # many layers over few rows (the DiffNet's 20 step projections on B rows): ONE weight-gradient launch with the
+            # concatenated output channels and one multi-tensor add of each layer's row block into its own gradient -- and ONE
+            # fork of the side stream: 20 forks were 20 event records on the main stream with no kernel between them, 117 us
+            # of bubbles on the step's critical path (profiles/r06_experiments.md)
+            with wgrad_stream(x, dy, torch_ops=True):
+                dwc, dbc = ops.conv1d_wgrad(x, dy, cin, sum(ctx.couts), 1, 1, 0)
+                dwl, dbl = dwc.view(sum(ctx.couts), -1).split(ctx.couts), dbc.split(ctx.couts)
+                torch._foreach_add_([w.grad.view(co, -1) for w, co in zip(ws, ctx.couts)] + [b.grad for b in bs], list(dwl) + list(dbl))
+            for p in params:
+                _done(p)
+            return (dx, None, *gw, *gb)
+        with wgrad_stream(*((x, dy) if ctx.direct else ())):  # (one fork for all layers)
+            for i, (w, b, co) in enumerate(zip(ws, bs, ctx.couts)):
                 dw, db = ops.conv1d_wgrad(x, dy[:, :, c0 : c0 + co], cin, co, 1, 1, 0,
                                           dw_out=w.grad if ctx.direct else None, db_out=b.grad if ctx.direct else None)
-            c0 += co
-            if ctx.direct:
-                _done(w)
-                _done(b)
-                gw.append(None)
-                gb.append(None)
-            else:
-                gw.append(dw.view_as(w))
-                gb.append(db)
+                c0 += co
+                if not ctx.direct:
+                    gw[i], gb[i] = dw.view_as(w), db
+        if ctx.direct:
+            for p in params:
+                _done(p)
         return (dx, None, *gw, *gb)
 
 

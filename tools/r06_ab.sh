@@ -4,11 +4,11 @@ out=$GRAFT_REPO_ROOT/gpurun_out/r06; mkdir -p $out
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 : > $out/ab_$tag.txt
-for round in 1 2; do
+for round in $(seq 1 ${AB_ROUNDS:-2}); do
   i=0
   for envs in "default" "$@"; do
     if [ "$envs" = "default" ]; then e=""; else e="$envs"; fi
-    env $e python $R/bench.py --no-cpu-baseline --no-vocoder --no-app > /tmp/ab.json 2> /tmp/ab.err
+    env $e python $R/bench.py --steps ${AB_STEPS:-20} --no-cpu-baseline --no-vocoder --no-app > /tmp/ab.json 2> /tmp/ab.err
     python - "$envs" <<'PY' >> $out/ab_$tag.txt
 import json, sys
 try:
