@@ -92,3 +92,30 @@ def test_rank_sharding_of_token_bucket_batches():
             assert max(tok) <= 30000 * 1.02                                      # ~max_tokens padded frames per GPU
             fr = [sum(ds.num_tokens(i) for i in s) for s in shards]
             assert (max(fr) - min(fr)) / max(fr) < 0.1                           # interleaving balances the work
+
+
+def test_default_bucket_layout_tapers_towards_the_end_of_the_backward(monkeypatch):
+    """The flat buffer is laid out in backward order, so the last buckets are the ones nothing hides: by default every bucket is
+    half the size of the one before, down to PTPP_DP_BUCKET_MIN_MB.  Every parameter keeps one bucket, the
+    buckets tile the buffer, each ends on a multiple of 64 floats; PTPP_DP_BUCKET_MIN_MB=0 and an explicit size stay constant."""
+    from promptttspp_amd.parallel import FlatGradReducer
+
+    ps = [torch.nn.Parameter(torch.zeros(50_000 + 13 * i)) for i in range(60)]  # 3.0 M floats, ragged sizes
+    monkeypatch.setenv("PTPP_DP_BUCKET_MB", "4")
+    monkeypatch.setenv("PTPP_DP_BUCKET_MIN_MB", "1")
+    red = FlatGradReducer(ps, direct=False)
+    mb = [(b - a) * 4 / 2 ** 20 for a, b, _ in red.buckets]
+    assert len(mb) >= 4 and 4.0 <= mb[0] < 4.3 and 2.0 <= mb[1] < 2.3 and all(1.0 <= m < 1.3 for m in mb[2:-1]) and mb[-1] < 1.3, mb
+    assert red.buckets[0][0] == 0 and all(red.buckets[i][1] == red.buckets[i + 1][0] for i in range(len(mb) - 1))
+    assert red.buckets[-1][1] == red.flat.numel() and all((b - a) % 64 == 0 for a, b, _ in red.buckets)
+    assert sum(n for _, _, n in red.buckets) == len(ps)
+    for p in ps:  # gradients are views of the flat buffer, inside their bucket
+        a, b, _ = red.buckets[red._bucket_of[id(p)]]
+        o = (p.grad.data_ptr() - red.flat.data_ptr()) // 4
+        assert a <= o and o + p.numel() <= b
+    monkeypatch.setenv("PTPP_DP_BUCKET_MIN_MB", "0")
+    const = [(b - a) * 4 / 2 ** 20 for a, b, _ in FlatGradReducer(ps, direct=False).buckets]
+    assert all(4.0 <= m < 4.3 for m in const[:-1]), const
+    monkeypatch.setenv("PTPP_DP_BUCKET_MIN_MB", "1")
+    fixed = [(b - a) for a, b, _ in FlatGradReducer(ps, bucket_elems=500_000, direct=False).buckets]
+    assert all(500_000 <= n < 560_000 for n in fixed[:-1]), fixed
