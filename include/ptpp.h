@@ -161,6 +161,15 @@ int ptpp_conv1d_rt_fwd(const ptpp_conv1d_args* a, const void* wstream, float res
  * output-projection gradient operand gx / sqrt2 from here instead of a separate pass over gx). */
 int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* aux, int ldaux, float aux_scale,
                            void* stream);
+/* ... and with per-utterance column sums of the ROUNDED output from the same epilogue (round 6; the DiffNet backward needs
+ * sum_t gx[l][b, t, :] of every layer for the step-projection gradients, modules/denoiser.py:72 differentiated -- a 307 MB pass
+ * over the stored gradients before): colpart is (B, ceil(T / 32), 256) f32, NOT initialised by the caller; the tile that starts at
+ * row t0 writes its sum to slot t0 / 32 and zeros to the other slots it covers, so ptpp_colsum_batch(colpart, out, B,
+ * ceil(T / 32), 256, PTPP_F32) gives the sums in a fixed order (bit-reproducible).  Only where the launch takes the
+ * global-weights form: ptpp_conv1d_rt_colpart_supported. */
+int ptpp_conv1d_rt_colpart_supported(int cin, int ks, int dil, int B, int T);
+int ptpp_conv1d_rt_fwd_cs(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* aux, int ldaux, float aux_scale,
+                          float* colpart, void* stream);
 
 /* Row-tile form for the phone-level feed-forward convs of the Conformer blocks (modules/esp/transformer/multi_layer_conv.py:52-67:
  * Conv1d 256 -> 1024 -> 256, k = 9; round 6): bf16, Cout %% 256 == 0 (column groups of 256 over one x window), Cin %% 128 == 0, ks = 9,
@@ -813,6 +822,9 @@ typedef struct {
   const void* const* dil_wst;  /* [L] pack mode 4 operands of the dilated convs or NULL: their data gradients on the row-tile kernel */
   const void* const* out_wst;  /* [L] pack mode 4 operands of the output projections or NULL: the fused gate backward on the row-tile
                                 * engine (ptpp_conv1d_rt_gate_bwd) where it is supported, bit-identically */
+  float* colpart;           /* round 6: (L, B, ceil(T / 32), C) f32 scratch or NULL.  With it (and dil_wst, C = 256, where
+                             * ptpp_conv1d_rt_colpart_supported) S comes from the data-gradient convs' epilogues
+                             * (ptpp_conv1d_rt_fwd_cs) instead of a pass over gx_all: same sums, another (fixed) order */
 } ptpp_diffnet_stack_bwd_args;
 int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void* stream);
 

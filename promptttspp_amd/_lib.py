@@ -116,7 +116,8 @@ class DiffNetBwdArgs(Structure):
                                         "dw_out", "db_out", "gx_all", "do_all", "dg_buf", "dcond_all", "S", "ws_main")] + \
                [("ws_main_bytes", ctypes.c_size_t), ("ws_side", c_void_p), ("ws_side_bytes", ctypes.c_size_t),
                 ("side_stream", c_void_p)] + \
-               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "dtype", "batched_wgrad")] + [("dil_wst", c_void_p), ("out_wst", c_void_p)]
+               [(n, c_int32) for n in ("B", "T", "C", "L", "cycle", "dtype", "batched_wgrad")] + \
+               [("dil_wst", c_void_p), ("out_wst", c_void_p), ("colpart", c_void_p)]
 
 
 class EncoderLayersFwdArgs(Structure):
@@ -314,6 +315,8 @@ SIGNATURES = {
     "ptpp_conv1d_rt_fwd_ex": (I, [POINTER(ConvArgs), P, ctypes.c_float, ctypes.c_float, U64, P, SZ, P]),
     "ptpp_conv1d_rt_fwd": (I, [POINTER(ConvArgs), P, ctypes.c_float, P]),
     "ptpp_conv1d_rt_fwd_aux": (I, [POINTER(ConvArgs), P, ctypes.c_float, P, I, ctypes.c_float, P]),
+    "ptpp_conv1d_rt_fwd_cs": (I, [POINTER(ConvArgs), P, ctypes.c_float, P, I, ctypes.c_float, P, P]),
+    "ptpp_conv1d_rt_colpart_supported": (I, [I, I, I, I, I]),
     "ptpp_diffnet_layer_supported": (I, [I, I]),
     "ptpp_diffnet_wstream_bytes": (ctypes.c_int64, [I]),
     "ptpp_diffnet_pack_wstream": (I, [P, P, P, I, I, P]),

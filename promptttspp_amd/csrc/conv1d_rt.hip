@@ -59,10 +59,13 @@ struct RtP {
   unsigned long long drop_seed;
   float* ws;
   int split_trips;  // trips (two 64-channel chunks) per split; Cin / 128 when there is no split
+  // round 6 (conv1d_rt_gw_kernel, plain epilogue): per-tile column sums of the ROUNDED output, (B, ceil(T / 32), 256) f32 -- a tile
+  // writes its sum to slot t0 / 32 and zeros to its other slots, so the caller needs no memset and sums the slots in a fixed order
+  float* colpart;
 };
 inline void rtp_plain(RtP& p) {  // the fields of the forms that came before round 6
   p.cout_total = RT_N; p.grp_stride = 0; p.drop_thresh16 = 0; p.drop_inv_keep = 1.f; p.drop_seed = 0; p.ws = nullptr;
-  p.split_trips = p.Cin >> 7;
+  p.split_trips = p.Cin >> 7; p.colpart = nullptr;
 }
 
 __device__ __forceinline__ void rt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -537,6 +540,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
     f32x4 bia[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) bia[u] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ch + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // (colpart) this lane's rows of the rounded output, per channel
 #pragma unroll
     for (int f0 = 0; f0 < FM; f0 += 4) {
       uint4 rr[4];
@@ -573,6 +577,12 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
         o.z = (uint32_t)f32_to_bf16(v[1][0]) | ((uint32_t)f32_to_bf16(v[1][1]) << 16);
         o.w = (uint32_t)f32_to_bf16(v[1][2]) | ((uint32_t)f32_to_bf16(v[1][3]) << 16);
         *reinterpret_cast<uint4*>(yb + (int64_t)t * p.ldy + ch) = o;
+        if (p.colpart) {
+          cs[0] += __uint_as_float(o.x << 16); cs[1] += __uint_as_float(o.x & 0xffff0000u);
+          cs[2] += __uint_as_float(o.y << 16); cs[3] += __uint_as_float(o.y & 0xffff0000u);
+          cs[4] += __uint_as_float(o.z << 16); cs[5] += __uint_as_float(o.z & 0xffff0000u);
+          cs[6] += __uint_as_float(o.w << 16); cs[7] += __uint_as_float(o.w & 0xffff0000u);
+        }
         if (p.aux) {  // from the ROUNDED output, like a separate pass over y would compute it
           const float sc = t < len ? p.aux_scale : 0.f;
           uint4 q;
@@ -582,6 +592,21 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
           q.w = (uint32_t)f32_to_bf16(__uint_as_float(o.w << 16) * sc) | ((uint32_t)f32_to_bf16(__uint_as_float(o.w & 0xffff0000u) * sc) << 16);
           *reinterpret_cast<uint4*>(p.aux + ((int64_t)b * T + t) * p.ldaux + ch) = q;
         }
+      }
+    }
+    if (p.colpart) {  // the 16 lanes of a channel group hold the tile's rows: fixed butterfly, then lane lr = k owns slot k of the tile
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = cs[e];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        cs[e] = v;
+      }
+      const int nslot = (T + 31) >> 5, s0 = t0 >> 5;
+      if (lr < BM / 32 && s0 + lr < nslot) {
+        float* d = p.colpart + ((int64_t)b * nslot + s0 + lr) * RT_N + wave * 32 + lg * 8;
+        const float z = lr == 0 ? 1.f : 0.f;
+        *reinterpret_cast<f32x4*>(d) = f32x4{cs[0] * z, cs[1] * z, cs[2] * z, cs[3] * z};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{cs[4] * z, cs[5] * z, cs[6] * z, cs[7] * z};
       }
     }
   }
@@ -660,9 +685,32 @@ extern "C" int ptpp_conv1d_rt_fwd(const ptpp_conv1d_args* a, const void* wstream
   return ptpp_conv1d_rt_fwd_aux(a, wstream, res_scale, nullptr, 0, 0.f, stream);
 }
 
+// whether a launch of this geometry takes the global-weights form (the only one with the column-sum epilogue), and its tile height
+static bool rt_takes_gw(int Cin, int ks, int dil, int B, int T, int* bm_out) {
+  const char* gwe = getenv("PTPP_CONV_RT_GW");
+  const bool gw_ok = !(gwe && gwe[0] == '0') && (Cin & 127) == 0 && (ks == 1 || ks == 3 || ks == 5 || ks == 17);
+  int bm = rt_bm_for(B, T, gw_ok);
+  if (bm == 160 && ((160 + (ks - 1) * dil + 7) >> 3) > 24) bm = rt_bm_for(B, T, false);  // (window pieces: 8 waves x 3)
+  if (bm_out) *bm_out = bm;
+  const int xr = (bm + (ks - 1) * dil + 7) & ~7;
+  const int npw = (bm + 7) / 8 + 6 > 16 ? 3 : 2;
+  return gw_ok && (xr >> 3) <= 8 * npw;
+}
+
+extern "C" int ptpp_conv1d_rt_colpart_supported(int cin, int ks, int dil, int B, int T) {
+  return B > 0 && T > 0 && rt_takes_gw(cin, ks, dil, B, T, nullptr) ? 1 : 0;
+}
+
 extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* aux, int ldaux, float aux_scale,
                                       void* stream) {
+  return ptpp_conv1d_rt_fwd_cs(a, wstream, res_scale, aux, ldaux, aux_scale, nullptr, stream);
+}
+
+extern "C" int ptpp_conv1d_rt_fwd_cs(const ptpp_conv1d_args* a, const void* wstream, float res_scale, void* aux, int ldaux, float aux_scale,
+                                     float* colpart, void* stream) {
   PTPP_CHECK_ARG(a && a->x && a->y && wstream, "conv1d_rt_fwd: null pointer");
+  PTPP_CHECK_ARG(!colpart || (((uintptr_t)colpart & 15) == 0 && rt_takes_gw(a->Cin, a->ks, a->dil, a->B, a->T, nullptr)),
+                 "conv1d_rt_fwd: the column-sum output needs the global-weights form (ptpp_conv1d_rt_colpart_supported)");
   PTPP_CHECK_ARG(!aux || ((ldaux & 7) == 0 && ldaux >= RT_N && ((uintptr_t)aux & 15) == 0), "conv1d_rt_fwd: bad aux output (ld %d)", ldaux);
   PTPP_CHECK_ARG(ptpp_conv1d_rt_supported(a->Cin, a->Cout, a->ks, a->dil, a->act, a->dtype),
                  "conv1d_rt_fwd: unsupported shape (bf16, Cout = 256, Cin %% 64 == 0, ks >= 3 or 1 x 1 with Cin %% 128 == 0, act none / relu; Cin %d Cout %d ks %d dil %d act %d)",
@@ -687,19 +735,15 @@ extern "C" int ptpp_conv1d_rt_fwd_aux(const ptpp_conv1d_args* a, const void* wst
   p.aux = reinterpret_cast<bf16_raw*>(aux); p.ldaux = ldaux; p.aux_scale = aux_scale;
   p.gate_a = nullptr; p.gate_da = nullptr; p.ldda = 0;
   rtp_plain(p);
+  p.colpart = colpart;
   // the global-weights form (1 x 8 wave grid) for the tap counts of the model's layers; PTPP_CONV_RT_GW=0: the ring form
-  const char* gwe = getenv("PTPP_CONV_RT_GW");
-  const bool gw_ok = !(gwe && gwe[0] == '0') && (a->Cin & 127) == 0 && (a->ks == 1 || a->ks == 3 || a->ks == 5 || a->ks == 17);
-  int bm = rt_bm_for(a->B, a->T, gw_ok);
-  if (bm == 160 && ((160 + (a->ks - 1) * a->dil + 7) >> 3) > 24) bm = rt_bm_for(a->B, a->T, false);  // (window pieces: 8 waves x 3)
+  int bm = 128;
+  const bool gw = rt_takes_gw(a->Cin, a->ks, a->dil, a->B, a->T, &bm);
   p.nMT = (a->T + bm - 1) / bm;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool relu = a->act == PTPP_ACT_RELU;
   {
-    const bool gw = gw_ok;
-    const int xr = (bm + (a->ks - 1) * a->dil + 7) & ~7;
-    const int npw = (bm + 7) / 8 + 6 > 16 ? 3 : 2;
-    if (gw && (xr >> 3) <= 8 * npw) {
+    if (gw) {
       if (a->ks == 1) return rt_gw_dispatch<1>(p, bm, relu, st);
       if (a->ks == 3) return rt_gw_dispatch<3>(p, bm, relu, st);
       if (a->ks == 5) return rt_gw_dispatch<5>(p, bm, relu, st);

@@ -202,6 +202,10 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
     fold = rt == 1;
   }
   if (fold) ST_TRY(ptpp_diffnet_post_bwd_fill(a->gS, a->do_all, a->lengths, B, T, C, L, dt, stream));
+  // Round 6: the per-layer column sums of gx (S) from the data-gradient convs' epilogues instead of a 307 MB pass over gx_all
+  const int nslot = (T + 31) / 32;
+  bool cs = fold && a->colpart != nullptr && C == 256;
+  for (int l = 0; l < L && cs; ++l) cs = ptpp_conv1d_rt_colpart_supported(2 * C, 3, 1 << (l % a->cycle), B, T) != 0;
   for (int l = L - 1; l >= 0; --l) {
     const int d = 1 << (l % a->cycle);
     const void* gx = at(a->gx_all, (size_t)(l + 1) * BTC, dt);
@@ -235,7 +239,8 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
     }
     ptpp_conv1d_args c = conv_args(da, ldc, a->dil_wpt[l], nullptr, gx, C, at(a->gx_all, (size_t)l * BTC, dt), C, a->lengths, B, T, 2 * C, C,
                                    3, d, d, PTPP_ACT_NONE, bmask, 0, dt);
-    if (fold) ST_TRY(ptpp_conv1d_rt_fwd_aux(&c, a->dil_wst[l], r2, l > 0 ? at(a->do_all, (size_t)(l - 1) * 2 * BTC, dt) : nullptr, 2 * C, r2, stream));
+    if (fold) ST_TRY(ptpp_conv1d_rt_fwd_cs(&c, a->dil_wst[l], r2, l > 0 ? at(a->do_all, (size_t)(l - 1) * 2 * BTC, dt) : nullptr, 2 * C, r2,
+                                           cs ? a->colpart + (size_t)l * B * nslot * C : nullptr, stream));
     else ST_TRY(ptpp_conv1d_fwd_ex(&c, nullptr, 0, r2, 0.f, 0, stream));  // (fold is false only without operand streams: checked above)
   }
   if (a->batched_wgrad) {
@@ -254,6 +259,7 @@ extern "C" int ptpp_diffnet_stack_bwd(const ptpp_diffnet_stack_bwd_args* a, void
     ST_TRY(ptpp_conv1d_wgrad_batched(pd, L, nullptr, B, T, C, 2 * C, 3, C, ldc, 0, dt, ws_w, ws_w_bytes, wstream));
     ST_TRY(ptpp_conv1d_wgrad_batched(po, L, nullptr, B, T, C, 2 * C, 1, C, 2 * C, 0, dt, ws_w, ws_w_bytes, wstream));
   }
+  if (cs) return ptpp_colsum_batch(a->colpart, a->S, L * B, nslot, C, PTPP_F32, stream);
   return ptpp_colsum_batch(a->gx_all, a->S, L * B, T, C, dt, stream);
 }
 

@@ -1532,6 +1532,11 @@ class DiffNetStackFn(Function):
         grads = [None] * (6 * L)
         r2 = 1.0 / math.sqrt(2.0)
         fuse_gbwd = FUSE_DIFFNET_POST and gout.is_cuda and ops.conv1d_gate_bwd_supported(C, 2 * C, dt)
+        colpart = None  # (as the driver: S from the data-gradient convs' epilogues where every layer takes the row-tile kernel)
+        if gout.is_cuda and C == 256 and ops.conv1d_rt_colpart_ok(2 * C, 3, [2 ** (l % ctx.cycle) for l in range(L)], B, T) and \
+                all(rt_stream(w[0], dcond_all[:, :, : 2 * C], C, 3, 2 ** (l % ctx.cycle), None, transposed=True) is not None
+                    for l, w in enumerate(ws)):
+            colpart = torch.empty((L, B, (T + 31) // 32, C), device=gout.device, dtype=torch.float32)
         for l in reversed(range(L)):
             yin, a, g = ctx.saved[l]
             dil_w, _, _, _, out_w, _ = ws[l]
@@ -1551,7 +1556,8 @@ class DiffNetStackFn(Function):
             # (do / da are zero past an utterance's end: the input mask is exact and lets those row tiles skip their K loops)
             wst = rt_stream(dil_w, da, C, 3, d, None, transposed=True)
             gx = ops.conv1d(da, packed(dil_w, dt, mode=1) if wst is None else None, None, C, ks=3, dil=d, pad=d, res=gx, res_scale=r2,
-                            out=gx_all[l], lengths=ctx.lengths, in_mask=ctx.lengths is not None, wstream=wst)
+                            out=gx_all[l], lengths=ctx.lengths, in_mask=ctx.lengths is not None, wstream=wst,
+                            colpart=colpart[l] if colpart is not None else None)
             if ctx.direct:
                 for i in (0, 1, 4, 5):
                     _done(ws[l][i])
@@ -1559,7 +1565,10 @@ class DiffNetStackFn(Function):
                 grads[6 * l + 0], grads[6 * l + 1] = dwd.view_as(dil_w), dbd
                 grads[6 * l + 4], grads[6 * l + 5] = dwo.view_as(out_w), dbo
             ctx.saved[l] = None
-        ops.colsum_batch(gx_all[:L].view(L * B, T, C), out=S[:L].view(L * B, C))
+        if colpart is not None:
+            ops.colsum_batch(colpart.view(L * B, -1, C), out=S[:L].view(L * B, C))
+        else:
+            ops.colsum_batch(gx_all[:L].view(L * B, T, C), out=S[:L].view(L * B, C))
         return DiffNetStackFn._backward_tail(ctx, cond, gx, S, dcond_all, grads)
 
     @staticmethod
@@ -1640,6 +1649,11 @@ def _diffnet_backward_driver(ctx, gS, gx_all):
         tabs.append(owst)  # (kept alive with the other tables until the call returns)
         a.out_wst = ctypes.cast(owst, ctypes.c_void_p)
     a.gx_all, a.do_all, a.dcond_all, a.S = gx_all.data_ptr(), do_all.data_ptr(), dcond_all.data_ptr(), S.data_ptr()
+    colpart = None
+    if rt and C == 256 and ops.conv1d_rt_colpart_ok(2 * C, 3, [2 ** (l % ctx.cycle) for l in range(L)], B, T):
+        # the column sums of every layer's input gradient (S) from the data-gradient convs' epilogues: no 307 MB pass over gx_all
+        colpart = torch.empty((L, B, (T + 31) // 32, C), device=dev, dtype=torch.float32)
+        a.colpart = colpart.data_ptr()
     a.dg_buf = dg_buf.data_ptr() if dg_buf is not None else None
     a.ws_main, a.ws_main_bytes = ws_main.data_ptr(), ws_main.numel()
     a.ws_side, a.ws_side_bytes = ws_side.data_ptr(), ws_side.numel()

@@ -238,8 +238,18 @@ def conv1d_rt_ex_ok(x, cout, ks, dil, act, res2=None):
     return ok
 
 
+COLPART = __import__("os").environ.get("PTPP_DIFFNET_COLPART", "1") != "0"
+
+
+def conv1d_rt_colpart_ok(cin, ks, dils, B, T):
+    """Whether row-tile launches of this geometry (every dilation of ``dils``) can emit per-tile column sums of their output
+    (ptpp_conv1d_rt_fwd_cs); PTPP_DIFFNET_COLPART=0 turns the only user -- the DiffNet backward -- back to the pass over gx."""
+    lib = _lib.load()
+    return COLPART and all(bool(lib.ptpp_conv1d_rt_colpart_supported(cin, ks, d, B, T)) for d in set(dils))
+
+
 def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mask=False, out_mask=False, res=None,
-           out_scale=1.0, res2=None, res_scale=1.0, drop_p=0.0, drop_seed=0, out=None, wstream=None):
+           out_scale=1.0, res2=None, res_scale=1.0, drop_p=0.0, drop_seed=0, out=None, wstream=None, colpart=None):
     """Channels-last conv / linear with the fused epilogue (see ptpp.h).
     x: (B, T, Cin); wp: packed weight; bias: (cout) f32 or None -> (B, T, cout).  ``wstream``: the same weight in pack mode
     3 (forward) / 4 (data gradient): where ``conv1d_rt_ok`` holds the launch goes to the row-tile kernel (bit-identical).
@@ -266,8 +276,13 @@ def conv1d(x, wp, bias, cout, ks=1, dil=1, pad=0, act=None, lengths=None, in_mas
                         BF16 if x.dtype == torch.bfloat16 else dtype_code(x.dtype))
     lib = _lib.load()
     if wstream is not None and conv1d_rt_ok(x, cout, ks, dil, act, res2, drop_p):
+        if colpart is not None:  # (B, ceil(T / 32), 256) f32: per-tile column sums of y from the epilogue (conv1d_rt_colpart_ok)
+            check(lib.ptpp_conv1d_rt_fwd_cs(_conv_args_ref, wstream.data_ptr(), float(res_scale), None, 0, 0.0, colpart.data_ptr(),
+                                            _stream()), "ptpp_conv1d_rt_fwd_cs")
+            return y
         check(lib.ptpp_conv1d_rt_fwd(_conv_args_ref, wstream.data_ptr(), float(res_scale), _stream()), "ptpp_conv1d_rt_fwd")
         return y
+    assert colpart is None, "conv1d: the column-sum output exists on the row-tile kernel only"
     if wstream is not None and conv1d_rt_ex_ok(x, cout, ks, dil, act, res2):
         ws = None if torch.cuda.is_current_stream_capturing() else workspace(x.device)
         check(lib.ptpp_conv1d_rt_fwd_ex(_conv_args_ref, wstream.data_ptr(), float(res_scale), float(drop_p), int(drop_seed),

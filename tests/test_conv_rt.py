@@ -169,3 +169,37 @@ def test_feed_forward_convs_on_the_row_tile_engine(dev, monkeypatch, B, T, cin, 
         ref2 = ops.conv1d(dy, ops.pack_conv_weight(w, torch.bfloat16, 1), None, cin, **kw2)
         got3 = ops.conv1d(dy, None, None, cin, wstream=ops.pack_conv_weight(w, torch.bfloat16, 4), **kw2)
         assert float((ref2.float() - got3.float()).abs().max()) <= 2e-2 * float(ref2.float().abs().max())
+
+
+@pytest.mark.parametrize("B,T,cin,ks,dil,masked,bm", [(9, 1000, 512, 3, 8, True, 128), (19, 900, 512, 3, 1, True, 0), (7, 333, 512, 3, 4, False, 96),
+                                                     (40, 130, 512, 3, 2, True, 64), (5, 1531, 256, 5, 1, False, 160)])
+def test_row_tile_conv_column_sums_from_the_epilogue(dev, monkeypatch, B, T, cin, ks, dil, masked, bm):
+    """ptpp_conv1d_rt_fwd_cs (round 6): the per-utterance column sums of the ROUNDED output -- what the DiffNet backward sums over
+    every layer's input gradient (reference modules/denoiser.py:72 differentiated: the step projection is broadcast over time) --
+    as per-tile partials from the conv's epilogue.  y unchanged bit for bit; slots a tile covers but does not sum into are
+    written as zeros (the buffer arrives poisoned); the slot sums equal a f64 sum of the stored y within f32 rounding, and
+    are bit-reproducible."""
+    from promptttspp_amd import ops
+
+    monkeypatch.setattr(ops, "CONV_RT_MIN_ROWS", 1)
+    if bm:
+        monkeypatch.setenv("PTPP_CONV_RT_BM", str(bm))
+    x, w, b, res = _mk(dev, B, T, cin, ks, 3 * ks + dil)
+    pad = dil * (ks - 1) // 2
+    lengths = torch.tensor([max(1, T - 41 * i) for i in range(B)], device=dev, dtype=torch.int32) if masked else None
+    assert ops.conv1d_rt_colpart_ok(cin, ks, [dil], B, T)
+    wst = ops.pack_conv_weight(w, torch.bfloat16, 3)
+    kw = dict(ks=ks, dil=dil, pad=pad, lengths=lengths, in_mask=masked, res=res, res_scale=0.7071067811865476, wstream=wst)
+    y0 = ops.conv1d(x, None, b, 256, **kw)
+    nslot = (T + 31) // 32
+    outs = []
+    for _ in range(2):
+        part = torch.full((B, nslot, 256), float("nan"), device=dev)
+        y1 = ops.conv1d(x, None, b, 256, colpart=part, **kw)
+        assert torch.equal(y0, y1)
+        assert bool(torch.isfinite(part).all())
+        outs.append(ops.colsum_batch(part))
+    assert torch.equal(outs[0], outs[1])
+    ref = y0.double().sum(1)
+    err = float((outs[0].double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
