@@ -44,7 +44,7 @@ def next_seed():
 # anything still stale when it is next used is re-packed on its own.
 # ----------------------------------------------------------------------------
 class _PackEntry:
-    __slots__ = ("refs", "vers", "wp", "mode", "dtype", "__weakref__")
+    __slots__ = ("refs", "vers", "wp", "mode", "dtype", "late", "__weakref__")
 
     def srcs(self):
         out = [r() for r in self.refs]
@@ -56,8 +56,39 @@ class _PackEntry:
 
 
 _pack_cache = {}
-_repack = {"key": None, "table": None, "map": None, "n": 0, "blocks": 0, "ents": [], "gen": None}
+_repack = {"key": None, "table": None, "map": None, "n": 0, "blocks": 0, "ents": [], "gen": None, "late": None}
 _pack_gen = [0]  # bumped whenever an entry is added to / dropped from _pack_cache
+# Round 6: operands the forward does not read for its first ~2 ms (variance adaptor, decoder: ``mark_late_pack``) are re-packed by a
+# SECOND launch on the weight-gradient side stream -- idle during the forward -- beside the phone encoder instead of in front of it
+# (the re-pack is 0.32 ms of serial HBM-bound work at the head of every step, ~40 % of it for these operands).  Whoever reads such
+# an operand first joins that launch (``join_late_pack``: the current stream, the main stream and every registered gradient stream
+# wait for its event).  PTPP_LATE_PACK=0: one launch on the caller's stream, as before.
+_late = {"ids": set(), "ev": None, "pending": False, "on": os.environ.get("PTPP_LATE_PACK", "1") != "0"}
+
+
+def mark_late_pack(params):
+    """``params``: parameters whose packed operands are first read late in the forward (see ``_late`` above)."""
+    n = len(_late["ids"])
+    _late["ids"].update(id(p) for p in params)
+    if len(_late["ids"]) != n:
+        _repack["key"] = _repack["gen"] = None  # the launch tables are rebuilt with the new split
+
+
+def join_late_pack():
+    """Order the current stream (and the main / gradient streams) after the late re-pack launch, if one is in flight."""
+    if not _late["pending"]:
+        return
+    _late["pending"] = False
+    ev = _late["ev"]
+    if torch.cuda.is_current_stream_capturing():  # (no cross-stream edge into a capture: the host waits instead)
+        ev.synchronize()
+        return
+    cur = torch.cuda.current_stream()
+    cur.wait_event(ev)
+    main = _direct.get("main")
+    for st in ([main] if main is not None else []) + _grad_streams:
+        if st != cur:
+            st.wait_event(ev)
 
 
 def _pack_now(ws, dtype, mode):
@@ -82,8 +113,11 @@ def _packed_entry(ws, dtype, mode):
         if live is not None and all(a is b for a, b in zip(live, ws)):
             if ent.vers != _PackEntry.stamp(ws):
                 ent.wp, ent.vers = _pack_now(ws, dtype, mode), _PackEntry.stamp(ws)
+            elif ent.late and _late["pending"]:
+                join_late_pack()
             return ent
     ent = _PackEntry()
+    ent.late = False
     _pack_gen[0] += 1
     ent.refs = [weakref.ref(w, lambda _r, k=key: (_pack_cache.pop(k, None), _pack_gen.__setitem__(0, _pack_gen[0] + 1)))
                 for w in ws]
@@ -119,6 +153,29 @@ def packed_cat(ws, dtype, mode=0):
     return _packed_entry(ws, dtype, mode).wp
 
 
+def _launch_repack():
+    ops.pack_conv_weights_batched(_repack["table"], _repack["n"], _repack["map"], _repack["blocks"])
+    late = _repack["late"]
+    if late is None:
+        return
+    d = _direct
+    if d["async"] and d["side"] is not None and not torch.cuda.is_current_stream_capturing():
+        join_late_pack()  # (a previous late launch nobody read from: its event object is about to be re-recorded)
+        side_h = d["side_h"]
+        _lib.check(_lib.load().ptpp_stream_wait(side_h, ops._stream()), "ptpp_stream_wait")
+        prev, ops._stream_override = ops._stream_override, side_h
+        try:
+            ops.pack_conv_weights_batched(*late)
+        finally:
+            ops._stream_override = prev
+        if _late["ev"] is None:
+            _late["ev"] = torch.cuda.Event()
+        _late["ev"].record(d["side"])
+        _late["pending"] = True
+    else:
+        ops.pack_conv_weights_batched(*late)
+
+
 def repack_all(bumped=None):
     """Refresh every stale cached operand in one launch (call right after an in-place parameter update).
     ``bumped``: the caller (FusedAdamW) advanced ``Tensor._version`` of exactly these parameters by one since
@@ -128,7 +185,7 @@ def repack_all(bumped=None):
     changed in any other way simply fails its stamp check at the next use and is re-packed on its own."""
     refresh_bias_cats()
     if bumped is not None and _repack["key"] is not None and _repack["gen"] == (_pack_gen[0], id(bumped), len(bumped)):
-        ops.pack_conv_weights_batched(_repack["table"], _repack["n"], _repack["map"], _repack["blocks"])
+        _launch_repack()
         for ent in _repack["ents"]:
             ent.vers = tuple((v + 1, p) for v, p in ent.vers)
         return
@@ -142,32 +199,45 @@ def repack_all(bumped=None):
             todo.append((ent, ws, st))
     if not todo:
         return
+    ids = _late["ids"] if _late["on"] else ()
+    for ent, ws, _ in todo:
+        ent.late = bool(ids) and all(id(w) in ids for w in ws)
+    todo.sort(key=lambda t: t[0].late)  # (stable: early operands first, then the late ones)
     key = tuple((id(e), e.wp.data_ptr(), st) for e, _, st in todo)
     key = tuple((k[0], k[1], tuple(p for _, p in k[2])) for k in key)  # entry, dst, source pointers
     if key != _repack["key"]:
         import numpy as np
 
-        rows, blk, owners = [], 0, []
-        for ent, ws, _ in todo:
-            w0 = ws[0]
-            cin = w0.shape[1]
-            ks = w0.shape[2] if w0.dim() == 3 else 1
-            dcode = ops.dtype_code(ent.dtype)
-            total_cout = sum(w.shape[0] for w in ws)
-            innerp = ops.cin_padded(cin if ent.mode not in (1, 4) else total_cout, ent.dtype)
-            off = 0
-            for w in ws:
-                assert w.dtype == torch.float32 and w.is_contiguous()
-                rows.append([w.data_ptr(), ent.wp.data_ptr(), w.shape[0], cin, ks, ent.mode, dcode, innerp, off, blk])
-                nb = ((w.shape[0] + 31) // 32) * ((cin + 31) // 32)
-                owners.append(np.full(nb, len(rows) - 1, dtype=np.int32))
-                blk += nb
-                off += w.shape[0]
-        dev = todo[0][1][0].device
-        _repack["table"] = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
-        _repack["map"] = torch.from_numpy(np.concatenate(owners)).to(dev)  # block -> table row
-        _repack["key"], _repack["n"], _repack["blocks"] = key, len(rows), blk
-    ops.pack_conv_weights_batched(_repack["table"], _repack["n"], _repack["map"], _repack["blocks"])
+        def table(part):
+            rows, blk, owners = [], 0, []
+            for ent, ws, _ in part:
+                w0 = ws[0]
+                cin = w0.shape[1]
+                ks = w0.shape[2] if w0.dim() == 3 else 1
+                dcode = ops.dtype_code(ent.dtype)
+                total_cout = sum(w.shape[0] for w in ws)
+                innerp = ops.cin_padded(cin if ent.mode not in (1, 4) else total_cout, ent.dtype)
+                off = 0
+                for w in ws:
+                    assert w.dtype == torch.float32 and w.is_contiguous()
+                    rows.append([w.data_ptr(), ent.wp.data_ptr(), w.shape[0], cin, ks, ent.mode, dcode, innerp, off, blk])
+                    nb = ((w.shape[0] + 31) // 32) * ((cin + 31) // 32)
+                    owners.append(np.full(nb, len(rows) - 1, dtype=np.int32))
+                    blk += nb
+                    off += w.shape[0]
+            if not rows:
+                return None
+            dev = part[0][1][0].device
+            return (torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows),
+                    torch.from_numpy(np.concatenate(owners)).to(dev), blk)  # table, rows, block -> table row, blocks
+
+        early = table([t for t in todo if not t[0].late])
+        _repack["late"] = table([t for t in todo if t[0].late])
+        _repack["key"] = key
+        if early is None:  # (everything is late: nothing to hide it behind)
+            early, _repack["late"] = _repack["late"], None
+        _repack["table"], _repack["n"], _repack["map"], _repack["blocks"] = early
+    _launch_repack()
     for ent, _, st in todo:
         ent.vers = st
     # the fast path is valid while the cache holds exactly these entries and the caller bumps the same list
@@ -260,6 +330,11 @@ def clear_caches():
     _pack_gen[0] += 1
     _repack["key"] = None
     _repack["gen"] = None
+    _repack["late"] = None
+    if _late["pending"]:
+        _late["ev"].synchronize()
+        _late["pending"] = False
+    _late["ids"].clear()
 
 
 def _f32c(t):
@@ -419,6 +494,7 @@ def sync_wgrad_stream():
     side stream are released (whatever reuses their memory is enqueued after this wait)."""
     cur = torch.cuda.current_stream()
     main = _direct.get("main")
+    join_late_pack()  # (a late re-pack launch still in flight on the side stream: every stream that may read its operands waits)
     if _direct["side"] is not None:
         cur.wait_stream(_direct["side"])
         if main is not None and main != cur:

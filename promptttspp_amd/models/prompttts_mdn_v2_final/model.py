@@ -152,6 +152,10 @@ class PromptTTSMDNDurCFG(nn.Module):
 
             PF._direct["main"] = torch.cuda.current_stream()
             PF._direct["main_h"] = ctypes.c_void_p(PF._direct["main"].cuda_stream)
+        if self.training and not getattr(self, "_late_marked", False):
+            # operands first read after the phone encoder: their share of the per-step weight re-pack runs beside it (functional._late)
+            PF.mark_late_pack([*self.variance_adaptor.parameters(), *self.decoder.parameters()])
+            self._late_marked = True
         sa = _branch_stream(dev, 1) if (branches and BRANCH_STREAMS in ("2", "3")) else None
         if sa is not None:
             sa.wait_stream(torch.cuda.current_stream())

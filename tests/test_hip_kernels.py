@@ -496,11 +496,14 @@ def test_skinny_gemm_path(rows, cin, cout, act, dtype, dev):
         assert rel_err(y.float().cpu().view(rows, cout), ref) < tol
 
 
-def test_fast_repack_path_keeps_packed_operands_current(dev):
+@pytest.mark.parametrize("late", [False, True])
+def test_fast_repack_path_keeps_packed_operands_current(dev, late):
     """The trainer's configuration (FlatGradReducer gradients + FusedAdamW.stable_grads): from the second
     step on the optimiser skips its pointer scan and functional.repack_all reuses the cached launch table and
     only advances the stamps.  After several steps every cached operand must equal a fresh pack of the
-    current weight, no entry may have needed a lazy re-pack, and adding a layer must fall back to the scan."""
+    current weight, no entry may have needed a lazy re-pack, and adding a layer must fall back to the scan.
+    ``late``: the last two layers' operands are marked as first read late in the forward (functional.mark_late_pack): their
+    share of the re-pack is a second launch on the weight-gradient side stream, joined by whoever reads such an operand first."""
     from promptttspp_amd import functional as PF
     from promptttspp_amd import ops
     from promptttspp_amd.optim import FusedAdamW
@@ -514,6 +517,8 @@ def test_fast_repack_path_keeps_packed_operands_current(dev):
     opt = FusedAdamW(params, lr=0.05)
     opt.stable_grads = True
     x = torch.randn(3, 20, 64, device=dev)
+    if late:
+        PF.mark_late_pack([*net[1].parameters(), *net[2].parameters()])
 
     def fwd(extra=None):
         h = PF.linear(x, net[0].weight, net[0].bias, act="relu")
@@ -534,6 +539,8 @@ def test_fast_repack_path_keeps_packed_operands_current(dev):
                 opt.step()
                 if it == 0:
                     n_first = len(calls)  # the first forward/backward packs every operand once
+                if late and PF._direct["side"] is not None:
+                    assert PF._repack["late"] is not None and PF._late["pending"]  # a second launch is in flight on the side stream
             assert PF._repack["gen"] is not None            # the fast path is armed ...
             assert len(calls) == n_first                    # ... and nothing was re-packed one by one since
             for m in net:
