@@ -956,6 +956,23 @@ def diffnet_post_bwd(gx, gskip, lengths):
     return dout
 
 
+def nsf_source_ok(f0, dim):
+    return f0.is_cuda and f0.dtype == torch.float32 and bool(_lib.load().ptpp_nsf_source_supported(int(dim)))
+
+
+def nsf_source(f0, rand_ini, noise, w, bias, sampling_rate, sine_amp, noise_std, voiced_threshold):
+    """ptpp_nsf_source: f0 (B, L) f32, rand_ini (B, dim), noise (B, L, dim), w (dim) -> (B, L) f32 merged source."""
+    B, L = f0.shape
+    dim = rand_ini.shape[1]
+    assert noise.shape == (B, L, dim) and w.numel() == dim
+    f0, rand_ini, noise, w = f0.contiguous(), rand_ini.contiguous().float(), noise.contiguous(), w.detach().reshape(-1).float().contiguous()
+    out = torch.empty((B, L), device=f0.device, dtype=torch.float32)
+    check(_lib.load().ptpp_nsf_source(_ptr(f0), _ptr(rand_ini), _ptr(noise), _ptr(w), float(bias), _ptr(out), B, L, dim,
+                                      float(sampling_rate), float(sine_amp), float(noise_std), float(voiced_threshold), _stream()),
+          "ptpp_nsf_source")
+    return out
+
+
 def colsum_batch(x, out=None):
     B, T, C = x.shape
     if out is None:

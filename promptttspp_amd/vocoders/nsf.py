@@ -13,6 +13,9 @@ import torch
 import torch.nn as nn
 
 
+FUSED_SOURCE = __import__("os").environ.get("PTPP_NSF_FUSED", "1") != "0"  # the one-launch source on device tensors (csrc/nsf.hip)
+
+
 class SineGen(nn.Module):
     def __init__(self, samp_rate, harmonic_num=0, sine_amp=0.1, noise_std=0.003, voiced_threshold=0, flag_for_pulse=False):
         super().__init__()
@@ -60,6 +63,23 @@ class SourceModuleHnNSF(nn.Module):
         self.l_tanh = nn.Tanh()
 
     def forward(self, x):
+        if FUSED_SOURCE and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.l_linear.parameters())):  # (no backward)
+            from .. import ops
+
+            g = self.l_sin_gen
+            if x.dim() == 3 and x.shape[2] == 1 and ops.nsf_source_ok(x, g.dim):
+                # ONE launch (csrc/nsf.hip) instead of ~20 elementwise passes and two scans over (B, L, dim); the same three RNG
+                # draws in the same order and shapes as the reference (rand: initial phases, randn_like: the additive noise of
+                # the sines, randn_like: SourceModuleHnNSF's unused noise)
+                B, L, _ = x.shape
+                rand_ini = torch.rand(B, g.dim, device=x.device)
+                rand_ini[:, 0] = 0
+                nz = torch.randn_like(torch.empty((B, L, g.dim), device=x.device, dtype=torch.float32))
+                merged = ops.nsf_source(x.reshape(B, L), rand_ini, nz, self.l_linear.weight, float(self.l_linear.bias.detach()),
+                                        g.sampling_rate, g.sine_amp, g.noise_std, g.voiced_threshold)
+                uv = g._f02uv(x)
+                noise = torch.randn_like(uv) * self.sine_amp / 3
+                return merged.unsqueeze(-1), noise, uv
         sine_wavs, uv, _ = self.l_sin_gen(x)
         sine_merge = self.l_tanh(self.l_linear(sine_wavs))
         noise = torch.randn_like(uv) * self.sine_amp / 3  # drawn (and unused) like the reference

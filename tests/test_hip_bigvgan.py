@@ -122,6 +122,52 @@ def test_f0_aware_bigvgan_matches_reference_golden(dev):
     assert rel_err(y, g["y"]) < 1e-3
 
 
+@pytest.mark.parametrize("B,L,voiced", [(3, 24000, 0.7), (2, 141600, 0.6), (5, 999, 1.0), (1, 1500, 0.0)])
+def test_fused_harmonic_source_against_the_tensor_op_chain(dev, B, L, voiced):
+    """ptpp_nsf_source (csrc/nsf.hip; reference vocoders/nsf.py:31-206) against the tensor-op chain of SourceModuleHnNSF with the same
+    three RNG draws: config-5 length (141 600 samples = 590 frames x 240), a length below the block's thread count, all-voiced and
+    all-unvoiced tracks.  The two prefix sums run in another order than torch.cumsum; a wrap of the first one detected a sample early
+    or late moves the phase by a whole period, which the sine does not see: the merged source agrees within 2e-3 absolute (its range is
+    (-1, 1); measured ~2e-4 at full length, dominated by the O(L) rounding walk of the second sum in both implementations) and the
+    launch is bit-reproducible."""
+    from promptttspp_amd.vocoders import nsf
+
+    torch.manual_seed(11)
+    m = nsf.SourceModuleHnNSF(24000, harmonic_num=8).to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    t = torch.arange(L) / 24000.0
+    f0 = 110.0 + 60.0 * torch.sin(2 * 3.14159 * 0.7 * t)[None, :] * torch.rand(B, 1, generator=g) + 40.0 * torch.rand(B, 1, generator=g)
+    seg = (torch.rand(B, (L + 2399) // 2400, generator=g) < voiced).repeat_interleave(2400, dim=1)[:, :L]
+    f0 = (f0 * seg).unsqueeze(-1).to(dev)
+
+    rand_ini = torch.rand(B, 9, generator=g).to(dev)
+    nz, nz2 = torch.randn(B, L, 9, generator=g).to(dev), torch.randn(B, L, 1, generator=g).to(dev)
+
+    def run(fused):  # (the draws are injected: the tensor-op chain draws its noise for a TRANSPOSED tensor, i.e. in another element order)
+        old, o_rand, o_like = nsf.FUSED_SOURCE, torch.rand, torch.randn_like
+        q_rand, q_like = [rand_ini.clone()], [nz, nz2]
+        nsf.FUSED_SOURCE = fused
+        torch.rand = lambda *a, **k: q_rand.pop(0)
+        torch.randn_like = lambda *a, **k: q_like.pop(0)
+        try:
+            with torch.no_grad():
+                out = m(f0)
+            assert not q_rand and not q_like  # all three draws were taken, in the reference's order
+            return out
+        finally:
+            nsf.FUSED_SOURCE, torch.rand, torch.randn_like = old, o_rand, o_like
+
+    ref, n_ref, uv_ref = run(False)
+    got, n_got, uv_got = run(True)
+    again, _, _ = run(True)
+    assert got.shape == ref.shape == (B, L, 1)
+    assert torch.equal(got, again)
+    assert torch.equal(uv_ref, uv_got) and torch.equal(n_ref, n_got)  # same draws, same order
+    err = float((got - ref).abs().max())
+    assert err < 2e-3, err
+    assert float(ref.abs().max()) > 0.05
+
+
 def test_bigvgan_bench_size_batch_independence(dev):
     """BASELINE config 4 size (64 x 1000 frames, bf16): tiles never span utterances, so every utterance of
     the batch must come out BIT-IDENTICAL to the same utterance synthesised alone (streams / tile order /
