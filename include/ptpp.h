@@ -501,14 +501,15 @@ int ptpp_diffnet_post_bwd(const void* gx, const void* gskip, void* dout,
 int ptpp_diffnet_post_bwd_fill(const void* gskip, void* do_all, const int32_t* lengths, int B, int T, int C, int L, int dtype,
                                void* stream);
 /* Harmonic-plus-noise source of the F0-aware vocoder (promptttspp/vocoders/nsf.py:31-206: SineGen._f02sine + SineGen.forward +
- * SourceModuleHnNSF.forward's Linear + tanh) in one launch.  f0: (B, L) f32 Hz at the sample rate (0 = unvoiced); rand_ini:
+ * SourceModuleHnNSF.forward's Linear + tanh) in three launches of one kernel.  f0: (B, L) f32 Hz at the sample rate (0 = unvoiced); rand_ini:
  * (B, dim) f32 initial phases (column 0 zero); noise: (B, L, dim) f32 standard-normal draws; w: (dim) f32 + bias: the merge
- * layer; out: (B, L) f32.  dim = harmonic_num + 1 in {9, 1} (ptpp_nsf_source_supported).  Both prefix sums run per workgroup in a
+ * layer; out: (B, L) f32.  dim = harmonic_num + 1 in {9, 1} (ptpp_nsf_source_supported).  Both prefix sums run in a
  * fixed order (bit-reproducible; not torch.cumsum's order: csrc/nsf.hip explains why the output does not depend on it). */
 int ptpp_nsf_source_supported(int dim);
+size_t ptpp_nsf_source_scratch_bytes(int B, int L, int dim);   /* the table of range sums between the three launches */
 int ptpp_nsf_source(const float* f0, const float* rand_ini, const float* noise, const float* w, float bias, float* out,
                     int B, int L, int dim, float sampling_rate, float sine_amp, float noise_std, float voiced_threshold,
-                    void* stream);
+                    void* scratch, size_t scratch_bytes, void* stream);
 
 /* out[b,c] = sum_t x[b,t,c] (f32) */
 int ptpp_colsum_batch(const void* x, float* out, int B, int T, int C, int dtype,

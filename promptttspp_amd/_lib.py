@@ -318,7 +318,8 @@ SIGNATURES = {
     "ptpp_conv1d_rt_fwd_cs": (I, [POINTER(ConvArgs), P, ctypes.c_float, P, I, ctypes.c_float, P, P]),
     "ptpp_conv1d_rt_colpart_supported": (I, [I, I, I, I, I]),
     "ptpp_nsf_source_supported": (I, [I]),
-    "ptpp_nsf_source": (I, [P, P, P, P, ctypes.c_float, P, I, I, I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, P]),
+    "ptpp_nsf_source_scratch_bytes": (SZ, [I, I, I]),
+    "ptpp_nsf_source": (I, [P, P, P, P, ctypes.c_float, P, I, I, I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, P, SZ, P]),
     "ptpp_diffnet_layer_supported": (I, [I, I]),
     "ptpp_diffnet_wstream_bytes": (ctypes.c_int64, [I]),
     "ptpp_diffnet_pack_wstream": (I, [P, P, P, I, I, P]),

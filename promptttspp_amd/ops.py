@@ -967,9 +967,11 @@ def nsf_source(f0, rand_ini, noise, w, bias, sampling_rate, sine_amp, noise_std,
     assert noise.shape == (B, L, dim) and w.numel() == dim
     f0, rand_ini, noise, w = f0.contiguous(), rand_ini.contiguous().float(), noise.contiguous(), w.detach().reshape(-1).float().contiguous()
     out = torch.empty((B, L), device=f0.device, dtype=torch.float32)
-    check(_lib.load().ptpp_nsf_source(_ptr(f0), _ptr(rand_ini), _ptr(noise), _ptr(w), float(bias), _ptr(out), B, L, dim,
-                                      float(sampling_rate), float(sine_amp), float(noise_std), float(voiced_threshold), _stream()),
-          "ptpp_nsf_source")
+    lib = _lib.load()
+    tab = torch.empty(int(lib.ptpp_nsf_source_scratch_bytes(B, L, dim)), device=f0.device, dtype=torch.uint8)
+    check(lib.ptpp_nsf_source(_ptr(f0), _ptr(rand_ini), _ptr(noise), _ptr(w), float(bias), _ptr(out), B, L, dim,
+                              float(sampling_rate), float(sine_amp), float(noise_std), float(voiced_threshold), _ptr(tab), tab.numel(),
+                              _stream()), "ptpp_nsf_source")
     return out
 
 
