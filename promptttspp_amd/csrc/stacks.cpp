@@ -275,6 +275,8 @@ static int linear_like_ops(const ptpp_conv1d_args& c, float drop_p, uint64_t see
 static int ffn_conv(const ptpp_conv1d_args& c, const void* wstream, float drop_p, uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
   if (wstream && ptpp_conv1d_rt_ex_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype))
     return ptpp_conv1d_rt_fwd_ex(&c, wstream, 1.0f, drop_p, seed, ws, ws_bytes, stream);
+  // (a caller that hands over streams packs ONLY those: without a usable stream the plain operand must be there)
+  ST_CHECK_ARG(c.wp, "conformer_block: a feed-forward conv has neither a usable operand stream nor a packed operand");
   return linear_like_ops(c, drop_p, seed, ws, ws_bytes, stream);
 }
 

@@ -119,8 +119,8 @@ def _packed_entry(ws, dtype, mode):
     ent = _PackEntry()
     ent.late = False
     _pack_gen[0] += 1
-    ent.refs = [weakref.ref(w, lambda _r, k=key: (_pack_cache.pop(k, None), _pack_gen.__setitem__(0, _pack_gen[0] + 1)))
-                for w in ws]
+    ent.refs = [weakref.ref(w, lambda _r, k=key, cache=_pack_cache, gen=_pack_gen: (cache.pop(k, None), gen.__setitem__(0, gen[0] + 1)))
+                for w in ws]  # (tables bound as defaults: at interpreter shutdown the module globals go before the last parameters)
     ent.mode, ent.dtype = mode, dtype
     ent.wp, ent.vers = _pack_now(ws, dtype, mode), _PackEntry.stamp(ws)
     _pack_cache[key] = ent
@@ -260,7 +260,7 @@ def _cat_cached(ts, kind, make):
     if ent is not None and ent[0] == vers and all(r() is t for r, t in zip(ent[2], ts)):
         return ent[1]
     val = make()
-    _cat_cache[key] = (vers, val, [weakref.ref(t, lambda _r, k=key: _cat_cache.pop(k, None)) for t in ts])
+    _cat_cache[key] = (vers, val, [weakref.ref(t, lambda _r, k=key, cache=_cat_cache: cache.pop(k, None)) for t in ts])
     return val
 
 

@@ -195,8 +195,11 @@ _N_LN, _I_FF, _I_ATT, _I_CM = 10, 10, 18, 29   # offsets into the flat list: nor
 _VARIANT = {"new": 0, "legacy": 1}
 
 
-def _fill_weights(w, P, dt, bn, training):
-    """ptpp_conformer_weights from the flat parameter list ``P`` (packed operands / f32 parameters)."""
+def _fill_weights(w, P, dt, bn, training, ffn_streams=False):
+    """ptpp_conformer_weights from the flat parameter list ``P`` (packed operands / f32 parameters).  ``ffn_streams``: the four
+    feed-forward convs run from operand streams (pack mode 3 / 4, ``ffn_ws``): their mode-0 operands are then never read and are
+    NOT requested -- every cached operand is re-packed after every optimiser step, and these four are 23 % of the model's packed
+    elements each way (tools/bench_pack.py)."""
     import ctypes
 
     f32 = PF._f32_param
@@ -209,10 +212,10 @@ def _fill_weights(w, P, dt, bn, training):
     for i in range(5):
         setattr(w, f"ln_g{i}", ptr(f32(P[i])))
         setattr(w, f"ln_b{i}", ptr(f32(P[5 + i])))
-    w.ffm_w1, w.ffm_b1 = ptr(PF.packed(P[10], dt)), ptr(f32(P[11]))
-    w.ffm_w2, w.ffm_b2 = ptr(PF.packed(P[12], dt)), ptr(f32(P[13]))
-    w.ff_w1, w.ff_b1 = ptr(PF.packed(P[14], dt)), ptr(f32(P[15]))
-    w.ff_w2, w.ff_b2 = ptr(PF.packed(P[16], dt)), ptr(f32(P[17]))
+    if not ffn_streams:
+        w.ffm_w1, w.ffm_w2 = ptr(PF.packed(P[10], dt)), ptr(PF.packed(P[12], dt))
+        w.ff_w1, w.ff_w2 = ptr(PF.packed(P[14], dt)), ptr(PF.packed(P[16], dt))
+    w.ffm_b1, w.ffm_b2, w.ff_b1, w.ff_b2 = ptr(f32(P[11])), ptr(f32(P[13])), ptr(f32(P[15])), ptr(f32(P[17]))
     w.qkv_w = ptr(PF.packed_cat((P[18], P[20], P[22]), dt))
     w.qkv_b = ptr(PF.bias_cat((P[19], P[21], P[23])))
     w.pos_w = ptr(PF.packed(P[24], dt))
@@ -252,7 +255,11 @@ class ConformerBlockFn(torch.autograd.Function):
         slab = torch.empty(lib.ptpp_conformer_block_slab_bytes(B, T, C, F_, H, L, dcode), device=dev, dtype=torch.uint8)
         y = torch.empty_like(x)
         a = _lib.ConformerFwdArgs()
-        keep = _fill_weights(a.w, P, dt, cfg.bn, cfg.training)
+        # the feed-forward convs on the row-tile engine where they qualify (operand streams, pack mode 3): ops.conv1d's rule
+        hF = x.new_empty((1, 1, F_))
+        streams = ops.conv1d_rt_ex_ok(x, F_, P[10].shape[2], 1, "relu") and ops.conv1d_rt_ex_ok(hF, C, P[10].shape[2], 1, None) and \
+            all(isinstance(P[i], torch.nn.Parameter) for i in (10, 12, 14, 16))
+        keep = _fill_weights(a.w, P, dt, cfg.bn, cfg.training, ffn_streams=streams)
         lens = ops.i32(cfg.lengths, dev)
         a.x, a.y, a.pos_emb, a.lengths = x.data_ptr(), y.data_ptr(), pos.data_ptr(), lens.data_ptr()
         a.slab, a.slab_bytes = slab.data_ptr(), slab.numel()
@@ -267,10 +274,7 @@ class ConformerBlockFn(torch.autograd.Function):
         a.B, a.T, a.C, a.F, a.H, a.L = B, T, C, F_, H, L
         a.ks_ffn, a.ks_dw, a.variant = P[10].shape[2], P[33].shape[-1], _VARIANT[cfg.variant]
         a.bn_train, a.save, a.dtype = int(cfg.training), int(need_bwd), dcode
-        # the feed-forward convs on the row-tile engine where they qualify (operand streams, pack mode 3): ops.conv1d's rule
-        hF = x.new_empty((1, 1, F_))
-        if ops.conv1d_rt_ex_ok(x, F_, P[10].shape[2], 1, "relu") and ops.conv1d_rt_ex_ok(hF, C, P[10].shape[2], 1, None) and \
-                all(isinstance(P[i], torch.nn.Parameter) for i in (10, 12, 14, 16)):
+        if streams:
             for k, i in enumerate((10, 12, 14, 16)):
                 t = PF.packed(P[i], dt, mode=3)
                 keep.append(t)
@@ -314,16 +318,20 @@ class ConformerBlockFn(torch.autograd.Function):
         a = _lib.ConformerBwdArgs()
         a.w = ctx.w
         a.gy, a.gx, a.x, a.pos_emb, a.lengths = gy.data_ptr(), gx.data_ptr(), x.data_ptr(), pos.data_ptr(), lens.data_ptr()
-        tr = [PF.packed(P[i], dt, mode=1) for i in (10, 12, 14, 16)] + [PF.packed_cat((P[18], P[20], P[22]), dt, mode=1)] + \
-             [PF.packed(P[i], dt, mode=1) for i in (25, 29, 31)]
-        (a.ffm_w1t, a.ffm_w2t, a.ff_w1t, a.ff_w2t, a.qkv_wt, a.out_wt, a.pw1_wt, a.pw2_wt) = [t.data_ptr() for t in tr]
         hF = gy.new_empty((1, 1, F_))
-        if ops.conv1d_rt_ex_ok(gy, F_, P[10].shape[2], 1, None) and ops.conv1d_rt_ex_ok(hF, C, P[10].shape[2], 1, None) and \
-                all(isinstance(P[i], torch.nn.Parameter) for i in (10, 12, 14, 16)):
-            for k, i in enumerate((10, 12, 14, 16)):  # the data gradients' operand streams (pack mode 4)
+        streams = ops.conv1d_rt_ex_ok(gy, F_, P[10].shape[2], 1, None) and ops.conv1d_rt_ex_ok(hF, C, P[10].shape[2], 1, None) and \
+            all(isinstance(P[i], torch.nn.Parameter) for i in (10, 12, 14, 16))
+        tr = [PF.packed_cat((P[18], P[20], P[22]), dt, mode=1)] + [PF.packed(P[i], dt, mode=1) for i in (25, 29, 31)]
+        (a.qkv_wt, a.out_wt, a.pw1_wt, a.pw2_wt) = [t.data_ptr() for t in tr]
+        if streams:  # the feed-forward data gradients' operand streams (pack mode 4); their mode-1 operands are not requested
+            for k, i in enumerate((10, 12, 14, 16)):
                 t = PF.packed(P[i], dt, mode=4)
                 tr.append(t)
                 a.ffn_wts[k] = t.data_ptr()
+        else:
+            tf = [PF.packed(P[i], dt, mode=1) for i in (10, 12, 14, 16)]
+            (a.ffm_w1t, a.ffm_w2t, a.ff_w1t, a.ff_w2t) = [t.data_ptr() for t in tf]
+            tr += tf
         g = a.g
         for i in range(5):
             setattr(g, f"ln_g{i}", tg[i].data_ptr())
