@@ -106,8 +106,19 @@ def _pack_now(ws, dtype, mode):
 
 
 def _packed_entry(ws, dtype, mode):
-    key = (tuple(id(w) for w in ws), mode, dtype)
-    ent = _pack_cache.get(key)
+    if len(ws) == 1:  # (the common case, ~250 calls per training step: no generator / list objects on the hit path)
+        w = ws[0]
+        key = ((id(w),), mode, dtype)
+        ent = _pack_cache.get(key)
+        if ent is not None and ent.refs[0]() is w:
+            v = ent.vers[0]
+            if v[0] == w._version and v[1] == w.data_ptr():
+                if ent.late and _late["pending"]:
+                    join_late_pack()
+                return ent
+    else:
+        key = (tuple(id(w) for w in ws), mode, dtype)
+        ent = _pack_cache.get(key)
     if ent is not None:
         live = ent.srcs()
         if live is not None and all(a is b for a, b in zip(live, ws)):

@@ -35,6 +35,7 @@ from ...utils.model import sequence_mask
 # dependency that is not found yet; modes 0 / 1 / 2: 6 of 6 clean), so it is never the default
 BRANCH_STREAMS = os.environ.get("PTPP_BRANCH_STREAMS", "2")
 REJOIN = not os.environ.get("PTPP_NO_REJOIN")  # the reference-encoder branch is differentiated from its join (functional.RejoinBranchFn)
+EARLY_QSAMPLE = not os.environ.get("PTPP_QSAMPLE_LATE")  # the decoder's draws + q_sample before the reference-encoder join
 PROMPT_FIRST = not os.environ.get("PTPP_PROMPT_LATE")  # the prompt branch is issued at the start of the forward
 FUSED_GLUE = not os.environ.get("PTPP_NO_FUSED_GLUE")  # (tests compare the fused training forward with the general one)
 JOIN_PROBE = None  # tools/diag_joins.py sets a list: (name, event on the waiting stream before the wait, event at the branch's end)
@@ -178,6 +179,8 @@ class PromptTTSMDNDurCFG(nn.Module):
         x = self.phoneme_emb.forward_cl(phoneme, None, dt, lengths=plen)
         x = self.encoder.forward_cl(x, plen, None)
         Tf = mel.shape[-1]
+        # (the decoder's draws and q_sample need neither branch: issued here, they fill the main stream's wait for the join below)
+        prep = self.decoder.prepare_bct(mel, dt) if EARLY_QSAMPLE else None
         if sa is not None:
             _probe("reference encoder -> x + style_emb", torch.cuda.current_stream(), sa)
             torch.cuda.current_stream().wait_stream(sa)
@@ -199,7 +202,7 @@ class PromptTTSMDNDurCFG(nn.Module):
         vb = (bs, sa) if (branches and BRANCH_STREAMS == "3") else None
         h, y_dur, pv, _, _ = self.variance_adaptor.forward_cl(x, plen, flen, None, duration.squeeze(1), log_cf0.squeeze(1), None,
                                                               branch_streams=vb, raw=True, Tf=Tf)
-        noise, pred = self.decoder.forward_bct(h, mel, flen)
+        noise, pred = self.decoder.forward_bct(h, mel, flen, prep=prep)
         if bs is not None:  # join: the losses read the branches' outputs
             main = torch.cuda.current_stream()
             _probe("prompt branch -> losses", main, bs)

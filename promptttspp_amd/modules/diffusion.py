@@ -157,20 +157,28 @@ class GaussianDiffusion(nn.Module):
         pred = self.denoise_fn.forward_cl(x_noisy.to(cond.dtype), t, cond, lengths)
         return noise, (pred.float() if pred_f32 else pred)
 
-    def forward_bct(self, cond, mel_bct, lengths):
-        """The training forward on the dataset's mel layout: cond (B,T,Cc) channels-last compute dtype, mel_bct (B,M,T) f32 ->
-        (noise (B,T,M) f32, prediction (B,T,M) in the compute dtype).  Normalisation, q_sample and the cast are ONE launch
-        (ptpp_q_sample_bct) instead of a transposed copy + nine tensor ops; same arithmetic as ``forward_cl``."""
-        B = cond.shape[0]
+    def prepare_bct(self, mel_bct, dtype):
+        """The part of ``forward_bct`` that does not depend on the conditioner: the step and noise draws and q_sample (no
+        parameters, no autograd nodes).  The model issues it while the main stream would otherwise wait for the reference-encoder
+        branch (profiles/r06_step_tail.txt: a 140 us gap before ``x + style_emb``)."""
+        B, dev = mel_bct.shape[0], mel_bct.device
         inj = self.injected
         self.injected = None
         if inj is not None:
-            t, noise = inj["t"].to(cond.device), inj["noise"].to(cond.device).transpose(1, 2).float().contiguous()
+            t, noise = inj["t"].to(dev), inj["noise"].to(dev).transpose(1, 2).float().contiguous()
         else:
-            t = torch.randint(0, self.K_step, (B,), device=cond.device).long()
-            noise = torch.randn((B, mel_bct.shape[2], mel_bct.shape[1]), device=cond.device, dtype=torch.float32)
+            t = torch.randint(0, self.K_step, (B,), device=dev).long()
+            noise = torch.randn((B, mel_bct.shape[2], mel_bct.shape[1]), device=dev, dtype=torch.float32)
         x_noisy = ops.q_sample_bct(mel_bct.float().contiguous(), noise, t.contiguous(), self.sqrt_alphas_cumprod,
-                                   self.sqrt_one_minus_alphas_cumprod, self.norm_scale, self.a_min, self.a_max, cond.dtype)
+                                   self.sqrt_one_minus_alphas_cumprod, self.norm_scale, self.a_min, self.a_max, dtype)
+        return t, noise, x_noisy
+
+    def forward_bct(self, cond, mel_bct, lengths, prep=None):
+        """The training forward on the dataset's mel layout: cond (B,T,Cc) channels-last compute dtype, mel_bct (B,M,T) f32 ->
+        (noise (B,T,M) f32, prediction (B,T,M) in the compute dtype).  Normalisation, q_sample and the cast are ONE launch
+        (ptpp_q_sample_bct) instead of a transposed copy + nine tensor ops; same arithmetic as ``forward_cl``.  ``prep``: the
+        result of an earlier ``prepare_bct(mel_bct, cond.dtype)``."""
+        t, noise, x_noisy = prep if prep is not None else self.prepare_bct(mel_bct, cond.dtype)
         return noise, self.denoise_fn.forward_cl(x_noisy, t, cond, lengths)
 
     def forward(self, cond, lengths=None, y=None, g=None, mask=None):
