@@ -179,16 +179,37 @@ class EncoderLayer(nn.Module):
 # autograd nodes per block.
 # ----------------------------------------------------------------------------------------------------------------------
 def _block_params(layer):
-    """The block's parameters in the order of ``ConformerBlockFn``'s flat argument list."""
-    a, cm = layer.self_attn, layer.conv_module
-    ffm, ff = layer.feed_forward_macaron, layer.feed_forward
-    norms = (layer.norm_ff_macaron, layer.norm_mha, layer.norm_conv, layer.norm_ff, layer.norm_final)
-    return ([n.weight for n in norms] + [n.bias for n in norms] +
-            [ffm.w_1.weight, ffm.w_1.bias, ffm.w_2.weight, ffm.w_2.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias,
-             a.linear_q.weight, a.linear_q.bias, a.linear_k.weight, a.linear_k.bias, a.linear_v.weight, a.linear_v.bias,
-             a.linear_pos.weight, a.linear_out.weight, a.linear_out.bias, a.pos_bias_u, a.pos_bias_v,
-             cm.pointwise_conv1.weight, cm.pointwise_conv1.bias, cm.pointwise_conv2.weight, cm.pointwise_conv2.bias,
-             cm.depthwise_conv.weight, cm.depthwise_conv.bias, cm.norm.weight, cm.norm.bias])
+    """The block's parameters in the order of ``ConformerBlockFn``'s flat argument list.  The (module, name) pairs are resolved
+    once per layer object; every call re-checks that each module on the paths is still the same child of its parent (20 dict reads)
+    and then reads the CURRENT Parameter objects from the modules' ``_parameters`` tables -- 57 dict reads instead of ~75
+    ``nn.Module.__getattr__`` calls per call, four calls per direction and step."""
+    spec = layer.__dict__.get("_ptpp_param_spec")
+    if spec is not None:
+        for d, n, o in spec[0]:
+            if d[n] is not o:
+                spec = None
+                break
+    if spec is None:
+        a, cm, ffm, ff = layer.self_attn, layer.conv_module, layer.feed_forward_macaron, layer.feed_forward
+        norms = (layer.norm_ff_macaron, layer.norm_mha, layer.norm_conv, layer.norm_ff, layer.norm_final)
+        pairs = [(n, "weight") for n in norms] + [(n, "bias") for n in norms] + \
+                [(ffm.w_1, "weight"), (ffm.w_1, "bias"), (ffm.w_2, "weight"), (ffm.w_2, "bias"),
+                 (ff.w_1, "weight"), (ff.w_1, "bias"), (ff.w_2, "weight"), (ff.w_2, "bias"),
+                 (a.linear_q, "weight"), (a.linear_q, "bias"), (a.linear_k, "weight"), (a.linear_k, "bias"),
+                 (a.linear_v, "weight"), (a.linear_v, "bias"), (a.linear_pos, "weight"), (a.linear_out, "weight"),
+                 (a.linear_out, "bias"), (a, "pos_bias_u"), (a, "pos_bias_v"),
+                 (cm.pointwise_conv1, "weight"), (cm.pointwise_conv1, "bias"), (cm.pointwise_conv2, "weight"),
+                 (cm.pointwise_conv2, "bias"), (cm.depthwise_conv, "weight"), (cm.depthwise_conv, "bias"),
+                 (cm.norm, "weight"), (cm.norm, "bias")]
+        checks = [(layer._modules, n, layer._modules[n]) for n in ("self_attn", "conv_module", "feed_forward_macaron", "feed_forward",
+                                                                  "norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff", "norm_final")]
+        for parent, names in ((ffm, ("w_1", "w_2")), (ff, ("w_1", "w_2")),
+                              (a, ("linear_q", "linear_k", "linear_v", "linear_pos", "linear_out")),
+                              (cm, ("pointwise_conv1", "pointwise_conv2", "depthwise_conv", "norm"))):
+            checks += [(parent._modules, n, parent._modules[n]) for n in names]
+        spec = (checks, [(m._parameters, n) for m, n in pairs])
+        layer.__dict__["_ptpp_param_spec"] = spec
+    return [d[n] for d, n in spec[1]]
 
 
 _N_LN, _I_FF, _I_ATT, _I_CM = 10, 10, 18, 29   # offsets into the flat list: norms, feed-forward pair, attention, conv module
@@ -199,40 +220,26 @@ def _fill_weights(w, P, dt, bn, training, ffn_streams=False):
     """ptpp_conformer_weights from the flat parameter list ``P`` (packed operands / f32 parameters).  ``ffn_streams``: the four
     feed-forward convs run from operand streams (pack mode 3 / 4, ``ffn_ws``): their mode-0 operands are then never read and are
     NOT requested -- every cached operand is re-packed after every optimiser step, and these four are 23 % of the model's packed
-    elements each way (tools/bench_pack.py)."""
-    import ctypes
+    elements each way (tools/bench_pack.py).  (Called once per block and direction: one positional struct construction instead of
+    ~40 attribute stores.)"""
+    from ... import _lib
 
-    f32 = PF._f32_param
-    keep = []
-
-    def ptr(t):
-        keep.append(t)
-        return t.data_ptr()
-
-    for i in range(5):
-        setattr(w, f"ln_g{i}", ptr(f32(P[i])))
-        setattr(w, f"ln_b{i}", ptr(f32(P[5 + i])))
-    if not ffn_streams:
-        w.ffm_w1, w.ffm_w2 = ptr(PF.packed(P[10], dt)), ptr(PF.packed(P[12], dt))
-        w.ff_w1, w.ff_w2 = ptr(PF.packed(P[14], dt)), ptr(PF.packed(P[16], dt))
-    w.ffm_b1, w.ffm_b2, w.ff_b1, w.ff_b2 = ptr(f32(P[11])), ptr(f32(P[13])), ptr(f32(P[15])), ptr(f32(P[17]))
-    w.qkv_w = ptr(PF.packed_cat((P[18], P[20], P[22]), dt))
-    w.qkv_b = ptr(PF.bias_cat((P[19], P[21], P[23])))
-    w.pos_w = ptr(PF.packed(P[24], dt))
-    w.out_w, w.out_b = ptr(PF.packed(P[25], dt)), ptr(f32(P[26]))
-    w.bias_u, w.bias_v = ptr(f32(P[27])), ptr(f32(P[28]))
-    w.pw1_w, w.pw1_b = ptr(PF.packed(P[29], dt)), ptr(f32(P[30]))
-    w.pw2_w, w.pw2_b = ptr(PF.packed(P[31], dt)), ptr(f32(P[32]))
+    f32, pk = PF._f32_param, PF.packed
     C = P[33].shape[0]
-    w.dw_w, w.dw_b = ptr(f32(P[33]).reshape(C, -1)), ptr(f32(P[34]))
-    w.bn_g, w.bn_b = ptr(f32(P[35])), ptr(f32(P[36]))
+    none4 = (None, None, None, None)
+    ffn = none4 if ffn_streams else (pk(P[10], dt), pk(P[12], dt), pk(P[14], dt), pk(P[16], dt))
     if training:
-        if bn.running_mean is not None and bn.running_var is not None:
-            w.bn_rmean, w.bn_rvar = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        has = bn.running_mean is not None and bn.running_var is not None
+        stats = (bn.running_mean if has else None, bn.running_var if has else None, None, None)
     else:
-        w.bn_mean_in = ptr(bn.running_mean.float().contiguous())
-        w.bn_rstd_in = ptr(torch.rsqrt(bn.running_var.float() + bn.eps).contiguous())
-    return keep
+        stats = (None, None, bn.running_mean.float().contiguous(), torch.rsqrt(bn.running_var.float() + bn.eps).contiguous())
+    ts = [f32(P[0]), f32(P[1]), f32(P[2]), f32(P[3]), f32(P[4]), f32(P[5]), f32(P[6]), f32(P[7]), f32(P[8]), f32(P[9]),
+          ffn[0], f32(P[11]), ffn[1], f32(P[13]), ffn[2], f32(P[15]), ffn[3], f32(P[17]),
+          PF.packed_cat((P[18], P[20], P[22]), dt), PF.bias_cat((P[19], P[21], P[23])), pk(P[24], dt), pk(P[25], dt), f32(P[26]),
+          f32(P[27]), f32(P[28]), pk(P[29], dt), f32(P[30]), pk(P[31], dt), f32(P[32]), f32(P[33]).reshape(C, -1), f32(P[34]),
+          f32(P[35]), f32(P[36]), *stats]
+    w.__init__(*[None if t is None else t.data_ptr() for t in ts])
+    return [t for t in ts if t is not None]
 
 
 class ConformerBlockFn(torch.autograd.Function):
@@ -332,15 +339,8 @@ class ConformerBlockFn(torch.autograd.Function):
             tf = [PF.packed(P[i], dt, mode=1) for i in (10, 12, 14, 16)]
             (a.ffm_w1t, a.ffm_w2t, a.ff_w1t, a.ff_w2t) = [t.data_ptr() for t in tf]
             tr += tf
-        g = a.g
-        for i in range(5):
-            setattr(g, f"ln_g{i}", tg[i].data_ptr())
-            setattr(g, f"ln_b{i}", tg[5 + i].data_ptr())
-        names = ("ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "ff_w1", "ff_b1", "ff_w2", "ff_b2", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b",
-                 "pos_w", "out_w", "out_b", "bias_u", "bias_v", "pw1_w", "pw1_b", "pw2_w", "pw2_b", "dw_w", "dw_b")
-        for n, t in zip(names, tg[10:35]):
-            setattr(g, n, t.data_ptr())
-        g.bn_sums = bn_sums.data_ptr()
+        # (the accumulation targets in the field order of ptpp_conformer_grads = the order of the flat parameter list)
+        a.g.__init__(*[t.data_ptr() for t in tg[:35]], bn_sums.data_ptr())
         a.slab, a.scratch, a.scratch_bytes = slab.data_ptr(), scratch.data_ptr(), scratch.numel()
         d = PF._direct
         side_h = None
