@@ -546,10 +546,20 @@ int ptpp_bn_act_bwd(const void* x, const void* dy, const float* mean,
                     const float* rstd, const float* gamma, const float* beta,
                     float* sums, void* dx, int64_t rows, int C, int act, int train,
                     int dtype, void* scratch, size_t scratch_bytes, void* stream);
+/* ... with the two sums also ADDED to the parameter gradients (dbeta_acc / dgamma_acc, (C) f32 each or NULL) by the same
+ * finishing launch (round 6: the Conformer block's backward added them with a tensor op per block before) */
+int ptpp_bn_act_bwd_acc(const void* x, const void* dy, const float* mean,
+                        const float* rstd, const float* gamma, const float* beta,
+                        float* sums, float* dbeta_acc, float* dgamma_acc, void* dx, int64_t rows, int C, int act,
+                        int train, int dtype, void* scratch, size_t scratch_bytes, void* stream);
 /* u = h[:, :C] * sigmoid(h[:, C:]) and its backward */
 int ptpp_glu_fwd(const void* h, void* u, int64_t rows, int C, int dtype, void* stream);
 int ptpp_glu_bwd(const void* h, const void* du, void* dh, int64_t rows, int C,
                  int dtype, void* stream);
+/* ... on (B, T, .) rows with the gradient of rows t >= lengths[b] written as zero (the mask of the pointwise conv that produced h,
+ * modules/esp/conformer/convolution.py:58-85 differentiated): one launch instead of glu_bwd + a masking pass; lengths NULL = no mask */
+int ptpp_glu_bwd_masked(const void* h, const void* du, void* dh, const int32_t* lengths, int B, int T, int C, int dtype,
+                        void* stream);
 /* depthwise conv over time, w: (C, ks) f32, "same" padding, output rows t >= len
  * zeroed; flip=1: data gradient (input = dy, masked rows ignored). ks in {7,15,31} */
 int ptpp_dwconv1d(const void* u, const float* w, const float* bias, void* y,
@@ -998,6 +1008,8 @@ typedef struct {
   void* side_stream2;                           /* round 6: with side_stream, a SECOND stream that takes the depthwise and the 1 x 1
                                                    weight gradients while side_stream runs the k = 9 ones; or NULL.  The caller
                                                    joins both before it reads the gradients. */
+  float* bn_dgamma; float* bn_dbeta;            /* round 6: accumulation targets of the BatchNorm parameter gradients or NULL (then
+                                                   the caller adds g.bn_sums itself) */
 } ptpp_conformer_block_bwd_args;
 size_t ptpp_conformer_block_bwd_scratch_bytes(int B, int T, int C, int F, int H, int L, int dtype);
 int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, void* stream);

@@ -196,7 +196,7 @@ class ConformerBwdArgs(Structure):
                 ("red_scratch", c_void_p), ("red_bytes", ctypes.c_size_t), ("side_stream", c_void_p), ("seeds", c_void_p),
                 ("p_ffn", c_float), ("p_drop", c_float)] + \
                [(n, c_int32) for n in ("B", "T", "C", "F", "H", "L", "ks_ffn", "ks_dw", "variant", "bn_train", "dtype")] + \
-               [("ffn_wts", c_void_p * 4), ("side_stream2", c_void_p)]
+               [("ffn_wts", c_void_p * 4), ("side_stream2", c_void_p), ("bn_dgamma", c_void_p), ("bn_dbeta", c_void_p)]
 
 
 class WgradGProblem(Structure):
@@ -280,6 +280,8 @@ SIGNATURES = {
     "ptpp_bn_stats": (I, [P, I64, I, F, F, P, P, P, P, I, P, SZ, P]),
     "ptpp_bn_act_fwd": (I, [P, P, P, P, P, P, I64, I, I, I, P]),
     "ptpp_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, I64, I, I, I, I, P, SZ, P]),
+    "ptpp_bn_act_bwd_acc": (I, [P, P, P, P, P, P, P, P, P, P, I64, I, I, I, I, P, SZ, P]),
+    "ptpp_glu_bwd_masked": (I, [P, P, P, P, I, I, I, I, P]),
     "ptpp_glu_fwd": (I, [P, P, I64, I, I, P]),
     "ptpp_glu_bwd": (I, [P, P, P, I64, I, I, P]),
     "ptpp_dwconv1d": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),

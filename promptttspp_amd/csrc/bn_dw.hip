@@ -216,11 +216,17 @@ __global__ void glu_fwd_kernel(const T* __restrict__ h, T* __restrict__ u, int C
   }
 }
 template <typename T>
-__global__ void glu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ du, T* __restrict__ dh, int C, int64_t nvec) {
+__global__ void glu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ du, T* __restrict__ dh, int C, int64_t nvec,
+                               const int* __restrict__ lengths, int Tlen) {
   const int cv = C >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / cv;
     const int c = (int)(i % cv) * 4;
+    if (lengths && (int)(row % Tlen) >= lengths[row / Tlen]) {  // (rows past an utterance's end: zero gradient)
+      Elem<T>::st4(dh + row * 2 * C + c, f32x4{0.f, 0.f, 0.f, 0.f});
+      Elem<T>::st4(dh + row * 2 * C + C + c, f32x4{0.f, 0.f, 0.f, 0.f});
+      continue;
+    }
     const f32x4 a = Elem<T>::ld4(h + row * 2 * C + c), g = Elem<T>::ld4(h + row * 2 * C + C + c), d = Elem<T>::ld4(du + i * 4);
     f32x4 da, dg;
 #pragma unroll
@@ -533,6 +539,13 @@ extern "C" int ptpp_bn_act_fwd(const void* x, const float* mean, const float* rs
 extern "C" int ptpp_bn_act_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, float* sums, void* dx, int64_t rows, int C, int act, int train, int dtype,
                                void* scratch, size_t scratch_bytes, void* stream) {
+  return ptpp_bn_act_bwd_acc(x, dy, mean, rstd, gamma, beta, sums, nullptr, nullptr, dx, rows, C, act, train, dtype, scratch, scratch_bytes,
+                             stream);
+}
+
+extern "C" int ptpp_bn_act_bwd_acc(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, float* sums, float* dbeta_acc, float* dgamma_acc, void* dx, int64_t rows, int C,
+                                   int act, int train, int dtype, void* scratch, size_t scratch_bytes, void* stream) {
   PTPP_CHECK_ARG(x && dy && mean && rstd && gamma && beta && sums && dx && rows > 0 && cgeom_ok(C), "bn_act_bwd: bad args");
   PTPP_CHECK_ARG(red_scratch_ok(scratch, scratch_bytes, 2 * C), "bn_act_bwd: reduction scratch missing or too small");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -544,7 +557,10 @@ extern "C" int ptpp_bn_act_bwd(const void* x, const void* dy, const float* mean,
   DISPATCH_T(dtype, "bn_act_bwd",
              hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)x, (const T*)dy, mean, rstd,
                                 gamma, beta, scratch, rows, C, act, rpb);
-             red_sum_launch(scratch, 2 * C, sums, 2 * C, nullptr, 0, st);
+             if (dbeta_acc || dgamma_acc)
+               hipLaunchKernelGGL(red_sum_both_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, st, reinterpret_cast<float*>(scratch), 2 * C, sums,
+                                  dbeta_acc, C, dgamma_acc);
+             else red_sum_launch(scratch, 2 * C, sums, 2 * C, nullptr, 0, st);
              hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(nb2), dim3(256), 0, st, (const T*)x, (const T*)dy, mean, rstd,
                                 gamma, beta, sums, (T*)dx, rows, C, act, 1.0f / (float)rows, train, rpb2));
   PTPP_CHECK_LAUNCH("bn_act_bwd");
@@ -561,11 +577,17 @@ extern "C" int ptpp_glu_fwd(const void* h, void* u, int64_t rows, int C, int dty
 }
 
 extern "C" int ptpp_glu_bwd(const void* h, const void* du, void* dh, int64_t rows, int C, int dtype, void* stream) {
-  PTPP_CHECK_ARG(h && du && dh && rows > 0 && C > 0 && C % 4 == 0, "glu_bwd: bad args");
-  const int64_t nvec = rows * C / 4;
+  return ptpp_glu_bwd_masked(h, du, dh, nullptr, 1, (int)rows, C, dtype, stream);
+}
+
+extern "C" int ptpp_glu_bwd_masked(const void* h, const void* du, void* dh, const int32_t* lengths, int B, int T_, int C, int dtype,
+                                   void* stream) {
+  PTPP_CHECK_ARG(h && du && dh && B > 0 && T_ > 0 && C > 0 && C % 4 == 0, "glu_bwd: bad args");
+  const int64_t nvec = (int64_t)B * T_ * C / 4;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   DISPATCH_T(dtype, "glu_bwd",
-             hipLaunchKernelGGL(glu_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)h, (const T*)du, (T*)dh, C, nvec));
+             hipLaunchKernelGGL(glu_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(256), 0, st, (const T*)h, (const T*)du, (T*)dh, C, nvec,
+                                lengths, T_));
   PTPP_CHECK_LAUNCH("glu_bwd");
   return PTPP_OK;
 }

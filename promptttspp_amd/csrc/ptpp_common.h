@@ -289,6 +289,25 @@ static __global__ void red_sum_kernel(float* __restrict__ scratch, int KC, float
   float* d = c < n0 ? (dst0 ? dst0 + c : nullptr) : (dst1 ? dst1 + (c - n0) : nullptr);
   if (d) *d = accumulate ? *d + s : s;
 }
+// ... the totals OVERWRITE dst[0 .. KC) (a consumer launch reads them at once) and are also ADDED to acc0 / acc1 (columns < n0 /
+// the rest; either may be NULL) -- BatchNorm's backward needs its two sums for dx and owes them to the parameter gradients
+static __global__ void red_sum_both_kernel(float* __restrict__ scratch, int KC, float* __restrict__ dst, float* __restrict__ acc0, int n0,
+                                           float* __restrict__ acc1) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= KC) return;
+  float v[PTPP_RED_NREP];
+#pragma unroll
+  for (int r = 0; r < PTPP_RED_NREP; ++r) v[r] = scratch[(size_t)r * KC + c];
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < PTPP_RED_NREP; ++r) {
+    s += v[r];
+    scratch[(size_t)r * KC + c] = 0.f;
+  }
+  dst[c] = s;
+  float* d = c < n0 ? (acc0 ? acc0 + c : nullptr) : (acc1 ? acc1 + (c - n0) : nullptr);
+  if (d) *d += s;
+}
 inline void red_sum_launch(void* scratch, int KC, float* dst0, int n0, float* dst1, int accumulate, hipStream_t st) {
   hipLaunchKernelGGL(red_sum_kernel, dim3((KC + 63) / 64), dim3(64), 0, st, reinterpret_cast<float*>(scratch), KC, dst0,
                      n0, dst1, accumulate);

@@ -629,11 +629,11 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
   // (the depthwise conv's output gradient gets a region of its own: its weight gradient joins the block's other weight
   //  gradients on the side stream at the end instead of sitting on the main one -- 60 us per block of a serial, atomics-bound kernel)
   void* dz_dw = sl(X, sc.dz_c[4]);
-  ST_TRY(ptpp_bn_act_bwd(sl(S, lo.d), t2, bmean, brstd, w.bn_g, w.bn_b, g.bn_sums, dz_dw, (int64_t)R, C, PTPP_ACT_SWISH, a->bn_train, dt,
-                         a->red_scratch, a->red_bytes, stream));
+  ST_TRY(ptpp_bn_act_bwd_acc(sl(S, lo.d), t2, bmean, brstd, w.bn_g, w.bn_b, g.bn_sums, a->bn_dbeta, a->bn_dgamma, dz_dw, (int64_t)R, C,
+                             PTPP_ACT_SWISH, a->bn_train, dt, a->red_scratch, a->red_bytes, stream));
   ST_TRY(ptpp_dwconv1d(dz_dw, w.dw_w, nullptr, t2, len, B, T, C, a->ks_dw, 1, dt, stream));
-  ST_TRY(ptpp_glu_bwd(sl(S, lo.g), t2, sl(X, sc.g2a), (int64_t)R, C, dt, stream));
-  ST_TRY(ptpp_epilogue_bwd(sl(X, sc.g2a), nullptr, sl(X, sc.dz_2c), len, B, T, 2 * C, 1.0f, 0, 1, 0.f, 0, dt, stream));
+  // (the GLU backward writes the masked gradient of the pointwise conv's output at once: round 5 ran a masking pass after it)
+  ST_TRY(ptpp_glu_bwd_masked(sl(S, lo.g), t2, sl(X, sc.dz_2c), len, B, T, C, dt, stream));
   c = conv_args(sl(X, sc.dz_2c), 2 * C, a->pw1_wt, nullptr, nullptr, 0, t1, C, len, B, T, 2 * C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
   ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
   ST_TRY(wgrad(sl(S, lo.n3), C, sl(X, sc.dz_2c), 2 * C, g.pw1_w, g.pw1_b, len, B, T, C, 2 * C, 1, 0, 0));

@@ -356,6 +356,8 @@ class ConformerBlockFn(torch.autograd.Function):
         a.red_scratch, a.red_bytes = ops.reduction_scratch(dev)
         a.side_stream = side_h
         a.side_stream2 = PF.second_wgrad_stream(dev) if side_h is not None else None
+        if ctx.bn_direct:  # the BatchNorm parameter gradients are added by the finishing launch of their sums
+            a.bn_dgamma, a.bn_dbeta = P[35].grad.data_ptr(), P[36].grad.data_ptr()
         sd = (ctypes.c_uint64 * 6)(*ctx.seeds)
         a.seeds = ctypes.cast(sd, ctypes.c_void_p)
         a.p_ffn, a.p_drop = cfg.p_ffn, cfg.p
@@ -368,7 +370,7 @@ class ConformerBlockFn(torch.autograd.Function):
             d["keep"].extend((x, pos, slab, scratch))
         ctx.tensors = None
         grads = []
-        if ctx.bn_direct:
+        if ctx.bn_direct and not a.bn_dgamma:
             torch._foreach_add_([P[35].grad, P[36].grad], [bn_sums[C:].view_as(P[35]), bn_sums[:C].view_as(P[36])])
         for i, (t, dr) in enumerate(zip(P, ctx.direct)):
             if dr or (ctx.bn_direct and i in (35, 36)):
