@@ -185,6 +185,12 @@ int ptpp_conv1d_rt_ex_supported(int cin, int cout, int ks, int dil, int act, int
 int ptpp_conv_rt_set_min_rows(long long rows);
 int ptpp_conv1d_rt_fwd_ex(const ptpp_conv1d_args* a, const void* wstream, float res_scale, float drop_p, uint64_t drop_seed,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* ... where y is only an intermediate of a backward chain (the Conformer feed-forward: gradient w.r.t. the hidden activation ->
+ * ReLU / dropout backward -> next data gradient): dz = [saved > 0 and t < lengths[b]] * bf16(y) / (1 - drop_p), the arithmetic of
+ * ptpp_epilogue_bwd(y, saved, dz, lengths, .., 1, 1, 1, drop_p) from the conv's epilogue -- a->y is scratch (written only when the
+ * launch had to be split).  a: no bias / residual / activation / output mask, ldy = Cout, lengths required. */
+int ptpp_conv1d_rt_fwd_ex_relu_bwd(const ptpp_conv1d_args* a, const void* wstream, const void* saved, void* dz, float drop_p,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same with an optional scratch (16-byte aligned device memory, NULL = none): layers with few
  * output tiles and a long K (Conformer FFN k = 9, BERT FFN) are then split over K -- f32 partial sums

@@ -315,6 +315,7 @@ SIGNATURES = {
     "ptpp_conv1d_rt_ex_supported": (I, [I, I, I, I, I, I]),
     "ptpp_conv_rt_set_min_rows": (I, [c_longlong]),
     "ptpp_conv1d_rt_fwd_ex": (I, [POINTER(ConvArgs), P, ctypes.c_float, ctypes.c_float, U64, P, SZ, P]),
+    "ptpp_conv1d_rt_fwd_ex_relu_bwd": (I, [POINTER(ConvArgs), P, P, P, ctypes.c_float, P, SZ, P]),
     "ptpp_conv1d_rt_fwd": (I, [POINTER(ConvArgs), P, ctypes.c_float, P]),
     "ptpp_conv1d_rt_fwd_aux": (I, [POINTER(ConvArgs), P, ctypes.c_float, P, I, ctypes.c_float, P]),
     "ptpp_conv1d_rt_fwd_cs": (I, [POINTER(ConvArgs), P, ctypes.c_float, P, I, ctypes.c_float, P, P]),

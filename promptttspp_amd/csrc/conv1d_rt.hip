@@ -62,10 +62,17 @@ struct RtP {
   // round 6 (conv1d_rt_gw_kernel, plain epilogue): per-tile column sums of the ROUNDED output, (B, ceil(T / 32), 256) f32 -- a tile
   // writes its sum to slot t0 / 32 and zeros to its other slots, so the caller needs no memset and sums the slots in a fixed order
   float* colpart;
+  // round 6 (plain epilogue): the ReLU / dropout backward of the NEXT layer towards the input as this launch's output --
+  // relu_dz[row][ch] = relu_src[row][ch] > 0 && row inside its utterance ? bf16(y) * relu_inv : 0 (ptpp_epilogue_bwd's arithmetic on
+  // the ROUNDED y, which is not stored): the Conformer feed-forward backward's  conv -> mask -> conv  chain without the middle pass
+  const bf16_raw* relu_src;
+  bf16_raw* relu_dz;
+  int ldrs, lddz;
+  float relu_inv;
 };
 inline void rtp_plain(RtP& p) {  // the fields of the forms that came before round 6
   p.cout_total = RT_N; p.grp_stride = 0; p.drop_thresh16 = 0; p.drop_inv_keep = 1.f; p.drop_seed = 0; p.ws = nullptr;
-  p.split_trips = p.Cin >> 7; p.colpart = nullptr;
+  p.split_trips = p.Cin >> 7; p.colpart = nullptr; p.relu_src = nullptr; p.relu_dz = nullptr; p.ldrs = p.lddz = 0; p.relu_inv = 1.f;
 }
 
 __device__ __forceinline__ void rt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -576,6 +583,20 @@ __global__ __launch_bounds__(512, 2) void conv1d_rt_gw_kernel(const RtP p) {
         o.y = (uint32_t)f32_to_bf16(v[0][2]) | ((uint32_t)f32_to_bf16(v[0][3]) << 16);
         o.z = (uint32_t)f32_to_bf16(v[1][0]) | ((uint32_t)f32_to_bf16(v[1][1]) << 16);
         o.w = (uint32_t)f32_to_bf16(v[1][2]) | ((uint32_t)f32_to_bf16(v[1][3]) << 16);
+        if (p.relu_src) {  // (y itself is not stored in this form)
+          const uint4 hv = *reinterpret_cast<const uint4*>(p.relu_src + ((int64_t)b * T + t) * p.ldrs + ch);
+          const float iv = p.relu_inv;
+          const bool rk = t < len;
+          auto gate2 = [&](uint32_t ov, uint32_t hw) __attribute__((always_inline)) {
+            const float lo = (rk && __uint_as_float(hw << 16) > 0.f) ? __uint_as_float(ov << 16) * iv : 0.f;
+            const float hi = (rk && __uint_as_float(hw & 0xffff0000u) > 0.f) ? __uint_as_float(ov & 0xffff0000u) * iv : 0.f;
+            return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+          };
+          uint4 q;
+          q.x = gate2(o.x, hv.x); q.y = gate2(o.y, hv.y); q.z = gate2(o.z, hv.z); q.w = gate2(o.w, hv.w);
+          *reinterpret_cast<uint4*>(p.relu_dz + ((int64_t)b * T + t) * p.lddz + ch) = q;
+          continue;
+        }
         *reinterpret_cast<uint4*>(yb + (int64_t)t * p.ldy + ch) = o;
         if (p.colpart) {
           cs[0] += __uint_as_float(o.x << 16); cs[1] += __uint_as_float(o.x & 0xffff0000u);
@@ -773,8 +794,32 @@ extern "C" int ptpp_conv1d_rt_ex_supported(int cin, int cout, int ks, int dil, i
   return act == PTPP_ACT_NONE || act == PTPP_ACT_RELU;
 }
 
+static int rt_fwd_ex_impl(const ptpp_conv1d_args* a, const void* wstream, float res_scale, float drop_p, uint64_t drop_seed, void* workspace,
+                          size_t workspace_bytes, const void* relu_src, void* relu_dz, float relu_inv, int* fused, void* stream);
+
 extern "C" int ptpp_conv1d_rt_fwd_ex(const ptpp_conv1d_args* a, const void* wstream, float res_scale, float drop_p, uint64_t drop_seed,
                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return rt_fwd_ex_impl(a, wstream, res_scale, drop_p, drop_seed, workspace, workspace_bytes, nullptr, nullptr, 1.f, nullptr, stream);
+}
+
+// y = conv(x) is an intermediate: dz = [saved > 0 and row inside its utterance] * y * inv_keep, i.e. ptpp_epilogue_bwd(y, saved, dz,
+// lengths, .., scale 1, relu 1, mask 1, p) fused into the conv's epilogue where the launch is not split (a->y is then NOT
+// written); a split launch runs the two steps one after the other through a->y.  saved / dz: (B, T, Cout) rows of Cout elements.
+extern "C" int ptpp_conv1d_rt_fwd_ex_relu_bwd(const ptpp_conv1d_args* a, const void* wstream, const void* saved, void* dz, float drop_p,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  PTPP_CHECK_ARG(a && saved && dz && a->lengths && !a->res && !a->bias && a->act == PTPP_ACT_NONE && a->out_scale == 1.f && !a->out_mask &&
+                     a->ldy == a->Cout && (((uintptr_t)saved | (uintptr_t)dz) & 15) == 0 && drop_p >= 0.f && drop_p < 1.f,
+                 "conv1d_rt_fwd_ex_relu_bwd: plain conv (no bias / residual / activation / output mask, dense y) with lengths expected");
+  const unsigned th = drop_p > 0.f ? (unsigned)(drop_p * 65536.f + 0.5f) : 0u;
+  const float inv = drop_p > 0.f ? 1.f / (1.f - th / 65536.f) : 1.f;
+  int fused = 0;
+  const int rc = rt_fwd_ex_impl(a, wstream, 1.f, 0.f, 0, workspace, workspace_bytes, saved, dz, inv, &fused, stream);
+  if (rc != PTPP_OK || fused) return rc;
+  return ptpp_epilogue_bwd(a->y, saved, dz, a->lengths, a->B, a->T, a->Cout, 1.0f, 1, 1, drop_p, 1, a->dtype, stream);
+}
+
+static int rt_fwd_ex_impl(const ptpp_conv1d_args* a, const void* wstream, float res_scale, float drop_p, uint64_t drop_seed, void* workspace,
+                          size_t workspace_bytes, const void* relu_src, void* relu_dz, float relu_inv, int* fused, void* stream) {
   PTPP_CHECK_ARG(a && a->x && a->y && wstream, "conv1d_rt_fwd_ex: null pointer");
   PTPP_CHECK_ARG(ptpp_conv1d_rt_ex_supported(a->Cin, a->Cout, a->ks, a->dil, a->act, a->dtype),
                  "conv1d_rt_fwd_ex: unsupported shape (bf16, Cout %% 256 == 0, Cin %% 128 == 0, ks = 9, act none / relu; Cin %d Cout %d ks %d dil %d act %d)",
@@ -844,6 +889,13 @@ extern "C" int ptpp_conv1d_rt_fwd_ex(const ptpp_conv1d_args* a, const void* wstr
     else rc = rt_gw_launch<4, 9, PTPP_ACT_NONE, 2>(p, st);
     if (rc != PTPP_OK) return rc;
     return ptpp_conv_splitk_finish_bf16(a, res_scale, drop_p, drop_seed, p.ws, nsplit, st);
+  }
+  if (relu_src) {  // (unsplit: the ReLU / dropout backward rides in the epilogue)
+    p.relu_src = reinterpret_cast<const bf16_raw*>(relu_src);
+    p.relu_dz = reinterpret_cast<bf16_raw*>(relu_dz);
+    p.ldrs = p.lddz = a->Cout;
+    p.relu_inv = relu_inv;
+    if (fused) *fused = 1;
   }
   if (bm == 128) return relu ? rt_gw_launch<8, 9, PTPP_ACT_RELU>(p, st) : rt_gw_launch<8, 9, PTPP_ACT_NONE>(p, st);
   if (bm == 96) return relu ? rt_gw_launch<6, 9, PTPP_ACT_RELU>(p, st) : rt_gw_launch<6, 9, PTPP_ACT_NONE>(p, st);

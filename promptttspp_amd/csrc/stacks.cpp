@@ -602,9 +602,14 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
                      float* db2, int s1, int s2, void* dz2, void* dzF, const void* w1ts, const void* w2ts) -> int {
     // (dz2 = gres * 0.5 * dropout mask s2, masked rows zero: written by the LayerNorm backward that produced gres)
     ptpp_conv1d_args c = conv_args(dz2, C, w2t, nullptr, nullptr, 0, gF, F, len, B, T, C, F, kf, 1, (kf - 1) - pf, PTPP_ACT_NONE, 0, 0, dt);
-    ST_TRY(ffn_conv(c, w2ts, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
     ST_TRY(wgrad(h, F, dz2, C, dw2, db2, len, B, T, F, C, kf, pf, 0));
-    ST_TRY(ptpp_epilogue_bwd(gF, h, dzF, len, B, T, F, 1.0f, 1, 1, a->p_ffn, seed(s1, a->p_ffn), dt, stream));
+    if (w2ts && ptpp_conv1d_rt_ex_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype)) {
+      // (round 6: the ReLU / dropout backward from the conv's epilogue -- no pass over gF, which is scratch here)
+      ST_TRY(ptpp_conv1d_rt_fwd_ex_relu_bwd(&c, w2ts, h, dzF, a->p_ffn, a->ws_main, a->ws_main_bytes, stream));
+    } else {
+      ST_TRY(ffn_conv(c, w2ts, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+      ST_TRY(ptpp_epilogue_bwd(gF, h, dzF, len, B, T, F, 1.0f, 1, 1, a->p_ffn, seed(s1, a->p_ffn), dt, stream));
+    }
     c = conv_args(dzF, F, w1t, nullptr, nullptr, 0, t1, C, len, B, T, F, C, kf, 1, (kf - 1) - pf, PTPP_ACT_NONE, 0, 1, dt);
     ST_TRY(ffn_conv(c, w1ts, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
     return wgrad(n, C, dzF, F, dw1, db1, len, B, T, C, F, kf, pf, 1);

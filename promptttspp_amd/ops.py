@@ -238,6 +238,21 @@ def conv1d_rt_ex_ok(x, cout, ks, dil, act, res2=None):
     return ok
 
 
+def conv1d_rt_ex_relu_bwd(x, wstream, saved, cout, ks, pad, lengths, drop_p=0.0):
+    """ptpp_conv1d_rt_fwd_ex_relu_bwd: dz = [saved > 0, t < len] * bf16(conv(x)) / (1 - drop_p) with the conv result as an
+    intermediate (tests; the product calls it from ptpp_conformer_block_bwd).  x: (B, T, Cin) bf16 -> dz (B, T, cout)."""
+    B, T, cin = x.shape
+    y = torch.empty((B, T, cout), device=x.device, dtype=x.dtype)
+    dz = torch.empty_like(y)
+    lengths = i32(lengths, x.device)
+    _CONV_FMT.pack_into(_conv_buf, 0, x.data_ptr(), 0, 0, 0, y.data_ptr(), lengths.data_ptr(), B, T, cin, cout, ks, 1, pad, _ld_fast(x),
+                        cout, 0, _ACT[None], 0, 0, 1.0, BF16)
+    ws = workspace(x.device)
+    check(_lib.load().ptpp_conv1d_rt_fwd_ex_relu_bwd(_conv_args_ref, wstream.data_ptr(), saved.data_ptr(), dz.data_ptr(), float(drop_p),
+                                                     ws.data_ptr(), ws.numel(), _stream()), "ptpp_conv1d_rt_fwd_ex_relu_bwd")
+    return dz
+
+
 COLPART = __import__("os").environ.get("PTPP_DIFFNET_COLPART", "1") != "0"
 
 

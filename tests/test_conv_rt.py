@@ -203,3 +203,32 @@ def test_row_tile_conv_column_sums_from_the_epilogue(dev, monkeypatch, B, T, cin
     ref = y0.double().sum(1)
     err = float((outs[0].double() - ref).abs().max() / ref.abs().max())
     assert err < 1e-5, err
+
+
+@pytest.mark.parametrize("B,T,nsplit,drop", [(19, 199, 0, 0.1), (41, 98, 0, 0.0), (3, 150, 2, 0.1), (7, 333, 0, 0.25)])
+def test_feed_forward_data_gradient_with_the_relu_backward_in_its_epilogue(dev, monkeypatch, B, T, nsplit, drop):
+    """ptpp_conv1d_rt_fwd_ex_relu_bwd (round 6): the Conformer feed-forward backward's  conv (256 -> 1024, k = 9) -> ReLU / dropout
+    backward  as one launch (reference modules/esp/transformer/multi_layer_conv.py:52-67 differentiated) against the two launches it
+    replaces -- ptpp_conv1d_rt_fwd_ex and ptpp_epilogue_bwd on the stored bf16 result -- BIT for bit, in the fused form (unsplit
+    launches) and in the fallback a split launch takes."""
+    from promptttspp_amd import ops
+
+    if nsplit:
+        monkeypatch.setenv("PTPP_CONV_RT_NSPLIT", str(nsplit))
+    g = torch.Generator().manual_seed(77 + B)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    cin, cout, ks, pad = 256, 1024, 9, 4
+    x = r(B, T, cin).bfloat16()
+    w = r(cout, cin, ks, sc=(cin * ks) ** -0.5)
+    saved = torch.relu(r(B, T, cout)).bfloat16()           # the forward's hidden activation: zero where ReLU or dropout cut it
+    lengths = torch.tensor([max(1, T - 7 * i) for i in range(B)], device=dev, dtype=torch.int32)
+    wst = ops.pack_conv_weight(w, torch.bfloat16, 3)
+    assert ops.conv1d_rt_ex_ok(x, cout, ks, 1, None)
+    y = ops.conv1d(x, None, None, cout, ks=ks, pad=pad, lengths=lengths, wstream=wst)
+    ref = ops.epilogue_bwd(y, saved, lengths, 1.0, True, True, drop, 1)
+    got = ops.conv1d_rt_ex_relu_bwd(x, wst, saved, cout, ks, pad, lengths, drop)
+    torch.cuda.synchronize()
+    assert torch.equal(ref, got), float((ref.float() - got.float()).abs().max())
+    assert float(ref.float().abs().max()) > 0
+    m = torch.arange(T, device=dev)[None, :] >= lengths[:, None]
+    assert float(got[m].float().abs().max()) == 0.0 if bool(m.any()) else True
