@@ -191,6 +191,11 @@ int ptpp_conv1d_rt_fwd_ex(const ptpp_conv1d_args* a, const void* wstream, float 
  * launch had to be split).  a: no bias / residual / activation / output mask, ldy = Cout, lengths required. */
 int ptpp_conv1d_rt_fwd_ex_relu_bwd(const ptpp_conv1d_args* a, const void* wstream, const void* saved, void* dz, float drop_p,
                                    void* workspace, size_t workspace_bytes, void* stream);
+/* ... without the finishing pass of a launch that is split over Cin: on return *nsplit > 1 means `workspace` holds the raw f32
+ * partial sums [nsplit][B][T][Cout] and a->y was NOT written (the consumer sums them: ptpp_layernorm_bwd_add_splitk);
+ * *nsplit == 1: a->y is complete.  a: no bias / residual / activation / scale (the output mask is the consumer's to apply). */
+int ptpp_conv1d_rt_fwd_ex_partial(const ptpp_conv1d_args* a, const void* wstream, void* workspace, size_t workspace_bytes,
+                                  int* nsplit, void* stream);
 
 /* The same with an optional scratch (16-byte aligned device memory, NULL = none): layers with few
  * output tiles and a long K (Conformer FFN k = 9, BERT FFN) are then split over K -- f32 partial sums
@@ -314,6 +319,15 @@ int ptpp_layernorm_bwd_add(const void* dy, const void* xsum, const void* z,
                            int act_in, float drop_in_p, uint64_t drop_in_seed,
                            float drop_out_p, uint64_t drop_out_seed, int dtype,
                            void* scratch, size_t scratch_bytes, void* stream);
+/* ptpp_layernorm_bwd_add whose dy is not a tensor but the split-K partial sums of the conv that produces it (round 6; the
+ * Conformer feed-forward backward: data gradient of the k = 9 conv 1024 -> 256, split over Cin, then the LayerNorm backward):
+ * dy[row] = dtype(sum_k partials[k][row]), rows t >= partial_lengths[b] zero (NULL: no mask) -- conv_splitk_finish_kernel's
+ * arithmetic, so the results are those of the two launches.  bf16 only; no act_in / drop_out. */
+int ptpp_layernorm_bwd_add_splitk(const float* partials, int nsplit, const int32_t* partial_lengths, const void* xsum,
+                                  const float* gamma, const float* mean, const float* rstd, void* dsum, void* dz, const void* add,
+                                  float dz_scale, int dz_mask, float* dgamma, float* dbeta, const int32_t* lengths, int B, int T,
+                                  int C, int out_mask, float drop_in_p, uint64_t drop_in_seed, int dtype, void* scratch,
+                                  size_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Relative-position multi-head attention for short sequences

@@ -316,6 +316,8 @@ SIGNATURES = {
     "ptpp_conv_rt_set_min_rows": (I, [c_longlong]),
     "ptpp_conv1d_rt_fwd_ex": (I, [POINTER(ConvArgs), P, ctypes.c_float, ctypes.c_float, U64, P, SZ, P]),
     "ptpp_conv1d_rt_fwd_ex_relu_bwd": (I, [POINTER(ConvArgs), P, P, P, ctypes.c_float, P, SZ, P]),
+    "ptpp_conv1d_rt_fwd_ex_partial": (I, [POINTER(ConvArgs), P, P, SZ, POINTER(ctypes.c_int), P]),
+    "ptpp_layernorm_bwd_add_splitk": (I, [P, I, P, P, P, P, P, P, P, P, ctypes.c_float, I, P, P, P, I, I, I, I, ctypes.c_float, U64, I, P, SZ, P]),
     "ptpp_conv1d_rt_fwd": (I, [POINTER(ConvArgs), P, ctypes.c_float, P]),
     "ptpp_conv1d_rt_fwd_aux": (I, [POINTER(ConvArgs), P, ctypes.c_float, P, I, ctypes.c_float, P]),
     "ptpp_conv1d_rt_fwd_cs": (I, [POINTER(ConvArgs), P, ctypes.c_float, P, I, ctypes.c_float, P, P]),

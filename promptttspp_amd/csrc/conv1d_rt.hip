@@ -795,7 +795,8 @@ extern "C" int ptpp_conv1d_rt_ex_supported(int cin, int cout, int ks, int dil, i
 }
 
 static int rt_fwd_ex_impl(const ptpp_conv1d_args* a, const void* wstream, float res_scale, float drop_p, uint64_t drop_seed, void* workspace,
-                          size_t workspace_bytes, const void* relu_src, void* relu_dz, float relu_inv, int* fused, void* stream);
+                          size_t workspace_bytes, const void* relu_src, void* relu_dz, float relu_inv, int* fused, void* stream,
+                          int* partial_nsplit = nullptr);
 
 extern "C" int ptpp_conv1d_rt_fwd_ex(const ptpp_conv1d_args* a, const void* wstream, float res_scale, float drop_p, uint64_t drop_seed,
                                      void* workspace, size_t workspace_bytes, void* stream) {
@@ -818,8 +819,21 @@ extern "C" int ptpp_conv1d_rt_fwd_ex_relu_bwd(const ptpp_conv1d_args* a, const v
   return ptpp_epilogue_bwd(a->y, saved, dz, a->lengths, a->B, a->T, a->Cout, 1.0f, 1, 1, drop_p, 1, a->dtype, stream);
 }
 
+// The launch WITHOUT its finishing pass where it is split over Cin: *nsplit > 1 on return means `workspace` holds [nsplit][B][T][Cout]
+// raw f32 partial sums and a->y was not written -- the caller's next kernel sums them (ptpp_layernorm_bwd_add_splitk: the finishing
+// pass of conv_splitk_finish_kernel folded into the LayerNorm backward that reads the result); *nsplit == 1: a->y is complete.
+// a: no bias / residual / activation / dropout (the epilogue the consumer reproduces is "sum, output mask, round").
+extern "C" int ptpp_conv1d_rt_fwd_ex_partial(const ptpp_conv1d_args* a, const void* wstream, void* workspace, size_t workspace_bytes,
+                                             int* nsplit, void* stream) {
+  PTPP_CHECK_ARG(a && nsplit && !a->res && !a->bias && a->act == PTPP_ACT_NONE && a->out_scale == 1.f,
+                 "conv1d_rt_fwd_ex_partial: plain conv expected (no bias / residual / activation / scale)");
+  *nsplit = 1;
+  return rt_fwd_ex_impl(a, wstream, 1.f, 0.f, 0, workspace, workspace_bytes, nullptr, nullptr, 1.f, nullptr, stream, nsplit);
+}
+
 static int rt_fwd_ex_impl(const ptpp_conv1d_args* a, const void* wstream, float res_scale, float drop_p, uint64_t drop_seed, void* workspace,
-                          size_t workspace_bytes, const void* relu_src, void* relu_dz, float relu_inv, int* fused, void* stream) {
+                          size_t workspace_bytes, const void* relu_src, void* relu_dz, float relu_inv, int* fused, void* stream,
+                          int* partial_nsplit) {
   PTPP_CHECK_ARG(a && a->x && a->y && wstream, "conv1d_rt_fwd_ex: null pointer");
   PTPP_CHECK_ARG(ptpp_conv1d_rt_ex_supported(a->Cin, a->Cout, a->ks, a->dil, a->act, a->dtype),
                  "conv1d_rt_fwd_ex: unsupported shape (bf16, Cout %% 256 == 0, Cin %% 128 == 0, ks = 9, act none / relu; Cin %d Cout %d ks %d dil %d act %d)",
@@ -888,6 +902,10 @@ static int rt_fwd_ex_impl(const ptpp_conv1d_args* a, const void* wstream, float 
     else if (bm == 96) rc = rt_gw_launch<6, 9, PTPP_ACT_NONE, 2>(p, st);
     else rc = rt_gw_launch<4, 9, PTPP_ACT_NONE, 2>(p, st);
     if (rc != PTPP_OK) return rc;
+    if (partial_nsplit) {  // (the caller's next kernel finishes)
+      *partial_nsplit = nsplit;
+      return PTPP_OK;
+    }
     return ptpp_conv_splitk_finish_bf16(a, res_scale, drop_p, drop_seed, p.ws, nsplit, st);
   }
   if (relu_src) {  // (unsplit: the ReLU / dropout backward rides in the epilogue)

@@ -20,6 +20,12 @@ struct LnDrop {
   float dz_scale;   // backward only: dz = dsum * dz_scale * [t < len if dz_mask] * dropmask_in * act_in'(z)
   int dz_mask;
   int dz_stored;    // dz from dsum AS STORED (rounded to T) -- what a separate pass over dsum would read
+  // backward only (round 6): dy is not a tensor but the raw split-K partial sums of the conv that produces it, [sp_n][rows][C] f32
+  // (conv_splitk_finish_kernel's job: summed in split order, rows at or past sp_len[b] zero, rounded to T as that kernel stores it)
+  const float* sp_ws;
+  const int* sp_len;
+  long long sp_slab;
+  int sp_n;
 };
 
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
@@ -130,7 +136,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       pos[i] = 0u;
       if (c < C && keep) {
-        d[i] = Elem<T>::ld4(dy + row * C + c);
+        if (dp.sp_ws) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(dp.sp_ws + row * C + c);
+          for (int k = 1; k < dp.sp_n; ++k) v += *reinterpret_cast<const f32x4*>(dp.sp_ws + k * dp.sp_slab + row * C + c);
+          if (dp.sp_len) {
+            const int b = (int)(row / Tlen), t = (int)(row % Tlen);
+            if (t >= min(dp.sp_len[b], Tlen)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+          }
+          d[i] = v;
+        } else {
+          d[i] = Elem<T>::ld4(dy + row * C + c);
+        }
         if (dp.out_thresh) d[i] *= drop_mask4(dp.out_seed, (uint64_t)(row * C + c) >> 2, dp.out_thresh, dp.out_inv);
         const f32x4 xv = Elem<T>::ld4(xs + row * C + c);
 #pragma unroll
@@ -221,6 +241,10 @@ LnDrop make_drop(float pin, uint64_t sin_, float pout, uint64_t sout) {
   d.dz_scale = 1.f;
   d.dz_mask = 0;
   d.dz_stored = 0;
+  d.sp_ws = nullptr;
+  d.sp_len = nullptr;
+  d.sp_slab = 0;
+  d.sp_n = 0;
   return d;
 }
 
@@ -305,7 +329,8 @@ extern "C" int ptpp_layernorm_fwd(const void* x, const void* res, const float* g
 static int ln_bwd_entry(const void* dy, const void* xsum, const void* z, const float* gamma, const float* mean, const float* rstd, void* dsum,
                         void* dz, const void* add, float dz_scale, int dz_mask, int dz_stored, float* dgamma, float* dbeta,
                         const int32_t* lengths, int B, int T, int C, int out_mask, int act_in, float drop_in_p, uint64_t drop_in_seed,
-                        float drop_out_p, uint64_t drop_out_seed, int dtype, void* scratch, size_t scratch_bytes, void* stream);
+                        float drop_out_p, uint64_t drop_out_seed, int dtype, void* scratch, size_t scratch_bytes, void* stream,
+                        const float* sp_ws = nullptr, int sp_n = 0, const int32_t* sp_len = nullptr);
 
 extern "C" int ptpp_layernorm_bwd(const void* dy, const void* xsum, const void* z, const float* gamma,
                                   const float* mean, const float* rstd, void* dsum, void* dz, float* dgamma,
@@ -325,11 +350,23 @@ extern "C" int ptpp_layernorm_bwd_add(const void* dy, const void* xsum, const vo
                       drop_in_p, drop_in_seed, drop_out_p, drop_out_seed, dtype, scratch, scratch_bytes, stream);
 }
 
+extern "C" int ptpp_layernorm_bwd_add_splitk(const float* partials, int nsplit, const int32_t* partial_lengths, const void* xsum,
+                                             const float* gamma, const float* mean, const float* rstd, void* dsum, void* dz, const void* add,
+                                             float dz_scale, int dz_mask, float* dgamma, float* dbeta, const int32_t* lengths, int B, int T,
+                                             int C, int out_mask, float drop_in_p, uint64_t drop_in_seed, int dtype, void* scratch,
+                                             size_t scratch_bytes, void* stream) {
+  PTPP_CHECK_ARG(partials && nsplit >= 1, "layernorm_bwd_add_splitk: no partial sums");
+  return ln_bwd_entry(nullptr, xsum, nullptr, gamma, mean, rstd, dsum, dz, add, dz_scale, dz_mask, 1, dgamma, dbeta, lengths, B, T, C, out_mask,
+                      PTPP_ACT_NONE, drop_in_p, drop_in_seed, 0.f, 0, dtype, scratch, scratch_bytes, stream, partials, nsplit, partial_lengths);
+}
+
 static int ln_bwd_entry(const void* dy, const void* xsum, const void* z, const float* gamma, const float* mean, const float* rstd, void* dsum,
                         void* dz, const void* add, float dz_scale, int dz_mask, int dz_stored, float* dgamma, float* dbeta,
                         const int32_t* lengths, int B, int T, int C, int out_mask, int act_in, float drop_in_p, uint64_t drop_in_seed,
-                        float drop_out_p, uint64_t drop_out_seed, int dtype, void* scratch, size_t scratch_bytes, void* stream) {
-  PTPP_CHECK_ARG(dy && xsum && gamma && mean && rstd && (dsum || dz), "layernorm_bwd: null pointer");
+                        float drop_out_p, uint64_t drop_out_seed, int dtype, void* scratch, size_t scratch_bytes, void* stream,
+                        const float* sp_ws, int sp_n, const int32_t* sp_len) {
+  PTPP_CHECK_ARG((dy || sp_ws) && xsum && gamma && mean && rstd && (dsum || dz), "layernorm_bwd: null pointer");
+  PTPP_CHECK_ARG(!sp_ws || (sp_n >= 1 && ((uintptr_t)sp_ws & 15) == 0 && dtype == PTPP_BF16), "layernorm_bwd: bad split-K source");
   PTPP_CHECK_ARG(!add || (dsum && add != dsum), "layernorm_bwd: `add` needs a dsum output that is another buffer");
   PTPP_CHECK_ARG(!dz_mask || lengths, "layernorm_bwd: dz_mask needs lengths");
   PTPP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0, "layernorm_bwd: bad shape");
@@ -343,6 +380,10 @@ static int ln_bwd_entry(const void* dy, const void* xsum, const void* z, const f
   dp.dz_scale = dz_scale;
   dp.dz_mask = dz_mask;
   dp.dz_stored = dz_stored;
+  dp.sp_ws = sp_ws;
+  dp.sp_n = sp_n;
+  dp.sp_len = sp_len;
+  dp.sp_slab = (long long)rows * C;
   if (dtype == PTPP_F32)
     return ln_bwd_dispatch<float>(dy, xsum, z, gamma, mean, rstd, dsum, dz, dgamma, dbeta, scratch, scratch_bytes, lengths, rows, T, C,
                                   out_mask, act_in, dp, st);

@@ -598,6 +598,7 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
   void* gF = sl(X, sc.gF);
 
   // backward of one feed-forward half: gres = gradient w.r.t. res + 0.5 drop(...) ; returns the gradient w.r.t. LN input in t1
+  int t1_nsplit = 1;
   auto ffn_bwd = [&](const void* gres, const void* h, const void* n, const void* w1t, const void* w2t, float* dw1, float* db1, float* dw2,
                      float* db2, int s1, int s2, void* dz2, void* dzF, const void* w1ts, const void* w2ts) -> int {
     // (dz2 = gres * 0.5 * dropout mask s2, masked rows zero: written by the LayerNorm backward that produced gres)
@@ -611,8 +612,26 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
       ST_TRY(ptpp_epilogue_bwd(gF, h, dzF, len, B, T, F, 1.0f, 1, 1, a->p_ffn, seed(s1, a->p_ffn), dt, stream));
     }
     c = conv_args(dzF, F, w1t, nullptr, nullptr, 0, t1, C, len, B, T, F, C, kf, 1, (kf - 1) - pf, PTPP_ACT_NONE, 0, 1, dt);
-    ST_TRY(ffn_conv(c, w1ts, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+    t1_nsplit = 1;
+    const char* fe = getenv("PTPP_FFN_LN_SPLITK");  // (0: the finishing launch of rounds 1-5; A/B and the bit-identity test)
+    if (!(fe && fe[0] == '0') && w1ts && ptpp_conv1d_rt_ex_supported(c.Cin, c.Cout, c.ks, c.dil, c.act, c.dtype) && a->ws_main &&
+        ((uintptr_t)a->ws_main & 15) == 0) {
+      // (round 6: where this launch is split over Cin its finishing pass is left to the LayerNorm backward that reads t1)
+      ST_TRY(ptpp_conv1d_rt_fwd_ex_partial(&c, w1ts, a->ws_main, a->ws_main_bytes, &t1_nsplit, stream));
+    } else {
+      ST_TRY(ffn_conv(c, w1ts, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
+    }
     return wgrad(n, C, dzF, F, dw1, db1, len, B, T, C, F, kf, pf, 1);
+  };
+  // the LayerNorm backward that follows a feed-forward half: dy = t1, or the partial sums the half's last conv left in ws_main
+  auto ln_bwd_t1 = [&](const void* x, const float* gam, const float* mean, const float* rstd, void* dsum, float* dg, float* db,
+                       const int32_t* lengths, const void* add, void* dz, float dz_scale, float dz_drop, uint64_t dz_seed) -> int {
+    if (t1_nsplit > 1)
+      return ptpp_layernorm_bwd_add_splitk(static_cast<const float*>(a->ws_main), t1_nsplit, len, x, gam, mean, rstd, dsum, dz, add, dz_scale,
+                                           dz != nullptr, dg, db, lengths, B, T, C, 0, dz_drop, dz_seed, dt, a->red_scratch, a->red_bytes,
+                                           stream);
+    return ln_bwd_plain(t1, x, gam, mean, rstd, dsum, dg, db, lengths, B, T, C, 0, dt, a->red_scratch, a->red_bytes, stream, add, dz, dz_scale,
+                        dz_drop, dz_seed);
   };
 
   // ---- final LayerNorm ----
@@ -623,8 +642,8 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
                  sl(X, sc.dz_f[0]), a->ffn_wts[2], a->ffn_wts[3]));
   // gradient w.r.t. x3 = gA + LayerNorm input gradient, and the pointwise conv's dropout backward, one pass
   void* dz_pw2 = sl(X, sc.dz_c[1]);
-  ST_TRY(ln_bwd_plain(t1, sl(S, lo.x3), w.ln_g[3], stats + 6 * R, stats + 7 * R, gB, g.ln_g[3], g.ln_b[3], len, B, T, C, 0, dt,
-                      a->red_scratch, a->red_bytes, stream, gA, dz_pw2, 1.0f, a->p_drop, seed(3, a->p_drop)));
+  ST_TRY(ln_bwd_t1(sl(S, lo.x3), w.ln_g[3], stats + 6 * R, stats + 7 * R, gB, g.ln_g[3], g.ln_b[3], len, gA, dz_pw2, 1.0f, a->p_drop,
+                   seed(3, a->p_drop)));
   // ---- convolution module ----
   ptpp_conv1d_args c = conv_args(dz_pw2, C, a->pw2_wt, nullptr, nullptr, 0, t2, C, len, B, T, C, C, 1, 1, 0, PTPP_ACT_NONE, 0, 0, dt);
   ST_TRY(linear_like_ops(c, 0.f, 0, a->ws_main, a->ws_main_bytes, stream));
@@ -674,8 +693,7 @@ extern "C" int ptpp_conformer_block_bwd(const ptpp_conformer_block_bwd_args* a, 
   // ---- macaron feed-forward ----
   ST_TRY(ffn_bwd(gA, sl(S, lo.h1), sl(S, lo.n1), a->ffm_w1t, a->ffm_w2t, g.ffm_w1, g.ffm_b1, g.ffm_w2, g.ffm_b2, 0, 1, sl(X, sc.dz_c[3]),
                  sl(X, sc.dz_f[1]), a->ffn_wts[0], a->ffn_wts[1]));
-  ST_TRY(ln_bwd_plain(t1, a->x, w.ln_g[0], stats, stats + R, a->gx, g.ln_g[0], g.ln_b[0], nullptr, B, T, C, 0, dt, a->red_scratch,
-                      a->red_bytes, stream, gA));
+  ST_TRY(ln_bwd_t1(a->x, w.ln_g[0], stats, stats + R, a->gx, g.ln_g[0], g.ln_b[0], nullptr, gA, nullptr, 1.f, 0.f, 0));
   if (a->side_stream) ST_TRY(ptpp_stream_wait(a->side_stream, stream));
   // Round 6: the three launches (depthwise, k = 9 group, 1 x 1 group) are independent and none fills the chip (76 / 192 / 32
   // workgroups): with a second side stream the k = 9 group runs beside the other two.  It matters at the END of the backward,
